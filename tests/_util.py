@@ -1,0 +1,50 @@
+"""Helpers shared by the test modules (fixture loading, synthetic intervals)."""
+import csv
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def read_csv_cols(path):
+    with open(path, newline="") as f:
+        rows = list(csv.reader(f))
+    hdr, body = rows[0], [r for r in rows[1:] if r]
+    return {h: [r[i] for r in body] for i, h in enumerate(hdr)}
+
+
+def load_intervals_csv(path):
+    t = read_csv_cols(path)
+    return t["contig"], np.array(t["pos_start"], np.int64), np.array(t["pos_end"], np.int64)
+
+
+def load_cases():
+    with open(os.path.join(GOLDEN, "cases.json")) as f:
+        return json.load(f)
+
+
+def load_parquet_intervals(name):
+    import pyarrow.parquet as pq
+    t = pq.read_table(os.path.join(GOLDEN, name))
+    return (t.column("contig").to_pylist(),
+            t.column("pos_start").to_numpy().astype(np.int64),
+            t.column("pos_end").to_numpy().astype(np.int64))
+
+
+def random_side(rng, n, n_contigs, span, max_len, zero_len_frac=0.05, dup_frac=0.1):
+    """Random intervals with duplicates, zero-length rows and heavy nesting."""
+    c = rng.integers(0, n_contigs, n).astype(np.int32)
+    s = rng.integers(0, span, n).astype(np.int32)
+    ln = rng.integers(0, max_len + 1, n).astype(np.int32)
+    ln[rng.random(n) < zero_len_frac] = 0
+    long_mask = rng.random(n) < 0.02
+    ln[long_mask] = rng.integers(0, span, long_mask.sum())
+    e = (s + ln).astype(np.int32)
+    if n > 1:
+        d = rng.random(n) < dup_frac
+        src = rng.integers(0, n, n)
+        c[d], s[d], e[d] = c[src[d]], s[src[d]], e[src[d]]
+    return c, s, e

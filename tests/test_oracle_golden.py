@@ -1,0 +1,215 @@
+"""Pin the CPU oracle against every golden table the reference's tests hold for
+the hot path, then pin the fast (sort + bound search)
+oracle against the brute-force definition on adversarial random inputs.
+
+CPU only (no GPU marker).  Reference sources of each golden are cited in
+tests/golden/make_golden.py.
+"""
+import numpy as np
+import pytest
+
+from _util import (load_cases, load_intervals_csv, load_parquet_intervals,
+                   random_side, read_csv_cols, GOLDEN)
+from oracle import oracle as O
+
+
+def _sides(df1, df2):
+    (c1, c2), n = O.encode_contigs(df1[0], df2[0])
+    return O.Side(c1, df1[1], df1[2]), O.Side(c2, df2[1], df2[2]), n
+
+
+def _case_side(d, dtype=None):
+    s = np.array(d["start"], dtype or np.int64)
+    e = np.array(d["end"], dtype or np.int64)
+    return d["chrom"], s, e
+
+
+# ---- CSV goldens: tests/_expected.py via test_native/test_polars/test_pandas ----
+
+def test_overlap_golden_weak():
+    reads = load_intervals_csv(f"{GOLDEN}/overlap/reads.csv")
+    targets = load_intervals_csv(f"{GOLDEN}/overlap/targets.csv")
+    probe, build, _ = _sides(reads, targets)           # pb.overlap(reads, targets)
+    exp = read_csv_cols(f"{GOLDEN}/expected_overlap.csv")
+    exp_rows = sorted(zip(exp["contig_1"], map(int, exp["pos_start_1"]), map(int, exp["pos_end_1"]),
+                          exp["contig_2"], map(int, exp["pos_start_2"]), map(int, exp["pos_end_2"])))
+    for fn in (lambda: O.overlap_brute(probe, build, False),
+               lambda: O.overlap_fast(O.Index(build, 8), probe, False),
+               lambda: O.np_overlap_pairs(probe, build, False)):
+        p, b = fn()
+        got = sorted((reads[0][i], int(reads[1][i]), int(reads[2][i]),
+                      targets[0][j], int(targets[1][j]), int(targets[2][j])) for i, j in zip(p, b))
+        assert len(got) == 16
+        assert got == exp_rows
+
+
+def test_count_overlaps_golden_weak():
+    targets = load_intervals_csv(f"{GOLDEN}/count_overlaps/targets.csv")  # df1
+    reads = load_intervals_csv(f"{GOLDEN}/count_overlaps/reads.csv")      # df2
+    probe, build, n = _sides(targets, reads)
+    exp = read_csv_cols(f"{GOLDEN}/expected_count_overlaps.csv")
+    exp_rows = sorted(zip(exp["contig"], map(int, exp["pos_start"]), map(int, exp["pos_end"]), map(int, exp["count"])))
+    for counts in (O.count_overlaps_brute(probe, build, False),
+                   O.count_overlaps_fast(O.Index(build, n), probe, False),
+                   O.np_count_overlaps(probe, build, False)):
+        got = sorted(zip(targets[0], map(int, targets[1]), map(int, targets[2]), map(int, counts)))
+        assert got == exp_rows
+
+
+def test_nearest_golden_weak_including_tiebreak():
+    targets = load_intervals_csv(f"{GOLDEN}/nearest/targets.csv")  # df1
+    reads = load_intervals_csv(f"{GOLDEN}/nearest/reads.csv")      # df2
+    probe, build, n = _sides(targets, reads)
+    exp = read_csv_cols(f"{GOLDEN}/expected_nearest.csv")
+    exp_rows = sorted(zip(exp["contig_1"], map(int, exp["pos_start_1"]), map(int, exp["pos_end_1"]),
+                          exp["contig_2"], map(int, exp["pos_start_2"]), map(int, exp["pos_end_2"]),
+                          map(int, exp["distance"])))
+    for idx, dist, cnt in (O.nearest_brute(probe, build, False),
+                           O.nearest_fast(O.Index(build, n), probe, False)):
+        assert (cnt == 1).all()
+        got = sorted((targets[0][i], int(targets[1][i]), int(targets[2][i]),
+                      reads[0][j], int(reads[1][j]), int(reads[2][j]), int(d))
+                     for i, (j, d) in enumerate(zip(idx[:, 0], dist[:, 0])))
+        assert got == exp_rows
+
+
+# ---- boundary semantics: tests/test_coordinate_system_metadata.py ----
+
+@pytest.mark.parametrize("case", load_cases()["boundary_overlap"], ids=lambda c: c["name"])
+def test_boundary_overlap(case):
+    probe, build, n = _sides(_case_side(case["df1"]), _case_side(case["df2"]))
+    strict = case["zero_based"]
+    assert len(O.overlap_brute(probe, build, strict)[0]) == case["n_pairs"]
+    assert O.overlap_fast(O.Index(build, n), probe, strict, count_only=True) == case["n_pairs"]
+
+
+@pytest.mark.parametrize("case", load_cases()["boundary_count"], ids=lambda c: c["name"])
+def test_boundary_count(case):
+    dt = np.dtype(case.get("dtype", "int64"))
+    probe, build, n = _sides(_case_side(case["df1"], dt), _case_side(case["df2"], dt))
+    strict = case["zero_based"]
+    assert O.count_overlaps_brute(probe, build, strict).tolist() == case["counts"]
+    assert O.count_overlaps_fast(O.Index(build, n), probe, strict).tolist() == case["counts"]
+    assert O.np_count_overlaps(probe, build, strict).tolist() == case["counts"]
+
+
+# ---- tutorial notebook cells 4/9/13/17 (1-based) ----
+
+def test_tutorial_example():
+    t = load_cases()["tutorial"]
+    d1, d2 = _case_side(t["df1"]), _case_side(t["df2"])
+    probe, build, n = _sides(d1, d2)
+    ix = O.Index(build, n)
+    p, b = O.overlap_fast(ix, probe, False)
+    got = sorted([int(d1[1][i]), int(d1[2][i]), int(d2[1][j]), int(d2[2][j])] for i, j in zip(p, b))
+    assert got == sorted(t["overlap"])
+    assert O.count_overlaps_fast(ix, probe, False).tolist() == t["count"]
+    idx, dist, cnt = O.nearest_fast(ix, probe, False)
+    got = [[int(d1[1][i]), int(d1[2][i]), int(d2[1][j]), int(d2[2][j]), int(d)]
+           for i, (j, d) in enumerate(zip(idx[:, 0], dist[:, 0]))]
+    assert got == t["nearest"]
+    bidx, bdist, _ = O.nearest_brute(probe, build, False)
+    assert (bidx == idx).all() and (bdist == dist).all()
+
+
+# ---- output modes (index level): tests/test_overlap_output_mode.py ----
+
+def test_output_mode_left_and_distinct():
+    t = load_cases()["output_mode"]
+    d1, d2 = _case_side(t["df1"]), _case_side(t["df2"])
+    probe, build, n = _sides(d1, d2)
+    p, _ = O.overlap_fast(O.Index(build, n), probe, t["zero_based"])
+    left = sorted((d1[0][i], int(d1[1][i]), int(d1[2][i]), t["df1"]["name"][i]) for i in p)
+    exp = t["left"]
+    assert left == sorted(zip(exp["chrom"], exp["start"], exp["end"], exp["name"]))
+    distinct = sorted((d1[0][i], int(d1[1][i]), int(d1[2][i]), t["df1"]["name"][i]) for i in np.unique(p))
+    exp = t["left_distinct"]
+    assert distinct == sorted(zip(exp["chrom"], exp["start"], exp["end"], exp["name"]))
+
+
+# ---- real fixtures: exons x fBrain, docs/supplement.md:108,149 -> 54,246 ----
+
+@pytest.fixture(scope="module")
+def real_sides():
+    exons = load_parquet_intervals("exons")
+    fbrain = load_parquet_intervals("fBrain-DS14718")
+    return exons, fbrain, _sides(exons, fbrain)
+
+
+def test_known_answer_54246(real_sides):
+    exons, fbrain, (probe, build, n) = real_sides
+    assert probe.n == 438694 and build.n == 198621
+    ix = O.Index(build, n)
+    known = load_cases()["known_answers"]["exons_x_fbrain_strict_pairs"]
+    assert O.overlap_fast(ix, probe, True, count_only=True) == known
+    counts = O.count_overlaps_fast(ix, probe, True)
+    assert int(counts.sum()) == known
+    assert (counts == O.np_count_overlaps(probe, build, True)).all()
+    # regression anchors derived in SURVEY.md section 8c (not reference-published)
+    assert O.overlap_fast(ix, probe, False, count_only=True) == 54343
+    assert int(counts.max()) == 7
+    idx, dist, cnt = O.nearest_fast(ix, probe, True)
+    assert (cnt == 1).all()
+    assert int(dist.sum()) == 15203982135
+    assert int((dist == 0).sum()) == 51521
+    # distance agrees with the numpy definition on a sample of rows
+    rng = np.random.default_rng(0)
+    sel = rng.choice(probe.n, 300, replace=False)
+    sub = O.Side(probe.contig[sel], probe.start[sel], probe.end[sel])
+    assert (O.np_nearest_distance(sub, build, True) == dist[sel, 0]).all()
+
+
+# ---- fast == brute on adversarial random inputs ----
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("seed", range(6))
+def test_fast_equals_brute_random(seed, strict):
+    rng = np.random.default_rng(1000 + seed)
+    n_contigs = int(rng.integers(1, 5))
+    span = int(rng.choice([40, 400, 100000]))
+    max_len = int(rng.choice([3, 30, 300]))
+    probe = O.Side(*random_side(rng, int(rng.integers(0, 300)), n_contigs + 1, span, max_len))
+    build = O.Side(*random_side(rng, int(rng.integers(0, 300)), n_contigs, span, max_len))
+    ix = O.Index(build, n_contigs)      # probe may carry a contig absent from build
+    pb, bb = O.overlap_brute(probe, build, strict)
+    pf, bf = O.overlap_fast(ix, probe, strict, threads=3)
+    assert (pb == pf).all() and (bb == bf).all()
+    pn, bn = O.np_overlap_pairs(probe, build, strict)
+    assert (pb == pn).all() and (bb == bn).all()
+    assert (O.count_overlaps_brute(probe, build, strict) == O.count_overlaps_fast(ix, probe, strict)).all()
+    for k, inc in ((1, True), (1, False), (3, True), (4, False)):
+        ib, db, nb = O.nearest_brute(probe, build, strict, k, inc)
+        i_f, d_f, n_f = O.nearest_fast(ix, probe, strict, k, inc)
+        assert (nb == n_f).all()
+        assert (db == d_f).all()
+        assert (ib == i_f).all()
+
+
+def test_inverted_rows_follow_the_inequality():
+    """start > end rows are unpinned in the reference; overlap/count follow the
+    inequality literally so brute == fast must still hold."""
+    rng = np.random.default_rng(7)
+    for strict in (True, False):
+        c, s, e = random_side(rng, 200, 2, 200, 20)
+        flip = rng.random(200) < 0.2
+        s2, e2 = np.where(flip, e, s), np.where(flip, s, e)
+        build = O.Side(c, s2, e2)
+        c, s, e = random_side(rng, 200, 2, 200, 20)
+        flip = rng.random(200) < 0.2
+        probe = O.Side(c, np.where(flip, e, s), np.where(flip, s, e))
+        ix = O.Index(build, 2)
+        pb, bb = O.overlap_brute(probe, build, strict)
+        pf, bf = O.overlap_fast(ix, probe, strict)
+        assert (pb == pf).all() and (bb == bf).all()
+        assert (O.count_overlaps_brute(probe, build, strict) == O.count_overlaps_fast(ix, probe, strict)).all()
+
+
+def test_empty_sides():
+    e = O.Side([], [], [])
+    one = O.Side([0], [5], [9])
+    for strict in (True, False):
+        assert len(O.overlap_fast(O.Index(e, 1), one, strict)[0]) == 0
+        assert len(O.overlap_fast(O.Index(one, 1), e, strict)[0]) == 0
+        assert O.count_overlaps_fast(O.Index(e, 1), one, strict).tolist() == [0]
+        idx, dist, n = O.nearest_fast(O.Index(e, 1), one, strict)
+        assert n.tolist() == [0] and idx.tolist() == [[-1]] and dist.tolist() == [[-1]]
