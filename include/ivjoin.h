@@ -1,0 +1,162 @@
+/*
+ * ivjoin.h -- C ABI of the MI355X-native interval-join engine (libivjoin_hip.so).
+ *
+ * This is the drop-in boundary for polars-bio's range-operation hot path.  It
+ * replaces what the reference reaches through its PyO3 module
+ * `polars_bio.polars_bio`:
+ *
+ *   range_operation_frame(py_ctx, df1, df2, range_options, limit)
+ *       /root/reference/src/lib.rs:79-145   (Arrow streams in, joined frame out)
+ *   do_range_operation -> do_overlap / do_nearest / do_count_overlaps_coverage_naive
+ *       /root/reference/src/operation.rs:27-98, 202-304, 100-200, 306-350
+ *   OverlapProvider / NearestProvider / CountOverlapsProvider (IntervalJoinExec + COITrees)
+ *       third-party datafusion-bio-function-ranges v0.11.0, call sites
+ *       /root/reference/src/operation.rs:146-158, 253-263, 331-340
+ *   RangeOptions / FilterOp
+ *       /root/reference/src/option.rs:6-41, 95-100
+ *
+ * Contract: plain pointers and sizes only.  The join keys cross the ABI as
+ * three int32 columns per side: `contig` (dictionary id of the chrom string,
+ * one dictionary shared by both sides, assigned by the caller), `start`, `end`.
+ * Every other column of the user's frames stays on the host and is gathered by
+ * the returned row indices (what the reference's SELECT in
+ * src/operation.rs:272-301 does with `left_*` / `right_*`).
+ *
+ * Side roles (Appendix A of SURVEY.md): probe = df1 (streamed side of the
+ * reference), build = df2 (indexed side) for all three operations, i.e. after
+ * the swaps in polars_bio/range_op.py:511 and src/operation.rs:143-158.
+ *
+ * All entry points return 0 on success, a negative IVJ_E* code otherwise;
+ * ivj_last_error() returns the thread-local message of the last failure.
+ * The library never retains a caller pointer after the call returns.
+ */
+#ifndef IVJOIN_H
+#define IVJOIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVJ_OK            0
+#define IVJ_EINVAL       -1   /* bad argument */
+#define IVJ_EHIP         -2   /* HIP runtime error (message has the hipError string) */
+#define IVJ_ENOMEM       -3   /* device or host allocation failed */
+#define IVJ_ECAPACITY    -4   /* caller-provided output capacity too small */
+#define IVJ_ESTATE       -5   /* fill called without a matching count */
+
+/* FilterOp of the reference (src/option.rs:95-100) */
+#define IVJ_FILTER_WEAK   0   /* 1-based closed:    a.start <= b.end && b.start <= a.end */
+#define IVJ_FILTER_STRICT 1   /* 0-based half-open: a.start <  b.end && b.start <  a.end */
+
+typedef struct ivj_ctx ivj_ctx;      /* one device, one stream, scratch arena */
+typedef struct ivj_index ivj_index;  /* sorted build side resident in HBM */
+
+/* One side of the join: three int32 columns of length n.  Host pointers for
+ * the host entry points, device pointers for the *_dev entry points.  Rows
+ * whose contig id is outside [0, n_contigs) never match anything. */
+typedef struct {
+    const int32_t* contig;
+    const int32_t* start;
+    const int32_t* end;
+    int64_t n;
+    const int32_t* row_id;  /* optional: the row id to report for row i (global ids of a
+                               contig shard); NULL = i.  Same memory space as the columns. */
+} ivj_side;
+
+/* The subset of RangeOptions (src/option.rs:6-41) that reaches the kernels. */
+typedef struct {
+    int32_t filter_op;         /* IVJ_FILTER_WEAK | IVJ_FILTER_STRICT */
+    int32_t n_contigs;         /* size of the shared chrom dictionary */
+    int32_t nearest_k;         /* RangeOptions.nearest_k, >= 1 (default 1) */
+    int32_t include_overlaps;  /* RangeOptions.include_overlaps (default 1) */
+    int32_t reserved[4];       /* must be zero */
+} ivj_opts;
+
+/* Result of overlap on the host path: library-owned host buffers. */
+typedef struct {
+    int64_t n_pairs;
+    int32_t* probe_idx;   /* row of df1 */
+    int32_t* build_idx;   /* row of df2 */
+} ivj_pairs;
+
+/* Per-kernel timing of the last operation (HIP events on the ctx stream). */
+typedef struct {
+    char name[32];
+    int32_t launches;
+    float ms;             /* sum over launches */
+} ivj_timing;
+
+/* ---- library / context -------------------------------------------------- */
+const char* ivj_last_error(void);
+const char* ivj_version(void);
+int ivj_device_count(int* n);
+int ivj_ctx_create(int device, ivj_ctx** out);
+void ivj_ctx_destroy(ivj_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL
+ * restores the context's own stream. */
+int ivj_ctx_set_stream(ivj_ctx* ctx, void* hip_stream);
+int ivj_ctx_sync(ivj_ctx* ctx);
+/* level 0: off; 1: HIP events around the probe kernels only; 2: around every kernel */
+int ivj_ctx_enable_timing(ivj_ctx* ctx, int level);
+/* Synchronises, then writes up to cap entries; *n = number of distinct kernels. */
+int ivj_ctx_get_timings(ivj_ctx* ctx, ivj_timing* out, int cap, int* n);
+
+/* ---- host-buffer entry points (what the reference FFI would bind) ------- *
+ * Inputs are borrowed host buffers; results come back in host memory.       */
+
+/* pb.overlap: all (probe_row, build_row) pairs, ordered by probe row, then by
+ * (build.start, build row).  Free with ivj_pairs_free. */
+int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
+                const ivj_opts* opts, ivj_pairs* out);
+void ivj_pairs_free(ivj_pairs* p);
+
+/* pb.count_overlaps (naive_query=True): counts[i] for every probe row, probe
+ * order kept (range_op_helpers.py:315-316: Int64). counts: caller buffer of probe->n. */
+int ivj_count_overlaps(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
+                       const ivj_opts* opts, int64_t* counts);
+
+/* pb.nearest: for every probe row up to k build rows.  idx/dist: caller
+ * buffers of probe->n * k (unused slots -1); n_found: probe->n. */
+int ivj_nearest(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
+                const ivj_opts* opts, int32_t* idx, int64_t* dist, int32_t* n_found);
+
+/* ---- device-resident entry points (inputs and outputs stay in HBM) ------ *
+ * Used by bench.py, the multi-GPU driver and any caller that already holds  *
+ * the columns on the GPU.  All work is enqueued on the context stream.      */
+
+/* Sort the build side by (contig, start), derive segment offsets and the
+ * prefix-max-of-end array.  with_end_order != 0 additionally sorts the ends
+ * (needed by count_overlaps and by nearest with k > 1 or include_overlaps = 0;
+ * built on demand otherwise).  The index copies what it needs: the caller's
+ * build columns may be released after the call returns. */
+int ivj_index_build_dev(ivj_ctx* ctx, const ivj_side* build_dev, const ivj_opts* opts,
+                        int with_end_order, ivj_index** out);
+void ivj_index_free(ivj_index* ix);
+
+/* overlap, two calls: count (+ scan, returns the number of pairs after one
+ * 8-byte D2H) then fill into caller-allocated device buffers of that size.
+ * The per-probe state between the two calls lives in ctx. */
+int ivj_overlap_count_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev,
+                          const ivj_opts* opts, int64_t* n_pairs);
+int ivj_overlap_fill_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev,
+                         const ivj_opts* opts, int32_t* probe_idx_dev, int32_t* build_idx_dev,
+                         int64_t capacity);
+
+int ivj_count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev,
+                           const ivj_opts* opts, int64_t* counts_dev);
+
+int ivj_nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev,
+                    const ivj_opts* opts, int32_t* idx_dev, int64_t* dist_dev, int32_t* n_found_dev);
+
+/* ---- device memory helpers for callers without a HIP binding ------------ */
+int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out);
+int ivj_dev_free(ivj_ctx* ctx, void* p);
+int ivj_memcpy_h2d(ivj_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
+int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVJOIN_H */

@@ -92,7 +92,7 @@ void orc_nearest_brute(const orc_side* probe, const orc_side* build, int strict,
             int b = cond_b(qs, build->end[j], strict);
             cand_t t;
             if (a && b) { if (!include_overlaps) continue; t.d = 0; t.cls = 0; }
-            else { t.d = gap_dist(qs, qe, build->start[j], build->end[j]); t.cls = b ? 2 : 1; }
+            else { t.d = gap_dist(qs, qe, build->start[j], build->end[j]); t.cls = a ? 1 : 2; }
             t.start = build->start[j]; t.row = (int32_t)j;
             c[nc++] = t;
         }
@@ -328,22 +328,24 @@ static void nearest_one(const orc_index* ix, int32_t c, int32_t qs, int32_t qe, 
         for (int64_t p = lo; p < hi && n < k; ++p)
             if (cond_b(qs, ix->s_end[p], strict)) { oi[n] = ix->s_row[p]; od[n] = 0; ++n; }
     }
-    /* left stream: rows failing "q.start (<) end", by end descending, runs of
-     * equal end in ascending (start,row) order.  right stream: rows at or
-     * after hi that still satisfy it, by start ascending. */
-    int64_t r_top = bound_r(ix, a, b, qs, strict);   /* left rows = e-order [a, r_top) */
+    /* left stream (class 1): rows with "start (<) q.end" that fail
+     * "q.start (<) end", by end descending, runs of equal end in ascending
+     * (start,row) order.  right stream (class 2): every row at or after hi
+     * (fails "start (<) q.end"), by (start,row) ascending. */
+    int64_t r_top = bound_r(ix, a, b, qs, strict);   /* rows failing B = e-order [a, r_top) */
     int64_t run_hi = r_top, run_lo = r_top, lp = r_top; /* current run [run_lo, run_hi), cursor lp */
     int64_t rp = hi;
     while (n < k) {
-        /* advance left cursor into a fresh run if the current one is exhausted */
-        if (lp >= run_hi && run_lo > a) {
+        for (;;) {
+            /* skip rows of the run that are not class 1 (start fails A: they sit at or after hi) */
+            while (lp < run_hi && ix->e_pos[lp] >= hi) ++lp;
+            if (lp < run_hi || run_lo <= a) break;
             run_hi = run_lo;
             int32_t e = ix->e_end[run_hi - 1];
             run_lo = lower_bound32(ix->e_end, a, run_hi, e);
             lp = run_lo;
         }
         int have_l = lp < run_hi;
-        while (rp < b && !cond_b(qs, ix->s_end[rp], strict)) ++rp; /* degenerate rows belong to the left class */
         int have_r = rp < b;
         if (!have_l && !have_r) break;
         int64_t dl = 0, dr = 0;

@@ -54,9 +54,10 @@ void orc_count_overlaps_brute(const orc_side* probe, const orc_side* build, int 
                               int64_t* counts);
 
 /* k nearest build rows for each probe row.
- * Candidate order (total): distance ascending; then class (0 overlapping,
- * 1 left / upstream of the probe, 2 right / downstream); then build.start,
- * then build row.  distance = 0 for overlapping pairs, else
+ * Candidate order (total): distance ascending; then class (0 overlapping;
+ * 1 "left": build.start (<) probe.end holds but probe.start (<) build.end
+ * fails; 2 "right": build.start (<) probe.end fails); then build.start, then
+ * build row.  distance = 0 for overlapping pairs, else
  * max(build.start - probe.end, probe.start - build.end) (no +-1 correction:
  * tests/_expected.py:130-172 -> 34; tutorial cell 13 -> 1).
  * include_overlaps = 0 removes class 0.

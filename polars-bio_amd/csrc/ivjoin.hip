@@ -1,0 +1,723 @@
+// ivjoin.hip -- host driver + C ABI (include/ivjoin.h) of the MI355X interval-join engine.
+//
+// Replaces, for the range-operation hot path, what the reference reaches through
+//   range_operation_frame        /root/reference/src/lib.rs:79-145
+//   do_range_operation & co      /root/reference/src/operation.rs:27-350
+//   IntervalJoinExec + COITrees  (datafusion-bio-function-ranges v0.11.0, call sites
+//                                 /root/reference/src/operation.rs:146-158,253-263,331-340)
+// gfx950 only: no CUDA paths, no CPU fallback -- every entry point fails with IVJ_EHIP when
+// no device is usable.
+#include "../../include/ivjoin.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "probe.hip.h"
+#include "radix_sort.hip.h"
+#include "scan.hip.h"
+
+using namespace ivj;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(IVJ_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    } while (0)
+
+#define IVJ_TRY(expr)                 \
+    do {                              \
+        int _r = (expr);              \
+        if (_r != IVJ_OK) return _r;  \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+};
+
+struct TimingRec {
+    const char* name;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct ivj_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    Arena arena;
+    // state handed from ivj_overlap_count_dev to ivj_overlap_fill_dev
+    char* ov_buf = nullptr;
+    size_t ov_cap = 0;
+    int64_t ov_n = -1;
+    const void* ov_probe_start = nullptr;
+    const ivj_index* ov_ix = nullptr;
+    int32_t ov_filter = -1;
+    int32_t* ov_hi = nullptr;
+    int32_t* ov_cnt = nullptr;
+    long long* ov_tile = nullptr;   // ntiles + 1: tile bases, last = total
+    long long* h_total = nullptr;   // pinned
+    int64_t ov_total = 0;
+    // timing
+    int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
+    bool t_open = false;
+    std::vector<TimingRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+};
+
+struct ivj_index {
+    ivj_ctx* ctx = nullptr;
+    int64_t n = 0;
+    int32_t n_contigs = 0;
+    int32_t* b_start = nullptr;
+    int2* ep = nullptr;
+    int32_t* b_row = nullptr;
+    int32_t* b_contig = nullptr;
+    int32_t* seg = nullptr;
+    int32_t* flags = nullptr;
+    int32_t* e_end = nullptr;
+    int32_t* e_pos = nullptr;
+    bool has_end_order = false;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int arena_reserve(ivj_ctx* ctx, size_t bytes) {
+    Arena& A = ctx->arena;
+    A.off = 0;
+    if (bytes <= A.cap) return IVJ_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (A.base) HIP_TRY(hipFree(A.base));
+    A.base = nullptr; A.cap = 0;
+    size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    hipError_t e = hipMalloc((void**)&A.base, want);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, "arena hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e));
+    A.cap = want;
+    return IVJ_OK;
+}
+
+template <class T>
+T* arena_take(ivj_ctx* ctx, size_t count) {
+    Arena& A = ctx->arena;
+    size_t bytes = align_up(count * sizeof(T));
+    if (A.off + bytes > A.cap) return nullptr;   // reserve() sized wrongly: programming error
+    T* p = reinterpret_cast<T*>(A.base + A.off);
+    A.off += bytes;
+    return p;
+}
+
+bool is_probe_kernel(const char* name) {
+    return !std::strncmp(name, "overlap_", 8) || !std::strncmp(name, "count_overlaps", 14) || !std::strncmp(name, "nearest", 7);
+}
+void t_begin(ivj_ctx* ctx, const char* name) {
+    ctx->t_open = false;
+    if (!ctx->timing) return;
+    if (ctx->timing == 1 && !is_probe_kernel(name)) return;
+    if (ctx->pool_used + 2 > ctx->pool.size()) {
+        for (int i = 0; i < 64; ++i) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return; ctx->pool.push_back(ev); }
+    }
+    TimingRec r{name, ctx->pool[ctx->pool_used], ctx->pool[ctx->pool_used + 1]};
+    ctx->pool_used += 2;
+    (void)hipEventRecord(r.a, ctx->stream);
+    ctx->recs.push_back(r);
+    ctx->t_open = true;
+}
+void t_end(ivj_ctx* ctx) {
+    if (!ctx->t_open) return;
+    (void)hipEventRecord(ctx->recs.back().b, ctx->stream);
+    ctx->t_open = false;
+}
+
+#define LAUNCH(ctx, name, kernel, grid, block, ...)                                   \
+    do {                                                                              \
+        t_begin(ctx, name);                                                           \
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, (ctx)->stream, __VA_ARGS__); \
+        t_end(ctx);                                                                   \
+    } while (0)
+
+inline unsigned grid1d(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+// device-wide scan: three launches (reduce, partials, apply)
+template <class T, class Op, bool INCLUSIVE>
+void device_scan(ivj_ctx* ctx, const char* name, const T* in, T* out, int64_t n, T identity, T* partials, T* total_out) {
+    const int64_t tiles = scan_num_tiles(n);
+    LAUNCH(ctx, name, (k_scan_reduce<T, Op>), tiles, SCAN_THREADS, in, n, identity, partials);
+    LAUNCH(ctx, name, (k_scan_partials<T, Op>), 1, SCAN_THREADS, partials, tiles, identity, total_out);
+    LAUNCH(ctx, name, (k_scan_apply<T, Op, INCLUSIVE>), tiles, SCAN_THREADS, in, out, n, identity, (const T*)partials);
+}
+
+struct SortBufs {
+    uint32_t *kA, *vA, *kB, *vB, *hist, *partials;
+};
+
+size_t sort_scratch_elems_hist(int64_t n) { return (size_t)RS_RADIX * (size_t)rs_num_blocks(n); }
+
+// LSD passes over `bits` low bits of the keys in (kA,vA); returns true when the result is in (kB,vB).
+bool radix_sort_pairs(ivj_ctx* ctx, const SortBufs& sb, int64_t n, int bits) {
+    const int nblocks = rs_num_blocks(n);
+    uint32_t *kin = sb.kA, *vin = sb.vA, *kout = sb.kB, *vout = sb.vB;
+    bool flipped = false;
+    for (int shift = 0; shift < bits; shift += 8) {
+        LAUNCH(ctx, "rs_hist", k_rs_hist, nblocks, RS_THREADS, (const uint32_t*)kin, n, shift, sb.hist, nblocks);
+        device_scan<uint32_t, SumOp, false>(ctx, "rs_scan", sb.hist, sb.hist, (int64_t)RS_RADIX * nblocks, 0u, sb.partials,
+                                             (uint32_t*)nullptr);
+        LAUNCH(ctx, "rs_scatter", k_rs_scatter, nblocks, RS_THREADS, (const uint32_t*)kin, (const uint32_t*)vin, kout, vout,
+               n, shift, (const uint32_t*)sb.hist, nblocks);
+        std::swap(kin, kout); std::swap(vin, vout);
+        flipped = !flipped;
+    }
+    return flipped;
+}
+
+int bits_for(uint32_t max_value) {
+    int b = 0;
+    while (b < 32 && (max_value >> b) != 0) ++b;
+    return b == 0 ? 1 : b;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_opts(const ivj_opts* o) {
+    if (!o) return fail(IVJ_EINVAL, "opts is NULL");
+    if (o->filter_op != IVJ_FILTER_WEAK && o->filter_op != IVJ_FILTER_STRICT) return fail(IVJ_EINVAL, "filter_op must be 0 (Weak) or 1 (Strict)");
+    if (o->n_contigs < 0) return fail(IVJ_EINVAL, "n_contigs < 0");
+    return IVJ_OK;
+}
+int check_side(const ivj_side* s, const char* what) {
+    if (!s) return fail(IVJ_EINVAL, std::string(what) + " is NULL");
+    if (s->n < 0) return fail(IVJ_EINVAL, std::string(what) + ".n < 0");
+    if (s->n > 0 && (!s->contig || !s->start || !s->end)) return fail(IVJ_EINVAL, std::string(what) + " has a NULL column");
+    if (s->n > 0x7fff0000ll) return fail(IVJ_EINVAL, std::string(what) + ".n exceeds the int32 row-index range");
+    return IVJ_OK;
+}
+
+IndexView view_of(const ivj_index* ix) {
+    IndexView v;
+    v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
+    v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
+    return v;
+}
+
+size_t sort_scratch_bytes(int64_t n) {
+    const size_t hist = sort_scratch_elems_hist(n);
+    return 4 * align_up((size_t)n * 4) + align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4);
+}
+void take_sort_bufs(ivj_ctx* ctx, int64_t n, SortBufs& sb) {
+    const size_t hist = sort_scratch_elems_hist(n);
+    sb.kA = arena_take<uint32_t>(ctx, n); sb.vA = arena_take<uint32_t>(ctx, n);
+    sb.kB = arena_take<uint32_t>(ctx, n); sb.vB = arena_take<uint32_t>(ctx, n);
+    sb.hist = arena_take<uint32_t>(ctx, hist);
+    sb.partials = arena_take<uint32_t>(ctx, scan_num_tiles((int64_t)hist) + 1);
+}
+
+int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
+    if (ix->has_end_order) return IVJ_OK;
+    const int64_t n = ix->n;
+    if (n == 0) { ix->has_end_order = true; return IVJ_OK; }
+    HIP_TRY(hipMalloc((void**)&ix->e_end, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&ix->e_pos, (size_t)n * 4));
+    IVJ_TRY(arena_reserve(ctx, sort_scratch_bytes(n) + 4096));
+    SortBufs sb; take_sort_bufs(ctx, n, sb);
+    LAUNCH(ctx, "end_keys", k_end_keys, grid1d(n, 256), 256, (const int2*)ix->ep, n, sb.kA, sb.vA);
+    bool fl = radix_sort_pairs(ctx, sb, n, 32);
+    if (fl) { std::swap(sb.kA, sb.kB); std::swap(sb.vA, sb.vB); }
+    // contig of each sorted position, then the contig passes
+    LAUNCH(ctx, "gather", k_gather_u32, grid1d(n, 256), 256, (const int32_t*)ix->b_contig, (const uint32_t*)sb.vA, n, sb.kA);
+    fl = radix_sort_pairs(ctx, sb, n, bits_for((uint32_t)ix->n_contigs));
+    const uint32_t* pos = fl ? sb.vB : sb.vA;
+    LAUNCH(ctx, "end_finalize", k_end_finalize, grid1d(n, 256), 256, (const int2*)ix->ep, pos, n, ix->e_end, ix->e_pos);
+    ix->has_end_order = true;
+    return IVJ_OK;
+}
+
+int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int with_end_order, ivj_index** out) {
+    ivj_index* ix = new ivj_index();
+    ix->ctx = ctx; ix->n = build->n; ix->n_contigs = opts->n_contigs;
+    const int64_t n = build->n;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    auto cleanup = [&](int code) { ivj_index_free(ix); return code; };
+#define IX_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+    IX_HIP(hipMalloc((void**)&ix->b_start, nn * 4));
+    IX_HIP(hipMalloc((void**)&ix->ep, nn * 8));
+    IX_HIP(hipMalloc((void**)&ix->b_row, nn * 4));
+    IX_HIP(hipMalloc((void**)&ix->b_contig, nn * 4));
+    IX_HIP(hipMalloc((void**)&ix->seg, ((size_t)opts->n_contigs + 2) * 4));
+    IX_HIP(hipMalloc((void**)&ix->flags, 16));
+    IX_HIP(hipMemsetAsync(ix->seg, 0, ((size_t)opts->n_contigs + 2) * 4, ctx->stream));
+    IX_HIP(hipMemsetAsync(ix->flags, 0, 16, ctx->stream));
+#undef IX_HIP
+    if (n > 0) {
+        const size_t comp_bytes = 2 * align_up((size_t)n * 8) + align_up((size_t)(scan_num_tiles(n) + 1) * 8);
+        int r = arena_reserve(ctx, sort_scratch_bytes(n) + comp_bytes + 4096);
+        if (r != IVJ_OK) return cleanup(r);
+        SortBufs sb; take_sort_bufs(ctx, n, sb);
+        unsigned long long* comp = arena_take<unsigned long long>(ctx, n);
+        unsigned long long* comp_max = arena_take<unsigned long long>(ctx, n);
+        unsigned long long* comp_part = arena_take<unsigned long long>(ctx, scan_num_tiles(n) + 1);
+        // 1. stable sort by start (row ids as payload), 2. stable sort by contig id
+        LAUNCH(ctx, "sort_keys", k_iota_flip, grid1d(n, 256), 256, build->start, n, sb.kA, sb.vA);
+        bool fl = radix_sort_pairs(ctx, sb, n, 32);
+        if (fl) { std::swap(sb.kA, sb.kB); std::swap(sb.vA, sb.vB); }
+        LAUNCH(ctx, "gather", k_gather_contig, grid1d(n, 256), 256, build->contig, (const uint32_t*)sb.vA, n, opts->n_contigs, sb.kA);
+        fl = radix_sort_pairs(ctx, sb, n, bits_for((uint32_t)opts->n_contigs));
+        const uint32_t* ckeys = fl ? sb.kB : sb.kA;
+        const uint32_t* rows = fl ? sb.vB : sb.vA;
+        // 3. sorted columns, segment offsets, (contig,end) composites; 4. prefix max; 5. interleave (end, pmax)
+        LAUNCH(ctx, "index_finalize", k_index_finalize, grid1d(n, 256), 256, build->start, build->end, rows, ckeys, build->row_id, n,
+               opts->n_contigs, ix->b_start, ix->b_row, ix->b_contig, comp, ix->seg, ix->flags);
+        device_scan<unsigned long long, MaxOp, true>(ctx, "pmax_scan", comp, comp_max, n, 0ull, comp_part,
+                                                      (unsigned long long*)nullptr);
+        LAUNCH(ctx, "emit_ep", k_emit_ep, grid1d(n, 256), 256, (const unsigned long long*)comp,
+               (const unsigned long long*)comp_max, n, ix->ep);
+        if (with_end_order) { r = build_end_order(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
+    } else {
+        ix->has_end_order = true;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("index build launch: ") + hipGetErrorString(e)));
+    *out = ix;
+    return IVJ_OK;
+}
+
+int ensure_ov(ivj_ctx* ctx, int64_t n) {
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    const size_t need = 2 * align_up((size_t)n * 4) + align_up((size_t)(tiles + 2) * 8) +
+                        align_up((size_t)(scan_num_tiles(tiles) + 2) * 8) + 1024;
+    if (need > ctx->ov_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->ov_buf) HIP_TRY(hipFree(ctx->ov_buf));
+        ctx->ov_buf = nullptr; ctx->ov_cap = 0;
+        size_t want = align_up(need + need / 8, 1 << 20);
+        hipError_t e = hipMalloc((void**)&ctx->ov_buf, want);
+        if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("overlap state hipMalloc: ") + hipGetErrorString(e));
+        ctx->ov_cap = want;
+    }
+    char* p = ctx->ov_buf;
+    ctx->ov_hi = (int32_t*)p; p += align_up((size_t)n * 4);
+    ctx->ov_cnt = (int32_t*)p; p += align_up((size_t)n * 4);
+    ctx->ov_tile = (long long*)p;
+    return IVJ_OK;
+}
+
+int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* n_pairs) {
+    const int64_t n = probe->n;
+    ctx->ov_n = -1;
+    if (n == 0 || ix->n == 0) {
+        ctx->ov_n = n; ctx->ov_total = 0; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
+        *n_pairs = 0;
+        return IVJ_OK;
+    }
+    IVJ_TRY(ensure_ov(ctx, n));
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    long long* tile = ctx->ov_tile;                       // tiles + 1
+    long long* partials = tile + align_up((size_t)(tiles + 2) * 8) / 8;
+    const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
+    IndexView v = view_of(ix);
+    if (opts->filter_op == IVJ_FILTER_STRICT)
+        LAUNCH(ctx, "overlap_count", (k_overlap_count<true>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec,
+               ctx->ov_hi, ctx->ov_cnt, tile);
+    else
+        LAUNCH(ctx, "overlap_count", (k_overlap_count<false>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec,
+               ctx->ov_hi, ctx->ov_cnt, tile);
+    device_scan<long long, SumOp, false>(ctx, "tile_scan", tile, tile, tiles, 0ll, partials, tile + tiles);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, tile + tiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    ctx->ov_total = *ctx->h_total;
+    ctx->ov_n = n; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
+    *n_pairs = ctx->ov_total;
+    return IVJ_OK;
+}
+
+int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
+                 int64_t capacity) {
+    if (ctx->ov_n != probe->n || ctx->ov_probe_start != probe->start || ctx->ov_ix != ix || ctx->ov_filter != opts->filter_op)
+        return fail(IVJ_ESTATE, "ivj_overlap_fill_dev must follow ivj_overlap_count_dev with the same index, probe and filter_op");
+    if (capacity < ctx->ov_total) return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->ov_total) + " pairs");
+    if (ctx->ov_total == 0) return IVJ_OK;
+    if (!out_p || !out_b) return fail(IVJ_EINVAL, "output buffers are NULL");
+    const int64_t n = probe->n;
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    const bool vec = aligned16(probe->start);
+    IndexView v = view_of(ix);
+    if (opts->filter_op == IVJ_FILTER_STRICT)
+        LAUNCH(ctx, "overlap_fill", (k_overlap_fill<true>), tiles, PROBE_THREADS, v, probe->start, n, vec, (const int32_t*)ctx->ov_hi,
+               (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, probe->row_id, out_p, out_b);
+    else
+        LAUNCH(ctx, "overlap_fill", (k_overlap_fill<false>), tiles, PROBE_THREADS, v, probe->start, n, vec, (const int32_t*)ctx->ov_hi,
+               (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, probe->row_id, out_p, out_b);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* counts) {
+    const int64_t n = probe->n;
+    if (n == 0) return IVJ_OK;
+    if (ix->n == 0) { HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
+    IVJ_TRY(build_end_order(ctx, ix));
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
+    IndexView v = view_of(ix);
+    if (opts->filter_op == IVJ_FILTER_STRICT)
+        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, (long long*)counts);
+    else
+        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, (long long*)counts);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* idx, int64_t* dist, int32_t* nf) {
+    const int64_t n = probe->n;
+    const int k = opts->nearest_k < 1 ? 1 : opts->nearest_k;
+    if (n == 0) return IVJ_OK;
+    IndexView v = view_of(ix);
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    if (k == 1 && opts->include_overlaps) {
+        const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+        const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
+        if (strict) LAUNCH(ctx, "nearest_k1", (k_nearest_k1<true>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, idx, (long long*)dist, nf);
+        else LAUNCH(ctx, "nearest_k1", (k_nearest_k1<false>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, idx, (long long*)dist, nf);
+    } else {
+        IVJ_TRY(build_end_order(ctx, ix));
+        v = view_of(ix);
+        if (strict) LAUNCH(ctx, "nearest_general", (k_nearest_general<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, k, (int)opts->include_overlaps, idx, (long long*)dist, nf);
+        else LAUNCH(ctx, "nearest_general", (k_nearest_general<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, k, (int)opts->include_overlaps, idx, (long long*)dist, nf);
+    }
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+// host side -> device copies of one side
+struct DevSide {
+    ivj_side s{nullptr, nullptr, nullptr, 0, nullptr};
+    int32_t* buf = nullptr;
+    ~DevSide() { if (buf) (void)hipFree(buf); }
+};
+int upload_side(ivj_ctx* ctx, const ivj_side* h, DevSide& d) {
+    d.s.n = h->n;
+    if (h->n == 0) return IVJ_OK;
+    const size_t col = align_up((size_t)h->n * 4);
+    hipError_t e = hipMalloc((void**)&d.buf, 3 * col);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(side): ") + hipGetErrorString(e));
+    int32_t* c = d.buf; int32_t* s = (int32_t*)((char*)d.buf + col); int32_t* en = (int32_t*)((char*)d.buf + 2 * col);
+    HIP_TRY(hipMemcpyAsync(c, h->contig, (size_t)h->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(s, h->start, (size_t)h->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(en, h->end, (size_t)h->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    d.s.contig = c; d.s.start = s; d.s.end = en;
+    return IVJ_OK;
+}
+
+struct IndexHolder {
+    ivj_index* ix = nullptr;
+    ~IndexHolder() { if (ix) ivj_index_free(ix); }
+};
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+// =============================================================================== C ABI
+
+extern "C" {
+
+const char* ivj_last_error(void) { return g_err.c_str(); }
+const char* ivj_version(void) { return "ivjoin-hip 0.1 (gfx950)"; }
+
+int ivj_device_count(int* n) {
+    if (!n) return fail(IVJ_EINVAL, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return fail(IVJ_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *n = c;
+    return IVJ_OK;
+}
+
+int ivj_ctx_create(int device, ivj_ctx** out) {
+    if (!out) return fail(IVJ_EINVAL, "out is NULL");
+    int cnt = 0;
+    IVJ_TRY(ivj_device_count(&cnt));
+    if (device < 0 || device >= cnt) return fail(IVJ_EHIP, "no usable HIP device " + std::to_string(device) + " (device count " + std::to_string(cnt) + ")");
+    HIP_TRY(hipSetDevice(device));
+    ivj_ctx* ctx = new ivj_ctx();
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(IVJ_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    ctx->stream = ctx->own_stream;
+    e = hipHostMalloc((void**)&ctx->h_total, 64, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(IVJ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    *out = ctx;
+    return IVJ_OK;
+}
+
+void ivj_ctx_destroy(ivj_ctx* ctx) {
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+    if (ctx->ov_buf) (void)hipFree(ctx->ov_buf);
+    if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+    for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int ivj_ctx_set_stream(ivj_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return IVJ_OK;
+}
+
+int ivj_ctx_sync(ivj_ctx* ctx) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IVJ_OK;
+}
+
+int ivj_ctx_enable_timing(ivj_ctx* ctx, int on) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
+    ctx->recs.clear();
+    ctx->pool_used = 0;
+    return IVJ_OK;
+}
+
+int ivj_ctx_get_timings(ivj_ctx* ctx, ivj_timing* out, int cap, int* n) {
+    if (!ctx || !n) return fail(IVJ_EINVAL, "ctx or n is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<ivj_timing> agg;
+    for (const TimingRec& r : ctx->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        size_t j = 0;
+        for (; j < agg.size(); ++j) if (std::strcmp(agg[j].name, r.name) == 0) break;
+        if (j == agg.size()) {
+            ivj_timing t; std::memset(&t, 0, sizeof t);
+            std::strncpy(t.name, r.name, sizeof(t.name) - 1);
+            agg.push_back(t);
+        }
+        agg[j].launches += 1; agg[j].ms += ms;
+    }
+    *n = (int)agg.size();
+    for (int i = 0; i < (int)agg.size() && i < cap; ++i) out[i] = agg[i];
+    ctx->recs.clear();
+    ctx->pool_used = 0;
+    return IVJ_OK;
+}
+
+// ---------------------------------------------------------------- device-resident API
+
+int ivj_index_build_dev(ivj_ctx* ctx, const ivj_side* build_dev, const ivj_opts* opts, int with_end_order, ivj_index** out) {
+    if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(build_dev, "build"));
+    DeviceGuard g(ctx->device);
+    return index_build(ctx, build_dev, opts, with_end_order, out);
+}
+
+void ivj_index_free(ivj_index* ix) {
+    if (!ix) return;
+    DeviceGuard g(ix->ctx ? ix->ctx->device : 0);
+    if (ix->ctx) {
+        (void)hipStreamSynchronize(ix->ctx->stream);
+        if (ix->ctx->ov_ix == ix) { ix->ctx->ov_ix = nullptr; ix->ctx->ov_n = -1; }
+    }
+    void* ps[] = {ix->b_start, ix->ep, ix->b_row, ix->b_contig, ix->seg, ix->flags, ix->e_end, ix->e_pos};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    delete ix;
+}
+
+int ivj_overlap_count_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* n_pairs) {
+    if (!ctx || !ix || !n_pairs) return fail(IVJ_EINVAL, "ctx, index or n_pairs is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    DeviceGuard g(ctx->device);
+    return overlap_count(ctx, ix, probe_dev, opts, n_pairs);
+}
+
+int ivj_overlap_fill_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts,
+                         int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity) {
+    if (!ctx || !ix) return fail(IVJ_EINVAL, "ctx or index is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    DeviceGuard g(ctx->device);
+    return overlap_fill(ctx, ix, probe_dev, opts, probe_idx_dev, build_idx_dev, capacity);
+}
+
+int ivj_count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* counts_dev) {
+    if (!ctx || !ix) return fail(IVJ_EINVAL, "ctx or index is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    if (probe_dev->n > 0 && !counts_dev) return fail(IVJ_EINVAL, "counts is NULL");
+    DeviceGuard g(ctx->device);
+    return count_overlaps_dev(ctx, ix, probe_dev, opts, counts_dev);
+}
+
+int ivj_nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int32_t* idx_dev,
+                    int64_t* dist_dev, int32_t* n_found_dev) {
+    if (!ctx || !ix) return fail(IVJ_EINVAL, "ctx or index is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    if (probe_dev->n > 0 && (!idx_dev || !dist_dev || !n_found_dev)) return fail(IVJ_EINVAL, "nearest output buffers are NULL");
+    if (opts->nearest_k > 1024) return fail(IVJ_EINVAL, "nearest_k > 1024");
+    DeviceGuard g(ctx->device);
+    return nearest_dev(ctx, ix, probe_dev, opts, idx_dev, dist_dev, n_found_dev);
+}
+
+// ---------------------------------------------------------------- host-buffer API
+
+int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, ivj_pairs* out) {
+    if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
+    out->n_pairs = 0; out->probe_idx = nullptr; out->build_idx = nullptr;
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe, "probe"));
+    IVJ_TRY(check_side(build, "build"));
+    DeviceGuard g(ctx->device);
+    DevSide dp, db;
+    IVJ_TRY(upload_side(ctx, build, db));
+    IVJ_TRY(upload_side(ctx, probe, dp));
+    IndexHolder h;
+    IVJ_TRY(index_build(ctx, &db.s, opts, 0, &h.ix));
+    int64_t total = 0;
+    IVJ_TRY(overlap_count(ctx, h.ix, &dp.s, opts, &total));
+    if (total == 0) return IVJ_OK;
+    DevBuf op, ob;
+    hipError_t e = hipMalloc(&op.p, (size_t)total * 4);
+    if (e == hipSuccess) e = hipMalloc(&ob.p, (size_t)total * 4);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(pairs): ") + hipGetErrorString(e));
+    IVJ_TRY(overlap_fill(ctx, h.ix, &dp.s, opts, (int32_t*)op.p, (int32_t*)ob.p, total));
+    out->probe_idx = (int32_t*)std::malloc((size_t)total * 4);
+    out->build_idx = (int32_t*)std::malloc((size_t)total * 4);
+    if (!out->probe_idx || !out->build_idx) { ivj_pairs_free(out); return fail(IVJ_ENOMEM, "host malloc(pairs)"); }
+    HIP_TRY(hipMemcpyAsync(out->probe_idx, op.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out->build_idx, ob.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    out->n_pairs = total;
+    return IVJ_OK;
+}
+
+void ivj_pairs_free(ivj_pairs* p) {
+    if (!p) return;
+    std::free(p->probe_idx); std::free(p->build_idx);
+    p->probe_idx = nullptr; p->build_idx = nullptr; p->n_pairs = 0;
+}
+
+int ivj_count_overlaps(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int64_t* counts) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe, "probe"));
+    IVJ_TRY(check_side(build, "build"));
+    if (probe->n == 0) return IVJ_OK;
+    if (!counts) return fail(IVJ_EINVAL, "counts is NULL");
+    DeviceGuard g(ctx->device);
+    DevSide dp, db;
+    IVJ_TRY(upload_side(ctx, build, db));
+    IVJ_TRY(upload_side(ctx, probe, dp));
+    IndexHolder h;
+    IVJ_TRY(index_build(ctx, &db.s, opts, 1, &h.ix));
+    DevBuf dc;
+    hipError_t e = hipMalloc(&dc.p, (size_t)probe->n * 8);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(counts): ") + hipGetErrorString(e));
+    IVJ_TRY(count_overlaps_dev(ctx, h.ix, &dp.s, opts, (int64_t*)dc.p));
+    HIP_TRY(hipMemcpyAsync(counts, dc.p, (size_t)probe->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IVJ_OK;
+}
+
+int ivj_nearest(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int32_t* idx, int64_t* dist,
+                int32_t* n_found) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe, "probe"));
+    IVJ_TRY(check_side(build, "build"));
+    if (probe->n == 0) return IVJ_OK;
+    if (!idx || !dist || !n_found) return fail(IVJ_EINVAL, "nearest output buffers are NULL");
+    const int k = opts->nearest_k < 1 ? 1 : opts->nearest_k;
+    if (k > 1024) return fail(IVJ_EINVAL, "nearest_k > 1024");
+    DeviceGuard g(ctx->device);
+    DevSide dp, db;
+    IVJ_TRY(upload_side(ctx, build, db));
+    IVJ_TRY(upload_side(ctx, probe, dp));
+    IndexHolder h;
+    const bool general = !(k == 1 && opts->include_overlaps);
+    IVJ_TRY(index_build(ctx, &db.s, opts, general ? 1 : 0, &h.ix));
+    const size_t slots = (size_t)probe->n * (size_t)k;
+    DevBuf di, dd, dn;
+    hipError_t e = hipMalloc(&di.p, slots * 4);
+    if (e == hipSuccess) e = hipMalloc(&dd.p, slots * 8);
+    if (e == hipSuccess) e = hipMalloc(&dn.p, (size_t)probe->n * 4);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(nearest): ") + hipGetErrorString(e));
+    IVJ_TRY(nearest_dev(ctx, h.ix, &dp.s, opts, (int32_t*)di.p, (int64_t*)dd.p, (int32_t*)dn.p));
+    HIP_TRY(hipMemcpyAsync(idx, di.p, slots * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dist, dd.p, slots * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(n_found, dn.p, (size_t)probe->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IVJ_OK;
+}
+
+// ---------------------------------------------------------------- memory helpers
+
+int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out) {
+    if (!ctx || !out || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
+    DeviceGuard g(ctx->device);
+    *out = nullptr;
+    if (bytes == 0) return IVJ_OK;
+    hipError_t e = hipMalloc(out, (size_t)bytes);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return IVJ_OK;
+}
+int ivj_dev_free(ivj_ctx* ctx, void* p) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    if (!p) return IVJ_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(p));
+    return IVJ_OK;
+}
+int ivj_memcpy_h2d(ivj_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes) {
+    if (!ctx || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
+    if (bytes == 0) return IVJ_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IVJ_OK;
+}
+int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes) {
+    if (!ctx || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
+    if (bytes == 0) return IVJ_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IVJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,415 @@
+// probe.hip.h -- index finalisation and probe kernels of the interval join.
+//
+// HBM layout of the build index (sorted by (contig, start, row)):
+//   b_start[Nb]  int32   start, the array the hi-bound search runs on
+//   ep[Nb]       int2    (end, prefix-max of end inside the contig segment)
+//   b_row[Nb]    int32   original build row
+//   b_contig[Nb] int32   contig id in that order (rows outside the dictionary get n_contigs)
+//   seg[n_contigs + 2]   segment offsets; seg[n_contigs] = number of valid rows
+//   e_end / e_pos [Nb]   optional: ends sorted by (contig, end, position), and that position
+//
+// Predicate (polars_bio/range_op.py:75-84; src/option.rs:95-100):
+//   STRICT: q.start <  b.end && b.start <  q.end      WEAK: <=
+// For a probe q on contig c with segment [a,b):
+//   hi = first p in [a,b) with !(b_start[p] (<) q.end)     -> every match has p < hi
+//   matches = { p in [a,hi) : q.start (<) end[p] };  the prefix max bounds the backward scan:
+//   stop at the first p (going down) with !(q.start (<) pmax[p]).
+#pragma once
+#include "scan.hip.h"
+
+namespace ivj {
+
+constexpr int PROBE_THREADS = 256;
+constexpr int PROBE_ITEMS = 4;
+constexpr int PROBE_TILE = PROBE_THREADS * PROBE_ITEMS;
+
+struct IndexView {
+    const int32_t* b_start;
+    const int2* ep;
+    const int32_t* b_row;
+    const int32_t* seg;
+    const int32_t* e_end;
+    const int32_t* e_pos;
+    const int32_t* flags;  // flags[0] != 0: some build row has start > end
+    int32_t n_contigs;
+};
+
+__device__ __forceinline__ uint32_t flip(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+__device__ __forceinline__ int32_t unflip(uint32_t v) { return (int32_t)(v ^ 0x80000000u); }
+
+template <bool STRICT>
+__device__ __forceinline__ bool lt_op(int32_t x, int32_t y) { return STRICT ? (x < y) : (x <= y); }
+
+__device__ __forceinline__ long long gap_dist(int32_t qs, int32_t qe, int32_t bs, int32_t be) {
+    const long long d1 = (long long)bs - (long long)qe;
+    const long long d2 = (long long)qs - (long long)be;
+    return d1 > d2 ? d1 : d2;
+}
+
+__device__ __forceinline__ void seg_bounds(const IndexView& ix, int32_t c, bool valid, int& a, int& b) {
+    if (valid && (uint32_t)c < (uint32_t)ix.n_contigs) { a = ix.seg[c]; b = ix.seg[c + 1]; }
+    else { a = 0; b = 0; }
+}
+
+// first p in [lo,hi) with arr[p] >= x (OR_EQUAL=false: lower bound) / arr[p] > x (true: upper bound)
+template <bool UPPER>
+__device__ __forceinline__ int bsearch32(const int32_t* __restrict__ arr, int lo, int hi, int32_t x) {
+    while (lo < hi) {
+        const int m = lo + ((hi - lo) >> 1);
+        const int32_t v = arr[m];
+        const bool right = UPPER ? (v <= x) : (v < x);
+        if (right) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+// same on the .y (prefix max) lane of ep
+template <bool UPPER>
+__device__ __forceinline__ int bsearch_pmax(const int2* __restrict__ ep, int lo, int hi, int32_t x) {
+    while (lo < hi) {
+        const int m = lo + ((hi - lo) >> 1);
+        const int32_t v = ep[m].y;
+        const bool right = UPPER ? (v <= x) : (v < x);
+        if (right) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+
+// hi: first position whose start fails "start (<) q.end"
+template <bool STRICT>
+__device__ __forceinline__ int bound_hi(const IndexView& ix, int a, int b, int32_t qe) {
+    return STRICT ? bsearch32<false>(ix.b_start, a, b, qe) : bsearch32<true>(ix.b_start, a, b, qe);
+}
+// lo: first position in [a,hi) whose prefix max satisfies "q.start (<) pmax"
+template <bool STRICT>
+__device__ __forceinline__ int bound_lo(const IndexView& ix, int a, int hi, int32_t qs) {
+    return STRICT ? bsearch_pmax<true>(ix.ep, a, hi, qs) : bsearch_pmax<false>(ix.ep, a, hi, qs);
+}
+// r: first position of the end-sorted segment whose end satisfies "q.start (<) end"
+template <bool STRICT>
+__device__ __forceinline__ int bound_r(const IndexView& ix, int a, int b, int32_t qs) {
+    return STRICT ? bsearch32<true>(ix.e_end, a, b, qs) : bsearch32<false>(ix.e_end, a, b, qs);
+}
+
+// Four interleaved hi-bound searches: the four gathers of a step are issued
+// back to back, so a thread keeps four HBM/L2 requests in flight.
+template <bool STRICT>
+__device__ __forceinline__ void bound_hi4(const IndexView& ix, const int (&a)[PROBE_ITEMS], const int (&b)[PROBE_ITEMS],
+                                          const int32_t (&qe)[PROBE_ITEMS], int (&out)[PROBE_ITEMS]) {
+    int lo[PROBE_ITEMS], hi[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) { lo[k] = a[k]; hi[k] = b[k]; }
+    for (;;) {
+        bool any = false;
+        int32_t v[PROBE_ITEMS];
+        int m[PROBE_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) {
+            m[k] = lo[k] + ((hi[k] - lo[k]) >> 1);
+            const bool act = lo[k] < hi[k];
+            any |= act;
+            v[k] = act ? ix.b_start[m[k]] : 0;
+        }
+        if (!any) break;
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) {
+            if (lo[k] < hi[k]) {
+                const bool right = STRICT ? (v[k] < qe[k]) : (v[k] <= qe[k]);
+                if (right) lo[k] = m[k] + 1; else hi[k] = m[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) out[k] = lo[k];
+}
+
+// exact count by the bounded backward scan (valid for every input, including
+// zero-length and inverted rows)
+template <bool STRICT>
+__device__ __forceinline__ int scan_count(const IndexView& ix, int a, int hi, int32_t qs) {
+    int cnt = 0;
+    for (int p = hi - 1; p >= a; --p) {
+        const int2 v = ix.ep[p];
+        if (!lt_op<STRICT>(qs, v.y)) break;
+        cnt += lt_op<STRICT>(qs, v.x) ? 1 : 0;
+    }
+    return cnt;
+}
+
+// Load PROBE_ITEMS consecutive int32 (16-byte vector load when the tile is full and aligned).
+__device__ __forceinline__ void load_items(const int32_t* __restrict__ p, int64_t i0, int64_t n, bool vec_ok,
+                                           int32_t fill, int32_t (&out)[PROBE_ITEMS]) {
+    if (vec_ok && i0 + PROBE_ITEMS <= n) {
+        const int4 v = *reinterpret_cast<const int4*>(p + i0);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) out[k] = (i0 + k < n) ? p[i0 + k] : fill;
+    }
+}
+__device__ __forceinline__ void store_items(int32_t* __restrict__ p, int64_t i0, int64_t n, bool vec_ok,
+                                            const int32_t (&v)[PROBE_ITEMS]) {
+    if (vec_ok && i0 + PROBE_ITEMS <= n) {
+        *reinterpret_cast<int4*>(p + i0) = make_int4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) if (i0 + k < n) p[i0 + k] = v[k];
+    }
+}
+
+// ------------------------------------------------------------------ index build
+
+__global__ void k_iota_flip(const int32_t* __restrict__ coord, int64_t n, uint32_t* __restrict__ keys,
+                            uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = flip(coord[i]); vals[i] = (uint32_t)i; }
+}
+
+// keys[i] = contig id of the row at sorted position i, clamped to n_contigs when outside the dictionary
+__global__ void k_gather_contig(const int32_t* __restrict__ contig, const uint32_t* __restrict__ rows, int64_t n,
+                                int32_t n_contigs, uint32_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int32_t c = contig[rows[i]];
+        keys[i] = ((uint32_t)c < (uint32_t)n_contigs) ? (uint32_t)c : (uint32_t)n_contigs;
+    }
+}
+
+// After the final pass: materialise the sorted columns, the (contig,end) composite for the
+// prefix-max scan, the segment offsets and the inverted-row flag.
+__global__ void k_index_finalize(const int32_t* __restrict__ start, const int32_t* __restrict__ end,
+                                 const uint32_t* __restrict__ rows, const uint32_t* __restrict__ ckeys,
+                                 const int32_t* __restrict__ row_id, int64_t n,
+                                 int32_t n_contigs, int32_t* __restrict__ b_start, int32_t* __restrict__ b_row,
+                                 int32_t* __restrict__ b_contig, unsigned long long* __restrict__ comp,
+                                 int32_t* __restrict__ seg, int32_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = rows[i];
+    const uint32_t c = ckeys[i];
+    const int32_t s = start[r], e = end[r];
+    b_start[i] = s;
+    b_row[i] = row_id ? row_id[r] : (int32_t)r;
+    b_contig[i] = (int32_t)c;
+    comp[i] = ((unsigned long long)c << 32) | (unsigned long long)flip(e);
+    if (s > e && c < (uint32_t)n_contigs) flags[0] = 1;
+    // seg[k] = first position whose contig key is >= k, for k in (prev, c]
+    const int32_t prev = (i == 0) ? -1 : (int32_t)ckeys[i - 1];
+    for (int32_t k = prev + 1; k <= (int32_t)c; ++k) seg[k] = (int32_t)i;
+    if (i == n - 1)
+        for (int32_t k = (int32_t)c + 1; k <= n_contigs + 1; ++k) seg[k] = (int32_t)n;
+}
+
+__global__ void k_emit_ep(const unsigned long long* __restrict__ comp_raw, const unsigned long long* __restrict__ comp_max,
+                          int64_t n, int2* __restrict__ ep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ep[i] = make_int2(unflip((uint32_t)comp_raw[i]), unflip((uint32_t)comp_max[i]));
+}
+
+__global__ void k_end_keys(const int2* __restrict__ ep, int64_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = flip(ep[i].x); vals[i] = (uint32_t)i; }
+}
+__global__ void k_gather_u32(const int32_t* __restrict__ src, const uint32_t* __restrict__ pos, int64_t n,
+                             uint32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)src[pos[i]];
+}
+__global__ void k_end_finalize(const int2* __restrict__ ep, const uint32_t* __restrict__ pos, int64_t n,
+                               int32_t* __restrict__ e_end, int32_t* __restrict__ e_pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t p = pos[i]; e_end[i] = ep[p].x; e_pos[i] = (int32_t)p; }
+}
+
+// ------------------------------------------------------------------ overlap: count -> fill
+
+// Pass 1.  One workgroup = PROBE_TILE probes, PROBE_ITEMS consecutive probes per thread.
+// Writes hi[i], cnt[i] (so the fill pass does not search again) and the tile total.
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, const int32_t* __restrict__ pc,
+                                                                 const int32_t* __restrict__ ps,
+                                                                 const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
+                                                                 int32_t* __restrict__ hi_out, int32_t* __restrict__ cnt_out,
+                                                                 long long* __restrict__ tile_tot) {
+    __shared__ long long lds[PROBE_THREADS / kWave];
+    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
+    load_items(pc, i0, n, vec_ok, -1, c);
+    load_items(ps, i0, n, vec_ok, 0, s);
+    load_items(pe, i0, n, vec_ok, 0, e);
+    int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS], cnt[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) seg_bounds(ix, c[k], i0 + k < n, a[k], b[k]);
+    bound_hi4<STRICT>(ix, a, b, e, hi);
+    long long tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) { cnt[k] = scan_count<STRICT>(ix, a[k], hi[k], s[k]); tsum += cnt[k]; }
+    store_items(hi_out, i0, n, vec_ok, hi);
+    store_items(cnt_out, i0, n, vec_ok, cnt);
+    long long tot;
+    block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
+    if (threadIdx.x == 0) tile_tot[blockIdx.x] = tot;
+}
+
+// Pass 2.  tile_base = exclusive scan of tile_tot.  Pairs of one probe are written in
+// ascending (build.start, build row) order: the backward scan fills its slots from the top.
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
+                                                                bool vec_ok, const int32_t* __restrict__ hi_in,
+                                                                const int32_t* __restrict__ cnt_in,
+                                                                const long long* __restrict__ tile_base,
+                                                                const int32_t* __restrict__ probe_ids,
+                                                                int32_t* __restrict__ out_probe,
+                                                                int32_t* __restrict__ out_build) {
+    __shared__ long long lds[PROBE_THREADS / kWave];
+    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    int32_t s[PROBE_ITEMS], hi[PROBE_ITEMS], cnt[PROBE_ITEMS];
+    load_items(ps, i0, n, vec_ok, 0, s);
+    load_items(hi_in, i0, n, vec_ok, 0, hi);
+    load_items(cnt_in, i0, n, vec_ok, 0, cnt);
+    long long tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) tsum += cnt[k];
+    long long tot;
+    long long off = tile_base[blockIdx.x] + block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) {
+        const int32_t row = (probe_ids && i0 + k < n) ? probe_ids[i0 + k] : (int32_t)(i0 + k);
+        int found = 0;
+        for (int p = hi[k] - 1; found < cnt[k]; --p) {
+            const int2 v = ix.ep[p];
+            if (lt_op<STRICT>(s[k], v.x)) {
+                const long long o = off + (cnt[k] - 1 - found);
+                out_probe[o] = row;
+                out_build[o] = ix.b_row[p];
+                ++found;
+            }
+        }
+        off += cnt[k];
+    }
+}
+
+// ------------------------------------------------------------------ count_overlaps
+
+// count = #{b.start (<) q.end} - #{!(q.start (<) b.end)}  (two-rank formula of the reference's
+// SQL sweep, polars_bio/range_op.py:548-595); the bounded scan replaces it for rows where the
+// formula is not exact (zero-length/inverted probe, or any inverted build row).
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, const int32_t* __restrict__ pc,
+                                                                  const int32_t* __restrict__ ps,
+                                                                  const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
+                                                                  long long* __restrict__ counts) {
+    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
+    load_items(pc, i0, n, vec_ok, -1, c);
+    load_items(ps, i0, n, vec_ok, 0, s);
+    load_items(pe, i0, n, vec_ok, 0, e);
+    int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) seg_bounds(ix, c[k], i0 + k < n, a[k], b[k]);
+    bound_hi4<STRICT>(ix, a, b, e, hi);
+    const bool inv = ix.flags[0] != 0;
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) {
+        if (i0 + k >= n) continue;
+        const bool degenerate = inv || (STRICT ? (s[k] >= e[k]) : (s[k] > e[k]));
+        long long cnt;
+        if (!degenerate) cnt = (long long)hi[k] - (long long)bound_r<STRICT>(ix, a[k], b[k], s[k]);
+        else cnt = scan_count<STRICT>(ix, a[k], hi[k], s[k]);
+        counts[i0 + k] = cnt;
+    }
+}
+
+// ------------------------------------------------------------------ nearest
+
+// k = 1, include_overlaps = 1 (the default pb.nearest).  An overlapping row wins with distance 0
+// (the one with the smallest (start,row): tests/_expected.py:130-172 tie-break); otherwise the
+// closer of the row with the largest end before the probe (ties: smallest (start,row)) and the
+// row with the smallest start after it; equal distance -> the left one.
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, const int32_t* __restrict__ pc,
+                                                              const int32_t* __restrict__ ps,
+                                                              const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
+                                                              int32_t* __restrict__ out_idx, long long* __restrict__ out_dist,
+                                                              int32_t* __restrict__ out_n) {
+    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
+    load_items(pc, i0, n, vec_ok, -1, c);
+    load_items(ps, i0, n, vec_ok, 0, s);
+    load_items(pe, i0, n, vec_ok, 0, e);
+    int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) seg_bounds(ix, c[k], i0 + k < n, a[k], b[k]);
+    bound_hi4<STRICT>(ix, a, b, e, hi);
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) {
+        if (i0 + k >= n) continue;
+        int32_t idx = -1; long long dist = -1; int32_t found = 0;
+        if (b[k] > a[k]) {
+            const int lo = bound_lo<STRICT>(ix, a[k], hi[k], s[k]);
+            if (lo < hi[k]) { idx = ix.b_row[lo]; dist = 0; found = 1; }
+            else {
+                bool have_l = hi[k] > a[k], have_r = hi[k] < b[k];
+                long long dl = 0, dr = 0; int lpos = 0;
+                if (have_l) {
+                    const int32_t maxend = ix.ep[hi[k] - 1].y;
+                    lpos = bsearch_pmax<false>(ix.ep, a[k], hi[k], maxend);
+                    dl = (long long)s[k] - (long long)maxend;
+                }
+                if (have_r) dr = gap_dist(s[k], e[k], ix.b_start[hi[k]], ix.ep[hi[k]].x);
+                if (have_l && (!have_r || dl <= dr)) { idx = ix.b_row[lpos]; dist = dl; found = 1; }
+                else if (have_r) { idx = ix.b_row[hi[k]]; dist = dr; found = 1; }
+            }
+        }
+        out_idx[i0 + k] = idx; out_dist[i0 + k] = dist; out_n[i0 + k] = found;
+    }
+}
+
+// General k / include_overlaps: per-probe merge of three ordered streams (overlapping rows in
+// (start,row) order; "left" rows by end descending; "right" rows by start ascending).
+// One thread per probe; k slots per probe, unused slots -1.
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_nearest_general(IndexView ix, const int32_t* __restrict__ pc,
+                                                                   const int32_t* __restrict__ ps,
+                                                                   const int32_t* __restrict__ pe, int64_t n, int kk,
+                                                                   int include_overlaps, int32_t* __restrict__ out_idx,
+                                                                   long long* __restrict__ out_dist,
+                                                                   int32_t* __restrict__ out_n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t qs = ps[i], qe = pe[i];
+    int32_t* oi = out_idx + i * kk;
+    long long* od = out_dist + i * kk;
+    for (int r = 0; r < kk; ++r) { oi[r] = -1; od[r] = -1; }
+    int a, b;
+    seg_bounds(ix, pc[i], true, a, b);
+    int found = 0;
+    if (b > a) {
+        const int hi = bound_hi<STRICT>(ix, a, b, qe);
+        if (include_overlaps) {
+            const int lo = bound_lo<STRICT>(ix, a, hi, qs);
+            for (int p = lo; p < hi && found < kk; ++p)
+                if (lt_op<STRICT>(qs, ix.ep[p].x)) { oi[found] = ix.b_row[p]; od[found] = 0; ++found; }
+        }
+        const int r_top = bound_r<STRICT>(ix, a, b, qs);
+        int run_hi = r_top, run_lo = r_top, lp = r_top, rp = hi;
+        while (found < kk) {
+            for (;;) {
+                while (lp < run_hi && ix.e_pos[lp] >= hi) ++lp;   // not class "left": start fails (<) q.end
+                if (lp < run_hi || run_lo <= a) break;
+                run_hi = run_lo;
+                run_lo = bsearch32<false>(ix.e_end, a, run_hi, ix.e_end[run_hi - 1]);
+                lp = run_lo;
+            }
+            const bool have_l = lp < run_hi, have_r = rp < b;
+            if (!have_l && !have_r) break;
+            long long dl = 0, dr = 0; int pl = 0;
+            if (have_l) { pl = ix.e_pos[lp]; dl = gap_dist(qs, qe, ix.b_start[pl], ix.ep[pl].x); }
+            if (have_r) dr = gap_dist(qs, qe, ix.b_start[rp], ix.ep[rp].x);
+            if (have_l && (!have_r || dl <= dr)) { oi[found] = ix.b_row[pl]; od[found] = dl; ++found; ++lp; }
+            else { oi[found] = ix.b_row[rp]; od[found] = dr; ++found; ++rp; }
+        }
+    }
+    out_n[i] = found;
+}
+
+}  // namespace ivj

@@ -1,0 +1,22 @@
+"""polars_bio_amd -- MI355X-native drop-in for polars-bio's range-operation hot path
+(pb.overlap / pb.nearest / pb.count_overlaps).
+
+    import polars_bio_amd as pb
+    pb.overlap(df1, df2, output_type="pandas.DataFrame")
+
+Public names mirror /root/reference/polars_bio/__init__.py:136-143.  The executor is
+libivjoin_hip.so (hand-written HIP kernels for gfx950) reached through ctypes; there is
+no CPU fallback.
+"""
+from .context import ctx, get_option, set_option
+from .exceptions import CoordinateSystemMismatchError, MissingCoordinateSystemError
+from .range_op import FilterOp, OverlapOutputMode, RangeOp, count_overlaps, nearest, overlap
+from ._metadata import get_coordinate_system, set_coordinate_system
+
+__version__ = "0.1.0"
+__all__ = [
+    "overlap", "nearest", "count_overlaps", "set_option", "get_option", "ctx",
+    "FilterOp", "RangeOp", "OverlapOutputMode",
+    "CoordinateSystemMismatchError", "MissingCoordinateSystemError",
+    "get_coordinate_system", "set_coordinate_system",
+]

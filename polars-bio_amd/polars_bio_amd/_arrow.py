@@ -1,0 +1,159 @@
+"""Arrow hand-off of the range-operation front end.
+
+Reference counterparts: ``_df_to_reader`` / ``_get_schema``
+(/root/reference/polars_bio/range_op_io.py:398-418, 318-374) and the column
+renaming SELECTs of /root/reference/src/operation.rs:170-197, 272-301.
+
+Only the three key columns cross the C ABI: ``chrom`` is dictionary-encoded on
+the host with one dictionary shared by both sides, ``start``/``end`` are
+narrowed to int32 with a range check (the documented int32 limit of the
+reference: docs/features/operations.md:36-37).  Every other column is gathered
+on the host by the row indices the engine returns.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+
+try:
+    import pandas as pd
+except ImportError:  # pragma: no cover
+    pd = None
+try:
+    import polars as pl
+except ImportError:
+    pl = None
+
+OUTPUT_TYPES = ("polars.LazyFrame", "polars.DataFrame", "pandas.DataFrame", "datafusion.DataFrame", "pyarrow.Table")
+
+
+def to_arrow(df) -> pa.Table:
+    """Any supported input kind -> pyarrow.Table (zero-copy where Arrow-backed)."""
+    if isinstance(df, pa.Table):
+        return df
+    if isinstance(df, pa.RecordBatch):
+        return pa.Table.from_batches([df])
+    if pd is not None and isinstance(df, pd.DataFrame):
+        return pa.Table.from_pandas(df, preserve_index=False)
+    if pl is not None and isinstance(df, pl.LazyFrame):
+        return df.collect().to_arrow()
+    if pl is not None and isinstance(df, pl.DataFrame):
+        return df.to_arrow()
+    if isinstance(df, str):
+        if df.endswith(".parquet"):
+            import pyarrow.parquet as pq
+            return pq.read_table(df)
+        if df.endswith(".csv"):
+            import pyarrow.csv as pcsv
+            return pcsv.read_csv(df)
+        if df.endswith(".bed"):
+            import pyarrow.csv as pcsv
+            return pcsv.read_csv(df, read_options=pcsv.ReadOptions(column_names=["chrom", "start", "end"]),
+                                 parse_options=pcsv.ParseOptions(delimiter="\t"))
+        raise AssertionError("Dataframe must be a Parquet, BED or CSV file")
+    if hasattr(df, "__arrow_c_stream__"):
+        return pa.table(df)
+    raise TypeError(f"unsupported input type {type(df)!r}")
+
+
+def _coord_to_i32(col: pa.ChunkedArray, name: str) -> np.ndarray:
+    if col.null_count:
+        raise ValueError(f"column '{name}' contains nulls; interval coordinates must be non-null")
+    if not (pa.types.is_integer(col.type)):
+        raise ValueError(f"column '{name}' must be an integer type, got {col.type}")
+    if col.type != pa.int32():
+        try:
+            col = pc.cast(col, pa.int32(), safe=True)
+        except pa.ArrowInvalid as e:
+            raise ValueError(f"column '{name}' does not fit int32 coordinates (reference limit): {e}") from None
+    arr = col.combine_chunks() if isinstance(col, pa.ChunkedArray) else col
+    if isinstance(arr, pa.ChunkedArray):  # zero chunks
+        arr = pa.array([], pa.int32())
+    return arr.to_numpy(zero_copy_only=False)
+
+
+def _as_string(col: pa.ChunkedArray) -> pa.ChunkedArray:
+    t = col.type
+    if pa.types.is_dictionary(t):
+        col = pc.cast(col, t.value_type)
+        t = col.type
+    if pa.types.is_string(t) or pa.types.is_large_string(t) or (hasattr(pa.types, "is_string_view") and pa.types.is_string_view(t)):
+        return pc.cast(col, pa.large_string())
+    return pc.cast(col, pa.large_string())
+
+
+def encode_keys(t1: pa.Table, cols1, t2: pa.Table, cols2) -> Tuple[tuple, tuple, int]:
+    """-> ((contig1,start1,end1), (contig2,start2,end2), n_contigs) as int32 numpy arrays.
+
+    Join key = exact string equality of chrom (Appendix A of SURVEY.md); rows
+    with a null chrom get id -1 and match nothing."""
+    for t, cols in ((t1, cols1), (t2, cols2)):
+        for c in cols:
+            if c not in t.column_names:
+                raise ValueError(f"column '{c}' not found in {t.column_names}")
+    ch1, ch2 = _as_string(t1.column(cols1[0])), _as_string(t2.column(cols2[0]))
+    u = pc.unique(pa.chunked_array(ch1.chunks + ch2.chunks, type=pa.large_string()))
+    u = pc.drop_null(u)
+    n_contigs = len(u)
+
+    def ids(ch):
+        if len(ch) == 0:
+            return np.empty(0, np.int32)
+        idx = pc.index_in(ch, value_set=u)
+        idx = pc.fill_null(idx, -1)
+        return idx.combine_chunks().to_numpy(zero_copy_only=False).astype(np.int32, copy=False) \
+            if isinstance(idx, pa.ChunkedArray) else idx.to_numpy(zero_copy_only=False).astype(np.int32, copy=False)
+
+    side1 = (ids(ch1), _coord_to_i32(t1.column(cols1[1]), cols1[1]), _coord_to_i32(t1.column(cols1[2]), cols1[2]))
+    side2 = (ids(ch2), _coord_to_i32(t2.column(cols2[1]), cols2[1]), _coord_to_i32(t2.column(cols2[2]), cols2[2]))
+    return side1, side2, n_contigs
+
+
+def take_rows(t: pa.Table, idx: np.ndarray, nullable: bool = False) -> pa.Table:
+    """Gather rows; with nullable=True an index of -1 yields an all-null row."""
+    if nullable:
+        mask = idx < 0
+        arr = pa.array(np.where(mask, 0, idx), type=pa.int32(), mask=mask)
+    else:
+        arr = pa.array(idx, type=pa.int32())
+    if t.num_rows == 0 and nullable:
+        return pa.table({n: pa.nulls(len(idx), t.schema.field(n).type) for n in t.column_names})
+    return t.take(arr)
+
+
+def with_suffix(t: pa.Table, suffix: str) -> pa.Table:
+    return t.rename_columns([f"{n}{suffix}" for n in t.column_names])
+
+
+def hconcat(*tables: pa.Table) -> pa.Table:
+    cols, names = [], []
+    for t in tables:
+        cols.extend(t.columns)
+        names.extend(t.column_names)
+    return pa.Table.from_arrays(cols, names=names)
+
+
+def from_arrow(t: pa.Table, output_type: str, zero_based: bool):
+    """Arrow result -> the requested output kind, coordinate-system metadata attached
+    (reference: range_op_helpers.py:36-53 ``_set_result_metadata``)."""
+    from ._metadata import set_coordinate_system
+    if output_type == "pyarrow.Table":
+        return set_coordinate_system(t, zero_based)
+    if output_type == "pandas.DataFrame":
+        if pd is None:
+            raise ImportError("pandas is not installed. Install pandas or use `polars-bio[pandas]`.")
+        return set_coordinate_system(t.to_pandas(), zero_based)
+    if output_type in ("polars.DataFrame", "polars.LazyFrame"):
+        if pl is None:
+            raise ImportError("polars is not installed in this environment; use output_type='pandas.DataFrame' "
+                              "or 'pyarrow.Table'")
+        df = pl.from_arrow(t)
+        if output_type == "polars.LazyFrame":
+            df = df.lazy()
+        return set_coordinate_system(df, zero_based)
+    if output_type == "datafusion.DataFrame":
+        raise ImportError("datafusion is not part of this engine; use 'pyarrow.Table', 'pandas.DataFrame' or polars")
+    raise ValueError("Only polars.LazyFrame, polars.DataFrame and pandas.DataFrame are supported")

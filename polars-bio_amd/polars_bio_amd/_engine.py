@@ -1,0 +1,298 @@
+"""ctypes binding of libivjoin_hip.so (include/ivjoin.h).
+
+This is the only place the package touches the native library.  There is no
+CPU fallback: if the library is missing or no MI355X is usable the engine
+raises -- it never routes through the oracle or numpy.
+
+Replaces the reference's PyO3 entry point
+``polars_bio.polars_bio.range_operation_frame`` (/root/reference/src/lib.rs:79-145).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libivjoin_hip.so")
+
+FILTER_WEAK = 0    # FilterOp.Weak   (1-based closed)    src/option.rs:95-100
+FILTER_STRICT = 1  # FilterOp.Strict (0-based half-open)
+
+# every symbol include/ivjoin.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "ivj_last_error", "ivj_version", "ivj_device_count", "ivj_ctx_create", "ivj_ctx_destroy",
+    "ivj_ctx_set_stream", "ivj_ctx_sync", "ivj_ctx_enable_timing", "ivj_ctx_get_timings",
+    "ivj_overlap", "ivj_pairs_free", "ivj_count_overlaps", "ivj_nearest",
+    "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev",
+    "ivj_count_overlaps_dev", "ivj_nearest_dev",
+    "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
+]
+
+
+class EngineError(RuntimeError):
+    """HIP / engine failure (the reference surfaces these as PanicException)."""
+
+
+class _Side(C.Structure):
+    _fields_ = [("contig", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p), ("n", C.c_int64),
+                ("row_id", C.c_void_p)]
+
+
+class _Opts(C.Structure):
+    _fields_ = [("filter_op", C.c_int32), ("n_contigs", C.c_int32), ("nearest_k", C.c_int32),
+                ("include_overlaps", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class _Pairs(C.Structure):
+    _fields_ = [("n_pairs", C.c_int64), ("probe_idx", C.POINTER(C.c_int32)), ("build_idx", C.POINTER(C.c_int32))]
+
+
+class _Timing(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int32), ("ms", C.c_float)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree HIP library; raise loudly when it is absent."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        P, O = C.POINTER(_Side), C.POINTER(_Opts)
+        vp = C.c_void_p
+        L.ivj_last_error.restype = C.c_char_p
+        L.ivj_version.restype = C.c_char_p
+        L.ivj_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.ivj_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.ivj_ctx_destroy.argtypes = [vp]
+        L.ivj_ctx_destroy.restype = None
+        L.ivj_ctx_set_stream.argtypes = [vp, vp]
+        L.ivj_ctx_sync.argtypes = [vp]
+        L.ivj_ctx_enable_timing.argtypes = [vp, C.c_int]
+        L.ivj_ctx_get_timings.argtypes = [vp, C.POINTER(_Timing), C.c_int, C.POINTER(C.c_int)]
+        L.ivj_overlap.argtypes = [vp, P, P, O, C.POINTER(_Pairs)]
+        L.ivj_pairs_free.argtypes = [C.POINTER(_Pairs)]
+        L.ivj_pairs_free.restype = None
+        L.ivj_count_overlaps.argtypes = [vp, P, P, O, vp]
+        L.ivj_nearest.argtypes = [vp, P, P, O, vp, vp, vp]
+        L.ivj_index_build_dev.argtypes = [vp, P, O, C.c_int, C.POINTER(vp)]
+        L.ivj_index_free.argtypes = [vp]
+        L.ivj_index_free.restype = None
+        L.ivj_overlap_count_dev.argtypes = [vp, vp, P, O, C.POINTER(C.c_int64)]
+        L.ivj_overlap_fill_dev.argtypes = [vp, vp, P, O, vp, vp, C.c_int64]
+        L.ivj_count_overlaps_dev.argtypes = [vp, vp, P, O, vp]
+        L.ivj_nearest_dev.argtypes = [vp, vp, P, O, vp, vp, vp]
+        L.ivj_dev_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
+        L.ivj_dev_free.argtypes = [vp, vp]
+        L.ivj_memcpy_h2d.argtypes = [vp, vp, vp, C.c_int64]
+        L.ivj_memcpy_d2h.argtypes = [vp, vp, vp, C.c_int64]
+        _lib = L
+        return L
+
+
+def _check(L, rc: int, what: str):
+    if rc != 0:
+        msg = L.ivj_last_error()
+        raise EngineError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def device_count() -> int:
+    L = load_library()
+    n = C.c_int(0)
+    rc = L.ivj_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _i32(a) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != np.int32 or not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a, dtype=np.int32)
+    return a
+
+
+def _host_side(contig, start, end) -> Tuple[_Side, tuple]:
+    c, s, e = _i32(contig), _i32(start), _i32(end)
+    if not (c.shape == s.shape == e.shape and c.ndim == 1):
+        raise ValueError("contig/start/end must be 1-D arrays of equal length")
+    return _Side(c.ctypes.data, s.ctypes.data, e.ctypes.data, c.shape[0], None), (c, s, e)
+
+
+def make_opts(strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True) -> _Opts:
+    o = _Opts()
+    o.filter_op = FILTER_STRICT if strict else FILTER_WEAK
+    o.n_contigs = int(n_contigs)
+    o.nearest_k = int(k)
+    o.include_overlaps = 1 if include_overlaps else 0
+    return o
+
+
+class DeviceIndex:
+    """Sorted build side resident in HBM (ivj_index)."""
+
+    def __init__(self, engine: "Engine", handle: int, n: int):
+        self.engine, self.handle, self.n = engine, handle, n
+
+    def close(self):
+        if self.handle:
+            self.engine.L.ivj_index_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One HIP device + stream + scratch arena (ivj_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L, self.L.ivj_ctx_create(int(device), C.byref(h)), "ivj_ctx_create")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ivj_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer entry points (numpy in, numpy out) --------------------
+    def overlap(self, probe, build, strict: bool, n_contigs: int):
+        """probe/build: (contig_id, start, end) int32 arrays -> (probe_idx, build_idx)."""
+        ps, keep_p = _host_side(*probe)
+        bs, keep_b = _host_side(*build)
+        o = make_opts(strict, n_contigs)
+        out = _Pairs()
+        _check(self.L, self.L.ivj_overlap(self.h, C.byref(ps), C.byref(bs), C.byref(o), C.byref(out)), "ivj_overlap")
+        try:
+            n = out.n_pairs
+            if n == 0:
+                return np.empty(0, np.int32), np.empty(0, np.int32)
+            p = np.ctypeslib.as_array(out.probe_idx, shape=(n,)).copy()
+            b = np.ctypeslib.as_array(out.build_idx, shape=(n,)).copy()
+            return p, b
+        finally:
+            self.L.ivj_pairs_free(C.byref(out))
+            del keep_p, keep_b
+
+    def count_overlaps(self, probe, build, strict: bool, n_contigs: int) -> np.ndarray:
+        ps, keep_p = _host_side(*probe)
+        bs, keep_b = _host_side(*build)
+        o = make_opts(strict, n_contigs)
+        counts = np.empty(ps.n, np.int64)
+        _check(self.L, self.L.ivj_count_overlaps(self.h, C.byref(ps), C.byref(bs), C.byref(o), counts.ctypes.data),
+               "ivj_count_overlaps")
+        del keep_p, keep_b
+        return counts
+
+    def nearest(self, probe, build, strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True):
+        ps, keep_p = _host_side(*probe)
+        bs, keep_b = _host_side(*build)
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        o = make_opts(strict, n_contigs, k, include_overlaps)
+        idx = np.empty((ps.n, k), np.int32)
+        dist = np.empty((ps.n, k), np.int64)
+        nf = np.empty(ps.n, np.int32)
+        _check(self.L, self.L.ivj_nearest(self.h, C.byref(ps), C.byref(bs), C.byref(o), idx.ctypes.data,
+                                           dist.ctypes.data, nf.ctypes.data), "ivj_nearest")
+        del keep_p, keep_b
+        return idx, dist, nf
+
+    # ---- device-resident entry points (raw device pointers) -----------------
+    def set_stream(self, hip_stream: Optional[int]):
+        _check(self.L, self.L.ivj_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)), "ivj_ctx_set_stream")
+
+    def sync(self):
+        _check(self.L, self.L.ivj_ctx_sync(self.h), "ivj_ctx_sync")
+
+    def enable_timing(self, level: int = 2):
+        """0 off, 1 probe kernels only, 2 every kernel (HIP events on the launch stream)."""
+        _check(self.L, self.L.ivj_ctx_enable_timing(self.h, int(level)), "ivj_ctx_enable_timing")
+
+    def timings(self) -> dict:
+        arr = (_Timing * 64)()
+        n = C.c_int(0)
+        _check(self.L, self.L.ivj_ctx_get_timings(self.h, arr, 64, C.byref(n)), "ivj_ctx_get_timings")
+        return {arr[i].name.decode(): {"launches": arr[i].launches, "ms": arr[i].ms} for i in range(min(n.value, 64))}
+
+    @staticmethod
+    def dev_side(contig_ptr: int, start_ptr: int, end_ptr: int, n: int, row_id_ptr: int = 0) -> _Side:
+        return _Side(contig_ptr or None, start_ptr or None, end_ptr or None, n, row_id_ptr or None)
+
+    def index_build_dev(self, build: _Side, opts: _Opts, with_end_order: bool = False) -> DeviceIndex:
+        h = C.c_void_p()
+        _check(self.L, self.L.ivj_index_build_dev(self.h, C.byref(build), C.byref(opts), int(with_end_order), C.byref(h)),
+               "ivj_index_build_dev")
+        return DeviceIndex(self, h, build.n)
+
+    def overlap_count_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts) -> int:
+        n = C.c_int64(0)
+        _check(self.L, self.L.ivj_overlap_count_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), C.byref(n)),
+               "ivj_overlap_count_dev")
+        return n.value
+
+    def overlap_fill_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, probe_idx_ptr: int, build_idx_ptr: int,
+                         capacity: int):
+        _check(self.L, self.L.ivj_overlap_fill_dev(self.h, ix.handle, C.byref(probe), C.byref(opts),
+                                                    C.c_void_p(probe_idx_ptr), C.c_void_p(build_idx_ptr), capacity),
+               "ivj_overlap_fill_dev")
+
+    def count_overlaps_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, counts_ptr: int):
+        _check(self.L, self.L.ivj_count_overlaps_dev(self.h, ix.handle, C.byref(probe), C.byref(opts),
+                                                      C.c_void_p(counts_ptr)), "ivj_count_overlaps_dev")
+
+    def nearest_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, idx_ptr: int, dist_ptr: int, nf_ptr: int):
+        _check(self.L, self.L.ivj_nearest_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), C.c_void_p(idx_ptr),
+                                               C.c_void_p(dist_ptr), C.c_void_p(nf_ptr)), "ivj_nearest_dev")
+
+    # ---- raw device memory (callers without torch) --------------------------
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        _check(self.L, self.L.ivj_dev_alloc(self.h, nbytes, C.byref(p)), "ivj_dev_alloc")
+        return p.value or 0
+
+    def dev_free(self, ptr: int):
+        _check(self.L, self.L.ivj_dev_free(self.h, C.c_void_p(ptr)), "ivj_dev_free")
+
+    def h2d(self, dst_ptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        _check(self.L, self.L.ivj_memcpy_h2d(self.h, C.c_void_p(dst_ptr), arr.ctypes.data, arr.nbytes), "ivj_memcpy_h2d")
+
+    def d2h(self, arr: np.ndarray, src_ptr: int):
+        assert arr.flags.c_contiguous
+        _check(self.L, self.L.ivj_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(src_ptr), arr.nbytes), "ivj_memcpy_d2h")
+
+
+_default_engine: Optional[Engine] = None
+_default_lock = threading.Lock()
+
+
+def default_engine() -> Engine:
+    """Process-wide engine on device LOCAL_RANK (or 0)."""
+    global _default_engine
+    with _default_lock:
+        if _default_engine is None:
+            _default_engine = Engine(int(os.environ.get("LOCAL_RANK", "0")))
+        return _default_engine

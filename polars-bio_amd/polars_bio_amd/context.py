@@ -1,0 +1,50 @@
+"""String key/value option store (reference: polars_bio/context.py:29-69,
+src/context.rs:35-54).  Only the keys that reach the range-operation hot path
+have an effect; the rest are stored and returned verbatim."""
+from __future__ import annotations
+
+import numbers
+import threading
+
+from .constants import POLARS_BIO_COORDINATE_SYSTEM_CHECK, POLARS_BIO_COORDINATE_SYSTEM_ZERO_BASED
+
+
+class Context:
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._opts = {
+            # reference defaults: polars_bio/context.py:33-50
+            "datafusion.execution.target_partitions": "1",
+            "datafusion.execution.batch_size": "8192",
+            POLARS_BIO_COORDINATE_SYSTEM_ZERO_BASED: "false",
+            POLARS_BIO_COORDINATE_SYSTEM_CHECK: "false",
+            "bio.interval_join_algorithm": "hip",
+            # engine options of this implementation
+            "ivj.device": "0",
+        }
+
+    def set_option(self, key, value):
+        if isinstance(value, bool):
+            value = "true" if value else "false"
+        elif isinstance(value, numbers.Number):
+            value = str(value)
+        with self._lock:
+            self._opts[key] = value
+
+    def get_option(self, key):
+        with self._lock:
+            return self._opts.get(key)
+
+    def sync_options(self):  # kept for call-shape parity (range_op_helpers.py:181)
+        return None
+
+
+ctx = Context()
+
+
+def set_option(key, value):
+    ctx.set_option(key, value)
+
+
+def get_option(key):
+    return ctx.get_option(key)

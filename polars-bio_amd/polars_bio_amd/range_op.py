@@ -1,0 +1,178 @@
+"""pb.overlap / pb.nearest / pb.count_overlaps on the MI355X engine.
+
+Same names, argument meaning and error behaviour as the reference's
+``IntervalOperations`` (/root/reference/polars_bio/range_op.py:117-256, 259-340,
+418-511) and its dispatcher ``range_operation``
+(/root/reference/polars_bio/range_op_helpers.py:171-376); the executor behind
+them is libivjoin_hip.so instead of DataFusion's IntervalJoinExec + COITrees.
+
+Side roles: probe = df1, build = df2 for all three
+operations -- i.e. the state after the reference's swaps in range_op.py:511
+(count_overlaps) and src/operation.rs:143-158 (nearest).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Literal, Union
+
+import numpy as np
+import pyarrow as pa
+
+from . import _arrow as A
+from ._engine import default_engine
+from ._metadata import validate_coordinate_systems
+from .constants import DEFAULT_INTERVAL_COLUMNS
+
+logger = logging.getLogger("polars_bio_amd")
+
+__all__ = ["overlap", "nearest", "count_overlaps", "FilterOp", "RangeOp", "OverlapOutputMode"]
+
+
+class FilterOp:      # src/option.rs:95-100
+    Weak = 0
+    Strict = 1
+
+
+class RangeOp:       # src/option.rs:102-112 (hot-path members only)
+    Overlap = 0
+    Nearest = 3
+    CountOverlapsNaive = 6
+
+
+class OverlapOutputMode:  # src/option.rs:87-92
+    Join = 0
+    Left = 1
+
+
+def _parse_overlap_output_mode(overlap_output: str) -> int:
+    normalized = overlap_output.lower()
+    if normalized == "join":
+        return OverlapOutputMode.Join
+    if normalized == "left":
+        return OverlapOutputMode.Left
+    raise ValueError("overlap_output must be either 'join' or 'left'")
+
+
+def _validate_overlap_input(col1, col2, on_cols, suffixes, output_type):
+    # reference: range_op_helpers.py:379-399
+    assert on_cols is None, "on_cols is not supported yet"
+    assert output_type in A.OUTPUT_TYPES, (
+        "Only polars.LazyFrame, polars.DataFrame and pandas DataFrame are supported")
+
+
+def _prepare(df1, df2, cols1, cols2):
+    cols1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
+    cols2 = list(DEFAULT_INTERVAL_COLUMNS if cols2 is None else cols2)
+    t1, t2 = A.to_arrow(df1), A.to_arrow(df2)
+    probe, build, n_contigs = A.encode_keys(t1, cols1, t2, cols2)
+    return t1, t2, probe, build, n_contigs
+
+
+def overlap(
+    df1,
+    df2,
+    suffixes: tuple = ("_1", "_2"),
+    on_cols: Union[list, None] = None,
+    cols1: Union[list, None] = ["chrom", "start", "end"],
+    cols2: Union[list, None] = ["chrom", "start", "end"],
+    algorithm: str = "Coitrees",
+    low_memory: bool = False,
+    overlap_output: Literal["join", "left"] = "join",
+    distinct_output: bool = False,
+    output_type: str = "polars.LazyFrame",
+    read_options1=None,
+    read_options2=None,
+    projection_pushdown: bool = True,
+):
+    """Find pairs of overlapping genomic intervals (reference: range_op.py:117-256).
+
+    ``algorithm`` / ``low_memory`` are accepted for call compatibility; the result is
+    algorithm-invariant in the reference (tests/test_overlap_algorithms.py:128-171) and the
+    HIP engine is always used.  Output: every df1 column + suffixes[0], then every df2
+    column + suffixes[1] (src/operation.rs:277-292); ``overlap_output="left"`` returns df1
+    columns only, one row per matching pair, or once per df1 row with ``distinct_output``
+    (src/operation.rs:224-233, 294-298)."""
+    _validate_overlap_input(cols1, cols2, on_cols, suffixes, output_type)
+    zero_based = validate_coordinate_systems(df1, df2)
+    mode = _parse_overlap_output_mode(overlap_output)
+    logger.info("Optimizing into IntervalJoinExec using %s algorithm (executed by the HIP engine)", algorithm)
+    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    p_idx, b_idx = default_engine().overlap(probe, build, strict=zero_based, n_contigs=n_contigs)
+    if mode == OverlapOutputMode.Left:
+        if distinct_output:
+            p_idx = np.unique(p_idx)
+        res = A.take_rows(t1, p_idx)
+    else:
+        res = A.hconcat(A.with_suffix(A.take_rows(t1, p_idx), suffixes[0]),
+                        A.with_suffix(A.take_rows(t2, b_idx), suffixes[1]))
+    return A.from_arrow(res, output_type, zero_based)
+
+
+def nearest(
+    df1,
+    df2,
+    suffixes: tuple = ("_1", "_2"),
+    on_cols: Union[list, None] = None,
+    cols1: Union[list, None] = ["chrom", "start", "end"],
+    cols2: Union[list, None] = ["chrom", "start", "end"],
+    k: int = 1,
+    overlap: bool = True,
+    distance: bool = True,
+    output_type: str = "polars.LazyFrame",
+    read_options=None,
+    projection_pushdown: bool = True,
+):
+    """Find the k closest df2 intervals of every df1 interval (reference: range_op.py:259-340;
+    column order df1+suffix[0], df2+suffix[1], distance: src/operation.rs:170-197).
+
+    A df1 row with no candidate on its contig yields one row with null df2 columns and a null
+    distance (unpinned in the reference; tests/test_native.py:133-140 drops such rows)."""
+    _validate_overlap_input(cols1, cols2, on_cols, suffixes, output_type)
+    zero_based = validate_coordinate_systems(df1, df2)
+    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    idx, dist, nf = default_engine().nearest(probe, build, strict=zero_based, n_contigs=n_contigs, k=int(k),
+                                             include_overlaps=bool(overlap))
+    n1 = t1.num_rows
+    # one output row per filled slot; rows without any candidate keep a single null slot
+    slots = np.maximum(nf, 1)
+    rep = np.repeat(np.arange(n1, dtype=np.int32), slots)
+    first = np.cumsum(slots) - slots
+    within = np.arange(rep.shape[0], dtype=np.int64) - np.repeat(first, slots)
+    b_sel = idx[rep, within] if n1 else np.empty(0, np.int32)
+    d_sel = dist[rep, within] if n1 else np.empty(0, np.int64)
+    parts = [A.with_suffix(A.take_rows(t1, rep), suffixes[0]),
+             A.with_suffix(A.take_rows(t2, b_sel, nullable=True), suffixes[1])]
+    res = A.hconcat(*parts)
+    if distance:
+        res = res.append_column("distance", pa.array(d_sel, type=pa.int64(), mask=(b_sel < 0)))
+    return A.from_arrow(res, output_type, zero_based)
+
+
+def count_overlaps(
+    df1,
+    df2,
+    suffixes: tuple = ("", "_"),
+    cols1: Union[list, None] = ["chrom", "start", "end"],
+    cols2: Union[list, None] = ["chrom", "start", "end"],
+    on_cols: Union[list, None] = None,
+    output_type: str = "polars.LazyFrame",
+    naive_query: bool = True,
+    projection_pushdown: bool = True,
+):
+    """Count the df2 intervals overlapping every df1 interval (reference: range_op.py:418-597).
+    Output = df1 columns + ``count`` (Int64), df1 row order kept
+    (tests/test_coordinate_system_metadata.py:1504-1506).  ``naive_query=False`` selects the
+    reference's SQL sweep (range_op.py:512-597), which computes the same two-rank formula the
+    device kernel uses; both values run the same kernel here, the sweep's output naming
+    (key columns + suffixes[0]) is honoured."""
+    _validate_overlap_input(cols1, cols2, on_cols, suffixes, output_type)
+    zero_based = validate_coordinate_systems(df1, df2)
+    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    counts = default_engine().count_overlaps(probe, build, strict=zero_based, n_contigs=n_contigs)
+    if naive_query:
+        res = t1.append_column("count", pa.array(counts, type=pa.int64()))
+    else:
+        c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
+        res = pa.table({f"{c}{suffixes[0]}": t1.column(c) for c in c1})
+        res = res.append_column("count", pa.array(counts, type=pa.int64()))
+    return A.from_arrow(res, output_type, zero_based)

@@ -48,3 +48,24 @@ def random_side(rng, n, n_contigs, span, max_len, zero_len_frac=0.05, dup_frac=0
         src = rng.integers(0, n, n)
         c[d], s[d], e[d] = c[src[d]], s[src[d]], e[src[d]]
     return c, s, e
+
+
+class OracleEngine:
+    """Test double with the Engine host API, backed by the CPU oracle.  Lets the
+    CPU suite exercise the front end's host logic (key encoding, result assembly,
+    metadata) without a GPU.  Never used by the product path."""
+
+    def overlap(self, probe, build, strict, n_contigs):
+        from oracle import oracle as O
+        b = O.Side(*build)
+        return O.overlap_fast(O.Index(b, n_contigs), O.Side(*probe), strict)
+
+    def count_overlaps(self, probe, build, strict, n_contigs):
+        from oracle import oracle as O
+        b = O.Side(*build)
+        return O.count_overlaps_fast(O.Index(b, n_contigs), O.Side(*probe), strict)
+
+    def nearest(self, probe, build, strict, n_contigs, k=1, include_overlaps=True):
+        from oracle import oracle as O
+        b = O.Side(*build)
+        return O.nearest_fast(O.Index(b, n_contigs), O.Side(*probe), strict, k, include_overlaps)

@@ -1,0 +1,201 @@
+"""Front-end tests shaped like the reference's own range-op tests
+(tests/test_pandas.py, tests/test_native.py, tests/test_coordinate_system_metadata.py,
+tests/test_overlap_output_mode.py, tests/test_suffix_handling.py).
+
+Every test runs twice:
+  * ``cpu``  -- the front end's host logic with the engine replaced by an oracle-backed
+                test double (no GPU needed; checks key encoding, result assembly, metadata);
+  * ``gpu``  -- the real HIP engine through the C ABI (marked ``gpu``).
+"""
+import warnings
+
+import numpy as np
+import pandas as pd
+import pyarrow as pa
+import pytest
+
+import polars_bio_amd as pb
+from polars_bio_amd import range_op
+from _util import GOLDEN, OracleEngine, load_cases
+
+COLS = ("contig", "pos_start", "pos_end")
+
+
+@pytest.fixture(params=["cpu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def engine(request, monkeypatch):
+    if request.param == "cpu":
+        monkeypatch.setattr(range_op, "default_engine", lambda: OracleEngine())
+    return request.param
+
+
+def _csv(path, zero_based=False):
+    df = pd.read_csv(path)
+    df.attrs["coordinate_system_zero_based"] = zero_based
+    return df
+
+
+def _sorted(df):
+    return df.sort_values(by=list(df.columns)).reset_index(drop=True)
+
+
+def _frame(d, zero_based, dtype=None):
+    df = pd.DataFrame(d)
+    if dtype:
+        df["start"] = df["start"].astype(dtype)
+        df["end"] = df["end"].astype(dtype)
+    df.attrs["coordinate_system_zero_based"] = zero_based
+    return df
+
+
+# ---- golden tables (tests/_expected.py via tests/test_pandas.py:33-107) ----
+
+def test_overlap_golden(engine):
+    res = pb.overlap(_csv(f"{GOLDEN}/overlap/reads.csv"), _csv(f"{GOLDEN}/overlap/targets.csv"),
+                     cols1=COLS, cols2=COLS, output_type="pandas.DataFrame")
+    exp = pd.read_csv(f"{GOLDEN}/expected_overlap.csv")
+    assert len(res) == 16
+    pd.testing.assert_frame_equal(_sorted(res), _sorted(exp))
+    assert res.attrs["coordinate_system_zero_based"] is False
+
+
+def test_nearest_golden(engine):
+    res = pb.nearest(_csv(f"{GOLDEN}/nearest/targets.csv"), _csv(f"{GOLDEN}/nearest/reads.csv"),
+                     cols1=COLS, cols2=COLS, output_type="pandas.DataFrame")
+    exp = pd.read_csv(f"{GOLDEN}/expected_nearest.csv")
+    pd.testing.assert_frame_equal(_sorted(res), _sorted(exp))
+
+
+@pytest.mark.parametrize("naive", [True, False])
+def test_count_overlaps_golden(engine, naive):
+    res = pb.count_overlaps(_csv(f"{GOLDEN}/count_overlaps/targets.csv"), _csv(f"{GOLDEN}/count_overlaps/reads.csv"),
+                            cols1=COLS, cols2=COLS, output_type="pandas.DataFrame", naive_query=naive)
+    exp = pd.read_csv(f"{GOLDEN}/expected_count_overlaps.csv")
+    pd.testing.assert_frame_equal(_sorted(res), _sorted(exp))
+
+
+def test_nearest_k2_no_overlap_no_distance(engine):
+    # tests/test_native.py:78-180 (shape-level properties only: the values are unpinned)
+    df1, df2 = _csv(f"{GOLDEN}/nearest/targets.csv"), _csv(f"{GOLDEN}/nearest/reads.csv")
+    k2 = pb.nearest(df1, df2, cols1=COLS, cols2=COLS, k=2, output_type="pandas.DataFrame")
+    assert len(k2) >= 11
+    assert k2.groupby(["contig_1", "pos_start_1", "pos_end_1"]).size().max() <= 2
+    assert set(k2.columns) == {"contig_1", "pos_start_1", "pos_end_1", "contig_2", "pos_start_2", "pos_end_2", "distance"}
+    no = pb.nearest(df1, df2, cols1=COLS, cols2=COLS, overlap=False, output_type="pandas.DataFrame")
+    valid = no.dropna(subset=["distance"])
+    assert len(valid) > 0 and (valid["distance"] > 0).all()
+    nd = pb.nearest(df1, df2, cols1=COLS, cols2=COLS, distance=False, output_type="pandas.DataFrame")
+    assert "distance" not in nd.columns and len(nd) == 11
+
+
+# ---- boundary semantics (tests/test_coordinate_system_metadata.py:738-819, 1172-1191, 1482-1506) ----
+
+@pytest.mark.parametrize("case", load_cases()["boundary_overlap"], ids=lambda c: c["name"])
+def test_boundary_overlap(engine, case):
+    res = pb.overlap(_frame(case["df1"], case["zero_based"]), _frame(case["df2"], case["zero_based"]),
+                     output_type="pandas.DataFrame")
+    assert len(res) == case["n_pairs"]
+
+
+@pytest.mark.parametrize("case", load_cases()["boundary_count"], ids=lambda c: c["name"])
+def test_boundary_count(engine, case):
+    dt = case.get("dtype")
+    res = pb.count_overlaps(_frame(case["df1"], case["zero_based"], dt), _frame(case["df2"], case["zero_based"], dt),
+                            output_type="pandas.DataFrame")
+    assert res["count"].tolist() == case["counts"]
+    assert res["count"].dtype == np.int64
+    assert list(res.columns) == ["chrom", "start", "end", "count"]
+
+
+def test_tutorial_example(engine):
+    t = load_cases()["tutorial"]
+    df1, df2 = _frame(t["df1"], False), _frame(t["df2"], False)
+    ov = pb.overlap(df1, df2, output_type="pandas.DataFrame")
+    assert sorted(ov[["start_1", "end_1", "start_2", "end_2"]].values.tolist()) == sorted(t["overlap"])
+    nn = pb.nearest(df1, df2, output_type="pandas.DataFrame")
+    assert nn[["start_1", "end_1", "start_2", "end_2", "distance"]].values.tolist() == t["nearest"]
+    assert pb.count_overlaps(df1, df2, output_type="pandas.DataFrame")["count"].tolist() == t["count"]
+
+
+# ---- output modes (tests/test_overlap_output_mode.py:99-197) ----
+
+def test_overlap_output_modes(engine):
+    t = load_cases()["output_mode"]
+    df1, df2 = _frame(t["df1"], True), _frame(t["df2"], True)
+    by = ["chrom", "start", "end", "name"]
+    left = pb.overlap(df1, df2, overlap_output="left", output_type="pandas.DataFrame")
+    assert list(left.columns) == by
+    pd.testing.assert_frame_equal(left.sort_values(by).reset_index(drop=True),
+                                  pd.DataFrame(t["left"]).sort_values(by).reset_index(drop=True))
+    assert left.attrs["coordinate_system_zero_based"] is True
+    dist = pb.overlap(df1, df2, overlap_output="left", distinct_output=True, output_type="pandas.DataFrame")
+    pd.testing.assert_frame_equal(dist.sort_values(by).reset_index(drop=True),
+                                  pd.DataFrame(t["left_distinct"]).sort_values(by).reset_index(drop=True))
+    join = pb.overlap(df1, df2, output_type="pandas.DataFrame")
+    for c in ("chrom_1", "chrom_2", "score_2", "name_1"):
+        assert c in join.columns
+    with pytest.raises(ValueError, match="overlap_output"):
+        pb.overlap(df1, df2, overlap_output="semi", output_type="pandas.DataFrame")
+
+
+# ---- suffixes, extra columns, dtypes, input kinds ----
+
+def test_suffixes_extra_columns_and_dtypes(engine):
+    df1 = pd.DataFrame({"chrom": ["chr1", "chr1", "chr2"], "start": np.array([10, 50, 10], np.int32),
+                        "end": np.array([20, 60, 20], np.int32), "score": [0.5, 1.5, 2.5], "tag": ["a", "b", "c"]})
+    df2 = pd.DataFrame({"chrom": ["chr1", "chr2", "chr9"], "start": np.array([15, 0, 0], np.int64),
+                        "end": np.array([55, 100, 5], np.int64), "gene": ["g1", "g2", "g3"]})
+    df1.attrs["coordinate_system_zero_based"] = True
+    df2.attrs["coordinate_system_zero_based"] = True
+    res = pb.overlap(df1, df2, suffixes=("_a", "_b"), output_type="pandas.DataFrame")
+    assert list(res.columns) == ["chrom_a", "start_a", "end_a", "score_a", "tag_a", "chrom_b", "start_b", "end_b", "gene_b"]
+    assert res["start_a"].dtype == np.int32 and res["start_b"].dtype == np.int64   # source dtypes kept
+    got = sorted(zip(res["tag_a"], res["gene_b"]))
+    assert got == [("a", "g1"), ("b", "g1"), ("c", "g2")]
+    tab = pb.overlap(pa.Table.from_pandas(df1).replace_schema_metadata({b"coordinate_system_zero_based": b"true"}),
+                     df2, output_type="pyarrow.Table")
+    assert tab.num_rows == 3 and tab.schema.metadata[b"coordinate_system_zero_based"] == b"true"
+
+
+def test_nearest_absent_contig_gives_null_row(engine):
+    df1 = _frame({"chrom": ["chr1", "chrZ"], "start": [10, 10], "end": [20, 20]}, True)
+    df2 = _frame({"chrom": ["chr1"], "start": [100], "end": [200]}, True)
+    res = pb.nearest(df1, df2, output_type="pandas.DataFrame")
+    assert len(res) == 2
+    assert res["distance"].iloc[0] == 80 and pd.isna(res["distance"].iloc[1]) and pd.isna(res["chrom_2"].iloc[1])
+
+
+def test_empty_inputs(engine):
+    e = _frame({"chrom": [], "start": [], "end": []}, True).astype({"chrom": str, "start": np.int64, "end": np.int64})
+    e.attrs["coordinate_system_zero_based"] = True
+    one = _frame({"chrom": ["chr1"], "start": [1], "end": [5]}, True)
+    assert len(pb.overlap(e, one, output_type="pandas.DataFrame")) == 0
+    assert len(pb.overlap(one, e, output_type="pandas.DataFrame")) == 0
+    assert pb.count_overlaps(one, e, output_type="pandas.DataFrame")["count"].tolist() == [0]
+    assert len(pb.nearest(one, e, output_type="pandas.DataFrame")) == 1
+
+
+# ---- validation / errors (range_op_helpers.py:379-399, _metadata.py:267-362) ----
+
+def test_validation_errors(engine):
+    a = _frame({"chrom": ["chr1"], "start": [100], "end": [200]}, True)
+    b = _frame({"chrom": ["chr1"], "start": [150], "end": [250]}, False)
+    with pytest.raises(pb.CoordinateSystemMismatchError):
+        pb.overlap(a, b, output_type="pandas.DataFrame")
+    with pytest.raises(AssertionError):
+        pb.overlap(a, a, on_cols=["x"], output_type="pandas.DataFrame")
+    with pytest.raises(AssertionError):
+        pb.overlap(a, a, output_type="numpy")
+    big = _frame({"chrom": ["chr1"], "start": [1], "end": [2 ** 31]}, True)
+    with pytest.raises(ValueError, match="int32"):
+        pb.overlap(big, a, output_type="pandas.DataFrame")
+    nometa = pd.DataFrame({"chrom": ["chr1"], "start": [100], "end": [200]})
+    pb.set_option("datafusion.bio.coordinate_system_check", True)
+    try:
+        with pytest.raises(pb.MissingCoordinateSystemError):
+            pb.overlap(nometa, a, output_type="pandas.DataFrame")
+    finally:
+        pb.set_option("datafusion.bio.coordinate_system_check", False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        r = pb.overlap(nometa, nometa.copy(), output_type="pandas.DataFrame")   # falls back to 1-based
+        assert len(r) == 1 and any("Coordinate system metadata is missing" in str(x.message) for x in w)

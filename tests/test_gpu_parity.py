@@ -1,0 +1,211 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI (libivjoin_hip.so).
+
+Bit-exact bar: integer index work -- pairs, counts, nearest rows and distances must be
+identical, including output order (probe row, then (build.start, build row)).
+All tests need a real MI355X (-m gpu).
+"""
+import numpy as np
+import pytest
+
+from _util import load_parquet_intervals, random_side
+from oracle import oracle as O
+from polars_bio_amd import _engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return _engine.Engine(0)
+
+
+def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1, True), (1, False), (3, True), (4, False))):
+    ps, bs = O.Side(*probe), O.Side(*build)
+    ix = O.Index(bs, n_contigs)
+    p, b = eng.overlap(probe, build, strict, n_contigs)
+    ep, eb = (O.overlap_brute(ps, bs, strict) if brute else O.overlap_fast(ix, ps, strict))
+    assert len(p) == len(ep), (len(p), len(ep))
+    assert (p == ep).all() and (b == eb).all()
+    c = eng.count_overlaps(probe, build, strict, n_contigs)
+    ec = O.count_overlaps_brute(ps, bs, strict) if brute else O.count_overlaps_fast(ix, ps, strict)
+    assert (c == ec).all()
+    for k, inc in nearest_cfgs:
+        i, d, n = eng.nearest(probe, build, strict, n_contigs, k, inc)
+        ei, ed, en = (O.nearest_brute(ps, bs, strict, k, inc) if brute else O.nearest_fast(ix, ps, strict, k, inc))
+        assert (n == en).all(), (k, inc)
+        assert (d == ed).all(), (k, inc)
+        assert (i == ei).all(), (k, inc)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("seed", range(8))
+def test_random_small_vs_brute(eng, seed, strict):
+    rng = np.random.default_rng(2000 + seed)
+    n_contigs = int(rng.integers(1, 5))
+    span = int(rng.choice([40, 400, 100000]))
+    max_len = int(rng.choice([3, 30, 300]))
+    probe = random_side(rng, int(rng.integers(1, 400)), n_contigs + 1, span, max_len)
+    build = random_side(rng, int(rng.integers(1, 400)), n_contigs, span, max_len)
+    _cmp_all(eng, probe, build, n_contigs, strict, brute=True)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_random_medium_ragged_sizes(eng, strict):
+    """Sizes straddling the tile boundaries of the sort (4096) and probe (1024) kernels."""
+    rng = np.random.default_rng(77)
+    for npr, nb in ((1023, 4095), (1025, 4097), (5000, 12289), (40000, 3), (3, 40000)):
+        probe = random_side(rng, npr, 4, 200000, 500)
+        build = random_side(rng, nb, 3, 200000, 500)
+        _cmp_all(eng, probe, build, 3, strict, nearest_cfgs=((1, True), (2, False)))
+
+
+def test_many_contigs_two_digit_passes(eng):
+    """More than 256 contigs -> two radix passes over the contig id; ids outside the dictionary never match."""
+    rng = np.random.default_rng(5)
+    nc = 700
+    build = random_side(rng, 30000, nc, 5000, 100)
+    probe = random_side(rng, 20000, nc + 5, 5000, 100)
+    probe[0][:10] = -3
+    build[0][:10] = nc + 7
+    _cmp_all(eng, probe, build, nc, True, nearest_cfgs=((1, True),))
+
+
+def test_negative_coordinates_and_duplicates(eng):
+    rng = np.random.default_rng(6)
+    c = np.zeros(5000, np.int32)
+    s = rng.integers(-1000, 1000, 5000).astype(np.int32)
+    e = (s + rng.integers(0, 50, 5000)).astype(np.int32)
+    s[:2000] = 7
+    e[:2000] = 9           # 2000 identical rows: stability of the sort decides the output order
+    pc = np.zeros(3000, np.int32)
+    ps = rng.integers(-1100, 1100, 3000).astype(np.int32)
+    pe = (ps + rng.integers(0, 50, 3000)).astype(np.int32)
+    for strict in (True, False):
+        _cmp_all(eng, (pc, ps, pe), (c, s, e), 1, strict, nearest_cfgs=((1, True), (3, False)))
+
+
+def test_inverted_rows_follow_the_inequality(eng):
+    rng = np.random.default_rng(8)
+    for strict in (True, False):
+        c, s, e = random_side(rng, 3000, 2, 2000, 40)
+        f = rng.random(3000) < 0.2
+        build = (c, np.where(f, e, s).astype(np.int32), np.where(f, s, e).astype(np.int32))
+        c, s, e = random_side(rng, 3000, 2, 2000, 40)
+        f = rng.random(3000) < 0.2
+        probe = (c, np.where(f, e, s).astype(np.int32), np.where(f, s, e).astype(np.int32))
+        ps, bs = O.Side(*probe), O.Side(*build)
+        p, b = eng.overlap(probe, build, strict, 2)
+        ep, eb = O.overlap_brute(ps, bs, strict)
+        assert (p == ep).all() and (b == eb).all()
+        assert (eng.count_overlaps(probe, build, strict, 2) == O.count_overlaps_brute(ps, bs, strict)).all()
+
+
+def test_empty_and_absent(eng):
+    e = (np.empty(0, np.int32),) * 3
+    one = (np.zeros(1, np.int32), np.array([5], np.int32), np.array([9], np.int32))
+    for strict in (True, False):
+        assert len(eng.overlap(e, one, strict, 1)[0]) == 0
+        assert len(eng.overlap(one, e, strict, 1)[0]) == 0
+        assert eng.count_overlaps(one, e, strict, 1).tolist() == [0]
+        i, d, n = eng.nearest(one, e, strict, 1)
+        assert n.tolist() == [0] and i.tolist() == [[-1]] and d.tolist() == [[-1]]
+
+
+def test_real_fixture_exons_x_fbrain(eng):
+    """docs/supplement.md:108,149 -> 54,246 pairs (0-based); bit-exact against the oracle."""
+    exons = load_parquet_intervals("exons")
+    fbrain = load_parquet_intervals("fBrain-DS14718")
+    (c1, c2), n = O.encode_contigs(exons[0], fbrain[0])
+    probe = (c1, exons[1].astype(np.int32), exons[2].astype(np.int32))
+    build = (c2, fbrain[1].astype(np.int32), fbrain[2].astype(np.int32))
+    p, b = eng.overlap(probe, build, True, n)
+    assert len(p) == 54246
+    _cmp_all(eng, probe, build, n, True, nearest_cfgs=((1, True), (2, True), (1, False)))
+    assert len(eng.overlap(probe, build, False, n)[0]) == 54343
+    i, d, nf = eng.nearest(probe, build, True, n)
+    assert int(d.sum()) == 15203982135 and int((d == 0).sum()) == 51521
+
+
+def test_synthetic_2M_x_200k_exact(eng):
+    probe = synth.make_side(2_000_000, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(200_000, 43, synth.BUILD_LEN, 24)
+    _cmp_all(eng, probe, build, 24, True, nearest_cfgs=((1, True),))
+
+
+def test_dense_nested_build(eng):
+    """Long intervals nested over short ones: the backward scan must look far past non-matches."""
+    rng = np.random.default_rng(11)
+    nb = 20000
+    c = np.zeros(nb, np.int32)
+    s = rng.integers(0, 1_000_000, nb).astype(np.int32)
+    ln = rng.integers(1, 50, nb)
+    ln[rng.random(nb) < 0.01] = 500_000
+    e = (s + ln).astype(np.int32)
+    probe = (np.zeros(5000, np.int32), rng.integers(0, 1_000_000, 5000).astype(np.int32), None)
+    probe = (probe[0], probe[1], (probe[1] + 100).astype(np.int32))
+    _cmp_all(eng, probe, (c, s, e), 1, True, nearest_cfgs=((1, True), (2, False)))
+
+
+def _device_overlap(eng, probe, build, strict, n_contigs):
+    """Device-resident entry points: what bench.py times."""
+    ptrs, sides = [], []
+    for side in (probe, build):
+        n = len(side[0])
+        ps = []
+        for col in side:
+            p = eng.dev_alloc(max(4 * n, 16))
+            eng.h2d(p, np.ascontiguousarray(col, np.int32))
+            ps.append(p)
+        ptrs += ps
+        sides.append(eng.dev_side(ps[0], ps[1], ps[2], n))
+    opts = _engine.make_opts(strict, n_contigs)
+    ix = eng.index_build_dev(sides[1], opts)
+    total = eng.overlap_count_dev(ix, sides[0], opts)
+    op, ob = eng.dev_alloc(max(4 * total, 16)), eng.dev_alloc(max(4 * total, 16))
+    eng.overlap_fill_dev(ix, sides[0], opts, op, ob, total)
+    hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
+    eng.d2h(hp, op)
+    eng.d2h(hb, ob)
+    counts = np.empty(len(probe[0]), np.int64)
+    cp = eng.dev_alloc(8 * max(len(probe[0]), 2))
+    eng.count_overlaps_dev(ix, sides[0], opts, cp)
+    eng.d2h(counts, cp)
+    ix.close()
+    for p in ptrs + [op, ob, cp]:
+        eng.dev_free(p)
+    return hp, hb, counts
+
+
+def test_device_resident_api_matches_host_api(eng):
+    probe = synth.make_side(300_001, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(50_003, 43, synth.BUILD_LEN, 24)
+    hp, hb, counts = _device_overlap(eng, probe, build, True, 24)
+    p, b = eng.overlap(probe, build, True, 24)
+    assert (hp == p).all() and (hb == b).all()
+    assert (counts == np.bincount(p, minlength=len(probe[0]))).all()
+    with pytest.raises(_engine.EngineError):      # fill without a matching count
+        opts = _engine.make_opts(True, 24)
+        s = eng.dev_side(0, 0, 0, 0)
+        ix = eng.index_build_dev(s, opts)
+        eng.overlap_fill_dev(ix, eng.dev_side(16, 16, 16, 5), opts, 0, 0, 0)
+
+
+def test_full_size_config2_properties(eng):
+    """BASELINE config 2 (10M x 1M, one contig) at full size: size-independent properties.
+    P equals the oracle's count; pairs are sorted by probe row; every emitted pair satisfies the
+    predicate; per-probe multiplicities equal count_overlaps; checksum of build rows equals the
+    oracle's."""
+    probe, build, nc = synth.workload("overlap_10M_1M_1contig")
+    hp, hb, counts = _device_overlap(eng, probe, build, True, nc)
+    ps, bs = O.Side(*probe), O.Side(*build)
+    ix = O.Index(bs, nc)
+    ecounts = O.count_overlaps_fast(ix, ps, True)
+    assert len(hp) == int(ecounts.sum())
+    assert abs(len(hp) / synth.expected_pairs(10_000_000, 1_000_000, 1) - 1) < 0.02
+    assert (counts == ecounts).all()
+    assert (np.diff(hp) >= 0).all()
+    assert (np.bincount(hp, minlength=len(probe[0])) == ecounts).all()
+    assert (probe[1][hp] < build[2][hb]).all() and (build[1][hb] < probe[2][hp]).all()
+    ep, eb = O.overlap_fast(ix, ps, True)
+    assert int(hb.astype(np.int64).sum()) == int(eb.astype(np.int64).sum())
+    assert (hb == eb).all()
