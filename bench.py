@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the interval-join hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+Metric (BASELINE.json): emitted overlap-pairs/s (+ achieved HBM GB/s) of pb.overlap on the
+100M x 5M, 24-contig synthetic set (SURVEY.md section 8d generator), inputs resident in HBM
+when the timed region starts, results left in HBM.
+
+A "step" is one full pass of the hot path over the batch: device radix sort of the build side
+(index build) -> count pass -> tile scan -> fill pass.  N > 1 (launched by
+torch.distributed.run, one rank per GPU): the SAME 100M x 5M job is contig-sharded over the
+ranks (LPT), every rank joins its contigs, and the result batches are exchanged with an RCCL
+all-gatherv inside the timed region ("scaling": "strong": total work is fixed as N grows).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      -- dominant kernel: algorithmic bytes / live HIP-event kernel time vs 8 TB/s
+  cpu_baseline  -- the oracle's sort + bound-search port timed on the host cores (N=1 only),
+                   on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "polars-bio_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="overlap_100M_5M_24contig",
+                    help="overlap_100M_5M_24contig | overlap_10M_1M_1contig | overlap_100M_5M_24contig_dense | "
+                         "nearest_50M_2M_24contig | count_200M_200k_24contig")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gatherv (reported in config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the CPU-baseline sample")
+    ap.add_argument("--kernel-table", action="store_true", help="print a per-kernel HIP-event table to stderr")
+    return ap.parse_args()
+
+
+def gen_workload(name, scale):
+    from polars_bio_amd import synth
+    cfg = {
+        "overlap_1k_1k_1contig": (1_000, 1_000, 1, synth.BUILD_LEN, "overlap"),
+        "overlap_10M_1M_1contig": (10_000_000, 1_000_000, 1, synth.BUILD_LEN, "overlap"),
+        "overlap_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "overlap"),
+        "overlap_100M_5M_24contig_dense": (100_000_000, 5_000_000, 24, synth.DENSE_BUILD_LEN, "overlap"),
+        "nearest_50M_2M_24contig": (50_000_000, 2_000_000, 24, synth.BUILD_LEN, "nearest"),
+        "count_200M_200k_24contig": (200_000_000, 200_000, 24, synth.BUILD_LEN, "count_overlaps"),
+    }[name]
+    n_p, n_b, nc, blen, op = cfg
+    n_p, n_b = max(1, int(n_p * scale)), max(1, int(n_b * scale))
+    t0 = time.time()
+    probe = synth.make_side(n_p, 42, synth.PROBE_LEN, nc)
+    build = synth.make_side(n_b, 43, blen, nc)
+    log(f"[bench] generated {name}: probe {n_p:,} build {n_b:,} contigs {nc} in {time.time() - t0:.1f}s")
+    return probe, build, nc, op
+
+
+def algorithmic_bytes(op, n_p, n_b, n_out):
+    """compulsory traffic only, int32 coords and row ids; contig ids are
+    read on device, so +4 B per row of both sides."""
+    contig = 4 * (n_p + n_b)
+    if op == "overlap":
+        return 8 * n_p + 8 * n_b + 8 * n_out + contig
+    if op == "count_overlaps":
+        return 8 * n_p + 8 * n_b + 8 * n_p + contig
+    return 8 * n_p + 8 * n_b + 12 * n_p + contig      # nearest k=1
+
+
+def cpu_baseline(op, probe, build, nc, sample_rows):
+    """Oracle 'port' (sort + bound search, OpenMP) on the host cores, bounded sample."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    n = min(sample_rows, len(probe[0]))
+    ps = O.Side(probe[0][:n], probe[1][:n], probe[2][:n])
+    bs = O.Side(*build)
+    t0 = time.time()
+    ix = O.Index(bs, nc)
+    t_index = time.time() - t0
+    t0 = time.time()
+    if op == "overlap":
+        p, b = O.overlap_fast(ix, ps, True, threads=cores)
+        units = len(p)
+    elif op == "count_overlaps":
+        O.count_overlaps_fast(ix, ps, True, threads=cores)
+        units = n
+    else:
+        O.nearest_fast(ix, ps, True, 1, True, threads=cores)
+        units = n
+    t_probe = time.time() - t0
+    unit = "overlap-pairs/s" if op == "overlap" else "probe-rows/s"
+    return {"value": units / (t_index + t_probe), "unit": unit, "cores": cores, "kind": "port",
+            "sample": f"first {n:,} probe rows x full build ({len(build[0]):,} rows), index build (1 thread) "
+                      f"{t_index:.2f}s + probe ({cores} threads) {t_probe:.2f}s, {units:,} units",
+            "index_s": round(t_index, 3), "probe_s": round(t_probe, 3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}")
+    n_gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from polars_bio_amd import distributed as D
+    from polars_bio_amd.device_api import DeviceJoin, DeviceSide
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if n_gpus > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    probe, build, nc, op = gen_workload(args.workload, args.scale)
+    n_p_total, n_b_total = len(probe[0]), len(build[0])
+    if n_gpus > 1:
+        lp, lp_ids, lb, lb_ids, mode = D.shard_sides(probe, build, nc, rank, n_gpus)
+    else:
+        lp, lp_ids, lb, lb_ids, mode = probe, None, build, None, "single"
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    d_probe = DeviceSide(up(lp[0]), up(lp[1]), up(lp[2]), up(lp_ids) if lp_ids is not None else None)
+    d_build = DeviceSide(up(lb[0]), up(lb[1]), up(lb[2]), up(lb_ids) if lb_ids is not None else None)
+    join = DeviceJoin(local_rank)
+    gather = n_gpus > 1 and not args.no_gather and op == "overlap"
+
+    def step():
+        """-> (units this rank produced, result tensors)"""
+        if op == "overlap":
+            p, b = join.overlap(d_probe, d_build, True, nc)
+            local = int(p.shape[0])
+            if gather:
+                (p, b), _ = D.all_gatherv([p, b])
+            return local, (p, b)
+        if op == "count_overlaps":
+            return d_probe.n, join.count_overlaps(d_probe, d_build, True, nc)
+        return d_probe.n, join.nearest(d_probe, d_build, True, nc)
+
+    def barrier():
+        if n_gpus > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        local_units, out = step()
+    barrier()
+    join.engine.enable_timing(1)          # HIP events around the probe kernels only, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        local_units, out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = join.engine.timings()
+    join.engine.enable_timing(0)
+
+    t = torch.tensor([local_units], dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if n_gpus > 1:
+        dist.all_reduce(t)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_units = int(t.item())
+    elapsed = float(tmax.item())
+    if gather:
+        assert int(out[0].shape[0]) == total_units, "all-gatherv lost pairs"
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # dominant kernel + roofline (per launch, this rank's shard)
+    dom_name, dom = None, None
+    for k, v in ktimes.items():
+        if dom is None or v["ms"] > dom["ms"]:
+            dom_name, dom = k, v
+    alg_bytes = algorithmic_bytes(op, d_probe.n, d_build.n, local_units)
+    roofline = None
+    if dom is not None and dom["launches"] > 0:
+        avg_ms = dom["ms"] / dom["launches"]
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel_avg_ms": round(avg_ms, 4), "algorithmic_bytes": int(alg_bytes),
+                    "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in ktimes.items()}}
+
+    if args.kernel_table:
+        join.engine.enable_timing(2)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        tab = join.engine.timings()
+        join.engine.enable_timing(0)
+        log("[bench] per-kernel HIP-event table (3 steps):")
+        for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["ms"]):
+            log(f"    {k:18s} launches/step {v['launches'] / 3:6.1f}  ms/step {v['ms'] / 3:9.4f}")
+
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(op, probe, build, nc, args.cpu_sample)
+        except Exception as e:  # the baseline must never take the bench line down
+            cpu = {"error": repr(e)}
+
+    if rank == 0:
+        unit = "overlap-pairs/s" if op == "overlap" else "probe-rows/s"
+        line = {
+            "metric": "overlap-pairs/sec" if op == "overlap" else f"{op} probe-rows/sec",
+            "value": total_units / (elapsed / args.steps),
+            "unit": unit,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic" if args.scale == 1.0 else f"synthetic (scaled x{args.scale}: INVALID as a headline number)",
+            "config": {"workload": args.workload, "probe_rows": n_p_total, "build_rows": n_b_total, "contigs": nc,
+                       "filter_op": "Strict", "units_per_step": total_units,
+                       "parallelism": ("single GPU" if n_gpus == 1 else
+                                       f"{mode}-sharded x{n_gpus}, " + ("RCCL all-gatherv in timed region" if gather else "no gather")),
+                       "step": "index build (radix sort) + count + scan + fill, inputs and outputs in HBM"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if n_gpus > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,9 @@ struct ivj_ctx {
     int32_t* ov_cnt = nullptr;
     long long* ov_tile = nullptr;   // ntiles + 1: tile bases, last = total
     long long* h_total = nullptr;   // pinned
+    // one released index slab kept for reuse (bench/streaming loops rebuild the index every call)
+    char* ix_cache = nullptr;
+    size_t ix_cache_cap = 0;
     int64_t ov_total = 0;
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
@@ -94,6 +97,8 @@ struct ivj_index {
     int32_t* e_end = nullptr;
     int32_t* e_pos = nullptr;
     bool has_end_order = false;
+    char* slab = nullptr;      // single allocation holding every array above
+    size_t slab_cap = 0;
 };
 
 namespace {
@@ -240,8 +245,6 @@ int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->has_end_order) return IVJ_OK;
     const int64_t n = ix->n;
     if (n == 0) { ix->has_end_order = true; return IVJ_OK; }
-    HIP_TRY(hipMalloc((void**)&ix->e_end, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void**)&ix->e_pos, (size_t)n * 4));
     IVJ_TRY(arena_reserve(ctx, sort_scratch_bytes(n) + 4096));
     SortBufs sb; take_sort_bufs(ctx, n, sb);
     LAUNCH(ctx, "end_keys", k_end_keys, grid1d(n, 256), 256, (const int2*)ix->ep, n, sb.kA, sb.vA);
@@ -262,16 +265,29 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
     const int64_t n = build->n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     auto cleanup = [&](int code) { ivj_index_free(ix); return code; };
-#define IX_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
-    IX_HIP(hipMalloc((void**)&ix->b_start, nn * 4));
-    IX_HIP(hipMalloc((void**)&ix->ep, nn * 8));
-    IX_HIP(hipMalloc((void**)&ix->b_row, nn * 4));
-    IX_HIP(hipMalloc((void**)&ix->b_contig, nn * 4));
-    IX_HIP(hipMalloc((void**)&ix->seg, ((size_t)opts->n_contigs + 2) * 4));
-    IX_HIP(hipMalloc((void**)&ix->flags, 16));
-    IX_HIP(hipMemsetAsync(ix->seg, 0, ((size_t)opts->n_contigs + 2) * 4, ctx->stream));
-    IX_HIP(hipMemsetAsync(ix->flags, 0, 16, ctx->stream));
-#undef IX_HIP
+    {
+        const size_t col = align_up(nn * 4);
+        const size_t need = 5 * col + align_up(nn * 8) + align_up(((size_t)opts->n_contigs + 2) * 4) + 256;
+        if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
+            ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
+            ctx->ix_cache = nullptr; ctx->ix_cache_cap = 0;
+        } else {
+            hipError_t e = hipMalloc((void**)&ix->slab, need);
+            if (e != hipSuccess) return cleanup(fail(IVJ_ENOMEM, std::string("hipMalloc(index): ") + hipGetErrorString(e)));
+            ix->slab_cap = need;
+        }
+        char* p = ix->slab;
+        ix->ep = (int2*)p; p += align_up(nn * 8);
+        ix->b_start = (int32_t*)p; p += col;
+        ix->b_row = (int32_t*)p; p += col;
+        ix->b_contig = (int32_t*)p; p += col;
+        ix->e_end = (int32_t*)p; p += col;
+        ix->e_pos = (int32_t*)p; p += col;
+        ix->seg = (int32_t*)p; p += align_up(((size_t)opts->n_contigs + 2) * 4);
+        ix->flags = (int32_t*)p;
+        hipError_t e = hipMemsetAsync(ix->seg, 0, align_up(((size_t)opts->n_contigs + 2) * 4) + 16, ctx->stream);
+        if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(seg): ") + hipGetErrorString(e)));
+    }
     if (n > 0) {
         const size_t comp_bytes = 2 * align_up((size_t)n * 8) + align_up((size_t)(scan_num_tiles(n) + 1) * 8);
         int r = arena_reserve(ctx, sort_scratch_bytes(n) + comp_bytes + 4096);
@@ -483,6 +499,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->ov_buf) (void)hipFree(ctx->ov_buf);
+    if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -546,13 +563,19 @@ int ivj_index_build_dev(ivj_ctx* ctx, const ivj_side* build_dev, const ivj_opts*
 
 void ivj_index_free(ivj_index* ix) {
     if (!ix) return;
-    DeviceGuard g(ix->ctx ? ix->ctx->device : 0);
-    if (ix->ctx) {
-        (void)hipStreamSynchronize(ix->ctx->stream);
-        if (ix->ctx->ov_ix == ix) { ix->ctx->ov_ix = nullptr; ix->ctx->ov_n = -1; }
+    ivj_ctx* ctx = ix->ctx;
+    if (ctx && ctx->ov_ix == ix) { ctx->ov_ix = nullptr; ctx->ov_n = -1; }
+    if (ix->slab) {
+        if (ctx && ix->slab_cap > ctx->ix_cache_cap) {
+            // keep the larger slab for the next index on this context (same stream => ordered reuse)
+            char* old = ctx->ix_cache;
+            ctx->ix_cache = ix->slab; ctx->ix_cache_cap = ix->slab_cap;
+            if (old) { DeviceGuard g(ctx->device); (void)hipFree(old); }
+        } else {
+            DeviceGuard g(ctx ? ctx->device : 0);
+            (void)hipFree(ix->slab);
+        }
     }
-    void* ps[] = {ix->b_start, ix->ep, ix->b_row, ix->b_contig, ix->seg, ix->flags, ix->e_end, ix->e_pos};
-    for (void* p : ps) if (p) (void)hipFree(p);
     delete ix;
 }
 

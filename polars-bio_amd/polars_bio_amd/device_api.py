@@ -1,0 +1,90 @@
+"""Device-resident range operations on torch CUDA(=HIP) tensors.
+
+torch is plumbing here (device memory, the current stream, torch.distributed); the
+work is done by libivjoin_hip.so through the ``*_dev`` entry points of include/ivjoin.h.
+Columns are int32 torch tensors already resident in HBM; results stay in HBM.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+from ._engine import Engine, make_opts
+
+
+class DeviceSide:
+    """(contig, start, end[, row_id]) int32 CUDA tensors of one side."""
+
+    def __init__(self, contig, start, end, row_id=None):
+        import torch
+        for t in (contig, start, end) + ((row_id,) if row_id is not None else ()):
+            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("columns must be contiguous int32 CUDA tensors")
+        self.contig, self.start, self.end, self.row_id = contig, start, end, row_id
+        self.n = int(contig.shape[0])
+
+    def as_c(self):
+        return Engine.dev_side(self.contig.data_ptr(), self.start.data_ptr(), self.end.data_ptr(), self.n,
+                               self.row_id.data_ptr() if self.row_id is not None else 0)
+
+
+class DeviceJoin:
+    """One engine bound to torch's current stream on ``device``."""
+
+    def __init__(self, device: int = 0):
+        import torch
+        self.torch = torch
+        self.device = device
+        torch.cuda.set_device(device)
+        self.engine = Engine(device)
+        self.engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def build_index(self, build: DeviceSide, strict: bool, n_contigs: int, with_end_order: bool = False):
+        return self.engine.index_build_dev(build.as_c(), make_opts(strict, n_contigs), with_end_order)
+
+    def overlap(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None):
+        """Index build (radix sort) + count + scan + fill.  -> (probe_idx, build_idx) int32 tensors."""
+        torch = self.torch
+        opts = make_opts(strict, n_contigs)
+        own = index is None
+        ix = self.engine.index_build_dev(build.as_c(), opts, False) if own else index
+        try:
+            side = probe.as_c()
+            total = self.engine.overlap_count_dev(ix, side, opts)
+            out_p = torch.empty(total, dtype=torch.int32, device=probe.start.device)
+            out_b = torch.empty(total, dtype=torch.int32, device=probe.start.device)
+            self.engine.overlap_fill_dev(ix, side, opts, out_p.data_ptr(), out_b.data_ptr(), total)
+        finally:
+            if own:
+                ix.close()
+        return out_p, out_b
+
+    def count_overlaps(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None):
+        torch = self.torch
+        opts = make_opts(strict, n_contigs)
+        own = index is None
+        ix = self.engine.index_build_dev(build.as_c(), opts, True) if own else index
+        try:
+            out = torch.empty(probe.n, dtype=torch.int64, device=probe.start.device)
+            self.engine.count_overlaps_dev(ix, probe.as_c(), opts, out.data_ptr())
+        finally:
+            if own:
+                ix.close()
+        return out
+
+    def nearest(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, k: int = 1,
+                include_overlaps: bool = True, index=None):
+        torch = self.torch
+        opts = make_opts(strict, n_contigs, k, include_overlaps)
+        own = index is None
+        general = not (k == 1 and include_overlaps)
+        ix = self.engine.index_build_dev(build.as_c(), opts, general) if own else index
+        try:
+            dev = probe.start.device
+            idx = torch.empty((probe.n, k), dtype=torch.int32, device=dev)
+            dist = torch.empty((probe.n, k), dtype=torch.int64, device=dev)
+            nf = torch.empty(probe.n, dtype=torch.int32, device=dev)
+            self.engine.nearest_dev(ix, probe.as_c(), opts, idx.data_ptr(), dist.data_ptr(), nf.data_ptr())
+        finally:
+            if own:
+                ix.close()
+        return idx, dist, nf

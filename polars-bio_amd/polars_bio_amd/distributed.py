@@ -1,0 +1,104 @@
+"""Multi-GPU driver of the interval join: contig sharding + all-gatherv of result batches.
+
+The reference has no multi-process path (its only parallelism is DataFusion
+``target_partitions`` over probe rows, /root/reference/src/scan.rs:233-277,
+docs/developers.md:648-649).  Intervals on different contigs never interact -- the
+reference builds one tree per contig and its SQL variant partitions by contig
+(/root/reference/polars_bio/range_op.py:550) -- so contigs are the natural shard:
+
+* one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI, "gloo" on CPU);
+* contigs are assigned to ranks by LPT (longest processing time first) on an estimated
+  work weight; each rank holds only the probe and build rows of its contigs, with their
+  global row ids in ``ivj_side.row_id`` so emitted pairs carry global rows;
+* no collective on the data path of the join itself; the variable-length result batches are
+  exchanged once at the end with an all-gatherv built from one grouped batch of
+  point-to-point sends/receives (direct peer links, not a ring: xGMI is point-to-point);
+* fewer contigs than ranks (BASELINE config 2 is single-contig): the small build side is
+  replicated and the probe rows are split evenly -- the results are still a disjoint union.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+def lpt_assign(weights: Sequence[float], n_ranks: int) -> List[int]:
+    """Longest-processing-time-first bin packing: contig -> rank."""
+    order = sorted(range(len(weights)), key=lambda c: (-weights[c], c))
+    load = [0.0] * n_ranks
+    owner = [0] * len(weights)
+    for c in order:
+        r = min(range(n_ranks), key=lambda i: (load[i], i))
+        owner[c] = r
+        load[r] += float(weights[c])
+    return owner
+
+
+def contig_weights(probe_contig: np.ndarray, build_contig: np.ndarray, n_contigs: int) -> np.ndarray:
+    """Work estimate per contig: probe rows + build rows (pairs scale with the probe rows for
+    a fixed interval density)."""
+    wp = np.bincount(probe_contig[(probe_contig >= 0) & (probe_contig < n_contigs)], minlength=n_contigs)
+    wb = np.bincount(build_contig[(build_contig >= 0) & (build_contig < n_contigs)], minlength=n_contigs)
+    return (wp + wb).astype(np.float64)
+
+
+def shard_sides(probe, build, n_contigs: int, rank: int, world: int):
+    """-> (probe_local, probe_row_id, build_local, build_row_id, mode).
+
+    probe/build are (contig, start, end) int32 arrays.  mode is "contig" or "rows"."""
+    pc, ps, pe = probe
+    bc, bs, be = build
+    if n_contigs >= world:
+        owner = np.asarray(lpt_assign(contig_weights(pc, bc, n_contigs), world), dtype=np.int32)
+        own_p = np.zeros(len(pc), bool)
+        valid = (pc >= 0) & (pc < n_contigs)
+        own_p[valid] = owner[pc[valid]] == rank
+        own_b = np.zeros(len(bc), bool)
+        validb = (bc >= 0) & (bc < n_contigs)
+        own_b[validb] = owner[bc[validb]] == rank
+        pi = np.nonzero(own_p)[0].astype(np.int32)
+        bi = np.nonzero(own_b)[0].astype(np.int32)
+        mode = "contig"
+    else:
+        lo, hi = len(pc) * rank // world, len(pc) * (rank + 1) // world
+        pi = np.arange(lo, hi, dtype=np.int32)
+        bi = np.arange(len(bc), dtype=np.int32)
+        mode = "rows"
+    return (pc[pi], ps[pi], pe[pi]), pi, (bc[bi], bs[bi], be[bi]), bi, mode
+
+
+def all_gatherv(tensors, group=None):
+    """All-gatherv of equally-typed 1-D tensors (one list entry per payload, e.g. probe_idx and
+    build_idx).  Every rank ends up with, for each payload, the concatenation over ranks in rank
+    order.  One all_gather of the lengths, then ONE grouped batch of isend/irecv (RCCL:
+    ncclGroupStart/End around ncclSend/ncclRecv -> every pair of GPUs uses its own xGMI link).
+
+    Returns (list of gathered tensors, counts per rank as a python list)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local = int(tensors[0].shape[0])
+    dev = tensors[0].device
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    cnts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    counts = [int(x) for x in cnts.tolist()]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    outs = [torch.empty(int(offs[-1]), dtype=t.dtype, device=dev) for t in tensors]
+    ops = []
+    for t, out in zip(tensors, outs):
+        out[offs[rank]:offs[rank + 1]].copy_(t)
+        for peer in range(world):
+            if peer == rank:
+                continue
+            if n_local:
+                ops.append(dist.P2POp(dist.isend, t, peer, group))
+            if counts[peer]:
+                ops.append(dist.P2POp(dist.irecv, out[offs[peer]:offs[peer + 1]], peer, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return outs, counts
