@@ -94,8 +94,9 @@ const char* ivj_version(void);
 int ivj_device_count(int* n);
 int ivj_ctx_create(int device, ivj_ctx** out);
 void ivj_ctx_destroy(ivj_ctx* ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL
- * restores the context's own stream. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream; NULL is the
+ * HIP legacy default stream, which is what torch uses unless told otherwise).
+ * (void*)-1 restores the context's own non-blocking stream. */
 int ivj_ctx_set_stream(ivj_ctx* ctx, void* hip_stream);
 int ivj_ctx_sync(ivj_ctx* ctx);
 /* level 0: off; 1: HIP events around the probe kernels only; 2: around every kernel */

@@ -509,7 +509,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
 int ivj_ctx_set_stream(ivj_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hip_stream == (void*)-1) ? ctx->own_stream : (hipStream_t)hip_stream;
     return IVJ_OK;
 }
 

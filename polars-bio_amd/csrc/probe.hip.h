@@ -275,7 +275,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
     for (int k = 0; k < PROBE_ITEMS; ++k) {
         const int32_t row = (probe_ids && i0 + k < n) ? probe_ids[i0 + k] : (int32_t)(i0 + k);
         int found = 0;
-        for (int p = hi[k] - 1; found < cnt[k]; --p) {
+        for (int p = hi[k] - 1; found < cnt[k] && p >= 0; --p) {
             const int2 v = ix.ep[p];
             if (lt_op<STRICT>(s[k], v.x)) {
                 const long long o = off + (cnt[k] - 1 - found);

@@ -222,7 +222,10 @@ class Engine:
 
     # ---- device-resident entry points (raw device pointers) -----------------
     def set_stream(self, hip_stream: Optional[int]):
-        _check(self.L, self.L.ivj_ctx_set_stream(self.h, C.c_void_p(hip_stream or 0)), "ivj_ctx_set_stream")
+        """hipStream_t handle as an int (0 = the legacy default stream torch uses); None restores
+        the engine's own stream."""
+        h = C.c_void_p(-1) if hip_stream is None else C.c_void_p(hip_stream)
+        _check(self.L, self.L.ivj_ctx_set_stream(self.h, h), "ivj_ctx_set_stream")
 
     def sync(self):
         _check(self.L, self.L.ivj_ctx_sync(self.h), "ivj_ctx_sync")
