@@ -96,6 +96,9 @@ struct ivj_index {
     int32_t* flags = nullptr;
     int32_t* e_end = nullptr;
     int32_t* e_pos = nullptr;
+    int4* cmeta = nullptr;
+    uint32_t* bins = nullptr;
+    int64_t bins_len = 0;
     bool has_end_order = false;
     char* slab = nullptr;      // single allocation holding every array above
     size_t slab_cap = 0;
@@ -226,6 +229,7 @@ IndexView view_of(const ivj_index* ix) {
     IndexView v;
     v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
     v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
+    v.cmeta = ix->cmeta; v.bins = ix->bins;
     return v;
 }
 
@@ -267,7 +271,10 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
     auto cleanup = [&](int code) { ivj_index_free(ix); return code; };
     {
         const size_t col = align_up(nn * 4);
-        const size_t need = 5 * col + align_up(nn * 8) + align_up(((size_t)opts->n_contigs + 2) * 4) + 256;
+        const size_t nc = (size_t)opts->n_contigs;
+        ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
+        const size_t small = align_up((nc + 2) * 4) + align_up(16) + align_up((nc + 1) * 32);   // seg, flags, cmeta
+        const size_t need = 5 * col + align_up(nn * 8) + align_up((size_t)ix->bins_len * 4) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
             ctx->ix_cache = nullptr; ctx->ix_cache_cap = 0;
@@ -283,19 +290,25 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->b_contig = (int32_t*)p; p += col;
         ix->e_end = (int32_t*)p; p += col;
         ix->e_pos = (int32_t*)p; p += col;
-        ix->seg = (int32_t*)p; p += align_up(((size_t)opts->n_contigs + 2) * 4);
-        ix->flags = (int32_t*)p;
-        hipError_t e = hipMemsetAsync(ix->seg, 0, align_up(((size_t)opts->n_contigs + 2) * 4) + 16, ctx->stream);
-        if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(seg): ") + hipGetErrorString(e)));
+        ix->bins = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
+        char* small_base = p;
+        ix->seg = (int32_t*)p; p += align_up((nc + 2) * 4);
+        ix->flags = (int32_t*)p; p += align_up(16);
+        ix->cmeta = (int4*)p;
+        // seg, flags and cmeta start zeroed: an empty index answers every probe with "no rows"
+        hipError_t e = hipMemsetAsync(small_base, 0, small, ctx->stream);
+        if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(index meta): ") + hipGetErrorString(e)));
     }
     if (n > 0) {
-        const size_t comp_bytes = 2 * align_up((size_t)n * 8) + align_up((size_t)(scan_num_tiles(n) + 1) * 8);
+        const size_t comp_bytes = 2 * align_up((size_t)n * 8) + align_up((size_t)(scan_num_tiles(n) + 1) * 8) +
+                                  align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4);
         int r = arena_reserve(ctx, sort_scratch_bytes(n) + comp_bytes + 4096);
         if (r != IVJ_OK) return cleanup(r);
         SortBufs sb; take_sort_bufs(ctx, n, sb);
         unsigned long long* comp = arena_take<unsigned long long>(ctx, n);
         unsigned long long* comp_max = arena_take<unsigned long long>(ctx, n);
         unsigned long long* comp_part = arena_take<unsigned long long>(ctx, scan_num_tiles(n) + 1);
+        uint32_t* bins_part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
         // 1. stable sort by start (row ids as payload), 2. stable sort by contig id
         LAUNCH(ctx, "sort_keys", k_iota_flip, grid1d(n, 256), 256, build->start, n, sb.kA, sb.vA);
         bool fl = radix_sort_pairs(ctx, sb, n, 32);
@@ -311,6 +324,16 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
                                                       (unsigned long long*)nullptr);
         LAUNCH(ctx, "emit_ep", k_emit_ep, grid1d(n, 256), 256, (const unsigned long long*)comp,
                (const unsigned long long*)comp_max, n, ix->ep);
+        // 6. direct-address table over start
+        if (opts->n_contigs > 0) {
+            LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(opts->n_contigs, 256), 256, (const int32_t*)ix->seg,
+                   (const int32_t*)ix->b_start, opts->n_contigs, ix->cmeta);
+            hipError_t me = hipMemsetAsync(ix->bins, 0, (size_t)ix->bins_len * 4, ctx->stream);
+            if (me != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(bins): ") + hipGetErrorString(me)));
+            LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int32_t*)ix->b_contig, n,
+                   opts->n_contigs, (const int4*)ix->cmeta, ix->bins);
+            device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", ix->bins, ix->bins, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
+        }
         if (with_end_order) { r = build_end_order(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
     } else {
         ix->has_end_order = true;

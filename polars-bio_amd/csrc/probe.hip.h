@@ -7,6 +7,10 @@
 //   b_contig[Nb] int32   contig id in that order (rows outside the dictionary get n_contigs)
 //   seg[n_contigs + 2]   segment offsets; seg[n_contigs] = number of valid rows
 //   e_end / e_pos [Nb]   optional: ends sorted by (contig, end, position), and that position
+//   cmeta[n_contigs]     per-contig {segment, min/max start, bin shift, table offset}
+//   bins[2 Nb + 2 n_contigs] direct-address table over start: about one build row per bin, so the
+//                        hi-bound of a probe is ONE table read plus a search over the few rows
+//                        of that bin instead of a log2(Nb)-step binary search of dependent gathers
 //
 // Predicate (polars_bio/range_op.py:75-84; src/option.rs:95-100):
 //   STRICT: q.start <  b.end && b.start <  q.end      WEAK: <=
@@ -31,6 +35,8 @@ struct IndexView {
     const int32_t* e_end;
     const int32_t* e_pos;
     const int32_t* flags;  // flags[0] != 0: some build row has start > end
+    const int4* cmeta;     // per contig: {a, b, ulo, uhi} {shift, tb, 0, 0}  (two int4)
+    const uint32_t* bins;  // direct-address table: bins[tb + j] = first position with ustart >= ulo + (j << shift)
     int32_t n_contigs;
 };
 
@@ -120,6 +126,95 @@ __device__ __forceinline__ void bound_hi4(const IndexView& ix, const int (&a)[PR
     }
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) out[k] = lo[k];
+}
+
+// hi-bound through the direct-address table, four probes interleaved.  target = q.end (STRICT:
+// first start >= q.end) or q.end + 1 (WEAK: first start > q.end), compared on the flipped
+// (unsigned-ordered) coordinates so that negative starts and INT32_MAX ends need no special case.
+template <bool STRICT>
+__device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t (&c)[PROBE_ITEMS],
+                                              const bool (&valid)[PROBE_ITEMS], const int32_t (&qe)[PROBE_ITEMS],
+                                              int (&a)[PROBE_ITEMS], int (&b)[PROBE_ITEMS], int (&out)[PROBE_ITEMS]) {
+    int lo[PROBE_ITEMS], hi[PROBE_ITEMS];
+    unsigned long long tu[PROBE_ITEMS];
+    int4 m0[PROBE_ITEMS], m1[PROBE_ITEMS];
+    bool ok[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) {
+        ok[k] = valid[k] && (uint32_t)c[k] < (uint32_t)ix.n_contigs;
+        if (ok[k]) { m0[k] = ix.cmeta[2 * c[k]]; m1[k] = ix.cmeta[2 * c[k] + 1]; }
+        else { m0[k] = make_int4(0, 0, 0, 0); m1[k] = make_int4(0, 0, 0, 0); }
+    }
+    uint32_t t0[PROBE_ITEMS], t1[PROBE_ITEMS];
+    bool inb[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) {
+        a[k] = m0[k].x; b[k] = m0[k].y;
+        const uint32_t ulo = (uint32_t)m0[k].z, uhi = (uint32_t)m0[k].w;
+        tu[k] = (unsigned long long)flip(qe[k]) + (STRICT ? 0ull : 1ull);
+        inb[k] = false;
+        if (b[k] <= a[k] || tu[k] <= ulo) { lo[k] = hi[k] = a[k]; }
+        else if (tu[k] > uhi) { lo[k] = hi[k] = b[k]; }
+        else {
+            const uint32_t j = ((uint32_t)tu[k] - ulo) >> m1[k].x;
+            inb[k] = true;
+            t0[k] = ix.bins[(uint32_t)m1[k].y + j];
+            t1[k] = ix.bins[(uint32_t)m1[k].y + j + 1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) if (inb[k]) { lo[k] = (int)t0[k]; hi[k] = (int)t1[k]; }
+    for (;;) {
+        bool any = false;
+        int32_t v[PROBE_ITEMS];
+        int m[PROBE_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) {
+            m[k] = lo[k] + ((hi[k] - lo[k]) >> 1);
+            const bool act = lo[k] < hi[k];
+            any |= act;
+            v[k] = act ? ix.b_start[m[k]] : 0;
+        }
+        if (!any) break;
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) {
+            if (lo[k] < hi[k]) {
+                if ((unsigned long long)flip(v[k]) < tu[k]) lo[k] = m[k] + 1; else hi[k] = m[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) out[k] = lo[k];
+}
+
+// Window of a probe below hi as a 32-bit match mask: bit j set <=> row hi-1-j overlaps.  The scan
+// stops at the first row whose prefix max fails "q.start (<) pmax".  Four (end,pmax) pairs are
+// fetched per round so the dependent-load chain is a quarter of the window length.  Returns false
+// (and the exact count in `cnt`) when the window is longer than 32 rows.
+template <bool STRICT>
+__device__ __forceinline__ bool window_mask(const IndexView& ix, int a, int hi, int32_t qs, uint32_t& mask, int& cnt) {
+    mask = 0; cnt = 0;
+    int p = hi - 1;
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {
+        int2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (p - j >= a) ? ix.ep[p - j] : make_int2(0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (p - j < a || !lt_op<STRICT>(qs, v[j].y)) { cnt = __popc(mask); return true; }
+            if (lt_op<STRICT>(qs, v[j].x)) mask |= 1u << (4 * t + j);
+        }
+        p -= 4;
+    }
+    cnt = __popc(mask);
+    if (p < a || !lt_op<STRICT>(qs, ix.ep[p].y)) return true;
+    for (; p >= a; --p) {                      // long window: exact count, the fill pass rescans
+        const int2 v = ix.ep[p];
+        if (!lt_op<STRICT>(qs, v.y)) break;
+        cnt += lt_op<STRICT>(qs, v.x) ? 1 : 0;
+    }
+    return false;
 }
 
 // exact count by the bounded backward scan (valid for every input, including
@@ -220,10 +315,47 @@ __global__ void k_end_finalize(const int2* __restrict__ ep, const uint32_t* __re
     if (i < n) { const uint32_t p = pos[i]; e_end[i] = ep[p].x; e_pos[i] = (int32_t)p; }
 }
 
+// Per-contig metadata of the direct-address table: bin width 2^shift chosen so that the contig has
+// at most 2 n_c bins (about one build row per bin for evenly spread rows); its slice of the table
+// starts at tb = 2 a + 2 c.
+__global__ void k_contig_meta(const int32_t* __restrict__ seg, const int32_t* __restrict__ b_start, int32_t n_contigs,
+                              int4* __restrict__ cmeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_contigs) return;
+    const int a = seg[c], b = seg[c + 1];
+    uint32_t ulo = 0, uhi = 0;
+    int shift = 0;
+    if (b > a) {
+        ulo = flip(b_start[a]); uhi = flip(b_start[b - 1]);
+        const unsigned long long span = (unsigned long long)(uhi - ulo), cap = 2ull * (unsigned long long)(b - a);
+        while ((span >> shift) + 1ull > cap) ++shift;
+    }
+    cmeta[2 * c] = make_int4(a, b, (int)ulo, (int)uhi);
+    cmeta[2 * c + 1] = make_int4(shift, 2 * a + 2 * c, 0, 0);
+}
+
+// bins (zero-filled) receives, for the last row p of every non-empty bin j, the value p + 1 at slot
+// j + 1, and a at slot 0 of every contig; an inclusive max-scan over the whole table then yields
+// bins[tb + k] = first position whose start falls in bin >= k (positions grow with the table index).
+__global__ void k_bins_mark(const int32_t* __restrict__ b_start, const int32_t* __restrict__ b_contig, int64_t n,
+                            int32_t n_contigs, const int4* __restrict__ cmeta, uint32_t* __restrict__ bins) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t c = b_contig[p];
+    if ((uint32_t)c >= (uint32_t)n_contigs) return;
+    const int4 m0 = cmeta[2 * c], m1 = cmeta[2 * c + 1];
+    const uint32_t ulo = (uint32_t)m0.z;
+    const uint32_t j = (flip(b_start[p]) - ulo) >> m1.x;
+    const bool last = (p == m0.y - 1) || (((flip(b_start[p + 1]) - ulo) >> m1.x) > j);
+    if (last) bins[(uint32_t)m1.y + j + 1] = (uint32_t)p + 1u;
+    if (p == m0.x) bins[(uint32_t)m1.y] = (uint32_t)p;
+}
+
 // ------------------------------------------------------------------ overlap: count -> fill
 
 // Pass 1.  One workgroup = PROBE_TILE probes, PROBE_ITEMS consecutive probes per thread.
-// Writes hi[i], cnt[i] (so the fill pass does not search again) and the tile total.
+// Writes hi[i] and the 32-row match mask of the window below hi (or, flagged in the sign bit of
+// hi, the exact count of a longer window) so the fill pass neither searches nor rescans.
 template <bool STRICT>
 __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, const int32_t* __restrict__ pc,
                                                                  const int32_t* __restrict__ ps,
@@ -236,15 +368,22 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
     load_items(pc, i0, n, vec_ok, -1, c);
     load_items(ps, i0, n, vec_ok, 0, s);
     load_items(pe, i0, n, vec_ok, 0, e);
-    int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS], cnt[PROBE_ITEMS];
+    int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS], x[PROBE_ITEMS];
+    bool valid[PROBE_ITEMS];
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) seg_bounds(ix, c[k], i0 + k < n, a[k], b[k]);
-    bound_hi4<STRICT>(ix, a, b, e, hi);
+    for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
+    bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
     long long tsum = 0;
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) { cnt[k] = scan_count<STRICT>(ix, a[k], hi[k], s[k]); tsum += cnt[k]; }
+    for (int k = 0; k < PROBE_ITEMS; ++k) {
+        uint32_t mask; int cnt;
+        const bool small = window_mask<STRICT>(ix, a[k], hi[k], s[k], mask, cnt);
+        x[k] = small ? (int)mask : cnt;
+        if (!small) hi[k] |= (int)0x80000000;      // flag: x is a count, the fill pass rescans
+        tsum += cnt;
+    }
     store_items(hi_out, i0, n, vec_ok, hi);
-    store_items(cnt_out, i0, n, vec_ok, cnt);
+    store_items(cnt_out, i0, n, vec_ok, x);
     long long tot;
     block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
     if (threadIdx.x == 0) tile_tot[blockIdx.x] = tot;
@@ -262,26 +401,41 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
                                                                 int32_t* __restrict__ out_build) {
     __shared__ long long lds[PROBE_THREADS / kWave];
     const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
-    int32_t s[PROBE_ITEMS], hi[PROBE_ITEMS], cnt[PROBE_ITEMS];
-    load_items(ps, i0, n, vec_ok, 0, s);
+    int32_t hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS];
     load_items(hi_in, i0, n, vec_ok, 0, hi);
-    load_items(cnt_in, i0, n, vec_ok, 0, cnt);
+    load_items(cnt_in, i0, n, vec_ok, 0, x);
     long long tsum = 0;
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) tsum += cnt[k];
+    for (int k = 0; k < PROBE_ITEMS; ++k) { cnt[k] = hi[k] < 0 ? x[k] : __popc((uint32_t)x[k]); tsum += cnt[k]; }
     long long tot;
     long long off = tile_base[blockIdx.x] + block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
-        const int32_t row = (probe_ids && i0 + k < n) ? probe_ids[i0 + k] : (int32_t)(i0 + k);
-        int found = 0;
-        for (int p = hi[k] - 1; found < cnt[k] && p >= 0; --p) {
-            const int2 v = ix.ep[p];
-            if (lt_op<STRICT>(s[k], v.x)) {
-                const long long o = off + (cnt[k] - 1 - found);
+        if (cnt[k] == 0) continue;
+        const int32_t row = probe_ids ? probe_ids[i0 + k] : (int32_t)(i0 + k);
+        if (hi[k] >= 0) {
+            // mask mode: bit j <=> row hi-1-j; ascending (start,row) order = descending j
+            uint32_t m = (uint32_t)x[k];
+            long long o = off;
+            while (m) {
+                const int j = 31 - __clz(m);
+                m &= ~(1u << j);
                 out_probe[o] = row;
-                out_build[o] = ix.b_row[p];
-                ++found;
+                out_build[o] = ix.b_row[hi[k] - 1 - j];
+                ++o;
+            }
+        } else {
+            const int32_t qs = ps[i0 + k];
+            const int h = hi[k] & 0x7fffffff;
+            int found = 0;
+            for (int p = h - 1; found < cnt[k] && p >= 0; --p) {
+                const int2 v = ix.ep[p];
+                if (lt_op<STRICT>(qs, v.x)) {
+                    const long long o = off + (cnt[k] - 1 - found);
+                    out_probe[o] = row;
+                    out_build[o] = ix.b_row[p];
+                    ++found;
+                }
             }
         }
         off += cnt[k];
@@ -304,9 +458,10 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
     load_items(ps, i0, n, vec_ok, 0, s);
     load_items(pe, i0, n, vec_ok, 0, e);
     int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS];
+    bool valid[PROBE_ITEMS];
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) seg_bounds(ix, c[k], i0 + k < n, a[k], b[k]);
-    bound_hi4<STRICT>(ix, a, b, e, hi);
+    for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
+    bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
     const bool inv = ix.flags[0] != 0;
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
@@ -337,9 +492,10 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
     load_items(ps, i0, n, vec_ok, 0, s);
     load_items(pe, i0, n, vec_ok, 0, e);
     int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS];
+    bool valid[PROBE_ITEMS];
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) seg_bounds(ix, c[k], i0 + k < n, a[k], b[k]);
-    bound_hi4<STRICT>(ix, a, b, e, hi);
+    for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
+    bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
         if (i0 + k >= n) continue;

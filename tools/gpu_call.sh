@@ -1,0 +1,19 @@
+#!/bin/bash
+# GPU session driver.  usage: tools/gpu_call.sh [first] [pytest] [pytest-fast] [c2] [c3] [prof] [c4] [c5]
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for stage in "$@"; do
+  case "$stage" in
+    first) echo "== gpu_first"; timeout 600 python tools/gpu_first.py 2>&1 | tee gpurun_out/gpu_first.log | tail -25 ;;
+    pytest) echo "== pytest gpu"; timeout 1800 python -m pytest tests -m gpu -q -x 2>&1 | tee gpurun_out/pytest_gpu.log | tail -30 ;;
+    pytest-fast) echo "== pytest gpu (no full-size)"; timeout 1500 python -m pytest tests -m gpu -q -x -k "not full_size" 2>&1 | tee gpurun_out/pytest_gpu.log | tail -30 ;;
+    c2) echo "== bench config2"; timeout 900 python bench.py --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c2.err | tee gpurun_out/bench_c2.json; tail -22 gpurun_out/bench_c2.err ;;
+    c3) echo "== bench config3"; timeout 1200 python bench.py --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c3.err | tee gpurun_out/bench_c3.json; tail -22 gpurun_out/bench_c3.err ;;
+    c3dense) echo "== bench config3 dense"; timeout 1200 python bench.py --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --kernel-table --no-cpu-baseline 2>gpurun_out/bench_c3d.err | tee gpurun_out/bench_c3d.json; tail -22 gpurun_out/bench_c3d.err ;;
+    c4) echo "== bench config4 nearest"; timeout 1200 python bench.py --workload nearest_50M_2M_24contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c4.err | tee gpurun_out/bench_c4.json; tail -22 gpurun_out/bench_c4.err ;;
+    c5) echo "== bench config5 count_overlaps"; timeout 1200 python bench.py --workload count_200M_200k_24contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c5.err | tee gpurun_out/bench_c5.json; tail -22 gpurun_out/bench_c5.err ;;
+    prof) echo "== rocprofv3 stats (config3)"; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_c3" -o c3 --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_c3.out" 2> "$OLDPWD/gpurun_out/prof_c3.err"); tail -3 gpurun_out/prof_c3.out; find gpurun_out/prof_c3 -name "*stats*" | head; f=$(find gpurun_out/prof_c3 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f" ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
