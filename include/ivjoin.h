@@ -71,7 +71,8 @@ typedef struct {
     int32_t n_contigs;         /* size of the shared chrom dictionary */
     int32_t nearest_k;         /* RangeOptions.nearest_k, >= 1 (default 1) */
     int32_t include_overlaps;  /* RangeOptions.include_overlaps (default 1) */
-    int32_t reserved[4];       /* must be zero */
+    int32_t partition_mode;    /* overlap: bucket the probe side first. 0 auto (large inputs), 1 always, 2 never */
+    int32_t reserved[3];       /* must be zero */
 } ivj_opts;
 
 /* Result of overlap on the host path: library-owned host buffers. */
@@ -107,8 +108,11 @@ int ivj_ctx_get_timings(ivj_ctx* ctx, ivj_timing* out, int cap, int* n);
 /* ---- host-buffer entry points (what the reference FFI would bind) ------- *
  * Inputs are borrowed host buffers; results come back in host memory.       */
 
-/* pb.overlap: all (probe_row, build_row) pairs, ordered by probe row, then by
- * (build.start, build row).  Free with ivj_pairs_free. */
+/* pb.overlap: all (probe_row, build_row) pairs.  The pairs of one probe row are contiguous and
+ * ordered by (build.start, build row).  Probe rows appear in input order, or -- when the probe
+ * side was bucketed (partition_mode) -- in the deterministic bucket order of the partition
+ * (by genomic position of the probe end, input order inside a bucket tile).  The reference leaves
+ * the row order unspecified (every reference test sorts).  Free with ivj_pairs_free. */
 int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
                 const ivj_opts* opts, ivj_pairs* out);
 void ivj_pairs_free(ivj_pairs* p);

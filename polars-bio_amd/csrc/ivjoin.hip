@@ -76,6 +76,10 @@ struct ivj_ctx {
     char* ix_cache = nullptr;
     size_t ix_cache_cap = 0;
     int64_t ov_total = 0;
+    // bucketed (partitioned) copies of the probe columns + their row ids, when the partition path ran
+    bool ov_part = false;
+    int32_t *pt_c = nullptr, *pt_s = nullptr, *pt_e = nullptr, *pt_row = nullptr;
+    bool part_attr_set = false;
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
     bool t_open = false;
@@ -215,6 +219,7 @@ int check_opts(const ivj_opts* o) {
     if (!o) return fail(IVJ_EINVAL, "opts is NULL");
     if (o->filter_op != IVJ_FILTER_WEAK && o->filter_op != IVJ_FILTER_STRICT) return fail(IVJ_EINVAL, "filter_op must be 0 (Weak) or 1 (Strict)");
     if (o->n_contigs < 0) return fail(IVJ_EINVAL, "n_contigs < 0");
+    if (o->partition_mode < 0 || o->partition_mode > 2) return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (always) or 2 (never)");
     return IVJ_OK;
 }
 int check_side(const ivj_side* s, const char* what) {
@@ -344,9 +349,10 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
     return IVJ_OK;
 }
 
-int ensure_ov(ivj_ctx* ctx, int64_t n) {
+int ensure_ov(ivj_ctx* ctx, int64_t n, bool with_part) {
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
-    const size_t need = 2 * align_up((size_t)n * 4) + align_up((size_t)(tiles + 2) * 8) +
+    const size_t col = align_up((size_t)n * 4);
+    const size_t need = (with_part ? 6 : 2) * col + align_up((size_t)(tiles + 2) * 8) +
                         align_up((size_t)(scan_num_tiles(tiles) + 2) * 8) + 1024;
     if (need > ctx->ov_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -358,9 +364,55 @@ int ensure_ov(ivj_ctx* ctx, int64_t n) {
         ctx->ov_cap = want;
     }
     char* p = ctx->ov_buf;
-    ctx->ov_hi = (int32_t*)p; p += align_up((size_t)n * 4);
-    ctx->ov_cnt = (int32_t*)p; p += align_up((size_t)n * 4);
+    ctx->ov_hi = (int32_t*)p; p += col;
+    ctx->ov_cnt = (int32_t*)p; p += col;
+    if (with_part) {
+        ctx->pt_c = (int32_t*)p; p += col;
+        ctx->pt_s = (int32_t*)p; p += col;
+        ctx->pt_e = (int32_t*)p; p += col;
+        ctx->pt_row = (int32_t*)p; p += col;
+    }
     ctx->ov_tile = (long long*)p;
+    return IVJ_OK;
+}
+
+// Probe bucketing pays once the index no longer fits the L2s and there are enough probes to
+// amortise the two extra passes.  opts->partition_mode: 0 auto, 1 always, 2 never.
+bool want_partition(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts) {
+    if (opts->partition_mode == 1) return true;
+    if (opts->partition_mode == 2) return false;
+    return n_probe >= (4ll << 20) && ix->n >= (256ll << 10);
+}
+
+int partition_probes(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts) {
+    const int64_t n = probe->n;
+    const int ntiles = (int)((n + PART_TILE - 1) / PART_TILE);
+    const int grid = 8 * ((ntiles + 7) / 8);
+    int bshift = 0;
+    while ((ix->bins_len >> bshift) > (int64_t)(PART_BUCKETS - 3)) ++bshift;
+    const size_t hist = (size_t)PART_BUCKETS * (size_t)ntiles;
+    IVJ_TRY(arena_reserve(ctx, align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4) + 4096));
+    uint32_t* blk = arena_take<uint32_t>(ctx, hist);
+    uint32_t* partials = arena_take<uint32_t>(ctx, scan_num_tiles((int64_t)hist) + 1);
+    if (!ctx->part_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
+        ctx->part_attr_set = true;
+    }
+    IndexView v = view_of(ix);
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, probe->contig, probe->end, n, bshift, blk, ntiles);
+    else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, probe->contig, probe->end, n, bshift, blk, ntiles);
+    device_scan<uint32_t, SumOp, false>(ctx, "part_scan", blk, blk, (int64_t)hist, 0u, partials, (uint32_t*)nullptr);
+    t_begin(ctx, "part_scatter");
+    if (strict)
+        hipLaunchKernelGGL((k_part_scatter<true>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, probe->contig, probe->start,
+                           probe->end, probe->row_id, n, bshift, (const uint32_t*)blk, ntiles, ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
+    else
+        hipLaunchKernelGGL((k_part_scatter<false>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, probe->contig, probe->start,
+                           probe->end, probe->row_id, n, bshift, (const uint32_t*)blk, ntiles, ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
+    t_end(ctx);
+    HIP_TRY(hipGetLastError());
     return IVJ_OK;
 }
 
@@ -372,17 +424,24 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         *n_pairs = 0;
         return IVJ_OK;
     }
-    IVJ_TRY(ensure_ov(ctx, n));
+    const bool part = want_partition(ix, n, opts);
+    IVJ_TRY(ensure_ov(ctx, n, part));
+    ctx->ov_part = part;
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     long long* tile = ctx->ov_tile;                       // tiles + 1
     long long* partials = tile + align_up((size_t)(tiles + 2) * 8) / 8;
-    const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end;
+    if (part) {
+        IVJ_TRY(partition_probes(ctx, ix, probe, opts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e;
+    }
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
     IndexView v = view_of(ix);
     if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "overlap_count", (k_overlap_count<true>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec,
+        LAUNCH(ctx, "overlap_count", (k_overlap_count<true>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec,
                ctx->ov_hi, ctx->ov_cnt, tile);
     else
-        LAUNCH(ctx, "overlap_count", (k_overlap_count<false>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec,
+        LAUNCH(ctx, "overlap_count", (k_overlap_count<false>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec,
                ctx->ov_hi, ctx->ov_cnt, tile);
     device_scan<long long, SumOp, false>(ctx, "tile_scan", tile, tile, tiles, 0ll, partials, tile + tiles);
     HIP_TRY(hipMemcpyAsync(ctx->h_total, tile + tiles, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -403,14 +462,16 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     if (!out_p || !out_b) return fail(IVJ_EINVAL, "output buffers are NULL");
     const int64_t n = probe->n;
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
-    const bool vec = aligned16(probe->start);
+    const int32_t* qs = ctx->ov_part ? ctx->pt_s : probe->start;
+    const int32_t* ids = ctx->ov_part ? ctx->pt_row : probe->row_id;
+    const bool vec = aligned16(qs);
     IndexView v = view_of(ix);
     if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "overlap_fill", (k_overlap_fill<true>), tiles, PROBE_THREADS, v, probe->start, n, vec, (const int32_t*)ctx->ov_hi,
-               (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, probe->row_id, out_p, out_b);
+        LAUNCH(ctx, "overlap_fill", (k_overlap_fill<true>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+               (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
     else
-        LAUNCH(ctx, "overlap_fill", (k_overlap_fill<false>), tiles, PROBE_THREADS, v, probe->start, n, vec, (const int32_t*)ctx->ov_hi,
-               (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, probe->row_id, out_p, out_b);
+        LAUNCH(ctx, "overlap_fill", (k_overlap_fill<false>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+               (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
 }

@@ -19,6 +19,7 @@
 //   matches = { p in [a,hi) : q.start (<) end[p] };  the prefix max bounds the backward scan:
 //   stop at the first p (going down) with !(q.start (<) pmax[p]).
 #pragma once
+#include "radix_sort.hip.h"
 #include "scan.hip.h"
 
 namespace ivj {
@@ -566,6 +567,173 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_general(IndexView ix,
         }
     }
     out_n[i] = found;
+}
+
+}  // namespace ivj
+
+// =================================================================== probe bucketing
+// One 256-way, stable, LDS-staged radix partition of the probe side by the direct-address table
+// index of q.end.  After it, consecutive probes touch one narrow slice of bins / b_start / ep /
+// b_row, so the random gathers of the count and fill passes hit the XCD's L2 instead of going to
+// the fabric.  Output: permuted copies of the three probe columns plus the original (or global)
+// row id of every permuted probe; the count and fill kernels then run unchanged on those columns.
+namespace ivj {
+
+constexpr int PART_THREADS = 1024;
+constexpr int PART_WAVES = PART_THREADS / kWave;
+constexpr int PART_ITEMS = 8;
+constexpr int PART_TILE = PART_THREADS * PART_ITEMS;
+constexpr int PART_BUCKETS = 256;   // bucket 255 = probes without any candidate row
+
+// dynamic LDS of k_part_scatter
+constexpr size_t PART_LDS_BYTES = 4 * (size_t)PART_TILE * 4 /* s,e,c,row */ + (size_t)PART_TILE /* bucket ids */ +
+                                  (size_t)PART_WAVES * PART_BUCKETS * 4 + 3 * PART_BUCKETS * 4;
+
+template <bool STRICT>
+__device__ __forceinline__ uint32_t probe_bucket(const IndexView& ix, int32_t c, int32_t qe, int bshift) {
+    if ((uint32_t)c >= (uint32_t)ix.n_contigs) return PART_BUCKETS - 1;
+    const int4 m0 = ix.cmeta[2 * c], m1 = ix.cmeta[2 * c + 1];
+    if (m0.y <= m0.x) return PART_BUCKETS - 1;
+    const uint32_t ulo = (uint32_t)m0.z, uhi = (uint32_t)m0.w;
+    const unsigned long long tu = (unsigned long long)flip(qe) + (STRICT ? 0ull : 1ull);
+    uint32_t j;
+    if (tu <= ulo) j = 0;
+    else if (tu > uhi) j = ((uhi - ulo) >> m1.x) + 1u;
+    else j = ((uint32_t)tu - ulo) >> m1.x;
+    const uint32_t bkt = ((uint32_t)m1.y + j) >> bshift;
+    return bkt < (uint32_t)(PART_BUCKETS - 2) ? bkt : (uint32_t)(PART_BUCKETS - 2);
+}
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch); give every XCD a
+// contiguous range of tiles so the partial 64-byte lines two neighbouring tiles write into the
+// same bucket meet in ONE L2.  Placement only affects speed, never the result.
+__device__ __forceinline__ int xcd_tile(int block, int ntiles) {
+    const int per = (ntiles + 7) / 8;
+    const int t = (block & 7) * per + (block >> 3);
+    return t;
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(PART_THREADS) void k_part_hist(IndexView ix, const int32_t* __restrict__ pc,
+                                                            const int32_t* __restrict__ pe, int64_t n, int bshift,
+                                                            uint32_t* __restrict__ blk_hist, int ntiles) {
+    __shared__ uint32_t h[PART_BUCKETS];
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    if (threadIdx.x < PART_BUCKETS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)tile * PART_TILE;
+    const uint64_t lt = lanemask_lt();
+#pragma unroll 2
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        const int64_t i = base + (int64_t)j * PART_THREADS + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t d = valid ? probe_bucket<STRICT>(ix, pc[i], pe[i], bshift) : 0u;
+        const uint64_t peers = wave_match8(d, valid);
+        if (valid && (peers & lt) == 0) atomicAdd(&h[d], (uint32_t)__popcll(peers));
+    }
+    __syncthreads();
+    if (threadIdx.x < PART_BUCKETS) blk_hist[(int64_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];
+}
+
+// blk_off = exclusive scan of blk_hist in bucket-major order.
+template <bool STRICT>
+__global__ __launch_bounds__(PART_THREADS) void k_part_scatter(IndexView ix, const int32_t* __restrict__ pc,
+                                                               const int32_t* __restrict__ ps,
+                                                               const int32_t* __restrict__ pe,
+                                                               const int32_t* __restrict__ row_id, int64_t n, int bshift,
+                                                               const uint32_t* __restrict__ blk_off, int ntiles,
+                                                               int32_t* __restrict__ oc, int32_t* __restrict__ os,
+                                                               int32_t* __restrict__ oe, int32_t* __restrict__ orow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char part_lds[];
+    int32_t* l_s = reinterpret_cast<int32_t*>(part_lds);
+    int32_t* l_e = l_s + PART_TILE;
+    int32_t* l_c = l_e + PART_TILE;
+    int32_t* l_r = l_c + PART_TILE;
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(l_r + PART_TILE);          // [PART_WAVES][PART_BUCKETS]
+    uint32_t* run = wcnt + PART_WAVES * PART_BUCKETS;                        // running count per bucket
+    uint32_t* lstart = run + PART_BUCKETS;                                   // tile-local start of each bucket
+    uint32_t* goff = lstart + PART_BUCKETS;                                  // global offset of (bucket, tile)
+    unsigned char* l_d = reinterpret_cast<unsigned char*>(goff + PART_BUCKETS);
+
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int tid = threadIdx.x, w = tid / kWave;
+    if (tid < PART_BUCKETS) {
+        run[tid] = 0;
+        goff[tid] = blk_off[(int64_t)tid * ntiles + tile];
+    }
+    for (int k = tid; k < PART_WAVES * PART_BUCKETS; k += PART_THREADS) wcnt[k] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)tile * PART_TILE;
+    const int tile_n = (int)((n - base) < (int64_t)PART_TILE ? (n - base) : (int64_t)PART_TILE);
+    const uint64_t lt = lanemask_lt();
+    int32_t c[PART_ITEMS], s[PART_ITEMS], e[PART_ITEMS], r[PART_ITEMS];
+    uint32_t d[PART_ITEMS], rank[PART_ITEMS];
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        const int64_t i = base + (int64_t)j * PART_THREADS + tid;
+        const bool valid = i < n;
+        c[j] = valid ? pc[i] : -1; s[j] = valid ? ps[i] : 0; e[j] = valid ? pe[i] : 0;
+        r[j] = valid ? (row_id ? row_id[i] : (int32_t)i) : -1;
+    }
+    // stable tile-local rank of every probe inside its bucket (same scheme as k_rs_scatter)
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        const bool valid = j * PART_THREADS + tid < tile_n;
+        d[j] = valid ? probe_bucket<STRICT>(ix, c[j], e[j], bshift) : 0u;
+        const uint64_t peers = wave_match8(d[j], valid);
+        const uint32_t rk = (uint32_t)__popcll(peers & lt);
+        if (valid && rk == 0) wcnt[w * PART_BUCKETS + d[j]] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        uint32_t v = 0;
+        if (valid) {
+            v = run[d[j]] + rk;
+            for (int k = 0; k < w; ++k) v += wcnt[k * PART_BUCKETS + d[j]];
+        }
+        rank[j] = v;
+        __syncthreads();
+        if (tid < PART_BUCKETS) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < PART_WAVES; ++k) { sum += wcnt[k * PART_BUCKETS + tid]; wcnt[k * PART_BUCKETS + tid] = 0; }
+            run[tid] += sum;
+        }
+        __syncthreads();
+    }
+    // tile-local exclusive scan of the bucket counts (256 values: first four wavefronts)
+    if (tid < PART_BUCKETS) {
+        const uint32_t cnt = run[tid];
+        uint32_t inc = wave_inclusive_scan(cnt, SumOp());
+        lstart[tid] = inc - cnt;                    // exclusive inside the wavefront
+        if ((tid & (kWave - 1)) == kWave - 1) wcnt[tid / kWave] = inc;   // wavefront totals
+    }
+    __syncthreads();
+    if (tid < PART_BUCKETS) {
+        uint32_t add = 0;
+        for (int k = 0; k < tid / kWave; ++k) add += wcnt[k];
+        lstart[tid] += add;
+    }
+    __syncthreads();
+    // stage the records at their sorted tile-local position
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        if (j * PART_THREADS + tid < tile_n) {
+            const uint32_t pos = lstart[d[j]] + rank[j];
+            l_s[pos] = s[j]; l_e[pos] = e[j]; l_c[pos] = c[j]; l_r[pos] = r[j];
+            l_d[pos] = (unsigned char)d[j];
+        }
+    }
+    __syncthreads();
+    // linear copy-out: consecutive threads write consecutive elements of one bucket run
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j) {
+        const int il = j * PART_THREADS + tid;
+        if (il < tile_n) {
+            const uint32_t dd = l_d[il];
+            const uint32_t g = goff[dd] + ((uint32_t)il - lstart[dd]);
+            os[g] = l_s[il]; oe[g] = l_e[il]; oc[g] = l_c[il]; orow[g] = l_r[il];
+        }
+    }
 }
 
 }  // namespace ivj

@@ -44,7 +44,7 @@ class _Side(C.Structure):
 
 class _Opts(C.Structure):
     _fields_ = [("filter_op", C.c_int32), ("n_contigs", C.c_int32), ("nearest_k", C.c_int32),
-                ("include_overlaps", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("include_overlaps", C.c_int32), ("partition_mode", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class _Pairs(C.Structure):
@@ -129,8 +129,9 @@ def _host_side(contig, start, end) -> Tuple[_Side, tuple]:
     return _Side(c.ctypes.data, s.ctypes.data, e.ctypes.data, c.shape[0], None), (c, s, e)
 
 
-def make_opts(strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True) -> _Opts:
+def make_opts(strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True, partition_mode: int = 0) -> _Opts:
     o = _Opts()
+    o.partition_mode = int(partition_mode)
     o.filter_op = FILTER_STRICT if strict else FILTER_WEAK
     o.n_contigs = int(n_contigs)
     o.nearest_k = int(k)
@@ -178,11 +179,12 @@ class Engine:
             pass
 
     # ---- host-buffer entry points (numpy in, numpy out) --------------------
-    def overlap(self, probe, build, strict: bool, n_contigs: int):
-        """probe/build: (contig_id, start, end) int32 arrays -> (probe_idx, build_idx)."""
+    def overlap(self, probe, build, strict: bool, n_contigs: int, partition_mode: int = 0):
+        """probe/build: (contig_id, start, end) int32 arrays -> (probe_idx, build_idx).
+        partition_mode: 0 auto, 1 force the bucketed path, 2 never (pairs then come in probe-row order)."""
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
-        o = make_opts(strict, n_contigs)
+        o = make_opts(strict, n_contigs, partition_mode=partition_mode)
         out = _Pairs()
         _check(self.L, self.L.ivj_overlap(self.h, C.byref(ps), C.byref(bs), C.byref(o), C.byref(out)), "ivj_overlap")
         try:

@@ -19,13 +19,23 @@ def eng():
     return _engine.Engine(0)
 
 
+def _canon(p, b):
+    """Probe rows may come in bucket order (partitioned path); the pairs of one probe row stay
+    contiguous and ordered, so a STABLE sort by probe row restores the oracle's exact order."""
+    o = np.argsort(p, kind="stable")
+    return p[o], b[o]
+
+
 def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1, True), (1, False), (3, True), (4, False))):
     ps, bs = O.Side(*probe), O.Side(*build)
     ix = O.Index(bs, n_contigs)
-    p, b = eng.overlap(probe, build, strict, n_contigs)
     ep, eb = (O.overlap_brute(ps, bs, strict) if brute else O.overlap_fast(ix, ps, strict))
+    p, b = eng.overlap(probe, build, strict, n_contigs, partition_mode=2)      # probe-row order, exact
     assert len(p) == len(ep), (len(p), len(ep))
     assert (p == ep).all() and (b == eb).all()
+    p, b = _canon(*eng.overlap(probe, build, strict, n_contigs, partition_mode=1))   # bucketed path
+    assert len(p) == len(ep), ("partitioned", len(p), len(ep))
+    assert (p == ep).all() and (b == eb).all(), "partitioned path"
     c = eng.count_overlaps(probe, build, strict, n_contigs)
     ec = O.count_overlaps_brute(ps, bs, strict) if brute else O.count_overlaps_fast(ix, ps, strict)
     assert (c == ec).all()
@@ -94,9 +104,10 @@ def test_inverted_rows_follow_the_inequality(eng):
         f = rng.random(3000) < 0.2
         probe = (c, np.where(f, e, s).astype(np.int32), np.where(f, s, e).astype(np.int32))
         ps, bs = O.Side(*probe), O.Side(*build)
-        p, b = eng.overlap(probe, build, strict, 2)
         ep, eb = O.overlap_brute(ps, bs, strict)
-        assert (p == ep).all() and (b == eb).all()
+        for mode in (2, 1):
+            p, b = _canon(*eng.overlap(probe, build, strict, 2, partition_mode=mode))
+            assert (p == ep).all() and (b == eb).all(), mode
         assert (eng.count_overlaps(probe, build, strict, 2) == O.count_overlaps_brute(ps, bs, strict)).all()
 
 
@@ -146,7 +157,7 @@ def test_dense_nested_build(eng):
     _cmp_all(eng, probe, (c, s, e), 1, True, nearest_cfgs=((1, True), (2, False)))
 
 
-def _device_overlap(eng, probe, build, strict, n_contigs):
+def _device_overlap(eng, probe, build, strict, n_contigs, partition_mode=0):
     """Device-resident entry points: what bench.py times."""
     ptrs, sides = [], []
     for side in (probe, build):
@@ -158,7 +169,7 @@ def _device_overlap(eng, probe, build, strict, n_contigs):
             ps.append(p)
         ptrs += ps
         sides.append(eng.dev_side(ps[0], ps[1], ps[2], n))
-    opts = _engine.make_opts(strict, n_contigs)
+    opts = _engine.make_opts(strict, n_contigs, partition_mode=partition_mode)
     ix = eng.index_build_dev(sides[1], opts)
     total = eng.overlap_count_dev(ix, sides[0], opts)
     op, ob = eng.dev_alloc(max(4 * total, 16)), eng.dev_alloc(max(4 * total, 16))
@@ -179,9 +190,11 @@ def _device_overlap(eng, probe, build, strict, n_contigs):
 def test_device_resident_api_matches_host_api(eng):
     probe = synth.make_side(300_001, 42, synth.PROBE_LEN, 24)
     build = synth.make_side(50_003, 43, synth.BUILD_LEN, 24)
-    hp, hb, counts = _device_overlap(eng, probe, build, True, 24)
-    p, b = eng.overlap(probe, build, True, 24)
-    assert (hp == p).all() and (hb == b).all()
+    p, b = eng.overlap(probe, build, True, 24, partition_mode=2)
+    for mode in (2, 1):
+        hp, hb, counts = _device_overlap(eng, probe, build, True, 24, partition_mode=mode)
+        hp, hb = _canon(hp, hb)
+        assert (hp == p).all() and (hb == b).all(), mode
     assert (counts == np.bincount(p, minlength=len(probe[0]))).all()
     with pytest.raises(_engine.EngineError):      # fill without a matching count
         opts = _engine.make_opts(True, 24)
@@ -196,7 +209,10 @@ def test_full_size_config2_properties(eng):
     predicate; per-probe multiplicities equal count_overlaps; checksum of build rows equals the
     oracle's."""
     probe, build, nc = synth.workload("overlap_10M_1M_1contig")
-    hp, hb, counts = _device_overlap(eng, probe, build, True, nc)
+    hp, hb, counts = _device_overlap(eng, probe, build, True, nc)      # auto -> bucketed path at this size
+    raw_runs = int((np.diff(hp) != 0).sum()) + 1
+    hp, hb = _canon(hp, hb)
+    assert raw_runs == len(np.unique(hp))          # the pairs of one probe row were contiguous
     ps, bs = O.Side(*probe), O.Side(*build)
     ix = O.Index(bs, nc)
     ecounts = O.count_overlaps_fast(ix, ps, True)

@@ -32,7 +32,9 @@ def check(eng, probe, build, nc, strict, tag):
     ix = O.Index(bs, nc)
     ok = True
     t0 = time.time()
-    p, b = eng.overlap(probe, build, strict, nc)
+    p, b = eng.overlap(probe, build, strict, nc, partition_mode=1)
+    o = np.argsort(p, kind="stable")
+    p, b = p[o], b[o]
     ep, eb = O.overlap_fast(ix, ps, strict)
     if len(p) != len(ep) or (p != ep).any() or (b != eb).any():
         ok = False
