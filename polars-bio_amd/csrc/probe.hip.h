@@ -195,27 +195,38 @@ __device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t
 template <bool STRICT>
 __device__ __forceinline__ bool window_mask(const IndexView& ix, int a, int hi, int32_t qs, uint32_t& mask, int& cnt) {
     mask = 0; cnt = 0;
-    int p = hi - 1;
-#pragma unroll 1
-    for (int t = 0; t < 8; ++t) {
-        int2 v[4];
+    const int top = hi - 1;
+    int p = top;
+    // rows are fetched as 32-byte aligned groups of four (end,pmax) pairs: two 16-byte loads per
+    // group, both in one 64-byte line.  Rows of the group above p or below a are ignored (the
+    // array is padded, so the loads stay in bounds).
+    while (p >= a) {
+        const int base = p & ~3;
+        const int4 v01 = *reinterpret_cast<const int4*>(ix.ep + base);
+        const int4 v23 = *reinterpret_cast<const int4*>(ix.ep + base + 2);
+        const int32_t en[4] = {v01.x, v01.z, v23.x, v23.z};
+        const int32_t pm[4] = {v01.y, v01.w, v23.y, v23.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (p - j >= a) ? ix.ep[p - j] : make_int2(0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (p - j < a || !lt_op<STRICT>(qs, v[j].y)) { cnt = __popc(mask); return true; }
-            if (lt_op<STRICT>(qs, v[j].x)) mask |= 1u << (4 * t + j);
+        for (int j = 3; j >= 0; --j) {
+            const int idx = base + j;
+            if (idx > p) continue;
+            if (idx < a || !lt_op<STRICT>(qs, pm[j])) { cnt = __popc(mask); return true; }
+            if (top - idx >= 32) {
+                // window longer than the mask: exact count, the fill pass rescans
+                cnt = __popc(mask);
+                for (int q = idx; q >= a; --q) {
+                    const int2 v = ix.ep[q];
+                    if (!lt_op<STRICT>(qs, v.y)) break;
+                    cnt += lt_op<STRICT>(qs, v.x) ? 1 : 0;
+                }
+                return false;
+            }
+            if (lt_op<STRICT>(qs, en[j])) mask |= 1u << (top - idx);
         }
-        p -= 4;
+        p = base - 1;
     }
     cnt = __popc(mask);
-    if (p < a || !lt_op<STRICT>(qs, ix.ep[p].y)) return true;
-    for (; p >= a; --p) {                      // long window: exact count, the fill pass rescans
-        const int2 v = ix.ep[p];
-        if (!lt_op<STRICT>(qs, v.y)) break;
-        cnt += lt_op<STRICT>(qs, v.x) ? 1 : 0;
-    }
-    return false;
+    return true;
 }
 
 // exact count by the bounded backward scan (valid for every input, including
@@ -390,8 +401,12 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
     if (threadIdx.x == 0) tile_tot[blockIdx.x] = tot;
 }
 
-// Pass 2.  tile_base = exclusive scan of tile_tot.  Pairs of one probe are written in
-// ascending (build.start, build row) order: the backward scan fills its slots from the top.
+// Pass 2.  tile_base = exclusive scan of tile_tot.  The pairs of one probe are emitted in
+// ascending (build.start, build row) order.  The pairs of a tile occupy ONE contiguous output
+// range, so they are first compacted in LDS at their tile-local offset and then copied out with
+// fully coalesced stores; tiles with more than FILL_STAGE pairs write directly.
+constexpr int FILL_STAGE = 3072;
+
 template <bool STRICT>
 __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
                                                                 bool vec_ok, const int32_t* __restrict__ hi_in,
@@ -401,45 +416,72 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
                                                                 int32_t* __restrict__ out_probe,
                                                                 int32_t* __restrict__ out_build) {
     __shared__ long long lds[PROBE_THREADS / kWave];
+    __shared__ int32_t st_p[FILL_STAGE];
+    __shared__ int32_t st_b[FILL_STAGE];
     const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
-    int32_t hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS];
+    int32_t hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS], row[PROBE_ITEMS];
     load_items(hi_in, i0, n, vec_ok, 0, hi);
     load_items(cnt_in, i0, n, vec_ok, 0, x);
     long long tsum = 0;
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) { cnt[k] = hi[k] < 0 ? x[k] : __popc((uint32_t)x[k]); tsum += cnt[k]; }
-    long long tot;
-    long long off = tile_base[blockIdx.x] + block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
-#pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
-        if (cnt[k] == 0) continue;
-        const int32_t row = probe_ids ? probe_ids[i0 + k] : (int32_t)(i0 + k);
-        if (hi[k] >= 0) {
-            // mask mode: bit j <=> row hi-1-j; ascending (start,row) order = descending j
-            uint32_t m = (uint32_t)x[k];
-            long long o = off;
-            while (m) {
-                const int j = 31 - __clz(m);
-                m &= ~(1u << j);
-                out_probe[o] = row;
-                out_build[o] = ix.b_row[hi[k] - 1 - j];
-                ++o;
-            }
-        } else {
-            const int32_t qs = ps[i0 + k];
-            const int h = hi[k] & 0x7fffffff;
-            int found = 0;
-            for (int p = h - 1; found < cnt[k] && p >= 0; --p) {
-                const int2 v = ix.ep[p];
-                if (lt_op<STRICT>(qs, v.x)) {
-                    const long long o = off + (cnt[k] - 1 - found);
-                    out_probe[o] = row;
-                    out_build[o] = ix.b_row[p];
-                    ++found;
+        cnt[k] = hi[k] < 0 ? x[k] : __popc((uint32_t)x[k]);
+        tsum += cnt[k];
+        row[k] = (int32_t)(i0 + k);
+    }
+    if (probe_ids && tsum) {
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) if (cnt[k]) row[k] = probe_ids[i0 + k];
+    }
+    long long tot;
+    const long long loc0 = block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
+    const long long tbase = tile_base[blockIdx.x];
+    // the tile's output range is processed in windows of FILL_STAGE pairs (usually one)
+    for (long long w0 = 0; w0 < tot; w0 += FILL_STAGE) {
+        const long long w1 = w0 + FILL_STAGE;
+        long long off = loc0;                                  // tile-local offset of the current probe
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) {
+            const long long end = off + cnt[k];
+            if (cnt[k] != 0 && end > w0 && off < w1) {
+                if (hi[k] >= 0) {
+                    // mask mode: bit j <=> row hi-1-j; ascending (start,row) order = descending j
+                    uint32_t m = (uint32_t)x[k];
+                    long long o = off;
+                    while (m) {
+                        const int j = 31 - __clz(m);
+                        m &= ~(1u << j);
+                        if (o >= w0 && o < w1) {
+                            st_p[o - w0] = row[k];
+                            st_b[o - w0] = ix.b_row[hi[k] - 1 - j];
+                        }
+                        ++o;
+                    }
+                } else {
+                    // long window (flagged): rescan; slot of the f-th match from the top is end-1-f
+                    const int32_t qs = ps[i0 + k];
+                    const int h = hi[k] & 0x7fffffff;
+                    int found = 0;
+                    for (int p = h - 1; found < cnt[k] && p >= 0; --p) {
+                        const int2 v = ix.ep[p];
+                        if (lt_op<STRICT>(qs, v.x)) {
+                            const long long o = end - 1 - found;
+                            if (o < w0) break;
+                            if (o < w1) { st_p[o - w0] = row[k]; st_b[o - w0] = ix.b_row[p]; }
+                            ++found;
+                        }
+                    }
                 }
             }
+            off = end;
         }
-        off += cnt[k];
+        __syncthreads();
+        const int t = (int)((tot - w0) < (long long)FILL_STAGE ? (tot - w0) : (long long)FILL_STAGE);
+        for (int i = threadIdx.x; i < t; i += PROBE_THREADS) {
+            out_probe[tbase + w0 + i] = st_p[i];
+            out_build[tbase + w0 + i] = st_b[i];
+        }
+        __syncthreads();
     }
 }
 
@@ -587,7 +629,7 @@ constexpr int PART_BUCKETS = 256;   // bucket 255 = probes without any candidate
 
 // dynamic LDS of k_part_scatter
 constexpr size_t PART_LDS_BYTES = 4 * (size_t)PART_TILE * 4 /* s,e,c,row */ + (size_t)PART_TILE /* bucket ids */ +
-                                  (size_t)PART_WAVES * PART_BUCKETS * 4 + 3 * PART_BUCKETS * 4;
+                                  (size_t)PART_WAVES * PART_BUCKETS * 4 + 3 * PART_BUCKETS * 4 + 16;
 
 template <bool STRICT>
 __device__ __forceinline__ uint32_t probe_bucket(const IndexView& ix, int32_t c, int32_t qe, int bshift) {
@@ -623,14 +665,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(IndexView ix, const 
     if (threadIdx.x < PART_BUCKETS) h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)tile * PART_TILE;
-    const uint64_t lt = lanemask_lt();
-#pragma unroll 2
+#pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j) {
         const int64_t i = base + (int64_t)j * PART_THREADS + threadIdx.x;
-        const bool valid = i < n;
-        const uint32_t d = valid ? probe_bucket<STRICT>(ix, pc[i], pe[i], bshift) : 0u;
-        const uint64_t peers = wave_match8(d, valid);
-        if (valid && (peers & lt) == 0) atomicAdd(&h[d], (uint32_t)__popcll(peers));
+        if (i < n) atomicAdd(&h[probe_bucket<STRICT>(ix, pc[i], pe[i], bshift)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < PART_BUCKETS) blk_hist[(int64_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];
@@ -655,14 +693,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(IndexView ix, con
     uint32_t* lstart = run + PART_BUCKETS;                                   // tile-local start of each bucket
     uint32_t* goff = lstart + PART_BUCKETS;                                  // global offset of (bucket, tile)
     unsigned char* l_d = reinterpret_cast<unsigned char*>(goff + PART_BUCKETS);
+    uint32_t* wtot = reinterpret_cast<uint32_t*>(l_d + PART_TILE);           // 4 wavefront totals of the 256-value scan
 
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
-    const int tid = threadIdx.x, w = tid / kWave;
-    if (tid < PART_BUCKETS) {
-        run[tid] = 0;
-        goff[tid] = blk_off[(int64_t)tid * ntiles + tile];
-    }
+    const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+    if (tid < PART_BUCKETS) goff[tid] = blk_off[(int64_t)tid * ntiles + tile];
     for (int k = tid; k < PART_WAVES * PART_BUCKETS; k += PART_THREADS) wcnt[k] = 0;
     __syncthreads();
     const int64_t base = (int64_t)tile * PART_TILE;
@@ -670,54 +706,57 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(IndexView ix, con
     const uint64_t lt = lanemask_lt();
     int32_t c[PART_ITEMS], s[PART_ITEMS], e[PART_ITEMS], r[PART_ITEMS];
     uint32_t d[PART_ITEMS], rank[PART_ITEMS];
+    // wavefront w owns the contiguous chunk [w*512, (w+1)*512) of the tile: item j of lane l is
+    // tile element w*512 + j*64 + l (every load is one contiguous 256-byte segment).
+    const int chunk0 = w * (PART_ITEMS * kWave);
 #pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j) {
-        const int64_t i = base + (int64_t)j * PART_THREADS + tid;
-        const bool valid = i < n;
+        const int il = chunk0 + j * kWave + lane;
+        const int64_t i = base + il;
+        const bool valid = il < tile_n;
         c[j] = valid ? pc[i] : -1; s[j] = valid ? ps[i] : 0; e[j] = valid ? pe[i] : 0;
         r[j] = valid ? (row_id ? row_id[i] : (int32_t)i) : -1;
     }
-    // stable tile-local rank of every probe inside its bucket (same scheme as k_rs_scatter)
+    // rank inside (wavefront chunk, bucket): the row wcnt[w][*] is private to wavefront w, so the
+    // eight rounds need no workgroup barrier (LDS operations of one wavefront execute in order).
+    uint32_t* my = wcnt + w * PART_BUCKETS;
+#pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j) {
-        const bool valid = j * PART_THREADS + tid < tile_n;
+        const bool valid = chunk0 + j * kWave + lane < tile_n;
         d[j] = valid ? probe_bucket<STRICT>(ix, c[j], e[j], bshift) : 0u;
         const uint64_t peers = wave_match8(d[j], valid);
         const uint32_t rk = (uint32_t)__popcll(peers & lt);
-        if (valid && rk == 0) wcnt[w * PART_BUCKETS + d[j]] = (uint32_t)__popcll(peers);
-        __syncthreads();
-        uint32_t v = 0;
-        if (valid) {
-            v = run[d[j]] + rk;
-            for (int k = 0; k < w; ++k) v += wcnt[k * PART_BUCKETS + d[j]];
-        }
-        rank[j] = v;
-        __syncthreads();
-        if (tid < PART_BUCKETS) {
-            uint32_t sum = 0;
-#pragma unroll
-            for (int k = 0; k < PART_WAVES; ++k) { sum += wcnt[k * PART_BUCKETS + tid]; wcnt[k * PART_BUCKETS + tid] = 0; }
-            run[tid] += sum;
-        }
-        __syncthreads();
+        const uint32_t before = valid ? my[d[j]] : 0u;
+        rank[j] = before + rk;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rk == 0) my[d[j]] = before + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
     }
-    // tile-local exclusive scan of the bucket counts (256 values: first four wavefronts)
+    __syncthreads();
+    // per bucket: exclusive prefix over the wavefronts (in place) and the tile total
     if (tid < PART_BUCKETS) {
-        const uint32_t cnt = run[tid];
-        uint32_t inc = wave_inclusive_scan(cnt, SumOp());
-        lstart[tid] = inc - cnt;                    // exclusive inside the wavefront
-        if ((tid & (kWave - 1)) == kWave - 1) wcnt[tid / kWave] = inc;   // wavefront totals
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < PART_WAVES; ++k) { const uint32_t t = wcnt[k * PART_BUCKETS + tid]; wcnt[k * PART_BUCKETS + tid] = x; x += t; }
+        run[tid] = x;
+        // tile-local exclusive scan of the bucket totals (256 values: four full wavefronts)
+        const uint32_t inc = wave_inclusive_scan(x, SumOp());
+        lstart[tid] = inc - x;
+        if (lane == kWave - 1) wtot[tid / kWave] = inc;
     }
     __syncthreads();
     if (tid < PART_BUCKETS) {
         uint32_t add = 0;
-        for (int k = 0; k < tid / kWave; ++k) add += wcnt[k];
+        for (int k = 0; k < tid / kWave; ++k) add += wtot[k];
         lstart[tid] += add;
     }
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PART_ITEMS; ++j) rank[j] += wcnt[w * PART_BUCKETS + d[j]];
     // stage the records at their sorted tile-local position
 #pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j) {
-        if (j * PART_THREADS + tid < tile_n) {
+        if (chunk0 + j * kWave + lane < tile_n) {
             const uint32_t pos = lstart[d[j]] + rank[j];
             l_s[pos] = s[j]; l_e[pos] = e[j]; l_c[pos] = c[j]; l_r[pos] = r[j];
             l_d[pos] = (unsigned char)d[j];
