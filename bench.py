@@ -196,11 +196,23 @@ def main():
             dom_name, dom = k, v
     alg_bytes = algorithmic_bytes(op, d_probe.n, d_build.n, local_units)
     roofline = None
+    traffic = None
+    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (same command)
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_traffic*.json")), reverse=True):
+            pm = json.load(open(f))
+            if pm.get("workload") == args.workload and n_gpus == 1 and args.scale == 1.0:
+                for kname, kv in pm["kernels"].items():
+                    if dom_name and ("k_" + dom_name) in kname:
+                        traffic = kv["hbm_bytes_per_launch_corrected"]
+                break
+    except Exception:
+        traffic = None
     if dom is not None and dom["launches"] > 0:
         avg_ms = dom["ms"] / dom["launches"]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel_avg_ms": round(avg_ms, 4), "algorithmic_bytes": int(alg_bytes),
                     "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in ktimes.items()}}

@@ -14,6 +14,13 @@ for stage in "$@"; do
     c4) echo "== bench config4 nearest"; timeout 1200 python bench.py --workload nearest_50M_2M_24contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c4.err | tee gpurun_out/bench_c4.json; tail -22 gpurun_out/bench_c4.err ;;
     c5) echo "== bench config5 count_overlaps"; timeout 1200 python bench.py --workload count_200M_200k_24contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c5.err | tee gpurun_out/bench_c5.json; tail -22 gpurun_out/bench_c5.err ;;
     prof) echo "== rocprofv3 stats (config3)"; (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_c3" -o c3 --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_c3.out" 2> "$OLDPWD/gpurun_out/prof_c3.err"); tail -3 gpurun_out/prof_c3.out; find gpurun_out/prof_c3 -name "*stats*" | head; f=$(find gpurun_out/prof_c3 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f" ;;
+    pmc) echo "== rocprofv3 PMC passes (config3)";
+      for ctr in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --pmc $ctr -d "$OLDPWD/gpurun_out/pmc_$ctr" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmc_$ctr.out" 2> "$OLDPWD/gpurun_out/pmc_$ctr.err");
+        tail -2 gpurun_out/pmc_$ctr.err; ls gpurun_out/pmc_$ctr | head;
+      done;
+      f=$(find gpurun_out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); [ -n "$f" ] && head -3 "$f";
+      python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.err; tail -5 gpurun_out/pmc_summary.err; head -c 3000 gpurun_out/pmc_summary.json ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
