@@ -102,8 +102,12 @@ struct ivj_index {
     int32_t* e_pos = nullptr;
     int4* cmeta = nullptr;
     uint32_t* bins = nullptr;
+    int4* cmeta_e = nullptr;
+    uint32_t* bins_e = nullptr;
+    int32_t* pargmax = nullptr;
     int64_t bins_len = 0;
     bool has_end_order = false;
+    bool has_argmax = false;
     char* slab = nullptr;      // single allocation holding every array above
     size_t slab_cap = 0;
 };
@@ -234,7 +238,7 @@ IndexView view_of(const ivj_index* ix) {
     IndexView v;
     v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
     v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
-    v.cmeta = ix->cmeta; v.bins = ix->bins;
+    v.cmeta = ix->cmeta; v.bins = ix->bins; v.cmeta_e = ix->cmeta_e; v.bins_e = ix->bins_e; v.pargmax = ix->pargmax;
     return v;
 }
 
@@ -254,8 +258,9 @@ int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->has_end_order) return IVJ_OK;
     const int64_t n = ix->n;
     if (n == 0) { ix->has_end_order = true; return IVJ_OK; }
-    IVJ_TRY(arena_reserve(ctx, sort_scratch_bytes(n) + 4096));
+    IVJ_TRY(arena_reserve(ctx, sort_scratch_bytes(n) + align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4) + 4096));
     SortBufs sb; take_sort_bufs(ctx, n, sb);
+    uint32_t* bins_part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
     LAUNCH(ctx, "end_keys", k_end_keys, grid1d(n, 256), 256, (const int2*)ix->ep, n, sb.kA, sb.vA);
     bool fl = radix_sort_pairs(ctx, sb, n, 32);
     if (fl) { std::swap(sb.kA, sb.kB); std::swap(sb.vA, sb.vB); }
@@ -263,8 +268,31 @@ int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
     LAUNCH(ctx, "gather", k_gather_u32, grid1d(n, 256), 256, (const int32_t*)ix->b_contig, (const uint32_t*)sb.vA, n, sb.kA);
     fl = radix_sort_pairs(ctx, sb, n, bits_for((uint32_t)ix->n_contigs));
     const uint32_t* pos = fl ? sb.vB : sb.vA;
+    const uint32_t* ckeys = fl ? sb.kB : sb.kA;
     LAUNCH(ctx, "end_finalize", k_end_finalize, grid1d(n, 256), 256, (const int2*)ix->ep, pos, n, ix->e_end, ix->e_pos);
+    // direct-address table over the sorted ends (same segments as the start order)
+    if (ix->n_contigs > 0) {
+        LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(ix->n_contigs, 256), 256, (const int32_t*)ix->seg,
+               (const int32_t*)ix->e_end, ix->n_contigs, ix->cmeta_e);
+        HIP_TRY(hipMemsetAsync(ix->bins_e, 0, (size_t)ix->bins_len * 4, ctx->stream));
+        LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->e_end, (const int32_t*)ckeys, n,
+               ix->n_contigs, (const int4*)ix->cmeta_e, ix->bins_e);
+        device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", ix->bins_e, ix->bins_e, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
+    }
     ix->has_end_order = true;
+    return IVJ_OK;
+}
+
+// pargmax[p] = position of the first row attaining the prefix max at p (nearest, k = 1)
+int build_argmax(ivj_ctx* ctx, ivj_index* ix) {
+    if (ix->has_argmax) return IVJ_OK;
+    const int64_t n = ix->n;
+    if (n == 0) { ix->has_argmax = true; return IVJ_OK; }
+    IVJ_TRY(arena_reserve(ctx, align_up((size_t)(scan_num_tiles(n) + 1) * 4) + 4096));
+    uint32_t* part = arena_take<uint32_t>(ctx, scan_num_tiles(n) + 1);
+    LAUNCH(ctx, "pmax_change", k_pmax_change, grid1d(n, 256), 256, (const int2*)ix->ep, (const int32_t*)ix->b_contig, n, (uint32_t*)ix->pargmax);
+    device_scan<uint32_t, MaxOp, true>(ctx, "argmax_scan", (uint32_t*)ix->pargmax, (uint32_t*)ix->pargmax, n, 0u, part, (uint32_t*)nullptr);
+    ix->has_argmax = true;
     return IVJ_OK;
 }
 
@@ -278,8 +306,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t col = align_up(nn * 4);
         const size_t nc = (size_t)opts->n_contigs;
         ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
-        const size_t small = align_up((nc + 2) * 4) + align_up(16) + align_up((nc + 1) * 32);   // seg, flags, cmeta
-        const size_t need = 5 * col + align_up(nn * 8) + align_up((size_t)ix->bins_len * 4) + small + 256;
+        const size_t small = align_up((nc + 2) * 4) + align_up(16) + 2 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e
+        const size_t need = 6 * col + align_up(nn * 8) + 2 * align_up((size_t)ix->bins_len * 4) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
             ctx->ix_cache = nullptr; ctx->ix_cache_cap = 0;
@@ -295,11 +323,14 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->b_contig = (int32_t*)p; p += col;
         ix->e_end = (int32_t*)p; p += col;
         ix->e_pos = (int32_t*)p; p += col;
+        ix->pargmax = (int32_t*)p; p += col;
         ix->bins = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
+        ix->bins_e = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
         char* small_base = p;
         ix->seg = (int32_t*)p; p += align_up((nc + 2) * 4);
         ix->flags = (int32_t*)p; p += align_up(16);
-        ix->cmeta = (int4*)p;
+        ix->cmeta = (int4*)p; p += align_up((nc + 1) * 32);
+        ix->cmeta_e = (int4*)p;
         // seg, flags and cmeta start zeroed: an empty index answers every probe with "no rows"
         hipError_t e = hipMemsetAsync(small_base, 0, small, ctx->stream);
         if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(index meta): ") + hipGetErrorString(e)));
@@ -499,6 +530,8 @@ int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_op
     IndexView v = view_of(ix);
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
     if (k == 1 && opts->include_overlaps) {
+        IVJ_TRY(build_argmax(ctx, ix));
+        v = view_of(ix);
         const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
         const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
         if (strict) LAUNCH(ctx, "nearest_k1", (k_nearest_k1<true>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, idx, (long long*)dist, nf);

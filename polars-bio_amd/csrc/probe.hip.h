@@ -38,6 +38,9 @@ struct IndexView {
     const int32_t* flags;  // flags[0] != 0: some build row has start > end
     const int4* cmeta;     // per contig: {a, b, ulo, uhi} {shift, tb, 0, 0}  (two int4)
     const uint32_t* bins;  // direct-address table: bins[tb + j] = first position with ustart >= ulo + (j << shift)
+    const int4* cmeta_e;   // the same pair of structures over the end-sorted order (e_end)
+    const uint32_t* bins_e;
+    const int32_t* pargmax; // position of the first row that attains ep[p].y (prefix max) -- nearest only
     int32_t n_contigs;
 };
 
@@ -129,21 +132,21 @@ __device__ __forceinline__ void bound_hi4(const IndexView& ix, const int (&a)[PR
     for (int k = 0; k < PROBE_ITEMS; ++k) out[k] = lo[k];
 }
 
-// hi-bound through the direct-address table, four probes interleaved.  target = q.end (STRICT:
-// first start >= q.end) or q.end + 1 (WEAK: first start > q.end), compared on the flipped
-// (unsigned-ordered) coordinates so that negative starts and INT32_MAX ends need no special case.
-template <bool STRICT>
-__device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t (&c)[PROBE_ITEMS],
-                                              const bool (&valid)[PROBE_ITEMS], const int32_t (&qe)[PROBE_ITEMS],
-                                              int (&a)[PROBE_ITEMS], int (&b)[PROBE_ITEMS], int (&out)[PROBE_ITEMS]) {
+// Lower bound through a direct-address table, four probes interleaved: out[k] = first position p
+// of contig c[k]'s segment with flip(keys[p]) >= tu[k].  Targets are compared on the flipped
+// (unsigned-ordered) coordinates in 64 bits, so negative coordinates and INT32_MAX + 1 need no
+// special case.  One table read + a search over the rows of one bin.
+__device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const uint32_t* __restrict__ bins,
+                                        const int32_t* __restrict__ keys, int32_t n_contigs,
+                                        const int32_t (&c)[PROBE_ITEMS], const bool (&valid)[PROBE_ITEMS],
+                                        const unsigned long long (&tu)[PROBE_ITEMS],
+                                        int (&a)[PROBE_ITEMS], int (&b)[PROBE_ITEMS], int (&out)[PROBE_ITEMS]) {
     int lo[PROBE_ITEMS], hi[PROBE_ITEMS];
-    unsigned long long tu[PROBE_ITEMS];
     int4 m0[PROBE_ITEMS], m1[PROBE_ITEMS];
-    bool ok[PROBE_ITEMS];
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
-        ok[k] = valid[k] && (uint32_t)c[k] < (uint32_t)ix.n_contigs;
-        if (ok[k]) { m0[k] = ix.cmeta[2 * c[k]]; m1[k] = ix.cmeta[2 * c[k] + 1]; }
+        const bool ok = valid[k] && (uint32_t)c[k] < (uint32_t)n_contigs;
+        if (ok) { m0[k] = cmeta[2 * c[k]]; m1[k] = cmeta[2 * c[k] + 1]; }
         else { m0[k] = make_int4(0, 0, 0, 0); m1[k] = make_int4(0, 0, 0, 0); }
     }
     uint32_t t0[PROBE_ITEMS], t1[PROBE_ITEMS];
@@ -152,15 +155,14 @@ __device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t
     for (int k = 0; k < PROBE_ITEMS; ++k) {
         a[k] = m0[k].x; b[k] = m0[k].y;
         const uint32_t ulo = (uint32_t)m0[k].z, uhi = (uint32_t)m0[k].w;
-        tu[k] = (unsigned long long)flip(qe[k]) + (STRICT ? 0ull : 1ull);
         inb[k] = false;
         if (b[k] <= a[k] || tu[k] <= ulo) { lo[k] = hi[k] = a[k]; }
         else if (tu[k] > uhi) { lo[k] = hi[k] = b[k]; }
         else {
             const uint32_t j = ((uint32_t)tu[k] - ulo) >> m1[k].x;
             inb[k] = true;
-            t0[k] = ix.bins[(uint32_t)m1[k].y + j];
-            t1[k] = ix.bins[(uint32_t)m1[k].y + j + 1];
+            t0[k] = bins[(uint32_t)m1[k].y + j];
+            t1[k] = bins[(uint32_t)m1[k].y + j + 1];
         }
     }
 #pragma unroll
@@ -174,7 +176,7 @@ __device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t
             m[k] = lo[k] + ((hi[k] - lo[k]) >> 1);
             const bool act = lo[k] < hi[k];
             any |= act;
-            v[k] = act ? ix.b_start[m[k]] : 0;
+            v[k] = act ? keys[m[k]] : 0;
         }
         if (!any) break;
 #pragma unroll
@@ -186,6 +188,29 @@ __device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t
     }
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) out[k] = lo[k];
+}
+
+// hi = first position whose start fails "start (<) q.end": first start >= q.end (STRICT) / > q.end (WEAK)
+template <bool STRICT>
+__device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t (&c)[PROBE_ITEMS],
+                                              const bool (&valid)[PROBE_ITEMS], const int32_t (&qe)[PROBE_ITEMS],
+                                              int (&a)[PROBE_ITEMS], int (&b)[PROBE_ITEMS], int (&out)[PROBE_ITEMS]) {
+    unsigned long long tu[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) tu[k] = (unsigned long long)flip(qe[k]) + (STRICT ? 0ull : 1ull);
+    lb_tab4(ix.cmeta, ix.bins, ix.b_start, ix.n_contigs, c, valid, tu, a, b, out);
+}
+// r = first position of the end-sorted segment whose end satisfies "q.start (<) end":
+// first end > q.start (STRICT) / >= q.start (WEAK)
+template <bool STRICT>
+__device__ __forceinline__ void bound_r_tab4(const IndexView& ix, const int32_t (&c)[PROBE_ITEMS],
+                                             const bool (&valid)[PROBE_ITEMS], const int32_t (&qs)[PROBE_ITEMS],
+                                             int (&out)[PROBE_ITEMS]) {
+    unsigned long long tu[PROBE_ITEMS];
+    int a[PROBE_ITEMS], b[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) tu[k] = (unsigned long long)flip(qs[k]) + (STRICT ? 1ull : 0ull);
+    lb_tab4(ix.cmeta_e, ix.bins_e, ix.e_end, ix.n_contigs, c, valid, tu, a, b, out);
 }
 
 // Window of a probe below hi as a 32-bit match mask: bit j set <=> row hi-1-j overlaps.  The scan
@@ -325,6 +350,16 @@ __global__ void k_end_finalize(const int2* __restrict__ ep, const uint32_t* __re
                                int32_t* __restrict__ e_end, int32_t* __restrict__ e_pos) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const uint32_t p = pos[i]; e_end[i] = ep[p].x; e_pos[i] = (int32_t)p; }
+}
+
+// change[p] = p where the prefix max changes (or the segment starts), else 0; an inclusive max-scan
+// turns it into pargmax[p] = position of the first row attaining the prefix max at p.
+__global__ void k_pmax_change(const int2* __restrict__ ep, const int32_t* __restrict__ b_contig, int64_t n,
+                              uint32_t* __restrict__ change) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const bool first = p == 0 || b_contig[p] != b_contig[p - 1] || ep[p].y != ep[p - 1].y;
+    change[p] = first ? (uint32_t)p : 0u;
 }
 
 // Per-contig metadata of the direct-address table: bin width 2^shift chosen so that the contig has
@@ -505,15 +540,22 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
     bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
+    int r[PROBE_ITEMS];
+    bound_r_tab4<STRICT>(ix, c, valid, s, r);
     const bool inv = ix.flags[0] != 0;
+    long long cnt[PROBE_ITEMS];
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
-        if (i0 + k >= n) continue;
         const bool degenerate = inv || (STRICT ? (s[k] >= e[k]) : (s[k] > e[k]));
-        long long cnt;
-        if (!degenerate) cnt = (long long)hi[k] - (long long)bound_r<STRICT>(ix, a[k], b[k], s[k]);
-        else cnt = scan_count<STRICT>(ix, a[k], hi[k], s[k]);
-        counts[i0 + k] = cnt;
+        if (!degenerate) cnt[k] = (long long)hi[k] - (long long)r[k];
+        else cnt[k] = scan_count<STRICT>(ix, a[k], hi[k], s[k]);
+    }
+    if (i0 + PROBE_ITEMS <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0) {
+        reinterpret_cast<longlong2*>(counts + i0)[0] = make_longlong2(cnt[0], cnt[1]);
+        reinterpret_cast<longlong2*>(counts + i0)[1] = make_longlong2(cnt[2], cnt[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) if (i0 + k < n) counts[i0 + k] = cnt[k];
     }
 }
 
@@ -544,14 +586,20 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
         if (i0 + k >= n) continue;
         int32_t idx = -1; long long dist = -1; int32_t found = 0;
         if (b[k] > a[k]) {
-            const int lo = bound_lo<STRICT>(ix, a[k], hi[k], s[k]);
-            if (lo < hi[k]) { idx = ix.b_row[lo]; dist = 0; found = 1; }
-            else {
+            // lo = first position of [a,hi) whose prefix max satisfies "q.start (<) pmax": walk down
+            // from hi-1 while it holds (pmax is non-decreasing), at most 8 rows, then bound-search.
+            int lo = hi[k];
+            {
+                int p = hi[k] - 1, steps = 0;
+                while (p >= a[k] && steps < 8 && lt_op<STRICT>(s[k], ix.ep[p].y)) { lo = p; --p; ++steps; }
+                if (steps == 8 && p >= a[k]) lo = bound_lo<STRICT>(ix, a[k], p + 1, s[k]);
+            }
+            if (lo < hi[k]) { idx = ix.b_row[lo]; dist = 0; found = 1; }            else {
                 bool have_l = hi[k] > a[k], have_r = hi[k] < b[k];
                 long long dl = 0, dr = 0; int lpos = 0;
                 if (have_l) {
                     const int32_t maxend = ix.ep[hi[k] - 1].y;
-                    lpos = bsearch_pmax<false>(ix.ep, a[k], hi[k], maxend);
+                    lpos = ix.pargmax[hi[k] - 1];
                     dl = (long long)s[k] - (long long)maxend;
                 }
                 if (have_r) dr = gap_dist(s[k], e[k], ix.b_start[hi[k]], ix.ep[hi[k]].x);
