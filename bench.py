@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the CPU-baseline sample")
     ap.add_argument("--kernel-table", action="store_true", help="print a per-kernel HIP-event table to stderr")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-process code path (RCCL init, sharding, all-gatherv) even with one rank")
     return ap.parse_args()
 
 
@@ -130,13 +132,15 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if n_gpus > 1:
+    multi = n_gpus > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=n_gpus)
 
     probe, build, nc, op = gen_workload(args.workload, args.scale)
     n_p_total, n_b_total = len(probe[0]), len(build[0])
-    if n_gpus > 1:
+    if multi:
         lp, lp_ids, lb, lb_ids, mode = D.shard_sides(probe, build, nc, rank, n_gpus)
     else:
         lp, lp_ids, lb, lb_ids, mode = probe, None, build, None, "single"
@@ -147,12 +151,18 @@ def main():
     d_probe = DeviceSide(up(lp[0]), up(lp[1]), up(lp[2]), up(lp_ids) if lp_ids is not None else None)
     d_build = DeviceSide(up(lb[0]), up(lb[1]), up(lb[2]), up(lb_ids) if lb_ids is not None else None)
     join = DeviceJoin(local_rank)
-    gather = n_gpus > 1 and not args.no_gather and op == "overlap"
+    gather = multi and not args.no_gather and op == "overlap"
+
+    state = {}
 
     def step():
         """-> (units this rank produced, result tensors)"""
         if op == "overlap":
-            p, b = join.overlap(d_probe, d_build, True, nc)
+            # the first (warmup) step sizes the result buffers; later steps write into them, so the
+            # timed region holds no device allocation
+            p, b = join.overlap(d_probe, d_build, True, nc, out=state.get("out"))
+            if "out" not in state:
+                state["out"] = (torch.empty_like(p), torch.empty_like(b))
             local = int(p.shape[0])
             if gather:
                 (p, b), _ = D.all_gatherv([p, b])
@@ -162,7 +172,7 @@ def main():
         return d_probe.n, join.nearest(d_probe, d_build, True, nc)
 
     def barrier():
-        if n_gpus > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,7 +190,7 @@ def main():
 
     t = torch.tensor([local_units], dtype=torch.int64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if n_gpus > 1:
+    if multi:
         dist.all_reduce(t)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_units = int(t.item())
@@ -250,14 +260,14 @@ def main():
             "data": "synthetic" if args.scale == 1.0 else f"synthetic (scaled x{args.scale}: INVALID as a headline number)",
             "config": {"workload": args.workload, "probe_rows": n_p_total, "build_rows": n_b_total, "contigs": nc,
                        "filter_op": "Strict", "units_per_step": total_units,
-                       "parallelism": ("single GPU" if n_gpus == 1 else
+                       "parallelism": ("single GPU" if not multi else
                                        f"{mode}-sharded x{n_gpus}, " + ("RCCL all-gatherv in timed region" if gather else "no gather")),
                        "step": "index build (radix sort) + count + scan + fill, inputs and outputs in HBM"},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if n_gpus > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

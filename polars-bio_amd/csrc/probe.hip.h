@@ -216,7 +216,7 @@ __device__ __forceinline__ void bound_r_tab4(const IndexView& ix, const int32_t 
 // Window of a probe below hi as a 32-bit match mask: bit j set <=> row hi-1-j overlaps.  The scan
 // stops at the first row whose prefix max fails "q.start (<) pmax".  Four (end,pmax) pairs are
 // fetched per round so the dependent-load chain is a quarter of the window length.  Returns false
-// (and the exact count in `cnt`) when the window is longer than 32 rows.
+// when the window is longer than 32 rows (the caller then counts it with the whole wavefront).
 template <bool STRICT>
 __device__ __forceinline__ bool window_mask(const IndexView& ix, int a, int hi, int32_t qs, uint32_t& mask, int& cnt) {
     mask = 0; cnt = 0;
@@ -236,22 +236,34 @@ __device__ __forceinline__ bool window_mask(const IndexView& ix, int a, int hi, 
             const int idx = base + j;
             if (idx > p) continue;
             if (idx < a || !lt_op<STRICT>(qs, pm[j])) { cnt = __popc(mask); return true; }
-            if (top - idx >= 32) {
-                // window longer than the mask: exact count, the fill pass rescans
-                cnt = __popc(mask);
-                for (int q = idx; q >= a; --q) {
-                    const int2 v = ix.ep[q];
-                    if (!lt_op<STRICT>(qs, v.y)) break;
-                    cnt += lt_op<STRICT>(qs, v.x) ? 1 : 0;
-                }
-                return false;
-            }
+            if (top - idx >= 32) { cnt = 0; return false; }   // longer than the mask: counted cooperatively
             if (lt_op<STRICT>(qs, en[j])) mask |= 1u << (top - idx);
         }
         p = base - 1;
     }
     cnt = __popc(mask);
     return true;
+}
+
+// Long windows (> 32 rows: dense / deeply nested build sides) are handled by the whole wavefront,
+// one probe at a time: lane l looks at row p0 - l, so a step covers 64 consecutive rows with one
+// coalesced 512-byte read; "q.start (<) pmax" holds for a prefix of the lanes (pmax is
+// non-decreasing in the position), a ballot finds where the window ends and a popcount of the
+// match ballot counts it.
+template <bool STRICT>
+__device__ __forceinline__ int wave_count_window(const IndexView& ix, int a, int hi, int32_t qs) {
+    const int lane = threadIdx.x & (kWave - 1);
+    int cnt = 0;
+    for (int p0 = hi - 1; p0 >= a; p0 -= kWave) {
+        const int p = p0 - lane;
+        int2 v = make_int2(0, 0);
+        if (p >= a) v = ix.ep[p];
+        const bool pass = p >= a && lt_op<STRICT>(qs, v.y);
+        const bool match = pass && lt_op<STRICT>(qs, v.x);
+        cnt += (int)__popcll(__ballot(match));
+        if (__popcll(__ballot(pass)) < kWave) break;
+    }
+    return cnt;
 }
 
 // exact count by the bounded backward scan (valid for every input, including
@@ -421,11 +433,46 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
     for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
     bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
     long long tsum = 0;
+    const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
         uint32_t mask; int cnt;
         const bool small = window_mask<STRICT>(ix, a[k], hi[k], s[k], mask, cnt);
-        x[k] = small ? (int)mask : cnt;
+        x[k] = (int)mask;
+        // wavefront-cooperative exact count of every long window of this round (uniform loop);
+        // four windows per step so that four first-chunk reads are in flight together
+        unsigned long long todo = __ballot(!small);
+        while (todo) {
+            int src[4], ca[4], chi[4]; int32_t cqs[4]; int2 v0[4], v1[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                src[t] = todo ? __ffsll((long long)todo) - 1 : -1;
+                if (todo) todo &= todo - 1;
+                const int sl = src[t] < 0 ? 0 : src[t];
+                ca[t] = __shfl(a[k], sl, kWave); chi[t] = __shfl(hi[k], sl, kWave); cqs[t] = __shfl(s[k], sl, kWave);
+                if (src[t] < 0) { ca[t] = 0; chi[t] = 0; }
+                const int p = chi[t] - 1 - lane;
+                v0[t] = (p >= ca[t]) ? ix.ep[p] : make_int2(0, 0);
+                v1[t] = (p - kWave >= ca[t]) ? ix.ep[p - kWave] : make_int2(0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (src[t] < 0) continue;                      // uniform
+                int c = 0;
+                int2 v = v0[t];
+                int step = 0;
+                for (int p0 = chi[t] - 1; p0 >= ca[t]; p0 -= kWave, ++step) {
+                    const int p = p0 - lane;
+                    if (step == 1) v = v1[t];
+                    else if (step > 1) v = (p >= ca[t]) ? ix.ep[p] : make_int2(0, 0);
+                    const bool pass = p >= ca[t] && lt_op<STRICT>(cqs[t], v.y);
+                    const bool match = pass && lt_op<STRICT>(cqs[t], v.x);
+                    c += (int)__popcll(__ballot(match));
+                    if (__popcll(__ballot(pass)) < kWave) break;
+                }
+                if (lane == src[t]) { cnt = c; x[k] = c; }
+            }
+        }
         if (!small) hi[k] |= (int)0x80000000;      // flag: x is a count, the fill pass rescans
         tsum += cnt;
     }
@@ -471,6 +518,11 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
     long long tot;
     const long long loc0 = block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
     const long long tbase = tile_base[blockIdx.x];
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned long long lt_lanes = (1ull << lane) - 1ull;
+    int32_t qs[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) qs[k] = (hi[k] < 0 && cnt[k] != 0) ? ps[i0 + k] : 0;
     // the tile's output range is processed in windows of FILL_STAGE pairs (usually one)
     for (long long w0 = 0; w0 < tot; w0 += FILL_STAGE) {
         const long long w1 = w0 + FILL_STAGE;
@@ -478,7 +530,8 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
 #pragma unroll
         for (int k = 0; k < PROBE_ITEMS; ++k) {
             const long long end = off + cnt[k];
-            if (cnt[k] != 0 && end > w0 && off < w1) {
+            const bool in_win = cnt[k] != 0 && end > w0 && off < w1;
+            if (in_win) {
                 if (hi[k] >= 0) {
                     // mask mode: bit j <=> row hi-1-j; ascending (start,row) order = descending j
                     uint32_t m = (uint32_t)x[k];
@@ -492,19 +545,53 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
                         }
                         ++o;
                     }
-                } else {
-                    // long window (flagged): rescan; slot of the f-th match from the top is end-1-f
-                    const int32_t qs = ps[i0 + k];
-                    const int h = hi[k] & 0x7fffffff;
+                }
+            }
+            // long windows (flagged): the whole wavefront rescans 64 rows per step; the f-th match
+            // counted from the top of the window owns slot end-1-f, so a ballot + popcount of the
+            // lower lanes gives every matching lane its slot (ascending (start,row) order).
+            unsigned long long todo = __ballot(in_win && hi[k] < 0);
+            while (todo) {
+                int src[4], h[4], c[4]; int32_t cqs[4], crow[4], r0[4], r1[4]; long long cend[4]; int2 v0[4], v1[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    src[t] = todo ? __ffsll((long long)todo) - 1 : -1;
+                    if (todo) todo &= todo - 1;
+                    const int sl = src[t] < 0 ? 0 : src[t];
+                    h[t] = __shfl(hi[k], sl, kWave) & 0x7fffffff;
+                    c[t] = __shfl(cnt[k], sl, kWave);
+                    cqs[t] = __shfl(qs[k], sl, kWave);
+                    crow[t] = __shfl(row[k], sl, kWave);
+                    cend[t] = ((long long)__shfl((int)(end >> 32), sl, kWave) << 32) |
+                              (unsigned long long)(unsigned int)__shfl((int)(end & 0xffffffffll), sl, kWave);
+                    if (src[t] < 0) { h[t] = 0; c[t] = 0; }
+                    const int p = h[t] - 1 - lane;
+                    // (end,pmax) and the build row of 2 x 64 rows per window are requested together, so
+                    // the emission below never waits on a dependent gather
+                    v0[t] = (p >= 0) ? ix.ep[p] : make_int2(0, 0);
+                    r0[t] = (p >= 0) ? ix.b_row[p] : 0;
+                    v1[t] = (p - kWave >= 0) ? ix.ep[p - kWave] : make_int2(0, 0);
+                    r1[t] = (p - kWave >= 0) ? ix.b_row[p - kWave] : 0;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (src[t] < 0) continue;                  // uniform
                     int found = 0;
-                    for (int p = h - 1; found < cnt[k] && p >= 0; --p) {
-                        const int2 v = ix.ep[p];
-                        if (lt_op<STRICT>(qs, v.x)) {
-                            const long long o = end - 1 - found;
-                            if (o < w0) break;
-                            if (o < w1) { st_p[o - w0] = row[k]; st_b[o - w0] = ix.b_row[p]; }
-                            ++found;
+                    int2 v = v0[t];
+                    int32_t br = r0[t];
+                    int step = 0;
+                    for (int p0 = h[t] - 1; found < c[t] && p0 >= 0 && cend[t] - found > w0; p0 -= kWave, ++step) {
+                        const int p = p0 - lane;
+                        if (step == 1) { v = v1[t]; br = r1[t]; }
+                        else if (step > 1) { v = (p >= 0) ? ix.ep[p] : make_int2(0, 0); br = (p >= 0) ? ix.b_row[p] : 0; }
+                        const bool m = p >= 0 && lt_op<STRICT>(cqs[t], v.x);
+                        const unsigned long long mm = __ballot(m);
+                        if (m) {
+                            // rows below the window (or of the previous contig) rank past the c-th match
+                            const long long o = cend[t] - 1 - found - (long long)__popcll(mm & lt_lanes);
+                            if (o >= w0 && o < w1 && o >= cend[t] - c[t]) { st_p[o - w0] = crow[t]; st_b[o - w0] = br; }
                         }
+                        found += (int)__popcll(mm);
                     }
                 }
             }

@@ -41,8 +41,10 @@ class DeviceJoin:
     def build_index(self, build: DeviceSide, strict: bool, n_contigs: int, with_end_order: bool = False):
         return self.engine.index_build_dev(build.as_c(), make_opts(strict, n_contigs), with_end_order)
 
-    def overlap(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None):
-        """Index build (radix sort) + count + scan + fill.  -> (probe_idx, build_idx) int32 tensors."""
+    def overlap(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None, out=None):
+        """Index build (radix sort) + count + scan + fill.  -> (probe_idx, build_idx) int32 tensors.
+        ``out``: optional pair of preallocated int32 CUDA tensors; views of their first n_pairs
+        elements are returned when they are large enough (no allocation on the call path)."""
         torch = self.torch
         opts = make_opts(strict, n_contigs)
         own = index is None
@@ -50,8 +52,11 @@ class DeviceJoin:
         try:
             side = probe.as_c()
             total = self.engine.overlap_count_dev(ix, side, opts)
-            out_p = torch.empty(total, dtype=torch.int32, device=probe.start.device)
-            out_b = torch.empty(total, dtype=torch.int32, device=probe.start.device)
+            if out is not None and out[0].numel() >= total and out[1].numel() >= total:
+                out_p, out_b = out[0][:total], out[1][:total]
+            else:
+                out_p = torch.empty(total, dtype=torch.int32, device=probe.start.device)
+                out_b = torch.empty(total, dtype=torch.int32, device=probe.start.device)
             self.engine.overlap_fill_dev(ix, side, opts, out_p.data_ptr(), out_b.data_ptr(), total)
         finally:
             if own:

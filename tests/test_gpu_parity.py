@@ -225,3 +225,32 @@ def test_full_size_config2_properties(eng):
     ep, eb = O.overlap_fast(ix, ps, True)
     assert int(hb.astype(np.int64).sum()) == int(eb.astype(np.int64).sum())
     assert (hb == eb).all()
+
+
+def test_bench_contract_and_rccl_path_single_rank(tmp_path):
+    """bench.py prints ONE JSON line with the contract's keys; --force-dist drives the multi-process
+    path (RCCL init, contig sharding with global row ids, all-gatherv, max-over-ranks timing) on
+    the one GPU that is available here."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    for extra in ([], ["--force-dist"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scale", "0.02", "--steps", "2",
+                              "--warmup", "1", "--cpu-sample", "200000"] + extra,
+                             capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        j = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                    "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in j, key
+        assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0
+        assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+        if extra:
+            assert "all-gatherv" in j["config"]["parallelism"]
+        else:
+            assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
