@@ -497,12 +497,20 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     const int32_t* ids = ctx->ov_part ? ctx->pt_row : probe->row_id;
     const bool vec = aligned16(qs);
     IndexView v = view_of(ix);
-    if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "overlap_fill", (k_overlap_fill<true>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
-               (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
-    else
-        LAUNCH(ctx, "overlap_fill", (k_overlap_fill<false>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
-               (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
+    // dense results (>= 8 pairs per probe on average): windows shared out over all wavefronts
+    const bool dense = ctx->ov_total >= 8 * n;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    if (dense) {
+        if (strict) LAUNCH(ctx, "overlap_fill_dense", (k_overlap_fill_dense<true>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+                           (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
+        else LAUNCH(ctx, "overlap_fill_dense", (k_overlap_fill_dense<false>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+                    (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
+    } else {
+        if (strict) LAUNCH(ctx, "overlap_fill", (k_overlap_fill<true>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+                           (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
+        else LAUNCH(ctx, "overlap_fill", (k_overlap_fill<false>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+                    (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
+    }
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
 }

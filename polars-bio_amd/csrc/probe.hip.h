@@ -552,53 +552,136 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
             // lower lanes gives every matching lane its slot (ascending (start,row) order).
             unsigned long long todo = __ballot(in_win && hi[k] < 0);
             while (todo) {
-                int src[4], h[4], c[4]; int32_t cqs[4], crow[4], r0[4], r1[4]; long long cend[4]; int2 v0[4], v1[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    src[t] = todo ? __ffsll((long long)todo) - 1 : -1;
-                    if (todo) todo &= todo - 1;
-                    const int sl = src[t] < 0 ? 0 : src[t];
-                    h[t] = __shfl(hi[k], sl, kWave) & 0x7fffffff;
-                    c[t] = __shfl(cnt[k], sl, kWave);
-                    cqs[t] = __shfl(qs[k], sl, kWave);
-                    crow[t] = __shfl(row[k], sl, kWave);
-                    cend[t] = ((long long)__shfl((int)(end >> 32), sl, kWave) << 32) |
-                              (unsigned long long)(unsigned int)__shfl((int)(end & 0xffffffffll), sl, kWave);
-                    if (src[t] < 0) { h[t] = 0; c[t] = 0; }
-                    const int p = h[t] - 1 - lane;
-                    // (end,pmax) and the build row of 2 x 64 rows per window are requested together, so
-                    // the emission below never waits on a dependent gather
-                    v0[t] = (p >= 0) ? ix.ep[p] : make_int2(0, 0);
-                    r0[t] = (p >= 0) ? ix.b_row[p] : 0;
-                    v1[t] = (p - kWave >= 0) ? ix.ep[p - kWave] : make_int2(0, 0);
-                    r1[t] = (p - kWave >= 0) ? ix.b_row[p - kWave] : 0;
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (src[t] < 0) continue;                  // uniform
-                    int found = 0;
-                    int2 v = v0[t];
-                    int32_t br = r0[t];
-                    int step = 0;
-                    for (int p0 = h[t] - 1; found < c[t] && p0 >= 0 && cend[t] - found > w0; p0 -= kWave, ++step) {
-                        const int p = p0 - lane;
-                        if (step == 1) { v = v1[t]; br = r1[t]; }
-                        else if (step > 1) { v = (p >= 0) ? ix.ep[p] : make_int2(0, 0); br = (p >= 0) ? ix.b_row[p] : 0; }
-                        const bool m = p >= 0 && lt_op<STRICT>(cqs[t], v.x);
-                        const unsigned long long mm = __ballot(m);
-                        if (m) {
-                            // rows below the window (or of the previous contig) rank past the c-th match
-                            const long long o = cend[t] - 1 - found - (long long)__popcll(mm & lt_lanes);
-                            if (o >= w0 && o < w1 && o >= cend[t] - c[t]) { st_p[o - w0] = crow[t]; st_b[o - w0] = br; }
-                        }
-                        found += (int)__popcll(mm);
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int h = __shfl(hi[k], src, kWave) & 0x7fffffff;
+                const int c = __shfl(cnt[k], src, kWave);
+                const int32_t cqs = __shfl(qs[k], src, kWave);
+                const int32_t crow = __shfl(row[k], src, kWave);
+                const long long cend = ((long long)__shfl((int)(end >> 32), src, kWave) << 32) |
+                                       (unsigned long long)(unsigned int)__shfl((int)(end & 0xffffffffll), src, kWave);
+                int found = 0;
+                for (int p0 = h - 1; found < c && p0 >= 0 && cend - found > w0; p0 -= kWave) {
+                    const int p = p0 - lane;
+                    int2 v = make_int2(0, 0);
+                    int32_t br = 0;
+                    if (p >= 0) { v = ix.ep[p]; br = ix.b_row[p]; }
+                    const bool m = p >= 0 && lt_op<STRICT>(cqs, v.x);
+                    const unsigned long long mm = __ballot(m);
+                    if (m) {
+                        // rows below the window (or of the previous contig) rank past the c-th match
+                        const long long o = cend - 1 - found - (long long)__popcll(mm & lt_lanes);
+                        if (o >= w0 && o < w1 && o >= cend - c) { st_p[o - w0] = crow; st_b[o - w0] = br; }
                     }
+                    found += (int)__popcll(mm);
                 }
             }
             off = end;
         }
         __syncthreads();
         const int t = (int)((tot - w0) < (long long)FILL_STAGE ? (tot - w0) : (long long)FILL_STAGE);
+        for (int i = threadIdx.x; i < t; i += PROBE_THREADS) {
+            out_probe[tbase + w0 + i] = st_p[i];
+            out_build[tbase + w0 + i] = st_b[i];
+        }
+        __syncthreads();
+    }
+}
+
+// Pass 2 for dense results (many pairs per probe).  Same tiles, same output layout as
+// k_overlap_fill, but the probes of a tile are first parked in LDS and every output window is
+// shared out over ALL wavefronts of the workgroup (probe q of the window goes to wavefront
+// q mod 4), because in a dense tile one window covers only a few dozen consecutive probes -- all
+// owned by one wavefront in the per-lane scheme.  A wavefront emits one probe at a time: a mask
+// probe with one lane per mask bit, a long window with 64 rows per step (ballot + popcount of the
+// lower lanes = slot), (end,pmax) and build row of 128 rows requested up front.
+constexpr int DENSE_STAGE = 2048;
+
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill_dense(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
+                                                                      bool vec_ok, const int32_t* __restrict__ hi_in,
+                                                                      const int32_t* __restrict__ cnt_in,
+                                                                      const long long* __restrict__ tile_base,
+                                                                      const int32_t* __restrict__ probe_ids,
+                                                                      int32_t* __restrict__ out_probe,
+                                                                      int32_t* __restrict__ out_build) {
+    __shared__ long long lds[PROBE_THREADS / kWave];
+    __shared__ int32_t st_p[DENSE_STAGE];
+    __shared__ int32_t st_b[DENSE_STAGE];
+    __shared__ int32_t l_hi[PROBE_TILE], l_x[PROBE_TILE], l_qs[PROBE_TILE], l_row[PROBE_TILE];
+    __shared__ long long l_off[PROBE_TILE + 1];
+    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const unsigned long long lt_lanes = (1ull << lane) - 1ull;
+    {
+        int32_t hi[PROBE_ITEMS], x[PROBE_ITEMS];
+        load_items(hi_in, i0, n, vec_ok, 0, hi);
+        load_items(cnt_in, i0, n, vec_ok, 0, x);
+        long long tsum = 0;
+        int cnt[PROBE_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) { cnt[k] = hi[k] < 0 ? x[k] : __popc((uint32_t)x[k]); tsum += cnt[k]; }
+        long long tot0;
+        long long off = block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot0);
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) {
+            const int q = threadIdx.x * PROBE_ITEMS + k;
+            l_hi[q] = hi[k]; l_x[q] = x[k]; l_off[q] = off;
+            l_qs[q] = (hi[k] < 0 && cnt[k] != 0) ? ps[i0 + k] : 0;
+            l_row[q] = (cnt[k] != 0 && probe_ids) ? probe_ids[i0 + k] : (int32_t)(i0 + k);
+            off += cnt[k];
+        }
+        if (threadIdx.x == PROBE_THREADS - 1) l_off[PROBE_TILE] = off;
+    }
+    __syncthreads();
+    const long long tot = l_off[PROBE_TILE];
+    const long long tbase = tile_base[blockIdx.x];
+    for (long long w0 = 0; w0 < tot; w0 += DENSE_STAGE) {
+        const long long w1 = w0 + DENSE_STAGE;
+        // probes intersecting [w0,w1): f = last probe with off <= w0, l = first probe with off >= w1
+        int f, l;
+        { int lo = 0, hi = PROBE_TILE; while (lo < hi) { const int m = (lo + hi) >> 1; if (l_off[m] <= w0) lo = m + 1; else hi = m; } f = lo - 1; }
+        { int lo = 0, hi = PROBE_TILE; while (lo < hi) { const int m = (lo + hi) >> 1; if (l_off[m] < w1) lo = m + 1; else hi = m; } l = lo; }
+        for (int q = f + w; q < l; q += PROBE_THREADS / kWave) {       // wavefront-uniform
+            const long long off = l_off[q], end = l_off[q + 1];
+            const int c = (int)(end - off);
+            if (c == 0) continue;
+            const int32_t hi = l_hi[q], crow = l_row[q];
+            if (hi >= 0) {
+                // mask probe: lane j owns bit j; its slot = off + number of set bits above j
+                const uint32_t x = (uint32_t)l_x[q];
+                if (lane < 32 && ((x >> lane) & 1u)) {
+                    const uint32_t above = lane == 31 ? 0u : (x & ~((2u << lane) - 1u));
+                    const long long o = off + __popc(above);
+                    if (o >= w0 && o < w1) { st_p[o - w0] = crow; st_b[o - w0] = ix.b_row[hi - 1 - lane]; }
+                }
+            } else {
+                const int h = hi & 0x7fffffff;
+                const int32_t cqs = l_qs[q];
+                const int pa = h - 1 - lane, pb = pa - kWave;
+                int2 va = make_int2(0, 0), vb = make_int2(0, 0);
+                int32_t ra = 0, rb = 0;
+                if (pa >= 0) { va = ix.ep[pa]; ra = ix.b_row[pa]; }
+                if (pb >= 0) { vb = ix.ep[pb]; rb = ix.b_row[pb]; }
+                int found = 0, step = 0;
+                for (int p0 = h - 1; found < c && p0 >= 0 && end - found > w0; p0 -= kWave, ++step) {
+                    const int p = p0 - lane;
+                    int2 v; int32_t br;
+                    if (step == 0) { v = va; br = ra; }
+                    else if (step == 1) { v = vb; br = rb; }
+                    else { v = make_int2(0, 0); br = 0; if (p >= 0) { v = ix.ep[p]; br = ix.b_row[p]; } }
+                    const bool m = p >= 0 && lt_op<STRICT>(cqs, v.x);
+                    const unsigned long long mm = __ballot(m);
+                    if (m) {
+                        const long long o = end - 1 - found - (long long)__popcll(mm & lt_lanes);
+                        if (o >= w0 && o < w1 && o >= off) { st_p[o - w0] = crow; st_b[o - w0] = br; }
+                    }
+                    found += (int)__popcll(mm);
+                }
+            }
+        }
+        __syncthreads();
+        const int t = (int)((tot - w0) < (long long)DENSE_STAGE ? (tot - w0) : (long long)DENSE_STAGE);
         for (int i = threadIdx.x; i < t; i += PROBE_THREADS) {
             out_probe[tbase + w0 + i] = st_p[i];
             out_build[tbase + w0 + i] = st_b[i];
