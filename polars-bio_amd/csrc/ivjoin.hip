@@ -432,8 +432,9 @@ int partition_probes(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     }
     IndexView v = view_of(ix);
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
-    if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, probe->contig, probe->end, n, bshift, blk, ntiles);
-    else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, probe->contig, probe->end, n, bshift, blk, ntiles);
+    const bool hvec = aligned16(probe->contig) && aligned16(probe->end);
+    if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, probe->contig, probe->end, n, bshift, blk, ntiles, hvec);
+    else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, probe->contig, probe->end, n, bshift, blk, ntiles, hvec);
     device_scan<uint32_t, SumOp, false>(ctx, "part_scan", blk, blk, (int64_t)hist, 0u, partials, (uint32_t*)nullptr);
     t_begin(ctx, "part_scatter");
     if (strict)

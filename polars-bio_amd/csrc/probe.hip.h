@@ -839,7 +839,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_general(IndexView ix,
 // row id of every permuted probe; the count and fill kernels then run unchanged on those columns.
 namespace ivj {
 
-constexpr int PART_THREADS = 1024;
+constexpr int PART_THREADS = 512;
 constexpr int PART_WAVES = PART_THREADS / kWave;
 constexpr int PART_ITEMS = 8;
 constexpr int PART_TILE = PART_THREADS * PART_ITEMS;
@@ -873,20 +873,52 @@ __device__ __forceinline__ int xcd_tile(int block, int ntiles) {
     return t;
 }
 
+constexpr int PART_LDS_CONTIGS = 1024;   // per-contig metadata is staged in LDS up to this many contigs
+
+template <bool STRICT>
+__device__ __forceinline__ uint32_t probe_bucket_m(const int4& m0, const int4& m1, int32_t qe, int bshift) {
+    if (m0.y <= m0.x) return PART_BUCKETS - 1;
+    const uint32_t ulo = (uint32_t)m0.z, uhi = (uint32_t)m0.w;
+    const unsigned long long tu = (unsigned long long)flip(qe) + (STRICT ? 0ull : 1ull);
+    uint32_t j;
+    if (tu <= ulo) j = 0;
+    else if (tu > uhi) j = ((uhi - ulo) >> m1.x) + 1u;
+    else j = ((uint32_t)tu - ulo) >> m1.x;
+    const uint32_t bkt = ((uint32_t)m1.y + j) >> bshift;
+    return bkt < (uint32_t)(PART_BUCKETS - 2) ? bkt : (uint32_t)(PART_BUCKETS - 2);
+}
+
 template <bool STRICT>
 __global__ __launch_bounds__(PART_THREADS) void k_part_hist(IndexView ix, const int32_t* __restrict__ pc,
                                                             const int32_t* __restrict__ pe, int64_t n, int bshift,
-                                                            uint32_t* __restrict__ blk_hist, int ntiles) {
+                                                            uint32_t* __restrict__ blk_hist, int ntiles, bool vec_ok) {
     __shared__ uint32_t h[PART_BUCKETS];
+    __shared__ int4 l_meta[2 * PART_LDS_CONTIGS];
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
     if (threadIdx.x < PART_BUCKETS) h[threadIdx.x] = 0;
+    const bool lmeta = ix.n_contigs <= PART_LDS_CONTIGS;
+    if (lmeta) for (int k = threadIdx.x; k < 2 * ix.n_contigs; k += PART_THREADS) l_meta[k] = ix.cmeta[k];
     __syncthreads();
     const int64_t base = (int64_t)tile * PART_TILE;
+    // each thread takes two groups of four consecutive probes (16-byte loads)
 #pragma unroll
-    for (int j = 0; j < PART_ITEMS; ++j) {
-        const int64_t i = base + (int64_t)j * PART_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[probe_bucket<STRICT>(ix, pc[i], pe[i], bshift)], 1u);
+    for (int g = 0; g < PART_ITEMS / 4; ++g) {
+        const int64_t i0 = base + (int64_t)g * (PART_THREADS * 4) + (int64_t)threadIdx.x * 4;
+        int32_t c[4], e[4];
+        load_items(pc, i0, n, vec_ok, -1, c);
+        load_items(pe, i0, n, vec_ok, 0, e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k >= n) continue;
+            uint32_t d = PART_BUCKETS - 1;
+            if ((uint32_t)c[k] < (uint32_t)ix.n_contigs) {
+                const int4 m0 = lmeta ? l_meta[2 * c[k]] : ix.cmeta[2 * c[k]];
+                const int4 m1 = lmeta ? l_meta[2 * c[k] + 1] : ix.cmeta[2 * c[k] + 1];
+                d = probe_bucket_m<STRICT>(m0, m1, e[k], bshift);
+            }
+            atomicAdd(&h[d], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < PART_BUCKETS) blk_hist[(int64_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];

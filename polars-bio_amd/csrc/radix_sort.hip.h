@@ -56,47 +56,58 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t* __restri
 }
 
 // blk_off = exclusive scan of blk_hist over the digit-major layout.
+// Wavefront w owns the contiguous quarter [w*1024, (w+1)*1024) of the tile and ranks its keys in
+// sixteen rounds against its PRIVATE counter row wcnt[w][*] (no workgroup barrier inside the
+// rounds: LDS operations of one wavefront execute in order).  One barrier, a per-digit exclusive
+// prefix over the four wavefronts, and every key knows its global slot.  Stable: the order inside a
+// digit is (wavefront, round, lane) = ascending input position.
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ vals_in,
                                                            uint32_t* __restrict__ keys_out,
                                                            uint32_t* __restrict__ vals_out, int64_t n, int shift,
                                                            const uint32_t* __restrict__ blk_off, int nblocks) {
-    __shared__ uint32_t run[RS_RADIX];             // next free slot of each digit for this workgroup
-    __shared__ uint32_t wcnt[RS_WAVES][RS_RADIX];  // per-round, per-wave digit counts
-    const int tid = threadIdx.x;
-    const int w = tid / kWave;
-    run[tid] = blk_off[(int64_t)tid * nblocks + blockIdx.x];
+    __shared__ uint32_t wcnt[RS_WAVES][RS_RADIX];
+    const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
 #pragma unroll
     for (int k = 0; k < RS_WAVES; ++k) wcnt[k][tid] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (RS_ITEMS * kWave);
     const uint64_t lt = lanemask_lt();
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
-        const int64_t i = base + (int64_t)j * RS_THREADS + tid;
+        const int64_t i = base + (int64_t)j * kWave + lane;
         const bool valid = i < n;
-        const uint32_t key = valid ? keys_in[i] : 0u;
-        const uint32_t val = valid ? vals_in[i] : 0u;
-        const uint32_t d = (key >> shift) & 0xFFu;
+        key[j] = valid ? keys_in[i] : 0u;
+        val[j] = valid ? vals_in[i] : 0u;
+    }
+    uint32_t* my = wcnt[w];
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const bool valid = base + (int64_t)j * kWave + lane < n;
+        const uint32_t d = (key[j] >> shift) & 0xFFu;
         const uint64_t peers = wave_match8(d, valid);
-        const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        if (valid && rank == 0) wcnt[w][d] = (uint32_t)__popcll(peers);
-        __syncthreads();
-        uint32_t dst = 0;
-        if (valid) {
-            dst = run[d] + rank;
+        const uint32_t rk = (uint32_t)__popcll(peers & lt);
+        const uint32_t before = valid ? my[d] : 0u;
+        rank[j] = before + rk;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rk == 0) my[d] = before + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {   // digit `tid`: exclusive prefix over the wavefronts, shifted by the global offset of (digit, block)
+        uint32_t x = blk_off[(int64_t)tid * nblocks + blockIdx.x];
 #pragma unroll
-            for (int k = 0; k < RS_WAVES; ++k)
-                if (k < w) dst += wcnt[k][d];
-        }
-        __syncthreads();
-        {
-            uint32_t s = 0;
+        for (int k = 0; k < RS_WAVES; ++k) { const uint32_t t = wcnt[k][tid]; wcnt[k][tid] = x; x += t; }
+    }
+    __syncthreads();
 #pragma unroll
-            for (int k = 0; k < RS_WAVES; ++k) { s += wcnt[k][tid]; wcnt[k][tid] = 0; }
-            run[tid] += s;
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        if (base + (int64_t)j * kWave + lane < n) {
+            const uint32_t dst = my[(key[j] >> shift) & 0xFFu] + rank[j];
+            keys_out[dst] = key[j];
+            vals_out[dst] = val[j];
         }
-        __syncthreads();
-        if (valid) { keys_out[dst] = key; vals_out[dst] = val; }
     }
 }
 

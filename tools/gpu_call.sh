@@ -21,6 +21,7 @@ for stage in "$@"; do
       done;
       f=$(find gpurun_out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); [ -n "$f" ] && head -3 "$f";
       python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.err; tail -5 gpurun_out/pmc_summary.err; head -c 3000 gpurun_out/pmc_summary.json ;;
+    hostpath) echo "== host-buffer (PCIe-inclusive) path"; timeout 900 python tools/host_path_timing.py 2>&1 | tee gpurun_out/host_path.log | tail -5 ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
