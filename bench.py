@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the CPU-baseline sample")
     ap.add_argument("--kernel-table", action="store_true", help="print a per-kernel HIP-event table to stderr")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="overlap: always use the deterministic count -> fill pair (default: the fused single pass "
+                         "into the preallocated result buffers once the warmup has sized them)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (RCCL init, sharding, all-gatherv) even with one rank")
     return ap.parse_args()
@@ -160,7 +163,7 @@ def main():
         if op == "overlap":
             # the first (warmup) step sizes the result buffers; later steps write into them, so the
             # timed region holds no device allocation
-            p, b = join.overlap(d_probe, d_build, True, nc, out=state.get("out"))
+            p, b = join.overlap(d_probe, d_build, True, nc, out=state.get("out"), fused=not args.two_pass)
             if "out" not in state:
                 state["out"] = (torch.empty_like(p), torch.empty_like(b))
             local = int(p.shape[0])
@@ -262,7 +265,11 @@ def main():
                        "filter_op": "Strict", "units_per_step": total_units,
                        "parallelism": ("single GPU" if not multi else
                                        f"{mode}-sharded x{n_gpus}, " + ("RCCL all-gatherv in timed region" if gather else "no gather")),
-                       "step": "index build (radix sort) + count + scan + fill, inputs and outputs in HBM"},
+                       "step": ("index build (radix sort) + probe bucketing + " +
+                                ("count + scan + fill" if (args.two_pass or "overlap_fused" not in ktimes) else
+                                 "fused count/fill into the preallocated result buffers") +
+                                ", inputs and outputs in HBM") if op == "overlap" else
+                               "index build (radix sort) + probe kernel, inputs and outputs in HBM"},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

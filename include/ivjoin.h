@@ -149,6 +149,16 @@ int ivj_overlap_fill_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev,
                          const ivj_opts* opts, int32_t* probe_idx_dev, int32_t* build_idx_dev,
                          int64_t capacity);
 
+/* overlap in ONE pass for callers that bring an output buffer of known capacity (steady-state /
+ * streaming batches: the previous batch sized it): counting and emitting are fused, every tile
+ * reserves its output range with one atomic, nothing is written to or re-read from HBM in between.
+ * *n_pairs receives the total.  Returns IVJ_ECAPACITY (and writes nothing past the capacity) when
+ * the buffer is too small: grow it to *n_pairs and call again, or use the count/fill pair.
+ * The pairs of one probe row are contiguous and ordered; the order of the tiles is NOT
+ * reproducible from run to run (the count/fill pair is the deterministic path). */
+int ivj_overlap_fused_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts,
+                          int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_pairs);
+
 int ivj_count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev,
                            const ivj_opts* opts, int64_t* counts_dev);
 

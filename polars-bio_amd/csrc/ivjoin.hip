@@ -516,6 +516,38 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     return IVJ_OK;
 }
 
+// single pass: (bucketing +) fused count/fill into a caller buffer of known capacity
+int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
+                  int64_t capacity, int64_t* n_pairs) {
+    const int64_t n = probe->n;
+    ctx->ov_n = -1;                                   // invalidates a pending count -> fill hand-over
+    *n_pairs = 0;
+    if (n == 0 || ix->n == 0) return IVJ_OK;
+    const bool part = want_partition(ix, n, opts);
+    IVJ_TRY(ensure_ov(ctx, n, part));
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    unsigned long long* state = (unsigned long long*)ctx->ov_tile;   // [0] cursor, [1] overflow
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *ids = probe->row_id;
+    if (part) {
+        IVJ_TRY(partition_probes(ctx, ix, probe, opts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e; ids = ctx->pt_row;
+    }
+    HIP_TRY(hipMemsetAsync(state, 0, 16, ctx->stream));
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+    IndexView v = view_of(ix);
+    if (opts->filter_op == IVJ_FILTER_STRICT)
+        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<true>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+    else
+        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<false>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    *n_pairs = ctx->h_total[0];
+    if (ctx->h_total[1] != 0)
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");
+    return IVJ_OK;
+}
+
 int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* counts) {
     const int64_t n = probe->n;
     if (n == 0) return IVJ_OK;
@@ -720,6 +752,16 @@ int ivj_overlap_fill_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev,
     IVJ_TRY(check_side(probe_dev, "probe"));
     DeviceGuard g(ctx->device);
     return overlap_fill(ctx, ix, probe_dev, opts, probe_idx_dev, build_idx_dev, capacity);
+}
+
+int ivj_overlap_fused_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts,
+                          int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_pairs) {
+    if (!ctx || !ix || !n_pairs) return fail(IVJ_EINVAL, "ctx, index or n_pairs is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    if (capacity < 0 || (capacity > 0 && (!probe_idx_dev || !build_idx_dev))) return fail(IVJ_EINVAL, "bad output buffers");
+    DeviceGuard g(ctx->device);
+    return overlap_fused(ctx, ix, probe_dev, opts, probe_idx_dev, build_idx_dev, capacity, n_pairs);
 }
 
 int ivj_count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* counts_dev) {

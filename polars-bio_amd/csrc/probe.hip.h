@@ -412,32 +412,23 @@ __global__ void k_bins_mark(const int32_t* __restrict__ b_start, const int32_t* 
 
 // ------------------------------------------------------------------ overlap: count -> fill
 
-// Pass 1.  One workgroup = PROBE_TILE probes, PROBE_ITEMS consecutive probes per thread.
-// Writes hi[i] and the 32-row match mask of the window below hi (or, flagged in the sign bit of
-// hi, the exact count of a longer window) so the fill pass neither searches nor rescans.
+// ---- shared bodies of the count / fill / fused kernels -------------------------------------------
+
+// For the PROBE_ITEMS probes of this thread: hi-bound through the table, then the window below hi
+// as a 32-row match mask (x = mask) or -- window longer than 32 rows -- an exact count made by
+// the whole wavefront (x = count, sign bit of hi set).  cnt = number of matches.
 template <bool STRICT>
-__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, const int32_t* __restrict__ pc,
-                                                                 const int32_t* __restrict__ ps,
-                                                                 const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
-                                                                 int32_t* __restrict__ hi_out, int32_t* __restrict__ cnt_out,
-                                                                 long long* __restrict__ tile_tot) {
-    __shared__ long long lds[PROBE_THREADS / kWave];
-    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
-    int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
-    load_items(pc, i0, n, vec_ok, -1, c);
-    load_items(ps, i0, n, vec_ok, 0, s);
-    load_items(pe, i0, n, vec_ok, 0, e);
-    int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS], x[PROBE_ITEMS];
-    bool valid[PROBE_ITEMS];
-#pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
+__device__ __forceinline__ void probe_windows(const IndexView& ix, const int32_t (&c)[PROBE_ITEMS],
+                                              const int32_t (&s)[PROBE_ITEMS], const int32_t (&e)[PROBE_ITEMS],
+                                              const bool (&valid)[PROBE_ITEMS], int (&hi)[PROBE_ITEMS],
+                                              int (&x)[PROBE_ITEMS], int (&cnt)[PROBE_ITEMS]) {
+    int a[PROBE_ITEMS], b[PROBE_ITEMS];
     bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
-    long long tsum = 0;
     const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
-        uint32_t mask; int cnt;
-        const bool small = window_mask<STRICT>(ix, a[k], hi[k], s[k], mask, cnt);
+        uint32_t mask; int cn;
+        const bool small = window_mask<STRICT>(ix, a[k], hi[k], s[k], mask, cn);
         x[k] = (int)mask;
         // wavefront-cooperative exact count of every long window of this round (uniform loop);
         // four windows per step so that four first-chunk reads are in flight together
@@ -458,7 +449,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (src[t] < 0) continue;                      // uniform
-                int c = 0;
+                int cc = 0;
                 int2 v = v0[t];
                 int step = 0;
                 for (int p0 = chi[t] - 1; p0 >= ca[t]; p0 -= kWave, ++step) {
@@ -467,63 +458,33 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
                     else if (step > 1) v = (p >= ca[t]) ? ix.ep[p] : make_int2(0, 0);
                     const bool pass = p >= ca[t] && lt_op<STRICT>(cqs[t], v.y);
                     const bool match = pass && lt_op<STRICT>(cqs[t], v.x);
-                    c += (int)__popcll(__ballot(match));
+                    cc += (int)__popcll(__ballot(match));
                     if (__popcll(__ballot(pass)) < kWave) break;
                 }
-                if (lane == src[t]) { cnt = c; x[k] = c; }
+                if (lane == src[t]) { cn = cc; x[k] = cc; }
             }
         }
-        if (!small) hi[k] |= (int)0x80000000;      // flag: x is a count, the fill pass rescans
-        tsum += cnt;
+        if (!small) hi[k] |= (int)0x80000000;      // flag: x is a count, the emission rescans
+        cnt[k] = cn;
     }
-    store_items(hi_out, i0, n, vec_ok, hi);
-    store_items(cnt_out, i0, n, vec_ok, x);
-    long long tot;
-    block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
-    if (threadIdx.x == 0) tile_tot[blockIdx.x] = tot;
 }
 
-// Pass 2.  tile_base = exclusive scan of tile_tot.  The pairs of one probe are emitted in
-// ascending (build.start, build row) order.  The pairs of a tile occupy ONE contiguous output
-// range, so they are first compacted in LDS at their tile-local offset and then copied out with
-// fully coalesced stores; tiles with more than FILL_STAGE pairs write directly.
+// Emission of one tile.  The pairs of a tile occupy ONE contiguous output range starting at
+// `tbase`; they are compacted in LDS (windows of FILL_STAGE pairs, usually one) at their
+// tile-local offset and copied out with fully coalesced stores.  Mask probes: bit j <=> row
+// hi-1-j, ascending (start,row) order = descending j.  Long windows (flagged): the whole wavefront
+// rescans 64 rows per step; the f-th match from the top of the window owns slot end-1-f, so a
+// ballot + popcount of the lower lanes gives every matching lane its slot.
 constexpr int FILL_STAGE = 3072;
 
 template <bool STRICT>
-__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
-                                                                bool vec_ok, const int32_t* __restrict__ hi_in,
-                                                                const int32_t* __restrict__ cnt_in,
-                                                                const long long* __restrict__ tile_base,
-                                                                const int32_t* __restrict__ probe_ids,
-                                                                int32_t* __restrict__ out_probe,
-                                                                int32_t* __restrict__ out_build) {
-    __shared__ long long lds[PROBE_THREADS / kWave];
-    __shared__ int32_t st_p[FILL_STAGE];
-    __shared__ int32_t st_b[FILL_STAGE];
-    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
-    int32_t hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS], row[PROBE_ITEMS];
-    load_items(hi_in, i0, n, vec_ok, 0, hi);
-    load_items(cnt_in, i0, n, vec_ok, 0, x);
-    long long tsum = 0;
-#pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) {
-        cnt[k] = hi[k] < 0 ? x[k] : __popc((uint32_t)x[k]);
-        tsum += cnt[k];
-        row[k] = (int32_t)(i0 + k);
-    }
-    if (probe_ids && tsum) {
-#pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) if (cnt[k]) row[k] = probe_ids[i0 + k];
-    }
-    long long tot;
-    const long long loc0 = block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
-    const long long tbase = tile_base[blockIdx.x];
+__device__ __forceinline__ void emit_tile(const IndexView& ix, const int32_t (&hi)[PROBE_ITEMS],
+                                          const int32_t (&x)[PROBE_ITEMS], const int32_t (&cnt)[PROBE_ITEMS],
+                                          const int32_t (&row)[PROBE_ITEMS], const int32_t (&qs)[PROBE_ITEMS],
+                                          long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b,
+                                          int32_t* __restrict__ out_probe, int32_t* __restrict__ out_build) {
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long lt_lanes = (1ull << lane) - 1ull;
-    int32_t qs[PROBE_ITEMS];
-#pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) qs[k] = (hi[k] < 0 && cnt[k] != 0) ? ps[i0 + k] : 0;
-    // the tile's output range is processed in windows of FILL_STAGE pairs (usually one)
     for (long long w0 = 0; w0 < tot; w0 += FILL_STAGE) {
         const long long w1 = w0 + FILL_STAGE;
         long long off = loc0;                                  // tile-local offset of the current probe
@@ -531,25 +492,19 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
         for (int k = 0; k < PROBE_ITEMS; ++k) {
             const long long end = off + cnt[k];
             const bool in_win = cnt[k] != 0 && end > w0 && off < w1;
-            if (in_win) {
-                if (hi[k] >= 0) {
-                    // mask mode: bit j <=> row hi-1-j; ascending (start,row) order = descending j
-                    uint32_t m = (uint32_t)x[k];
-                    long long o = off;
-                    while (m) {
-                        const int j = 31 - __clz(m);
-                        m &= ~(1u << j);
-                        if (o >= w0 && o < w1) {
-                            st_p[o - w0] = row[k];
-                            st_b[o - w0] = ix.b_row[hi[k] - 1 - j];
-                        }
-                        ++o;
+            if (in_win && hi[k] >= 0) {
+                uint32_t m = (uint32_t)x[k];
+                long long o = off;
+                while (m) {
+                    const int j = 31 - __clz(m);
+                    m &= ~(1u << j);
+                    if (o >= w0 && o < w1) {
+                        st_p[o - w0] = row[k];
+                        st_b[o - w0] = ix.b_row[hi[k] - 1 - j];
                     }
+                    ++o;
                 }
             }
-            // long windows (flagged): the whole wavefront rescans 64 rows per step; the f-th match
-            // counted from the top of the window owns slot end-1-f, so a ballot + popcount of the
-            // lower lanes gives every matching lane its slot (ascending (start,row) order).
             unsigned long long todo = __ballot(in_win && hi[k] < 0);
             while (todo) {
                 const int src = __ffsll((long long)todo) - 1;
@@ -586,6 +541,120 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
         }
         __syncthreads();
     }
+}
+
+// Pass 1.  One workgroup = PROBE_TILE probes, PROBE_ITEMS consecutive probes per thread.
+// Writes hi[i] and the 32-row match mask of the window below hi (or, flagged in the sign bit of
+// hi, the exact count of a longer window) so the fill pass neither searches nor rescans.
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, const int32_t* __restrict__ pc,
+                                                                 const int32_t* __restrict__ ps,
+                                                                 const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
+                                                                 int32_t* __restrict__ hi_out, int32_t* __restrict__ cnt_out,
+                                                                 long long* __restrict__ tile_tot) {
+    __shared__ long long lds[PROBE_THREADS / kWave];
+    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
+    load_items(pc, i0, n, vec_ok, -1, c);
+    load_items(ps, i0, n, vec_ok, 0, s);
+    load_items(pe, i0, n, vec_ok, 0, e);
+    int hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS];
+    bool valid[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
+    probe_windows<STRICT>(ix, c, s, e, valid, hi, x, cnt);
+    long long tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) tsum += cnt[k];
+    store_items(hi_out, i0, n, vec_ok, hi);
+    store_items(cnt_out, i0, n, vec_ok, x);
+    long long tot;
+    block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
+    if (threadIdx.x == 0) tile_tot[blockIdx.x] = tot;
+}
+
+// Pass 2.  tile_base = exclusive scan of tile_tot.
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
+                                                                bool vec_ok, const int32_t* __restrict__ hi_in,
+                                                                const int32_t* __restrict__ cnt_in,
+                                                                const long long* __restrict__ tile_base,
+                                                                const int32_t* __restrict__ probe_ids,
+                                                                int32_t* __restrict__ out_probe,
+                                                                int32_t* __restrict__ out_build) {
+    __shared__ long long lds[PROBE_THREADS / kWave];
+    __shared__ int32_t st_p[FILL_STAGE];
+    __shared__ int32_t st_b[FILL_STAGE];
+    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    int32_t hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS], row[PROBE_ITEMS], qs[PROBE_ITEMS];
+    load_items(hi_in, i0, n, vec_ok, 0, hi);
+    load_items(cnt_in, i0, n, vec_ok, 0, x);
+    long long tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) {
+        cnt[k] = hi[k] < 0 ? x[k] : __popc((uint32_t)x[k]);
+        tsum += cnt[k];
+        row[k] = (int32_t)(i0 + k);
+    }
+    if (probe_ids && tsum) {
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) if (cnt[k]) row[k] = probe_ids[i0 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) qs[k] = (hi[k] < 0 && cnt[k] != 0) ? ps[i0 + k] : 0;
+    long long tot;
+    const long long loc0 = block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
+    emit_tile<STRICT>(ix, hi, x, cnt, row, qs, loc0, tot, tile_base[blockIdx.x], st_p, st_b, out_probe, out_build);
+}
+
+// Fused single pass (count + fill) for callers that bring an output buffer of known capacity
+// (steady-state / streaming use: the previous batch sized it).  Each tile reserves its output range
+// with ONE 64-bit atomicAdd on a cursor, so no tile waits for another and nothing is written to or
+// re-read from HBM between counting and emitting.  Tile ranges land in reservation order: the
+// pairs of one probe row stay contiguous and ordered, the order of tiles is not reproducible from
+// run to run (the two-pass path is the deterministic one).  state[0] = cursor (= total on exit),
+// state[1] = 1 when the capacity was exceeded (nothing is written past it).
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fused(IndexView ix, const int32_t* __restrict__ pc,
+                                                                 const int32_t* __restrict__ ps,
+                                                                 const int32_t* __restrict__ pe,
+                                                                 const int32_t* __restrict__ probe_ids, int64_t n,
+                                                                 bool vec_ok, long long capacity,
+                                                                 unsigned long long* __restrict__ state,
+                                                                 int32_t* __restrict__ out_probe,
+                                                                 int32_t* __restrict__ out_build) {
+    __shared__ long long lds[PROBE_THREADS / kWave];
+    __shared__ long long s_base;
+    __shared__ int32_t st_p[FILL_STAGE];
+    __shared__ int32_t st_b[FILL_STAGE];
+    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
+    load_items(pc, i0, n, vec_ok, -1, c);
+    load_items(ps, i0, n, vec_ok, 0, s);
+    load_items(pe, i0, n, vec_ok, 0, e);
+    int hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS], row[PROBE_ITEMS];
+    bool valid[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
+    probe_windows<STRICT>(ix, c, s, e, valid, hi, x, cnt);
+    long long tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) { tsum += cnt[k]; row[k] = (int32_t)(i0 + k); }
+    if (probe_ids && tsum) {
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) if (cnt[k]) row[k] = probe_ids[i0 + k];
+    }
+    long long tot;
+    const long long loc0 = block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
+    if (threadIdx.x == 0) {
+        const long long base = tot ? (long long)atomicAdd(&state[0], (unsigned long long)tot) : 0ll;
+        if (base + tot > capacity) { atomicExch(&state[1], 1ull); s_base = -1; }
+        else s_base = base;
+    }
+    __syncthreads();
+    const long long tbase = s_base;
+    if (tbase < 0 || tot == 0) return;                     // uniform
+    emit_tile<STRICT>(ix, hi, x, cnt, row, s, loc0, tot, tbase, st_p, st_b, out_probe, out_build);
 }
 
 // Pass 2 for dense results (many pairs per probe).  Same tiles, same output layout as

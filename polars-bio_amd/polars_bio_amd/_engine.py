@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "ivj_last_error", "ivj_version", "ivj_device_count", "ivj_ctx_create", "ivj_ctx_destroy",
     "ivj_ctx_set_stream", "ivj_ctx_sync", "ivj_ctx_enable_timing", "ivj_ctx_get_timings",
     "ivj_overlap", "ivj_pairs_free", "ivj_count_overlaps", "ivj_nearest",
-    "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev",
+    "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev", "ivj_overlap_fused_dev",
     "ivj_count_overlaps_dev", "ivj_nearest_dev",
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
 ]
@@ -92,6 +92,7 @@ def load_library() -> C.CDLL:
         L.ivj_index_free.restype = None
         L.ivj_overlap_count_dev.argtypes = [vp, vp, P, O, C.POINTER(C.c_int64)]
         L.ivj_overlap_fill_dev.argtypes = [vp, vp, P, O, vp, vp, C.c_int64]
+        L.ivj_overlap_fused_dev.argtypes = [vp, vp, P, O, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
         L.ivj_count_overlaps_dev.argtypes = [vp, vp, P, O, vp]
         L.ivj_nearest_dev.argtypes = [vp, vp, P, O, vp, vp, vp]
         L.ivj_dev_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
@@ -263,6 +264,17 @@ class Engine:
         _check(self.L, self.L.ivj_overlap_fill_dev(self.h, ix.handle, C.byref(probe), C.byref(opts),
                                                     C.c_void_p(probe_idx_ptr), C.c_void_p(build_idx_ptr), capacity),
                "ivj_overlap_fill_dev")
+
+    def overlap_fused_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, probe_idx_ptr: int, build_idx_ptr: int,
+                          capacity: int):
+        """-> (n_pairs, fits).  fits=False: nothing usable was written, grow the buffers to n_pairs."""
+        n = C.c_int64(0)
+        rc = self.L.ivj_overlap_fused_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), C.c_void_p(probe_idx_ptr),
+                                          C.c_void_p(build_idx_ptr), capacity, C.byref(n))
+        if rc == -4:      # IVJ_ECAPACITY
+            return n.value, False
+        _check(self.L, rc, "ivj_overlap_fused_dev")
+        return n.value, True
 
     def count_overlaps_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, counts_ptr: int):
         _check(self.L, self.L.ivj_count_overlaps_dev(self.h, ix.handle, C.byref(probe), C.byref(opts),

@@ -41,16 +41,25 @@ class DeviceJoin:
     def build_index(self, build: DeviceSide, strict: bool, n_contigs: int, with_end_order: bool = False):
         return self.engine.index_build_dev(build.as_c(), make_opts(strict, n_contigs), with_end_order)
 
-    def overlap(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None, out=None):
+    def overlap(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None, out=None,
+                fused: bool = True):
         """Index build (radix sort) + count + scan + fill.  -> (probe_idx, build_idx) int32 tensors.
         ``out``: optional pair of preallocated int32 CUDA tensors; views of their first n_pairs
-        elements are returned when they are large enough (no allocation on the call path)."""
+        elements are returned when they are large enough (no allocation on the call path).  With
+        ``out`` and ``fused`` the single-pass ivj_overlap_fused_dev is tried first."""
         torch = self.torch
         opts = make_opts(strict, n_contigs)
         own = index is None
         ix = self.engine.index_build_dev(build.as_c(), opts, False) if own else index
         try:
             side = probe.as_c()
+            if out is not None and fused and out[0].numel() < 8 * max(probe.n, 1):
+                # single fused pass into the caller's buffers (sparse results; dense ones use the
+                # two-pass path whose fill kernel shares a tile's windows over all wavefronts)
+                cap = min(out[0].numel(), out[1].numel())
+                total, fits = self.engine.overlap_fused_dev(ix, side, opts, out[0].data_ptr(), out[1].data_ptr(), cap)
+                if fits:
+                    return out[0][:total], out[1][:total]
             total = self.engine.overlap_count_dev(ix, side, opts)
             if out is not None and out[0].numel() >= total and out[1].numel() >= total:
                 out_p, out_b = out[0][:total], out[1][:total]

@@ -254,3 +254,39 @@ def test_bench_contract_and_rccl_path_single_rank(tmp_path):
             assert "all-gatherv" in j["config"]["parallelism"]
         else:
             assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+
+
+def test_fused_single_pass_matches_two_pass(eng):
+    """ivj_overlap_fused_dev: same pair set; the pairs of one probe row stay contiguous and ordered
+    (a stable sort by probe row gives the oracle's exact sequence); a too-small buffer is refused."""
+    for (npr, nb, nc, pm) in ((300_001, 50_003, 24, 1), (300_001, 50_003, 24, 2), (5000, 700, 3, 1)):
+        probe = synth.make_side(npr, 42, synth.PROBE_LEN, nc)
+        build = synth.make_side(nb, 43, synth.DENSE_BUILD_LEN if npr < 10000 else synth.BUILD_LEN, nc)
+        ep, eb = eng.overlap(probe, build, True, nc, partition_mode=2)
+        ptrs, sides = [], []
+        for side in (probe, build):
+            ps = []
+            for col in side:
+                p = eng.dev_alloc(max(4 * len(col), 16))
+                eng.h2d(p, np.ascontiguousarray(col, np.int32))
+                ps.append(p)
+            ptrs += ps
+            sides.append(eng.dev_side(ps[0], ps[1], ps[2], len(side[0])))
+        opts = _engine.make_opts(True, nc, partition_mode=pm)
+        ix = eng.index_build_dev(sides[1], opts)
+        total = len(ep)
+        op, ob = eng.dev_alloc(max(4 * total, 16)), eng.dev_alloc(max(4 * total, 16))
+        n_small, fits = eng.overlap_fused_dev(ix, sides[0], opts, op, ob, max(total // 2, 1))
+        assert not fits and n_small == total
+        n_pairs, fits = eng.overlap_fused_dev(ix, sides[0], opts, op, ob, total)
+        assert fits and n_pairs == total
+        hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
+        eng.d2h(hp, op)
+        eng.d2h(hb, ob)
+        raw_runs = int((np.diff(hp) != 0).sum()) + 1
+        assert raw_runs == len(np.unique(hp))
+        hp, hb = _canon(hp, hb)
+        assert (hp == ep).all() and (hb == eb).all()
+        ix.close()
+        for p in ptrs + [op, ob]:
+            eng.dev_free(p)

@@ -10,6 +10,7 @@ for stage in "$@"; do
     pytest-fast) echo "== pytest gpu (no full-size)"; timeout 1500 python -m pytest tests -m gpu -q -x -k "not full_size" 2>&1 | tee gpurun_out/pytest_gpu.log | tail -30 ;;
     c2) echo "== bench config2"; timeout 900 python bench.py --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c2.err | tee gpurun_out/bench_c2.json; tail -22 gpurun_out/bench_c2.err ;;
     c3) echo "== bench config3"; timeout 1200 python bench.py --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c3.err | tee gpurun_out/bench_c3.json; tail -22 gpurun_out/bench_c3.err ;;
+    c3two) echo "== bench config3 two-pass"; timeout 1200 python bench.py --steps 10 --warmup 2 --two-pass --no-cpu-baseline 2>gpurun_out/bench_c3two.err | tee gpurun_out/bench_c3two.json ;;
     c3dense) echo "== bench config3 dense"; timeout 1200 python bench.py --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --kernel-table --no-cpu-baseline 2>gpurun_out/bench_c3d.err | tee gpurun_out/bench_c3d.json; tail -22 gpurun_out/bench_c3d.err ;;
     c4) echo "== bench config4 nearest"; timeout 1200 python bench.py --workload nearest_50M_2M_24contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c4.err | tee gpurun_out/bench_c4.json; tail -22 gpurun_out/bench_c4.err ;;
     c5) echo "== bench config5 count_overlaps"; timeout 1200 python bench.py --workload count_200M_200k_24contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c5.err | tee gpurun_out/bench_c5.json; tail -22 gpurun_out/bench_c5.err ;;
