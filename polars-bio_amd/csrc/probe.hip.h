@@ -575,7 +575,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
 
 // Pass 2.  tile_base = exclusive scan of tile_tot.
 template <bool STRICT>
-__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
+__global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fill(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
                                                                 bool vec_ok, const int32_t* __restrict__ hi_in,
                                                                 const int32_t* __restrict__ cnt_in,
                                                                 const long long* __restrict__ tile_base,
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill(IndexView ix, co
 // run to run (the two-pass path is the deterministic one).  state[0] = cursor (= total on exit),
 // state[1] = 1 when the capacity was exceeded (nothing is written past it).
 template <bool STRICT>
-__global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fused(IndexView ix, const int32_t* __restrict__ pc,
+__global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fused(IndexView ix, const int32_t* __restrict__ pc,
                                                                  const int32_t* __restrict__ ps,
                                                                  const int32_t* __restrict__ pe,
                                                                  const int32_t* __restrict__ probe_ids, int64_t n,
@@ -908,14 +908,14 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_general(IndexView ix,
 // row id of every permuted probe; the count and fill kernels then run unchanged on those columns.
 namespace ivj {
 
-constexpr int PART_THREADS = 512;
+constexpr int PART_THREADS = 1024;
 constexpr int PART_WAVES = PART_THREADS / kWave;
-constexpr int PART_ITEMS = 8;
+constexpr int PART_ITEMS = 4;
 constexpr int PART_TILE = PART_THREADS * PART_ITEMS;
 constexpr int PART_BUCKETS = 256;   // bucket 255 = probes without any candidate row
 
 // dynamic LDS of k_part_scatter
-constexpr size_t PART_LDS_BYTES = 4 * (size_t)PART_TILE * 4 /* s,e,c,row */ + (size_t)PART_TILE /* bucket ids */ +
+constexpr size_t PART_LDS_BYTES = (size_t)PART_TILE * 4 /* one column at a time */ + (size_t)PART_TILE /* bucket ids */ +
                                   (size_t)PART_WAVES * PART_BUCKETS * 4 + 3 * PART_BUCKETS * 4 + 16;
 
 template <bool STRICT>
@@ -1003,11 +1003,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(IndexView ix, con
                                                                int32_t* __restrict__ oc, int32_t* __restrict__ os,
                                                                int32_t* __restrict__ oe, int32_t* __restrict__ orow) {
     extern __shared__ __attribute__((aligned(16))) unsigned char part_lds[];
-    int32_t* l_s = reinterpret_cast<int32_t*>(part_lds);
-    int32_t* l_e = l_s + PART_TILE;
-    int32_t* l_c = l_e + PART_TILE;
-    int32_t* l_r = l_c + PART_TILE;
-    uint32_t* wcnt = reinterpret_cast<uint32_t*>(l_r + PART_TILE);          // [PART_WAVES][PART_BUCKETS]
+    int32_t* l_buf = reinterpret_cast<int32_t*>(part_lds);                   // one column of the tile
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(l_buf + PART_TILE);         // [PART_WAVES][PART_BUCKETS]
     uint32_t* run = wcnt + PART_WAVES * PART_BUCKETS;                        // running count per bucket
     uint32_t* lstart = run + PART_BUCKETS;                                   // tile-local start of each bucket
     uint32_t* goff = lstart + PART_BUCKETS;                                  // global offset of (bucket, tile)
@@ -1072,26 +1069,40 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(IndexView ix, con
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j) rank[j] += wcnt[w * PART_BUCKETS + d[j]];
-    // stage the records at their sorted tile-local position
+    // Columns are exchanged ONE AT A TIME through a single LDS buffer (4 KiB-threads x 4 B): small
+    // LDS footprint -> four workgroups per CU overlap their load / rank / store phases.
+    uint32_t pos[PART_ITEMS];
 #pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j) {
-        if (chunk0 + j * kWave + lane < tile_n) {
-            const uint32_t pos = lstart[d[j]] + rank[j];
-            l_s[pos] = s[j]; l_e[pos] = e[j]; l_c[pos] = c[j]; l_r[pos] = r[j];
-            l_d[pos] = (unsigned char)d[j];
-        }
+        pos[j] = lstart[d[j]] + rank[j];
+        if (chunk0 + j * kWave + lane < tile_n) l_d[pos[j]] = (unsigned char)d[j];
     }
     __syncthreads();
-    // linear copy-out: consecutive threads write consecutive elements of one bucket run
+    // destination of the sorted tile element il = j*PART_THREADS + tid (consecutive threads ->
+    // consecutive elements of one bucket run -> coalesced stores)
+    uint32_t g[PART_ITEMS];
 #pragma unroll
     for (int j = 0; j < PART_ITEMS; ++j) {
         const int il = j * PART_THREADS + tid;
-        if (il < tile_n) {
-            const uint32_t dd = l_d[il];
-            const uint32_t g = goff[dd] + ((uint32_t)il - lstart[dd]);
-            os[g] = l_s[il]; oe[g] = l_e[il]; oc[g] = l_c[il]; orow[g] = l_r[il];
-        }
+        g[j] = 0;
+        if (il < tile_n) { const uint32_t dd = l_d[il]; g[j] = goff[dd] + ((uint32_t)il - lstart[dd]); }
     }
+#define IVJ_PART_EXCHANGE(SRC, DST)                                                          \
+    do {                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < PART_ITEMS; ++j)                                \
+            if (chunk0 + j * kWave + lane < tile_n) l_buf[pos[j]] = SRC[j];                   \
+        __syncthreads();                                                                      \
+        _Pragma("unroll") for (int j = 0; j < PART_ITEMS; ++j) {                              \
+            const int il = j * PART_THREADS + tid;                                            \
+            if (il < tile_n) DST[g[j]] = l_buf[il];                                           \
+        }                                                                                     \
+        __syncthreads();                                                                      \
+    } while (0)
+    IVJ_PART_EXCHANGE(s, os);
+    IVJ_PART_EXCHANGE(e, oe);
+    IVJ_PART_EXCHANGE(c, oc);
+    IVJ_PART_EXCHANGE(r, orow);
+#undef IVJ_PART_EXCHANGE
 }
 
 }  // namespace ivj
