@@ -228,7 +228,8 @@ __device__ __forceinline__ bool window_mask(const IndexView& ix, int a, int hi, 
     while (p >= a) {
         const int base = p & ~3;
         const int4 v01 = *reinterpret_cast<const int4*>(ix.ep + base);
-        const int4 v23 = *reinterpret_cast<const int4*>(ix.ep + base + 2);
+        int4 v23 = make_int4(0, 0, 0, 0);                   // rows base+2, base+3: only when p reaches them
+        if ((p & 3) >= 2) v23 = *reinterpret_cast<const int4*>(ix.ep + base + 2);
         const int32_t en[4] = {v01.x, v01.z, v23.x, v23.z};
         const int32_t pm[4] = {v01.y, v01.w, v23.y, v23.w};
 #pragma unroll
