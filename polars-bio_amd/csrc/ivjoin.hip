@@ -104,6 +104,8 @@ struct ivj_index {
     uint32_t* bins = nullptr;
     int4* cmeta_e = nullptr;
     uint32_t* bins_e = nullptr;
+    int4* brec = nullptr;
+    int4* brec_e = nullptr;
     int32_t* pargmax = nullptr;
     int64_t bins_len = 0;
     bool has_end_order = false;
@@ -238,7 +240,10 @@ IndexView view_of(const ivj_index* ix) {
     IndexView v;
     v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
     v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
-    v.cmeta = ix->cmeta; v.bins = ix->bins; v.cmeta_e = ix->cmeta_e; v.bins_e = ix->bins_e; v.pargmax = ix->pargmax;
+    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax;
+    v.bins = ix->bins; v.bins_e = ix->bins_e;
+    // 16-byte bin records once the 4-byte tables + key arrays no longer fit the XCD L2s anyway
+    v.use_rec = ix->n >= (1ll << 20) ? 1 : 0;
     return v;
 }
 
@@ -278,6 +283,8 @@ int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
         LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->e_end, (const int32_t*)ckeys, n,
                ix->n_contigs, (const int4*)ix->cmeta_e, ix->bins_e);
         device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", ix->bins_e, ix->bins_e, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
+        LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins_e, ix->bins_len,
+               (const int32_t*)ix->e_end, (const int4*)ix->cmeta_e, ix->n_contigs, ix->brec_e);
     }
     ix->has_end_order = true;
     return IVJ_OK;
@@ -307,7 +314,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t nc = (size_t)opts->n_contigs;
         ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
         const size_t small = align_up((nc + 2) * 4) + align_up(16) + 2 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e
-        const size_t need = 6 * col + align_up(nn * 8) + 2 * align_up((size_t)ix->bins_len * 4) + small + 256;
+        const size_t need = 6 * col + align_up(nn * 8) + 2 * align_up((size_t)ix->bins_len * 4) +
+                            2 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
             ctx->ix_cache = nullptr; ctx->ix_cache_cap = 0;
@@ -326,6 +334,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->pargmax = (int32_t*)p; p += col;
         ix->bins = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
         ix->bins_e = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
+        ix->brec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
+        ix->brec_e = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
         char* small_base = p;
         ix->seg = (int32_t*)p; p += align_up((nc + 2) * 4);
         ix->flags = (int32_t*)p; p += align_up(16);
@@ -369,6 +379,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
             LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int32_t*)ix->b_contig, n,
                    opts->n_contigs, (const int4*)ix->cmeta, ix->bins);
             device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", ix->bins, ix->bins, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
+            LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
+                   (const int32_t*)ix->b_start, (const int4*)ix->cmeta, opts->n_contigs, ix->brec);
         }
         if (with_end_order) { r = build_end_order(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
     } else {

@@ -8,9 +8,10 @@
 //   seg[n_contigs + 2]   segment offsets; seg[n_contigs] = number of valid rows
 //   e_end / e_pos [Nb]   optional: ends sorted by (contig, end, position), and that position
 //   cmeta[n_contigs]     per-contig {segment, min/max start, bin shift, table offset}
-//   bins[2 Nb + 2 n_contigs] direct-address table over start: about one build row per bin, so the
-//                        hi-bound of a probe is ONE table read plus a search over the few rows
-//                        of that bin instead of a log2(Nb)-step binary search of dependent gathers
+//   brec[2 Nb + 2 n_contigs] direct-address table over start, 16 B per bin: first position of the
+//                        bin and the keys of the next three rows; about one build row per bin, so
+//                        the hi-bound of a probe is ONE 16-byte gather (3 compares) instead of a
+//                        log2(Nb)-step binary search of dependent gathers
 //
 // Predicate (polars_bio/range_op.py:75-84; src/option.rs:95-100):
 //   STRICT: q.start <  b.end && b.start <  q.end      WEAK: <=
@@ -37,9 +38,14 @@ struct IndexView {
     const int32_t* e_pos;
     const int32_t* flags;  // flags[0] != 0: some build row has start > end
     const int4* cmeta;     // per contig: {a, b, ulo, uhi} {shift, tb, 0, 0}  (two int4)
-    const uint32_t* bins;  // direct-address table: bins[tb + j] = first position with ustart >= ulo + (j << shift)
+    const int4* brec;      // direct-address table: brec[tb + j] = {p0, key[p0], key[p0+1], key[p0+2]} with
+                           // p0 = first position whose ustart >= ulo + (j << shift)
+    const uint32_t* bins;  // the same table as plain first positions (4 B per bin): used instead of brec for
+                           // small build sides, whose 4-byte tables + key arrays stay L2-resident
     const int4* cmeta_e;   // the same pair of structures over the end-sorted order (e_end)
+    const int4* brec_e;
     const uint32_t* bins_e;
+    int32_t use_rec;       // 1: gather 16-byte records, 0: 4-byte bins + bound search on the key array
     const int32_t* pargmax; // position of the first row that attains ep[p].y (prefix max) -- nearest only
     int32_t n_contigs;
 };
@@ -136,12 +142,12 @@ __device__ __forceinline__ void bound_hi4(const IndexView& ix, const int (&a)[PR
 // of contig c[k]'s segment with flip(keys[p]) >= tu[k].  Targets are compared on the flipped
 // (unsigned-ordered) coordinates in 64 bits, so negative coordinates and INT32_MAX + 1 need no
 // special case.  One table read + a search over the rows of one bin.
-__device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const uint32_t* __restrict__ bins,
+__device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const int4* __restrict__ brec,
+                                        const uint32_t* __restrict__ bins, bool use_rec,
                                         const int32_t* __restrict__ keys, int32_t n_contigs,
                                         const int32_t (&c)[PROBE_ITEMS], const bool (&valid)[PROBE_ITEMS],
                                         const unsigned long long (&tu)[PROBE_ITEMS],
                                         int (&a)[PROBE_ITEMS], int (&b)[PROBE_ITEMS], int (&out)[PROBE_ITEMS]) {
-    int lo[PROBE_ITEMS], hi[PROBE_ITEMS];
     int4 m0[PROBE_ITEMS], m1[PROBE_ITEMS];
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
@@ -149,45 +155,70 @@ __device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const ui
         if (ok) { m0[k] = cmeta[2 * c[k]]; m1[k] = cmeta[2 * c[k] + 1]; }
         else { m0[k] = make_int4(0, 0, 0, 0); m1[k] = make_int4(0, 0, 0, 0); }
     }
-    uint32_t t0[PROBE_ITEMS], t1[PROBE_ITEMS];
+    int4 rec[PROBE_ITEMS];
+    uint32_t slot[PROBE_ITEMS];
     bool inb[PROBE_ITEMS];
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
         a[k] = m0[k].x; b[k] = m0[k].y;
         const uint32_t ulo = (uint32_t)m0[k].z, uhi = (uint32_t)m0[k].w;
-        inb[k] = false;
-        if (b[k] <= a[k] || tu[k] <= ulo) { lo[k] = hi[k] = a[k]; }
-        else if (tu[k] > uhi) { lo[k] = hi[k] = b[k]; }
+        inb[k] = false; slot[k] = 0; rec[k] = make_int4(0, 0, 0, 0);
+        if (b[k] <= a[k] || tu[k] <= ulo) out[k] = a[k];
+        else if (tu[k] > uhi) out[k] = b[k];
         else {
-            const uint32_t j = ((uint32_t)tu[k] - ulo) >> m1[k].x;
             inb[k] = true;
-            t0[k] = bins[(uint32_t)m1[k].y + j];
-            t1[k] = bins[(uint32_t)m1[k].y + j + 1];
+            slot[k] = (uint32_t)m1[k].y + (((uint32_t)tu[k] - ulo) >> m1[k].x);
+            if (use_rec) rec[k] = brec[slot[k]];
+            else { rec[k].x = (int)bins[slot[k]]; rec[k].y = (int)bins[slot[k] + 1]; }
         }
     }
-#pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) if (inb[k]) { lo[k] = (int)t0[k]; hi[k] = (int)t1[k]; }
-    for (;;) {
-        bool any = false;
-        int32_t v[PROBE_ITEMS];
-        int m[PROBE_ITEMS];
+    if (use_rec) {
 #pragma unroll
         for (int k = 0; k < PROBE_ITEMS; ++k) {
-            m[k] = lo[k] + ((hi[k] - lo[k]) >> 1);
-            const bool act = lo[k] < hi[k];
-            any |= act;
-            v[k] = act ? keys[m[k]] : 0;
+            if (!inb[k]) continue;
+            // rows p0, p0+1, p0+2 of the bin (or later bins / a sentinel past the segment): keys
+            // ascend, so the number of leading keys below the target is the offset of the bound
+            const bool n0 = (unsigned long long)flip(rec[k].y) < tu[k];
+            const bool n1 = n0 && (unsigned long long)flip(rec[k].z) < tu[k];
+            const bool n2 = n1 && (unsigned long long)flip(rec[k].w) < tu[k];
+            int lo = rec[k].x + (n0 ? 1 : 0) + (n1 ? 1 : 0) + (n2 ? 1 : 0);
+            if (n2) {
+                // crowded bin: finish with a bound search up to the first row of the next bin
+                int hi = brec[slot[k] + 1].x;
+                while (lo < hi) {
+                    const int m = lo + ((hi - lo) >> 1);
+                    if ((unsigned long long)flip(keys[m]) < tu[k]) lo = m + 1; else hi = m;
+                }
+            }
+            out[k] = lo;
         }
-        if (!any) break;
+    } else {
+        // four interleaved bound searches over the rows of one bin each
+        int lo[PROBE_ITEMS], hi[PROBE_ITEMS];
 #pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) {
-            if (lo[k] < hi[k]) {
-                if ((unsigned long long)flip(v[k]) < tu[k]) lo[k] = m[k] + 1; else hi[k] = m[k];
+        for (int k = 0; k < PROBE_ITEMS; ++k) { lo[k] = inb[k] ? rec[k].x : 0; hi[k] = inb[k] ? rec[k].y : 0; }
+        for (;;) {
+            bool any = false;
+            int32_t v[PROBE_ITEMS];
+            int m[PROBE_ITEMS];
+#pragma unroll
+            for (int k = 0; k < PROBE_ITEMS; ++k) {
+                m[k] = lo[k] + ((hi[k] - lo[k]) >> 1);
+                const bool act = lo[k] < hi[k];
+                any |= act;
+                v[k] = act ? keys[m[k]] : 0;
+            }
+            if (!any) break;
+#pragma unroll
+            for (int k = 0; k < PROBE_ITEMS; ++k) {
+                if (lo[k] < hi[k]) {
+                    if ((unsigned long long)flip(v[k]) < tu[k]) lo[k] = m[k] + 1; else hi[k] = m[k];
+                }
             }
         }
-    }
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) out[k] = lo[k];
+        for (int k = 0; k < PROBE_ITEMS; ++k) if (inb[k]) out[k] = lo[k];
+    }
 }
 
 // hi = first position whose start fails "start (<) q.end": first start >= q.end (STRICT) / > q.end (WEAK)
@@ -198,7 +229,7 @@ __device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t
     unsigned long long tu[PROBE_ITEMS];
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) tu[k] = (unsigned long long)flip(qe[k]) + (STRICT ? 0ull : 1ull);
-    lb_tab4(ix.cmeta, ix.bins, ix.b_start, ix.n_contigs, c, valid, tu, a, b, out);
+    lb_tab4(ix.cmeta, ix.brec, ix.bins, ix.use_rec != 0, ix.b_start, ix.n_contigs, c, valid, tu, a, b, out);
 }
 // r = first position of the end-sorted segment whose end satisfies "q.start (<) end":
 // first end > q.start (STRICT) / >= q.start (WEAK)
@@ -210,7 +241,7 @@ __device__ __forceinline__ void bound_r_tab4(const IndexView& ix, const int32_t 
     int a[PROBE_ITEMS], b[PROBE_ITEMS];
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) tu[k] = (unsigned long long)flip(qs[k]) + (STRICT ? 1ull : 0ull);
-    lb_tab4(ix.cmeta_e, ix.bins_e, ix.e_end, ix.n_contigs, c, valid, tu, a, b, out);
+    lb_tab4(ix.cmeta_e, ix.brec_e, ix.bins_e, ix.use_rec != 0, ix.e_end, ix.n_contigs, c, valid, tu, a, b, out);
 }
 
 // Window of a probe below hi as a 32-bit match mask: bit j set <=> row hi-1-j overlaps.  The scan
@@ -409,6 +440,28 @@ __global__ void k_bins_mark(const int32_t* __restrict__ b_start, const int32_t* 
     const bool last = (p == m0.y - 1) || (((flip(b_start[p + 1]) - ulo) >> m1.x) > j);
     if (last) bins[(uint32_t)m1.y + j + 1] = (uint32_t)p + 1u;
     if (p == m0.x) bins[(uint32_t)m1.y] = (uint32_t)p;
+}
+
+// brec[i] = {p0, key[p0], key[p0+1], key[p0+2]} for table slot i (p0 = bins[i] after the max-scan);
+// keys past the end of the slot's contig segment are replaced by INT32_MAX (compares as "not below"
+// any reachable target).  The contig of a slot is found by a bound search over the table offsets.
+__global__ void k_bins_records(const uint32_t* __restrict__ bins, int64_t bins_len, const int32_t* __restrict__ keys,
+                               const int4* __restrict__ cmeta, int32_t n_contigs, int4* __restrict__ brec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bins_len) return;
+    // last contig whose table offset tb = cmeta[2c+1].y is <= i
+    int lo = 0, hi = n_contigs;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= i) lo = m + 1; else hi = m; }
+    const int c = lo - 1;
+    const int p0 = (int)bins[i];
+    int32_t k0 = 0x7fffffff, k1 = 0x7fffffff, k2 = 0x7fffffff;
+    if (c >= 0) {
+        const int bend = cmeta[2 * c].y;
+        if (p0 < bend) k0 = keys[p0];
+        if (p0 + 1 < bend) k1 = keys[p0 + 1];
+        if (p0 + 2 < bend) k2 = keys[p0 + 2];
+    }
+    brec[i] = make_int4(p0, k0, k1, k2);
 }
 
 // ------------------------------------------------------------------ overlap: count -> fill
