@@ -90,6 +90,7 @@ struct ivj_ctx {
 
 struct ivj_index {
     ivj_ctx* ctx = nullptr;
+    int32_t table_mode = 0;
     int64_t n = 0;
     int32_t n_contigs = 0;
     int32_t* b_start = nullptr;
@@ -225,6 +226,7 @@ int check_opts(const ivj_opts* o) {
     if (!o) return fail(IVJ_EINVAL, "opts is NULL");
     if (o->filter_op != IVJ_FILTER_WEAK && o->filter_op != IVJ_FILTER_STRICT) return fail(IVJ_EINVAL, "filter_op must be 0 (Weak) or 1 (Strict)");
     if (o->n_contigs < 0) return fail(IVJ_EINVAL, "n_contigs < 0");
+    if (o->table_mode < 0 || o->table_mode > 2) return fail(IVJ_EINVAL, "table_mode must be 0 (auto), 1 (records) or 2 (bins)");
     if (o->partition_mode < 0 || o->partition_mode > 2) return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (always) or 2 (never)");
     return IVJ_OK;
 }
@@ -243,7 +245,7 @@ IndexView view_of(const ivj_index* ix) {
     v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax;
     v.bins = ix->bins; v.bins_e = ix->bins_e;
     // 16-byte bin records once the 4-byte tables + key arrays no longer fit the XCD L2s anyway
-    v.use_rec = ix->n >= (1ll << 20) ? 1 : 0;
+    v.use_rec = ix->table_mode == 1 ? 1 : (ix->table_mode == 2 ? 0 : (ix->n >= (1ll << 20) ? 1 : 0));
     return v;
 }
 
@@ -305,7 +307,7 @@ int build_argmax(ivj_ctx* ctx, ivj_index* ix) {
 
 int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int with_end_order, ivj_index** out) {
     ivj_index* ix = new ivj_index();
-    ix->ctx = ctx; ix->n = build->n; ix->n_contigs = opts->n_contigs;
+    ix->ctx = ctx; ix->n = build->n; ix->n_contigs = opts->n_contigs; ix->table_mode = opts->table_mode;
     const int64_t n = build->n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     auto cleanup = [&](int code) { ivj_index_free(ix); return code; };

@@ -44,7 +44,7 @@ class _Side(C.Structure):
 
 class _Opts(C.Structure):
     _fields_ = [("filter_op", C.c_int32), ("n_contigs", C.c_int32), ("nearest_k", C.c_int32),
-                ("include_overlaps", C.c_int32), ("partition_mode", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("include_overlaps", C.c_int32), ("partition_mode", C.c_int32), ("table_mode", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class _Pairs(C.Structure):
@@ -130,8 +130,10 @@ def _host_side(contig, start, end) -> Tuple[_Side, tuple]:
     return _Side(c.ctypes.data, s.ctypes.data, e.ctypes.data, c.shape[0], None), (c, s, e)
 
 
-def make_opts(strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True, partition_mode: int = 0) -> _Opts:
+def make_opts(strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True, partition_mode: int = 0,
+              table_mode: int = 0) -> _Opts:
     o = _Opts()
+    o.table_mode = int(table_mode)
     o.partition_mode = int(partition_mode)
     o.filter_op = FILTER_STRICT if strict else FILTER_WEAK
     o.n_contigs = int(n_contigs)
@@ -180,12 +182,12 @@ class Engine:
             pass
 
     # ---- host-buffer entry points (numpy in, numpy out) --------------------
-    def overlap(self, probe, build, strict: bool, n_contigs: int, partition_mode: int = 0):
+    def overlap(self, probe, build, strict: bool, n_contigs: int, partition_mode: int = 0, table_mode: int = 0):
         """probe/build: (contig_id, start, end) int32 arrays -> (probe_idx, build_idx).
         partition_mode: 0 auto, 1 force the bucketed path, 2 never (pairs then come in probe-row order)."""
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
-        o = make_opts(strict, n_contigs, partition_mode=partition_mode)
+        o = make_opts(strict, n_contigs, partition_mode=partition_mode, table_mode=table_mode)
         out = _Pairs()
         _check(self.L, self.L.ivj_overlap(self.h, C.byref(ps), C.byref(bs), C.byref(o), C.byref(out)), "ivj_overlap")
         try:
@@ -199,22 +201,23 @@ class Engine:
             self.L.ivj_pairs_free(C.byref(out))
             del keep_p, keep_b
 
-    def count_overlaps(self, probe, build, strict: bool, n_contigs: int) -> np.ndarray:
+    def count_overlaps(self, probe, build, strict: bool, n_contigs: int, table_mode: int = 0) -> np.ndarray:
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
-        o = make_opts(strict, n_contigs)
+        o = make_opts(strict, n_contigs, table_mode=table_mode)
         counts = np.empty(ps.n, np.int64)
         _check(self.L, self.L.ivj_count_overlaps(self.h, C.byref(ps), C.byref(bs), C.byref(o), counts.ctypes.data),
                "ivj_count_overlaps")
         del keep_p, keep_b
         return counts
 
-    def nearest(self, probe, build, strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True):
+    def nearest(self, probe, build, strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True,
+                table_mode: int = 0):
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
         if k < 1:
             raise ValueError("k must be >= 1")
-        o = make_opts(strict, n_contigs, k, include_overlaps)
+        o = make_opts(strict, n_contigs, k, include_overlaps, table_mode=table_mode)
         idx = np.empty((ps.n, k), np.int32)
         dist = np.empty((ps.n, k), np.int64)
         nf = np.empty(ps.n, np.int32)

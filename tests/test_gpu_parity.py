@@ -36,15 +36,18 @@ def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1
     p, b = _canon(*eng.overlap(probe, build, strict, n_contigs, partition_mode=1))   # bucketed path
     assert len(p) == len(ep), ("partitioned", len(p), len(ep))
     assert (p == ep).all() and (b == eb).all(), "partitioned path"
-    c = eng.count_overlaps(probe, build, strict, n_contigs)
+    p, b = _canon(*eng.overlap(probe, build, strict, n_contigs, partition_mode=1, table_mode=1))   # 16-byte bin records
+    assert len(p) == len(ep) and (p == ep).all() and (b == eb).all(), "record table"
     ec = O.count_overlaps_brute(ps, bs, strict) if brute else O.count_overlaps_fast(ix, ps, strict)
-    assert (c == ec).all()
+    for tm in (2, 1):                                    # 4-byte bins / 16-byte records
+        assert (eng.count_overlaps(probe, build, strict, n_contigs, table_mode=tm) == ec).all(), tm
     for k, inc in nearest_cfgs:
-        i, d, n = eng.nearest(probe, build, strict, n_contigs, k, inc)
         ei, ed, en = (O.nearest_brute(ps, bs, strict, k, inc) if brute else O.nearest_fast(ix, ps, strict, k, inc))
-        assert (n == en).all(), (k, inc)
-        assert (d == ed).all(), (k, inc)
-        assert (i == ei).all(), (k, inc)
+        for tm in (2, 1):
+            i, d, n = eng.nearest(probe, build, strict, n_contigs, k, inc, table_mode=tm)
+            assert (n == en).all(), (k, inc, tm)
+            assert (d == ed).all(), (k, inc, tm)
+            assert (i == ei).all(), (k, inc, tm)
 
 
 @pytest.mark.parametrize("strict", [True, False])
@@ -69,10 +72,11 @@ def test_random_medium_ragged_sizes(eng, strict):
         _cmp_all(eng, probe, build, 3, strict, nearest_cfgs=((1, True), (2, False)))
 
 
-def test_many_contigs_two_digit_passes(eng):
-    """More than 256 contigs -> two radix passes over the contig id; ids outside the dictionary never match."""
+@pytest.mark.parametrize("nc", [700, 1500])
+def test_many_contigs_two_digit_passes(eng, nc):
+    """More than 256 contigs -> two radix passes over the contig id (1500: per-contig metadata no
+    longer staged in LDS by the bucketing kernels); ids outside the dictionary never match."""
     rng = np.random.default_rng(5)
-    nc = 700
     build = random_side(rng, 30000, nc, 5000, 100)
     probe = random_side(rng, 20000, nc + 5, 5000, 100)
     probe[0][:10] = -3
