@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--two-pass", action="store_true",
                     help="overlap: always use the deterministic count -> fill pair (default: the fused single pass "
                          "into the preallocated result buffers once the warmup has sized them)")
+    ap.add_argument("--partition-mode", type=int, default=0,
+                    help="ivj_opts.partition_mode: 0 auto, 1 256-way, 2 none, 3 fine (8192-way + LDS-resident slices)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (RCCL init, sharding, all-gatherv) even with one rank")
     return ap.parse_args()
@@ -163,7 +165,8 @@ def main():
         if op == "overlap":
             # the first (warmup) step sizes the result buffers; later steps write into them, so the
             # timed region holds no device allocation
-            p, b = join.overlap(d_probe, d_build, True, nc, out=state.get("out"), fused=not args.two_pass)
+            p, b = join.overlap(d_probe, d_build, True, nc, out=state.get("out"), fused=not args.two_pass,
+                                partition_mode=args.partition_mode)
             if "out" not in state:
                 state["out"] = (torch.empty_like(p), torch.empty_like(b))
             local = int(p.shape[0])

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "probe.hip.h"
+#include "fine.hip.h"
 #include "radix_sort.hip.h"
 #include "scan.hip.h"
 
@@ -227,7 +228,7 @@ int check_opts(const ivj_opts* o) {
     if (o->filter_op != IVJ_FILTER_WEAK && o->filter_op != IVJ_FILTER_STRICT) return fail(IVJ_EINVAL, "filter_op must be 0 (Weak) or 1 (Strict)");
     if (o->n_contigs < 0) return fail(IVJ_EINVAL, "n_contigs < 0");
     if (o->table_mode < 0 || o->table_mode > 2) return fail(IVJ_EINVAL, "table_mode must be 0 (auto), 1 (records) or 2 (bins)");
-    if (o->partition_mode < 0 || o->partition_mode > 2) return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (always) or 2 (never)");
+    if (o->partition_mode < 0 || o->partition_mode > 3) return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (always), 2 (never) or 3 (fine, fused path only)");
     return IVJ_OK;
 }
 int check_side(const ivj_side* s, const char* what) {
@@ -424,7 +425,7 @@ int ensure_ov(ivj_ctx* ctx, int64_t n, bool with_part) {
 // Probe bucketing pays once the index no longer fits the L2s and there are enough probes to
 // amortise the two extra passes.  opts->partition_mode: 0 auto, 1 always, 2 never.
 bool want_partition(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts) {
-    if (opts->partition_mode == 1) return true;
+    if (opts->partition_mode == 1 || opts->partition_mode == 3) return true;
     if (opts->partition_mode == 2) return false;
     return n_probe >= (4ll << 20) && ix->n >= (256ll << 10);
 }
@@ -530,6 +531,61 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     return IVJ_OK;
 }
 
+// "fine" single pass: 8192-way bucketing (atomics) + join kernel with LDS-resident index slices.
+// Available when a bucket spans at most FINE_SLOTS table slots.
+bool fine_available(const ivj_index* ix) { return (ix->bins_len >> FINE_SLOT_BITS) <= (int64_t)(FINE_BUCKETS - 2); }
+
+int overlap_fused_fine(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
+                       int64_t capacity, int64_t* n_pairs) {
+    const int64_t n = probe->n;
+    ctx->ov_n = -1;
+    *n_pairs = 0;
+    if (n == 0 || ix->n == 0) return IVJ_OK;
+    IVJ_TRY(ensure_ov(ctx, n, true));
+    int bshift = 0;
+    while ((ix->bins_len >> bshift) > (int64_t)(FINE_BUCKETS - 2)) ++bshift;
+    const int64_t jgrid = (n + FINE_TILE - 1) / FINE_TILE + FINE_BUCKETS;      // upper bound on the number of tiles
+    IVJ_TRY(arena_reserve(ctx, 4 * align_up((size_t)(FINE_BUCKETS + 1) * 4) + align_up((size_t)FINE_BUCKETS * 8) +
+                               align_up((size_t)jgrid * 4) + 4096));
+    uint32_t* gcount = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
+    uint32_t* gstart = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
+    uint32_t* cursor = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
+    uint32_t* tprefix = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
+    int2* brange = arena_take<int2>(ctx, FINE_BUCKETS);
+    uint32_t* tbucket = arena_take<uint32_t>(ctx, jgrid);
+    int4* prec = reinterpret_cast<int4*>(ctx->pt_c);          // the four permuted columns' space holds the 16-byte records
+    unsigned long long* state = (unsigned long long*)ctx->ov_tile;
+    HIP_TRY(hipMemsetAsync(gcount, 0, (size_t)(FINE_BUCKETS + 1) * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(state, 0, 16, ctx->stream));
+    IndexView v = view_of(ix);
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
+    const int hgrid = 1024;
+    if (strict) LAUNCH(ctx, "fine_hist", (k_fine_hist<true>), hgrid, 1024, v, probe->contig, probe->end, n, bshift, vec, gcount);
+    else LAUNCH(ctx, "fine_hist", (k_fine_hist<false>), hgrid, 1024, v, probe->contig, probe->end, n, bshift, vec, gcount);
+    LAUNCH(ctx, "fine_offsets", k_fine_offsets, 1, 1024, (const uint32_t*)gcount, gstart, cursor, tprefix);
+    LAUNCH(ctx, "fine_tilemap", k_fine_tilemap, grid1d(FINE_BUCKETS, 256), 256, (const uint32_t*)ix->bins, (long long)ix->bins_len, bshift,
+           (const uint32_t*)tprefix, brange, tbucket);
+    const int64_t sgrid = (n + 8192 - 1) / 8192;
+    if (strict) LAUNCH(ctx, "fine_scatter", (k_fine_scatter<true>), sgrid, 1024, v, probe->contig, probe->start, probe->end, probe->row_id, n, bshift, vec,
+                       cursor, prec);
+    else LAUNCH(ctx, "fine_scatter", (k_fine_scatter<false>), sgrid, 1024, v, probe->contig, probe->start, probe->end, probe->row_id, n, bshift, vec,
+                cursor, prec);
+    if (strict) LAUNCH(ctx, "overlap_fused_fine", (k_overlap_fused_fine<true>), jgrid, FINE_THREADS, v, (const int4*)prec, (const uint32_t*)gstart,
+                       (const uint32_t*)tprefix, (const uint32_t*)tbucket, (const int2*)brange, bshift, (long long)ix->bins_len, (long long)capacity,
+                       state, out_p, out_b);
+    else LAUNCH(ctx, "overlap_fused_fine", (k_overlap_fused_fine<false>), jgrid, FINE_THREADS, v, (const int4*)prec, (const uint32_t*)gstart,
+                (const uint32_t*)tprefix, (const uint32_t*)tbucket, (const int2*)brange, bshift, (long long)ix->bins_len, (long long)capacity,
+                state, out_p, out_b);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    *n_pairs = ctx->h_total[0];
+    if (ctx->h_total[1] != 0)
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");
+    return IVJ_OK;
+}
+
 // single pass: (bucketing +) fused count/fill into a caller buffer of known capacity
 int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
                   int64_t capacity, int64_t* n_pairs) {
@@ -537,6 +593,7 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     ctx->ov_n = -1;                                   // invalidates a pending count -> fill hand-over
     *n_pairs = 0;
     if (n == 0 || ix->n == 0) return IVJ_OK;
+    if (opts->partition_mode == 3 && fine_available(ix)) return overlap_fused_fine(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
     const bool part = want_partition(ix, n, opts);
     IVJ_TRY(ensure_ov(ctx, n, part));
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;

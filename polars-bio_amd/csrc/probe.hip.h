@@ -531,16 +531,21 @@ __device__ __forceinline__ void probe_windows(const IndexView& ix, const int32_t
 // ballot + popcount of the lower lanes gives every matching lane its slot.
 constexpr int FILL_STAGE = 3072;
 
-template <bool STRICT>
-__device__ __forceinline__ void emit_tile(const IndexView& ix, const int32_t (&hi)[PROBE_ITEMS],
-                                          const int32_t (&x)[PROBE_ITEMS], const int32_t (&cnt)[PROBE_ITEMS],
-                                          const int32_t (&row)[PROBE_ITEMS], const int32_t (&qs)[PROBE_ITEMS],
-                                          long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b,
-                                          int32_t* __restrict__ out_probe, int32_t* __restrict__ out_build) {
+struct GlobalRow {
+    const int32_t* b_row;
+    __device__ __forceinline__ int32_t operator()(int p) const { return b_row[p]; }
+};
+
+template <bool STRICT, int THREADS, int STAGE, class RowOf>
+__device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf& rowof, const int32_t (&hi)[PROBE_ITEMS],
+                                               const int32_t (&x)[PROBE_ITEMS], const int32_t (&cnt)[PROBE_ITEMS],
+                                               const int32_t (&row)[PROBE_ITEMS], const int32_t (&qs)[PROBE_ITEMS],
+                                               long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b,
+                                               int32_t* __restrict__ out_probe, int32_t* __restrict__ out_build) {
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long lt_lanes = (1ull << lane) - 1ull;
-    for (long long w0 = 0; w0 < tot; w0 += FILL_STAGE) {
-        const long long w1 = w0 + FILL_STAGE;
+    for (long long w0 = 0; w0 < tot; w0 += STAGE) {
+        const long long w1 = w0 + STAGE;
         long long off = loc0;                                  // tile-local offset of the current probe
 #pragma unroll
         for (int k = 0; k < PROBE_ITEMS; ++k) {
@@ -588,13 +593,23 @@ __device__ __forceinline__ void emit_tile(const IndexView& ix, const int32_t (&h
             off = end;
         }
         __syncthreads();
-        const int t = (int)((tot - w0) < (long long)FILL_STAGE ? (tot - w0) : (long long)FILL_STAGE);
-        for (int i = threadIdx.x; i < t; i += PROBE_THREADS) {
+        const int t = (int)((tot - w0) < (long long)STAGE ? (tot - w0) : (long long)STAGE);
+        for (int i = threadIdx.x; i < t; i += THREADS) {
             out_probe[tbase + w0 + i] = st_p[i];
             out_build[tbase + w0 + i] = st_b[i];
         }
         __syncthreads();
     }
+}
+
+template <bool STRICT>
+__device__ __forceinline__ void emit_tile(const IndexView& ix, const int32_t (&hi)[PROBE_ITEMS],
+                                          const int32_t (&x)[PROBE_ITEMS], const int32_t (&cnt)[PROBE_ITEMS],
+                                          const int32_t (&row)[PROBE_ITEMS], const int32_t (&qs)[PROBE_ITEMS],
+                                          long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b,
+                                          int32_t* __restrict__ out_probe, int32_t* __restrict__ out_build) {
+    emit_tile_rows<STRICT, PROBE_THREADS, FILL_STAGE>(ix, GlobalRow{ix.b_row}, hi, x, cnt, row, qs, loc0, tot, tbase, st_p, st_b,
+                                                       out_probe, out_build);
 }
 
 // Pass 1.  One workgroup = PROBE_TILE probes, PROBE_ITEMS consecutive probes per thread.

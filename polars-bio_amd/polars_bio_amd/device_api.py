@@ -42,13 +42,13 @@ class DeviceJoin:
         return self.engine.index_build_dev(build.as_c(), make_opts(strict, n_contigs), with_end_order)
 
     def overlap(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None, out=None,
-                fused: bool = True):
+                fused: bool = True, partition_mode: int = 0):
         """Index build (radix sort) + count + scan + fill.  -> (probe_idx, build_idx) int32 tensors.
         ``out``: optional pair of preallocated int32 CUDA tensors; views of their first n_pairs
         elements are returned when they are large enough (no allocation on the call path).  With
         ``out`` and ``fused`` the single-pass ivj_overlap_fused_dev is tried first."""
         torch = self.torch
-        opts = make_opts(strict, n_contigs)
+        opts = make_opts(strict, n_contigs, partition_mode=partition_mode)
         own = index is None
         ix = self.engine.index_build_dev(build.as_c(), opts, False) if own else index
         try:

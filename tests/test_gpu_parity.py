@@ -263,7 +263,8 @@ def test_bench_contract_and_rccl_path_single_rank(tmp_path):
 def test_fused_single_pass_matches_two_pass(eng):
     """ivj_overlap_fused_dev: same pair set; the pairs of one probe row stay contiguous and ordered
     (a stable sort by probe row gives the oracle's exact sequence); a too-small buffer is refused."""
-    for (npr, nb, nc, pm) in ((300_001, 50_003, 24, 1), (300_001, 50_003, 24, 2), (5000, 700, 3, 1)):
+    for (npr, nb, nc, pm) in ((300_001, 50_003, 24, 1), (300_001, 50_003, 24, 2), (5000, 700, 3, 1),
+                              (300_001, 50_003, 24, 3), (5000, 700, 3, 3), (777_777, 1_300_000, 24, 3)):
         probe = synth.make_side(npr, 42, synth.PROBE_LEN, nc)
         build = synth.make_side(nb, 43, synth.DENSE_BUILD_LEN if npr < 10000 else synth.BUILD_LEN, nc)
         ep, eb = eng.overlap(probe, build, True, nc, partition_mode=2)

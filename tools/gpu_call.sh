@@ -10,6 +10,9 @@ for stage in "$@"; do
     pytest-fast) echo "== pytest gpu (no full-size)"; timeout 1500 python -m pytest tests -m gpu -q -x -k "not full_size" 2>&1 | tee gpurun_out/pytest_gpu.log | tail -30 ;;
     c2) echo "== bench config2"; timeout 900 python bench.py --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c2.err | tee gpurun_out/bench_c2.json; tail -22 gpurun_out/bench_c2.err ;;
     c3) echo "== bench config3"; timeout 1200 python bench.py --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c3.err | tee gpurun_out/bench_c3.json; tail -22 gpurun_out/bench_c3.err ;;
+    c3fine) echo "== bench config3 fine"; timeout 1200 python bench.py --steps 10 --warmup 2 --partition-mode 3 --no-cpu-baseline --kernel-table 2>gpurun_out/bench_c3fine.err | tee gpurun_out/bench_c3fine.json; tail -24 gpurun_out/bench_c3fine.err ;;
+    c2fine) echo "== bench config2 fine"; timeout 1200 python bench.py --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --partition-mode 3 --no-cpu-baseline 2>gpurun_out/bench_c2fine.err | tee gpurun_out/bench_c2fine.json ;;
+    fusedtest) echo "== fused tests"; timeout 900 python -m pytest tests -m gpu -q -x -k "fused" 2>&1 | tail -15 ;;
     c3two) echo "== bench config3 two-pass"; timeout 1200 python bench.py --steps 10 --warmup 2 --two-pass --no-cpu-baseline 2>gpurun_out/bench_c3two.err | tee gpurun_out/bench_c3two.json ;;
     c3dense) echo "== bench config3 dense"; timeout 1200 python bench.py --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --kernel-table --no-cpu-baseline 2>gpurun_out/bench_c3d.err | tee gpurun_out/bench_c3d.json; tail -22 gpurun_out/bench_c3d.err ;;
     c4) echo "== bench config4 nearest"; timeout 1200 python bench.py --workload nearest_50M_2M_24contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c4.err | tee gpurun_out/bench_c4.json; tail -22 gpurun_out/bench_c4.err ;;
@@ -31,6 +34,14 @@ for stage in "$@"; do
         tail -1 gpurun_out/pmcx_$i.err | cut -c1-200; dirs="$dirs gpurun_out/pmcx_$i";
       done;
       python tools/pmc_summary.py $dirs > gpurun_out/pmcx_summary.json 2> gpurun_out/pmcx_summary.err; tail -3 gpurun_out/pmcx_summary.err ;;
+    pmcfine) echo "== PMC on the fine path";
+      i=0; dirs="";
+      for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM"; do
+        i=$((i+1));
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set -d "$OLDPWD/gpurun_out/pmcf_$i" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --partition-mode 3 > "$OLDPWD/gpurun_out/pmcf_$i.out" 2> "$OLDPWD/gpurun_out/pmcf_$i.err");
+        tail -1 gpurun_out/pmcf_$i.err | cut -c1-160; dirs="$dirs gpurun_out/pmcf_$i";
+      done;
+      python tools/pmc_summary.py $dirs > gpurun_out/pmcf_summary.json 2> gpurun_out/pmcf_summary.err; tail -3 gpurun_out/pmcf_summary.err ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
