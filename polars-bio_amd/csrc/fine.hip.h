@@ -24,7 +24,7 @@ constexpr int FINE_SLOTS = 1 << FINE_SLOT_BITS;
 constexpr int FINE_ROWS = 2560;          // build rows of a bucket cached in LDS
 constexpr int FINE_MARGIN = 128;         // rows below the bucket cached for the windows
 constexpr int FINE_THREADS = 512;
-constexpr int FINE_TILE = FINE_THREADS * PROBE_ITEMS;   // 2048 probes per workgroup
+constexpr int FINE_TILE = FINE_THREADS * PROBE_ITEMS;   // probes per workgroup
 constexpr int FINE_STAGE = 3072;         // pairs per output window
 
 template <bool STRICT>

@@ -517,9 +517,9 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     const bool dense = ctx->ov_total >= 8 * n;
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
     if (dense) {
-        if (strict) LAUNCH(ctx, "overlap_fill_dense", (k_overlap_fill_dense<true>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+        if (strict) LAUNCH(ctx, "overlap_fill_dense", (k_overlap_fill_dense<true, PROBE_ITEMS>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
                            (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
-        else LAUNCH(ctx, "overlap_fill_dense", (k_overlap_fill_dense<false>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+        else LAUNCH(ctx, "overlap_fill_dense", (k_overlap_fill_dense<false, PROBE_ITEMS>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
                     (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
     } else {
         if (strict) LAUNCH(ctx, "overlap_fill", (k_overlap_fill<true>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
@@ -644,10 +644,11 @@ int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_op
     if (k == 1 && opts->include_overlaps) {
         IVJ_TRY(build_argmax(ctx, ix));
         v = view_of(ix);
-        const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+        constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT;
+        const int64_t tiles = (n + NT - 1) / NT;
         const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
-        if (strict) LAUNCH(ctx, "nearest_k1", (k_nearest_k1<true>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, idx, (long long*)dist, nf);
-        else LAUNCH(ctx, "nearest_k1", (k_nearest_k1<false>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, idx, (long long*)dist, nf);
+        if (strict) LAUNCH(ctx, "nearest_k1", (k_nearest_k1<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, idx, (long long*)dist, nf);
+        else LAUNCH(ctx, "nearest_k1", (k_nearest_k1<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, idx, (long long*)dist, nf);
     } else {
         IVJ_TRY(build_end_order(ctx, ix));
         v = view_of(ix);

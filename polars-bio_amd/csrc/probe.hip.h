@@ -26,7 +26,8 @@
 namespace ivj {
 
 constexpr int PROBE_THREADS = 256;
-constexpr int PROBE_ITEMS = 4;
+constexpr int PROBE_ITEMS = 4;   // probes per thread of the overlap count / fill / fused kernels
+constexpr int PROBE_ITEMS_LAT = 2;   // nearest and the dense fill: shorter per-thread chains, full occupancy
 constexpr int PROBE_TILE = PROBE_THREADS * PROBE_ITEMS;
 
 struct IndexView {
@@ -142,24 +143,25 @@ __device__ __forceinline__ void bound_hi4(const IndexView& ix, const int (&a)[PR
 // of contig c[k]'s segment with flip(keys[p]) >= tu[k].  Targets are compared on the flipped
 // (unsigned-ordered) coordinates in 64 bits, so negative coordinates and INT32_MAX + 1 need no
 // special case.  One table read + a search over the rows of one bin.
+template <int N>
 __device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const int4* __restrict__ brec,
                                         const uint32_t* __restrict__ bins, bool use_rec,
                                         const int32_t* __restrict__ keys, int32_t n_contigs,
-                                        const int32_t (&c)[PROBE_ITEMS], const bool (&valid)[PROBE_ITEMS],
-                                        const unsigned long long (&tu)[PROBE_ITEMS],
-                                        int (&a)[PROBE_ITEMS], int (&b)[PROBE_ITEMS], int (&out)[PROBE_ITEMS]) {
-    int4 m0[PROBE_ITEMS], m1[PROBE_ITEMS];
+                                        const int32_t (&c)[N], const bool (&valid)[N],
+                                        const unsigned long long (&tu)[N],
+                                        int (&a)[N], int (&b)[N], int (&out)[N]) {
+    int4 m0[N], m1[N];
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) {
+    for (int k = 0; k < N; ++k) {
         const bool ok = valid[k] && (uint32_t)c[k] < (uint32_t)n_contigs;
         if (ok) { m0[k] = cmeta[2 * c[k]]; m1[k] = cmeta[2 * c[k] + 1]; }
         else { m0[k] = make_int4(0, 0, 0, 0); m1[k] = make_int4(0, 0, 0, 0); }
     }
-    int4 rec[PROBE_ITEMS];
-    uint32_t slot[PROBE_ITEMS];
-    bool inb[PROBE_ITEMS];
+    int4 rec[N];
+    uint32_t slot[N];
+    bool inb[N];
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) {
+    for (int k = 0; k < N; ++k) {
         a[k] = m0[k].x; b[k] = m0[k].y;
         const uint32_t ulo = (uint32_t)m0[k].z, uhi = (uint32_t)m0[k].w;
         inb[k] = false; slot[k] = 0; rec[k] = make_int4(0, 0, 0, 0);
@@ -174,7 +176,7 @@ __device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const in
     }
     if (use_rec) {
 #pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) {
+        for (int k = 0; k < N; ++k) {
             if (!inb[k]) continue;
             // rows p0, p0+1, p0+2 of the bin (or later bins / a sentinel past the segment): keys
             // ascend, so the number of leading keys below the target is the offset of the bound
@@ -194,15 +196,15 @@ __device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const in
         }
     } else {
         // four interleaved bound searches over the rows of one bin each
-        int lo[PROBE_ITEMS], hi[PROBE_ITEMS];
+        int lo[N], hi[N];
 #pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) { lo[k] = inb[k] ? rec[k].x : 0; hi[k] = inb[k] ? rec[k].y : 0; }
+        for (int k = 0; k < N; ++k) { lo[k] = inb[k] ? rec[k].x : 0; hi[k] = inb[k] ? rec[k].y : 0; }
         for (;;) {
             bool any = false;
-            int32_t v[PROBE_ITEMS];
-            int m[PROBE_ITEMS];
+            int32_t v[N];
+            int m[N];
 #pragma unroll
-            for (int k = 0; k < PROBE_ITEMS; ++k) {
+            for (int k = 0; k < N; ++k) {
                 m[k] = lo[k] + ((hi[k] - lo[k]) >> 1);
                 const bool act = lo[k] < hi[k];
                 any |= act;
@@ -210,37 +212,37 @@ __device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const in
             }
             if (!any) break;
 #pragma unroll
-            for (int k = 0; k < PROBE_ITEMS; ++k) {
+            for (int k = 0; k < N; ++k) {
                 if (lo[k] < hi[k]) {
                     if ((unsigned long long)flip(v[k]) < tu[k]) lo[k] = m[k] + 1; else hi[k] = m[k];
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) if (inb[k]) out[k] = lo[k];
+        for (int k = 0; k < N; ++k) if (inb[k]) out[k] = lo[k];
     }
 }
 
 // hi = first position whose start fails "start (<) q.end": first start >= q.end (STRICT) / > q.end (WEAK)
-template <bool STRICT>
-__device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t (&c)[PROBE_ITEMS],
-                                              const bool (&valid)[PROBE_ITEMS], const int32_t (&qe)[PROBE_ITEMS],
-                                              int (&a)[PROBE_ITEMS], int (&b)[PROBE_ITEMS], int (&out)[PROBE_ITEMS]) {
-    unsigned long long tu[PROBE_ITEMS];
+template <bool STRICT, int N>
+__device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t (&c)[N],
+                                              const bool (&valid)[N], const int32_t (&qe)[N],
+                                              int (&a)[N], int (&b)[N], int (&out)[N]) {
+    unsigned long long tu[N];
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) tu[k] = (unsigned long long)flip(qe[k]) + (STRICT ? 0ull : 1ull);
+    for (int k = 0; k < N; ++k) tu[k] = (unsigned long long)flip(qe[k]) + (STRICT ? 0ull : 1ull);
     lb_tab4(ix.cmeta, ix.brec, ix.bins, ix.use_rec != 0, ix.b_start, ix.n_contigs, c, valid, tu, a, b, out);
 }
 // r = first position of the end-sorted segment whose end satisfies "q.start (<) end":
 // first end > q.start (STRICT) / >= q.start (WEAK)
-template <bool STRICT>
-__device__ __forceinline__ void bound_r_tab4(const IndexView& ix, const int32_t (&c)[PROBE_ITEMS],
-                                             const bool (&valid)[PROBE_ITEMS], const int32_t (&qs)[PROBE_ITEMS],
-                                             int (&out)[PROBE_ITEMS]) {
-    unsigned long long tu[PROBE_ITEMS];
-    int a[PROBE_ITEMS], b[PROBE_ITEMS];
+template <bool STRICT, int N>
+__device__ __forceinline__ void bound_r_tab4(const IndexView& ix, const int32_t (&c)[N],
+                                             const bool (&valid)[N], const int32_t (&qs)[N],
+                                             int (&out)[N]) {
+    unsigned long long tu[N];
+    int a[N], b[N];
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) tu[k] = (unsigned long long)flip(qs[k]) + (STRICT ? 1ull : 0ull);
+    for (int k = 0; k < N; ++k) tu[k] = (unsigned long long)flip(qs[k]) + (STRICT ? 1ull : 0ull);
     lb_tab4(ix.cmeta_e, ix.brec_e, ix.bins_e, ix.use_rec != 0, ix.e_end, ix.n_contigs, c, valid, tu, a, b, out);
 }
 
@@ -311,25 +313,34 @@ __device__ __forceinline__ int scan_count(const IndexView& ix, int a, int hi, in
     return cnt;
 }
 
-// Load PROBE_ITEMS consecutive int32 (16-byte vector load when the tile is full and aligned).
+// Load / store N consecutive int32 of one thread (16- or 8-byte vector access when the group is
+// complete and the column is 16-byte aligned; i0 is a multiple of N).
+template <int N>
 __device__ __forceinline__ void load_items(const int32_t* __restrict__ p, int64_t i0, int64_t n, bool vec_ok,
-                                           int32_t fill, int32_t (&out)[PROBE_ITEMS]) {
-    if (vec_ok && i0 + PROBE_ITEMS <= n) {
-        const int4 v = *reinterpret_cast<const int4*>(p + i0);
-        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) out[k] = (i0 + k < n) ? p[i0 + k] : fill;
+                                           int32_t fill, int32_t (&out)[N]) {
+    if (vec_ok && i0 + N <= n) {
+        if constexpr (N == 4) {
+            const int4 v = *reinterpret_cast<const int4*>(p + i0);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+            return;
+        } else if constexpr (N == 2) {
+            const int2 v = *reinterpret_cast<const int2*>(p + i0);
+            out[0] = v.x; out[1] = v.y;
+            return;
+        }
     }
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = (i0 + k < n) ? p[i0 + k] : fill;
 }
+template <int N>
 __device__ __forceinline__ void store_items(int32_t* __restrict__ p, int64_t i0, int64_t n, bool vec_ok,
-                                            const int32_t (&v)[PROBE_ITEMS]) {
-    if (vec_ok && i0 + PROBE_ITEMS <= n) {
-        *reinterpret_cast<int4*>(p + i0) = make_int4(v[0], v[1], v[2], v[3]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) if (i0 + k < n) p[i0 + k] = v[k];
+                                            const int32_t (&v)[N]) {
+    if (vec_ok && i0 + N <= n) {
+        if constexpr (N == 4) { *reinterpret_cast<int4*>(p + i0) = make_int4(v[0], v[1], v[2], v[3]); return; }
+        else if constexpr (N == 2) { *reinterpret_cast<int2*>(p + i0) = make_int2(v[0], v[1]); return; }
     }
+#pragma unroll
+    for (int k = 0; k < N; ++k) if (i0 + k < n) p[i0 + k] = v[k];
 }
 
 // ------------------------------------------------------------------ index build
@@ -536,10 +547,10 @@ struct GlobalRow {
     __device__ __forceinline__ int32_t operator()(int p) const { return b_row[p]; }
 };
 
-template <bool STRICT, int THREADS, int STAGE, class RowOf>
-__device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf& rowof, const int32_t (&hi)[PROBE_ITEMS],
-                                               const int32_t (&x)[PROBE_ITEMS], const int32_t (&cnt)[PROBE_ITEMS],
-                                               const int32_t (&row)[PROBE_ITEMS], const int32_t (&qs)[PROBE_ITEMS],
+template <bool STRICT, int THREADS, int STAGE, class RowOf, int N>
+__device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf& rowof, const int32_t (&hi)[N],
+                                               const int32_t (&x)[N], const int32_t (&cnt)[N],
+                                               const int32_t (&row)[N], const int32_t (&qs)[N],
                                                long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b,
                                                int32_t* __restrict__ out_probe, int32_t* __restrict__ out_build) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -548,7 +559,7 @@ __device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf&
         const long long w1 = w0 + STAGE;
         long long off = loc0;                                  // tile-local offset of the current probe
 #pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) {
+        for (int k = 0; k < N; ++k) {
             const long long end = off + cnt[k];
             const bool in_win = cnt[k] != 0 && end > w0 && off < w1;
             if (in_win && hi[k] >= 0) {
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fused(IndexView ix
 // lower lanes = slot), (end,pmax) and build row of 128 rows requested up front.
 constexpr int DENSE_STAGE = 2048;
 
-template <bool STRICT>
+template <bool STRICT, int N>
 __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill_dense(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
                                                                       bool vec_ok, const int32_t* __restrict__ hi_in,
                                                                       const int32_t* __restrict__ cnt_in,
@@ -746,40 +757,40 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill_dense(IndexView 
     __shared__ long long lds[PROBE_THREADS / kWave];
     __shared__ int32_t st_p[DENSE_STAGE];
     __shared__ int32_t st_b[DENSE_STAGE];
-    __shared__ int32_t l_hi[PROBE_TILE], l_x[PROBE_TILE], l_qs[PROBE_TILE], l_row[PROBE_TILE];
-    __shared__ long long l_off[PROBE_TILE + 1];
-    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    __shared__ int32_t l_hi[(PROBE_THREADS * N)], l_x[(PROBE_THREADS * N)], l_qs[(PROBE_THREADS * N)], l_row[(PROBE_THREADS * N)];
+    __shared__ long long l_off[(PROBE_THREADS * N) + 1];
+    const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
     const unsigned long long lt_lanes = (1ull << lane) - 1ull;
     {
-        int32_t hi[PROBE_ITEMS], x[PROBE_ITEMS];
+        int32_t hi[N], x[N];
         load_items(hi_in, i0, n, vec_ok, 0, hi);
         load_items(cnt_in, i0, n, vec_ok, 0, x);
         long long tsum = 0;
-        int cnt[PROBE_ITEMS];
+        int cnt[N];
 #pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) { cnt[k] = hi[k] < 0 ? x[k] : __popc((uint32_t)x[k]); tsum += cnt[k]; }
+        for (int k = 0; k < N; ++k) { cnt[k] = hi[k] < 0 ? x[k] : __popc((uint32_t)x[k]); tsum += cnt[k]; }
         long long tot0;
         long long off = block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot0);
 #pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) {
-            const int q = threadIdx.x * PROBE_ITEMS + k;
+        for (int k = 0; k < N; ++k) {
+            const int q = threadIdx.x * N + k;
             l_hi[q] = hi[k]; l_x[q] = x[k]; l_off[q] = off;
             l_qs[q] = (hi[k] < 0 && cnt[k] != 0) ? ps[i0 + k] : 0;
             l_row[q] = (cnt[k] != 0 && probe_ids) ? probe_ids[i0 + k] : (int32_t)(i0 + k);
             off += cnt[k];
         }
-        if (threadIdx.x == PROBE_THREADS - 1) l_off[PROBE_TILE] = off;
+        if (threadIdx.x == PROBE_THREADS - 1) l_off[(PROBE_THREADS * N)] = off;
     }
     __syncthreads();
-    const long long tot = l_off[PROBE_TILE];
+    const long long tot = l_off[(PROBE_THREADS * N)];
     const long long tbase = tile_base[blockIdx.x];
     for (long long w0 = 0; w0 < tot; w0 += DENSE_STAGE) {
         const long long w1 = w0 + DENSE_STAGE;
         // probes intersecting [w0,w1): f = last probe with off <= w0, l = first probe with off >= w1
         int f, l;
-        { int lo = 0, hi = PROBE_TILE; while (lo < hi) { const int m = (lo + hi) >> 1; if (l_off[m] <= w0) lo = m + 1; else hi = m; } f = lo - 1; }
-        { int lo = 0, hi = PROBE_TILE; while (lo < hi) { const int m = (lo + hi) >> 1; if (l_off[m] < w1) lo = m + 1; else hi = m; } l = lo; }
+        { int lo = 0, hi = (PROBE_THREADS * N); while (lo < hi) { const int m = (lo + hi) >> 1; if (l_off[m] <= w0) lo = m + 1; else hi = m; } f = lo - 1; }
+        { int lo = 0, hi = (PROBE_THREADS * N); while (lo < hi) { const int m = (lo + hi) >> 1; if (l_off[m] < w1) lo = m + 1; else hi = m; } l = lo; }
         for (int q = f + w; q < l; q += PROBE_THREADS / kWave) {       // wavefront-uniform
             const long long off = l_off[q], end = l_off[q + 1];
             const int c = (int)(end - off);
@@ -858,9 +869,10 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
         if (!degenerate) cnt[k] = (long long)hi[k] - (long long)r[k];
         else cnt[k] = scan_count<STRICT>(ix, a[k], hi[k], s[k]);
     }
-    if (i0 + PROBE_ITEMS <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0) {
-        reinterpret_cast<longlong2*>(counts + i0)[0] = make_longlong2(cnt[0], cnt[1]);
-        reinterpret_cast<longlong2*>(counts + i0)[1] = make_longlong2(cnt[2], cnt[3]);
+    if (i0 + PROBE_ITEMS <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0 && (PROBE_ITEMS % 2) == 0) {
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; k += 2)
+            reinterpret_cast<longlong2*>(counts + i0)[k / 2] = make_longlong2(cnt[k], cnt[k + 1]);
     } else {
 #pragma unroll
         for (int k = 0; k < PROBE_ITEMS; ++k) if (i0 + k < n) counts[i0 + k] = cnt[k];
@@ -873,24 +885,24 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
 // (the one with the smallest (start,row): tests/_expected.py:130-172 tie-break); otherwise the
 // closer of the row with the largest end before the probe (ties: smallest (start,row)) and the
 // row with the smallest start after it; equal distance -> the left one.
-template <bool STRICT>
+template <bool STRICT, int N>
 __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, const int32_t* __restrict__ pc,
                                                               const int32_t* __restrict__ ps,
                                                               const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
                                                               int32_t* __restrict__ out_idx, long long* __restrict__ out_dist,
                                                               int32_t* __restrict__ out_n) {
-    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
-    int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
+    const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
+    int32_t c[N], s[N], e[N];
     load_items(pc, i0, n, vec_ok, -1, c);
     load_items(ps, i0, n, vec_ok, 0, s);
     load_items(pe, i0, n, vec_ok, 0, e);
-    int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS];
-    bool valid[PROBE_ITEMS];
+    int a[N], b[N], hi[N];
+    bool valid[N];
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
+    for (int k = 0; k < N; ++k) valid[k] = i0 + k < n;
     bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) {
+    for (int k = 0; k < N; ++k) {
         if (i0 + k >= n) continue;
         int32_t idx = -1; long long dist = -1; int32_t found = 0;
         if (b[k] > a[k]) {
