@@ -287,6 +287,61 @@ class Engine:
         _check(self.L, self.L.ivj_nearest_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), C.c_void_p(idx_ptr),
                                                C.c_void_p(dist_ptr), C.c_void_p(nf_ptr)), "ivj_nearest_dev")
 
+    # ---- streaming: build side resident, probe side in bounded tiles ---------
+    def overlap_batches(self, probe, build, strict: bool, n_contigs: int, batch_rows: int = 8_000_000):
+        """Generator of (probe_idx, build_idx) numpy batches.
+
+        The build side is sorted once and stays in HBM; the probe side goes through the device in
+        tiles of ``batch_rows`` rows, so device memory and the size of every result batch are bounded
+        (the reference's streaming probe side + ``low_memory``: docs/developers.md:641-646,
+        polars_bio/range_op.py:168).  probe_idx are rows of the WHOLE probe side."""
+        pc, ps, pe = (_i32(a) for a in probe)
+        bc, bs, be = (_i32(a) for a in build)
+        n, nb = pc.shape[0], bc.shape[0]
+        if n == 0 or nb == 0:
+            return
+        opts = make_opts(strict, n_contigs)
+        ptrs = []
+        try:
+            bp = [self.dev_alloc(4 * nb) for _ in range(3)]
+            ptrs += bp
+            for p, col in zip(bp, (bc, bs, be)):
+                self.h2d(p, col)
+            ix = self.index_build_dev(self.dev_side(bp[0], bp[1], bp[2], nb), opts)
+            rows = int(min(batch_rows, n))
+            pp = [self.dev_alloc(4 * rows) for _ in range(4)]       # contig, start, end, row ids of the tile
+            ptrs += pp
+            cap, op, ob = 0, 0, 0
+            for lo in range(0, n, rows):
+                hi = min(lo + rows, n)
+                m = hi - lo
+                for p, col in zip(pp[:3], (pc, ps, pe)):
+                    self.h2d(p, col[lo:hi])
+                self.h2d(pp[3], np.arange(lo, hi, dtype=np.int32))
+                side = self.dev_side(pp[0], pp[1], pp[2], m, pp[3])
+                total = self.overlap_count_dev(ix, side, opts)
+                if total > cap:
+                    for q in (op, ob):
+                        if q:
+                            self.dev_free(q)
+                    cap = int(total * 1.25) + 1024
+                    op, ob = self.dev_alloc(4 * cap), self.dev_alloc(4 * cap)
+                if total:
+                    self.overlap_fill_dev(ix, side, opts, op, ob, total)
+                hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
+                if total:
+                    self.d2h(hp, op)
+                    self.d2h(hb, ob)
+                yield hp, hb
+            ix.close()
+            ptrs += [q for q in (op, ob) if q]
+        finally:
+            for q in ptrs:
+                try:
+                    self.dev_free(q)
+                except Exception:
+                    pass
+
     # ---- raw device memory (callers without torch) --------------------------
     def dev_alloc(self, nbytes: int) -> int:
         p = C.c_void_p()

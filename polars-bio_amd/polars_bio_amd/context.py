@@ -21,6 +21,7 @@ class Context:
             "bio.interval_join_algorithm": "hip",
             # engine options of this implementation
             "ivj.device": "0",
+            "ivj.low_memory_batch_rows": "8000000",
         }
 
     def set_option(self, key, value):

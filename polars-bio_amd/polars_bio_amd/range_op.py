@@ -25,7 +25,7 @@ from .constants import DEFAULT_INTERVAL_COLUMNS
 
 logger = logging.getLogger("polars_bio_amd")
 
-__all__ = ["overlap", "nearest", "count_overlaps", "FilterOp", "RangeOp", "OverlapOutputMode"]
+__all__ = ["overlap", "overlap_batches", "nearest", "count_overlaps", "FilterOp", "RangeOp", "OverlapOutputMode"]
 
 
 class FilterOp:      # src/option.rs:95-100
@@ -58,6 +58,27 @@ def _validate_overlap_input(col1, col2, on_cols, suffixes, output_type):
     assert on_cols is None, "on_cols is not supported yet"
     assert output_type in A.OUTPUT_TYPES, (
         "Only polars.LazyFrame, polars.DataFrame and pandas DataFrame are supported")
+
+
+def _low_memory_batch_rows() -> int:
+    from .context import get_option
+    try:
+        return max(1024, int(get_option("ivj.low_memory_batch_rows") or 8_000_000))
+    except ValueError:
+        return 8_000_000
+
+
+def overlap_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, batch_rows: int = 8_000_000):
+    """Streaming form of ``overlap``: yields pyarrow.Table batches of joined rows; the build side
+    (df2) is indexed once on the device, the probe side (df1) streams through it in tiles of
+    ``batch_rows`` rows.  Counterpart of the reference's lazy ``range_lazy_scan`` generator
+    (/root/reference/polars_bio/range_op_io.py:100-174) for Arrow consumers."""
+    zero_based = validate_coordinate_systems(df1, df2)
+    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    for p_idx, b_idx in default_engine().overlap_batches(probe, build, strict=zero_based, n_contigs=n_contigs,
+                                                         batch_rows=batch_rows):
+        yield A.hconcat(A.with_suffix(A.take_rows(t1, p_idx), suffixes[0]),
+                        A.with_suffix(A.take_rows(t2, b_idx), suffixes[1]))
 
 
 def _prepare(df1, df2, cols1, cols2):
@@ -97,7 +118,15 @@ def overlap(
     mode = _parse_overlap_output_mode(overlap_output)
     logger.info("Optimizing into IntervalJoinExec using %s algorithm (executed by the HIP engine)", algorithm)
     t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
-    p_idx, b_idx = default_engine().overlap(probe, build, strict=zero_based, n_contigs=n_contigs)
+    if low_memory:
+        # bounded device footprint and result batches: the probe side streams through the GPU in
+        # tiles against the resident build index (reference: low_memory caps the output batch size)
+        parts = list(default_engine().overlap_batches(probe, build, strict=zero_based, n_contigs=n_contigs,
+                                                      batch_rows=_low_memory_batch_rows()))
+        p_idx = np.concatenate([p for p, _ in parts]) if parts else np.empty(0, np.int32)
+        b_idx = np.concatenate([b for _, b in parts]) if parts else np.empty(0, np.int32)
+    else:
+        p_idx, b_idx = default_engine().overlap(probe, build, strict=zero_based, n_contigs=n_contigs)
     if mode == OverlapOutputMode.Left:
         if distinct_output:
             p_idx = np.unique(p_idx)

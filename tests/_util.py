@@ -60,6 +60,16 @@ class OracleEngine:
         b = O.Side(*build)
         return O.overlap_fast(O.Index(b, n_contigs), O.Side(*probe), strict)
 
+    def overlap_batches(self, probe, build, strict, n_contigs, batch_rows=8_000_000):
+        import numpy as np
+        from oracle import oracle as O
+        ix = O.Index(O.Side(*build), n_contigs)
+        n = len(probe[0])
+        for lo in range(0, n, batch_rows):
+            hi = min(lo + batch_rows, n)
+            p, b = O.overlap_fast(ix, O.Side(probe[0][lo:hi], probe[1][lo:hi], probe[2][lo:hi]), strict)
+            yield (p + lo).astype(np.int32), b
+
     def count_overlaps(self, probe, build, strict, n_contigs):
         from oracle import oracle as O
         b = O.Side(*build)

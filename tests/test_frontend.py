@@ -199,3 +199,27 @@ def test_validation_errors(engine):
         warnings.simplefilter("always")
         r = pb.overlap(nometa, nometa.copy(), output_type="pandas.DataFrame")   # falls back to 1-based
         assert len(r) == 1 and any("Coordinate system metadata is missing" in str(x.message) for x in w)
+
+
+def test_low_memory_and_streaming_batches(engine):
+    """low_memory=True and overlap_batches give the same rows as the one-shot call, in bounded batches."""
+    rng = np.random.default_rng(3)
+    n1, n2 = 5000, 800
+    df1 = pd.DataFrame({"chrom": rng.choice(["chr1", "chr2", "chrX"], n1), "start": rng.integers(0, 100000, n1)})
+    df1["end"] = df1["start"] + rng.integers(1, 300, n1)
+    df1["tag"] = np.arange(n1)
+    df2 = pd.DataFrame({"chrom": rng.choice(["chr1", "chr2"], n2), "start": rng.integers(0, 100000, n2)})
+    df2["end"] = df2["start"] + rng.integers(1, 3000, n2)
+    for d in (df1, df2):
+        d.attrs["coordinate_system_zero_based"] = True
+    full = pb.overlap(df1, df2, output_type="pandas.DataFrame")
+    pb.set_option("ivj.low_memory_batch_rows", 1500)
+    try:
+        low = pb.overlap(df1, df2, low_memory=True, output_type="pandas.DataFrame")
+    finally:
+        pb.set_option("ivj.low_memory_batch_rows", 8000000)
+    pd.testing.assert_frame_equal(_sorted(low), _sorted(full))
+    batches = list(pb.overlap_batches(df1, df2, batch_rows=1024))
+    assert len(batches) == 5 and all(isinstance(b, pa.Table) for b in batches)
+    cat = pa.concat_tables(batches).to_pandas()
+    pd.testing.assert_frame_equal(_sorted(cat), _sorted(full))
