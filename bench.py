@@ -171,7 +171,13 @@ def main():
                 state["out"] = (torch.empty_like(p), torch.empty_like(b))
             local = int(p.shape[0])
             if gather:
+                # the exchange is timed on its own as well (torch events on the current stream: the
+                # waits of the grouped isend/irecv order the stream behind RCCL's)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
                 (p, b), _ = D.all_gatherv([p, b])
+                ev[1].record()
+                state.setdefault("gather_events", []).append(ev)
             return local, (p, b)
         if op == "count_overlaps":
             return d_probe.n, join.count_overlaps(d_probe, d_build, True, nc)
@@ -185,6 +191,7 @@ def main():
     for _ in range(args.warmup):
         local_units, out = step()
     barrier()
+    state.pop("gather_events", None)
     join.engine.enable_timing(1)          # HIP events around the probe kernels only, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -204,6 +211,9 @@ def main():
     if gather:
         assert int(out[0].shape[0]) == total_units, "all-gatherv lost pairs"
     ms_per_step = elapsed / args.steps * 1e3
+    gather_ms = None
+    if state.get("gather_events"):
+        gather_ms = sum(a.elapsed_time(b) for a, b in state["gather_events"]) / len(state["gather_events"])
 
     # dominant kernel + roofline (per launch, this rank's shard)
     dom_name, dom = None, None
@@ -273,6 +283,8 @@ def main():
                                  "fused count/fill into the preallocated result buffers") +
                                 ", inputs and outputs in HBM") if op == "overlap" else
                                "index build (radix sort) + probe kernel, inputs and outputs in HBM"},
+            "phases_ms": ({"join_rank0": round(ms_per_step - gather_ms, 4), "allgatherv_rank0": round(gather_ms, 4)}
+                          if gather_ms is not None else None),
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
