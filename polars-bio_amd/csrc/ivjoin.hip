@@ -109,6 +109,7 @@ struct ivj_index {
     int4* brec = nullptr;
     int4* brec_e = nullptr;
     int32_t* pargmax = nullptr;
+    int4* nrec = nullptr;
     int64_t bins_len = 0;
     bool has_end_order = false;
     bool has_argmax = false;
@@ -243,7 +244,7 @@ IndexView view_of(const ivj_index* ix) {
     IndexView v;
     v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
     v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
-    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax;
+    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec;
     v.bins = ix->bins; v.bins_e = ix->bins_e;
     // 16-byte bin records once the 4-byte tables + key arrays no longer fit the XCD L2s anyway
     v.use_rec = ix->table_mode == 1 ? 1 : (ix->table_mode == 2 ? 0 : (ix->n >= (1ll << 20) ? 1 : 0));
@@ -302,6 +303,8 @@ int build_argmax(ivj_ctx* ctx, ivj_index* ix) {
     uint32_t* part = arena_take<uint32_t>(ctx, scan_num_tiles(n) + 1);
     LAUNCH(ctx, "pmax_change", k_pmax_change, grid1d(n, 256), 256, (const int2*)ix->ep, (const int32_t*)ix->b_contig, n, (uint32_t*)ix->pargmax);
     device_scan<uint32_t, MaxOp, true>(ctx, "argmax_scan", (uint32_t*)ix->pargmax, (uint32_t*)ix->pargmax, n, 0u, part, (uint32_t*)nullptr);
+    LAUNCH(ctx, "nearest_records", k_nearest_records, grid1d(n + 1, 256), 256, (const int32_t*)ix->b_start, (const int2*)ix->ep,
+           (const int32_t*)ix->b_row, (const int32_t*)ix->pargmax, n, ix->nrec);
     ix->has_argmax = true;
     return IVJ_OK;
 }
@@ -317,7 +320,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t nc = (size_t)opts->n_contigs;
         ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
         const size_t small = align_up((nc + 2) * 4) + align_up(16) + 2 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e
-        const size_t need = 6 * col + align_up(nn * 8) + 2 * align_up((size_t)ix->bins_len * 4) +
+        const size_t need = 6 * col + align_up(nn * 8) + align_up((nn + 1) * 16) + 2 * align_up((size_t)ix->bins_len * 4) +
                             2 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
@@ -335,6 +338,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->e_end = (int32_t*)p; p += col;
         ix->e_pos = (int32_t*)p; p += col;
         ix->pargmax = (int32_t*)p; p += col;
+        ix->nrec = (int4*)p; p += align_up((nn + 1) * 16);
         ix->bins = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
         ix->bins_e = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
         ix->brec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);

@@ -48,6 +48,7 @@ struct IndexView {
     const uint32_t* bins_e;
     int32_t use_rec;       // 1: gather 16-byte records, 0: 4-byte bins + bound search on the key array
     const int32_t* pargmax; // position of the first row that attains ep[p].y (prefix max) -- nearest only
+    const int4* nrec;       // nearest: nrec[p] = {pmax[p-1], row of its argmax, start[p], end[p]} (left / right candidate of hi = p)
     int32_t n_contigs;
 };
 
@@ -415,6 +416,20 @@ __global__ void k_pmax_change(const int2* __restrict__ ep, const int32_t* __rest
     if (p >= n) return;
     const bool first = p == 0 || b_contig[p] != b_contig[p - 1] || ep[p].y != ep[p - 1].y;
     change[p] = first ? (uint32_t)p : 0u;
+}
+
+// nearest (k = 1): everything the no-overlap case needs about a bound position p in ONE 16-byte
+// record: the best row on the left (largest end among rows < p: value and build row) and the row
+// at p (start, end).  n + 1 records; the fields that do not exist (p = 0 / p = n) are never read.
+__global__ void k_nearest_records(const int32_t* __restrict__ b_start, const int2* __restrict__ ep,
+                                  const int32_t* __restrict__ b_row, const int32_t* __restrict__ pargmax, int64_t n,
+                                  int4* __restrict__ nrec) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n) return;
+    int4 r = make_int4(0, -1, 0, 0);
+    if (p >= 1) { r.x = ep[p - 1].y; r.y = b_row[pargmax[p - 1]]; }
+    if (p < n) { r.z = b_start[p]; r.w = ep[p].x; }
+    nrec[p] = r;
 }
 
 // Per-contig metadata of the direct-address table: bin width 2^shift chosen so that the contig has
@@ -906,24 +921,21 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
         if (i0 + k >= n) continue;
         int32_t idx = -1; long long dist = -1; int32_t found = 0;
         if (b[k] > a[k]) {
-            // lo = first position of [a,hi) whose prefix max satisfies "q.start (<) pmax": walk down
-            // from hi-1 while it holds (pmax is non-decreasing), at most 8 rows, then bound-search.
-            int lo = hi[k];
-            {
-                int p = hi[k] - 1, steps = 0;
+            const int4 R = ix.nrec[hi[k]];     // {pmax[hi-1], its build row, start[hi], end[hi]}
+            const bool have_l = hi[k] > a[k], have_r = hi[k] < b[k];
+            if (have_l && lt_op<STRICT>(s[k], R.x)) {
+                // some row below hi overlaps: the first position whose prefix max satisfies
+                // "q.start (<) pmax" is the overlapping row with the smallest (start,row); walk down
+                // from hi-1 while it holds (pmax is non-decreasing), at most 8 rows, then bound-search
+                int lo = hi[k] - 1;
+                int p = hi[k] - 2, steps = 1;
                 while (p >= a[k] && steps < 8 && lt_op<STRICT>(s[k], ix.ep[p].y)) { lo = p; --p; ++steps; }
                 if (steps == 8 && p >= a[k]) lo = bound_lo<STRICT>(ix, a[k], p + 1, s[k]);
-            }
-            if (lo < hi[k]) { idx = ix.b_row[lo]; dist = 0; found = 1; }            else {
-                bool have_l = hi[k] > a[k], have_r = hi[k] < b[k];
-                long long dl = 0, dr = 0; int lpos = 0;
-                if (have_l) {
-                    const int32_t maxend = ix.ep[hi[k] - 1].y;
-                    lpos = ix.pargmax[hi[k] - 1];
-                    dl = (long long)s[k] - (long long)maxend;
-                }
-                if (have_r) dr = gap_dist(s[k], e[k], ix.b_start[hi[k]], ix.ep[hi[k]].x);
-                if (have_l && (!have_r || dl <= dr)) { idx = ix.b_row[lpos]; dist = dl; found = 1; }
+                idx = ix.b_row[lo]; dist = 0; found = 1;
+            } else {
+                const long long dl = (long long)s[k] - (long long)R.x;
+                const long long dr = have_r ? gap_dist(s[k], e[k], R.z, R.w) : 0;
+                if (have_l && (!have_r || dl <= dr)) { idx = R.y; dist = dl; found = 1; }
                 else if (have_r) { idx = ix.b_row[hi[k]]; dist = dr; found = 1; }
             }
         }
