@@ -26,6 +26,10 @@
  * reference), build = df2 (indexed side) for all three operations, i.e. after
  * the swaps in polars_bio/range_op.py:511 and src/operation.rs:143-158.
  *
+ * Limits: a side holds at most 0x7fff0000 rows (int32 row indices); the build side at most
+ * 2^30 - n_contigs - 32 rows (int32 table offsets).  A context (ivj_ctx) is not thread-safe: use one
+ * context per host thread / per device; different contexts may be used concurrently.
+ *
  * All entry points return 0 on success, a negative IVJ_E* code otherwise;
  * ivj_last_error() returns the thread-local message of the last failure.
  * The library never retains a caller pointer after the call returns.

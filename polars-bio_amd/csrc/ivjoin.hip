@@ -310,6 +310,9 @@ int build_argmax(ivj_ctx* ctx, ivj_index* ix) {
 }
 
 int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int with_end_order, ivj_index** out) {
+    // table offsets (2 a + 2 c) and slot counts are int32: 2 Nb + 2 n_contigs must stay below 2^31
+    if (2 * build->n + 2 * (int64_t)opts->n_contigs + 64 > 0x7fffffffll)
+        return fail(IVJ_EINVAL, "build side too large for the int32 direct-address table (2*rows + 2*contigs must be < 2^31)");
     ivj_index* ix = new ivj_index();
     ix->ctx = ctx; ix->n = build->n; ix->n_contigs = opts->n_contigs; ix->table_mode = opts->table_mode;
     const int64_t n = build->n;
