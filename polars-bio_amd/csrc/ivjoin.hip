@@ -110,6 +110,8 @@ struct ivj_index {
     int4* brec_e = nullptr;
     int32_t* pargmax = nullptr;
     int4* nrec = nullptr;
+    int4* cmeta_j = nullptr;
+    int4* crec = nullptr;
     int64_t bins_len = 0;
     bool has_end_order = false;
     bool has_argmax = false;
@@ -244,7 +246,7 @@ IndexView view_of(const ivj_index* ix) {
     IndexView v;
     v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
     v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
-    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec;
+    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec; v.cmeta_j = ix->cmeta_j; v.crec = ix->crec;
     v.bins = ix->bins; v.bins_e = ix->bins_e;
     // 16-byte bin records once the 4-byte tables + key arrays no longer fit the XCD L2s anyway
     v.use_rec = ix->table_mode == 1 ? 1 : (ix->table_mode == 2 ? 0 : (ix->n >= (1ll << 20) ? 1 : 0));
@@ -267,9 +269,12 @@ int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->has_end_order) return IVJ_OK;
     const int64_t n = ix->n;
     if (n == 0) { ix->has_end_order = true; return IVJ_OK; }
-    IVJ_TRY(arena_reserve(ctx, sort_scratch_bytes(n) + align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4) + 4096));
+    IVJ_TRY(arena_reserve(ctx, sort_scratch_bytes(n) + align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4) +
+                               2 * align_up((size_t)ix->bins_len * 4) + 4096));
     SortBufs sb; take_sort_bufs(ctx, n, sb);
     uint32_t* bins_part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
+    uint32_t* jb_s = arena_take<uint32_t>(ctx, ix->bins_len);
+    uint32_t* jb_e = arena_take<uint32_t>(ctx, ix->bins_len);
     LAUNCH(ctx, "end_keys", k_end_keys, grid1d(n, 256), 256, (const int2*)ix->ep, n, sb.kA, sb.vA);
     bool fl = radix_sort_pairs(ctx, sb, n, 32);
     if (fl) { std::swap(sb.kA, sb.kB); std::swap(sb.vA, sb.vB); }
@@ -289,6 +294,19 @@ int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
         device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", ix->bins_e, ix->bins_e, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
         LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins_e, ix->bins_len,
                (const int32_t*)ix->e_end, (const int4*)ix->cmeta_e, ix->n_contigs, ix->brec_e);
+        // joint grid for count_overlaps: the same bins for the start order and the end order
+        LAUNCH(ctx, "contig_meta", k_contig_meta_joint, grid1d(ix->n_contigs, 256), 256, (const int32_t*)ix->seg,
+               (const int32_t*)ix->b_start, (const int32_t*)ix->e_end, ix->n_contigs, ix->cmeta_j);
+        HIP_TRY(hipMemsetAsync(jb_s, 0, (size_t)ix->bins_len * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(jb_e, 0, (size_t)ix->bins_len * 4, ctx->stream));
+        LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int32_t*)ix->b_contig, n,
+               ix->n_contigs, (const int4*)ix->cmeta_j, jb_s);
+        LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->e_end, (const int32_t*)ckeys, n,
+               ix->n_contigs, (const int4*)ix->cmeta_j, jb_e);
+        device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", jb_s, jb_s, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
+        device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", jb_e, jb_e, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
+        LAUNCH(ctx, "joint_records", k_joint_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)jb_s, (const uint32_t*)jb_e,
+               ix->bins_len, (const int32_t*)ix->b_start, (const int32_t*)ix->e_end, (const int4*)ix->cmeta_j, ix->n_contigs, ix->crec);
     }
     ix->has_end_order = true;
     return IVJ_OK;
@@ -322,9 +340,9 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t col = align_up(nn * 4);
         const size_t nc = (size_t)opts->n_contigs;
         ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
-        const size_t small = align_up((nc + 2) * 4) + align_up(16) + 2 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e
+        const size_t small = align_up((nc + 2) * 4) + align_up(16) + 3 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e, cmeta_j
         const size_t need = 6 * col + align_up(nn * 8) + align_up((nn + 1) * 16) + 2 * align_up((size_t)ix->bins_len * 4) +
-                            2 * align_up((size_t)ix->bins_len * 16) + small + 256;
+                            3 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
             ctx->ix_cache = nullptr; ctx->ix_cache_cap = 0;
@@ -346,11 +364,13 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->bins_e = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
         ix->brec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
         ix->brec_e = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
+        ix->crec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
         char* small_base = p;
         ix->seg = (int32_t*)p; p += align_up((nc + 2) * 4);
         ix->flags = (int32_t*)p; p += align_up(16);
         ix->cmeta = (int4*)p; p += align_up((nc + 1) * 32);
-        ix->cmeta_e = (int4*)p;
+        ix->cmeta_e = (int4*)p; p += align_up((nc + 1) * 32);
+        ix->cmeta_j = (int4*)p;
         // seg, flags and cmeta start zeroed: an empty index answers every probe with "no rows"
         hipError_t e = hipMemsetAsync(small_base, 0, small, ctx->stream);
         if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(index meta): ") + hipGetErrorString(e)));
@@ -631,13 +651,14 @@ int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
     if (n == 0) return IVJ_OK;
     if (ix->n == 0) { HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
     IVJ_TRY(build_end_order(ctx, ix));
-    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT;
+    const int64_t tiles = (n + NT - 1) / NT;
     const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
     IndexView v = view_of(ix);
     if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, (long long*)counts);
+        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, (long long*)counts);
     else
-        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, (long long*)counts);
+        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, (long long*)counts);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
 }

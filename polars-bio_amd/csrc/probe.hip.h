@@ -48,6 +48,8 @@ struct IndexView {
     const uint32_t* bins_e;
     int32_t use_rec;       // 1: gather 16-byte records, 0: 4-byte bins + bound search on the key array
     const int32_t* pargmax; // position of the first row that attains ep[p].y (prefix max) -- nearest only
+    const int4* cmeta_j;    // count_overlaps: ONE bin grid per contig shared by the start- and the end-sorted order
+    const int4* crec;       //   crec[slot] = {first start position, its start, first end position, its end} of the bin
     const int4* nrec;       // nearest: nrec[p] = {pmax[p-1], row of its argmax, start[p], end[p]} (left / right candidate of hi = p)
     int32_t n_contigs;
 };
@@ -416,6 +418,45 @@ __global__ void k_pmax_change(const int2* __restrict__ ep, const int32_t* __rest
     if (p >= n) return;
     const bool first = p == 0 || b_contig[p] != b_contig[p - 1] || ep[p].y != ep[p - 1].y;
     change[p] = first ? (uint32_t)p : 0u;
+}
+
+// count_overlaps: joint bin grid.  Both rank queries of a probe -- #{start (<) q.end} over the
+// start order and #{!(q.start (<) end)} over the end order -- use the SAME coordinate bins, and a
+// read is ~125 bp long while a bin is thousands of bp wide, so q.start and q.end almost always
+// fall into one bin: ONE 16-byte gather answers both ranks.
+__global__ void k_contig_meta_joint(const int32_t* __restrict__ seg, const int32_t* __restrict__ b_start,
+                                    const int32_t* __restrict__ e_end, int32_t n_contigs, int4* __restrict__ cmeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_contigs) return;
+    const int a = seg[c], b = seg[c + 1];
+    uint32_t ulo = 0, uhi = 0;
+    int shift = 0;
+    if (b > a) {
+        const uint32_t s0 = flip(b_start[a]), e0 = flip(e_end[a]), s1 = flip(b_start[b - 1]), e1 = flip(e_end[b - 1]);
+        ulo = s0 < e0 ? s0 : e0; uhi = s1 > e1 ? s1 : e1;
+        const unsigned long long span = (unsigned long long)(uhi - ulo), cap = 2ull * (unsigned long long)(b - a);
+        while ((span >> shift) + 1ull > cap) ++shift;
+    }
+    cmeta[2 * c] = make_int4(a, b, (int)ulo, (int)uhi);
+    cmeta[2 * c + 1] = make_int4(shift, 2 * a + 2 * c, 0, 0);
+}
+
+__global__ void k_joint_records(const uint32_t* __restrict__ bins_s, const uint32_t* __restrict__ bins_e, int64_t bins_len,
+                                const int32_t* __restrict__ b_start, const int32_t* __restrict__ e_end,
+                                const int4* __restrict__ cmeta, int32_t n_contigs, int4* __restrict__ crec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bins_len) return;
+    int lo = 0, hi = n_contigs;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= i) lo = m + 1; else hi = m; }
+    const int c = lo - 1;
+    const int ps = (int)bins_s[i], pe = (int)bins_e[i];
+    int32_t ks = 0x7fffffff, ke = 0x7fffffff;
+    if (c >= 0) {
+        const int bend = cmeta[2 * c].y;
+        if (ps < bend) ks = b_start[ps];
+        if (pe < bend) ke = e_end[pe];
+    }
+    crec[i] = make_int4(ps, ks, pe, ke);
 }
 
 // nearest (k = 1): everything the no-overlap case needs about a bound position p in ONE 16-byte
@@ -859,38 +900,77 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill_dense(IndexView 
 // count = #{b.start (<) q.end} - #{!(q.start (<) b.end)}  (two-rank formula of the reference's
 // SQL sweep, polars_bio/range_op.py:548-595); the bounded scan replaces it for rows where the
 // formula is not exact (zero-length/inverted probe, or any inverted build row).
-template <bool STRICT>
+// rank of a target inside one joint-grid slot: p0/k0 come from the record; when the first row of the
+// bin is still below the target look at the next row, and only then bound-search up to the next bin
+__device__ __forceinline__ int joint_rank(const int32_t* __restrict__ keys, int p0, int32_t k0, unsigned long long t, int b,
+                                          const int4* __restrict__ crec, uint32_t slot, bool end_table) {
+    if (!((unsigned long long)flip(k0) < t)) return p0;
+    int lo = p0 + 1;
+    if (lo < b && (unsigned long long)flip(keys[lo]) < t) {
+        ++lo;
+        const int4 nx = crec[slot + 1];
+        int hi = end_table ? nx.z : nx.x;
+        while (lo < hi) {
+            const int m = lo + ((hi - lo) >> 1);
+            if ((unsigned long long)flip(keys[m]) < t) lo = m + 1; else hi = m;
+        }
+    }
+    return lo;
+}
+
+template <bool STRICT, int N>
 __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, const int32_t* __restrict__ pc,
                                                                   const int32_t* __restrict__ ps,
                                                                   const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
                                                                   long long* __restrict__ counts) {
-    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
-    int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
+    const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
+    int32_t c[N], s[N], e[N];
     load_items(pc, i0, n, vec_ok, -1, c);
     load_items(ps, i0, n, vec_ok, 0, s);
     load_items(pe, i0, n, vec_ok, 0, e);
-    int a[PROBE_ITEMS], b[PROBE_ITEMS], hi[PROBE_ITEMS];
-    bool valid[PROBE_ITEMS];
-#pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
-    bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
-    int r[PROBE_ITEMS];
-    bound_r_tab4<STRICT>(ix, c, valid, s, r);
     const bool inv = ix.flags[0] != 0;
-    long long cnt[PROBE_ITEMS];
+    // phase 1: metadata and the (usually single) record gather of every probe, issued together
+    int a[N], b[N];
+    unsigned long long te[N], ts[N];
+    uint32_t se[N], ss[N];
+    int he[N], hs[N];          // 0: rank = a, 1: rank = b, 2: table
+    int4 re[N], rs[N];
 #pragma unroll
-    for (int k = 0; k < PROBE_ITEMS; ++k) {
-        const bool degenerate = inv || (STRICT ? (s[k] >= e[k]) : (s[k] > e[k]));
-        if (!degenerate) cnt[k] = (long long)hi[k] - (long long)r[k];
-        else cnt[k] = scan_count<STRICT>(ix, a[k], hi[k], s[k]);
+    for (int k = 0; k < N; ++k) {
+        const bool ok = i0 + k < n && (uint32_t)c[k] < (uint32_t)ix.n_contigs;
+        int4 m0 = make_int4(0, 0, 0, 0), m1 = make_int4(0, 0, 0, 0);
+        if (ok) { m0 = ix.cmeta_j[2 * c[k]]; m1 = ix.cmeta_j[2 * c[k] + 1]; }
+        a[k] = m0.x; b[k] = m0.y;
+        const uint32_t ulo = (uint32_t)m0.z, uhi = (uint32_t)m0.w;
+        te[k] = (unsigned long long)flip(e[k]) + (STRICT ? 0ull : 1ull);   // first start >= / > q.end
+        ts[k] = (unsigned long long)flip(s[k]) + (STRICT ? 1ull : 0ull);   // first end > / >= q.start
+        he[k] = (b[k] <= a[k] || te[k] <= ulo) ? 0 : (te[k] > uhi ? 1 : 2);
+        hs[k] = (b[k] <= a[k] || ts[k] <= ulo) ? 0 : (ts[k] > uhi ? 1 : 2);
+        se[k] = he[k] == 2 ? (uint32_t)m1.y + (((uint32_t)te[k] - ulo) >> m1.x) : 0u;
+        ss[k] = hs[k] == 2 ? (uint32_t)m1.y + (((uint32_t)ts[k] - ulo) >> m1.x) : 0u;
+        re[k] = make_int4(0, 0, 0, 0); rs[k] = make_int4(0, 0, 0, 0);
+        if (he[k] == 2) re[k] = ix.crec[se[k]];
+        if (hs[k] == 2) rs[k] = (he[k] == 2 && ss[k] == se[k]) ? re[k] : ix.crec[ss[k]];
     }
-    if (i0 + PROBE_ITEMS <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0 && (PROBE_ITEMS % 2) == 0) {
+    long long cnt[N];
 #pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; k += 2)
+    for (int k = 0; k < N; ++k) {
+        const int hi = he[k] == 0 ? a[k] : (he[k] == 1 ? b[k] : joint_rank(ix.b_start, re[k].x, re[k].y, te[k], b[k], ix.crec, se[k], false));
+        const bool degenerate = inv || (STRICT ? (s[k] >= e[k]) : (s[k] > e[k]));
+        if (!degenerate) {
+            const int r = hs[k] == 0 ? a[k] : (hs[k] == 1 ? b[k] : joint_rank(ix.e_end, rs[k].z, rs[k].w, ts[k], b[k], ix.crec, ss[k], true));
+            cnt[k] = (long long)hi - (long long)r;
+        } else {
+            cnt[k] = scan_count<STRICT>(ix, a[k], hi, s[k]);
+        }
+    }
+    if (i0 + N <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0 && (N % 2) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k += 2)
             reinterpret_cast<longlong2*>(counts + i0)[k / 2] = make_longlong2(cnt[k], cnt[k + 1]);
     } else {
 #pragma unroll
-        for (int k = 0; k < PROBE_ITEMS; ++k) if (i0 + k < n) counts[i0 + k] = cnt[k];
+        for (int k = 0; k < N; ++k) if (i0 + k < n) counts[i0 + k] = cnt[k];
     }
 }
 
