@@ -295,3 +295,33 @@ def test_fused_single_pass_matches_two_pass(eng):
         ix.close()
         for p in ptrs + [op, ob]:
             eng.dev_free(p)
+
+
+def test_torch_device_api_matches_oracle():
+    """polars_bio_amd.device_api (torch tensors in HBM, torch's current stream): what bench.py drives."""
+    import torch
+    from polars_bio_amd.device_api import DeviceJoin, DeviceSide
+    probe = synth.make_side(150_001, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(30_003, 43, synth.BUILD_LEN, 24)
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dp, db = DeviceSide(*map(up, probe)), DeviceSide(*map(up, build))
+    join = DeviceJoin(0)
+    ps, bs = O.Side(*probe), O.Side(*build)
+    ix = O.Index(bs, 24)
+    ep, eb = O.overlap_fast(ix, ps, True)
+    p, b = join.overlap(dp, db, True, 24)
+    hp, hb = _canon(p.cpu().numpy(), b.cpu().numpy())
+    assert (hp == ep).all() and (hb == eb).all()
+    out = (torch.empty(len(ep) + 100, dtype=torch.int32, device=dev), torch.empty(len(ep) + 100, dtype=torch.int32, device=dev))
+    p2, b2 = join.overlap(dp, db, True, 24, out=out)              # fused single pass into caller buffers
+    assert p2.data_ptr() == out[0].data_ptr() and p2.shape[0] == len(ep)
+    hp, hb = _canon(p2.cpu().numpy(), b2.cpu().numpy())
+    assert (hp == ep).all() and (hb == eb).all()
+    assert (join.count_overlaps(dp, db, True, 24).cpu().numpy() == O.count_overlaps_fast(ix, ps, True)).all()
+    i, d, n = join.nearest(dp, db, True, 24)
+    ei, ed, en = O.nearest_fast(ix, ps, True)
+    assert (i.cpu().numpy() == ei).all() and (d.cpu().numpy() == ed).all() and (n.cpu().numpy() == en).all()
+    i, d, n = join.nearest(dp, db, False, 24, k=3, include_overlaps=False)
+    ei, ed, en = O.nearest_fast(ix, ps, False, 3, False)
+    assert (i.cpu().numpy() == ei).all() and (d.cpu().numpy() == ed).all() and (n.cpu().numpy() == en).all()
