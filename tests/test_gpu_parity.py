@@ -124,6 +124,13 @@ def test_empty_and_absent(eng):
         assert eng.count_overlaps(one, e, strict, 1).tolist() == [0]
         i, d, n = eng.nearest(one, e, strict, 1)
         assert n.tolist() == [0] and i.tolist() == [[-1]] and d.tolist() == [[-1]]
+        # empty dictionary (every chrom null on both sides): nothing can match
+        nul = (np.full(3, -1, np.int32), np.array([1, 5, 9], np.int32), np.array([4, 8, 12], np.int32))
+        for pm in (1, 2):
+            assert len(eng.overlap(nul, nul, strict, 0, partition_mode=pm)[0]) == 0
+        assert eng.count_overlaps(nul, nul, strict, 0).tolist() == [0, 0, 0]
+        assert eng.nearest(nul, nul, strict, 0)[2].tolist() == [0, 0, 0]
+        assert eng.nearest(nul, nul, strict, 0, 2, False)[2].tolist() == [0, 0, 0]
 
 
 def test_real_fixture_exons_x_fbrain(eng):
