@@ -3,8 +3,15 @@
 torch is plumbing here (device memory, the current stream, torch.distributed); the
 work is done by libivjoin_hip.so through the ``*_dev`` entry points of include/ivjoin.h.
 Columns are int32 torch tensors already resident in HBM; results stay in HBM.
+
+Import order: torch wheels bundle their own ROCm runtime; in a process that uses both, import
+torch BEFORE the first ``Engine`` is created (this module does so itself), otherwise torch may not
+see its GPUs ("No HIP GPUs are available").
 """
+
 from __future__ import annotations
+
+import torch  # noqa: F401  (must precede the dlopen of libivjoin_hip.so in this process)
 
 from typing import Optional, Tuple
 

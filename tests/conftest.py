@@ -4,6 +4,15 @@ import sys
 
 import pytest
 
+# torch bundles its own ROCm runtime (libamdhip64 7.0) while libivjoin_hip.so links the system one
+# (/opt/rocm, 7.2).  Whichever loads first serves the whole process; torch only finds its GPUs when
+# its own copy came first.  Tests that mix both (device_api, bench) therefore need torch imported
+# before the engine library is dlopen'ed -- do it once, up front.
+try:  # pragma: no cover
+    import torch  # noqa: F401
+except Exception:
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(ROOT, "polars-bio_amd")
 for p in (ROOT, PKG_DIR):
