@@ -1,0 +1,183 @@
+// count_nearest.hip.h -- pb.count_overlaps (joint bin grid) and pb.nearest (k = 1 records, general k merge) kernels.
+#pragma once
+#include "index_view.hip.h"
+
+namespace ivj {
+
+// ------------------------------------------------------------------ count_overlaps
+
+// count = #{b.start (<) q.end} - #{!(q.start (<) b.end)}  (two-rank formula of the reference's
+// SQL sweep, polars_bio/range_op.py:548-595); the bounded scan replaces it for rows where the
+// formula is not exact (zero-length/inverted probe, or any inverted build row).
+// rank of a target inside one joint-grid slot: p0/k0 come from the record; when the first row of the
+// bin is still below the target look at the next row, and only then bound-search up to the next bin
+__device__ __forceinline__ int joint_rank(const int32_t* __restrict__ keys, int p0, int32_t k0, unsigned long long t, int b,
+                                          const int4* __restrict__ crec, uint32_t slot, bool end_table) {
+    if (!((unsigned long long)flip(k0) < t)) return p0;
+    int lo = p0 + 1;
+    if (lo < b && (unsigned long long)flip(keys[lo]) < t) {
+        ++lo;
+        const int4 nx = crec[slot + 1];
+        int hi = end_table ? nx.z : nx.x;
+        while (lo < hi) {
+            const int m = lo + ((hi - lo) >> 1);
+            if ((unsigned long long)flip(keys[m]) < t) lo = m + 1; else hi = m;
+        }
+    }
+    return lo;
+}
+
+template <bool STRICT, int N>
+__global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, const int32_t* __restrict__ pc,
+                                                                  const int32_t* __restrict__ ps,
+                                                                  const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
+                                                                  long long* __restrict__ counts) {
+    const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
+    int32_t c[N], s[N], e[N];
+    load_items(pc, i0, n, vec_ok, -1, c);
+    load_items(ps, i0, n, vec_ok, 0, s);
+    load_items(pe, i0, n, vec_ok, 0, e);
+    const bool inv = ix.flags[0] != 0;
+    // phase 1: metadata and the (usually single) record gather of every probe, issued together
+    int a[N], b[N];
+    unsigned long long te[N], ts[N];
+    uint32_t se[N], ss[N];
+    int he[N], hs[N];          // 0: rank = a, 1: rank = b, 2: table
+    int4 re[N], rs[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const bool ok = i0 + k < n && (uint32_t)c[k] < (uint32_t)ix.n_contigs;
+        int4 m0 = make_int4(0, 0, 0, 0), m1 = make_int4(0, 0, 0, 0);
+        if (ok) { m0 = ix.cmeta_j[2 * c[k]]; m1 = ix.cmeta_j[2 * c[k] + 1]; }
+        a[k] = m0.x; b[k] = m0.y;
+        const uint32_t ulo = (uint32_t)m0.z, uhi = (uint32_t)m0.w;
+        te[k] = (unsigned long long)flip(e[k]) + (STRICT ? 0ull : 1ull);   // first start >= / > q.end
+        ts[k] = (unsigned long long)flip(s[k]) + (STRICT ? 1ull : 0ull);   // first end > / >= q.start
+        he[k] = (b[k] <= a[k] || te[k] <= ulo) ? 0 : (te[k] > uhi ? 1 : 2);
+        hs[k] = (b[k] <= a[k] || ts[k] <= ulo) ? 0 : (ts[k] > uhi ? 1 : 2);
+        se[k] = he[k] == 2 ? (uint32_t)m1.y + (((uint32_t)te[k] - ulo) >> m1.x) : 0u;
+        ss[k] = hs[k] == 2 ? (uint32_t)m1.y + (((uint32_t)ts[k] - ulo) >> m1.x) : 0u;
+        re[k] = make_int4(0, 0, 0, 0); rs[k] = make_int4(0, 0, 0, 0);
+        if (he[k] == 2) re[k] = ix.crec[se[k]];
+        if (hs[k] == 2) rs[k] = (he[k] == 2 && ss[k] == se[k]) ? re[k] : ix.crec[ss[k]];
+    }
+    long long cnt[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int hi = he[k] == 0 ? a[k] : (he[k] == 1 ? b[k] : joint_rank(ix.b_start, re[k].x, re[k].y, te[k], b[k], ix.crec, se[k], false));
+        const bool degenerate = inv || (STRICT ? (s[k] >= e[k]) : (s[k] > e[k]));
+        if (!degenerate) {
+            const int r = hs[k] == 0 ? a[k] : (hs[k] == 1 ? b[k] : joint_rank(ix.e_end, rs[k].z, rs[k].w, ts[k], b[k], ix.crec, ss[k], true));
+            cnt[k] = (long long)hi - (long long)r;
+        } else {
+            cnt[k] = scan_count<STRICT>(ix, a[k], hi, s[k]);
+        }
+    }
+    if (i0 + N <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0 && (N % 2) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k += 2)
+            reinterpret_cast<longlong2*>(counts + i0)[k / 2] = make_longlong2(cnt[k], cnt[k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) if (i0 + k < n) counts[i0 + k] = cnt[k];
+    }
+}
+
+// ------------------------------------------------------------------ nearest
+
+// k = 1, include_overlaps = 1 (the default pb.nearest).  An overlapping row wins with distance 0
+// (the one with the smallest (start,row): tests/_expected.py:130-172 tie-break); otherwise the
+// closer of the row with the largest end before the probe (ties: smallest (start,row)) and the
+// row with the smallest start after it; equal distance -> the left one.
+template <bool STRICT, int N>
+__global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, const int32_t* __restrict__ pc,
+                                                              const int32_t* __restrict__ ps,
+                                                              const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
+                                                              int32_t* __restrict__ out_idx, long long* __restrict__ out_dist,
+                                                              int32_t* __restrict__ out_n) {
+    const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
+    int32_t c[N], s[N], e[N];
+    load_items(pc, i0, n, vec_ok, -1, c);
+    load_items(ps, i0, n, vec_ok, 0, s);
+    load_items(pe, i0, n, vec_ok, 0, e);
+    int a[N], b[N], hi[N];
+    bool valid[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) valid[k] = i0 + k < n;
+    bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (i0 + k >= n) continue;
+        int32_t idx = -1; long long dist = -1; int32_t found = 0;
+        if (b[k] > a[k]) {
+            const int4 R = ix.nrec[hi[k]];     // {pmax[hi-1], its build row, start[hi], end[hi]}
+            const bool have_l = hi[k] > a[k], have_r = hi[k] < b[k];
+            if (have_l && lt_op<STRICT>(s[k], R.x)) {
+                // some row below hi overlaps: the first position whose prefix max satisfies
+                // "q.start (<) pmax" is the overlapping row with the smallest (start,row); walk down
+                // from hi-1 while it holds (pmax is non-decreasing), at most 8 rows, then bound-search
+                int lo = hi[k] - 1;
+                int p = hi[k] - 2, steps = 1;
+                while (p >= a[k] && steps < 8 && lt_op<STRICT>(s[k], ix.ep[p].y)) { lo = p; --p; ++steps; }
+                if (steps == 8 && p >= a[k]) lo = bound_lo<STRICT>(ix, a[k], p + 1, s[k]);
+                idx = ix.b_row[lo]; dist = 0; found = 1;
+            } else {
+                const long long dl = (long long)s[k] - (long long)R.x;
+                const long long dr = have_r ? gap_dist(s[k], e[k], R.z, R.w) : 0;
+                if (have_l && (!have_r || dl <= dr)) { idx = R.y; dist = dl; found = 1; }
+                else if (have_r) { idx = ix.b_row[hi[k]]; dist = dr; found = 1; }
+            }
+        }
+        out_idx[i0 + k] = idx; out_dist[i0 + k] = dist; out_n[i0 + k] = found;
+    }
+}
+
+// General k / include_overlaps: per-probe merge of three ordered streams (overlapping rows in
+// (start,row) order; "left" rows by end descending; "right" rows by start ascending).
+// One thread per probe; k slots per probe, unused slots -1.
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_nearest_general(IndexView ix, const int32_t* __restrict__ pc,
+                                                                   const int32_t* __restrict__ ps,
+                                                                   const int32_t* __restrict__ pe, int64_t n, int kk,
+                                                                   int include_overlaps, int32_t* __restrict__ out_idx,
+                                                                   long long* __restrict__ out_dist,
+                                                                   int32_t* __restrict__ out_n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t qs = ps[i], qe = pe[i];
+    int32_t* oi = out_idx + i * kk;
+    long long* od = out_dist + i * kk;
+    for (int r = 0; r < kk; ++r) { oi[r] = -1; od[r] = -1; }
+    int a, b;
+    seg_bounds(ix, pc[i], true, a, b);
+    int found = 0;
+    if (b > a) {
+        const int hi = bound_hi<STRICT>(ix, a, b, qe);
+        if (include_overlaps) {
+            const int lo = bound_lo<STRICT>(ix, a, hi, qs);
+            for (int p = lo; p < hi && found < kk; ++p)
+                if (lt_op<STRICT>(qs, ix.ep[p].x)) { oi[found] = ix.b_row[p]; od[found] = 0; ++found; }
+        }
+        const int r_top = bound_r<STRICT>(ix, a, b, qs);
+        int run_hi = r_top, run_lo = r_top, lp = r_top, rp = hi;
+        while (found < kk) {
+            for (;;) {
+                while (lp < run_hi && ix.e_pos[lp] >= hi) ++lp;   // not class "left": start fails (<) q.end
+                if (lp < run_hi || run_lo <= a) break;
+                run_hi = run_lo;
+                run_lo = bsearch32<false>(ix.e_end, a, run_hi, ix.e_end[run_hi - 1]);
+                lp = run_lo;
+            }
+            const bool have_l = lp < run_hi, have_r = rp < b;
+            if (!have_l && !have_r) break;
+            long long dl = 0, dr = 0; int pl = 0;
+            if (have_l) { pl = ix.e_pos[lp]; dl = gap_dist(qs, qe, ix.b_start[pl], ix.ep[pl].x); }
+            if (have_r) dr = gap_dist(qs, qe, ix.b_start[rp], ix.ep[rp].x);
+            if (have_l && (!have_r || dl <= dr)) { oi[found] = ix.b_row[pl]; od[found] = dl; ++found; ++lp; }
+            else { oi[found] = ix.b_row[rp]; od[found] = dr; ++found; ++rp; }
+        }
+    }
+    out_n[i] = found;
+}
+
+}  // namespace ivj

@@ -1,0 +1,194 @@
+// index_build.hip.h -- kernels that turn the radix-sorted build side into the index of index_view.hip.h
+// (sorted columns, segment offsets, prefix max, direct-address tables and their 16-byte records,
+// end order, nearest candidate records).
+#pragma once
+#include "index_view.hip.h"
+
+namespace ivj {
+
+// ------------------------------------------------------------------ index build
+
+__global__ void k_iota_flip(const int32_t* __restrict__ coord, int64_t n, uint32_t* __restrict__ keys,
+                            uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = flip(coord[i]); vals[i] = (uint32_t)i; }
+}
+
+// keys[i] = contig id of the row at sorted position i, clamped to n_contigs when outside the dictionary
+__global__ void k_gather_contig(const int32_t* __restrict__ contig, const uint32_t* __restrict__ rows, int64_t n,
+                                int32_t n_contigs, uint32_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int32_t c = contig[rows[i]];
+        keys[i] = ((uint32_t)c < (uint32_t)n_contigs) ? (uint32_t)c : (uint32_t)n_contigs;
+    }
+}
+
+// After the final pass: materialise the sorted columns, the (contig,end) composite for the
+// prefix-max scan, the segment offsets and the inverted-row flag.
+__global__ void k_index_finalize(const int32_t* __restrict__ start, const int32_t* __restrict__ end,
+                                 const uint32_t* __restrict__ rows, const uint32_t* __restrict__ ckeys,
+                                 const int32_t* __restrict__ row_id, int64_t n,
+                                 int32_t n_contigs, int32_t* __restrict__ b_start, int32_t* __restrict__ b_row,
+                                 int32_t* __restrict__ b_contig, unsigned long long* __restrict__ comp,
+                                 int32_t* __restrict__ seg, int32_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = rows[i];
+    const uint32_t c = ckeys[i];
+    const int32_t s = start[r], e = end[r];
+    b_start[i] = s;
+    b_row[i] = row_id ? row_id[r] : (int32_t)r;
+    b_contig[i] = (int32_t)c;
+    comp[i] = ((unsigned long long)c << 32) | (unsigned long long)flip(e);
+    if (s > e && c < (uint32_t)n_contigs) flags[0] = 1;
+    // seg[k] = first position whose contig key is >= k, for k in (prev, c]
+    const int32_t prev = (i == 0) ? -1 : (int32_t)ckeys[i - 1];
+    for (int32_t k = prev + 1; k <= (int32_t)c; ++k) seg[k] = (int32_t)i;
+    if (i == n - 1)
+        for (int32_t k = (int32_t)c + 1; k <= n_contigs + 1; ++k) seg[k] = (int32_t)n;
+}
+
+__global__ void k_emit_ep(const unsigned long long* __restrict__ comp_raw, const unsigned long long* __restrict__ comp_max,
+                          int64_t n, int2* __restrict__ ep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ep[i] = make_int2(unflip((uint32_t)comp_raw[i]), unflip((uint32_t)comp_max[i]));
+}
+
+__global__ void k_end_keys(const int2* __restrict__ ep, int64_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = flip(ep[i].x); vals[i] = (uint32_t)i; }
+}
+__global__ void k_gather_u32(const int32_t* __restrict__ src, const uint32_t* __restrict__ pos, int64_t n,
+                             uint32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)src[pos[i]];
+}
+__global__ void k_end_finalize(const int2* __restrict__ ep, const uint32_t* __restrict__ pos, int64_t n,
+                               int32_t* __restrict__ e_end, int32_t* __restrict__ e_pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t p = pos[i]; e_end[i] = ep[p].x; e_pos[i] = (int32_t)p; }
+}
+
+// change[p] = p where the prefix max changes (or the segment starts), else 0; an inclusive max-scan
+// turns it into pargmax[p] = position of the first row attaining the prefix max at p.
+__global__ void k_pmax_change(const int2* __restrict__ ep, const int32_t* __restrict__ b_contig, int64_t n,
+                              uint32_t* __restrict__ change) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const bool first = p == 0 || b_contig[p] != b_contig[p - 1] || ep[p].y != ep[p - 1].y;
+    change[p] = first ? (uint32_t)p : 0u;
+}
+
+// count_overlaps: joint bin grid.  Both rank queries of a probe -- #{start (<) q.end} over the
+// start order and #{!(q.start (<) end)} over the end order -- use the SAME coordinate bins, and a
+// read is ~125 bp long while a bin is thousands of bp wide, so q.start and q.end almost always
+// fall into one bin: ONE 16-byte gather answers both ranks.
+__global__ void k_contig_meta_joint(const int32_t* __restrict__ seg, const int32_t* __restrict__ b_start,
+                                    const int32_t* __restrict__ e_end, int32_t n_contigs, int4* __restrict__ cmeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_contigs) return;
+    const int a = seg[c], b = seg[c + 1];
+    uint32_t ulo = 0, uhi = 0;
+    int shift = 0;
+    if (b > a) {
+        const uint32_t s0 = flip(b_start[a]), e0 = flip(e_end[a]), s1 = flip(b_start[b - 1]), e1 = flip(e_end[b - 1]);
+        ulo = s0 < e0 ? s0 : e0; uhi = s1 > e1 ? s1 : e1;
+        const unsigned long long span = (unsigned long long)(uhi - ulo), cap = 2ull * (unsigned long long)(b - a);
+        while ((span >> shift) + 1ull > cap) ++shift;
+    }
+    cmeta[2 * c] = make_int4(a, b, (int)ulo, (int)uhi);
+    cmeta[2 * c + 1] = make_int4(shift, 2 * a + 2 * c, 0, 0);
+}
+
+__global__ void k_joint_records(const uint32_t* __restrict__ bins_s, const uint32_t* __restrict__ bins_e, int64_t bins_len,
+                                const int32_t* __restrict__ b_start, const int32_t* __restrict__ e_end,
+                                const int4* __restrict__ cmeta, int32_t n_contigs, int4* __restrict__ crec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bins_len) return;
+    int lo = 0, hi = n_contigs;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= i) lo = m + 1; else hi = m; }
+    const int c = lo - 1;
+    const int ps = (int)bins_s[i], pe = (int)bins_e[i];
+    int32_t ks = 0x7fffffff, ke = 0x7fffffff;
+    if (c >= 0) {
+        const int bend = cmeta[2 * c].y;
+        if (ps < bend) ks = b_start[ps];
+        if (pe < bend) ke = e_end[pe];
+    }
+    crec[i] = make_int4(ps, ks, pe, ke);
+}
+
+// nearest (k = 1): everything the no-overlap case needs about a bound position p in ONE 16-byte
+// record: the best row on the left (largest end among rows < p: value and build row) and the row
+// at p (start, end).  n + 1 records; the fields that do not exist (p = 0 / p = n) are never read.
+__global__ void k_nearest_records(const int32_t* __restrict__ b_start, const int2* __restrict__ ep,
+                                  const int32_t* __restrict__ b_row, const int32_t* __restrict__ pargmax, int64_t n,
+                                  int4* __restrict__ nrec) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n) return;
+    int4 r = make_int4(0, -1, 0, 0);
+    if (p >= 1) { r.x = ep[p - 1].y; r.y = b_row[pargmax[p - 1]]; }
+    if (p < n) { r.z = b_start[p]; r.w = ep[p].x; }
+    nrec[p] = r;
+}
+
+// Per-contig metadata of the direct-address table: bin width 2^shift chosen so that the contig has
+// at most 2 n_c bins (about one build row per bin for evenly spread rows); its slice of the table
+// starts at tb = 2 a + 2 c.
+__global__ void k_contig_meta(const int32_t* __restrict__ seg, const int32_t* __restrict__ b_start, int32_t n_contigs,
+                              int4* __restrict__ cmeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_contigs) return;
+    const int a = seg[c], b = seg[c + 1];
+    uint32_t ulo = 0, uhi = 0;
+    int shift = 0;
+    if (b > a) {
+        ulo = flip(b_start[a]); uhi = flip(b_start[b - 1]);
+        const unsigned long long span = (unsigned long long)(uhi - ulo), cap = 2ull * (unsigned long long)(b - a);
+        while ((span >> shift) + 1ull > cap) ++shift;
+    }
+    cmeta[2 * c] = make_int4(a, b, (int)ulo, (int)uhi);
+    cmeta[2 * c + 1] = make_int4(shift, 2 * a + 2 * c, 0, 0);
+}
+
+// bins (zero-filled) receives, for the last row p of every non-empty bin j, the value p + 1 at slot
+// j + 1, and a at slot 0 of every contig; an inclusive max-scan over the whole table then yields
+// bins[tb + k] = first position whose start falls in bin >= k (positions grow with the table index).
+__global__ void k_bins_mark(const int32_t* __restrict__ b_start, const int32_t* __restrict__ b_contig, int64_t n,
+                            int32_t n_contigs, const int4* __restrict__ cmeta, uint32_t* __restrict__ bins) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t c = b_contig[p];
+    if ((uint32_t)c >= (uint32_t)n_contigs) return;
+    const int4 m0 = cmeta[2 * c], m1 = cmeta[2 * c + 1];
+    const uint32_t ulo = (uint32_t)m0.z;
+    const uint32_t j = (flip(b_start[p]) - ulo) >> m1.x;
+    const bool last = (p == m0.y - 1) || (((flip(b_start[p + 1]) - ulo) >> m1.x) > j);
+    if (last) bins[(uint32_t)m1.y + j + 1] = (uint32_t)p + 1u;
+    if (p == m0.x) bins[(uint32_t)m1.y] = (uint32_t)p;
+}
+
+// brec[i] = {p0, key[p0], key[p0+1], key[p0+2]} for table slot i (p0 = bins[i] after the max-scan);
+// keys past the end of the slot's contig segment are replaced by INT32_MAX (compares as "not below"
+// any reachable target).  The contig of a slot is found by a bound search over the table offsets.
+__global__ void k_bins_records(const uint32_t* __restrict__ bins, int64_t bins_len, const int32_t* __restrict__ keys,
+                               const int4* __restrict__ cmeta, int32_t n_contigs, int4* __restrict__ brec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bins_len) return;
+    // last contig whose table offset tb = cmeta[2c+1].y is <= i
+    int lo = 0, hi = n_contigs;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= i) lo = m + 1; else hi = m; }
+    const int c = lo - 1;
+    const int p0 = (int)bins[i];
+    int32_t k0 = 0x7fffffff, k1 = 0x7fffffff, k2 = 0x7fffffff;
+    if (c >= 0) {
+        const int bend = cmeta[2 * c].y;
+        if (p0 < bend) k0 = keys[p0];
+        if (p0 + 1 < bend) k1 = keys[p0 + 1];
+        if (p0 + 2 < bend) k2 = keys[p0 + 2];
+    }
+    brec[i] = make_int4(p0, k0, k1, k2);
+}
+
+}  // namespace ivj

@@ -1,0 +1,317 @@
+// index_view.hip.h -- the build index as the kernels see it: layout, predicate, bound searches, window scans.
+//
+// HBM layout of the build index (sorted by (contig, start, row)):
+//   b_start[Nb]  int32   start, the array the hi-bound search runs on
+//   ep[Nb]       int2    (end, prefix-max of end inside the contig segment)
+//   b_row[Nb]    int32   original build row
+//   b_contig[Nb] int32   contig id in that order (rows outside the dictionary get n_contigs)
+//   seg[n_contigs + 2]   segment offsets; seg[n_contigs] = number of valid rows
+//   e_end / e_pos [Nb]   optional: ends sorted by (contig, end, position), and that position
+//   cmeta[n_contigs]     per-contig {segment, min/max start, bin shift, table offset}
+//   brec[2 Nb + 2 n_contigs] direct-address table over start, 16 B per bin: first position of the
+//                        bin and the keys of the next three rows; about one build row per bin, so
+//                        the hi-bound of a probe is ONE 16-byte gather (3 compares) instead of a
+//                        log2(Nb)-step binary search of dependent gathers
+//
+// Predicate (polars_bio/range_op.py:75-84; src/option.rs:95-100):
+//   STRICT: q.start <  b.end && b.start <  q.end      WEAK: <=
+// For a probe q on contig c with segment [a,b):
+//   hi = first p in [a,b) with !(b_start[p] (<) q.end)     -> every match has p < hi
+//   matches = { p in [a,hi) : q.start (<) end[p] };  the prefix max bounds the backward scan:
+//   stop at the first p (going down) with !(q.start (<) pmax[p]).
+#pragma once
+#include "radix_sort.hip.h"
+#include "scan.hip.h"
+
+namespace ivj {
+
+constexpr int PROBE_THREADS = 256;
+constexpr int PROBE_ITEMS = 4;   // probes per thread of the overlap count / fill / fused kernels
+constexpr int PROBE_ITEMS_LAT = 2;   // nearest and the dense fill: shorter per-thread chains, full occupancy
+constexpr int PROBE_TILE = PROBE_THREADS * PROBE_ITEMS;
+
+struct IndexView {
+    const int32_t* b_start;
+    const int2* ep;
+    const int32_t* b_row;
+    const int32_t* seg;
+    const int32_t* e_end;
+    const int32_t* e_pos;
+    const int32_t* flags;  // flags[0] != 0: some build row has start > end
+    const int4* cmeta;     // per contig: {a, b, ulo, uhi} {shift, tb, 0, 0}  (two int4)
+    const int4* brec;      // direct-address table: brec[tb + j] = {p0, key[p0], key[p0+1], key[p0+2]} with
+                           // p0 = first position whose ustart >= ulo + (j << shift)
+    const uint32_t* bins;  // the same table as plain first positions (4 B per bin): used instead of brec for
+                           // small build sides, whose 4-byte tables + key arrays stay L2-resident
+    const int4* cmeta_e;   // the same pair of structures over the end-sorted order (e_end)
+    const int4* brec_e;
+    const uint32_t* bins_e;
+    int32_t use_rec;       // 1: gather 16-byte records, 0: 4-byte bins + bound search on the key array
+    const int32_t* pargmax; // position of the first row that attains ep[p].y (prefix max) -- nearest only
+    const int4* cmeta_j;    // count_overlaps: ONE bin grid per contig shared by the start- and the end-sorted order
+    const int4* crec;       //   crec[slot] = {first start position, its start, first end position, its end} of the bin
+    const int4* nrec;       // nearest: nrec[p] = {pmax[p-1], row of its argmax, start[p], end[p]} (left / right candidate of hi = p)
+    int32_t n_contigs;
+};
+
+__device__ __forceinline__ uint32_t flip(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+__device__ __forceinline__ int32_t unflip(uint32_t v) { return (int32_t)(v ^ 0x80000000u); }
+
+template <bool STRICT>
+__device__ __forceinline__ bool lt_op(int32_t x, int32_t y) { return STRICT ? (x < y) : (x <= y); }
+
+__device__ __forceinline__ long long gap_dist(int32_t qs, int32_t qe, int32_t bs, int32_t be) {
+    const long long d1 = (long long)bs - (long long)qe;
+    const long long d2 = (long long)qs - (long long)be;
+    return d1 > d2 ? d1 : d2;
+}
+
+__device__ __forceinline__ void seg_bounds(const IndexView& ix, int32_t c, bool valid, int& a, int& b) {
+    if (valid && (uint32_t)c < (uint32_t)ix.n_contigs) { a = ix.seg[c]; b = ix.seg[c + 1]; }
+    else { a = 0; b = 0; }
+}
+
+// first p in [lo,hi) with arr[p] >= x (OR_EQUAL=false: lower bound) / arr[p] > x (true: upper bound)
+template <bool UPPER>
+__device__ __forceinline__ int bsearch32(const int32_t* __restrict__ arr, int lo, int hi, int32_t x) {
+    while (lo < hi) {
+        const int m = lo + ((hi - lo) >> 1);
+        const int32_t v = arr[m];
+        const bool right = UPPER ? (v <= x) : (v < x);
+        if (right) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+// same on the .y (prefix max) lane of ep
+template <bool UPPER>
+__device__ __forceinline__ int bsearch_pmax(const int2* __restrict__ ep, int lo, int hi, int32_t x) {
+    while (lo < hi) {
+        const int m = lo + ((hi - lo) >> 1);
+        const int32_t v = ep[m].y;
+        const bool right = UPPER ? (v <= x) : (v < x);
+        if (right) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+
+// hi: first position whose start fails "start (<) q.end"
+template <bool STRICT>
+__device__ __forceinline__ int bound_hi(const IndexView& ix, int a, int b, int32_t qe) {
+    return STRICT ? bsearch32<false>(ix.b_start, a, b, qe) : bsearch32<true>(ix.b_start, a, b, qe);
+}
+// lo: first position in [a,hi) whose prefix max satisfies "q.start (<) pmax"
+template <bool STRICT>
+__device__ __forceinline__ int bound_lo(const IndexView& ix, int a, int hi, int32_t qs) {
+    return STRICT ? bsearch_pmax<true>(ix.ep, a, hi, qs) : bsearch_pmax<false>(ix.ep, a, hi, qs);
+}
+// r: first position of the end-sorted segment whose end satisfies "q.start (<) end"
+template <bool STRICT>
+__device__ __forceinline__ int bound_r(const IndexView& ix, int a, int b, int32_t qs) {
+    return STRICT ? bsearch32<true>(ix.e_end, a, b, qs) : bsearch32<false>(ix.e_end, a, b, qs);
+}
+
+// Lower bound through a direct-address table, four probes interleaved: out[k] = first position p
+// of contig c[k]'s segment with flip(keys[p]) >= tu[k].  Targets are compared on the flipped
+// (unsigned-ordered) coordinates in 64 bits, so negative coordinates and INT32_MAX + 1 need no
+// special case.  One table read + a search over the rows of one bin.
+template <int N>
+__device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const int4* __restrict__ brec,
+                                        const uint32_t* __restrict__ bins, bool use_rec,
+                                        const int32_t* __restrict__ keys, int32_t n_contigs,
+                                        const int32_t (&c)[N], const bool (&valid)[N],
+                                        const unsigned long long (&tu)[N],
+                                        int (&a)[N], int (&b)[N], int (&out)[N]) {
+    int4 m0[N], m1[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const bool ok = valid[k] && (uint32_t)c[k] < (uint32_t)n_contigs;
+        if (ok) { m0[k] = cmeta[2 * c[k]]; m1[k] = cmeta[2 * c[k] + 1]; }
+        else { m0[k] = make_int4(0, 0, 0, 0); m1[k] = make_int4(0, 0, 0, 0); }
+    }
+    int4 rec[N];
+    uint32_t slot[N];
+    bool inb[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        a[k] = m0[k].x; b[k] = m0[k].y;
+        const uint32_t ulo = (uint32_t)m0[k].z, uhi = (uint32_t)m0[k].w;
+        inb[k] = false; slot[k] = 0; rec[k] = make_int4(0, 0, 0, 0);
+        if (b[k] <= a[k] || tu[k] <= ulo) out[k] = a[k];
+        else if (tu[k] > uhi) out[k] = b[k];
+        else {
+            inb[k] = true;
+            slot[k] = (uint32_t)m1[k].y + (((uint32_t)tu[k] - ulo) >> m1[k].x);
+            if (use_rec) rec[k] = brec[slot[k]];
+            else { rec[k].x = (int)bins[slot[k]]; rec[k].y = (int)bins[slot[k] + 1]; }
+        }
+    }
+    if (use_rec) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (!inb[k]) continue;
+            // rows p0, p0+1, p0+2 of the bin (or later bins / a sentinel past the segment): keys
+            // ascend, so the number of leading keys below the target is the offset of the bound
+            const bool n0 = (unsigned long long)flip(rec[k].y) < tu[k];
+            const bool n1 = n0 && (unsigned long long)flip(rec[k].z) < tu[k];
+            const bool n2 = n1 && (unsigned long long)flip(rec[k].w) < tu[k];
+            int lo = rec[k].x + (n0 ? 1 : 0) + (n1 ? 1 : 0) + (n2 ? 1 : 0);
+            if (n2) {
+                // crowded bin: finish with a bound search up to the first row of the next bin
+                int hi = brec[slot[k] + 1].x;
+                while (lo < hi) {
+                    const int m = lo + ((hi - lo) >> 1);
+                    if ((unsigned long long)flip(keys[m]) < tu[k]) lo = m + 1; else hi = m;
+                }
+            }
+            out[k] = lo;
+        }
+    } else {
+        // four interleaved bound searches over the rows of one bin each
+        int lo[N], hi[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) { lo[k] = inb[k] ? rec[k].x : 0; hi[k] = inb[k] ? rec[k].y : 0; }
+        for (;;) {
+            bool any = false;
+            int32_t v[N];
+            int m[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                m[k] = lo[k] + ((hi[k] - lo[k]) >> 1);
+                const bool act = lo[k] < hi[k];
+                any |= act;
+                v[k] = act ? keys[m[k]] : 0;
+            }
+            if (!any) break;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                if (lo[k] < hi[k]) {
+                    if ((unsigned long long)flip(v[k]) < tu[k]) lo[k] = m[k] + 1; else hi[k] = m[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) if (inb[k]) out[k] = lo[k];
+    }
+}
+
+// hi = first position whose start fails "start (<) q.end": first start >= q.end (STRICT) / > q.end (WEAK)
+template <bool STRICT, int N>
+__device__ __forceinline__ void bound_hi_tab4(const IndexView& ix, const int32_t (&c)[N],
+                                              const bool (&valid)[N], const int32_t (&qe)[N],
+                                              int (&a)[N], int (&b)[N], int (&out)[N]) {
+    unsigned long long tu[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) tu[k] = (unsigned long long)flip(qe[k]) + (STRICT ? 0ull : 1ull);
+    lb_tab4(ix.cmeta, ix.brec, ix.bins, ix.use_rec != 0, ix.b_start, ix.n_contigs, c, valid, tu, a, b, out);
+}
+// r = first position of the end-sorted segment whose end satisfies "q.start (<) end":
+// first end > q.start (STRICT) / >= q.start (WEAK)
+template <bool STRICT, int N>
+__device__ __forceinline__ void bound_r_tab4(const IndexView& ix, const int32_t (&c)[N],
+                                             const bool (&valid)[N], const int32_t (&qs)[N],
+                                             int (&out)[N]) {
+    unsigned long long tu[N];
+    int a[N], b[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) tu[k] = (unsigned long long)flip(qs[k]) + (STRICT ? 1ull : 0ull);
+    lb_tab4(ix.cmeta_e, ix.brec_e, ix.bins_e, ix.use_rec != 0, ix.e_end, ix.n_contigs, c, valid, tu, a, b, out);
+}
+
+// Window of a probe below hi as a 32-bit match mask: bit j set <=> row hi-1-j overlaps.  The scan
+// stops at the first row whose prefix max fails "q.start (<) pmax".  Four (end,pmax) pairs are
+// fetched per round so the dependent-load chain is a quarter of the window length.  Returns false
+// when the window is longer than 32 rows (the caller then counts it with the whole wavefront).
+template <bool STRICT>
+__device__ __forceinline__ bool window_mask(const IndexView& ix, int a, int hi, int32_t qs, uint32_t& mask, int& cnt) {
+    mask = 0; cnt = 0;
+    const int top = hi - 1;
+    int p = top;
+    // rows are fetched as 32-byte aligned groups of four (end,pmax) pairs: two 16-byte loads per
+    // group, both in one 64-byte line.  Rows of the group above p or below a are ignored (the
+    // array is padded, so the loads stay in bounds).
+    while (p >= a) {
+        const int base = p & ~3;
+        const int4 v01 = *reinterpret_cast<const int4*>(ix.ep + base);
+        int4 v23 = make_int4(0, 0, 0, 0);                   // rows base+2, base+3: only when p reaches them
+        if ((p & 3) >= 2) v23 = *reinterpret_cast<const int4*>(ix.ep + base + 2);
+        const int32_t en[4] = {v01.x, v01.z, v23.x, v23.z};
+        const int32_t pm[4] = {v01.y, v01.w, v23.y, v23.w};
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const int idx = base + j;
+            if (idx > p) continue;
+            if (idx < a || !lt_op<STRICT>(qs, pm[j])) { cnt = __popc(mask); return true; }
+            if (top - idx >= 32) { cnt = 0; return false; }   // longer than the mask: counted cooperatively
+            if (lt_op<STRICT>(qs, en[j])) mask |= 1u << (top - idx);
+        }
+        p = base - 1;
+    }
+    cnt = __popc(mask);
+    return true;
+}
+
+// Long windows (> 32 rows: dense / deeply nested build sides) are handled by the whole wavefront,
+// one probe at a time: lane l looks at row p0 - l, so a step covers 64 consecutive rows with one
+// coalesced 512-byte read; "q.start (<) pmax" holds for a prefix of the lanes (pmax is
+// non-decreasing in the position), a ballot finds where the window ends and a popcount of the
+// match ballot counts it.
+template <bool STRICT>
+__device__ __forceinline__ int wave_count_window(const IndexView& ix, int a, int hi, int32_t qs) {
+    const int lane = threadIdx.x & (kWave - 1);
+    int cnt = 0;
+    for (int p0 = hi - 1; p0 >= a; p0 -= kWave) {
+        const int p = p0 - lane;
+        int2 v = make_int2(0, 0);
+        if (p >= a) v = ix.ep[p];
+        const bool pass = p >= a && lt_op<STRICT>(qs, v.y);
+        const bool match = pass && lt_op<STRICT>(qs, v.x);
+        cnt += (int)__popcll(__ballot(match));
+        if (__popcll(__ballot(pass)) < kWave) break;
+    }
+    return cnt;
+}
+
+// exact count by the bounded backward scan (valid for every input, including
+// zero-length and inverted rows)
+template <bool STRICT>
+__device__ __forceinline__ int scan_count(const IndexView& ix, int a, int hi, int32_t qs) {
+    int cnt = 0;
+    for (int p = hi - 1; p >= a; --p) {
+        const int2 v = ix.ep[p];
+        if (!lt_op<STRICT>(qs, v.y)) break;
+        cnt += lt_op<STRICT>(qs, v.x) ? 1 : 0;
+    }
+    return cnt;
+}
+
+// Load / store N consecutive int32 of one thread (16- or 8-byte vector access when the group is
+// complete and the column is 16-byte aligned; i0 is a multiple of N).
+template <int N>
+__device__ __forceinline__ void load_items(const int32_t* __restrict__ p, int64_t i0, int64_t n, bool vec_ok,
+                                           int32_t fill, int32_t (&out)[N]) {
+    if (vec_ok && i0 + N <= n) {
+        if constexpr (N == 4) {
+            const int4 v = *reinterpret_cast<const int4*>(p + i0);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+            return;
+        } else if constexpr (N == 2) {
+            const int2 v = *reinterpret_cast<const int2*>(p + i0);
+            out[0] = v.x; out[1] = v.y;
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = (i0 + k < n) ? p[i0 + k] : fill;
+}
+template <int N>
+__device__ __forceinline__ void store_items(int32_t* __restrict__ p, int64_t i0, int64_t n, bool vec_ok,
+                                            const int32_t (&v)[N]) {
+    if (vec_ok && i0 + N <= n) {
+        if constexpr (N == 4) { *reinterpret_cast<int4*>(p + i0) = make_int4(v[0], v[1], v[2], v[3]); return; }
+        else if constexpr (N == 2) { *reinterpret_cast<int2*>(p + i0) = make_int2(v[0], v[1]); return; }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) if (i0 + k < n) p[i0 + k] = v[k];
+}
+
+}  // namespace ivj
