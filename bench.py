@@ -55,7 +55,7 @@ def parse():
                     help="overlap: always use the deterministic count -> fill pair (default: the fused single pass "
                          "into the preallocated result buffers once the warmup has sized them)")
     ap.add_argument("--partition-mode", type=int, default=0,
-                    help="ivj_opts.partition_mode: 0 auto, 1 256-way, 2 none, 3 fine (8192-way + LDS-resident slices)")
+                    help="ivj_opts.partition_mode: 0 auto, 1 256-way, 2 none, 3 fine (8192-way + LDS-resident slices), 4 two-level (65536 buckets), 5 flat (load-balanced candidates)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (RCCL init, sharding, all-gatherv) even with one rank")
     return ap.parse_args()

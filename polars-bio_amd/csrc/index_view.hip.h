@@ -8,6 +8,9 @@
 //   seg[n_contigs + 2]   segment offsets; seg[n_contigs] = number of valid rows
 //   e_end / e_pos [Nb]   optional: ends sorted by (contig, end, position), and that position
 //   cmeta[n_contigs]     per-contig {segment, min/max start, bin shift, table offset}
+//   rec4[Nb]     int4    {start, end, row, pmax}: the one read per candidate of the flat overlap path (flat.hip.h)
+//   tab2[2 Nb + 2 n_contigs] uint2 per start bin: {first position of the bin, first position whose prefix max
+//                        reaches the bin's lower edge}
 //   brec[2 Nb + 2 n_contigs] direct-address table over start, 16 B per bin: first position of the
 //                        bin and the keys of the next three rows; about one build row per bin, so
 //                        the hi-bound of a probe is ONE 16-byte gather (3 compares) instead of a
@@ -51,6 +54,8 @@ struct IndexView {
     const int4* cmeta_j;    // count_overlaps: ONE bin grid per contig shared by the start- and the end-sorted order
     const int4* crec;       //   crec[slot] = {first start position, its start, first end position, its end} of the bin
     const int4* nrec;       // nearest: nrec[p] = {pmax[p-1], row of its argmax, start[p], end[p]} (left / right candidate of hi = p)
+    const int4* rec4;       // flat overlap path: {start, end, build row, prefix max} per sorted position
+    const uint2* tab2;      //   tab2[slot] = {first position of start bin `slot`, first position whose prefix max reaches its lower edge}
     int32_t n_contigs;
 };
 

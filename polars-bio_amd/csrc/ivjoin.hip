@@ -80,6 +80,7 @@ struct ivj_ctx {
     // bucketed (partitioned) copies of the probe columns + their row ids, when the partition path ran
     bool ov_part = false;
     int32_t *pt_c = nullptr, *pt_s = nullptr, *pt_e = nullptr, *pt_row = nullptr;
+    int32_t *pu_c = nullptr, *pu_s = nullptr, *pu_e = nullptr, *pu_row = nullptr;   // second set (two-level bucketing)
     bool part_attr_set = false;
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
@@ -96,6 +97,9 @@ struct ivj_index {
     int32_t n_contigs = 0;
     int32_t* b_start = nullptr;
     int2* ep = nullptr;
+    int4* rec4 = nullptr;
+    uint32_t* lot = nullptr;
+    uint2* tab2 = nullptr;
     int32_t* b_row = nullptr;
     int32_t* b_contig = nullptr;
     int32_t* seg = nullptr;
@@ -115,6 +119,7 @@ struct ivj_index {
     int64_t bins_len = 0;
     bool has_end_order = false;
     bool has_argmax = false;
+    bool has_flat = false;
     char* slab = nullptr;      // single allocation holding every array above
     size_t slab_cap = 0;
 };
@@ -231,7 +236,7 @@ int check_opts(const ivj_opts* o) {
     if (o->filter_op != IVJ_FILTER_WEAK && o->filter_op != IVJ_FILTER_STRICT) return fail(IVJ_EINVAL, "filter_op must be 0 (Weak) or 1 (Strict)");
     if (o->n_contigs < 0) return fail(IVJ_EINVAL, "n_contigs < 0");
     if (o->table_mode < 0 || o->table_mode > 2) return fail(IVJ_EINVAL, "table_mode must be 0 (auto), 1 (records) or 2 (bins)");
-    if (o->partition_mode < 0 || o->partition_mode > 3) return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (always), 2 (never) or 3 (fine, fused path only)");
+    if (o->partition_mode < 0 || o->partition_mode > 5) return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (256-way), 2 (never), 3 (fine, fused path only), 4 (two-level) or 5 (flat, fused path only)");
     return IVJ_OK;
 }
 int check_side(const ivj_side* s, const char* what) {
@@ -247,7 +252,7 @@ IndexView view_of(const ivj_index* ix) {
     v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
     v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
     v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec; v.cmeta_j = ix->cmeta_j; v.crec = ix->crec;
-    v.bins = ix->bins; v.bins_e = ix->bins_e;
+    v.bins = ix->bins; v.bins_e = ix->bins_e; v.rec4 = ix->rec4; v.tab2 = ix->tab2;
     // 16-byte bin records once the 4-byte tables + key arrays no longer fit the XCD L2s anyway
     v.use_rec = ix->table_mode == 1 ? 1 : (ix->table_mode == 2 ? 0 : (ix->n >= (1ll << 20) ? 1 : 0));
     return v;
@@ -341,7 +346,9 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t nc = (size_t)opts->n_contigs;
         ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
         const size_t small = align_up((nc + 2) * 4) + align_up(16) + 3 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e, cmeta_j
-        const size_t need = 6 * col + align_up(nn * 8) + align_up((nn + 1) * 16) + 2 * align_up((size_t)ix->bins_len * 4) +
+        const bool want_flat = opts->partition_mode == 5;
+        const size_t flat_bytes = want_flat ? align_up((nn + 1) * 16) + 3 * align_up((size_t)ix->bins_len * 4) : 0;
+        const size_t need = flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 16) + 2 * align_up((size_t)ix->bins_len * 4) +
                             3 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
@@ -365,6 +372,11 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->brec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
         ix->brec_e = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
         ix->crec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
+        if (want_flat) {
+            ix->rec4 = (int4*)p; p += align_up((nn + 1) * 16);
+            ix->lot = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
+            ix->tab2 = (uint2*)p; p += 2 * align_up((size_t)ix->bins_len * 4);
+        }
         char* small_base = p;
         ix->seg = (int32_t*)p; p += align_up((nc + 2) * 4);
         ix->flags = (int32_t*)p; p += align_up(16);
@@ -412,6 +424,17 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
             LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
                    (const int32_t*)ix->b_start, (const int4*)ix->cmeta, opts->n_contigs, ix->brec);
         }
+        // 7. flat overlap path (partition_mode 5 at build time): per start bin the first position whose prefix max reaches it
+        if (opts->n_contigs > 0 && opts->partition_mode == 5) {
+            hipError_t me = hipMemsetAsync(ix->lot, 0, (size_t)ix->bins_len * 4, ctx->stream);
+            if (me != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(lot): ") + hipGetErrorString(me)));
+            LAUNCH(ctx, "lot_mark", k_lot_mark, grid1d(n, 256), 256, (const int2*)ix->ep, (const int32_t*)ix->b_contig, n,
+                   opts->n_contigs, (const int4*)ix->cmeta, ix->lot);
+            device_scan<uint32_t, MaxOp, true>(ctx, "lot_scan", ix->lot, ix->lot, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
+            LAUNCH(ctx, "tab2", k_tab2, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, (const uint32_t*)ix->lot, ix->bins_len, ix->tab2);
+            LAUNCH(ctx, "rec4", k_rec4, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int2*)ix->ep, (const int32_t*)ix->b_row, n, ix->rec4);
+            ix->has_flat = true;
+        }
         if (with_end_order) { r = build_end_order(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
     } else {
         ix->has_end_order = true;
@@ -422,10 +445,10 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
     return IVJ_OK;
 }
 
-int ensure_ov(ivj_ctx* ctx, int64_t n, bool with_part) {
+int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one permuted column set, 2: two
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     const size_t col = align_up((size_t)n * 4);
-    const size_t need = (with_part ? 6 : 2) * col + align_up((size_t)(tiles + 2) * 8) +
+    const size_t need = (size_t)(2 + 4 * with_part) * col + align_up((size_t)(tiles + 2) * 8) +
                         align_up((size_t)(scan_num_tiles(tiles) + 2) * 8) + 1024;
     if (need > ctx->ov_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -445,6 +468,12 @@ int ensure_ov(ivj_ctx* ctx, int64_t n, bool with_part) {
         ctx->pt_e = (int32_t*)p; p += col;
         ctx->pt_row = (int32_t*)p; p += col;
     }
+    if (with_part > 1) {
+        ctx->pu_c = (int32_t*)p; p += col;
+        ctx->pu_s = (int32_t*)p; p += col;
+        ctx->pu_e = (int32_t*)p; p += col;
+        ctx->pu_row = (int32_t*)p; p += col;
+    }
     ctx->ov_tile = (long long*)p;
     return IVJ_OK;
 }
@@ -452,17 +481,16 @@ int ensure_ov(ivj_ctx* ctx, int64_t n, bool with_part) {
 // Probe bucketing pays once the index no longer fits the L2s and there are enough probes to
 // amortise the two extra passes.  opts->partition_mode: 0 auto, 1 always, 2 never.
 bool want_partition(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts) {
-    if (opts->partition_mode == 1 || opts->partition_mode == 3) return true;
+    if (opts->partition_mode == 1 || opts->partition_mode >= 3) return true;
     if (opts->partition_mode == 2) return false;
     return n_probe >= (4ll << 20) && ix->n >= (256ll << 10);
 }
 
-int partition_probes(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts) {
-    const int64_t n = probe->n;
+// one stable 256-way pass: src columns -> dst columns
+int partition_pass(ivj_ctx* ctx, ivj_index* ix, bool strict, const int32_t* sc, const int32_t* ss, const int32_t* se,
+                   const int32_t* srow, int64_t n, int packed, int32_t* dc, int32_t* ds, int32_t* de, int32_t* drow) {
     const int ntiles = (int)((n + PART_TILE - 1) / PART_TILE);
     const int grid = 8 * ((ntiles + 7) / 8);
-    int bshift = 0;
-    while ((ix->bins_len >> bshift) > (int64_t)(PART_BUCKETS - 3)) ++bshift;
     const size_t hist = (size_t)PART_BUCKETS * (size_t)ntiles;
     IVJ_TRY(arena_reserve(ctx, align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4) + 4096));
     uint32_t* blk = arena_take<uint32_t>(ctx, hist);
@@ -473,21 +501,44 @@ int partition_probes(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
         ctx->part_attr_set = true;
     }
     IndexView v = view_of(ix);
-    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
-    const bool hvec = aligned16(probe->contig) && aligned16(probe->end);
-    if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, probe->contig, probe->end, n, bshift, blk, ntiles, hvec);
-    else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, probe->contig, probe->end, n, bshift, blk, ntiles, hvec);
+    const bool hvec = aligned16(sc) && aligned16(se);
+    if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, sc, se, n, packed, blk, ntiles, hvec);
+    else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, sc, se, n, packed, blk, ntiles, hvec);
     device_scan<uint32_t, SumOp, false>(ctx, "part_scan", blk, blk, (int64_t)hist, 0u, partials, (uint32_t*)nullptr);
     t_begin(ctx, "part_scatter");
     if (strict)
-        hipLaunchKernelGGL((k_part_scatter<true>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, probe->contig, probe->start,
-                           probe->end, probe->row_id, n, bshift, (const uint32_t*)blk, ntiles, ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
+        hipLaunchKernelGGL((k_part_scatter<true>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, sc, ss, se, srow, n, packed,
+                           (const uint32_t*)blk, ntiles, dc, ds, de, drow);
     else
-        hipLaunchKernelGGL((k_part_scatter<false>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, probe->contig, probe->start,
-                           probe->end, probe->row_id, n, bshift, (const uint32_t*)blk, ntiles, ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
+        hipLaunchKernelGGL((k_part_scatter<false>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, sc, ss, se, srow, n, packed,
+                           (const uint32_t*)blk, ntiles, dc, ds, de, drow);
     t_end(ctx);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
+}
+
+// partition_mode 4 (or auto for very large probe sides): two stable passes -> 65536 buckets of ~76
+// build rows: the 64 probes of a wavefront then look at the same few cache lines.
+bool want_two_level(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts) {
+    (void)ix; (void)n_probe;
+    return opts->partition_mode == 4;
+}
+
+int partition_probes(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts) {
+    const int64_t n = probe->n;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    if (want_two_level(ix, n, opts)) {
+        int bs = 0;
+        while ((ix->bins_len >> bs) > 65533ll) ++bs;
+        IVJ_TRY(partition_pass(ctx, ix, strict, probe->contig, probe->start, probe->end, probe->row_id, n, part_pack(bs, 0, true),
+                               ctx->pu_c, ctx->pu_s, ctx->pu_e, ctx->pu_row));
+        return partition_pass(ctx, ix, strict, ctx->pu_c, ctx->pu_s, ctx->pu_e, ctx->pu_row, n, part_pack(bs, 8, true),
+                              ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
+    }
+    int bshift = 0;
+    while ((ix->bins_len >> bshift) > (int64_t)(PART_BUCKETS - 3)) ++bshift;
+    return partition_pass(ctx, ix, strict, probe->contig, probe->start, probe->end, probe->row_id, n, part_pack(bshift, 0, false),
+                          ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
 }
 
 int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* n_pairs) {
@@ -499,7 +550,7 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         return IVJ_OK;
     }
     const bool part = want_partition(ix, n, opts);
-    IVJ_TRY(ensure_ov(ctx, n, part));
+    IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
     ctx->ov_part = part;
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     long long* tile = ctx->ov_tile;                       // tiles + 1
@@ -568,7 +619,7 @@ int overlap_fused_fine(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
     ctx->ov_n = -1;
     *n_pairs = 0;
     if (n == 0 || ix->n == 0) return IVJ_OK;
-    IVJ_TRY(ensure_ov(ctx, n, true));
+    IVJ_TRY(ensure_ov(ctx, n, 1));
     int bshift = 0;
     while ((ix->bins_len >> bshift) > (int64_t)(FINE_BUCKETS - 2)) ++bshift;
     const int64_t jgrid = (n + FINE_TILE - 1) / FINE_TILE + FINE_BUCKETS;      // upper bound on the number of tiles
@@ -622,8 +673,10 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     if (n == 0 || ix->n == 0) return IVJ_OK;
     if (opts->partition_mode == 3 && fine_available(ix)) return overlap_fused_fine(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
     const bool part = want_partition(ix, n, opts);
-    IVJ_TRY(ensure_ov(ctx, n, part));
-    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
+    const bool flat = opts->partition_mode == 5;
+    if (flat && !ix->has_flat) return fail(IVJ_ESTATE, "partition_mode 5 (flat) needs an index built with partition_mode 5");
+    const int64_t tiles = flat ? (n + FLAT_TILE - 1) / FLAT_TILE : (n + PROBE_TILE - 1) / PROBE_TILE;
     unsigned long long* state = (unsigned long long*)ctx->ov_tile;   // [0] cursor, [1] overflow
     const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *ids = probe->row_id;
     if (part) {
@@ -633,7 +686,12 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     HIP_TRY(hipMemsetAsync(state, 0, 16, ctx->stream));
     const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
     IndexView v = view_of(ix);
-    if (opts->filter_op == IVJ_FILTER_STRICT)
+    if (flat) {
+        if (opts->filter_op == IVJ_FILTER_STRICT)
+            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<true>), tiles, FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+        else
+            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<false>), tiles, FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+    } else if (opts->filter_op == IVJ_FILTER_STRICT)
         LAUNCH(ctx, "overlap_fused", (k_overlap_fused<true>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
     else
         LAUNCH(ctx, "overlap_fused", (k_overlap_fused<false>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);

@@ -20,6 +20,22 @@ constexpr int PART_BUCKETS = 256;   // bucket 255 = probes without any candidate
 constexpr size_t PART_LDS_BYTES = (size_t)PART_TILE * 4 /* one column at a time */ + (size_t)PART_TILE /* bucket ids */ +
                                   (size_t)PART_WAVES * PART_BUCKETS * 4 + 3 * PART_BUCKETS * 4 + 16;
 
+// `bshift` packs the digit of this pass: bits 0-5 = table-slot shift, bits 8-11 = digit shift,
+// bit 16 = two-level (65536 buckets, two stable 256-way passes: low digit first, then high digit;
+// the result is ordered by the 16-bit bucket id).  Single level: 254 buckets.  Digit 255 of every
+// pass = probes without any candidate row (they end up at the very end).
+__host__ __device__ __forceinline__ int part_pack(int slot_shift, int digit_shift, bool two_level) {
+    return slot_shift | (digit_shift << 8) | ((two_level ? 1 : 0) << 16);
+}
+__device__ __forceinline__ uint32_t part_digit(uint32_t slot, int packed) {
+    const uint32_t id = slot >> (packed & 63);
+    if ((packed >> 16) & 1) {
+        const uint32_t cl = id < 65533u ? id : 65533u;
+        return (cl >> ((packed >> 8) & 15)) & 255u;
+    }
+    return id < (uint32_t)(PART_BUCKETS - 2) ? id : (uint32_t)(PART_BUCKETS - 2);
+}
+
 template <bool STRICT>
 __device__ __forceinline__ uint32_t probe_bucket(const IndexView& ix, int32_t c, int32_t qe, int bshift) {
     if ((uint32_t)c >= (uint32_t)ix.n_contigs) return PART_BUCKETS - 1;
@@ -31,8 +47,7 @@ __device__ __forceinline__ uint32_t probe_bucket(const IndexView& ix, int32_t c,
     if (tu <= ulo) j = 0;
     else if (tu > uhi) j = ((uhi - ulo) >> m1.x) + 1u;
     else j = ((uint32_t)tu - ulo) >> m1.x;
-    const uint32_t bkt = ((uint32_t)m1.y + j) >> bshift;
-    return bkt < (uint32_t)(PART_BUCKETS - 2) ? bkt : (uint32_t)(PART_BUCKETS - 2);
+    return part_digit((uint32_t)m1.y + j, bshift);
 }
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch); give every XCD a
@@ -55,8 +70,7 @@ __device__ __forceinline__ uint32_t probe_bucket_m(const int4& m0, const int4& m
     if (tu <= ulo) j = 0;
     else if (tu > uhi) j = ((uhi - ulo) >> m1.x) + 1u;
     else j = ((uint32_t)tu - ulo) >> m1.x;
-    const uint32_t bkt = ((uint32_t)m1.y + j) >> bshift;
-    return bkt < (uint32_t)(PART_BUCKETS - 2) ? bkt : (uint32_t)(PART_BUCKETS - 2);
+    return part_digit((uint32_t)m1.y + j, bshift);
 }
 
 template <bool STRICT>

@@ -6,3 +6,4 @@
 #include "overlap.hip.h"
 #include "count_nearest.hip.h"
 #include "partition.hip.h"
+#include "flat.hip.h"

@@ -26,6 +26,32 @@ def _canon(p, b):
     return p[o], b[o]
 
 
+def _fused_overlap(eng, probe, build, strict, n_contigs, partition_mode, total):
+    """ivj_overlap_fused_dev with device-resident columns; returns the raw (probe, build) pair arrays."""
+    ptrs, sides = [], []
+    for side in (probe, build):
+        n = len(side[0])
+        ps = []
+        for col in side:
+            p = eng.dev_alloc(max(4 * n, 16))
+            eng.h2d(p, np.ascontiguousarray(col, np.int32))
+            ps.append(p)
+        ptrs += ps
+        sides.append(eng.dev_side(ps[0], ps[1], ps[2], n))
+    opts = _engine.make_opts(strict, n_contigs, partition_mode=partition_mode)
+    ix = eng.index_build_dev(sides[1], opts)
+    op, ob = eng.dev_alloc(max(4 * total, 16)), eng.dev_alloc(max(4 * total, 16))
+    n_pairs, fits = eng.overlap_fused_dev(ix, sides[0], opts, op, ob, total)
+    assert fits and n_pairs == total, (partition_mode, n_pairs, total)
+    hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
+    eng.d2h(hp, op)
+    eng.d2h(hb, ob)
+    ix.close()
+    for p in ptrs + [op, ob]:
+        eng.dev_free(p)
+    return hp, hb
+
+
 def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1, True), (1, False), (3, True), (4, False))):
     ps, bs = O.Side(*probe), O.Side(*build)
     ix = O.Index(bs, n_contigs)
@@ -38,6 +64,14 @@ def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1
     assert (p == ep).all() and (b == eb).all(), "partitioned path"
     p, b = _canon(*eng.overlap(probe, build, strict, n_contigs, partition_mode=1, table_mode=1))   # 16-byte bin records
     assert len(p) == len(ep) and (p == ep).all() and (b == eb).all(), "record table"
+    p, b = _canon(*eng.overlap(probe, build, strict, n_contigs, partition_mode=4))   # two-level buckets
+    assert len(p) == len(ep) and (p == ep).all() and (b == eb).all(), "two-level partition"
+    if len(probe[0]) and len(build[0]):
+        for pm in (0, 5):                                # fused single pass: window scan / flat candidates
+            hp, hb = _fused_overlap(eng, probe, build, strict, n_contigs, pm, len(ep))
+            assert int((np.diff(hp) != 0).sum()) + 1 == len(np.unique(hp)) or len(hp) == 0, ("probe runs split", pm)
+            p, b = _canon(hp, hb)
+            assert (p == ep).all() and (b == eb).all(), ("fused", pm)
     ec = O.count_overlaps_brute(ps, bs, strict) if brute else O.count_overlaps_fast(ix, ps, strict)
     for tm in (2, 1):                                    # 4-byte bins / 16-byte records
         assert (eng.count_overlaps(probe, build, strict, n_contigs, table_mode=tm) == ec).all(), tm
@@ -109,7 +143,7 @@ def test_inverted_rows_follow_the_inequality(eng):
         probe = (c, np.where(f, e, s).astype(np.int32), np.where(f, s, e).astype(np.int32))
         ps, bs = O.Side(*probe), O.Side(*build)
         ep, eb = O.overlap_brute(ps, bs, strict)
-        for mode in (2, 1):
+        for mode in (2, 1, 4):
             p, b = _canon(*eng.overlap(probe, build, strict, 2, partition_mode=mode))
             assert (p == ep).all() and (b == eb).all(), mode
         assert (eng.count_overlaps(probe, build, strict, 2) == O.count_overlaps_brute(ps, bs, strict)).all()
@@ -126,7 +160,7 @@ def test_empty_and_absent(eng):
         assert n.tolist() == [0] and i.tolist() == [[-1]] and d.tolist() == [[-1]]
         # empty dictionary (every chrom null on both sides): nothing can match
         nul = (np.full(3, -1, np.int32), np.array([1, 5, 9], np.int32), np.array([4, 8, 12], np.int32))
-        for pm in (1, 2):
+        for pm in (1, 2, 4):
             assert len(eng.overlap(nul, nul, strict, 0, partition_mode=pm)[0]) == 0
         assert eng.count_overlaps(nul, nul, strict, 0).tolist() == [0, 0, 0]
         assert eng.nearest(nul, nul, strict, 0)[2].tolist() == [0, 0, 0]
@@ -202,7 +236,7 @@ def test_device_resident_api_matches_host_api(eng):
     probe = synth.make_side(300_001, 42, synth.PROBE_LEN, 24)
     build = synth.make_side(50_003, 43, synth.BUILD_LEN, 24)
     p, b = eng.overlap(probe, build, True, 24, partition_mode=2)
-    for mode in (2, 1):
+    for mode in (2, 1, 4):
         hp, hb, counts = _device_overlap(eng, probe, build, True, 24, partition_mode=mode)
         hp, hb = _canon(hp, hb)
         assert (hp == p).all() and (hb == b).all(), mode
@@ -271,7 +305,9 @@ def test_fused_single_pass_matches_two_pass(eng):
     """ivj_overlap_fused_dev: same pair set; the pairs of one probe row stay contiguous and ordered
     (a stable sort by probe row gives the oracle's exact sequence); a too-small buffer is refused."""
     for (npr, nb, nc, pm) in ((300_001, 50_003, 24, 1), (300_001, 50_003, 24, 2), (5000, 700, 3, 1),
-                              (300_001, 50_003, 24, 3), (5000, 700, 3, 3), (777_777, 1_300_000, 24, 3)):
+                              (300_001, 50_003, 24, 3), (5000, 700, 3, 3), (777_777, 1_300_000, 24, 3),
+                              (300_001, 50_003, 24, 4), (5000, 700, 3, 4), (777_777, 1_300_000, 24, 4),
+                              (300_001, 50_003, 24, 5), (5000, 700, 3, 5), (777_777, 1_300_000, 24, 5)):
         probe = synth.make_side(npr, 42, synth.PROBE_LEN, nc)
         build = synth.make_side(nb, 43, synth.DENSE_BUILD_LEN if npr < 10000 else synth.BUILD_LEN, nc)
         ep, eb = eng.overlap(probe, build, True, nc, partition_mode=2)

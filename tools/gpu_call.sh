@@ -11,6 +11,10 @@ for stage in "$@"; do
     c2) echo "== bench config2"; timeout 900 python bench.py --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c2.err | tee gpurun_out/bench_c2.json; tail -22 gpurun_out/bench_c2.err ;;
     c3) echo "== bench config3"; timeout 1200 python bench.py --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c3.err | tee gpurun_out/bench_c3.json; tail -22 gpurun_out/bench_c3.err ;;
     c3fine) echo "== bench config3 fine"; timeout 1200 python bench.py --steps 10 --warmup 2 --partition-mode 3 --no-cpu-baseline --kernel-table 2>gpurun_out/bench_c3fine.err | tee gpurun_out/bench_c3fine.json; tail -24 gpurun_out/bench_c3fine.err ;;
+    c3lvl2) echo "== bench config3 two-level buckets"; timeout 1200 python bench.py --steps 10 --warmup 2 --partition-mode 4 --no-cpu-baseline --kernel-table 2>gpurun_out/bench_c3lvl2.err | tee gpurun_out/bench_c3lvl2.json; tail -24 gpurun_out/bench_c3lvl2.err ;;
+    c2lvl2) echo "== bench config2 two-level buckets"; timeout 1200 python bench.py --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --partition-mode 4 --no-cpu-baseline 2>gpurun_out/bench_c2lvl2.err | tee gpurun_out/bench_c2lvl2.json ;;
+    c3flat) echo "== bench config3 flat"; timeout 1200 python bench.py --steps 10 --warmup 2 --partition-mode 5 --no-cpu-baseline --kernel-table 2>gpurun_out/bench_c3flat.err | tee gpurun_out/bench_c3flat.json; tail -26 gpurun_out/bench_c3flat.err ;;
+    c2flat) echo "== bench config2 flat"; timeout 1200 python bench.py --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --partition-mode 5 --no-cpu-baseline 2>gpurun_out/bench_c2flat.err | tee gpurun_out/bench_c2flat.json ;;
     c2fine) echo "== bench config2 fine"; timeout 1200 python bench.py --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --partition-mode 3 --no-cpu-baseline 2>gpurun_out/bench_c2fine.err | tee gpurun_out/bench_c2fine.json ;;
     fusedtest) echo "== fused tests"; timeout 900 python -m pytest tests -m gpu -q -x -k "fused" 2>&1 | tail -15 ;;
     c3two) echo "== bench config3 two-pass"; timeout 1200 python bench.py --steps 10 --warmup 2 --two-pass --no-cpu-baseline 2>gpurun_out/bench_c3two.err | tee gpurun_out/bench_c3two.json ;;
@@ -34,6 +38,14 @@ for stage in "$@"; do
         tail -1 gpurun_out/pmcx_$i.err | cut -c1-200; dirs="$dirs gpurun_out/pmcx_$i";
       done;
       python tools/pmc_summary.py $dirs > gpurun_out/pmcx_summary.json 2> gpurun_out/pmcx_summary.err; tail -3 gpurun_out/pmcx_summary.err ;;
+    pmcsq) echo "== PMC SQ issue/wait breakdown (config3, partition mode ${PMODE:-0})";
+      i=0; dirs="";
+      for set in "SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE"; do
+        i=$((i+1));
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set -d "$OLDPWD/gpurun_out/pmcsq${PMODE:-0}_$i" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --partition-mode ${PMODE:-0} > "$OLDPWD/gpurun_out/pmcsq${PMODE:-0}_$i.out" 2> "$OLDPWD/gpurun_out/pmcsq${PMODE:-0}_$i.err");
+        tail -1 gpurun_out/pmcsq${PMODE:-0}_$i.err | cut -c1-160; dirs="$dirs gpurun_out/pmcsq${PMODE:-0}_$i";
+      done;
+      python tools/pmc_summary.py $dirs > gpurun_out/pmcsq${PMODE:-0}_summary.json 2> gpurun_out/pmcsq${PMODE:-0}_summary.err; tail -3 gpurun_out/pmcsq${PMODE:-0}_summary.err ;;
     pmcfine) echo "== PMC on the fine path";
       i=0; dirs="";
       for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM"; do
