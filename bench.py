@@ -56,6 +56,9 @@ def parse():
                          "into the preallocated result buffers once the warmup has sized them)")
     ap.add_argument("--partition-mode", type=int, default=0,
                     help="ivj_opts.partition_mode: 0 auto, 1 256-way, 2 none, 3 fine (8192-way + LDS-resident slices), 4 two-level (65536 buckets), 5 flat (load-balanced candidates)")
+    ap.add_argument("--materialize", action="store_true",
+                    help="overlap workloads: also gather the key columns of both sides for every pair in HBM "
+                         "(ivj_materialize_dev, SURVEY.md 8f row 1) inside the step")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (RCCL init, sharding, all-gatherv) even with one rank")
     return ap.parse_args()
@@ -165,11 +168,23 @@ def main():
         if op == "overlap":
             # the first (warmup) step sizes the result buffers; later steps write into them, so the
             # timed region holds no device allocation
+            if args.materialize and not args.two_pass and "rows" in state:
+                # join + materialisation in ONE pass (ivj_overlap_fused_rows_dev) into the preallocated columns
+                cols, local, fits = join.overlap_rows(d_probe, d_build, True, nc, state["rows"], partition_mode=args.partition_mode)
+                assert fits, "row buffers too small"
+                return local, (cols["probe_idx"], cols["build_idx"])
             p, b = join.overlap(d_probe, d_build, True, nc, out=state.get("out"), fused=not args.two_pass,
                                 partition_mode=args.partition_mode)
             if "out" not in state:
                 state["out"] = (torch.empty_like(p), torch.empty_like(b))
             local = int(p.shape[0])
+            if args.materialize:
+                # first (warmup) step or --two-pass: separate gather pass over the finished pair list
+                if "rows_sep" not in state:
+                    state["rows_sep"] = {k: torch.empty_like(p) for k in ("contig", "start_1", "end_1", "start_2", "end_2")}
+                state["cols"] = join.materialize(d_probe, d_build, p, b, out=state["rows_sep"])
+                if not args.two_pass and "rows" not in state:
+                    state["rows"] = dict(state["rows_sep"], probe_idx=state["out"][0], build_idx=state["out"][1])
             if gather:
                 # the exchange is timed on its own as well (torch events on the current stream: the
                 # waits of the grouped isend/irecv order the stream behind RCCL's)
@@ -221,6 +236,8 @@ def main():
         if dom is None or v["ms"] > dom["ms"]:
             dom_name, dom = k, v
     alg_bytes = algorithmic_bytes(op, d_probe.n, d_build.n, local_units)
+    if args.materialize and op == "overlap":
+        alg_bytes += 20 * local_units      # per pair: five more int32 output columns (the key values are already counted as inputs)
     roofline = None
     traffic = None
     try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (same command)
@@ -279,8 +296,9 @@ def main():
                        "parallelism": ("single GPU" if not multi else
                                        f"{mode}-sharded x{n_gpus}, " + ("RCCL all-gatherv in timed region" if gather else "no gather")),
                        "step": ("index build (radix sort) + probe bucketing + " +
-                                ("count + scan + fill" if (args.two_pass or "overlap_fused" not in ktimes) else
+                                ("count + scan + fill" if (args.two_pass or not any(k.startswith(("overlap_fused", "overlap_flat")) for k in ktimes)) else
                                  "fused count/fill into the preallocated result buffers") +
+                                (" + key-column materialisation of every pair" if args.materialize else "") +
                                 ", inputs and outputs in HBM") if op == "overlap" else
                                "index build (radix sort) + probe kernel, inputs and outputs in HBM"},
             "phases_ms": ({"join_rank0": round(ms_per_step - gather_ms, 4), "allgatherv_rank0": round(gather_ms, 4)}

@@ -176,6 +176,58 @@ int ivj_count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_de
 int ivj_nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev,
                     const ivj_opts* opts, int32_t* idx_dev, int64_t* dist_dev, int32_t* n_found_dev);
 
+/* ---- row materialisation -------------------- *
+ * The step right after the join: gather the columns of both sides for every emitted pair     *
+ * (reference: the renaming SELECT of src/operation.rs:272-301 over the joined batches).      *
+ * Output columns are Arrow-layout value buffers (fixed-width little-endian values, optional   *
+ * validity bitmap, LSB first).                                                               */
+
+/* Key columns of an overlap result, n_pairs values each.  Device pointers for
+ * ivj_materialize_dev (caller-allocated; a NULL column is skipped), library-owned host
+ * buffers for ivj_overlap_rows (free with ivj_rows_free). */
+typedef struct {
+    int64_t n_pairs;
+    int32_t* probe_idx;   /* row of df1 */
+    int32_t* build_idx;   /* row of df2 */
+    int32_t* contig;      /* contig id of the pair (equal on both sides) */
+    int32_t* start_1;     /* df1.start[probe_idx] */
+    int32_t* end_1;
+    int32_t* start_2;     /* df2.start[build_idx] */
+    int32_t* end_2;
+} ivj_rows;
+
+/* Gathers contig / start_1 / end_1 / start_2 / end_2 for the pairs (rows->probe_idx,
+ * rows->build_idx) = positions into probe_dev / build_dev, in one pass over the pair list. */
+int ivj_materialize_dev(ivj_ctx* ctx, const ivj_side* probe_dev, const ivj_side* build_dev, const ivj_rows* rows);
+
+/* Join AND materialisation in one pass (the fast path: the probe values never leave the workgroup,
+ * the build values come with one 16-byte read per row; a separate ivj_materialize_dev over the
+ * finished pair list has to fetch the probe columns at random).  rows_dev: device column pointers
+ * (NULL = column not wanted), rows_dev->n_pairs = capacity of every column on entry.  Otherwise the
+ * contract of ivj_overlap_fused_dev: *n_pairs = total, IVJ_ECAPACITY when it does not fit, rows of one
+ * probe contiguous and ordered, tile order not reproducible.  Works with row_id (global ids). */
+int ivj_overlap_fused_rows_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts,
+                               const ivj_rows* rows_dev, int64_t* n_pairs);
+
+/* Arrow `take` of one fixed-width device column: dst[i] = src[idx[i]]; elem_bytes is 4 or 8.
+ * A negative index (the "no candidate" slot of nearest) writes 0 and, when validity_dev is given
+ * (ceil(n / 64) 64-bit words), clears that row's validity bit. */
+int ivj_take_dev(ivj_ctx* ctx, const void* src_dev, int32_t elem_bytes, const int32_t* idx_dev, int64_t n,
+                 void* dst_dev, uint64_t* validity_dev);
+
+/* Host-buffer form of overlap + materialisation: index pairs AND the five key columns come back
+ * (one H2D of the inputs, join and gathers in HBM, one D2H per column). */
+int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, ivj_rows* out);
+void ivj_rows_free(ivj_rows* rows);
+
+/* Arrow C Data Interface export of an ivj_overlap_rows result as ONE struct array
+ * {probe_idx, build_idx, contig, start_1, end_1, start_2, end_2 : int32 not null} without copying:
+ * ownership of the host buffers moves to the ArrowArray (its release callback frees them; *rows is
+ * cleared).  out_array / out_schema point to caller-allocated `struct ArrowArray` / `struct
+ * ArrowSchema` (https://arrow.apache.org/docs/format/CDataInterface.html); a consumer such as
+ * pyarrow.RecordBatch._import_from_c takes it from there. */
+int ivj_rows_export_arrow(ivj_rows* rows, void* out_array, void* out_schema);
+
 /* ---- device memory helpers for callers without a HIP binding ------------ */
 int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out);
 int ivj_dev_free(ivj_ctx* ctx, void* p);

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(FINE_THREADS) void k_overlap_fused_fine(IndexView i
     const long long tbase = s_base;
     if (tbase < 0 || tot == 0) return;                     // uniform
     FineRow rowof{&ix, &fc};
-    emit_tile_rows<STRICT, FINE_THREADS, FINE_STAGE>(ix, rowof, hi, x, cnt, row, s, loc0, tot, tbase, st_p, st_b, out_probe, out_build);
+    emit_tile_rows<STRICT, FINE_THREADS, FINE_STAGE>(ix, rowof, PairOut{out_probe, out_build}, hi, x, cnt, row, s, loc0, tot, tbase, st_p, st_b);
 }
 
 }  // namespace ivj

@@ -120,6 +120,7 @@ struct ivj_index {
     bool has_end_order = false;
     bool has_argmax = false;
     bool has_flat = false;
+    bool has_rec4 = false;     // rec4 is filled on demand (join + materialisation path, flat path)
     char* slab = nullptr;      // single allocation holding every array above
     size_t slab_cap = 0;
 };
@@ -161,7 +162,8 @@ T* arena_take(ivj_ctx* ctx, size_t count) {
 }
 
 bool is_probe_kernel(const char* name) {
-    return !std::strncmp(name, "overlap_", 8) || !std::strncmp(name, "count_overlaps", 14) || !std::strncmp(name, "nearest", 7);
+    return !std::strncmp(name, "overlap_", 8) || !std::strncmp(name, "count_overlaps", 14) || !std::strncmp(name, "nearest", 7) ||
+           !std::strncmp(name, "materialize", 11) || !std::strncmp(name, "take", 4);
 }
 void t_begin(ivj_ctx* ctx, const char* name) {
     ctx->t_open = false;
@@ -332,6 +334,15 @@ int build_argmax(ivj_ctx* ctx, ivj_index* ix) {
     return IVJ_OK;
 }
 
+// rec4[p] = {start, end, build row, prefix max}: built on demand for the join + materialisation path
+int build_rec4(ivj_ctx* ctx, ivj_index* ix) {
+    if (ix->has_rec4 || ix->n == 0) return IVJ_OK;
+    LAUNCH(ctx, "rec4", k_rec4, grid1d(ix->n, 256), 256, (const int32_t*)ix->b_start, (const int2*)ix->ep, (const int32_t*)ix->b_row, ix->n, ix->rec4);
+    HIP_TRY(hipGetLastError());
+    ix->has_rec4 = true;
+    return IVJ_OK;
+}
+
 int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int with_end_order, ivj_index** out) {
     // table offsets (2 a + 2 c) and slot counts are int32: 2 Nb + 2 n_contigs must stay below 2^31
     if (2 * build->n + 2 * (int64_t)opts->n_contigs + 64 > 0x7fffffffll)
@@ -347,7 +358,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
         const size_t small = align_up((nc + 2) * 4) + align_up(16) + 3 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e, cmeta_j
         const bool want_flat = opts->partition_mode == 5;
-        const size_t flat_bytes = want_flat ? align_up((nn + 1) * 16) + 3 * align_up((size_t)ix->bins_len * 4) : 0;
+        const size_t flat_bytes = align_up((nn + 1) * 16) + (want_flat ? 3 * align_up((size_t)ix->bins_len * 4) : 0);
         const size_t need = flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 16) + 2 * align_up((size_t)ix->bins_len * 4) +
                             3 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
@@ -372,8 +383,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->brec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
         ix->brec_e = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
         ix->crec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
+        ix->rec4 = (int4*)p; p += align_up((nn + 1) * 16);
         if (want_flat) {
-            ix->rec4 = (int4*)p; p += align_up((nn + 1) * 16);
             ix->lot = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
             ix->tab2 = (uint2*)p; p += 2 * align_up((size_t)ix->bins_len * 4);
         }
@@ -432,8 +443,9 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
                    opts->n_contigs, (const int4*)ix->cmeta, ix->lot);
             device_scan<uint32_t, MaxOp, true>(ctx, "lot_scan", ix->lot, ix->lot, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
             LAUNCH(ctx, "tab2", k_tab2, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, (const uint32_t*)ix->lot, ix->bins_len, ix->tab2);
-            LAUNCH(ctx, "rec4", k_rec4, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int2*)ix->ep, (const int32_t*)ix->b_row, n, ix->rec4);
             ix->has_flat = true;
+            r = build_rec4(ctx, ix);
+            if (r != IVJ_OK) return cleanup(r);
         }
         if (with_end_order) { r = build_end_order(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
     } else {
@@ -704,6 +716,40 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     return IVJ_OK;
 }
 
+// fused join + key-column materialisation (k_overlap_fused_rows); same partitioning as overlap_fused
+int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const ivj_rows* rows, int64_t* n_pairs) {
+    const int64_t n = probe->n;
+    const int64_t capacity = rows->n_pairs;
+    ctx->ov_n = -1;
+    *n_pairs = 0;
+    if (n == 0 || ix->n == 0) return IVJ_OK;
+    IVJ_TRY(build_rec4(ctx, ix));
+    const bool part = want_partition(ix, n, opts);
+    IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    unsigned long long* state = (unsigned long long*)ctx->ov_tile;
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *ids = probe->row_id;
+    if (part) {
+        IVJ_TRY(partition_probes(ctx, ix, probe, opts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e; ids = ctx->pt_row;
+    }
+    HIP_TRY(hipMemsetAsync(state, 0, 16, ctx->stream));
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe) && aligned16(ids);
+    IndexView v = view_of(ix);
+    RowColumns cols{rows->probe_idx, rows->build_idx, rows->contig, rows->start_1, rows->end_1, rows->start_2, rows->end_2};
+    if (opts->filter_op == IVJ_FILTER_STRICT)
+        LAUNCH(ctx, "overlap_fused_rows", (k_overlap_fused_rows<true>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, cols);
+    else
+        LAUNCH(ctx, "overlap_fused_rows", (k_overlap_fused_rows<false>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, cols);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    *n_pairs = ctx->h_total[0];
+    if (ctx->h_total[1] != 0)
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " rows");
+    return IVJ_OK;
+}
+
 int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* counts) {
     const int64_t n = probe->n;
     if (n == 0) return IVJ_OK;
@@ -922,6 +968,17 @@ int ivj_overlap_fused_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev
     return overlap_fused(ctx, ix, probe_dev, opts, probe_idx_dev, build_idx_dev, capacity, n_pairs);
 }
 
+int ivj_overlap_fused_rows_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, const ivj_rows* rows_dev,
+                               int64_t* n_pairs) {
+    if (!ctx || !ix || !rows_dev || !n_pairs) return fail(IVJ_EINVAL, "ctx, index, rows or n_pairs is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    if (rows_dev->n_pairs < 0) return fail(IVJ_EINVAL, "capacity (rows->n_pairs) < 0");
+    if (opts->partition_mode == 3 || opts->partition_mode == 5) return fail(IVJ_EINVAL, "partition_mode 3 / 5 are not available for the rows path");
+    DeviceGuard g(ctx->device);
+    return overlap_fused_rows(ctx, ix, probe_dev, opts, rows_dev, n_pairs);
+}
+
 int ivj_count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* counts_dev) {
     if (!ctx || !ix) return fail(IVJ_EINVAL, "ctx or index is NULL");
     IVJ_TRY(check_opts(opts));
@@ -971,6 +1028,155 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     HIP_TRY(hipMemcpyAsync(out->build_idx, ob.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     out->n_pairs = total;
+    return IVJ_OK;
+}
+
+// ---------------------------------------------------------------- row materialisation
+
+int ivj_materialize_dev(ivj_ctx* ctx, const ivj_side* probe_dev, const ivj_side* build_dev, const ivj_rows* rows) {
+    if (!ctx || !rows) return fail(IVJ_EINVAL, "ctx or rows is NULL");
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    IVJ_TRY(check_side(build_dev, "build"));
+    const int64_t n = rows->n_pairs;
+    if (n < 0) return fail(IVJ_EINVAL, "n_pairs < 0");
+    if (n == 0) return IVJ_OK;
+    if (!rows->probe_idx || !rows->build_idx) return fail(IVJ_EINVAL, "pair index columns are NULL");
+    DeviceGuard g(ctx->device);
+    const bool vec = aligned16(rows->probe_idx) && aligned16(rows->build_idx) && aligned16(rows->contig) && aligned16(rows->start_1) &&
+                     aligned16(rows->end_1) && aligned16(rows->start_2) && aligned16(rows->end_2);
+    const int64_t per = (int64_t)MAT_THREADS * MAT_ITEMS;
+    LAUNCH(ctx, "materialize_keys", k_materialize_keys, (n + per - 1) / per, MAT_THREADS, probe_dev->contig, probe_dev->start, probe_dev->end,
+           build_dev->start, build_dev->end, (const int32_t*)rows->probe_idx, (const int32_t*)rows->build_idx, n, vec, rows->contig,
+           rows->start_1, rows->end_1, rows->start_2, rows->end_2);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+int ivj_take_dev(ivj_ctx* ctx, const void* src_dev, int32_t elem_bytes, const int32_t* idx_dev, int64_t n, void* dst_dev,
+                 uint64_t* validity_dev) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(IVJ_EINVAL, "elem_bytes must be 4 or 8");
+    if (n < 0) return fail(IVJ_EINVAL, "n < 0");
+    if (n == 0) return IVJ_OK;
+    if (!src_dev || !idx_dev || !dst_dev) return fail(IVJ_EINVAL, "take: NULL buffer");
+    DeviceGuard g(ctx->device);
+    if (elem_bytes == 4)
+        LAUNCH(ctx, "take", (k_take<uint32_t>), grid1d(n, MAT_THREADS), MAT_THREADS, (const uint32_t*)src_dev, idx_dev, n, (uint32_t*)dst_dev,
+               (unsigned long long*)validity_dev);
+    else
+        LAUNCH(ctx, "take", (k_take<unsigned long long>), grid1d(n, MAT_THREADS), MAT_THREADS, (const unsigned long long*)src_dev, idx_dev, n,
+               (unsigned long long*)dst_dev, (unsigned long long*)validity_dev);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+void ivj_rows_free(ivj_rows* r) {
+    if (!r) return;
+    int32_t** cols[7] = {&r->probe_idx, &r->build_idx, &r->contig, &r->start_1, &r->end_1, &r->start_2, &r->end_2};
+    for (auto c : cols) { std::free(*c); *c = nullptr; }
+    r->n_pairs = 0;
+}
+
+int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, ivj_rows* out) {
+    if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
+    std::memset(out, 0, sizeof(*out));
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe, "probe"));
+    IVJ_TRY(check_side(build, "build"));
+    if (probe->row_id || build->row_id) return fail(IVJ_EINVAL, "ivj_overlap_rows gathers by position: row_id must be NULL");
+    DeviceGuard g(ctx->device);
+    DevSide dp, db;
+    IVJ_TRY(upload_side(ctx, build, db));
+    IVJ_TRY(upload_side(ctx, probe, dp));
+    IndexHolder h;
+    IVJ_TRY(index_build(ctx, &db.s, opts, 0, &h.ix));
+    int64_t total = 0;
+    IVJ_TRY(overlap_count(ctx, h.ix, &dp.s, opts, &total));
+    if (total == 0) return IVJ_OK;
+    DevBuf cols;                                            // 7 columns in one allocation
+    const size_t col = align_up((size_t)total * 4);
+    hipError_t e = hipMalloc(&cols.p, 7 * col);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(rows): ") + hipGetErrorString(e));
+    ivj_rows d;
+    d.n_pairs = total;
+    int32_t** dcols[7] = {&d.probe_idx, &d.build_idx, &d.contig, &d.start_1, &d.end_1, &d.start_2, &d.end_2};
+    for (int k = 0; k < 7; ++k) *dcols[k] = (int32_t*)((char*)cols.p + k * col);
+    IVJ_TRY(overlap_fill(ctx, h.ix, &dp.s, opts, d.probe_idx, d.build_idx, total));
+    IVJ_TRY(ivj_materialize_dev(ctx, &dp.s, &db.s, &d));
+    int32_t** hcols[7] = {&out->probe_idx, &out->build_idx, &out->contig, &out->start_1, &out->end_1, &out->start_2, &out->end_2};
+    for (int k = 0; k < 7; ++k) {
+        *hcols[k] = (int32_t*)std::malloc((size_t)total * 4);
+        if (!*hcols[k]) { ivj_rows_free(out); return fail(IVJ_ENOMEM, "host malloc(rows)"); }
+        hipError_t ce = hipMemcpyAsync(*hcols[k], *dcols[k], (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (ce != hipSuccess) { ivj_rows_free(out); return fail(IVJ_EHIP, std::string("D2H(rows): ") + hipGetErrorString(ce)); }
+    }
+    hipError_t se = hipStreamSynchronize(ctx->stream);
+    if (se != hipSuccess) { ivj_rows_free(out); return fail(IVJ_EHIP, std::string("sync(rows): ") + hipGetErrorString(se)); }
+    out->n_pairs = total;
+    return IVJ_OK;
+}
+
+// Arrow C Data Interface (ABI-stable structs of the Arrow specification).
+struct ArrowSchema {
+    const char* format; const char* name; const char* metadata; int64_t flags; int64_t n_children;
+    struct ArrowSchema** children; struct ArrowSchema* dictionary; void (*release)(struct ArrowSchema*); void* private_data;
+};
+struct ArrowArray {
+    int64_t length; int64_t null_count; int64_t offset; int64_t n_buffers; int64_t n_children; const void** buffers;
+    struct ArrowArray** children; struct ArrowArray* dictionary; void (*release)(struct ArrowArray*); void* private_data;
+};
+
+namespace {
+constexpr int kRowCols = 7;
+const char* const kRowNames[kRowCols] = {"probe_idx", "build_idx", "contig", "start_1", "end_1", "start_2", "end_2"};
+
+struct RowsSchemaHolder { ArrowSchema child[kRowCols]; ArrowSchema* ptrs[kRowCols]; };
+struct RowsArrayHolder { ArrowArray child[kRowCols]; ArrowArray* ptrs[kRowCols]; const void* cbuf[kRowCols][2]; const void* pbuf[1]; };
+
+void release_child_schema(ArrowSchema* s) { s->release = nullptr; }
+void release_child_array(ArrowArray* a) { a->release = nullptr; }
+void release_rows_schema(ArrowSchema* s) {
+    auto* h = static_cast<RowsSchemaHolder*>(s->private_data);
+    for (int k = 0; k < kRowCols; ++k) if (h->child[k].release) h->child[k].release(&h->child[k]);
+    delete h;
+    s->release = nullptr;
+}
+void release_rows_array(ArrowArray* a) {
+    auto* h = static_cast<RowsArrayHolder*>(a->private_data);
+    for (int k = 0; k < kRowCols; ++k) {
+        std::free(const_cast<void*>(h->cbuf[k][1]));       // the value buffer this array owns
+        if (h->child[k].release) h->child[k].release(&h->child[k]);
+    }
+    delete h;
+    a->release = nullptr;
+}
+}  // namespace
+
+int ivj_rows_export_arrow(ivj_rows* rows, void* out_array, void* out_schema) {
+    if (!rows || !out_array || !out_schema) return fail(IVJ_EINVAL, "export: NULL argument");
+    auto* arr = static_cast<ArrowArray*>(out_array);
+    auto* sch = static_cast<ArrowSchema*>(out_schema);
+    const int64_t n = rows->n_pairs;
+    int32_t** cols[kRowCols] = {&rows->probe_idx, &rows->build_idx, &rows->contig, &rows->start_1, &rows->end_1, &rows->start_2, &rows->end_2};
+    for (int k = 0; k < kRowCols; ++k) {
+        if (n > 0 && !*cols[k]) return fail(IVJ_EINVAL, std::string("export: column ") + kRowNames[k] + " is NULL");
+        if (!*cols[k]) *cols[k] = (int32_t*)std::calloc(1, 4);   // empty result: consumers still expect a buffer
+    }
+    auto* sh = new RowsSchemaHolder();
+    auto* ah = new RowsArrayHolder();
+    for (int k = 0; k < kRowCols; ++k) {
+        sh->child[k] = ArrowSchema{"i", kRowNames[k], nullptr, 0, 0, nullptr, nullptr, release_child_schema, nullptr};
+        sh->ptrs[k] = &sh->child[k];
+        ah->cbuf[k][0] = nullptr;                           // no validity bitmap: no nulls
+        ah->cbuf[k][1] = *cols[k];
+        ah->child[k] = ArrowArray{n, 0, 0, 2, 0, ah->cbuf[k], nullptr, nullptr, release_child_array, nullptr};
+        ah->ptrs[k] = &ah->child[k];
+        *cols[k] = nullptr;                                 // ownership moved
+    }
+    rows->n_pairs = 0;
+    ah->pbuf[0] = nullptr;
+    *sch = ArrowSchema{"+s", "", nullptr, 0, kRowCols, sh->ptrs, nullptr, release_rows_schema, sh};
+    *arr = ArrowArray{n, 0, 0, 1, kRowCols, ah->pbuf, ah->ptrs, nullptr, release_rows_array, ah};
     return IVJ_OK;
 }
 

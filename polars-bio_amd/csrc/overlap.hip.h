@@ -71,17 +71,31 @@ __device__ __forceinline__ void probe_windows(const IndexView& ix, const int32_t
 // ballot + popcount of the lower lanes gives every matching lane its slot.
 constexpr int FILL_STAGE = 3072;
 
-struct GlobalRow {
+struct GlobalRow {                      // staged build value = original build row of sorted position p
     const int32_t* b_row;
     __device__ __forceinline__ int32_t operator()(int p) const { return b_row[p]; }
 };
+struct PositionRow {                    // staged build value = the sorted position itself (resolved at copy-out)
+    __device__ __forceinline__ int32_t operator()(int p) const { return p; }
+};
+struct PairPosOut {                     // staged build value = sorted position; the build row is read at copy-out
+    int32_t* __restrict__ out_probe;
+    int32_t* __restrict__ out_build;
+    const int32_t* __restrict__ b_row;
+    __device__ __forceinline__ void operator()(long long o, int32_t a, int32_t b) const { out_probe[o] = a; out_build[o] = b_row[b]; }
+};
+// copy-out of one staged pair (a = staged probe value, b = staged build value) to output slot o
+struct PairOut {
+    int32_t* __restrict__ out_probe;
+    int32_t* __restrict__ out_build;
+    __device__ __forceinline__ void operator()(long long o, int32_t a, int32_t b) const { out_probe[o] = a; out_build[o] = b; }
+};
 
-template <bool STRICT, int THREADS, int STAGE, class RowOf, int N>
-__device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf& rowof, const int32_t (&hi)[N],
+template <bool STRICT, int THREADS, int STAGE, class RowOf, class Out, int N>
+__device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf& rowof, const Out& out, const int32_t (&hi)[N],
                                                const int32_t (&x)[N], const int32_t (&cnt)[N],
                                                const int32_t (&row)[N], const int32_t (&qs)[N],
-                                               long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b,
-                                               int32_t* __restrict__ out_probe, int32_t* __restrict__ out_build) {
+                                               long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b) {
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned long long lt_lanes = (1ull << lane) - 1ull;
     for (long long w0 = 0; w0 < tot; w0 += STAGE) {
@@ -99,7 +113,7 @@ __device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf&
                     m &= ~(1u << j);
                     if (o >= w0 && o < w1) {
                         st_p[o - w0] = row[k];
-                        st_b[o - w0] = ix.b_row[hi[k] - 1 - j];
+                        st_b[o - w0] = rowof(hi[k] - 1 - j);
                     }
                     ++o;
                 }
@@ -119,7 +133,7 @@ __device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf&
                     const int p = p0 - lane;
                     int2 v = make_int2(0, 0);
                     int32_t br = 0;
-                    if (p >= 0) { v = ix.ep[p]; br = ix.b_row[p]; }
+                    if (p >= 0) { v = ix.ep[p]; br = rowof(p); }
                     const bool m = p >= 0 && lt_op<STRICT>(cqs, v.x);
                     const unsigned long long mm = __ballot(m);
                     if (m) {
@@ -134,10 +148,7 @@ __device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf&
         }
         __syncthreads();
         const int t = (int)((tot - w0) < (long long)STAGE ? (tot - w0) : (long long)STAGE);
-        for (int i = threadIdx.x; i < t; i += THREADS) {
-            out_probe[tbase + w0 + i] = st_p[i];
-            out_build[tbase + w0 + i] = st_b[i];
-        }
+        for (int i = threadIdx.x; i < t; i += THREADS) out(tbase + w0 + i, st_p[i], st_b[i]);
         __syncthreads();
     }
 }
@@ -148,8 +159,8 @@ __device__ __forceinline__ void emit_tile(const IndexView& ix, const int32_t (&h
                                           const int32_t (&row)[PROBE_ITEMS], const int32_t (&qs)[PROBE_ITEMS],
                                           long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b,
                                           int32_t* __restrict__ out_probe, int32_t* __restrict__ out_build) {
-    emit_tile_rows<STRICT, PROBE_THREADS, FILL_STAGE>(ix, GlobalRow{ix.b_row}, hi, x, cnt, row, qs, loc0, tot, tbase, st_p, st_b,
-                                                       out_probe, out_build);
+    emit_tile_rows<STRICT, PROBE_THREADS, FILL_STAGE>(ix, PositionRow{}, PairPosOut{out_probe, out_build, ix.b_row}, hi, x, cnt, row, qs, loc0, tot,
+                                                       tbase, st_p, st_b);
 }
 
 // Pass 1.  One workgroup = PROBE_TILE probes, PROBE_ITEMS consecutive probes per thread.
@@ -264,6 +275,85 @@ __global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fused(IndexView ix
     const long long tbase = s_base;
     if (tbase < 0 || tot == 0) return;                     // uniform
     emit_tile<STRICT>(ix, hi, x, cnt, row, s, loc0, tot, tbase, st_p, st_b, out_probe, out_build);
+}
+
+// ---- fused join + row materialisation ---------------------------------
+// The joined ROWS leave the kernel, not just the index pairs: per pair the probe row, the build row,
+// the contig id and start/end of both sides (reference: the SELECT over the joined batches,
+// src/operation.rs:272-301, for the key columns).  A separate gather pass over the finished pair list
+// has to fetch three probe columns at random over the whole probe side (10 ms for config 3); here
+// the probe values never leave the workgroup (staged pair = tile-local probe slot -> LDS tables of the
+// tile) and the build values come with ONE 16-byte rec4 read per pair at copy-out, where consecutive
+// lanes hold consecutive rows of the same probe.
+constexpr int ROWS_STAGE = 2048;
+
+struct RowColumns {                     // device pointers, any may be null (column skipped)
+    int32_t *probe_idx, *build_idx, *contig, *start_1, *end_1, *start_2, *end_2;
+};
+struct RowsOut {
+    RowColumns c;
+    const int4* __restrict__ rec4;      // {start, end, build row, pmax} per sorted position
+    const int32_t *l_row, *l_c, *l_s, *l_e;   // LDS tables of the tile, by tile-local probe slot
+    __device__ __forceinline__ void operator()(long long o, int32_t q, int32_t pos) const {
+        const int4 r = rec4[pos];
+        if (c.probe_idx) c.probe_idx[o] = l_row[q];
+        if (c.build_idx) c.build_idx[o] = r.z;
+        if (c.contig) c.contig[o] = l_c[q];
+        if (c.start_1) c.start_1[o] = l_s[q];
+        if (c.end_1) c.end_1[o] = l_e[q];
+        if (c.start_2) c.start_2[o] = r.x;
+        if (c.end_2) c.end_2[o] = r.y;
+    }
+};
+
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS, 4) void k_overlap_fused_rows(IndexView ix, const int32_t* __restrict__ pc,
+                                                                       const int32_t* __restrict__ ps,
+                                                                       const int32_t* __restrict__ pe,
+                                                                       const int32_t* __restrict__ probe_ids, int64_t n,
+                                                                       bool vec_ok, long long capacity,
+                                                                       unsigned long long* __restrict__ state, RowColumns cols) {
+    __shared__ long long lds[PROBE_THREADS / kWave];
+    __shared__ long long s_base;
+    __shared__ int32_t st_p[ROWS_STAGE];
+    __shared__ int32_t st_b[ROWS_STAGE];
+    __shared__ int32_t l_row[PROBE_TILE], l_c[PROBE_TILE], l_s[PROBE_TILE], l_e[PROBE_TILE];
+    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS], row[PROBE_ITEMS];
+    load_items(pc, i0, n, vec_ok, -1, c);
+    load_items(ps, i0, n, vec_ok, 0, s);
+    load_items(pe, i0, n, vec_ok, 0, e);
+    if (probe_ids) load_items(probe_ids, i0, n, vec_ok, 0, row);
+    else {
+#pragma unroll
+        for (int k = 0; k < PROBE_ITEMS; ++k) row[k] = (int32_t)(i0 + k);
+    }
+    int32_t slot[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) {
+        slot[k] = threadIdx.x * PROBE_ITEMS + k;
+        l_row[slot[k]] = row[k]; l_c[slot[k]] = c[k]; l_s[slot[k]] = s[k]; l_e[slot[k]] = e[k];
+    }
+    int hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS];
+    bool valid[PROBE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) valid[k] = i0 + k < n;
+    probe_windows<STRICT>(ix, c, s, e, valid, hi, x, cnt);
+    long long tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PROBE_ITEMS; ++k) tsum += cnt[k];
+    long long tot;
+    const long long loc0 = block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);     // (its barriers publish the LDS tables)
+    if (threadIdx.x == 0) {
+        const long long base = tot ? (long long)atomicAdd(&state[0], (unsigned long long)tot) : 0ll;
+        if (base + tot > capacity) { atomicExch(&state[1], 1ull); s_base = -1; }
+        else s_base = base;
+    }
+    __syncthreads();
+    const long long tbase = s_base;
+    if (tbase < 0 || tot == 0) return;                     // uniform
+    emit_tile_rows<STRICT, PROBE_THREADS, ROWS_STAGE>(ix, PositionRow{}, RowsOut{cols, ix.rec4, l_row, l_c, l_s, l_e}, hi, x, cnt, slot, s, loc0,
+                                                       tot, tbase, st_p, st_b);
 }
 
 // Pass 2 for dense results (many pairs per probe).  Same tiles, same output layout as

@@ -7,3 +7,4 @@
 #include "count_nearest.hip.h"
 #include "partition.hip.h"
 #include "flat.hip.h"
+#include "materialize.hip.h"

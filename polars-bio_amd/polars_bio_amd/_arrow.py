@@ -85,8 +85,9 @@ def _as_string(col: pa.ChunkedArray) -> pa.ChunkedArray:
     return pc.cast(col, pa.large_string())
 
 
-def encode_keys(t1: pa.Table, cols1, t2: pa.Table, cols2) -> Tuple[tuple, tuple, int]:
-    """-> ((contig1,start1,end1), (contig2,start2,end2), n_contigs) as int32 numpy arrays.
+def encode_keys(t1: pa.Table, cols1, t2: pa.Table, cols2, with_dictionary: bool = False):
+    """-> ((contig1,start1,end1), (contig2,start2,end2), n_contigs) as int32 numpy arrays
+    (+ the shared chrom dictionary, a large_string array, with ``with_dictionary``).
 
     Join key = exact string equality of chrom (Appendix A of SURVEY.md); rows
     with a null chrom get id -1 and match nothing."""
@@ -109,6 +110,8 @@ def encode_keys(t1: pa.Table, cols1, t2: pa.Table, cols2) -> Tuple[tuple, tuple,
 
     side1 = (ids(ch1), _coord_to_i32(t1.column(cols1[1]), cols1[1]), _coord_to_i32(t1.column(cols1[2]), cols1[2]))
     side2 = (ids(ch2), _coord_to_i32(t2.column(cols2[1]), cols2[1]), _coord_to_i32(t2.column(cols2[2]), cols2[2]))
+    if with_dictionary:
+        return side1, side2, n_contigs, (u.combine_chunks() if isinstance(u, pa.ChunkedArray) else u)
     return side1, side2, n_contigs
 
 

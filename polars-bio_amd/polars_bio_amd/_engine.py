@@ -29,8 +29,11 @@ ABI_SYMBOLS = [
     "ivj_overlap", "ivj_pairs_free", "ivj_count_overlaps", "ivj_nearest",
     "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev", "ivj_overlap_fused_dev",
     "ivj_count_overlaps_dev", "ivj_nearest_dev",
+    "ivj_materialize_dev", "ivj_overlap_fused_rows_dev", "ivj_take_dev", "ivj_overlap_rows", "ivj_rows_free", "ivj_rows_export_arrow",
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
 ]
+
+ROW_COLUMNS = ("probe_idx", "build_idx", "contig", "start_1", "end_1", "start_2", "end_2")
 
 
 class EngineError(RuntimeError):
@@ -49,6 +52,23 @@ class _Opts(C.Structure):
 
 class _Pairs(C.Structure):
     _fields_ = [("n_pairs", C.c_int64), ("probe_idx", C.POINTER(C.c_int32)), ("build_idx", C.POINTER(C.c_int32))]
+
+
+class _Rows(C.Structure):
+    _fields_ = [("n_pairs", C.c_int64)] + [(name, C.POINTER(C.c_int32)) for name in
+                                            ("probe_idx", "build_idx", "contig", "start_1", "end_1", "start_2", "end_2")]
+
+
+class _ArrowSchema(C.Structure):     # Arrow C Data Interface, opaque to Python: only its address is handed on
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64),
+                ("n_children", C.c_int64), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p),
+                ("private_data", C.c_void_p)]
+
+
+class _ArrowArray(C.Structure):
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                ("n_children", C.c_int64), ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p),
+                ("release", C.c_void_p), ("private_data", C.c_void_p)]
 
 
 class _Timing(C.Structure):
@@ -95,6 +115,13 @@ def load_library() -> C.CDLL:
         L.ivj_overlap_fused_dev.argtypes = [vp, vp, P, O, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
         L.ivj_count_overlaps_dev.argtypes = [vp, vp, P, O, vp]
         L.ivj_nearest_dev.argtypes = [vp, vp, P, O, vp, vp, vp]
+        L.ivj_materialize_dev.argtypes = [vp, P, P, C.POINTER(_Rows)]
+        L.ivj_overlap_fused_rows_dev.argtypes = [vp, vp, P, O, C.POINTER(_Rows), C.POINTER(C.c_int64)]
+        L.ivj_take_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, vp, vp]
+        L.ivj_overlap_rows.argtypes = [vp, P, P, O, C.POINTER(_Rows)]
+        L.ivj_rows_free.argtypes = [C.POINTER(_Rows)]
+        L.ivj_rows_free.restype = None
+        L.ivj_rows_export_arrow.argtypes = [C.POINTER(_Rows), vp, vp]
         L.ivj_dev_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
         L.ivj_dev_free.argtypes = [vp, vp]
         L.ivj_memcpy_h2d.argtypes = [vp, vp, vp, C.c_int64]
@@ -201,6 +228,30 @@ class Engine:
             self.L.ivj_pairs_free(C.byref(out))
             del keep_p, keep_b
 
+    def overlap_rows(self, probe, build, strict: bool, n_contigs: int, partition_mode: int = 0, as_arrow: bool = False):
+        """overlap + row materialisation on the device (ivj_overlap_rows): the pair indices AND the key
+        columns of both sides for every pair.  -> dict of int32 numpy arrays keyed by ROW_COLUMNS, or
+        (as_arrow=True) a pyarrow.RecordBatch that owns the library's host buffers through the Arrow C
+        Data interface (ivj_rows_export_arrow; no copy)."""
+        ps, keep_p = _host_side(*probe)
+        bs, keep_b = _host_side(*build)
+        o = make_opts(strict, n_contigs, partition_mode=partition_mode)
+        out = _Rows()
+        _check(self.L, self.L.ivj_overlap_rows(self.h, C.byref(ps), C.byref(bs), C.byref(o), C.byref(out)), "ivj_overlap_rows")
+        del keep_p, keep_b
+        try:
+            if as_arrow:
+                import pyarrow as pa
+                arr, sch = _ArrowArray(), _ArrowSchema()
+                _check(self.L, self.L.ivj_rows_export_arrow(C.byref(out), C.addressof(arr), C.addressof(sch)),
+                       "ivj_rows_export_arrow")
+                return pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+            n = out.n_pairs
+            return {name: (np.ctypeslib.as_array(getattr(out, name), shape=(n,)).copy() if n else np.empty(0, np.int32))
+                    for name in ROW_COLUMNS}
+        finally:
+            self.L.ivj_rows_free(C.byref(out))
+
     def count_overlaps(self, probe, build, strict: bool, n_contigs: int, table_mode: int = 0) -> np.ndarray:
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
@@ -278,6 +329,36 @@ class Engine:
             return n.value, False
         _check(self.L, rc, "ivj_overlap_fused_dev")
         return n.value, True
+
+    def materialize_dev(self, probe: _Side, build: _Side, n_pairs: int, probe_idx_ptr: int, build_idx_ptr: int,
+                        contig_ptr: int = 0, start_1_ptr: int = 0, end_1_ptr: int = 0, start_2_ptr: int = 0, end_2_ptr: int = 0):
+        """ivj_materialize_dev: gather the key columns of both sides for every pair (device pointers;
+        0 skips a column)."""
+        r = _Rows()
+        r.n_pairs = int(n_pairs)
+        for name, ptr in zip(ROW_COLUMNS, (probe_idx_ptr, build_idx_ptr, contig_ptr, start_1_ptr, end_1_ptr, start_2_ptr, end_2_ptr)):
+            setattr(r, name, C.cast(C.c_void_p(ptr or None), C.POINTER(C.c_int32)))
+        _check(self.L, self.L.ivj_materialize_dev(self.h, C.byref(probe), C.byref(build), C.byref(r)), "ivj_materialize_dev")
+
+    def overlap_fused_rows_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, capacity: int, probe_idx_ptr: int = 0,
+                               build_idx_ptr: int = 0, contig_ptr: int = 0, start_1_ptr: int = 0, end_1_ptr: int = 0,
+                               start_2_ptr: int = 0, end_2_ptr: int = 0):
+        """ivj_overlap_fused_rows_dev: join + key-column materialisation in one pass.  -> (n_rows, fits)."""
+        r = _Rows()
+        r.n_pairs = int(capacity)
+        for name, ptr in zip(ROW_COLUMNS, (probe_idx_ptr, build_idx_ptr, contig_ptr, start_1_ptr, end_1_ptr, start_2_ptr, end_2_ptr)):
+            setattr(r, name, C.cast(C.c_void_p(ptr or None), C.POINTER(C.c_int32)))
+        n = C.c_int64(0)
+        rc = self.L.ivj_overlap_fused_rows_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), C.byref(r), C.byref(n))
+        if rc == -4:      # IVJ_ECAPACITY
+            return n.value, False
+        _check(self.L, rc, "ivj_overlap_fused_rows_dev")
+        return n.value, True
+
+    def take_dev(self, src_ptr: int, elem_bytes: int, idx_ptr: int, n: int, dst_ptr: int, validity_ptr: int = 0):
+        """ivj_take_dev: Arrow take of one 4- or 8-byte device column; negative indices -> 0 / null bit."""
+        _check(self.L, self.L.ivj_take_dev(self.h, C.c_void_p(src_ptr), int(elem_bytes), C.c_void_p(idx_ptr), int(n),
+                                            C.c_void_p(dst_ptr), C.c_void_p(validity_ptr or None)), "ivj_take_dev")
 
     def count_overlaps_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, counts_ptr: int):
         _check(self.L, self.L.ivj_count_overlaps_dev(self.h, ix.handle, C.byref(probe), C.byref(opts),

@@ -22,6 +22,9 @@ class Context:
             # engine options of this implementation
             "ivj.device": "0",
             "ivj.low_memory_batch_rows": "8000000",
+            # "host": result rows are gathered with Arrow take on the host from the index pairs;
+            # "device": the key columns of both sides are materialised in HBM (ivj_overlap_rows)
+            "ivj.materialize": "host",
         }
 
     def set_option(self, key, value):

@@ -79,6 +79,48 @@ class DeviceJoin:
                 ix.close()
         return out_p, out_b
 
+    def overlap_rows(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, out: dict, index=None,
+                     partition_mode: int = 0):
+        """Join + row materialisation in one pass (ivj_overlap_fused_rows_dev) into the preallocated int32
+        CUDA tensors of ``out`` (keys from _engine.ROW_COLUMNS; a missing key = column not wanted).
+        -> (dict of views of the first n_rows elements, n_rows, fits); fits=False: grow ``out`` to n_rows."""
+        opts = make_opts(strict, n_contigs, partition_mode=partition_mode)
+        own = index is None
+        ix = self.engine.index_build_dev(build.as_c(), opts, False) if own else index
+        try:
+            cap = min(int(t.numel()) for t in out.values())
+            ptrs = {f"{k}_ptr": t.data_ptr() for k, t in out.items()}
+            total, fits = self.engine.overlap_fused_rows_dev(ix, probe.as_c(), opts, cap, **ptrs)
+        finally:
+            if own:
+                ix.close()
+        return ({k: t[:total] for k, t in out.items()} if fits else {}), total, fits
+
+    def materialize(self, probe: DeviceSide, build: DeviceSide, probe_idx, build_idx, out=None):
+        """Row materialisation (ivj_materialize_dev): for every pair the key columns of both sides.
+        -> dict contig / start_1 / end_1 / start_2 / end_2 of int32 CUDA tensors (``out``: optional dict
+        of preallocated tensors of at least n_pairs elements)."""
+        torch = self.torch
+        n = int(probe_idx.shape[0])
+        names = ("contig", "start_1", "end_1", "start_2", "end_2")
+        cols = {k: (out[k][:n] if out is not None else torch.empty(n, dtype=torch.int32, device=probe.start.device)) for k in names}
+        self.engine.materialize_dev(probe.as_c(), build.as_c(), n, probe_idx.data_ptr(), build_idx.data_ptr(),
+                                    *(cols[k].data_ptr() for k in names))
+        return cols
+
+    def take(self, column, idx, with_validity: bool = False):
+        """Arrow take of one 4- or 8-byte CUDA column by int32 row indices (negative -> 0 / null).
+        -> values, or (values, validity bitmap as int64 words) with ``with_validity``."""
+        torch = self.torch
+        if column.element_size() not in (4, 8) or not column.is_contiguous():
+            raise ValueError("column must be a contiguous tensor of 4- or 8-byte elements")
+        n = int(idx.shape[0])
+        dst = torch.empty(n, dtype=column.dtype, device=column.device)
+        val = torch.zeros((n + 63) // 64, dtype=torch.int64, device=column.device) if with_validity else None
+        self.engine.take_dev(column.data_ptr(), column.element_size(), idx.data_ptr(), n, dst.data_ptr(),
+                             val.data_ptr() if val is not None else 0)
+        return (dst, val) if with_validity else dst
+
     def count_overlaps(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None):
         torch = self.torch
         opts = make_opts(strict, n_contigs)

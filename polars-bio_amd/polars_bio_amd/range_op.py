@@ -17,6 +17,7 @@ from typing import Literal, Union
 
 import numpy as np
 import pyarrow as pa
+import pyarrow.compute as pc
 
 from . import _arrow as A
 from ._engine import default_engine
@@ -66,6 +67,46 @@ def _low_memory_batch_rows() -> int:
         return max(1024, int(get_option("ivj.low_memory_batch_rows") or 8_000_000))
     except ValueError:
         return 8_000_000
+
+
+def _materialize_on_device() -> bool:
+    from .context import get_option
+    return str(get_option("ivj.materialize") or "host").lower() == "device"
+
+
+def _overlap_device_rows(t1, t2, cols1, cols2, suffixes, zero_based) -> pa.Table:
+    """Join-mode overlap whose key columns are materialised in HBM (ivj_overlap_rows, SURVEY.md
+    section 8f row 1) and arrive through the Arrow C Data interface; only the non-key columns are
+    gathered on the host.  Same output contract as the host path (src/operation.rs:272-301)."""
+    c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
+    c2 = list(DEFAULT_INTERVAL_COLUMNS if cols2 is None else cols2)
+    probe, build, n_contigs, dictionary = A.encode_keys(t1, c1, t2, c2, with_dictionary=True)
+    rows = default_engine().overlap_rows(probe, build, strict=zero_based, n_contigs=n_contigs, as_arrow=True)
+    p_idx, b_idx = rows.column("probe_idx"), rows.column("build_idx")
+    other1 = [n for n in t1.column_names if n not in c1]
+    other2 = [n for n in t2.column_names if n not in c2]
+    # non-key columns: host take; key columns: placeholders that are replaced below
+    left = t1.select(other1).take(p_idx) if other1 else None
+    right = t2.select(other2).take(b_idx) if other2 else None
+
+    def assemble(src, names_other, taken_other, cols, contig, start, end):
+        arrays = {}
+        for name in src.column_names:
+            typ = src.schema.field(name).type
+            if name == cols[0]:
+                val = pc.take(dictionary, contig)
+                arrays[name] = pc.cast(val, typ) if not pa.types.is_dictionary(typ) else pc.cast(pc.dictionary_encode(pc.cast(val, typ.value_type)), typ)
+            elif name == cols[1]:
+                arrays[name] = pc.cast(start, typ)
+            elif name == cols[2]:
+                arrays[name] = pc.cast(end, typ)
+            else:
+                arrays[name] = taken_other.column(name)
+        return pa.table(arrays)
+
+    res1 = assemble(t1, other1, left, c1, rows.column("contig"), rows.column("start_1"), rows.column("end_1"))
+    res2 = assemble(t2, other2, right, c2, rows.column("contig"), rows.column("start_2"), rows.column("end_2"))
+    return A.hconcat(A.with_suffix(res1, suffixes[0]), A.with_suffix(res2, suffixes[1]))
 
 
 def overlap_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, batch_rows: int = 8_000_000):
@@ -118,6 +159,8 @@ def overlap(
     mode = _parse_overlap_output_mode(overlap_output)
     logger.info("Optimizing into IntervalJoinExec using %s algorithm (executed by the HIP engine)", algorithm)
     t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    if mode == OverlapOutputMode.Join and not low_memory and _materialize_on_device():
+        return A.from_arrow(_overlap_device_rows(t1, t2, cols1, cols2, suffixes, zero_based), output_type, zero_based)
     if low_memory:
         # bounded device footprint and result batches: the probe side streams through the GPU in
         # tiles against the resident build index (reference: low_memory caps the output batch size)

@@ -60,6 +60,15 @@ class OracleEngine:
         b = O.Side(*build)
         return O.overlap_fast(O.Index(b, n_contigs), O.Side(*probe), strict)
 
+    def overlap_rows(self, probe, build, strict, n_contigs, partition_mode=0, as_arrow=False):
+        import numpy as np
+        import pyarrow as pa
+        p, b = self.overlap(probe, build, strict, n_contigs)
+        cols = {"probe_idx": p, "build_idx": b, "contig": probe[0][p], "start_1": probe[1][p], "end_1": probe[2][p],
+                "start_2": build[1][b], "end_2": build[2][b]}
+        cols = {k: np.ascontiguousarray(v, np.int32) for k, v in cols.items()}
+        return pa.record_batch(cols) if as_arrow else cols
+
     def overlap_batches(self, probe, build, strict, n_contigs, batch_rows=8_000_000):
         import numpy as np
         from oracle import oracle as O

@@ -223,3 +223,41 @@ def test_low_memory_and_streaming_batches(engine):
     assert len(batches) == 5 and all(isinstance(b, pa.Table) for b in batches)
     cat = pa.concat_tables(batches).to_pandas()
     pd.testing.assert_frame_equal(_sorted(cat), _sorted(full))
+
+
+def test_device_materialised_key_columns_equal_host_take(engine):
+    """ivj.materialize="device": key columns come from HBM (ivj_overlap_rows + Arrow C Data export),
+    the other columns from the host take -- same frame as the all-host assembly, same dtypes, also
+    for int64 coordinates, extra columns on both sides, a dictionary-typed chrom and the golden CSVs."""
+    rng = np.random.default_rng(5)
+    n1, n2 = 4000, 700
+    df1 = pd.DataFrame({"chrom": rng.choice(["chr1", "chr2", "chrX"], n1), "start": rng.integers(0, 100000, n1).astype(np.int64)})
+    df1["end"] = df1["start"] + rng.integers(1, 300, n1)
+    df1["tag"] = np.arange(n1)
+    df1["score"] = rng.random(n1)
+    df2 = pd.DataFrame({"chrom": pd.Categorical(rng.choice(["chr1", "chr2", "chr7"], n2)), "start": rng.integers(0, 100000, n2).astype(np.int32)})
+    df2["end"] = (df2["start"] + rng.integers(1, 3000, n2)).astype(np.int32)
+    df2["gene"] = [f"g{i}" for i in range(n2)]
+    for d in (df1, df2):
+        d.attrs["coordinate_system_zero_based"] = True
+    host = pb.overlap(df1, df2, suffixes=("_x", "_y"), output_type="pandas.DataFrame")
+    gold_host = pb.overlap(_csv(f"{GOLDEN}/overlap/reads.csv"), _csv(f"{GOLDEN}/overlap/targets.csv"),
+                           cols1=COLS, cols2=COLS, output_type="pandas.DataFrame")
+    pb.set_option("ivj.materialize", "device")
+    try:
+        dev = pb.overlap(df1, df2, suffixes=("_x", "_y"), output_type="pandas.DataFrame")
+        gold_dev = pb.overlap(_csv(f"{GOLDEN}/overlap/reads.csv"), _csv(f"{GOLDEN}/overlap/targets.csv"),
+                              cols1=COLS, cols2=COLS, output_type="pandas.DataFrame")
+        left = pb.overlap(df1, df2, overlap_output="left", output_type="pandas.DataFrame")    # not a join: host path
+    finally:
+        pb.set_option("ivj.materialize", "host")
+    assert list(dev.columns) == list(host.columns) and len(dev) == len(host) > 100
+    assert dev["start_x"].dtype == np.int64 and dev["start_y"].dtype == np.int32
+    key = ["tag_x", "gene_y"]
+    a = dev.sort_values(key).reset_index(drop=True)
+    b = host.sort_values(key).reset_index(drop=True)
+    for col in host.columns:
+        assert (a[col].astype(str) == b[col].astype(str)).all(), col
+    pd.testing.assert_frame_equal(_sorted(gold_dev), _sorted(pd.read_csv(f"{GOLDEN}/expected_overlap.csv")))
+    pd.testing.assert_frame_equal(_sorted(gold_dev), _sorted(gold_host))
+    assert len(left) == len(host)

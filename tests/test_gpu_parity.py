@@ -368,3 +368,125 @@ def test_torch_device_api_matches_oracle():
     i, d, n = join.nearest(dp, db, False, 24, k=3, include_overlaps=False)
     ei, ed, en = O.nearest_fast(ix, ps, False, 3, False)
     assert (i.cpu().numpy() == ei).all() and (d.cpu().numpy() == ed).all() and (n.cpu().numpy() == en).all()
+
+
+# ---- row materialisation on the device --------------------------------
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_overlap_rows_equals_host_take(eng, strict):
+    """ivj_overlap_rows: the five key columns gathered in HBM == numpy take of the oracle's pairs
+    (the reference's joined rows, src/operation.rs:272-301, restricted to the key columns)."""
+    rng = np.random.default_rng(11)
+    probe = random_side(rng, 40_000, 5, 200_000, 300)
+    build = random_side(rng, 9_000, 5, 200_000, 3000)
+    ep, eb = O.overlap_fast(O.Index(O.Side(*build), 5), O.Side(*probe), strict)
+    rows = eng.overlap_rows(probe, build, strict, 5, partition_mode=2)        # probe-row order: exact sequence
+    assert (rows["probe_idx"] == ep).all() and (rows["build_idx"] == eb).all()
+    assert (rows["contig"] == probe[0][ep]).all() and (rows["contig"] == build[0][eb]).all()
+    assert (rows["start_1"] == probe[1][ep]).all() and (rows["end_1"] == probe[2][ep]).all()
+    assert (rows["start_2"] == build[1][eb]).all() and (rows["end_2"] == build[2][eb]).all()
+    rows = eng.overlap_rows(probe, build, strict, 5, partition_mode=1)        # bucketed order: same multiset of rows
+    o = np.lexsort((rows["build_idx"], rows["probe_idx"]))
+    eo = np.lexsort((eb, ep))
+    for name, exp in (("probe_idx", ep), ("build_idx", eb), ("start_1", probe[1][ep]), ("end_2", build[2][eb])):
+        assert (rows[name][o] == exp[eo]).all(), name
+    empty = eng.overlap_rows((probe[0][:0], probe[1][:0], probe[2][:0]), build, strict, 5)
+    assert all(len(v) == 0 for v in empty.values())
+
+
+def test_overlap_rows_arrow_c_data_export(eng):
+    """ivj_rows_export_arrow: pyarrow imports the struct array without a copy and owns the buffers."""
+    import pyarrow as pa
+    probe = synth.make_side(60_000, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(20_000, 43, synth.DENSE_BUILD_LEN, 24)
+    ref = eng.overlap_rows(probe, build, True, 24, partition_mode=2)
+    batch = eng.overlap_rows(probe, build, True, 24, partition_mode=2, as_arrow=True)
+    assert isinstance(batch, pa.RecordBatch) and batch.schema.names == list(_engine.ROW_COLUMNS)
+    assert batch.num_rows == len(ref["probe_idx"]) > 1000
+    for name in _engine.ROW_COLUMNS:
+        col = batch.column(name)
+        assert col.type == pa.int32() and col.null_count == 0
+        assert (col.to_numpy() == ref[name]).all(), name
+    tbl = pa.Table.from_batches([batch])
+    del batch
+    assert tbl.column("end_2").to_numpy()[-1] == ref["end_2"][-1]              # buffers outlive the batch object
+    empty = eng.overlap_rows((probe[0][:0], probe[1][:0], probe[2][:0]), build, True, 24, as_arrow=True)
+    assert empty.num_rows == 0 and empty.schema.names == list(_engine.ROW_COLUMNS)
+
+
+def test_materialize_and_take_dev():
+    """ivj_materialize_dev with skipped columns and ivj_take_dev (4- and 8-byte values, null slots) on
+    torch tensors: what a device-resident consumer calls after the join."""
+    import torch
+    from polars_bio_amd.device_api import DeviceJoin, DeviceSide
+    dev = torch.device("cuda", 0)
+    probe = synth.make_side(90_001, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(25_003, 43, synth.DENSE_BUILD_LEN, 24)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dp, db = DeviceSide(*map(up, probe)), DeviceSide(*map(up, build))
+    join = DeviceJoin(0)
+    p, b = join.overlap(dp, db, True, 24)
+    cols = join.materialize(dp, db, p, b)
+    hp, hb = p.cpu().numpy(), b.cpu().numpy()
+    assert len(hp) > 1000
+    assert (cols["contig"].cpu().numpy() == probe[0][hp]).all()
+    assert (cols["start_1"].cpu().numpy() == probe[1][hp]).all() and (cols["end_1"].cpu().numpy() == probe[2][hp]).all()
+    assert (cols["start_2"].cpu().numpy() == build[1][hb]).all() and (cols["end_2"].cpu().numpy() == build[2][hb]).all()
+    # only one column wanted, odd length (no 16-byte tail)
+    n = len(hp) - 3
+    only = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    join.engine.materialize_dev(dp.as_c(), db.as_c(), n, p.data_ptr(), b.data_ptr(), end_2_ptr=only.data_ptr())
+    assert (only.cpu().numpy() == build[2][hb[:n]]).all()
+    # take: nearest's idx column has -1 slots -> nulls
+    idx, dist, nf = join.nearest(dp, db, True, 24, k=2, include_overlaps=False)
+    flat = idx.reshape(-1).contiguous()
+    hflat = flat.cpu().numpy()
+    payload64 = torch.arange(db.n, dtype=torch.int64, device=dev) * 3 + 1
+    v64, bits = join.take(payload64, flat, with_validity=True)
+    exp = np.where(hflat >= 0, hflat.astype(np.int64) * 3 + 1, 0)
+    assert (v64.cpu().numpy() == exp).all()
+    hb_bits = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")[:len(hflat)]
+    assert (hb_bits.astype(bool) == (hflat >= 0)).all()
+    v32 = join.take(db.end, flat)
+    assert (v32.cpu().numpy() == np.where(hflat >= 0, build[2][np.maximum(hflat, 0)], 0)).all()
+
+
+def test_fused_rows_join_and_materialise_in_one_pass():
+    """ivj_overlap_fused_rows_dev == the pair list of the oracle with the key columns taken on the host;
+    global row ids (contig shard), skipped columns, Weak, unpartitioned / two-level, too-small capacity."""
+    import torch
+    from polars_bio_amd.device_api import DeviceJoin, DeviceSide
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    join = DeviceJoin(0)
+    for (npr, nb, nc, strict, pm, blen) in ((300_001, 50_003, 24, True, 1, synth.BUILD_LEN), (120_000, 30_000, 24, False, 2, synth.DENSE_BUILD_LEN),
+                                            (5000, 700, 3, True, 4, synth.DENSE_BUILD_LEN), (777_777, 1_300_000, 24, True, 0, synth.BUILD_LEN)):
+        probe = synth.make_side(npr, 42, synth.PROBE_LEN, nc)
+        build = synth.make_side(nb, 43, blen, nc)
+        ep, eb = O.overlap_fast(O.Index(O.Side(*build), nc), O.Side(*probe), strict)
+        total = len(ep)
+        assert total > 100
+        # global row ids as a contig shard would carry them
+        pid = (np.arange(npr, dtype=np.int32) * 2 + 7)
+        bid = (np.arange(nb, dtype=np.int32) * 3 + 1)
+        dp = DeviceSide(*map(up, probe), row_id=up(pid))
+        db = DeviceSide(*map(up, build), row_id=up(bid))
+        out = {k: torch.empty(total, dtype=torch.int32, device=dev) for k in _engine.ROW_COLUMNS}
+        small = {k: torch.empty(max(total // 2, 1), dtype=torch.int32, device=dev) for k in _engine.ROW_COLUMNS}
+        _, n_small, fits = join.overlap_rows(dp, db, strict, nc, small, partition_mode=pm)
+        assert not fits and n_small == total
+        cols, n_rows, fits = join.overlap_rows(dp, db, strict, nc, out, partition_mode=pm)
+        assert fits and n_rows == total
+        h = {k: v.cpu().numpy() for k, v in cols.items()}
+        assert int((np.diff(h["probe_idx"]) != 0).sum()) + 1 == len(np.unique(h["probe_idx"]))      # rows of a probe contiguous
+        o = np.argsort(h["probe_idx"], kind="stable")
+        assert (h["probe_idx"][o] == pid[ep]).all() and (h["build_idx"][o] == bid[eb]).all()
+        assert (h["contig"][o] == probe[0][ep]).all()
+        assert (h["start_1"][o] == probe[1][ep]).all() and (h["end_1"][o] == probe[2][ep]).all()
+        assert (h["start_2"][o] == build[1][eb]).all() and (h["end_2"][o] == build[2][eb]).all()
+        # only two columns wanted
+        two = {k: torch.full((total,), -9, dtype=torch.int32, device=dev) for k in ("probe_idx", "end_2")}
+        cols2, n2, fits2 = join.overlap_rows(dp, db, strict, nc, two, partition_mode=pm)
+        assert fits2 and n2 == total
+        o2 = np.argsort(cols2["probe_idx"].cpu().numpy(), kind="stable")
+        assert (cols2["end_2"].cpu().numpy()[o2] == build[2][eb]).all()
