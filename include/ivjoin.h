@@ -228,6 +228,39 @@ void ivj_rows_free(ivj_rows* rows);
  * pyarrow.RecordBatch._import_from_c takes it from there. */
 int ivj_rows_export_arrow(ivj_rows* rows, void* out_array, void* out_schema);
 
+/* ---- sort-scan family: merge / cluster / coverage ---------------- *
+ * One sweep over the (contig, start)-sorted index with its prefix max of the ends: a row joins the  *
+ * running cluster iff start (<) max end so far + min_dist, (<) = "<" Strict / "<=" Weak.             *
+ * Replaces MergeProvider / ClusterProvider / CountOverlapsProvider(coverage = true)               *
+ * (src/operation.rs:352-418, 306-350).  min_dist = 0 does not merge bookended half-open intervals   *
+ * (tests/_expected.py:174-181).                                                                   */
+
+/* pb.merge result on the host path: library-owned buffers in (contig id, start) order. */
+typedef struct {
+    int64_t n;
+    int32_t* contig;        /* contig id; -1 for the pseudo-contig of rows outside the dictionary */
+    int32_t* start;
+    int32_t* end;
+    int64_t* n_intervals;   /* rows merged into the interval */
+} ivj_merged;
+
+int ivj_merge(ivj_ctx* ctx, const ivj_side* frame, const ivj_opts* opts, int64_t min_dist, ivj_merged* out);
+void ivj_merged_free(ivj_merged* m);
+/* pb.cluster: per input row the cluster id (clusters numbered in (contig id, start) order) and the
+ * cluster's bounds; caller buffers of frame->n. */
+int ivj_cluster(ivj_ctx* ctx, const ivj_side* frame, const ivj_opts* opts, int64_t min_dist, int64_t* cluster,
+                int32_t* cluster_start, int32_t* cluster_end, int64_t* n_clusters);
+/* pb.coverage: for every probe row the number of its positions covered by the union of the build
+ * intervals of the same contig (Int64, probe order kept; [s, e) Strict, [s, e] Weak). */
+int ivj_coverage(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int64_t* coverage);
+
+/* device-resident forms: the index of the frame / build side is built with ivj_index_build_dev */
+int ivj_cluster_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min_dist, int64_t* cluster_dev,
+                    int32_t* cluster_start_dev, int32_t* cluster_end_dev, int64_t* n_clusters);
+int ivj_merge_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min_dist, int64_t capacity,
+                  int32_t* contig_dev, int32_t* start_dev, int32_t* end_dev, int64_t* n_intervals_dev, int64_t* n_merged);
+int ivj_coverage_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* coverage_dev);
+
 /* ---- device memory helpers for callers without a HIP binding ------------ */
 int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out);
 int ivj_dev_free(ivj_ctx* ctx, void* p);

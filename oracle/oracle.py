@@ -232,3 +232,173 @@ def encode_contigs(*cols):
             ids[i] = table.setdefault(v, len(table))
         outs.append(ids)
     return outs, len(table)
+
+
+# ---------------------------------------------------------------------------------------------
+# Sort-scan operations: merge / cluster / coverage / complement /
+# subtract.  The arithmetic lives in the un-vendored crate behind MergeProvider / ClusterProvider /
+# CountOverlapsProvider(coverage=true) / ComplementProvider / SubtractProvider
+# (/root/reference/src/operation.rs:352-510, 306-350); what is restated here is the behaviour the
+# reference's own tests pin:
+#   merge ...... tests/_expected.py:174-181 (0-based: bookended intervals are NOT merged at
+#                min_dist=0, i.e. pb.merge(min_dist=0) == bioframe.merge(min_dist=None),
+#                tests/test_bioframe.py:120-124) and EXPECTED_MERGE of
+#                tests/test_partitioned_range_operation_regressions.py:24-31
+#   cluster .... EXPECTED_CLUSTER (:49-59); ids count clusters in (chrom, start) order
+#                (tests/test_bioframe.py:398-419 compares the id column with bioframe's)
+#   complement . EXPECTED_COMPLEMENT (:33-39), subtract: EXPECTED_SUBTRACT (:41-47)
+#   coverage ... bases of every df1 interval covered by the union of df2 (tests/test_bioframe.py:302-340)
+# PARITY UNPINNED in the reference (no test fixes it; the choices below follow the Strict/Weak
+# definition of range_op.py:75-84): min_dist > 0, every one of these operations under Weak
+# (1-based closed) coordinates, rows with start > end, rows with a null chrom.
+# Rule used throughout: a Weak (closed) interval [s, e] is the half-open interval [s, e + 1).
+
+def _half_open_end(end: np.ndarray, strict: bool) -> np.ndarray:
+    return end.astype(np.int64) + (0 if strict else 1)
+
+
+def np_cluster(side: Side, strict: bool, min_dist: int = 0):
+    """-> (cluster id per input row, cluster_start, cluster_end per input row, merged table
+    (contig, start, end, n_intervals) in (contig id, start) order).  A row joins the running
+    cluster iff start (<) running max end + min_dist, (<) being < for Strict and <= for Weak."""
+    c, s, e = side.contig, side.start, side.end
+    n = len(c)
+    order = np.lexsort((np.arange(n), s, c))
+    cid = np.empty(n, np.int64)
+    cs = np.empty(n, np.int64)
+    ce = np.empty(n, np.int64)
+    m_c, m_s, m_e, m_n = [], [], [], []
+    cur = -1
+    cur_c = None
+    cur_end = 0
+    first = 0
+    members = []
+    for p in order:
+        new = cur_c is None or c[p] != cur_c or not ((int(s[p]) < cur_end + min_dist) if strict else (int(s[p]) <= cur_end + min_dist))
+        if new:
+            if members:
+                for r in members:
+                    cid[r], cs[r], ce[r] = cur, first, cur_end
+                m_c.append(cur_c); m_s.append(first); m_e.append(cur_end); m_n.append(len(members))
+            cur += 1
+            cur_c, first, cur_end, members = c[p], int(s[p]), int(e[p]), []
+        cur_end = max(cur_end, int(e[p]))
+        members.append(p)
+    if members:
+        for r in members:
+            cid[r], cs[r], ce[r] = cur, first, cur_end
+        m_c.append(cur_c); m_s.append(first); m_e.append(cur_end); m_n.append(len(members))
+    merged = (np.array(m_c, np.int32), np.array(m_s, np.int64), np.array(m_e, np.int64), np.array(m_n, np.int64))
+    return cid, cs, ce, merged
+
+
+def np_coverage_brute(probe: Side, build: Side, strict: bool) -> np.ndarray:
+    """Definition: for every probe row the number of integer positions of the probe interval that lie in
+    at least one build interval of the same contig (positions of [s, e) for Strict, of [s, e] for Weak).
+    O(Np * Nb) interval clipping + a union by sorting: small inputs only."""
+    out = np.zeros(len(probe.contig), np.int64)
+    be_all = _half_open_end(build.end, strict)
+    for i in range(len(probe.contig)):
+        qs, qe = int(probe.start[i]), int(probe.end[i]) + (0 if strict else 1)
+        sel = build.contig == probe.contig[i]
+        if probe.contig[i] < 0 or not sel.any() or qe <= qs:
+            continue
+        lo = np.maximum(build.start[sel].astype(np.int64), qs)
+        hi = np.minimum(be_all[sel], qe)
+        keep = hi > lo
+        if not keep.any():
+            continue
+        lo, hi = lo[keep], hi[keep]
+        o = np.argsort(lo, kind="stable")
+        lo, hi = lo[o], hi[o]
+        run = np.maximum.accumulate(hi)
+        prev = np.concatenate([[lo[0]], run[:-1]])
+        out[i] = int(np.maximum(hi - np.maximum(lo, prev), 0).sum())
+    return out
+
+
+def np_coverage_fast(probe: Side, build: Side, strict: bool) -> np.ndarray:
+    """Same result through merged (disjoint) build intervals + prefix sums of their lengths."""
+    mc, ms, me, _ = _merged_half_open(build, strict)
+    out = np.zeros(len(probe.contig), np.int64)
+    for c in np.unique(mc):
+        sel = mc == c
+        s_, e_ = ms[sel], me[sel]
+        ln = np.maximum(e_ - s_, 0)
+        pl = np.concatenate([[0], np.cumsum(ln)])
+        rows = np.nonzero(probe.contig == c)[0]
+        qs = probe.start[rows].astype(np.int64)
+        qe = _half_open_end(probe.end[rows], strict)
+        first = np.searchsorted(e_, qs, side="right")        # first merged interval with end > qs
+        last = np.searchsorted(s_, qe, side="left")          # first merged interval with start >= qe
+        ok = (last > first) & (qe > qs)
+        f = np.minimum(first, len(s_) - 1)
+        l = np.maximum(last - 1, 0)
+        full = pl[np.maximum(last, first)] - pl[first]
+        clip_l = np.maximum(qs - s_[f], 0)
+        clip_r = np.maximum(e_[l] - qe, 0)
+        # clipping never removes more than the end intervals hold
+        cov = full - np.minimum(clip_l, ln[f]) - np.minimum(clip_r, ln[l])
+        single = ok & (f == l)
+        cov = np.where(single, np.maximum(np.minimum(e_[f], qe) - np.maximum(s_[f], qs), 0), cov)
+        out[rows] = np.where(ok, np.maximum(cov, 0), 0)
+    return out
+
+
+def _merged_half_open(build: Side, strict: bool):
+    """Disjoint union of the build intervals as half-open (contig, start, end) arrays, (contig, start) order."""
+    c, s = build.contig, build.start.astype(np.int64)
+    e = _half_open_end(build.end, strict)
+    keep = c >= 0
+    c, s, e = c[keep], s[keep], e[keep]
+    order = np.lexsort((s, c))
+    c, s, e = c[order], s[order], e[order]
+    mc, ms, me = [], [], []
+    for i in range(len(c)):
+        if mc and mc[-1] == c[i] and s[i] < me[-1]:
+            me[-1] = max(me[-1], int(e[i]))
+        else:
+            mc.append(c[i]); ms.append(int(s[i])); me.append(int(e[i]))
+    return np.array(mc, np.int32), np.array(ms, np.int64), np.array(me, np.int64), None
+
+
+def np_complement(side: Side, view: Side, strict: bool):
+    """Gaps of the union of ``side`` inside every view interval -> (contig, start, end), in view order then by
+    position.  Weak (closed) coordinates: the gap between [a, b] and [c, d] is [b + 1, c - 1]."""
+    mc, ms, me, _ = _merged_half_open(side, strict)
+    out = []
+    for i in range(len(view.contig)):
+        vc, vs, ve = view.contig[i], int(view.start[i]), int(view.end[i]) + (0 if strict else 1)
+        cur = vs
+        sel = mc == vc
+        for s_, e_ in zip(ms[sel], me[sel]):
+            if e_ <= vs or s_ >= ve:
+                continue
+            if s_ > cur:
+                out.append((vc, cur, int(s_)))
+            cur = max(cur, int(e_))
+        if cur < ve:
+            out.append((vc, cur, ve))
+    arr = np.array(out, np.int64).reshape(-1, 3)
+    return arr[:, 0].astype(np.int32), arr[:, 1], arr[:, 2] - (0 if strict else 1)
+
+
+def np_subtract(left: Side, right: Side, strict: bool):
+    """Every left interval minus the union of the right intervals of its contig -> (left row, start, end) pieces,
+    left-row order then by position (a fully covered left row yields nothing)."""
+    mc, ms, me, _ = _merged_half_open(right, strict)
+    out = []
+    for i in range(len(left.contig)):
+        ls, le = int(left.start[i]), int(left.end[i]) + (0 if strict else 1)
+        cur = ls
+        sel = mc == left.contig[i]
+        for s_, e_ in zip(ms[sel], me[sel]):
+            if e_ <= ls or s_ >= le:
+                continue
+            if s_ > cur:
+                out.append((i, cur, int(s_)))
+            cur = max(cur, int(e_))
+        if cur < le:
+            out.append((i, cur, le))
+    arr = np.array(out, np.int64).reshape(-1, 3)
+    return arr[:, 0].astype(np.int32), arr[:, 1], arr[:, 2] - (0 if strict else 1)

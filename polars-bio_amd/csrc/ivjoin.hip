@@ -716,6 +716,62 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     return IVJ_OK;
 }
 
+// ---- sort-scan family (sortscan.hip.h) ------------------------------------------------------------
+struct Clusters {                 // arena-backed (valid until the next arena_reserve on this context)
+    int64_t n = 0;                // number of clusters
+    uint32_t* cid1 = nullptr;     // per sorted position: 1-based cluster id
+    int32_t *m_contig = nullptr, *m_start = nullptr, *m_end = nullptr, *m_first = nullptr;
+};
+
+int cluster_core(ivj_ctx* ctx, ivj_index* ix, bool strict, long long min_dist, size_t extra_bytes, Clusters& cl) {
+    const int64_t n = ix->n;
+    cl = Clusters();
+    if (n == 0) return IVJ_OK;
+    const size_t col = align_up((size_t)(n + 1) * 4);
+    IVJ_TRY(arena_reserve(ctx, 6 * col + align_up((size_t)(scan_num_tiles(n) + 1) * 4) + extra_bytes + 4096));
+    uint32_t* flags = arena_take<uint32_t>(ctx, n + 1);
+    cl.cid1 = arena_take<uint32_t>(ctx, n + 1);
+    cl.m_contig = arena_take<int32_t>(ctx, n + 1);
+    cl.m_start = arena_take<int32_t>(ctx, n + 1);
+    cl.m_end = arena_take<int32_t>(ctx, n + 1);
+    cl.m_first = arena_take<int32_t>(ctx, n + 1);
+    uint32_t* partials = arena_take<uint32_t>(ctx, scan_num_tiles(n) + 1);
+    if (strict) LAUNCH(ctx, "cluster_flags", (k_cluster_flags<true>), grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int2*)ix->ep, (const int32_t*)ix->b_contig, n, min_dist, flags);
+    else LAUNCH(ctx, "cluster_flags", (k_cluster_flags<false>), grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int2*)ix->ep, (const int32_t*)ix->b_contig, n, min_dist, flags);
+    device_scan<uint32_t, SumOp, true>(ctx, "cluster_scan", flags, cl.cid1, n, 0u, partials, (uint32_t*)nullptr);
+    LAUNCH(ctx, "cluster_bounds", k_cluster_bounds, grid1d(n, 256), 256, (const uint32_t*)flags, (const uint32_t*)cl.cid1, (const int32_t*)ix->b_start,
+           (const int2*)ix->ep, (const int32_t*)ix->b_contig, n, ix->n_contigs, cl.m_contig, cl.m_start, cl.m_end, cl.m_first);
+    uint32_t last = 0;
+    HIP_TRY(hipMemcpyAsync(&last, cl.cid1 + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    cl.n = (int64_t)last;
+    return IVJ_OK;
+}
+
+int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* cov) {
+    const int64_t n = probe->n;
+    if (n == 0) return IVJ_OK;
+    if (ix->n == 0) { HIP_TRY(hipMemsetAsync(cov, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    Clusters cl;
+    const size_t extra = 2 * align_up((size_t)(ix->n + 2) * 8) + align_up((size_t)(scan_num_tiles(ix->n + 1) + 1) * 8);
+    IVJ_TRY(cluster_core(ctx, ix, strict, 0, extra, cl));
+    long long* len = arena_take<long long>(ctx, ix->n + 2);
+    long long* pl = arena_take<long long>(ctx, ix->n + 2);
+    long long* partials = arena_take<long long>(ctx, scan_num_tiles(ix->n + 1) + 1);
+    if (strict) LAUNCH(ctx, "merged_lengths", (k_merged_lengths<true>), grid1d(cl.n, 256), 256, (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, cl.n, len);
+    else LAUNCH(ctx, "merged_lengths", (k_merged_lengths<false>), grid1d(cl.n, 256), 256, (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, cl.n, len);
+    HIP_TRY(hipMemsetAsync(len + cl.n, 0, 8, ctx->stream));      // one padding element: pl[n_clusters] = total
+    device_scan<long long, SumOp, false>(ctx, "merged_scan", len, pl, cl.n + 1, 0ll, partials, (long long*)nullptr);
+    if (strict) LAUNCH(ctx, "coverage", (k_coverage<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, (const int32_t*)ix->seg, (const uint32_t*)cl.cid1,
+                       (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, ix->n_contigs, probe->contig, probe->start, probe->end, n, (long long*)cov);
+    else LAUNCH(ctx, "coverage", (k_coverage<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, (const int32_t*)ix->seg, (const uint32_t*)cl.cid1,
+                (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, ix->n_contigs, probe->contig, probe->start, probe->end, n, (long long*)cov);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
 // fused join + key-column materialisation (k_overlap_fused_rows); same partitioning as overlap_fused
 int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const ivj_rows* rows, int64_t* n_pairs) {
     const int64_t n = probe->n;
@@ -1028,6 +1084,144 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     HIP_TRY(hipMemcpyAsync(out->build_idx, ob.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     out->n_pairs = total;
+    return IVJ_OK;
+}
+
+// ---------------------------------------------------------------- merge / cluster / coverage
+
+int ivj_cluster_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min_dist, int64_t* cluster_dev, int32_t* cluster_start_dev,
+                    int32_t* cluster_end_dev, int64_t* n_clusters) {
+    if (!ctx || !ix || !n_clusters) return fail(IVJ_EINVAL, "ctx, index or n_clusters is NULL");
+    IVJ_TRY(check_opts(opts));
+    if (min_dist < 0) return fail(IVJ_EINVAL, "min_dist < 0");
+    if (ix->n > 0 && (!cluster_dev || !cluster_start_dev || !cluster_end_dev)) return fail(IVJ_EINVAL, "cluster output buffers are NULL");
+    DeviceGuard g(ctx->device);
+    Clusters cl;
+    IVJ_TRY(cluster_core(ctx, ix, opts->filter_op == IVJ_FILTER_STRICT, (long long)min_dist, 0, cl));
+    *n_clusters = cl.n;
+    if (ix->n == 0) return IVJ_OK;
+    LAUNCH(ctx, "cluster_scatter", k_cluster_scatter, grid1d(ix->n, 256), 256, (const int32_t*)ix->b_row, (const uint32_t*)cl.cid1, (const int32_t*)cl.m_start,
+           (const int32_t*)cl.m_end, ix->n, (long long*)cluster_dev, cluster_start_dev, cluster_end_dev);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+int ivj_merge_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min_dist, int64_t capacity, int32_t* contig_dev, int32_t* start_dev,
+                  int32_t* end_dev, int64_t* n_intervals_dev, int64_t* n_merged) {
+    if (!ctx || !ix || !n_merged) return fail(IVJ_EINVAL, "ctx, index or n_merged is NULL");
+    IVJ_TRY(check_opts(opts));
+    if (min_dist < 0 || capacity < 0) return fail(IVJ_EINVAL, "min_dist or capacity < 0");
+    DeviceGuard g(ctx->device);
+    Clusters cl;
+    IVJ_TRY(cluster_core(ctx, ix, opts->filter_op == IVJ_FILTER_STRICT, (long long)min_dist, 0, cl));
+    *n_merged = cl.n;
+    if (cl.n == 0) return IVJ_OK;
+    if (cl.n > capacity) return fail(IVJ_ECAPACITY, "merge output capacity " + std::to_string(capacity) + " < " + std::to_string(cl.n) + " intervals");
+    if (!contig_dev || !start_dev || !end_dev || !n_intervals_dev) return fail(IVJ_EINVAL, "merge output buffers are NULL");
+    HIP_TRY(hipMemcpyAsync(contig_dev, cl.m_contig, (size_t)cl.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(start_dev, cl.m_start, (size_t)cl.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(end_dev, cl.m_end, (size_t)cl.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    LAUNCH(ctx, "cluster_counts", k_cluster_counts, grid1d(cl.n, 256), 256, (const int32_t*)cl.m_first, cl.n, (long long*)n_intervals_dev);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+int ivj_coverage_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* coverage_dev) {
+    if (!ctx || !ix) return fail(IVJ_EINVAL, "ctx or index is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    if (probe_dev->n > 0 && !coverage_dev) return fail(IVJ_EINVAL, "coverage is NULL");
+    DeviceGuard g(ctx->device);
+    return coverage_core(ctx, ix, probe_dev, opts, coverage_dev);
+}
+
+void ivj_merged_free(ivj_merged* m) {
+    if (!m) return;
+    std::free(m->contig); std::free(m->start); std::free(m->end); std::free(m->n_intervals);
+    m->contig = m->start = m->end = nullptr; m->n_intervals = nullptr; m->n = 0;
+}
+
+int ivj_merge(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_t min_dist, ivj_merged* out) {
+    if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
+    std::memset(out, 0, sizeof(*out));
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(side, "frame"));
+    if (min_dist < 0) return fail(IVJ_EINVAL, "min_dist < 0");
+    if (side->n == 0) return IVJ_OK;
+    DeviceGuard g(ctx->device);
+    DevSide ds;
+    IVJ_TRY(upload_side(ctx, side, ds));
+    IndexHolder h;
+    IVJ_TRY(index_build(ctx, &ds.s, opts, 0, &h.ix));
+    Clusters cl;
+    IVJ_TRY(cluster_core(ctx, h.ix, opts->filter_op == IVJ_FILTER_STRICT, (long long)min_dist, align_up((size_t)(side->n + 1) * 8), cl));
+    long long* cnt = arena_take<long long>(ctx, side->n + 1);
+    LAUNCH(ctx, "cluster_counts", k_cluster_counts, grid1d(cl.n, 256), 256, (const int32_t*)cl.m_first, cl.n, cnt);
+    out->contig = (int32_t*)std::malloc((size_t)cl.n * 4);
+    out->start = (int32_t*)std::malloc((size_t)cl.n * 4);
+    out->end = (int32_t*)std::malloc((size_t)cl.n * 4);
+    out->n_intervals = (int64_t*)std::malloc((size_t)cl.n * 8);
+    if (!out->contig || !out->start || !out->end || !out->n_intervals) { ivj_merged_free(out); return fail(IVJ_ENOMEM, "host malloc(merged)"); }
+    hipError_t e = hipMemcpyAsync(out->contig, cl.m_contig, (size_t)cl.n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out->start, cl.m_start, (size_t)cl.n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out->end, cl.m_end, (size_t)cl.n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out->n_intervals, cnt, (size_t)cl.n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ivj_merged_free(out); return fail(IVJ_EHIP, std::string("D2H(merged): ") + hipGetErrorString(e)); }
+    out->n = cl.n;
+    return IVJ_OK;
+}
+
+int ivj_cluster(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_t min_dist, int64_t* cluster, int32_t* cluster_start,
+                int32_t* cluster_end, int64_t* n_clusters) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(side, "frame"));
+    if (side->row_id) return fail(IVJ_EINVAL, "ivj_cluster reports per input row: row_id must be NULL");
+    if (n_clusters) *n_clusters = 0;
+    if (side->n == 0) return IVJ_OK;
+    if (!cluster || !cluster_start || !cluster_end) return fail(IVJ_EINVAL, "cluster output buffers are NULL");
+    DeviceGuard g(ctx->device);
+    DevSide ds;
+    IVJ_TRY(upload_side(ctx, side, ds));
+    IndexHolder h;
+    IVJ_TRY(index_build(ctx, &ds.s, opts, 0, &h.ix));
+    DevBuf out;
+    const size_t n = (size_t)side->n;
+    hipError_t e = hipMalloc(&out.p, align_up(n * 8) + 2 * align_up(n * 4));
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(cluster): ") + hipGetErrorString(e));
+    int64_t* d_c = (int64_t*)out.p;
+    int32_t* d_s = (int32_t*)((char*)out.p + align_up(n * 8));
+    int32_t* d_e = (int32_t*)((char*)d_s + align_up(n * 4));
+    int64_t ncl = 0;
+    IVJ_TRY(ivj_cluster_dev(ctx, h.ix, opts, min_dist, d_c, d_s, d_e, &ncl));
+    HIP_TRY(hipMemcpyAsync(cluster, d_c, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(cluster_start, d_s, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(cluster_end, d_e, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_clusters) *n_clusters = ncl;
+    return IVJ_OK;
+}
+
+int ivj_coverage(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int64_t* coverage) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe, "probe"));
+    IVJ_TRY(check_side(build, "build"));
+    if (probe->n == 0) return IVJ_OK;
+    if (!coverage) return fail(IVJ_EINVAL, "coverage is NULL");
+    DeviceGuard g(ctx->device);
+    DevSide dp, db;
+    IVJ_TRY(upload_side(ctx, build, db));
+    IVJ_TRY(upload_side(ctx, probe, dp));
+    IndexHolder h;
+    IVJ_TRY(index_build(ctx, &db.s, opts, 0, &h.ix));
+    DevBuf out;
+    hipError_t e = hipMalloc(&out.p, (size_t)probe->n * 8);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(coverage): ") + hipGetErrorString(e));
+    IVJ_TRY(coverage_core(ctx, h.ix, &dp.s, opts, (int64_t*)out.p));
+    HIP_TRY(hipMemcpyAsync(coverage, out.p, (size_t)probe->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return IVJ_OK;
 }
 

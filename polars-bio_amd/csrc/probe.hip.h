@@ -8,3 +8,4 @@
 #include "partition.hip.h"
 #include "flat.hip.h"
 #include "materialize.hip.h"
+#include "sortscan.hip.h"

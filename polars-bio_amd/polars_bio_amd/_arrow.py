@@ -115,6 +115,27 @@ def encode_keys(t1: pa.Table, cols1, t2: pa.Table, cols2, with_dictionary: bool 
     return side1, side2, n_contigs
 
 
+def encode_frame(t: pa.Table, cols):
+    """One frame -> ((contig, start, end) int32 arrays, n_contigs, dictionary).  The dictionary is sorted
+    lexicographically so that ids ascend in chrom order: merge / cluster number their results in
+    (chrom, start) order, as bioframe does (/root/reference/tests/test_bioframe.py:398-419)."""
+    for c in cols:
+        if c not in t.column_names:
+            raise ValueError(f"column '{c}' not found in {t.column_names}")
+    ch = _as_string(t.column(cols[0]))
+    u = pc.drop_null(pc.unique(ch))
+    u = u.combine_chunks() if isinstance(u, pa.ChunkedArray) else u
+    u = pc.take(u, pc.sort_indices(u))
+    if len(ch) == 0:
+        ids = np.empty(0, np.int32)
+    else:
+        idx = pc.fill_null(pc.index_in(ch, value_set=u), -1)
+        idx = idx.combine_chunks() if isinstance(idx, pa.ChunkedArray) else idx
+        ids = idx.to_numpy(zero_copy_only=False).astype(np.int32, copy=False)
+    side = (ids, _coord_to_i32(t.column(cols[1]), cols[1]), _coord_to_i32(t.column(cols[2]), cols[2]))
+    return side, len(u), u
+
+
 def take_rows(t: pa.Table, idx: np.ndarray, nullable: bool = False) -> pa.Table:
     """Gather rows; with nullable=True an index of -1 yields an all-null row."""
     if nullable:

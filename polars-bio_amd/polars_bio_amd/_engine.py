@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev", "ivj_overlap_fused_dev",
     "ivj_count_overlaps_dev", "ivj_nearest_dev",
     "ivj_materialize_dev", "ivj_overlap_fused_rows_dev", "ivj_take_dev", "ivj_overlap_rows", "ivj_rows_free", "ivj_rows_export_arrow",
+    "ivj_merge", "ivj_merged_free", "ivj_cluster", "ivj_coverage", "ivj_cluster_dev", "ivj_merge_dev", "ivj_coverage_dev",
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
 ]
 
@@ -57,6 +58,11 @@ class _Pairs(C.Structure):
 class _Rows(C.Structure):
     _fields_ = [("n_pairs", C.c_int64)] + [(name, C.POINTER(C.c_int32)) for name in
                                             ("probe_idx", "build_idx", "contig", "start_1", "end_1", "start_2", "end_2")]
+
+
+class _Merged(C.Structure):
+    _fields_ = [("n", C.c_int64), ("contig", C.POINTER(C.c_int32)), ("start", C.POINTER(C.c_int32)), ("end", C.POINTER(C.c_int32)),
+                ("n_intervals", C.POINTER(C.c_int64))]
 
 
 class _ArrowSchema(C.Structure):     # Arrow C Data Interface, opaque to Python: only its address is handed on
@@ -122,6 +128,14 @@ def load_library() -> C.CDLL:
         L.ivj_rows_free.argtypes = [C.POINTER(_Rows)]
         L.ivj_rows_free.restype = None
         L.ivj_rows_export_arrow.argtypes = [C.POINTER(_Rows), vp, vp]
+        L.ivj_merge.argtypes = [vp, P, O, C.c_int64, C.POINTER(_Merged)]
+        L.ivj_merged_free.argtypes = [C.POINTER(_Merged)]
+        L.ivj_merged_free.restype = None
+        L.ivj_cluster.argtypes = [vp, P, O, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64)]
+        L.ivj_coverage.argtypes = [vp, P, P, O, vp]
+        L.ivj_cluster_dev.argtypes = [vp, vp, O, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64)]
+        L.ivj_merge_dev.argtypes = [vp, vp, O, C.c_int64, C.c_int64, vp, vp, vp, vp, C.POINTER(C.c_int64)]
+        L.ivj_coverage_dev.argtypes = [vp, vp, P, O, vp]
         L.ivj_dev_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
         L.ivj_dev_free.argtypes = [vp, vp]
         L.ivj_memcpy_h2d.argtypes = [vp, vp, vp, C.c_int64]
@@ -252,6 +266,46 @@ class Engine:
         finally:
             self.L.ivj_rows_free(C.byref(out))
 
+    # ---- sort-scan family ---------------------------------------------
+    def merge(self, frame, strict: bool, n_contigs: int, min_dist: int = 0):
+        """pb.merge: -> (contig id, start, end, n_intervals) of the merged intervals, (contig id, start) order."""
+        fs, keep = _host_side(*frame)
+        o = make_opts(strict, n_contigs)
+        out = _Merged()
+        _check(self.L, self.L.ivj_merge(self.h, C.byref(fs), C.byref(o), int(min_dist), C.byref(out)), "ivj_merge")
+        del keep
+        try:
+            n = out.n
+            if n == 0:
+                return np.empty(0, np.int32), np.empty(0, np.int32), np.empty(0, np.int32), np.empty(0, np.int64)
+            return (np.ctypeslib.as_array(out.contig, shape=(n,)).copy(), np.ctypeslib.as_array(out.start, shape=(n,)).copy(),
+                    np.ctypeslib.as_array(out.end, shape=(n,)).copy(), np.ctypeslib.as_array(out.n_intervals, shape=(n,)).copy())
+        finally:
+            self.L.ivj_merged_free(C.byref(out))
+
+    def cluster(self, frame, strict: bool, n_contigs: int, min_dist: int = 0):
+        """pb.cluster: -> (cluster id int64, cluster_start, cluster_end) per input row + number of clusters."""
+        fs, keep = _host_side(*frame)
+        o = make_opts(strict, n_contigs)
+        cid = np.empty(fs.n, np.int64)
+        cs = np.empty(fs.n, np.int32)
+        ce = np.empty(fs.n, np.int32)
+        ncl = C.c_int64(0)
+        _check(self.L, self.L.ivj_cluster(self.h, C.byref(fs), C.byref(o), int(min_dist), cid.ctypes.data, cs.ctypes.data,
+                                           ce.ctypes.data, C.byref(ncl)), "ivj_cluster")
+        del keep
+        return cid, cs, ce, ncl.value
+
+    def coverage(self, probe, build, strict: bool, n_contigs: int) -> np.ndarray:
+        """pb.coverage: covered positions of every probe row (int64, probe order)."""
+        ps, keep_p = _host_side(*probe)
+        bs, keep_b = _host_side(*build)
+        o = make_opts(strict, n_contigs)
+        cov = np.empty(ps.n, np.int64)
+        _check(self.L, self.L.ivj_coverage(self.h, C.byref(ps), C.byref(bs), C.byref(o), cov.ctypes.data), "ivj_coverage")
+        del keep_p, keep_b
+        return cov
+
     def count_overlaps(self, probe, build, strict: bool, n_contigs: int, table_mode: int = 0) -> np.ndarray:
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
@@ -359,6 +413,27 @@ class Engine:
         """ivj_take_dev: Arrow take of one 4- or 8-byte device column; negative indices -> 0 / null bit."""
         _check(self.L, self.L.ivj_take_dev(self.h, C.c_void_p(src_ptr), int(elem_bytes), C.c_void_p(idx_ptr), int(n),
                                             C.c_void_p(dst_ptr), C.c_void_p(validity_ptr or None)), "ivj_take_dev")
+
+    def cluster_dev(self, ix: DeviceIndex, opts: _Opts, min_dist: int, cluster_ptr: int, start_ptr: int, end_ptr: int) -> int:
+        n = C.c_int64(0)
+        _check(self.L, self.L.ivj_cluster_dev(self.h, ix.handle, C.byref(opts), int(min_dist), C.c_void_p(cluster_ptr),
+                                               C.c_void_p(start_ptr), C.c_void_p(end_ptr), C.byref(n)), "ivj_cluster_dev")
+        return n.value
+
+    def merge_dev(self, ix: DeviceIndex, opts: _Opts, min_dist: int, capacity: int, contig_ptr: int, start_ptr: int, end_ptr: int,
+                  n_intervals_ptr: int):
+        """-> (n_merged, fits)"""
+        n = C.c_int64(0)
+        rc = self.L.ivj_merge_dev(self.h, ix.handle, C.byref(opts), int(min_dist), int(capacity), C.c_void_p(contig_ptr or None),
+                                  C.c_void_p(start_ptr or None), C.c_void_p(end_ptr or None), C.c_void_p(n_intervals_ptr or None), C.byref(n))
+        if rc == -4:
+            return n.value, False
+        _check(self.L, rc, "ivj_merge_dev")
+        return n.value, True
+
+    def coverage_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, coverage_ptr: int):
+        _check(self.L, self.L.ivj_coverage_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), C.c_void_p(coverage_ptr)),
+               "ivj_coverage_dev")
 
     def count_overlaps_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, counts_ptr: int):
         _check(self.L, self.L.ivj_count_overlaps_dev(self.h, ix.handle, C.byref(probe), C.byref(opts),

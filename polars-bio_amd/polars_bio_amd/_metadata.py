@@ -113,3 +113,22 @@ def validate_coordinate_systems(df1, df2) -> bool:
             f"Coordinate system mismatch: first input uses {s(cs1)} coordinates, "
             f"second input uses {s(cs2)} coordinates.")
     return cs1
+
+
+def validate_coordinate_system_single(df) -> bool:
+    """Single-input form (reference: polars_bio/_metadata.py validate_coordinate_system_single, used by
+    merge / cluster / complement, range_op.py:87-111): returns zero_based."""
+    cs = get_coordinate_system(df)
+    if cs is None:
+        check = (get_option(POLARS_BIO_COORDINATE_SYSTEM_CHECK) or "false").lower() == "true"
+        if check:
+            raise MissingCoordinateSystemError(
+                f"{_type_name(df)} is missing coordinate system metadata.\n\n"
+                f"Set df.attrs['{COORDINATE_SYSTEM_KEY}'] (pandas), schema metadata (pyarrow) or "
+                f"config_meta (polars), or disable {POLARS_BIO_COORDINATE_SYSTEM_CHECK}.")
+        cs = (get_option(POLARS_BIO_COORDINATE_SYSTEM_ZERO_BASED) or "false").lower() == "true"
+        warnings.warn(
+            f"Coordinate system metadata is missing for: {_type_name(df)}. "
+            f"Using global POLARS_BIO_COORDINATE_SYSTEM_ZERO_BASED setting ({'0-based' if cs else '1-based'}).",
+            UserWarning, stacklevel=4)
+    return cs

@@ -21,12 +21,13 @@ import pyarrow.compute as pc
 
 from . import _arrow as A
 from ._engine import default_engine
-from ._metadata import validate_coordinate_systems
+from ._metadata import validate_coordinate_system_single, validate_coordinate_systems
 from .constants import DEFAULT_INTERVAL_COLUMNS
 
 logger = logging.getLogger("polars_bio_amd")
 
-__all__ = ["overlap", "overlap_batches", "nearest", "count_overlaps", "FilterOp", "RangeOp", "OverlapOutputMode"]
+__all__ = ["overlap", "overlap_batches", "nearest", "count_overlaps", "coverage", "merge", "cluster",
+           "FilterOp", "RangeOp", "OverlapOutputMode"]
 
 
 class FilterOp:      # src/option.rs:95-100
@@ -37,7 +38,10 @@ class FilterOp:      # src/option.rs:95-100
 class RangeOp:       # src/option.rs:102-112 (hot-path members only)
     Overlap = 0
     Nearest = 3
+    Coverage = 4
     CountOverlapsNaive = 6
+    Merge = 7
+    Cluster = 8
 
 
 class OverlapOutputMode:  # src/option.rs:87-92
@@ -247,4 +251,79 @@ def count_overlaps(
         c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
         res = pa.table({f"{c}{suffixes[0]}": t1.column(c) for c in c1})
         res = res.append_column("count", pa.array(counts, type=pa.int64()))
+    return A.from_arrow(res, output_type, zero_based)
+
+
+# ---- sort-scan family ----------------------------------------------------
+
+def coverage(
+    df1,
+    df2,
+    suffixes: tuple = ("_1", "_2"),
+    on_cols: Union[list, None] = None,
+    cols1: Union[list, None] = ["chrom", "start", "end"],
+    cols2: Union[list, None] = ["chrom", "start", "end"],
+    output_type: str = "polars.LazyFrame",
+    read_options=None,
+    projection_pushdown: bool = True,
+):
+    """Covered positions of every df1 interval by the union of the df2 intervals (reference:
+    range_op.py:342-415; executed by CountOverlapsProvider(coverage=true), src/operation.rs:306-350).
+    Output = df1 columns + ``coverage`` (Int64), df1 row order kept (range_op_helpers.py:214-222, 317-318)."""
+    _validate_overlap_input(cols1, cols2, on_cols, suffixes, output_type)
+    zero_based = validate_coordinate_systems(df1, df2)
+    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    cov = default_engine().coverage(probe, build, strict=zero_based, n_contigs=n_contigs)
+    return A.from_arrow(t1.append_column("coverage", pa.array(cov, type=pa.int64())), output_type, zero_based)
+
+
+def merge(
+    df,
+    min_dist: int = 0,
+    cols: Union[list, None] = ["chrom", "start", "end"],
+    on_cols: Union[list, None] = None,
+    output_type: str = "polars.LazyFrame",
+    projection_pushdown: bool = True,
+):
+    """Merge overlapping intervals (reference: range_op.py:599-657; MergeProvider, src/operation.rs:352-381).
+    Output: (chrom, start: Int64, end: Int64, n_intervals: Int64) in (chrom, start) order
+    (range_op_helpers.py:78-90).  ``min_dist=0`` merges overlapping intervals only: bookended half-open
+    intervals stay apart (tests/_expected.py:174-181)."""
+    _validate_overlap_input(cols, cols, on_cols, ("_1", "_2"), output_type)
+    zero_based = validate_coordinate_system_single(df)
+    cols = list(DEFAULT_INTERVAL_COLUMNS if cols is None else cols)
+    t = A.to_arrow(df)
+    side, n_contigs, dictionary = A.encode_frame(t, cols)
+    keep = side[0] >= 0                                   # rows with a null chrom belong to no contig
+    side = tuple(a[keep] for a in side) if not keep.all() else side
+    c, s, e, n = default_engine().merge(side, strict=zero_based, n_contigs=n_contigs, min_dist=int(min_dist))
+    res = pa.table({cols[0]: pc.cast(pc.take(dictionary, pa.array(c, type=pa.int32())), pa.string()),
+                    cols[1]: pa.array(s.astype(np.int64)), cols[2]: pa.array(e.astype(np.int64)),
+                    "n_intervals": pa.array(n, type=pa.int64())})
+    return A.from_arrow(res, output_type, zero_based)
+
+
+def cluster(
+    df,
+    min_dist: int = 0,
+    cols: Union[list, None] = ["chrom", "start", "end"],
+    output_type: str = "polars.LazyFrame",
+    projection_pushdown: bool = True,
+):
+    """Cluster ids for overlapping / nearby intervals (reference: range_op.py:660-715; ClusterProvider,
+    src/operation.rs:383-418).  Output: every input column + ``cluster``, ``cluster_start``, ``cluster_end``
+    (Int64), input row order; clusters are numbered in (chrom, start) order (range_op_helpers.py:93-121)."""
+    _validate_overlap_input(cols, cols, None, ("_1", "_2"), output_type)
+    zero_based = validate_coordinate_system_single(df)
+    cols = list(DEFAULT_INTERVAL_COLUMNS if cols is None else cols)
+    t = A.to_arrow(df)
+    side, n_contigs, _ = A.encode_frame(t, cols)
+    cid, cs, ce, _ = default_engine().cluster(side, strict=zero_based, n_contigs=n_contigs, min_dist=int(min_dist))
+    res = t
+    if t.num_columns == 3:                                # the classic triplet comes back with Int64 coordinates
+        res = pa.table({cols[0]: t.column(cols[0]), cols[1]: pc.cast(t.column(cols[1]), pa.int64()),
+                        cols[2]: pc.cast(t.column(cols[2]), pa.int64())})
+    res = res.append_column("cluster", pa.array(cid, type=pa.int64()))
+    res = res.append_column("cluster_start", pa.array(cs.astype(np.int64)))
+    res = res.append_column("cluster_end", pa.array(ce.astype(np.int64)))
     return A.from_arrow(res, output_type, zero_based)

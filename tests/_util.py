@@ -69,6 +69,22 @@ class OracleEngine:
         cols = {k: np.ascontiguousarray(v, np.int32) for k, v in cols.items()}
         return pa.record_batch(cols) if as_arrow else cols
 
+    def merge(self, frame, strict, n_contigs, min_dist=0):
+        import numpy as np
+        from oracle import oracle as O
+        _, _, _, (c, s, e, n) = O.np_cluster(O.Side(*frame), strict, min_dist)
+        return c, s.astype(np.int32), e.astype(np.int32), n
+
+    def cluster(self, frame, strict, n_contigs, min_dist=0):
+        import numpy as np
+        from oracle import oracle as O
+        cid, cs, ce, merged = O.np_cluster(O.Side(*frame), strict, min_dist)
+        return cid, cs.astype(np.int32), ce.astype(np.int32), len(merged[0])
+
+    def coverage(self, probe, build, strict, n_contigs):
+        from oracle import oracle as O
+        return O.np_coverage_fast(O.Side(*probe), O.Side(*build), strict)
+
     def overlap_batches(self, probe, build, strict, n_contigs, batch_rows=8_000_000):
         import numpy as np
         from oracle import oracle as O

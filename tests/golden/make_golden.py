@@ -9,6 +9,9 @@ Sources (all under /root/reference):
   tests/_expected.py:10-128   PD_DF_OVERLAP         -> expected_overlap.csv
   tests/_expected.py:130-172  PD_DF_NEAREST         -> expected_nearest.csv
   tests/_expected.py:183-202  PD_DF_COUNT_OVERLAPS  -> expected_count_overlaps.csv
+  tests/_expected.py:174-181  PD_DF_MERGE           -> expected_merge.csv
+  tests/data/merge/input.csv, tests/data/coverage/{reads,targets}.csv -> inputs, copied
+  tests/test_partitioned_range_operation_regressions.py:24-59,128-190 -> cases.json (sort_scan)
   tests/data/exons/*.parquet, tests/data/fBrain-DS14718/*.parquet -> copied
       (known answer 54,246 overlaps 0-based: docs/supplement.md:108,111,149)
   tests/test_coordinate_system_metadata.py:738-819,1172-1191,1482-1506 -> cases.json (boundary)
@@ -34,7 +37,8 @@ def extract_tables():
     tree = ast.parse(src)
     want = {"PD_DF_OVERLAP": "expected_overlap.csv",
             "PD_DF_NEAREST": "expected_nearest.csv",
-            "PD_DF_COUNT_OVERLAPS": "expected_count_overlaps.csv"}
+            "PD_DF_COUNT_OVERLAPS": "expected_count_overlaps.csv",
+            "PD_DF_MERGE": "expected_merge.csv"}
     done = set()
     for node in tree.body:
         if not isinstance(node, ast.Assign) or len(node.targets) != 1:
@@ -71,6 +75,11 @@ def copy_inputs():
         os.makedirs(os.path.join(OUT, op), exist_ok=True)
         for f in ("reads.csv", "targets.csv"):
             shutil.copyfile(os.path.join(REF, "tests/data", op, f), os.path.join(OUT, op, f))
+    os.makedirs(os.path.join(OUT, "merge"), exist_ok=True)
+    shutil.copyfile(os.path.join(REF, "tests/data/merge/input.csv"), os.path.join(OUT, "merge/input.csv"))
+    os.makedirs(os.path.join(OUT, "coverage"), exist_ok=True)
+    for f in ("reads.csv", "targets.csv"):
+        shutil.copyfile(os.path.join(REF, "tests/data/coverage", f), os.path.join(OUT, "coverage", f))
     for d in ("exons", "fBrain-DS14718"):
         os.makedirs(os.path.join(OUT, d), exist_ok=True)
         for f in os.listdir(os.path.join(REF, "tests/data", d)):
@@ -123,6 +132,19 @@ def write_cases():
             "overlap": [[1, 5, 4, 8], [3, 8, 4, 8], [8, 10, 4, 8], [8, 10, 10, 11]],
             "nearest": [[1, 5, 4, 8, 0], [3, 8, 4, 8, 0], [8, 10, 4, 8, 0], [12, 14, 10, 11, 1]],
             "count": [1, 1, 2, 0],
+        },
+        "sort_scan": {
+            # tests/test_partitioned_range_operation_regressions.py: inputs :128-160, view :178-186,
+            # expected tables :24-59 (0-based)
+            "zero_based": True,
+            "left": iv([("chr1", 0, 10), ("chr1", 20, 30), ("chr1", 8, 25)]),
+            "right": iv([("chr1", 5, 10), ("chr1", 20, 25)]),
+            "view": iv([("chr1", 0, 40)]),
+            "merge": {"start": [0], "end": [30], "n_intervals": [3]},
+            "complement": {"start": [30], "end": [40]},
+            "subtract": {"start": [0, 10, 25], "end": [5, 20, 30]},
+            "cluster": {"start": [0, 8, 20], "end": [10, 25, 30], "cluster": [0, 0, 0], "cluster_start": [0, 0, 0],
+                        "cluster_end": [30, 30, 30]},
         },
         "known_answers": {
             # docs/supplement.md:108,111,149 -- exons (df1) x fBrain (df2), 0-based

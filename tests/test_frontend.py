@@ -261,3 +261,63 @@ def test_device_materialised_key_columns_equal_host_take(engine):
     pd.testing.assert_frame_equal(_sorted(gold_dev), _sorted(pd.read_csv(f"{GOLDEN}/expected_overlap.csv")))
     pd.testing.assert_frame_equal(_sorted(gold_dev), _sorted(gold_host))
     assert len(left) == len(host)
+
+
+# ---- sort-scan family ----------------------------------------------
+
+def test_merge_golden(engine):
+    """tests/test_pandas.py:109-124: merge of the 0-based fixture == PD_DF_MERGE (tests/_expected.py:174-181)."""
+    res = pb.merge(_csv(f"{GOLDEN}/merge/input.csv", zero_based=True), cols=COLS, output_type="pandas.DataFrame")
+    exp = pd.read_csv(f"{GOLDEN}/expected_merge.csv").astype({"pos_start": "int64", "pos_end": "int64", "n_intervals": "int64"})
+    assert len(res) == 8 and list(res.columns) == ["contig", "pos_start", "pos_end", "n_intervals"]
+    pd.testing.assert_frame_equal(_sorted(res), _sorted(exp))
+    assert res.attrs["coordinate_system_zero_based"] is True
+    one = pb.merge(_csv(f"{GOLDEN}/merge/input.csv", zero_based=True), min_dist=1, cols=COLS, output_type="pandas.DataFrame")
+    assert len(one) == 6 and (one["n_intervals"] == 7).sum() == 2          # bookended 300/300 now joins
+
+
+def test_cluster_and_merge_regression_case(engine):
+    """tests/test_partitioned_range_operation_regressions.py:24-59 on its own inputs; extra columns and
+    input row order are kept by cluster; ids count clusters in (chrom, start) order."""
+    case = load_cases()["sort_scan"]
+    left = _frame(case["left"], True)
+    m = pb.merge(left, output_type="pandas.DataFrame")
+    assert m["start"].tolist() == case["merge"]["start"] and m["end"].tolist() == case["merge"]["end"]
+    assert m["n_intervals"].tolist() == case["merge"]["n_intervals"]
+    cl = pb.cluster(left, output_type="pandas.DataFrame").sort_values("start").reset_index(drop=True)
+    for k in ("cluster", "cluster_start", "cluster_end"):
+        assert cl[k].tolist() == case["cluster"][k] and cl[k].dtype == np.int64
+    assert cl["start"].dtype == np.int64                      # the classic triplet comes back as Int64
+    df = pd.DataFrame({"chrom": ["chr2", "chr10", "chr2", "chr10", "chr2"], "start": np.array([5, 1, 50, 3, 8], np.int32),
+                       "end": np.array([9, 4, 60, 7, 20], np.int32), "name": list("abcde")})
+    df.attrs["coordinate_system_zero_based"] = True
+    cl = pb.cluster(df, output_type="pandas.DataFrame")
+    assert cl["name"].tolist() == list("abcde") and cl["start"].dtype == np.int32
+    # chr10 < chr2 lexicographically: chr10 holds cluster 0 (1-7); chr2: 5-20 -> 1, 50-60 -> 2
+    assert cl["cluster"].tolist() == [1, 0, 2, 0, 1]
+    assert cl["cluster_start"].tolist() == [5, 1, 50, 1, 5] and cl["cluster_end"].tolist() == [20, 7, 60, 7, 20]
+    weak = df.copy()
+    weak.attrs["coordinate_system_zero_based"] = False
+    touching = pd.DataFrame({"chrom": ["c", "c"], "start": [1, 5], "end": [5, 9]})
+    touching.attrs["coordinate_system_zero_based"] = False   # closed [1,5] and [5,9] share position 5
+    assert len(pb.merge(touching, output_type="pandas.DataFrame")) == 1
+    touching.attrs["coordinate_system_zero_based"] = True    # half-open [1,5) and [5,9) do not
+    assert len(pb.merge(touching, output_type="pandas.DataFrame")) == 2
+
+
+def test_coverage_fixture_and_semantics(engine):
+    """pb.coverage(df1, df2): df1 columns + coverage (Int64), df1 order kept (range_op_helpers.py:214-222)."""
+    reads = _csv(f"{GOLDEN}/coverage/reads.csv")
+    targets = _csv(f"{GOLDEN}/coverage/targets.csv")
+    res = pb.coverage(targets, reads, cols1=COLS, cols2=COLS, output_type="pandas.DataFrame")
+    assert list(res.columns) == ["contig", "pos_start", "pos_end", "coverage"] and res["coverage"].dtype == np.int64
+    assert res["pos_start"].tolist() == targets["pos_start"].tolist()
+    from oracle import oracle as O
+    from _util import load_intervals_csv
+    (c1, c2), _ = O.encode_contigs(targets["contig"].tolist(), reads["contig"].tolist())
+    exp = O.np_coverage_brute(O.Side(c1, targets["pos_start"].to_numpy(), targets["pos_end"].to_numpy()),
+                              O.Side(c2, reads["pos_start"].to_numpy(), reads["pos_end"].to_numpy()), False)
+    assert res["coverage"].tolist() == exp.tolist() and exp.sum() > 0
+    df1 = _frame({"chrom": ["chr1", "chr1", "chr9"], "start": [0, 100, 0], "end": [50, 200, 10]}, True)
+    df2 = _frame({"chrom": ["chr1", "chr1", "chr1"], "start": [10, 20, 150], "end": [30, 40, 400]}, True)
+    assert pb.coverage(df1, df2, output_type="pandas.DataFrame")["coverage"].tolist() == [30, 50, 0]

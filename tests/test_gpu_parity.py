@@ -490,3 +490,78 @@ def test_fused_rows_join_and_materialise_in_one_pass():
         assert fits2 and n2 == total
         o2 = np.argsort(cols2["probe_idx"].cpu().numpy(), kind="stable")
         assert (cols2["end_2"].cpu().numpy()[o2] == build[2][eb]).all()
+
+
+# ---- merge / cluster / coverage ------------------------------------------
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_merge_cluster_coverage_parity(eng, strict):
+    """HIP sweep over the sorted index == the oracle's sequential sweep, bit-exact: random frames with
+    nested, zero-length, bookended and negative-coordinate rows, rows outside the dictionary, several
+    min_dist values; coverage against the per-probe clipping definition."""
+    rng = np.random.default_rng(23)
+    for (n, nc, span, maxlen) in ((5000, 3, 20_000, 60), (20_000, 24, 3_000_000, 5000), (1, 1, 10, 5), (777, 2, 500, 400)):
+        c, s, e = random_side(rng, n, nc, span, maxlen)
+        s = (s - span // 4).astype(np.int32)
+        e = (e - span // 4).astype(np.int32)
+        if n > 100:
+            c = c.copy(); c[rng.integers(0, n, 5)] = -1                    # null chrom rows
+        frame = (c, s, e)
+        for md in (0, 1, 37):
+            ecid, ecs, ece, (mc, ms, me, mn) = O.np_cluster(O.Side(*frame), strict, md)
+            gc, gs, ge, gn = eng.merge(frame, strict, nc, md)
+            # the oracle orders the pseudo-contig of null rows (-1) first, the engine (dictionary overflow) last
+            eo = np.lexsort((ms, np.where(mc < 0, nc, mc)))
+            assert len(gc) == len(mc), (n, md)
+            assert (gc == mc[eo]).all() and (gs == ms[eo]).all() and (ge == me[eo]).all() and (gn == mn[eo]).all(), (n, md)
+            cid, cs, ce, ncl = eng.cluster(frame, strict, nc, md)
+            assert ncl == len(mc)
+            assert (cs == ecs).all() and (ce == ece).all()
+            # ids: same partition of the rows, numbered in (contig, start) order with the null rows last
+            remap = np.empty(len(mc), np.int64); remap[eo] = np.arange(len(mc))
+            assert (cid == remap[ecid]).all(), (n, md)
+        pc, ps, pe = random_side(rng, max(n // 2, 3), nc + 1, span, maxlen * 3)
+        probe = (pc, (ps - span // 4).astype(np.int32), (pe - span // 4).astype(np.int32))
+        exp = O.np_coverage_fast(O.Side(*probe), O.Side(*frame), strict)
+        got = eng.coverage(probe, frame, strict, nc)
+        assert got.dtype == np.int64 and (got == exp).all(), n
+        if n <= 5000:
+            assert (got == O.np_coverage_brute(O.Side(*probe), O.Side(*frame), strict)).all()
+    e0 = (np.empty(0, np.int32),) * 3
+    one = (np.zeros(2, np.int32), np.array([5, 7], np.int32), np.array([9, 30], np.int32))
+    assert len(eng.merge(e0, strict, 1)[0]) == 0 and eng.cluster(e0, strict, 1)[3] == 0
+    assert eng.coverage(one, e0, strict, 1).tolist() == [0, 0] and len(eng.coverage(e0, one, strict, 1)) == 0
+    assert eng.coverage(one, one, strict, 1).tolist() == ([4, 23] if strict else [5, 24])
+
+
+def test_sort_scan_device_entry_points():
+    """ivj_merge_dev / ivj_cluster_dev / ivj_coverage_dev on torch tensors against the host entry points."""
+    import torch
+    from polars_bio_amd.device_api import DeviceJoin, DeviceSide
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    probe = synth.make_side(200_000, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(300_000, 43, synth.DENSE_BUILD_LEN, 24)
+    join = DeviceJoin(0)
+    db, dp = DeviceSide(*map(up, build)), DeviceSide(*map(up, probe))
+    opts = _engine.make_opts(True, 24)
+    ix = join.engine.index_build_dev(db.as_c(), opts)
+    ecid, ecs, ece, (mc, ms, me, mn) = O.np_cluster(O.Side(*build), True, 0)
+    cap = len(mc)
+    t = {k: torch.empty(cap, dtype=torch.int32, device=dev) for k in ("c", "s", "e")}
+    cnt = torch.empty(cap, dtype=torch.int64, device=dev)
+    n_small, fits = join.engine.merge_dev(ix, opts, 0, cap // 2, t["c"].data_ptr(), t["s"].data_ptr(), t["e"].data_ptr(), cnt.data_ptr())
+    assert not fits and n_small == cap
+    n_m, fits = join.engine.merge_dev(ix, opts, 0, cap, t["c"].data_ptr(), t["s"].data_ptr(), t["e"].data_ptr(), cnt.data_ptr())
+    assert fits and n_m == cap and 1000 < cap < len(build[0])
+    assert (t["c"].cpu().numpy() == mc).all() and (t["s"].cpu().numpy() == ms).all() and (t["e"].cpu().numpy() == me).all()
+    assert (cnt.cpu().numpy() == mn).all()
+    cid = torch.empty(db.n, dtype=torch.int64, device=dev)
+    cs = torch.empty(db.n, dtype=torch.int32, device=dev)
+    ce = torch.empty(db.n, dtype=torch.int32, device=dev)
+    assert join.engine.cluster_dev(ix, opts, 0, cid.data_ptr(), cs.data_ptr(), ce.data_ptr()) == cap
+    assert (cid.cpu().numpy() == ecid).all() and (cs.cpu().numpy() == ecs).all() and (ce.cpu().numpy() == ece).all()
+    cov = torch.empty(dp.n, dtype=torch.int64, device=dev)
+    join.engine.coverage_dev(ix, dp.as_c(), opts, cov.data_ptr())
+    assert (cov.cpu().numpy() == O.np_coverage_fast(O.Side(*probe), O.Side(*build), True)).all()
+    ix.close()

@@ -213,3 +213,68 @@ def test_empty_sides():
         assert O.count_overlaps_fast(O.Index(e, 1), one, strict).tolist() == [0]
         idx, dist, n = O.nearest_fast(O.Index(e, 1), one, strict)
         assert n.tolist() == [0] and idx.tolist() == [[-1]] and dist.tolist() == [[-1]]
+
+
+# ---- sort-scan family: merge / cluster / coverage / complement / subtract ----
+
+def _one_frame(df):
+    (c,), n = O.encode_contigs(df[0])
+    return O.Side(c, df[1], df[2]), n
+
+
+def test_merge_golden_zero_based():
+    """tests/_expected.py:174-181 via tests/test_native.py:205-224 (0-based: bookended intervals stay apart)."""
+    frame = load_intervals_csv(f"{GOLDEN}/merge/input.csv")
+    side, _ = _one_frame(frame)
+    _, _, _, (mc, ms, me, mn) = O.np_cluster(side, True, 0)
+    names = sorted(set(frame[0]))
+    got = sorted((names[c], int(s), int(e), int(n)) for c, s, e, n in zip(mc, ms, me, mn))
+    exp = read_csv_cols(f"{GOLDEN}/expected_merge.csv")
+    want = sorted(zip(exp["contig"], map(int, exp["pos_start"]), map(int, exp["pos_end"]), map(int, exp["n_intervals"])))
+    assert got == want and len(got) == 8
+    # min_dist = 1 merges the bookended pair (300 joins 100-300): chr1 gets 100-700 with 7 rows
+    _, _, _, (mc, ms, me, mn) = O.np_cluster(side, True, 1)
+    assert (100, 700, 7) in set(zip(ms.tolist(), me.tolist(), mn.tolist()))
+
+
+def test_sort_scan_regression_cases():
+    """tests/test_partitioned_range_operation_regressions.py:24-59 (expected) on its own inputs."""
+    case = load_cases()["sort_scan"]
+    mk = lambda d: O.Side(np.zeros(len(d["start"]), np.int32), np.array(d["start"], np.int32), np.array(d["end"], np.int32))
+    left, right, view = mk(case["left"]), mk(case["right"]), mk(case["view"])
+    strict = case["zero_based"]
+    cid, cs, ce, (mc, ms, me, mn) = O.np_cluster(left, strict, 0)
+    assert ms.tolist() == case["merge"]["start"] and me.tolist() == case["merge"]["end"] and mn.tolist() == case["merge"]["n_intervals"]
+    order = np.argsort(left.start)
+    assert left.start[order].tolist() == case["cluster"]["start"]
+    assert cid[order].tolist() == case["cluster"]["cluster"]
+    assert cs[order].tolist() == case["cluster"]["cluster_start"] and ce[order].tolist() == case["cluster"]["cluster_end"]
+    c, s, e = O.np_complement(left, view, strict)
+    assert s.tolist() == case["complement"]["start"] and e.tolist() == case["complement"]["end"]
+    r, s, e = O.np_subtract(left, right, strict)
+    assert sorted(zip(s.tolist(), e.tolist())) == sorted(zip(case["subtract"]["start"], case["subtract"]["end"]))
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_coverage_fast_equals_definition(strict):
+    """Two independent restatements of pb.coverage agree on the reference's coverage fixtures
+    (tests/data/coverage/*.csv) and on adversarial random inputs (zero-length, nested, absent contigs)."""
+    reads = load_intervals_csv(f"{GOLDEN}/coverage/reads.csv")
+    targets = load_intervals_csv(f"{GOLDEN}/coverage/targets.csv")
+    p, b, _ = _sides(targets, reads)
+    a = O.np_coverage_brute(p, b, strict)
+    assert (a == O.np_coverage_fast(p, b, strict)).all() and a.sum() > 0
+    rng = np.random.default_rng(17)
+    for _ in range(25):
+        nb, npr = int(rng.integers(0, 60)), int(rng.integers(1, 60))
+        bc = rng.integers(0, 3, nb).astype(np.int32)
+        bs = rng.integers(-50, 300, nb).astype(np.int32)
+        be = (bs + rng.integers(0, 60, nb)).astype(np.int32)
+        pc = rng.integers(-1, 4, npr).astype(np.int32)
+        ps = rng.integers(-50, 300, npr).astype(np.int32)
+        pe = (ps + rng.integers(0, 90, npr)).astype(np.int32)
+        P, B = O.Side(pc, ps, pe), O.Side(bc, bs, be)
+        assert (O.np_coverage_brute(P, B, strict) == O.np_coverage_fast(P, B, strict)).all()
+    # a probe inside one build interval is fully covered; Weak counts both end positions
+    one = O.np_coverage_brute(O.Side([0], [10], [20]), O.Side([0], [0], [100]), strict)
+    assert one.tolist() == [10 if strict else 11]
