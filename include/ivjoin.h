@@ -254,7 +254,28 @@ int ivj_cluster(ivj_ctx* ctx, const ivj_side* frame, const ivj_opts* opts, int64
  * intervals of the same contig (Int64, probe order kept; [s, e) Strict, [s, e] Weak). */
 int ivj_coverage(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int64_t* coverage);
 
+/* pb.subtract / pb.complement (SubtractProvider / ComplementProvider, src/operation.rs:420-510): every left
+ * interval minus the union of the right intervals of its contig.  Result = the remaining pieces as
+ * (left row, start, end), left-row order, ascending inside a row; a fully covered row yields nothing, a row
+ * whose contig is absent on the right comes back whole.  Library-owned host buffers. */
+typedef struct {
+    int64_t n;
+    int32_t* row;     /* row of the left side (left->row_id when given) */
+    int32_t* start;
+    int32_t* end;
+} ivj_pieces;
+
+int ivj_subtract(ivj_ctx* ctx, const ivj_side* left, const ivj_side* right, const ivj_opts* opts, ivj_pieces* out);
+/* complement = the gaps of `frame` inside every interval of `view` (e.g. one row per chromosome):
+ * ivj_subtract(view, frame); row = view row. */
+int ivj_complement(ivj_ctx* ctx, const ivj_side* frame, const ivj_side* view, const ivj_opts* opts, ivj_pieces* out);
+void ivj_pieces_free(ivj_pieces* p);
+
 /* device-resident forms: the index of the frame / build side is built with ivj_index_build_dev */
+/* subtract with the RIGHT side indexed; *n_pieces = total, IVJ_ECAPACITY when it exceeds the capacity of the
+ * caller's columns (nothing is written then: grow and call again). */
+int ivj_subtract_dev(ivj_ctx* ctx, ivj_index* right_ix, const ivj_side* left_dev, const ivj_opts* opts, int64_t capacity,
+                     int32_t* row_dev, int32_t* start_dev, int32_t* end_dev, int64_t* n_pieces);
 int ivj_cluster_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min_dist, int64_t* cluster_dev,
                     int32_t* cluster_start_dev, int32_t* cluster_end_dev, int64_t* n_clusters);
 int ivj_merge_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min_dist, int64_t capacity,

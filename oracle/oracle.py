@@ -349,56 +349,52 @@ def _merged_half_open(build: Side, strict: bool):
     """Disjoint union of the build intervals as half-open (contig, start, end) arrays, (contig, start) order."""
     c, s = build.contig, build.start.astype(np.int64)
     e = _half_open_end(build.end, strict)
-    keep = c >= 0
+    keep = (c >= 0) & (e > s)                             # rows that hold no position cover nothing
     c, s, e = c[keep], s[keep], e[keep]
     order = np.lexsort((s, c))
     c, s, e = c[order], s[order], e[order]
     mc, ms, me = [], [], []
     for i in range(len(c)):
-        if mc and mc[-1] == c[i] and s[i] < me[-1]:
+        if mc and mc[-1] == c[i] and s[i] <= me[-1]:     # bookended intervals leave no gap between them
             me[-1] = max(me[-1], int(e[i]))
         else:
             mc.append(c[i]); ms.append(int(s[i])); me.append(int(e[i]))
     return np.array(mc, np.int32), np.array(ms, np.int64), np.array(me, np.int64), None
 
 
+def _minus_union(c, s, e, mc, ms, me):
+    """pieces of the half-open rows (c, s, e) outside the disjoint sorted union (mc, ms, me) -> [(row, start, end)]"""
+    by_contig = {int(k): (ms[mc == k], me[mc == k]) for k in np.unique(mc)}
+    out = []
+    for i in range(len(c)):
+        ls, le = int(s[i]), int(e[i])
+        if le <= ls:
+            continue
+        us, ue = by_contig.get(int(c[i]), (None, None))
+        cur = ls
+        if us is not None:
+            first = int(np.searchsorted(ue, ls, side="right"))     # first union interval with end > ls
+            last = int(np.searchsorted(us, le, side="left"))       # first union interval with start >= le
+            for j in range(first, last):
+                if us[j] > cur:
+                    out.append((i, cur, int(us[j])))
+                cur = max(cur, int(ue[j]))
+        if cur < le:
+            out.append((i, cur, le))
+    return np.array(out, np.int64).reshape(-1, 3)
+
+
 def np_complement(side: Side, view: Side, strict: bool):
     """Gaps of the union of ``side`` inside every view interval -> (contig, start, end), in view order then by
     position.  Weak (closed) coordinates: the gap between [a, b] and [c, d] is [b + 1, c - 1]."""
     mc, ms, me, _ = _merged_half_open(side, strict)
-    out = []
-    for i in range(len(view.contig)):
-        vc, vs, ve = view.contig[i], int(view.start[i]), int(view.end[i]) + (0 if strict else 1)
-        cur = vs
-        sel = mc == vc
-        for s_, e_ in zip(ms[sel], me[sel]):
-            if e_ <= vs or s_ >= ve:
-                continue
-            if s_ > cur:
-                out.append((vc, cur, int(s_)))
-            cur = max(cur, int(e_))
-        if cur < ve:
-            out.append((vc, cur, ve))
-    arr = np.array(out, np.int64).reshape(-1, 3)
-    return arr[:, 0].astype(np.int32), arr[:, 1], arr[:, 2] - (0 if strict else 1)
+    arr = _minus_union(view.contig, view.start.astype(np.int64), _half_open_end(view.end, strict), mc, ms, me)
+    return view.contig[arr[:, 0]].astype(np.int32), arr[:, 1], arr[:, 2] - (0 if strict else 1)
 
 
 def np_subtract(left: Side, right: Side, strict: bool):
     """Every left interval minus the union of the right intervals of its contig -> (left row, start, end) pieces,
     left-row order then by position (a fully covered left row yields nothing)."""
     mc, ms, me, _ = _merged_half_open(right, strict)
-    out = []
-    for i in range(len(left.contig)):
-        ls, le = int(left.start[i]), int(left.end[i]) + (0 if strict else 1)
-        cur = ls
-        sel = mc == left.contig[i]
-        for s_, e_ in zip(ms[sel], me[sel]):
-            if e_ <= ls or s_ >= le:
-                continue
-            if s_ > cur:
-                out.append((i, cur, int(s_)))
-            cur = max(cur, int(e_))
-        if cur < le:
-            out.append((i, cur, le))
-    arr = np.array(out, np.int64).reshape(-1, 3)
+    arr = _minus_union(left.contig, left.start.astype(np.int64), _half_open_end(left.end, strict), mc, ms, me)
     return arr[:, 0].astype(np.int32), arr[:, 1], arr[:, 2] - (0 if strict else 1)

@@ -716,6 +716,11 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     return IVJ_OK;
 }
 
+struct DevBuf {                   // owning device allocation of the host-buffer entry points
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
 // ---- sort-scan family (sortscan.hip.h) ------------------------------------------------------------
 struct Clusters {                 // arena-backed (valid until the next arena_reserve on this context)
     int64_t n = 0;                // number of clusters
@@ -768,6 +773,87 @@ int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
                        (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, ix->n_contigs, probe->contig, probe->start, probe->end, n, (long long*)cov);
     else LAUNCH(ctx, "coverage", (k_coverage<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, (const int32_t*)ix->seg, (const uint32_t*)cl.cid1,
                 (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, ix->n_contigs, probe->contig, probe->start, probe->end, n, (long long*)cov);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+// union of the index's intervals as compacted half-open int64 ranges + everything k_subtract_* needs
+struct UnionView {
+    Clusters cl;
+    uint32_t* newidx = nullptr;
+    long long *u_start = nullptr, *u_end = nullptr;
+};
+
+int union_core(ivj_ctx* ctx, ivj_index* ix, bool strict, size_t extra_bytes, UnionView& u) {
+    const int64_t n = ix->n;
+    const size_t mine = 2 * align_up((size_t)(n + 2) * 4) + 2 * align_up((size_t)(n + 2) * 8) + align_up((size_t)(scan_num_tiles(n + 1) + 1) * 4);
+    IVJ_TRY(cluster_core(ctx, ix, strict, 1, mine + extra_bytes, u.cl));
+    if (n == 0) return IVJ_OK;
+    uint32_t* keep = arena_take<uint32_t>(ctx, n + 2);
+    u.newidx = arena_take<uint32_t>(ctx, n + 2);
+    u.u_start = arena_take<long long>(ctx, n + 2);
+    u.u_end = arena_take<long long>(ctx, n + 2);
+    uint32_t* partials = arena_take<uint32_t>(ctx, scan_num_tiles(n + 1) + 1);
+    const int64_t ncl = u.cl.n;
+    if (strict) LAUNCH(ctx, "union_flags", (k_union_flags<true>), grid1d(ncl, 256), 256, (const int32_t*)u.cl.m_start, (const int32_t*)u.cl.m_end, ncl, keep);
+    else LAUNCH(ctx, "union_flags", (k_union_flags<false>), grid1d(ncl, 256), 256, (const int32_t*)u.cl.m_start, (const int32_t*)u.cl.m_end, ncl, keep);
+    HIP_TRY(hipMemsetAsync(keep + ncl, 0, 4, ctx->stream));
+    device_scan<uint32_t, SumOp, false>(ctx, "union_scan", keep, u.newidx, ncl + 1, 0u, partials, (uint32_t*)nullptr);
+    if (strict) LAUNCH(ctx, "union_compact", (k_union_compact<true>), grid1d(ncl, 256), 256, (const int32_t*)u.cl.m_start, (const int32_t*)u.cl.m_end,
+                       (const uint32_t*)keep, (const uint32_t*)u.newidx, ncl, u.u_start, u.u_end);
+    else LAUNCH(ctx, "union_compact", (k_union_compact<false>), grid1d(ncl, 256), 256, (const int32_t*)u.cl.m_start, (const int32_t*)u.cl.m_end,
+                (const uint32_t*)keep, (const uint32_t*)u.newidx, ncl, u.u_start, u.u_end);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+// left minus the union of the index.  capacity < 0: library-allocated device outputs (host path), otherwise the
+// caller's buffers; *n_pieces always receives the total.
+int subtract_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* left, const ivj_opts* opts, int64_t capacity, int32_t** o_row,
+                  int32_t** o_start, int32_t** o_end, DevBuf* own, int64_t* n_pieces) {
+    const int64_t n = left->n;
+    *n_pieces = 0;
+    if (n == 0) return IVJ_OK;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    const size_t extra = 2 * align_up((size_t)(n + 1) * 8) + align_up((size_t)(scan_num_tiles(n) + 2) * 8) + 256;
+    UnionView u;
+    IVJ_TRY(union_core(ctx, ix, strict, extra, u));
+    if (ix->n == 0) {
+        // nothing to subtract: union_core took nothing from the arena, reserve the per-row arrays here
+        IVJ_TRY(arena_reserve(ctx, extra + 4096));
+    }
+    long long* cnt = arena_take<long long>(ctx, n + 1);
+    long long* off = arena_take<long long>(ctx, n + 1);
+    long long* partials = arena_take<long long>(ctx, scan_num_tiles(n) + 2);
+    IndexView v = view_of(ix);
+    // an empty index has zeroed segment offsets: every row then keeps its one piece
+    if (strict) LAUNCH(ctx, "subtract_count", (k_subtract_count<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v.seg, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.newidx,
+                       (const long long*)u.u_start, (const long long*)u.u_end, ix->n_contigs, left->contig, left->start, left->end, n, cnt);
+    else LAUNCH(ctx, "subtract_count", (k_subtract_count<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v.seg, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.newidx,
+                (const long long*)u.u_start, (const long long*)u.u_end, ix->n_contigs, left->contig, left->start, left->end, n, cnt);
+    long long* total_dev = partials + scan_num_tiles(n) + 1;
+    device_scan<long long, SumOp, false>(ctx, "subtract_scan", cnt, off, n, 0ll, partials, total_dev);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, total_dev, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int64_t total = ctx->h_total[0];
+    *n_pieces = total;
+    if (total == 0) return IVJ_OK;
+    if (capacity < 0) {
+        const size_t col = align_up((size_t)total * 4);
+        hipError_t e = hipMalloc(&own->p, 3 * col);
+        if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(pieces): ") + hipGetErrorString(e));
+        *o_row = (int32_t*)own->p; *o_start = (int32_t*)((char*)own->p + col); *o_end = (int32_t*)((char*)own->p + 2 * col);
+    } else if (total > capacity) {
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(total) + " pieces");
+    } else if (!*o_row || !*o_start || !*o_end) {
+        return fail(IVJ_EINVAL, "subtract output buffers are NULL");
+    }
+    if (strict) LAUNCH(ctx, "subtract_fill", (k_subtract_fill<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v.seg, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.newidx,
+                       (const long long*)u.u_start, (const long long*)u.u_end, ix->n_contigs, left->contig, left->start, left->end, left->row_id, n,
+                       (const long long*)off, *o_row, *o_start, *o_end);
+    else LAUNCH(ctx, "subtract_fill", (k_subtract_fill<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v.seg, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.newidx,
+                (const long long*)u.u_start, (const long long*)u.u_end, ix->n_contigs, left->contig, left->start, left->end, left->row_id, n,
+                (const long long*)off, *o_row, *o_start, *o_end);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
 }
@@ -871,11 +957,6 @@ struct IndexHolder {
     ivj_index* ix = nullptr;
     ~IndexHolder() { if (ix) ivj_index_free(ix); }
 };
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
-
 }  // namespace
 
 // =============================================================================== C ABI
@@ -1223,6 +1304,59 @@ int ivj_coverage(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, con
     HIP_TRY(hipMemcpyAsync(coverage, out.p, (size_t)probe->n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return IVJ_OK;
+}
+
+// ---------------------------------------------------------------- subtract / complement
+
+int ivj_subtract_dev(ivj_ctx* ctx, ivj_index* right_ix, const ivj_side* left_dev, const ivj_opts* opts, int64_t capacity, int32_t* row_dev,
+                     int32_t* start_dev, int32_t* end_dev, int64_t* n_pieces) {
+    if (!ctx || !right_ix || !n_pieces) return fail(IVJ_EINVAL, "ctx, index or n_pieces is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(left_dev, "left"));
+    if (capacity < 0) return fail(IVJ_EINVAL, "capacity < 0");
+    DeviceGuard g(ctx->device);
+    return subtract_core(ctx, right_ix, left_dev, opts, capacity, &row_dev, &start_dev, &end_dev, nullptr, n_pieces);
+}
+
+void ivj_pieces_free(ivj_pieces* p) {
+    if (!p) return;
+    std::free(p->row); std::free(p->start); std::free(p->end);
+    p->row = p->start = p->end = nullptr; p->n = 0;
+}
+
+int ivj_subtract(ivj_ctx* ctx, const ivj_side* left, const ivj_side* right, const ivj_opts* opts, ivj_pieces* out) {
+    if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
+    std::memset(out, 0, sizeof(*out));
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(left, "left"));
+    IVJ_TRY(check_side(right, "right"));
+    if (left->n == 0) return IVJ_OK;
+    DeviceGuard g(ctx->device);
+    DevSide dl, dr;
+    IVJ_TRY(upload_side(ctx, right, dr));
+    IVJ_TRY(upload_side(ctx, left, dl));
+    IndexHolder h;
+    IVJ_TRY(index_build(ctx, &dr.s, opts, 0, &h.ix));
+    DevBuf own;
+    int32_t *d_row = nullptr, *d_start = nullptr, *d_end = nullptr;
+    int64_t total = 0;
+    IVJ_TRY(subtract_core(ctx, h.ix, &dl.s, opts, -1, &d_row, &d_start, &d_end, &own, &total));
+    if (total == 0) return IVJ_OK;
+    out->row = (int32_t*)std::malloc((size_t)total * 4);
+    out->start = (int32_t*)std::malloc((size_t)total * 4);
+    out->end = (int32_t*)std::malloc((size_t)total * 4);
+    if (!out->row || !out->start || !out->end) { ivj_pieces_free(out); return fail(IVJ_ENOMEM, "host malloc(pieces)"); }
+    hipError_t e = hipMemcpyAsync(out->row, d_row, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out->start, d_start, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out->end, d_end, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ivj_pieces_free(out); return fail(IVJ_EHIP, std::string("D2H(pieces): ") + hipGetErrorString(e)); }
+    out->n = total;
+    return IVJ_OK;
+}
+
+int ivj_complement(ivj_ctx* ctx, const ivj_side* frame, const ivj_side* view, const ivj_opts* opts, ivj_pieces* out) {
+    return ivj_subtract(ctx, view, frame, opts, out);      // the gaps of `frame` inside every view interval
 }
 
 // ---------------------------------------------------------------- row materialisation

@@ -113,4 +113,92 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_coverage(const int32_t* __res
     cov[i] = out;
 }
 
+// ---- subtract / complement -------------------------------------------------------------------------
+// Both are "an interval minus the union of the other side": subtract(df1, df2) per df1 row,
+// complement(df, view) = subtract(view, df).  The union is the cluster sweep with min_dist = 1 (bookended
+// half-open intervals, adjacent closed ones, leave no position between them), compacted to the clusters
+// that hold at least one position; everything is carried as half-open int64 [s, e').
+
+template <bool STRICT>
+__global__ void k_union_flags(const int32_t* __restrict__ m_start, const int32_t* __restrict__ m_end, int64_t n_clusters,
+                              uint32_t* __restrict__ keep) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_clusters) keep[c] = ((long long)m_end[c] + (STRICT ? 0 : 1) > (long long)m_start[c]) ? 1u : 0u;
+}
+
+// newidx = exclusive sum scan of keep (n_clusters + 1 entries: the last one is the number of kept clusters)
+template <bool STRICT>
+__global__ void k_union_compact(const int32_t* __restrict__ m_start, const int32_t* __restrict__ m_end,
+                                const uint32_t* __restrict__ keep, const uint32_t* __restrict__ newidx, int64_t n_clusters,
+                                long long* __restrict__ u_start, long long* __restrict__ u_end) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_clusters && keep[c]) {
+        u_start[newidx[c]] = (long long)m_start[c];
+        u_end[newidx[c]] = (long long)m_end[c] + (STRICT ? 0 : 1);
+    }
+}
+
+// first / last union interval touching [ls, le') of a left row, and the number of pieces that remain
+template <bool STRICT>
+__device__ __forceinline__ int subtract_span(const int32_t* __restrict__ seg, const uint32_t* __restrict__ cid1,
+                                             const uint32_t* __restrict__ newidx, const long long* __restrict__ u_start,
+                                             const long long* __restrict__ u_end, int32_t n_contigs, int32_t c, long long ls,
+                                             long long le, int& first, int& last) {
+    first = 0; last = 0;
+    if (le <= ls) return 0;                                   // the row holds no position
+    if ((uint32_t)c >= (uint32_t)n_contigs) return 1;
+    const int a = seg[c], b = seg[c + 1];
+    if (b <= a) return 1;
+    const int j0 = (int)newidx[cid1[a] - 1u], j1 = (int)newidx[cid1[b - 1]];
+    int lo = j0, hi = j1;
+    while (lo < hi) { const int m = lo + ((hi - lo) >> 1); if (u_end[m] > ls) hi = m; else lo = m + 1; }
+    first = lo;
+    hi = j1;
+    while (lo < hi) { const int m = lo + ((hi - lo) >> 1); if (u_start[m] >= le) hi = m; else lo = m + 1; }
+    last = lo;
+    if (last == first) return 1;
+    return (u_start[first] > ls ? 1 : 0) + (last - first - 1) + (u_end[last - 1] < le ? 1 : 0);
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_subtract_count(const int32_t* __restrict__ seg, const uint32_t* __restrict__ cid1,
+                                                                  const uint32_t* __restrict__ newidx,
+                                                                  const long long* __restrict__ u_start, const long long* __restrict__ u_end,
+                                                                  int32_t n_contigs, const int32_t* __restrict__ lc,
+                                                                  const int32_t* __restrict__ lstart, const int32_t* __restrict__ lend,
+                                                                  int64_t n, long long* __restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * PROBE_THREADS + threadIdx.x;
+    if (i >= n) return;
+    int first, last;
+    cnt[i] = subtract_span<STRICT>(seg, cid1, newidx, u_start, u_end, n_contigs, lc[i], (long long)lstart[i],
+                                   (long long)lend[i] + (STRICT ? 0 : 1), first, last);
+}
+
+// off = exclusive sum scan of cnt; pieces of one left row are written in ascending order
+template <bool STRICT>
+__global__ __launch_bounds__(PROBE_THREADS) void k_subtract_fill(const int32_t* __restrict__ seg, const uint32_t* __restrict__ cid1,
+                                                                 const uint32_t* __restrict__ newidx,
+                                                                 const long long* __restrict__ u_start, const long long* __restrict__ u_end,
+                                                                 int32_t n_contigs, const int32_t* __restrict__ lc,
+                                                                 const int32_t* __restrict__ lstart, const int32_t* __restrict__ lend,
+                                                                 const int32_t* __restrict__ row_id, int64_t n,
+                                                                 const long long* __restrict__ off, int32_t* __restrict__ o_row,
+                                                                 int32_t* __restrict__ o_start, int32_t* __restrict__ o_end) {
+    const int64_t i = (int64_t)blockIdx.x * PROBE_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const long long ls = lstart[i], le = (long long)lend[i] + (STRICT ? 0 : 1);
+    int first, last;
+    const int k = subtract_span<STRICT>(seg, cid1, newidx, u_start, u_end, n_contigs, lc[i], ls, le, first, last);
+    if (k == 0) return;
+    long long o = off[i];
+    const int32_t r = row_id ? row_id[i] : (int32_t)i;
+    auto emit = [&](long long s, long long e) {
+        o_row[o] = r; o_start[o] = (int32_t)s; o_end[o] = (int32_t)(e - (STRICT ? 0 : 1)); ++o;
+    };
+    if (last == first) { emit(ls, le); return; }
+    if (u_start[first] > ls) emit(ls, u_start[first]);
+    for (int j = first; j + 1 < last; ++j) emit(u_end[j], u_start[j + 1]);
+    if (u_end[last - 1] < le) emit(u_end[last - 1], le);
+}
+
 }  // namespace ivj

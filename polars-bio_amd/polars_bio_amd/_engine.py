@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev", "ivj_overlap_fused_dev",
     "ivj_count_overlaps_dev", "ivj_nearest_dev",
     "ivj_materialize_dev", "ivj_overlap_fused_rows_dev", "ivj_take_dev", "ivj_overlap_rows", "ivj_rows_free", "ivj_rows_export_arrow",
+    "ivj_subtract", "ivj_complement", "ivj_pieces_free", "ivj_subtract_dev",
     "ivj_merge", "ivj_merged_free", "ivj_cluster", "ivj_coverage", "ivj_cluster_dev", "ivj_merge_dev", "ivj_coverage_dev",
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
 ]
@@ -63,6 +64,10 @@ class _Rows(C.Structure):
 class _Merged(C.Structure):
     _fields_ = [("n", C.c_int64), ("contig", C.POINTER(C.c_int32)), ("start", C.POINTER(C.c_int32)), ("end", C.POINTER(C.c_int32)),
                 ("n_intervals", C.POINTER(C.c_int64))]
+
+
+class _Pieces(C.Structure):
+    _fields_ = [("n", C.c_int64), ("row", C.POINTER(C.c_int32)), ("start", C.POINTER(C.c_int32)), ("end", C.POINTER(C.c_int32))]
 
 
 class _ArrowSchema(C.Structure):     # Arrow C Data Interface, opaque to Python: only its address is handed on
@@ -128,6 +133,11 @@ def load_library() -> C.CDLL:
         L.ivj_rows_free.argtypes = [C.POINTER(_Rows)]
         L.ivj_rows_free.restype = None
         L.ivj_rows_export_arrow.argtypes = [C.POINTER(_Rows), vp, vp]
+        L.ivj_subtract.argtypes = [vp, P, P, O, C.POINTER(_Pieces)]
+        L.ivj_complement.argtypes = [vp, P, P, O, C.POINTER(_Pieces)]
+        L.ivj_pieces_free.argtypes = [C.POINTER(_Pieces)]
+        L.ivj_pieces_free.restype = None
+        L.ivj_subtract_dev.argtypes = [vp, vp, P, O, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64)]
         L.ivj_merge.argtypes = [vp, P, O, C.c_int64, C.POINTER(_Merged)]
         L.ivj_merged_free.argtypes = [C.POINTER(_Merged)]
         L.ivj_merged_free.restype = None
@@ -306,6 +316,29 @@ class Engine:
         del keep_p, keep_b
         return cov
 
+    def _pieces(self, fn, name, a, b, strict, n_contigs):
+        sa, keep_a = _host_side(*a)
+        sb, keep_b = _host_side(*b)
+        o = make_opts(strict, n_contigs)
+        out = _Pieces()
+        _check(self.L, fn(self.h, C.byref(sa), C.byref(sb), C.byref(o), C.byref(out)), name)
+        del keep_a, keep_b
+        try:
+            n = out.n
+            if n == 0:
+                return np.empty(0, np.int32), np.empty(0, np.int32), np.empty(0, np.int32)
+            return tuple(np.ctypeslib.as_array(getattr(out, k), shape=(n,)).copy() for k in ("row", "start", "end"))
+        finally:
+            self.L.ivj_pieces_free(C.byref(out))
+
+    def subtract(self, left, right, strict: bool, n_contigs: int):
+        """pb.subtract: every left interval minus the union of the right ones -> (left row, start, end) pieces."""
+        return self._pieces(self.L.ivj_subtract, "ivj_subtract", left, right, strict, n_contigs)
+
+    def complement(self, frame, view, strict: bool, n_contigs: int):
+        """pb.complement: the gaps of ``frame`` inside every view interval -> (view row, start, end)."""
+        return self._pieces(self.L.ivj_complement, "ivj_complement", frame, view, strict, n_contigs)
+
     def count_overlaps(self, probe, build, strict: bool, n_contigs: int, table_mode: int = 0) -> np.ndarray:
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
@@ -429,6 +462,16 @@ class Engine:
         if rc == -4:
             return n.value, False
         _check(self.L, rc, "ivj_merge_dev")
+        return n.value, True
+
+    def subtract_dev(self, right_ix: DeviceIndex, left: _Side, opts: _Opts, capacity: int, row_ptr: int, start_ptr: int, end_ptr: int):
+        """-> (n_pieces, fits)"""
+        n = C.c_int64(0)
+        rc = self.L.ivj_subtract_dev(self.h, right_ix.handle, C.byref(left), C.byref(opts), int(capacity), C.c_void_p(row_ptr or None),
+                                     C.c_void_p(start_ptr or None), C.c_void_p(end_ptr or None), C.byref(n))
+        if rc == -4:
+            return n.value, False
+        _check(self.L, rc, "ivj_subtract_dev")
         return n.value, True
 
     def coverage_dev(self, ix: DeviceIndex, probe: _Side, opts: _Opts, coverage_ptr: int):

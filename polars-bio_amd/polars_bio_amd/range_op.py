@@ -26,7 +26,7 @@ from .constants import DEFAULT_INTERVAL_COLUMNS
 
 logger = logging.getLogger("polars_bio_amd")
 
-__all__ = ["overlap", "overlap_batches", "nearest", "count_overlaps", "coverage", "merge", "cluster",
+__all__ = ["overlap", "overlap_batches", "nearest", "count_overlaps", "coverage", "merge", "cluster", "complement", "subtract",
            "FilterOp", "RangeOp", "OverlapOutputMode"]
 
 
@@ -42,6 +42,8 @@ class RangeOp:       # src/option.rs:102-112 (hot-path members only)
     CountOverlapsNaive = 6
     Merge = 7
     Cluster = 8
+    Complement = 9
+    Subtract = 10
 
 
 class OverlapOutputMode:  # src/option.rs:87-92
@@ -326,4 +328,71 @@ def cluster(
     res = res.append_column("cluster", pa.array(cid, type=pa.int64()))
     res = res.append_column("cluster_start", pa.array(cs.astype(np.int64)))
     res = res.append_column("cluster_end", pa.array(ce.astype(np.int64)))
+    return A.from_arrow(res, output_type, zero_based)
+
+
+_I32_MAX = np.iinfo(np.int32).max
+_I64_MAX = np.iinfo(np.int64).max
+
+
+def complement(
+    df,
+    view_df=None,
+    cols: Union[list, None] = ["chrom", "start", "end"],
+    view_cols: Union[list, None] = None,
+    output_type: str = "polars.LazyFrame",
+    projection_pushdown: bool = True,
+):
+    """Gaps between the intervals of ``df`` (reference: range_op.py:717-790; ComplementProvider,
+    src/operation.rs:420-455).  With ``view_df`` the gaps are taken inside its intervals (e.g. one row per
+    chromosome); without it every contig of ``df`` spans [0, i64::MAX) and a warning says so.
+    Output: (chrom, start: Int64, end: Int64) (range_op_helpers.py:124-137)."""
+    _validate_overlap_input(cols, cols, None, ("_1", "_2"), output_type)
+    zero_based = validate_coordinate_system_single(df)
+    cols = list(DEFAULT_INTERVAL_COLUMNS if cols is None else cols)
+    view_cols = cols if view_cols is None else list(view_cols)
+    t = A.to_arrow(df)
+    open_ended = view_df is None
+    if open_ended:
+        logger.warning("No view_df provided -- complement will span [0, i64::MAX) per contig. "
+                       "Pass a view_df with contig boundaries (e.g., chromosome sizes).")
+        chroms = pc.drop_null(pc.unique(A._as_string(t.column(cols[0]))))
+        chroms = chroms.combine_chunks() if isinstance(chroms, pa.ChunkedArray) else chroms
+        # the device works on int32 coordinates: the open end is carried as INT32_MAX and restored below
+        tv = pa.table({view_cols[0]: chroms, view_cols[1]: pa.array(np.zeros(len(chroms), np.int32)),
+                       view_cols[2]: pa.array(np.full(len(chroms), _I32_MAX, np.int32))})
+    else:
+        tv = A.to_arrow(view_df)
+    frame, view, n_contigs, dictionary = A.encode_keys(t, cols, tv, view_cols, with_dictionary=True)
+    row, s, e = default_engine().complement(frame, view, strict=zero_based, n_contigs=n_contigs)
+    e64 = e.astype(np.int64)
+    if open_ended:
+        e64[e == (_I32_MAX if zero_based else _I32_MAX)] = _I64_MAX
+    chrom = pc.take(dictionary, pa.array(view[0][row], type=pa.int32()))
+    res = pa.table({cols[0]: pc.cast(chrom, pa.string()), cols[1]: pa.array(s.astype(np.int64)), cols[2]: pa.array(e64)})
+    return A.from_arrow(res, output_type, zero_based)
+
+
+def subtract(
+    df1,
+    df2,
+    cols1: Union[list, None] = ["chrom", "start", "end"],
+    cols2: Union[list, None] = ["chrom", "start", "end"],
+    output_type: str = "polars.LazyFrame",
+    projection_pushdown: bool = True,
+):
+    """Every df1 interval minus the parts covered by df2 intervals (reference: range_op.py:792-857;
+    SubtractProvider, src/operation.rs:457-510).  Output: the df1 columns, one row per remaining fragment,
+    start / end replaced by the fragment's; the classic triplet comes back with Int64 coordinates
+    (range_op_helpers.py:140-158)."""
+    _validate_overlap_input(cols1, cols2, None, ("_1", "_2"), output_type)
+    zero_based = validate_coordinate_systems(df1, df2)
+    t1, t2, left, right, n_contigs = _prepare(df1, df2, cols1, cols2)
+    c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
+    row, s, e = default_engine().subtract(left, right, strict=zero_based, n_contigs=n_contigs)
+    res = A.take_rows(t1, row)
+    triplet = t1.num_columns == 3
+    for name, arr in ((c1[1], s), (c1[2], e)):
+        typ = pa.int64() if triplet else t1.schema.field(name).type
+        res = res.set_column(res.column_names.index(name), pa.field(name, typ), pc.cast(pa.array(arr, type=pa.int32()), typ))
     return A.from_arrow(res, output_type, zero_based)

@@ -85,6 +85,15 @@ class OracleEngine:
         from oracle import oracle as O
         return O.np_coverage_fast(O.Side(*probe), O.Side(*build), strict)
 
+    def subtract(self, left, right, strict, n_contigs):
+        import numpy as np
+        from oracle import oracle as O
+        r, s, e = O.np_subtract(O.Side(*left), O.Side(*right), strict)
+        return r, s.astype(np.int32), e.astype(np.int32)
+
+    def complement(self, frame, view, strict, n_contigs):
+        return self.subtract(view, frame, strict, n_contigs)
+
     def overlap_batches(self, probe, build, strict, n_contigs, batch_rows=8_000_000):
         import numpy as np
         from oracle import oracle as O

@@ -321,3 +321,33 @@ def test_coverage_fixture_and_semantics(engine):
     df1 = _frame({"chrom": ["chr1", "chr1", "chr9"], "start": [0, 100, 0], "end": [50, 200, 10]}, True)
     df2 = _frame({"chrom": ["chr1", "chr1", "chr1"], "start": [10, 20, 150], "end": [30, 40, 400]}, True)
     assert pb.coverage(df1, df2, output_type="pandas.DataFrame")["coverage"].tolist() == [30, 50, 0]
+
+
+def test_complement_and_subtract_regression_case(engine):
+    """tests/test_partitioned_range_operation_regressions.py:33-47 on its own inputs + the open-ended
+    complement, extra columns through subtract, Weak coordinates."""
+    case = load_cases()["sort_scan"]
+    left, right, view = _frame(case["left"], True), _frame(case["right"], True), _frame(case["view"], True)
+    comp = pb.complement(left, view_df=view, output_type="pandas.DataFrame")
+    assert list(comp.columns) == ["chrom", "start", "end"] and comp["start"].dtype == np.int64
+    assert comp["start"].tolist() == case["complement"]["start"] and comp["end"].tolist() == case["complement"]["end"]
+    sub = pb.subtract(left, right, output_type="pandas.DataFrame")
+    assert sorted(zip(sub["start"], sub["end"])) == sorted(zip(case["subtract"]["start"], case["subtract"]["end"]))
+    assert sub["start"].dtype == np.int64 and (sub["chrom"] == "chr1").all()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        open_ended = pb.complement(left, output_type="pandas.DataFrame")
+    assert open_ended["start"].tolist() == [30] and open_ended["end"].tolist() == [np.iinfo(np.int64).max]
+    df1 = pd.DataFrame({"chrom": ["chr1", "chr1", "chr2", "chr3"], "start": np.array([0, 50, 0, 5], np.int32),
+                        "end": np.array([40, 60, 10, 9], np.int32), "name": ["a", "b", "c", "d"]})
+    df2 = pd.DataFrame({"chrom": ["chr1", "chr1", "chr1", "chr2"], "start": [10, 20, 45, 0], "end": [20, 30, 70, 10]})
+    for d in (df1, df2):
+        d.attrs["coordinate_system_zero_based"] = True
+    sub = pb.subtract(df1, df2, output_type="pandas.DataFrame")
+    assert list(sub.columns) == ["chrom", "start", "end", "name"] and sub["start"].dtype == np.int32
+    # a: [0,40) minus [10,30) (bookended 10-20, 20-30 leave no gap) -> [0,10), [30,40); b, c fully covered; d untouched
+    assert sorted(zip(sub["name"], sub["start"], sub["end"])) == [("a", 0, 10), ("a", 30, 40), ("d", 5, 9)]
+    for d in (df1, df2):
+        d.attrs["coordinate_system_zero_based"] = False     # closed: [0,40] minus [10,20] u [20,30] -> [0,9], [31,40]
+    sub = pb.subtract(df1, df2, output_type="pandas.DataFrame")
+    assert sorted(zip(sub["name"], sub["start"], sub["end"])) == [("a", 0, 9), ("a", 31, 40), ("d", 5, 9)]

@@ -540,8 +540,8 @@ def test_sort_scan_device_entry_points():
     from polars_bio_amd.device_api import DeviceJoin, DeviceSide
     dev = torch.device("cuda", 0)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    probe = synth.make_side(200_000, 42, synth.PROBE_LEN, 24)
-    build = synth.make_side(300_000, 43, synth.DENSE_BUILD_LEN, 24)
+    probe = synth.make_side(100_000, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(60_000, 43, synth.DENSE_BUILD_LEN, 24)
     join = DeviceJoin(0)
     db, dp = DeviceSide(*map(up, build)), DeviceSide(*map(up, probe))
     opts = _engine.make_opts(True, 24)
@@ -564,4 +564,53 @@ def test_sort_scan_device_entry_points():
     cov = torch.empty(dp.n, dtype=torch.int64, device=dev)
     join.engine.coverage_dev(ix, dp.as_c(), opts, cov.data_ptr())
     assert (cov.cpu().numpy() == O.np_coverage_fast(O.Side(*probe), O.Side(*build), True)).all()
+    ix.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_subtract_complement_parity(eng, strict):
+    """HIP subtract / complement == the oracle's sequential sweep, bit-exact incl. the piece order (left row,
+    then position): nested / bookended / zero-length / inverted right rows, absent contigs, empty sides."""
+    rng = np.random.default_rng(31)
+    for (n, m, nc, span, maxlen) in ((4000, 3000, 3, 30_000, 200), (12_000, 20_000, 24, 2_000_000, 3000), (50, 1, 2, 100, 300), (300, 2000, 1, 2000, 30)):
+        left = random_side(rng, n, nc + 1, span, maxlen * 4)
+        rc, rs, re = random_side(rng, m, nc, span, maxlen)
+        if m > 100:
+            f = rng.random(m) < 0.05                         # some inverted rows: they cover nothing
+            rs, re = np.where(f, re, rs).astype(np.int32), np.where(f, rs, re).astype(np.int32)
+        right = (rc, rs, re)
+        er, es, ee = O.np_subtract(O.Side(*left), O.Side(*right), strict)
+        gr, gs, ge = eng.subtract(left, right, strict, nc + 1)
+        assert len(gr) == len(er), (n, m)
+        assert (gr == er).all() and (gs == es).all() and (ge == ee).all(), (n, m)
+        view = (np.arange(nc, dtype=np.int32), np.zeros(nc, np.int32), np.full(nc, span, np.int32))
+        ec, es, ee = O.np_complement(O.Side(*right), O.Side(*view), strict)
+        gr, gs, ge = eng.complement(right, view, strict, nc + 1)
+        assert (view[0][gr] == ec).all() and (gs == es).all() and (ge == ee).all(), (n, m)
+    e0 = (np.empty(0, np.int32),) * 3
+    one = (np.zeros(2, np.int32), np.array([5, 7], np.int32), np.array([9, 30], np.int32))
+    r, s, e = eng.subtract(one, e0, strict, 1)               # nothing to subtract: rows come back whole
+    assert r.tolist() == [0, 1] and s.tolist() == [5, 7] and e.tolist() == [9, 30]
+    assert len(eng.subtract(e0, one, strict, 1)[0]) == 0 and len(eng.subtract(one, one, strict, 1)[0]) == 0
+
+
+def test_subtract_device_entry_point():
+    import torch
+    from polars_bio_amd.device_api import DeviceJoin, DeviceSide
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    left = synth.make_side(40_000, 42, synth.DENSE_BUILD_LEN, 24)
+    right = synth.make_side(120_000, 43, synth.BUILD_LEN, 24)
+    join = DeviceJoin(0)
+    dl, dr = DeviceSide(*map(up, left)), DeviceSide(*map(up, right))
+    opts = _engine.make_opts(True, 24)
+    ix = join.engine.index_build_dev(dr.as_c(), opts)
+    er, es, ee = O.np_subtract(O.Side(*left), O.Side(*right), True)
+    total = len(er)
+    cols = [torch.empty(total, dtype=torch.int32, device=dev) for _ in range(3)]
+    n_small, fits = join.engine.subtract_dev(ix, dl.as_c(), opts, total // 2, *(c.data_ptr() for c in cols))
+    assert not fits and n_small == total > 10_000
+    n_p, fits = join.engine.subtract_dev(ix, dl.as_c(), opts, total, *(c.data_ptr() for c in cols))
+    assert fits and n_p == total
+    assert (cols[0].cpu().numpy() == er).all() and (cols[1].cpu().numpy() == es).all() and (cols[2].cpu().numpy() == ee).all()
     ix.close()
