@@ -73,6 +73,10 @@ def gen_workload(name, scale):
         "overlap_100M_5M_24contig_dense": (100_000_000, 5_000_000, 24, synth.DENSE_BUILD_LEN, "overlap"),
         "nearest_50M_2M_24contig": (50_000_000, 2_000_000, 24, synth.BUILD_LEN, "nearest"),
         "count_200M_200k_24contig": (200_000_000, 200_000, 24, synth.BUILD_LEN, "count_overlaps"),
+        # sort-scan family; not headline workloads
+        "coverage_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "coverage"),
+        "subtract_20M_5M_24contig": (20_000_000, 5_000_000, 24, synth.BUILD_LEN, "subtract"),
+        "merge_100M_24contig": (1, 100_000_000, 24, synth.PROBE_LEN, "merge"),
     }[name]
     n_p, n_b, nc, blen, op = cfg
     n_p, n_b = max(1, int(n_p * scale)), max(1, int(n_b * scale))
@@ -89,8 +93,12 @@ def algorithmic_bytes(op, n_p, n_b, n_out):
     contig = 4 * (n_p + n_b)
     if op == "overlap":
         return 8 * n_p + 8 * n_b + 8 * n_out + contig
-    if op == "count_overlaps":
+    if op in ("count_overlaps", "coverage"):
         return 8 * n_p + 8 * n_b + 8 * n_p + contig
+    if op == "subtract":
+        return 8 * n_p + 8 * n_b + 12 * n_out + contig     # pieces: (row, start, end)
+    if op == "merge":
+        return 12 * n_b + 20 * n_out                       # read the frame, write (contig, start, end, n_intervals)
     return 8 * n_p + 8 * n_b + 12 * n_p + contig      # nearest k=1
 
 
@@ -196,6 +204,20 @@ def main():
             return local, (p, b)
         if op == "count_overlaps":
             return d_probe.n, join.count_overlaps(d_probe, d_build, True, nc)
+        if op == "coverage":
+            if "cov" not in state:
+                state["cov"] = torch.empty(d_probe.n, dtype=torch.int64, device=dev)
+            return d_probe.n, join.coverage(d_probe, d_build, True, nc, out=state["cov"])
+        if op == "subtract":
+            res = join.subtract(d_probe, d_build, True, nc, out=state.get("pieces"))
+            if "pieces" not in state:
+                state["pieces"] = tuple(torch.empty_like(t) for t in res)
+            return int(res[0].shape[0]), res
+        if op == "merge":
+            if "merged" not in state:
+                state["merged"] = tuple(torch.empty(d_build.n, dtype=dt, device=dev) for dt in (torch.int32, torch.int32, torch.int32, torch.int64))
+            res = join.merge(d_build, True, nc, out=state["merged"])
+            return int(res[0].shape[0]), res
         return d_probe.n, join.nearest(d_probe, d_build, True, nc)
 
     def barrier():
@@ -272,16 +294,16 @@ def main():
             log(f"    {k:18s} launches/step {v['launches'] / 3:6.1f}  ms/step {v['ms'] / 3:9.4f}")
 
     cpu = None
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and op in ("overlap", "nearest", "count_overlaps"):
         try:
             cpu = cpu_baseline(op, probe, build, nc, args.cpu_sample)
         except Exception as e:  # the baseline must never take the bench line down
             cpu = {"error": repr(e)}
 
     if rank == 0:
-        unit = "overlap-pairs/s" if op == "overlap" else "probe-rows/s"
+        unit = {"overlap": "overlap-pairs/s", "subtract": "pieces/s", "merge": "merged-intervals/s"}.get(op, "probe-rows/s")
         line = {
-            "metric": "overlap-pairs/sec" if op == "overlap" else f"{op} probe-rows/sec",
+            "metric": "overlap-pairs/sec" if op == "overlap" else f"{op} {unit.replace('/s', '/sec')}",
             "value": total_units / (elapsed / args.steps),
             "unit": unit,
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,

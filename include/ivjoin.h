@@ -145,8 +145,9 @@ int ivj_nearest(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
 /* Sort the build side by (contig, start), derive segment offsets and the
  * prefix-max-of-end array.  with_end_order != 0 additionally sorts the ends
  * (needed by count_overlaps and by nearest with k > 1 or include_overlaps = 0;
- * built on demand otherwise).  The index copies what it needs: the caller's
- * build columns may be released after the call returns. */
+ * built on demand otherwise); bit 1 (value 2): sweep-only index for ivj_merge_dev / ivj_cluster_dev -- the
+ * lookup tables of the join kernels are not built (every other *_dev call then fails with IVJ_ESTATE).
+ * The index copies what it needs: the caller's build columns may be released after the call returns. */
 int ivj_index_build_dev(ivj_ctx* ctx, const ivj_side* build_dev, const ivj_opts* opts,
                         int with_end_order, ivj_index** out);
 void ivj_index_free(ivj_index* ix);

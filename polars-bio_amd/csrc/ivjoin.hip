@@ -120,7 +120,8 @@ struct ivj_index {
     bool has_end_order = false;
     bool has_argmax = false;
     bool has_flat = false;
-    bool has_rec4 = false;     // rec4 is filled on demand (join + materialisation path, flat path)
+    bool has_rec4 = false;
+    bool has_tables = true;    // false: built for merge / cluster only (with_end_order & 2)     // rec4 is filled on demand (join + materialisation path, flat path)
     char* slab = nullptr;      // single allocation holding every array above
     size_t slab_cap = 0;
 };
@@ -163,7 +164,8 @@ T* arena_take(ivj_ctx* ctx, size_t count) {
 
 bool is_probe_kernel(const char* name) {
     return !std::strncmp(name, "overlap_", 8) || !std::strncmp(name, "count_overlaps", 14) || !std::strncmp(name, "nearest", 7) ||
-           !std::strncmp(name, "materialize", 11) || !std::strncmp(name, "take", 4);
+           !std::strncmp(name, "materialize", 11) || !std::strncmp(name, "take", 4) || !std::strncmp(name, "coverage", 8) ||
+           !std::strncmp(name, "subtract_", 9) || !std::strncmp(name, "cluster_", 8);
 }
 void t_begin(ivj_ctx* ctx, const char* name) {
     ctx->t_open = false;
@@ -270,6 +272,11 @@ void take_sort_bufs(ivj_ctx* ctx, int64_t n, SortBufs& sb) {
     sb.kB = arena_take<uint32_t>(ctx, n); sb.vB = arena_take<uint32_t>(ctx, n);
     sb.hist = arena_take<uint32_t>(ctx, hist);
     sb.partials = arena_take<uint32_t>(ctx, scan_num_tiles((int64_t)hist) + 1);
+}
+
+int need_tables(const ivj_index* ix) {
+    if (ix->has_tables) return IVJ_OK;
+    return fail(IVJ_ESTATE, "this index was built for merge / cluster only (with_end_order & 2): it has no lookup tables");
 }
 
 int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
@@ -424,7 +431,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         LAUNCH(ctx, "emit_ep", k_emit_ep, grid1d(n, 256), 256, (const unsigned long long*)comp,
                (const unsigned long long*)comp_max, n, ix->ep);
         // 6. direct-address table over start
-        if (opts->n_contigs > 0) {
+        ix->has_tables = !(with_end_order & 2);
+        if (opts->n_contigs > 0 && ix->has_tables) {
             LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(opts->n_contigs, 256), 256, (const int32_t*)ix->seg,
                    (const int32_t*)ix->b_start, opts->n_contigs, ix->cmeta);
             hipError_t me = hipMemsetAsync(ix->bins, 0, (size_t)ix->bins_len * 4, ctx->stream);
@@ -447,7 +455,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
             r = build_rec4(ctx, ix);
             if (r != IVJ_OK) return cleanup(r);
         }
-        if (with_end_order) { r = build_end_order(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
+        if (with_end_order & 1) { r = build_end_order(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
     } else {
         ix->has_end_order = true;
     }
@@ -554,6 +562,7 @@ int partition_probes(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
 }
 
 int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* n_pairs) {
+    IVJ_TRY(need_tables(ix));
     const int64_t n = probe->n;
     ctx->ov_n = -1;
     if (n == 0 || ix->n == 0) {
@@ -679,6 +688,7 @@ int overlap_fused_fine(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
 // single pass: (bucketing +) fused count/fill into a caller buffer of known capacity
 int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
                   int64_t capacity, int64_t* n_pairs) {
+    IVJ_TRY(need_tables(ix));
     const int64_t n = probe->n;
     ctx->ov_n = -1;                                   // invalidates a pending count -> fill hand-over
     *n_pairs = 0;
@@ -755,10 +765,19 @@ int cluster_core(ivj_ctx* ctx, ivj_index* ix, bool strict, long long min_dist, s
 }
 
 int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* cov) {
+    IVJ_TRY(need_tables(ix));
     const int64_t n = probe->n;
     if (n == 0) return IVJ_OK;
     if (ix->n == 0) { HIP_TRY(hipMemsetAsync(cov, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    const bool bucketed = want_partition(ix, n, opts) && !probe->row_id;
+    if (bucketed) {                                          // before cluster_core: the partition uses the arena too
+        ivj_side plain = *probe;
+        IVJ_TRY(ensure_ov(ctx, n, 1));
+        ctx->ov_n = -1;
+        ivj_opts popts = *opts; popts.partition_mode = 1;
+        IVJ_TRY(partition_probes(ctx, ix, &plain, &popts));
+    }
     Clusters cl;
     const size_t extra = 2 * align_up((size_t)(ix->n + 2) * 8) + align_up((size_t)(scan_num_tiles(ix->n + 1) + 1) * 8);
     IVJ_TRY(cluster_core(ctx, ix, strict, 0, extra, cl));
@@ -769,10 +788,17 @@ int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     else LAUNCH(ctx, "merged_lengths", (k_merged_lengths<false>), grid1d(cl.n, 256), 256, (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, cl.n, len);
     HIP_TRY(hipMemsetAsync(len + cl.n, 0, 8, ctx->stream));      // one padding element: pl[n_clusters] = total
     device_scan<long long, SumOp, false>(ctx, "merged_scan", len, pl, cl.n + 1, 0ll, partials, (long long*)nullptr);
-    if (strict) LAUNCH(ctx, "coverage", (k_coverage<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, (const int32_t*)ix->seg, (const uint32_t*)cl.cid1,
-                       (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, ix->n_contigs, probe->contig, probe->start, probe->end, n, (long long*)cov);
-    else LAUNCH(ctx, "coverage", (k_coverage<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, (const int32_t*)ix->seg, (const uint32_t*)cl.cid1,
-                (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, ix->n_contigs, probe->contig, probe->start, probe->end, n, (long long*)cov);
+    IndexView v = view_of(ix);
+    // large probe sides: bucket them by genomic position first (the table / cluster gathers then stay in L2);
+    // the kernel writes each result to the probe's original row
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *qrow = nullptr;
+    if (bucketed) { qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e; qrow = ctx->pt_row; }
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+    const int64_t per = (int64_t)PROBE_THREADS * COV_ITEMS;
+    if (strict) LAUNCH(ctx, "coverage", (k_coverage<true>), (n + per - 1) / per, PROBE_THREADS, v, (const uint32_t*)cl.cid1,
+                       (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, qc, qs, qe, qrow, n, vec, (long long*)cov);
+    else LAUNCH(ctx, "coverage", (k_coverage<false>), (n + per - 1) / per, PROBE_THREADS, v, (const uint32_t*)cl.cid1,
+                (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, qc, qs, qe, qrow, n, vec, (long long*)cov);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
 }
@@ -780,7 +806,7 @@ int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
 // union of the index's intervals as compacted half-open int64 ranges + everything k_subtract_* needs
 struct UnionView {
     Clusters cl;
-    uint32_t* newidx = nullptr;
+    uint32_t *keep = nullptr, *newidx = nullptr;
     long long *u_start = nullptr, *u_end = nullptr;
 };
 
@@ -789,7 +815,7 @@ int union_core(ivj_ctx* ctx, ivj_index* ix, bool strict, size_t extra_bytes, Uni
     const size_t mine = 2 * align_up((size_t)(n + 2) * 4) + 2 * align_up((size_t)(n + 2) * 8) + align_up((size_t)(scan_num_tiles(n + 1) + 1) * 4);
     IVJ_TRY(cluster_core(ctx, ix, strict, 1, mine + extra_bytes, u.cl));
     if (n == 0) return IVJ_OK;
-    uint32_t* keep = arena_take<uint32_t>(ctx, n + 2);
+    uint32_t* keep = u.keep = arena_take<uint32_t>(ctx, n + 2);
     u.newidx = arena_take<uint32_t>(ctx, n + 2);
     u.u_start = arena_take<long long>(ctx, n + 2);
     u.u_end = arena_take<long long>(ctx, n + 2);
@@ -811,10 +837,22 @@ int union_core(ivj_ctx* ctx, ivj_index* ix, bool strict, size_t extra_bytes, Uni
 // caller's buffers; *n_pieces always receives the total.
 int subtract_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* left, const ivj_opts* opts, int64_t capacity, int32_t** o_row,
                   int32_t** o_start, int32_t** o_end, DevBuf* own, int64_t* n_pieces) {
+    IVJ_TRY(need_tables(ix));
     const int64_t n = left->n;
     *n_pieces = 0;
     if (n == 0) return IVJ_OK;
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    const bool bucketed = want_partition(ix, n, opts) && ix->n > 0;
+    if (bucketed) {                                          // before union_core: the partition uses the arena too
+        ivj_side plain = *left;
+        plain.row_id = nullptr;                              // pt_row = position in the caller's columns
+        IVJ_TRY(ensure_ov(ctx, n, 1));
+        ctx->ov_n = -1;
+        ivj_opts popts = *opts; popts.partition_mode = 1;
+        IVJ_TRY(partition_probes(ctx, ix, &plain, &popts));
+    }
+    const int32_t *lc = left->contig, *lst = left->start, *len_ = left->end, *lpos = nullptr;
+    if (bucketed) { lc = ctx->pt_c; lst = ctx->pt_s; len_ = ctx->pt_e; lpos = ctx->pt_row; }
     const size_t extra = 2 * align_up((size_t)(n + 1) * 8) + align_up((size_t)(scan_num_tiles(n) + 2) * 8) + 256;
     UnionView u;
     IVJ_TRY(union_core(ctx, ix, strict, extra, u));
@@ -827,10 +865,10 @@ int subtract_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* left, const ivj_o
     long long* partials = arena_take<long long>(ctx, scan_num_tiles(n) + 2);
     IndexView v = view_of(ix);
     // an empty index has zeroed segment offsets: every row then keeps its one piece
-    if (strict) LAUNCH(ctx, "subtract_count", (k_subtract_count<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v.seg, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.newidx,
-                       (const long long*)u.u_start, (const long long*)u.u_end, ix->n_contigs, left->contig, left->start, left->end, n, cnt);
-    else LAUNCH(ctx, "subtract_count", (k_subtract_count<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v.seg, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.newidx,
-                (const long long*)u.u_start, (const long long*)u.u_end, ix->n_contigs, left->contig, left->start, left->end, n, cnt);
+    if (strict) LAUNCH(ctx, "subtract_count", (k_subtract_count<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.keep, (const uint32_t*)u.newidx,
+                       (const long long*)u.u_start, (const long long*)u.u_end, lc, lst, len_, lpos, n, cnt);
+    else LAUNCH(ctx, "subtract_count", (k_subtract_count<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.keep, (const uint32_t*)u.newidx,
+                (const long long*)u.u_start, (const long long*)u.u_end, lc, lst, len_, lpos, n, cnt);
     long long* total_dev = partials + scan_num_tiles(n) + 1;
     device_scan<long long, SumOp, false>(ctx, "subtract_scan", cnt, off, n, 0ll, partials, total_dev);
     HIP_TRY(hipMemcpyAsync(ctx->h_total, total_dev, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -848,11 +886,11 @@ int subtract_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* left, const ivj_o
     } else if (!*o_row || !*o_start || !*o_end) {
         return fail(IVJ_EINVAL, "subtract output buffers are NULL");
     }
-    if (strict) LAUNCH(ctx, "subtract_fill", (k_subtract_fill<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v.seg, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.newidx,
-                       (const long long*)u.u_start, (const long long*)u.u_end, ix->n_contigs, left->contig, left->start, left->end, left->row_id, n,
+    if (strict) LAUNCH(ctx, "subtract_fill", (k_subtract_fill<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.keep, (const uint32_t*)u.newidx,
+                       (const long long*)u.u_start, (const long long*)u.u_end, lc, lst, len_, lpos, left->row_id, n,
                        (const long long*)off, *o_row, *o_start, *o_end);
-    else LAUNCH(ctx, "subtract_fill", (k_subtract_fill<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v.seg, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.newidx,
-                (const long long*)u.u_start, (const long long*)u.u_end, ix->n_contigs, left->contig, left->start, left->end, left->row_id, n,
+    else LAUNCH(ctx, "subtract_fill", (k_subtract_fill<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.keep, (const uint32_t*)u.newidx,
+                (const long long*)u.u_start, (const long long*)u.u_end, lc, lst, len_, lpos, left->row_id, n,
                 (const long long*)off, *o_row, *o_start, *o_end);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
@@ -860,6 +898,7 @@ int subtract_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* left, const ivj_o
 
 // fused join + key-column materialisation (k_overlap_fused_rows); same partitioning as overlap_fused
 int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const ivj_rows* rows, int64_t* n_pairs) {
+    IVJ_TRY(need_tables(ix));
     const int64_t n = probe->n;
     const int64_t capacity = rows->n_pairs;
     ctx->ov_n = -1;
@@ -893,6 +932,7 @@ int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
 }
 
 int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* counts) {
+    IVJ_TRY(need_tables(ix));
     const int64_t n = probe->n;
     if (n == 0) return IVJ_OK;
     if (ix->n == 0) { HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
@@ -910,6 +950,7 @@ int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
 }
 
 int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* idx, int64_t* dist, int32_t* nf) {
+    IVJ_TRY(need_tables(ix));
     const int64_t n = probe->n;
     const int k = opts->nearest_k < 1 ? 1 : opts->nearest_k;
     if (n == 0) return IVJ_OK;
@@ -1233,7 +1274,7 @@ int ivj_merge(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_t 
     DevSide ds;
     IVJ_TRY(upload_side(ctx, side, ds));
     IndexHolder h;
-    IVJ_TRY(index_build(ctx, &ds.s, opts, 0, &h.ix));
+    IVJ_TRY(index_build(ctx, &ds.s, opts, 2, &h.ix));      // sweep only: no lookup tables
     Clusters cl;
     IVJ_TRY(cluster_core(ctx, h.ix, opts->filter_op == IVJ_FILTER_STRICT, (long long)min_dist, align_up((size_t)(side->n + 1) * 8), cl));
     long long* cnt = arena_take<long long>(ctx, side->n + 1);
@@ -1266,7 +1307,7 @@ int ivj_cluster(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_
     DevSide ds;
     IVJ_TRY(upload_side(ctx, side, ds));
     IndexHolder h;
-    IVJ_TRY(index_build(ctx, &ds.s, opts, 0, &h.ix));
+    IVJ_TRY(index_build(ctx, &ds.s, opts, 2, &h.ix));      // sweep only: no lookup tables
     DevBuf out;
     const size_t n = (size_t)side->n;
     hipError_t e = hipMalloc(&out.p, align_up(n * 8) + 2 * align_up(n * 4));

@@ -306,20 +306,20 @@ class Engine:
         del keep
         return cid, cs, ce, ncl.value
 
-    def coverage(self, probe, build, strict: bool, n_contigs: int) -> np.ndarray:
+    def coverage(self, probe, build, strict: bool, n_contigs: int, partition_mode: int = 0) -> np.ndarray:
         """pb.coverage: covered positions of every probe row (int64, probe order)."""
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
-        o = make_opts(strict, n_contigs)
+        o = make_opts(strict, n_contigs, partition_mode=partition_mode)
         cov = np.empty(ps.n, np.int64)
         _check(self.L, self.L.ivj_coverage(self.h, C.byref(ps), C.byref(bs), C.byref(o), cov.ctypes.data), "ivj_coverage")
         del keep_p, keep_b
         return cov
 
-    def _pieces(self, fn, name, a, b, strict, n_contigs):
+    def _pieces(self, fn, name, a, b, strict, n_contigs, partition_mode=0):
         sa, keep_a = _host_side(*a)
         sb, keep_b = _host_side(*b)
-        o = make_opts(strict, n_contigs)
+        o = make_opts(strict, n_contigs, partition_mode=partition_mode)
         out = _Pieces()
         _check(self.L, fn(self.h, C.byref(sa), C.byref(sb), C.byref(o), C.byref(out)), name)
         del keep_a, keep_b
@@ -331,13 +331,14 @@ class Engine:
         finally:
             self.L.ivj_pieces_free(C.byref(out))
 
-    def subtract(self, left, right, strict: bool, n_contigs: int):
-        """pb.subtract: every left interval minus the union of the right ones -> (left row, start, end) pieces."""
-        return self._pieces(self.L.ivj_subtract, "ivj_subtract", left, right, strict, n_contigs)
+    def subtract(self, left, right, strict: bool, n_contigs: int, partition_mode: int = 0):
+        """pb.subtract: every left interval minus the union of the right ones -> (left row, start, end) pieces.
+        partition_mode 0 auto / 1 bucket the left rows first / 2 never: same result, same order."""
+        return self._pieces(self.L.ivj_subtract, "ivj_subtract", left, right, strict, n_contigs, partition_mode)
 
-    def complement(self, frame, view, strict: bool, n_contigs: int):
+    def complement(self, frame, view, strict: bool, n_contigs: int, partition_mode: int = 0):
         """pb.complement: the gaps of ``frame`` inside every view interval -> (view row, start, end)."""
-        return self._pieces(self.L.ivj_complement, "ivj_complement", frame, view, strict, n_contigs)
+        return self._pieces(self.L.ivj_complement, "ivj_complement", frame, view, strict, n_contigs, partition_mode)
 
     def count_overlaps(self, probe, build, strict: bool, n_contigs: int, table_mode: int = 0) -> np.ndarray:
         ps, keep_p = _host_side(*probe)
@@ -388,8 +389,10 @@ class Engine:
     def dev_side(contig_ptr: int, start_ptr: int, end_ptr: int, n: int, row_id_ptr: int = 0) -> _Side:
         return _Side(contig_ptr or None, start_ptr or None, end_ptr or None, n, row_id_ptr or None)
 
-    def index_build_dev(self, build: _Side, opts: _Opts, with_end_order: bool = False) -> DeviceIndex:
+    def index_build_dev(self, build: _Side, opts: _Opts, with_end_order: bool = False, sweep_only: bool = False) -> DeviceIndex:
+        """sweep_only: index for merge_dev / cluster_dev only (no lookup tables)."""
         h = C.c_void_p()
+        with_end_order = int(bool(with_end_order)) | (2 if sweep_only else 0)
         _check(self.L, self.L.ivj_index_build_dev(self.h, C.byref(build), C.byref(opts), int(with_end_order), C.byref(h)),
                "ivj_index_build_dev")
         return DeviceIndex(self, h, build.n)

@@ -134,6 +134,58 @@ class DeviceJoin:
                 ix.close()
         return out
 
+    # ---- sort-scan family ---------------------------------------------
+    def coverage(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None, out=None):
+        """Covered positions of every probe row by the union of the build side -> int64 tensor."""
+        torch = self.torch
+        opts = make_opts(strict, n_contigs)
+        own = index is None
+        ix = self.engine.index_build_dev(build.as_c(), opts, False) if own else index
+        try:
+            cov = out if out is not None else torch.empty(probe.n, dtype=torch.int64, device=probe.start.device)
+            self.engine.coverage_dev(ix, probe.as_c(), opts, cov.data_ptr())
+        finally:
+            if own:
+                ix.close()
+        return cov
+
+    def merge(self, frame: DeviceSide, strict: bool, n_contigs: int, min_dist: int = 0, out=None):
+        """Merged intervals of one frame -> (contig, start, end int32, n_intervals int64) tensors.
+        ``out``: optional preallocated 4-tuple (views of the first n_merged elements are returned)."""
+        torch = self.torch
+        opts = make_opts(strict, n_contigs)
+        ix = self.engine.index_build_dev(frame.as_c(), opts, False, sweep_only=True)
+        try:
+            if out is None:
+                dev = frame.start.device
+                out = tuple(torch.empty(frame.n, dtype=dt, device=dev) for dt in (torch.int32, torch.int32, torch.int32, torch.int64))
+            n, fits = self.engine.merge_dev(ix, opts, min_dist, min(int(t.numel()) for t in out), *(t.data_ptr() for t in out))
+            if not fits:
+                raise ValueError(f"merge output buffers hold fewer than {n} intervals")
+        finally:
+            ix.close()
+        return tuple(t[:n] for t in out)
+
+    def subtract(self, left: DeviceSide, right: DeviceSide, strict: bool, n_contigs: int, index=None, out=None):
+        """left minus the union of right -> (left row, start, end) int32 tensors of the remaining pieces."""
+        torch = self.torch
+        opts = make_opts(strict, n_contigs)
+        own = index is None
+        ix = self.engine.index_build_dev(right.as_c(), opts, False) if own else index
+        try:
+            if out is not None:
+                n, fits = self.engine.subtract_dev(ix, left.as_c(), opts, min(int(t.numel()) for t in out), *(t.data_ptr() for t in out))
+                if fits:
+                    return tuple(t[:n] for t in out)
+            else:
+                n, _ = self.engine.subtract_dev(ix, left.as_c(), opts, 0, 0, 0, 0)
+            out = tuple(torch.empty(n, dtype=torch.int32, device=left.start.device) for _ in range(3))
+            n, fits = self.engine.subtract_dev(ix, left.as_c(), opts, n, *(t.data_ptr() for t in out))
+        finally:
+            if own:
+                ix.close()
+        return out
+
     def nearest(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, k: int = 1,
                 include_overlaps: bool = True, index=None):
         torch = self.torch

@@ -523,8 +523,9 @@ def test_merge_cluster_coverage_parity(eng, strict):
         pc, ps, pe = random_side(rng, max(n // 2, 3), nc + 1, span, maxlen * 3)
         probe = (pc, (ps - span // 4).astype(np.int32), (pe - span // 4).astype(np.int32))
         exp = O.np_coverage_fast(O.Side(*probe), O.Side(*frame), strict)
-        got = eng.coverage(probe, frame, strict, nc)
-        assert got.dtype == np.int64 and (got == exp).all(), n
+        for pm in (2, 1):                                    # probe order / bucketed probes: same result
+            got = eng.coverage(probe, frame, strict, nc, partition_mode=pm)
+            assert got.dtype == np.int64 and (got == exp).all(), (n, pm)
         if n <= 5000:
             assert (got == O.np_coverage_brute(O.Side(*probe), O.Side(*frame), strict)).all()
     e0 = (np.empty(0, np.int32),) * 3
@@ -580,12 +581,13 @@ def test_subtract_complement_parity(eng, strict):
             rs, re = np.where(f, re, rs).astype(np.int32), np.where(f, rs, re).astype(np.int32)
         right = (rc, rs, re)
         er, es, ee = O.np_subtract(O.Side(*left), O.Side(*right), strict)
-        gr, gs, ge = eng.subtract(left, right, strict, nc + 1)
-        assert len(gr) == len(er), (n, m)
-        assert (gr == er).all() and (gs == es).all() and (ge == ee).all(), (n, m)
+        for pm in (2, 1):                                    # probe order / bucketed rows: same pieces, same order
+            gr, gs, ge = eng.subtract(left, right, strict, nc + 1, partition_mode=pm)
+            assert len(gr) == len(er), (n, m, pm)
+            assert (gr == er).all() and (gs == es).all() and (ge == ee).all(), (n, m, pm)
         view = (np.arange(nc, dtype=np.int32), np.zeros(nc, np.int32), np.full(nc, span, np.int32))
         ec, es, ee = O.np_complement(O.Side(*right), O.Side(*view), strict)
-        gr, gs, ge = eng.complement(right, view, strict, nc + 1)
+        gr, gs, ge = eng.complement(right, view, strict, nc + 1, partition_mode=1)
         assert (view[0][gr] == ec).all() and (gs == es).all() and (ge == ee).all(), (n, m)
     e0 = (np.empty(0, np.int32),) * 3
     one = (np.zeros(2, np.int32), np.array([5, 7], np.int32), np.array([9, 30], np.int32))
@@ -614,3 +616,26 @@ def test_subtract_device_entry_point():
     assert fits and n_p == total
     assert (cols[0].cpu().numpy() == er).all() and (cols[1].cpu().numpy() == es).all() and (cols[2].cpu().numpy() == ee).all()
     ix.close()
+
+
+def test_sweep_only_index_refuses_join_calls(eng):
+    """with_end_order & 2: an index for merge / cluster carries no lookup tables; join entry points say so."""
+    frame = synth.make_side(5000, 43, synth.BUILD_LEN, 3)
+    ptrs = [eng.dev_alloc(4 * 5000) for _ in range(3)]
+    for p, col in zip(ptrs, frame):
+        eng.h2d(p, np.ascontiguousarray(col, np.int32))
+    side = eng.dev_side(ptrs[0], ptrs[1], ptrs[2], 5000)
+    opts = _engine.make_opts(True, 3)
+    ix = eng.index_build_dev(side, opts, sweep_only=True)
+    with pytest.raises(_engine.EngineError, match="merge / cluster only"):
+        eng.overlap_count_dev(ix, side, opts)
+    out = [eng.dev_alloc(8 * 5000) for _ in range(4)]
+    n, fits = eng.merge_dev(ix, opts, 0, 5000, *out)
+    _, _, _, (mc, ms, me, mn) = O.np_cluster(O.Side(*frame), True, 0)
+    assert fits and n == len(mc)
+    got = np.empty(n, np.int32)
+    eng.d2h(got, out[1])
+    assert (got == ms).all()
+    ix.close()
+    for p in ptrs + out:
+        eng.dev_free(p)

@@ -18,6 +18,10 @@ for stage in "$@"; do
     c2fine) echo "== bench config2 fine"; timeout 1200 python bench.py --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --partition-mode 3 --no-cpu-baseline 2>gpurun_out/bench_c2fine.err | tee gpurun_out/bench_c2fine.json ;;
     fusedtest) echo "== fused tests"; timeout 900 python -m pytest tests -m gpu -q -x -k "fused" 2>&1 | tail -15 ;;
     c3rows) echo "== bench config3 + row materialisation"; timeout 1200 python bench.py --steps 10 --warmup 2 --materialize --no-cpu-baseline --kernel-table 2>gpurun_out/bench_c3rows.err | tee gpurun_out/bench_c3rows.json; tail -22 gpurun_out/bench_c3rows.err | head -6 ;;
+    sortscan) echo "== bench sort-scan family";
+      for w in coverage_100M_5M_24contig subtract_20M_5M_24contig merge_100M_24contig; do
+        timeout 900 python bench.py --workload $w --steps 5 --warmup 2 --kernel-table 2>gpurun_out/bench_$w.err | tee gpurun_out/bench_$w.json | cut -c1-400; grep -A12 "per-kernel" gpurun_out/bench_$w.err | head -14;
+      done ;;
     c3two) echo "== bench config3 two-pass"; timeout 1200 python bench.py --steps 10 --warmup 2 --two-pass --no-cpu-baseline 2>gpurun_out/bench_c3two.err | tee gpurun_out/bench_c3two.json ;;
     c3dense) echo "== bench config3 dense"; timeout 1200 python bench.py --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --kernel-table --no-cpu-baseline 2>gpurun_out/bench_c3d.err | tee gpurun_out/bench_c3d.json; tail -22 gpurun_out/bench_c3d.err ;;
     c4) echo "== bench config4 nearest"; timeout 1200 python bench.py --workload nearest_50M_2M_24contig --steps 10 --warmup 2 --kernel-table 2>gpurun_out/bench_c4.err | tee gpurun_out/bench_c4.json; tail -22 gpurun_out/bench_c4.err ;;
