@@ -2,6 +2,8 @@
 """Aggregate rocprofv3 --pmc counter_collection CSVs per kernel (mean per launch).
 
 usage: pmc_summary.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass>
+       pmc_summary.py --traffic <workload> <note> <FETCH_SIZE dir> <WRITE_SIZE dir>   (the profiles/*pmc_traffic*.json form
+                                                                                     bench.py reads roofline.traffic from)
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  gfx950 correction from
 /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-byte streaming
 requests at 64 bytes, so the read side of a wide coalesced stream is 2x the reported value;
@@ -29,7 +31,28 @@ def load(d):
     return acc
 
 
+def traffic(workload, note, dirs):
+    per = {}
+    for d in dirs:
+        for name, ctrs in load(d).items():
+            short = name.split("(")[0].replace("void ", "").strip()
+            e = per.setdefault(short, {})
+            for ctr, vals in ctrs.items():
+                e[ctr] = (len(vals), sum(vals))
+    kernels = {}
+    for k, e in per.items():
+        fn, fs = e.get("FETCH_SIZE", (0, 0.0))
+        wn, ws = e.get("WRITE_SIZE", (0, 0.0))
+        n = max(fn, wn, 1)
+        f_kib, w_kib = fs / max(fn, 1), ws / max(wn, 1)
+        kernels[k] = {"launches_sampled": n, "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
+                      "hbm_bytes_per_launch_corrected": int((2 * f_kib + w_kib) * 1024)}
+    print(json.dumps({"_note": note, "workload": workload, "kernels": kernels}, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
+        return traffic(sys.argv[2], sys.argv[3], sys.argv[4:])
     out = {}
     for d in sys.argv[1:]:
         for name, ctrs in load(d).items():
