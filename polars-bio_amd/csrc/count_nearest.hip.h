@@ -93,8 +93,10 @@ template <bool STRICT, int N>
 __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, const int32_t* __restrict__ pc,
                                                               const int32_t* __restrict__ ps,
                                                               const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
+                                                              const int32_t* __restrict__ out_row,
                                                               int32_t* __restrict__ out_idx, long long* __restrict__ out_dist,
                                                               int32_t* __restrict__ out_n) {
+    // out_row: the probes are a bucketed permutation (partition.hip.h); results go to the original rows
     const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
     int32_t c[N], s[N], e[N];
     load_items(pc, i0, n, vec_ok, -1, c);
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
                 else if (have_r) { idx = ix.b_row[hi[k]]; dist = dr; found = 1; }
             }
         }
-        out_idx[i0 + k] = idx; out_dist[i0 + k] = dist; out_n[i0 + k] = found;
+        const int64_t o = out_row ? (int64_t)out_row[i0 + k] : i0 + k;
+        out_idx[o] = idx; out_dist[o] = dist; out_n[o] = found;
     }
 }
 
@@ -139,14 +142,16 @@ template <bool STRICT>
 __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_general(IndexView ix, const int32_t* __restrict__ pc,
                                                                    const int32_t* __restrict__ ps,
                                                                    const int32_t* __restrict__ pe, int64_t n, int kk,
-                                                                   int include_overlaps, int32_t* __restrict__ out_idx,
+                                                                   int include_overlaps, const int32_t* __restrict__ out_row,
+                                                                   int32_t* __restrict__ out_idx,
                                                                    long long* __restrict__ out_dist,
                                                                    int32_t* __restrict__ out_n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t qs = ps[i], qe = pe[i];
-    int32_t* oi = out_idx + i * kk;
-    long long* od = out_dist + i * kk;
+    const int64_t o = out_row ? (int64_t)out_row[i] : i;
+    int32_t* oi = out_idx + o * kk;
+    long long* od = out_dist + o * kk;
     for (int r = 0; r < kk; ++r) { oi[r] = -1; od[r] = -1; }
     int a, b;
     seg_bounds(ix, pc[i], true, a, b);
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_general(IndexView ix,
             else { oi[found] = ix.b_row[rp]; od[found] = dr; ++found; ++rp; }
         }
     }
-    out_n[i] = found;
+    out_n[o] = found;
 }
 
 }  // namespace ivj

@@ -81,6 +81,7 @@ struct ivj_ctx {
     bool ov_part = false;
     int32_t *pt_c = nullptr, *pt_s = nullptr, *pt_e = nullptr, *pt_row = nullptr;
     int32_t *pu_c = nullptr, *pu_s = nullptr, *pu_e = nullptr, *pu_row = nullptr;   // second set (two-level bucketing)
+    uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
     bool part_attr_set = false;
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
@@ -469,7 +470,7 @@ int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one 
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     const size_t col = align_up((size_t)n * 4);
     const size_t need = (size_t)(2 + 4 * with_part) * col + align_up((size_t)(tiles + 2) * 8) +
-                        align_up((size_t)(scan_num_tiles(tiles) + 2) * 8) + 1024;
+                        align_up((size_t)(scan_num_tiles(tiles) + 2) * 8) + align_up((PART_BUCKETS + 1) * 4) + 1024;
     if (need > ctx->ov_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->ov_buf) HIP_TRY(hipFree(ctx->ov_buf));
@@ -494,6 +495,7 @@ int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one 
         ctx->pu_e = (int32_t*)p; p += col;
         ctx->pu_row = (int32_t*)p; p += col;
     }
+    ctx->pt_bstart = (uint32_t*)p; p += align_up((PART_BUCKETS + 1) * 4);
     ctx->ov_tile = (long long*)p;
     return IVJ_OK;
 }
@@ -525,6 +527,9 @@ int partition_pass(ivj_ctx* ctx, ivj_index* ix, bool strict, const int32_t* sc, 
     if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, sc, se, n, packed, blk, ntiles, hvec);
     else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, sc, se, n, packed, blk, ntiles, hvec);
     device_scan<uint32_t, SumOp, false>(ctx, "part_scan", blk, blk, (int64_t)hist, 0u, partials, (uint32_t*)nullptr);
+    // bucket b starts at blk[b * ntiles] (bucket-major scan); kept for the inverse permutation (k_unpermute)
+    HIP_TRY(hipMemcpy2DAsync(ctx->pt_bstart, 4, blk, (size_t)ntiles * 4, 4, PART_BUCKETS, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->pt_bstart + PART_BUCKETS), (int)n, 1, ctx->stream));
     t_begin(ctx, "part_scatter");
     if (strict)
         hipLaunchKernelGGL((k_part_scatter<true>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, sc, ss, se, srow, n, packed,
@@ -731,6 +736,13 @@ struct DevBuf {                   // owning device allocation of the host-buffer
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+// per-probe results of a kernel that ran over the bucketed probes (pt_*) -> original row order
+int unpermute(ivj_ctx* ctx, int64_t n, const UnpermuteCols& cols) {
+    LAUNCH(ctx, "unpermute", k_unpermute, (n + UNP_TILE - 1) / UNP_TILE, UNP_THREADS, (const int32_t*)ctx->pt_row, (const uint32_t*)ctx->pt_bstart, n, cols);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
 // ---- sort-scan family (sortscan.hip.h) ------------------------------------------------------------
 struct Clusters {                 // arena-backed (valid until the next arena_reserve on this context)
     int64_t n = 0;                // number of clusters
@@ -779,7 +791,8 @@ int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         IVJ_TRY(partition_probes(ctx, ix, &plain, &popts));
     }
     Clusters cl;
-    const size_t extra = 2 * align_up((size_t)(ix->n + 2) * 8) + align_up((size_t)(scan_num_tiles(ix->n + 1) + 1) * 8);
+    const size_t extra = 2 * align_up((size_t)(ix->n + 2) * 8) + align_up((size_t)(scan_num_tiles(ix->n + 1) + 1) * 8) +
+                         (bucketed ? align_up((size_t)n * 8) : 0);
     IVJ_TRY(cluster_core(ctx, ix, strict, 0, extra, cl));
     long long* len = arena_take<long long>(ctx, ix->n + 2);
     long long* pl = arena_take<long long>(ctx, ix->n + 2);
@@ -795,10 +808,16 @@ int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     if (bucketed) { qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e; qrow = ctx->pt_row; }
     const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
     const int64_t per = (int64_t)PROBE_THREADS * COV_ITEMS;
+    long long* o_cov = bucketed ? arena_take<long long>(ctx, n) : (long long*)cov;    // bucket order, un-permuted below
+    (void)qrow;
     if (strict) LAUNCH(ctx, "coverage", (k_coverage<true>), (n + per - 1) / per, PROBE_THREADS, v, (const uint32_t*)cl.cid1,
-                       (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, qc, qs, qe, qrow, n, vec, (long long*)cov);
+                       (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, qc, qs, qe, (const int32_t*)nullptr, n, vec, o_cov);
     else LAUNCH(ctx, "coverage", (k_coverage<false>), (n + per - 1) / per, PROBE_THREADS, v, (const uint32_t*)cl.cid1,
-                (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, qc, qs, qe, qrow, n, vec, (long long*)cov);
+                (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, qc, qs, qe, (const int32_t*)nullptr, n, vec, o_cov);
+    if (bucketed) {
+        UnpermuteCols uc{{o_cov, nullptr, nullptr}, {cov, nullptr, nullptr}, {8, 0, 0}, 1, nullptr};
+        IVJ_TRY(unpermute(ctx, n, uc));
+    }
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
 }
@@ -954,21 +973,44 @@ int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_op
     const int64_t n = probe->n;
     const int k = opts->nearest_k < 1 ? 1 : opts->nearest_k;
     if (n == 0) return IVJ_OK;
-    IndexView v = view_of(ix);
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
-    if (k == 1 && opts->include_overlaps) {
-        IVJ_TRY(build_argmax(ctx, ix));
-        v = view_of(ix);
+    const bool k1 = k == 1 && opts->include_overlaps;
+    if (k1) IVJ_TRY(build_argmax(ctx, ix));
+    else IVJ_TRY(build_end_order(ctx, ix));
+    // large probe sides: bucket them by genomic position first (every gather of the kernel then stays in the
+    // XCD L2s); the kernels write each result to the probe's original row
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *qrow = nullptr;
+    if (want_partition(ix, n, opts) && ix->n > 0) {
+        ivj_side plain = *probe;
+        plain.row_id = nullptr;
+        IVJ_TRY(ensure_ov(ctx, n, 1));
+        ctx->ov_n = -1;
+        ivj_opts popts = *opts; popts.partition_mode = 1;
+        IVJ_TRY(partition_probes(ctx, ix, &plain, &popts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e; qrow = ctx->pt_row;
+    }
+    IndexView v = view_of(ix);
+    if (k1) {
         constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT;
         const int64_t tiles = (n + NT - 1) / NT;
-        const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
-        if (strict) LAUNCH(ctx, "nearest_k1", (k_nearest_k1<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, idx, (long long*)dist, nf);
-        else LAUNCH(ctx, "nearest_k1", (k_nearest_k1<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, idx, (long long*)dist, nf);
+        const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+        int32_t *o_idx = idx, *o_nf = nf;
+        long long* o_dist = (long long*)dist;
+        if (qrow) {
+            // bucket-order results in scratch, then ONE coalesced inverse permutation of the three columns
+            IVJ_TRY(arena_reserve(ctx, 2 * align_up((size_t)n * 4) + align_up((size_t)n * 8) + 4096));
+            o_idx = arena_take<int32_t>(ctx, n); o_nf = arena_take<int32_t>(ctx, n); o_dist = arena_take<long long>(ctx, n);
+        }
+        if (strict) LAUNCH(ctx, "nearest_k1", (k_nearest_k1<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, (const int32_t*)nullptr, o_idx, o_dist, o_nf);
+        else LAUNCH(ctx, "nearest_k1", (k_nearest_k1<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, (const int32_t*)nullptr, o_idx, o_dist, o_nf);
+        if (qrow) {
+            // n_found of k = 1 is "a row was found": derived from the row index while it is written
+            UnpermuteCols uc{{o_idx, o_dist, nullptr}, {idx, dist, nullptr}, {4, 8, 0}, 2, nf};
+            IVJ_TRY(unpermute(ctx, n, uc));
+        }
     } else {
-        IVJ_TRY(build_end_order(ctx, ix));
-        v = view_of(ix);
-        if (strict) LAUNCH(ctx, "nearest_general", (k_nearest_general<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, k, (int)opts->include_overlaps, idx, (long long*)dist, nf);
-        else LAUNCH(ctx, "nearest_general", (k_nearest_general<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, k, (int)opts->include_overlaps, idx, (long long*)dist, nf);
+        if (strict) LAUNCH(ctx, "nearest_general", (k_nearest_general<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, qc, qs, qe, n, k, (int)opts->include_overlaps, qrow, idx, (long long*)dist, nf);
+        else LAUNCH(ctx, "nearest_general", (k_nearest_general<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, qc, qs, qe, n, k, (int)opts->include_overlaps, qrow, idx, (long long*)dist, nf);
     }
     HIP_TRY(hipGetLastError());
     return IVJ_OK;

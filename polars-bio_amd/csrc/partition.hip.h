@@ -221,4 +221,88 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(IndexView ix, con
 #undef IVJ_PART_EXCHANGE
 }
 
+// ---- inverse of the one-level partition for per-probe results -------------------------------------------
+// A kernel that ran over the bucketed probes leaves its per-probe results in bucket order.  Scattering them
+// to the original rows costs one partial-line HBM write per value (measured: ~2 ms per 50 M values and
+// column).  The partition is stable, so inside every bucket the original row ids ascend: the values of the
+// output rows [r0, r0 + UNP_TILE) are 256 short CONTIGUOUS runs (one per bucket, found by two bound searches
+// on the row-id column).  A workgroup reads those runs coalesced, places them in LDS by row and writes the
+// tile out coalesced.  Up to three columns of 4- or 8-byte values share the searches.
+constexpr int UNP_THREADS = 256;
+constexpr int UNP_TILE = 8192;
+
+struct UnpermuteCols {
+    const void* src[3];
+    void* dst[3];
+    int bytes[3];     // 4 or 8
+    int ncols;
+    int32_t* flag_dst;   // optional: flag_dst[row] = (int32 value of column 0 >= 0), written with column 0
+};
+
+__global__ __launch_bounds__(UNP_THREADS) void k_unpermute(const int32_t* __restrict__ rows, const uint32_t* __restrict__ bstart,
+                                                           int64_t n, UnpermuteCols cols) {
+    __shared__ int l_lo[PART_BUCKETS];
+    __shared__ int l_pre[PART_BUCKETS + 1];
+    __shared__ int lds_i[UNP_THREADS / kWave];
+    __shared__ __align__(16) uint8_t l_bucket[UNP_TILE];      // bucket of the t-th element of the concatenated runs
+    __shared__ unsigned long long stage[UNP_TILE];
+    static_assert(PART_BUCKETS == UNP_THREADS, "one thread per bucket");
+    static_assert(UNP_TILE == UNP_THREADS * 32, "32 elements per thread");
+    const long long r0 = (long long)blockIdx.x * UNP_TILE;
+    const long long r1 = (r0 + UNP_TILE) < n ? (r0 + UNP_TILE) : n;
+    const int t_all = (int)(r1 - r0);                          // every row of the tile sits in exactly one bucket
+    int cnt;
+    {
+        const int b = threadIdx.x;
+        const int s = (int)bstart[b], e = (int)bstart[b + 1];
+        int lo = s, hi = e;
+        while (lo < hi) { const int m = lo + ((hi - lo) >> 1); if ((long long)rows[m] < r0) lo = m + 1; else hi = m; }
+        const int first = lo;
+        hi = e;
+        while (lo < hi) { const int m = lo + ((hi - lo) >> 1); if ((long long)rows[m] < r1) lo = m + 1; else hi = m; }
+        cnt = lo - first;
+        l_lo[b] = first;
+    }
+    // element t of the concatenated runs belongs to the last bucket whose prefix is <= t: mark + max-scan
+    int tot;
+    const int pre = block_exclusive_scan(cnt, SumOp(), 0, lds_i, &tot);
+    l_pre[threadIdx.x] = pre;
+    uint4* lb4 = reinterpret_cast<uint4*>(l_bucket);
+    lb4[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    lb4[threadIdx.x + UNP_THREADS] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    if (cnt > 0) l_bucket[pre] = (uint8_t)threadIdx.x;
+    __syncthreads();
+    {
+        // thread owns 32 consecutive entries; the running max starts from the buckets before them
+        uint32_t own = 0;
+        uint8_t* mine = l_bucket + threadIdx.x * 32;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) own = own > mine[j] ? own : mine[j];
+        int dummy;
+        uint32_t run = (uint32_t)block_exclusive_scan((int)own, MaxOp(), 0, lds_i, &dummy);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { run = run > mine[j] ? run : mine[j]; mine[j] = (uint8_t)run; }
+    }
+    __syncthreads();
+    for (int c = 0; c < cols.ncols; ++c) {
+        const bool wide = cols.bytes[c] == 8;
+        const unsigned long long* s8 = reinterpret_cast<const unsigned long long*>(cols.src[c]);
+        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(cols.src[c]);
+#pragma unroll 4
+        for (int t = threadIdx.x; t < t_all; t += UNP_THREADS) {
+            const int b = l_bucket[t];
+            const int p = l_lo[b] + (t - l_pre[b]);
+            const int r = rows[p] - (int)r0;
+            stage[r] = wide ? s8[p] : (unsigned long long)s4[p];
+        }
+        __syncthreads();
+        if (wide) for (int i = threadIdx.x; i < t_all; i += UNP_THREADS) reinterpret_cast<unsigned long long*>(cols.dst[c])[r0 + i] = stage[i];
+        else for (int i = threadIdx.x; i < t_all; i += UNP_THREADS) reinterpret_cast<uint32_t*>(cols.dst[c])[r0 + i] = (uint32_t)stage[i];
+        if (c == 0 && cols.flag_dst)
+            for (int i = threadIdx.x; i < t_all; i += UNP_THREADS) cols.flag_dst[r0 + i] = ((int32_t)(uint32_t)stage[i] >= 0) ? 1 : 0;
+        __syncthreads();
+    }
+}
+
 }  // namespace ivj

@@ -351,12 +351,13 @@ class Engine:
         return counts
 
     def nearest(self, probe, build, strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True,
-                table_mode: int = 0):
+                table_mode: int = 0, partition_mode: int = 0):
+        """partition_mode 0 auto / 1 bucket the probe side first / 2 never: same result, probe order kept."""
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
         if k < 1:
             raise ValueError("k must be >= 1")
-        o = make_opts(strict, n_contigs, k, include_overlaps, table_mode=table_mode)
+        o = make_opts(strict, n_contigs, k, include_overlaps, table_mode=table_mode, partition_mode=partition_mode)
         idx = np.empty((ps.n, k), np.int32)
         dist = np.empty((ps.n, k), np.int64)
         nf = np.empty(ps.n, np.int32)

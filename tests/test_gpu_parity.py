@@ -77,11 +77,11 @@ def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1
         assert (eng.count_overlaps(probe, build, strict, n_contigs, table_mode=tm) == ec).all(), tm
     for k, inc in nearest_cfgs:
         ei, ed, en = (O.nearest_brute(ps, bs, strict, k, inc) if brute else O.nearest_fast(ix, ps, strict, k, inc))
-        for tm in (2, 1):
-            i, d, n = eng.nearest(probe, build, strict, n_contigs, k, inc, table_mode=tm)
-            assert (n == en).all(), (k, inc, tm)
-            assert (d == ed).all(), (k, inc, tm)
-            assert (i == ei).all(), (k, inc, tm)
+        for tm, pm in ((2, 2), (1, 2), (1, 1)):         # bins / records, probe order / bucketed probes
+            i, d, n = eng.nearest(probe, build, strict, n_contigs, k, inc, table_mode=tm, partition_mode=pm)
+            assert (n == en).all(), (k, inc, tm, pm)
+            assert (d == ed).all(), (k, inc, tm, pm)
+            assert (i == ei).all(), (k, inc, tm, pm)
 
 
 @pytest.mark.parametrize("strict", [True, False])
