@@ -9,16 +9,17 @@ namespace ivj {
 // count = #{b.start (<) q.end} - #{!(q.start (<) b.end)}  (two-rank formula of the reference's
 // SQL sweep, polars_bio/range_op.py:548-595); the bounded scan replaces it for rows where the
 // formula is not exact (zero-length/inverted probe, or any inverted build row).
-// rank of a target inside one joint-grid slot: p0/k0 come from the record; when the first row of the
-// bin is still below the target look at the next row, and only then bound-search up to the next bin
-__device__ __forceinline__ int joint_rank(const int32_t* __restrict__ keys, int p0, int32_t k0, unsigned long long t, int b,
+// rank of a target inside one joint-grid slot: rec = {p0, key[p0], key[p0+1], key[p0+2]} (keys past the
+// segment are INT32_MAX); the number of leading keys below the target is the offset of the bound, and only a
+// bin with more than three rows below the target needs a bound search up to the next bin's first position
+__device__ __forceinline__ int joint_rank(const int32_t* __restrict__ keys, const int4& rec, unsigned long long t,
                                           const int4* __restrict__ crec, uint32_t slot, bool end_table) {
-    if (!((unsigned long long)flip(k0) < t)) return p0;
-    int lo = p0 + 1;
-    if (lo < b && (unsigned long long)flip(keys[lo]) < t) {
-        ++lo;
-        const int4 nx = crec[slot + 1];
-        int hi = end_table ? nx.z : nx.x;
+    const bool n0 = (unsigned long long)flip(rec.y) < t;
+    const bool n1 = n0 && (unsigned long long)flip(rec.z) < t;
+    const bool n2 = n1 && (unsigned long long)flip(rec.w) < t;
+    int lo = rec.x + (n0 ? 1 : 0) + (n1 ? 1 : 0) + (n2 ? 1 : 0);
+    if (n2) {
+        int hi = crec[2 * (slot + 1) + (end_table ? 1 : 0)].x;
         while (lo < hi) {
             const int m = lo + ((hi - lo) >> 1);
             if ((unsigned long long)flip(keys[m]) < t) lo = m + 1; else hi = m;
@@ -34,9 +35,9 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
                                                                   long long* __restrict__ counts) {
     const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
     int32_t c[N], s[N], e[N];
-    load_items(pc, i0, n, vec_ok, -1, c);
-    load_items(ps, i0, n, vec_ok, 0, s);
-    load_items(pe, i0, n, vec_ok, 0, e);
+    load_items_nt(pc, i0, n, vec_ok, -1, c);
+    load_items_nt(ps, i0, n, vec_ok, 0, s);
+    load_items_nt(pe, i0, n, vec_ok, 0, e);
     const bool inv = ix.flags[0] != 0;
     // phase 1: metadata and the (usually single) record gather of every probe, issued together
     int a[N], b[N];
@@ -58,16 +59,16 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
         se[k] = he[k] == 2 ? (uint32_t)m1.y + (((uint32_t)te[k] - ulo) >> m1.x) : 0u;
         ss[k] = hs[k] == 2 ? (uint32_t)m1.y + (((uint32_t)ts[k] - ulo) >> m1.x) : 0u;
         re[k] = make_int4(0, 0, 0, 0); rs[k] = make_int4(0, 0, 0, 0);
-        if (he[k] == 2) re[k] = ix.crec[se[k]];
-        if (hs[k] == 2) rs[k] = (he[k] == 2 && ss[k] == se[k]) ? re[k] : ix.crec[ss[k]];
+        if (he[k] == 2) re[k] = ix.crec[2 * se[k]];              // start half of the slot's record
+        if (hs[k] == 2) rs[k] = ix.crec[2 * ss[k] + 1];          // end half (the same 32-byte record when ss == se)
     }
     long long cnt[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const int hi = he[k] == 0 ? a[k] : (he[k] == 1 ? b[k] : joint_rank(ix.b_start, re[k].x, re[k].y, te[k], b[k], ix.crec, se[k], false));
+        const int hi = he[k] == 0 ? a[k] : (he[k] == 1 ? b[k] : joint_rank(ix.b_start, re[k], te[k], ix.crec, se[k], false));
         const bool degenerate = inv || (STRICT ? (s[k] >= e[k]) : (s[k] > e[k]));
         if (!degenerate) {
-            const int r = hs[k] == 0 ? a[k] : (hs[k] == 1 ? b[k] : joint_rank(ix.e_end, rs[k].z, rs[k].w, ts[k], b[k], ix.crec, ss[k], true));
+            const int r = hs[k] == 0 ? a[k] : (hs[k] == 1 ? b[k] : joint_rank(ix.e_end, rs[k], ts[k], ix.crec, ss[k], true));
             cnt[k] = (long long)hi - (long long)r;
         } else {
             cnt[k] = scan_count<STRICT>(ix, a[k], hi, s[k]);
@@ -76,7 +77,11 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
     if (i0 + N <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0 && (N % 2) == 0) {
 #pragma unroll
         for (int k = 0; k < N; k += 2)
-            reinterpret_cast<longlong2*>(counts + i0)[k / 2] = make_longlong2(cnt[k], cnt[k + 1]);
+        {
+            typedef long long v2ll __attribute__((ext_vector_type(2)));
+            v2ll v; v.x = cnt[k]; v.y = cnt[k + 1];
+            __builtin_nontemporal_store(v, reinterpret_cast<v2ll*>(counts + i0) + k / 2);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < N; ++k) if (i0 + k < n) counts[i0 + k] = cnt[k];

@@ -83,9 +83,11 @@ __global__ void k_pmax_change(const int2* __restrict__ ep, const int32_t* __rest
 // count_overlaps: joint bin grid.  Both rank queries of a probe -- #{start (<) q.end} over the
 // start order and #{!(q.start (<) end)} over the end order -- use the SAME coordinate bins, and a
 // read is ~125 bp long while a bin is thousands of bp wide, so q.start and q.end almost always
-// fall into one bin: ONE 16-byte gather answers both ranks.
+// fall into one bin: ONE 32-byte record (two 16-byte reads of one line) answers both ranks, with the keys
+// of the bin's first three rows of either order inline (no dependent key gather unless the bin is crowded).
 __global__ void k_contig_meta_joint(const int32_t* __restrict__ seg, const int32_t* __restrict__ b_start,
-                                    const int32_t* __restrict__ e_end, int32_t n_contigs, int4* __restrict__ cmeta) {
+                                    const int32_t* __restrict__ e_end, int32_t n_contigs, int bins_per_row,
+                                    int4* __restrict__ cmeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_contigs) return;
     const int a = seg[c], b = seg[c + 1];
@@ -94,7 +96,7 @@ __global__ void k_contig_meta_joint(const int32_t* __restrict__ seg, const int32
     if (b > a) {
         const uint32_t s0 = flip(b_start[a]), e0 = flip(e_end[a]), s1 = flip(b_start[b - 1]), e1 = flip(e_end[b - 1]);
         ulo = s0 < e0 ? s0 : e0; uhi = s1 > e1 ? s1 : e1;
-        const unsigned long long span = (unsigned long long)(uhi - ulo), cap = 2ull * (unsigned long long)(b - a);
+        const unsigned long long span = (unsigned long long)(uhi - ulo), cap = (unsigned long long)bins_per_row * (unsigned long long)(b - a);
         while ((span >> shift) + 1ull > cap) ++shift;
     }
     cmeta[2 * c] = make_int4(a, b, (int)ulo, (int)uhi);
@@ -110,13 +112,18 @@ __global__ void k_joint_records(const uint32_t* __restrict__ bins_s, const uint3
     while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= i) lo = m + 1; else hi = m; }
     const int c = lo - 1;
     const int ps = (int)bins_s[i], pe = (int)bins_e[i];
-    int32_t ks = 0x7fffffff, ke = 0x7fffffff;
+    int32_t ks[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, ke[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
     if (c >= 0) {
         const int bend = cmeta[2 * c].y;
-        if (ps < bend) ks = b_start[ps];
-        if (pe < bend) ke = e_end[pe];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (ps + j < bend) ks[j] = b_start[ps + j];
+            if (pe + j < bend) ke[j] = e_end[pe + j];
+        }
     }
-    crec[i] = make_int4(ps, ks, pe, ke);
+    // one 32-byte record per bin: {first start position, its three keys}, {first end position, its three keys}
+    crec[2 * i] = make_int4(ps, ks[0], ks[1], ks[2]);
+    crec[2 * i + 1] = make_int4(pe, ke[0], ke[1], ke[2]);
 }
 
 // nearest (k = 1): everything the no-overlap case needs about a bound position p in ONE 16-byte

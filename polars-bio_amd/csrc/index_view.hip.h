@@ -52,7 +52,7 @@ struct IndexView {
     int32_t use_rec;       // 1: gather 16-byte records, 0: 4-byte bins + bound search on the key array
     const int32_t* pargmax; // position of the first row that attains ep[p].y (prefix max) -- nearest only
     const int4* cmeta_j;    // count_overlaps: ONE bin grid per contig shared by the start- and the end-sorted order
-    const int4* crec;       //   crec[slot] = {first start position, its start, first end position, its end} of the bin
+    const int4* crec;       //   crec[2 slot] = {first start position, its 3 keys}, crec[2 slot + 1] = {first end position, its 3 keys}
     const int4* nrec;       // nearest: nrec[p] = {pmax[p-1], row of its argmax, start[p], end[p]} (left / right candidate of hi = p)
     const int4* rec4;       // flat overlap path: {start, end, build row, prefix max} per sorted position
     const uint2* tab2;      //   tab2[slot] = {first position of start bin `slot`, first position whose prefix max reaches its lower edge}
@@ -308,6 +308,28 @@ __device__ __forceinline__ void load_items(const int32_t* __restrict__ p, int64_
 #pragma unroll
     for (int k = 0; k < N; ++k) out[k] = (i0 + k < n) ? p[i0 + k] : fill;
 }
+// Streaming variant: the probe columns are read exactly once, so they are fetched with the non-temporal hint and
+// do not push the (re-used) lookup tables out of the XCD's L2.
+template <int N>
+__device__ __forceinline__ void load_items_nt(const int32_t* __restrict__ p, int64_t i0, int64_t n, bool vec_ok,
+                                              int32_t fill, int32_t (&out)[N]) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    if (vec_ok && i0 + N <= n) {
+        if constexpr (N == 4) {
+            const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p + i0));
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+            return;
+        } else if constexpr (N == 2) {
+            const v2i v = __builtin_nontemporal_load(reinterpret_cast<const v2i*>(p + i0));
+            out[0] = v.x; out[1] = v.y;
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = (i0 + k < n) ? __builtin_nontemporal_load(p + i0 + k) : fill;
+}
+
 template <int N>
 __device__ __forceinline__ void store_items(int32_t* __restrict__ p, int64_t i0, int64_t n, bool vec_ok,
                                             const int32_t (&v)[N]) {
