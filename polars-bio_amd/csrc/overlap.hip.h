@@ -82,7 +82,10 @@ struct PairPosOut {                     // staged build value = sorted position;
     int32_t* __restrict__ out_probe;
     int32_t* __restrict__ out_build;
     const int32_t* __restrict__ b_row;
-    __device__ __forceinline__ void operator()(long long o, int32_t a, int32_t b) const { out_probe[o] = a; out_build[o] = b_row[b]; }
+    __device__ __forceinline__ void operator()(long long o, int32_t a, int32_t b) const {
+        __builtin_nontemporal_store(a, out_probe + o);            // the result is a write-once stream
+        __builtin_nontemporal_store(b_row[b], out_build + o);
+    }
 };
 // copy-out of one staged pair (a = staged probe value, b = staged build value) to output slot o
 struct PairOut {
@@ -249,9 +252,9 @@ __global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fused(IndexView ix
     __shared__ int32_t st_b[FILL_STAGE];
     const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
     int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
-    load_items(pc, i0, n, vec_ok, -1, c);
-    load_items(ps, i0, n, vec_ok, 0, s);
-    load_items(pe, i0, n, vec_ok, 0, e);
+    load_items_nt(pc, i0, n, vec_ok, -1, c);
+    load_items_nt(ps, i0, n, vec_ok, 0, s);
+    load_items_nt(pe, i0, n, vec_ok, 0, e);
     int hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS], row[PROBE_ITEMS];
     bool valid[PROBE_ITEMS];
 #pragma unroll
