@@ -47,7 +47,7 @@ for stage in "$@"; do
       i=0; dirs="";
       for set in "SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE"; do
         i=$((i+1));
-        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set -d "$OLDPWD/gpurun_out/pmcsq${PMODE:-0}_$i" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --partition-mode ${PMODE:-0} > "$OLDPWD/gpurun_out/pmcsq${PMODE:-0}_$i.out" 2> "$OLDPWD/gpurun_out/pmcsq${PMODE:-0}_$i.err");
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set -d "$OLDPWD/gpurun_out/pmcsq${PMODE:-0}_$i" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --partition-mode ${PMODE:-0} ${WL:+--workload $WL} > "$OLDPWD/gpurun_out/pmcsq${PMODE:-0}_$i.out" 2> "$OLDPWD/gpurun_out/pmcsq${PMODE:-0}_$i.err");
         tail -1 gpurun_out/pmcsq${PMODE:-0}_$i.err | cut -c1-160; dirs="$dirs gpurun_out/pmcsq${PMODE:-0}_$i";
       done;
       python tools/pmc_summary.py $dirs > gpurun_out/pmcsq${PMODE:-0}_summary.json 2> gpurun_out/pmcsq${PMODE:-0}_summary.err; tail -3 gpurun_out/pmcsq${PMODE:-0}_summary.err ;;
