@@ -78,9 +78,9 @@ typedef struct {
     int32_t partition_mode;    /* overlap: bucket the probe side first. 0 auto (large inputs), 1 always (256-way,
                                   deterministic), 2 never, 3 fine (8192-way + LDS-resident index slices; used by
                                   ivj_overlap_fused_dev, the count/fill pair treats it as 1), 4 two-level
-                                  (two stable 256-way passes -> 65536 buckets, deterministic), 5 flat (experimental:
-                                  256-way buckets + load-balanced candidate test, ivj_overlap_fused_dev only; the index must
-                                  be built with the same value) */
+                                  (two stable 256-way passes -> 65536 buckets, deterministic), 5 flat (256-way buckets +
+                                  load-balanced candidate test, ivj_overlap_fused_dev only; with 0 the fused entry point
+                                  picks it by itself when capacity >= 8 pairs per probe row, i.e. for dense results) */
     int32_t table_mode;        /* direct-address table form: 0 auto (16-byte records for build sides >= 2^20 rows),
                                   1 records, 2 plain 4-byte bins */
     int32_t reserved[2];       /* must be zero */

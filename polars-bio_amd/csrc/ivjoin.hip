@@ -354,6 +354,24 @@ int build_rec4(ivj_ctx* ctx, ivj_index* ix) {
     return IVJ_OK;
 }
 
+// flat overlap path (flat.hip.h): per start bin the first position whose prefix max reaches it, interleaved with the
+// bin table; rec4.  Filled on first use (dense results, partition_mode 5).
+int build_flat(ivj_ctx* ctx, ivj_index* ix) {
+    if (ix->has_flat || ix->n == 0 || ix->n_contigs <= 0) return IVJ_OK;
+    IVJ_TRY(need_tables(ix));
+    IVJ_TRY(arena_reserve(ctx, align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4) + 4096));
+    uint32_t* part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
+    HIP_TRY(hipMemsetAsync(ix->lot, 0, (size_t)ix->bins_len * 4, ctx->stream));
+    LAUNCH(ctx, "lot_mark", k_lot_mark, grid1d(ix->n, 256), 256, (const int2*)ix->ep, (const int32_t*)ix->b_contig, ix->n,
+           ix->n_contigs, (const int4*)ix->cmeta, ix->lot);
+    device_scan<uint32_t, MaxOp, true>(ctx, "lot_scan", ix->lot, ix->lot, ix->bins_len, 0u, part, (uint32_t*)nullptr);
+    LAUNCH(ctx, "tab2", k_tab2, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, (const uint32_t*)ix->lot, ix->bins_len, ix->tab2);
+    HIP_TRY(hipGetLastError());
+    IVJ_TRY(build_rec4(ctx, ix));
+    ix->has_flat = true;
+    return IVJ_OK;
+}
+
 int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int with_end_order, ivj_index** out) {
     // table offsets (2 a + 2 c) and slot counts are int32: 2 Nb + 2 n_contigs must stay below 2^31
     if (2 * build->n + 2 * (int64_t)opts->n_contigs + 64 > 0x7fffffffll)
@@ -368,8 +386,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t nc = (size_t)opts->n_contigs;
         ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
         const size_t small = align_up((nc + 2) * 4) + align_up(16) + 3 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e, cmeta_j
-        const bool want_flat = opts->partition_mode == 5;
-        const size_t flat_bytes = align_up((nn + 1) * 16) + (want_flat ? 3 * align_up((size_t)ix->bins_len * 4) : 0);
+        const size_t flat_bytes = align_up((nn + 1) * 16) + 3 * align_up((size_t)ix->bins_len * 4);   // rec4, lot, tab2 (filled on demand)
         const size_t need = flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 16) + 2 * align_up((size_t)ix->bins_len * 4) +
                             4 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
@@ -395,7 +412,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->brec_e = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
         ix->crec = (int4*)p; p += align_up((size_t)ix->bins_len * 32);     // 32-byte joint records
         ix->rec4 = (int4*)p; p += align_up((nn + 1) * 16);
-        if (want_flat) {
+        {
             ix->lot = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
             ix->tab2 = (uint2*)p; p += 2 * align_up((size_t)ix->bins_len * 4);
         }
@@ -447,18 +464,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
             LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
                    (const int32_t*)ix->b_start, (const int4*)ix->cmeta, opts->n_contigs, ix->brec);
         }
-        // 7. flat overlap path (partition_mode 5 at build time): per start bin the first position whose prefix max reaches it
-        if (opts->n_contigs > 0 && opts->partition_mode == 5) {
-            hipError_t me = hipMemsetAsync(ix->lot, 0, (size_t)ix->bins_len * 4, ctx->stream);
-            if (me != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(lot): ") + hipGetErrorString(me)));
-            LAUNCH(ctx, "lot_mark", k_lot_mark, grid1d(n, 256), 256, (const int2*)ix->ep, (const int32_t*)ix->b_contig, n,
-                   opts->n_contigs, (const int4*)ix->cmeta, ix->lot);
-            device_scan<uint32_t, MaxOp, true>(ctx, "lot_scan", ix->lot, ix->lot, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
-            LAUNCH(ctx, "tab2", k_tab2, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, (const uint32_t*)ix->lot, ix->bins_len, ix->tab2);
-            ix->has_flat = true;
-            r = build_rec4(ctx, ix);
-            if (r != IVJ_OK) return cleanup(r);
-        }
+        // 7. the flat overlap path's arrays (lot / tab2 / rec4) are filled on first use: build_flat
+        if (opts->partition_mode == 5) { r = build_flat(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
         if (with_end_order & 1) { r = build_end_order(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
     } else {
         ix->has_end_order = true;
@@ -704,8 +711,10 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     if (opts->partition_mode == 3 && fine_available(ix)) return overlap_fused_fine(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
     const bool part = want_partition(ix, n, opts);
     IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
-    const bool flat = opts->partition_mode == 5;
-    if (flat && !ix->has_flat) return fail(IVJ_ESTATE, "partition_mode 5 (flat) needs an index built with partition_mode 5");
+    // dense results (the caller expects >= 8 pairs per probe): the flat kernel spreads every window over the whole
+    // workgroup (1.8x the count + dense-fill pair on 37 pairs per probe); sparse ones keep the window-scan kernel
+    const bool flat = opts->partition_mode == 5 || (opts->partition_mode == 0 && capacity >= 8 * n && ix->n_contigs > 0);
+    if (flat) IVJ_TRY(build_flat(ctx, ix));
     const int64_t tiles = flat ? (n + FLAT_TILE - 1) / FLAT_TILE : (n + PROBE_TILE - 1) / PROBE_TILE;
     unsigned long long* state = (unsigned long long*)ctx->ov_tile;   // [0] cursor, [1] overflow
     const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *ids = probe->row_id;

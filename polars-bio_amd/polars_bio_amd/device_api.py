@@ -60,9 +60,9 @@ class DeviceJoin:
         ix = self.engine.index_build_dev(build.as_c(), opts, False) if own else index
         try:
             side = probe.as_c()
-            if out is not None and fused and out[0].numel() < 8 * max(probe.n, 1):
-                # single fused pass into the caller's buffers (sparse results; dense ones use the
-                # two-pass path whose fill kernel shares a tile's windows over all wavefronts)
+            if out is not None and fused:
+                # single fused pass into the caller's buffers (the library picks the window-scan kernel for
+                # sparse results and the flat candidate kernel when the buffers say >= 8 pairs per probe)
                 cap = min(out[0].numel(), out[1].numel())
                 total, fits = self.engine.overlap_fused_dev(ix, side, opts, out[0].data_ptr(), out[1].data_ptr(), cap)
                 if fits:
