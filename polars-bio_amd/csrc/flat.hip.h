@@ -176,7 +176,7 @@ __global__ __launch_bounds__(FLAT_THREADS, 6) void k_overlap_flat(IndexView ix, 
                                                                 bool vec_ok, long long capacity,
                                                                 unsigned long long* __restrict__ state,
                                                                 int32_t* __restrict__ out_probe,
-                                                                int32_t* __restrict__ out_build) {
+                                                                int32_t* __restrict__ out_build, int rank_counts) {
     __shared__ long long lds_ll[FLAT_THREADS / kWave];
     __shared__ int lds_i[FLAT_THREADS / kWave];
     __shared__ long long s_wtot[FLAT_THREADS / kWave];
@@ -224,10 +224,37 @@ __global__ __launch_bounds__(FLAT_THREADS, 6) void k_overlap_flat(IndexView ix, 
         const int per = ((nC + FLAT_THREADS - 1) / FLAT_THREADS) * kWave;
         wcnt = flat_chunk<STRICT, true>(ix, 0ll, nC, per, off, cn, l_lo, l_off, l_q, marks, st_b, lds_i);
     } else {
-        for (long long c0 = 0; c0 < T; c0 += FLAT_CH) {
-            const int nC = (int)((T - c0) < (long long)FLAT_CH ? (T - c0) : (long long)FLAT_CH);
-            const int per = ((nC + FLAT_THREADS - 1) / FLAT_THREADS) * kWave;
-            wcnt += flat_chunk<STRICT, false>(ix, c0, nC, per, off, cn, l_lo, l_off, l_q, marks, st_b, lds_i);
+        // A tile with more candidates than one chunk must know its number of matches before it can reserve its
+        // output range.  With the end order at hand (rank_counts) that number comes from the two-rank formula of
+        // count_overlaps -- #{start (<) q.end} - #{!(q.start (<) end)}: two table reads per probe instead of a sweep
+        // over all candidates -- whenever the formula is exact (no inverted build row, no degenerate probe).
+        bool formula = rank_counts != 0 && ix.flags[0] == 0;
+        long long mine = 0;
+        if (formula) {
+            bool valid[FLAT_ITEMS], bad = false;
+            int a[FLAT_ITEMS], b[FLAT_ITEMS], hi[FLAT_ITEMS], r[FLAT_ITEMS];
+#pragma unroll
+            for (int k = 0; k < FLAT_ITEMS; ++k) {
+                valid[k] = i0 + k < n;
+                bad |= valid[k] && (STRICT ? (s[k] >= e[k]) : (s[k] > e[k]));
+            }
+            bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
+            bound_r_tab4<STRICT>(ix, c, valid, s, r);
+#pragma unroll
+            for (int k = 0; k < FLAT_ITEMS; ++k) if (valid[k] && b[k] > a[k]) mine += (long long)hi[k] - (long long)r[k];
+            formula = __syncthreads_or(bad ? 1 : 0) == 0;      // a degenerate probe anywhere in the tile: count by sweep
+        }
+        if (formula) {
+            // reduce over the wavefront so that lane 0 holds the wavefront's total
+#pragma unroll
+            for (int d = kWave / 2; d > 0; d >>= 1) mine += __shfl_down(mine, d, kWave);
+            wcnt = mine;                                        // meaningful in lane 0 only (that is what is stored)
+        } else {
+            for (long long c0 = 0; c0 < T; c0 += FLAT_CH) {
+                const int nC = (int)((T - c0) < (long long)FLAT_CH ? (T - c0) : (long long)FLAT_CH);
+                const int per = ((nC + FLAT_THREADS - 1) / FLAT_THREADS) * kWave;
+                wcnt += flat_chunk<STRICT, false>(ix, c0, nC, per, off, cn, l_lo, l_off, l_q, marks, st_b, lds_i);
+            }
         }
     }
     if (lane == 0) s_wtot[w] = wcnt;

@@ -715,6 +715,9 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     // workgroup (1.8x the count + dense-fill pair on 37 pairs per probe); sparse ones keep the window-scan kernel
     const bool flat = opts->partition_mode == 5 || (opts->partition_mode == 0 && capacity >= 8 * n && ix->n_contigs > 0);
     if (flat) IVJ_TRY(build_flat(ctx, ix));
+    // dense tiles of the flat kernel get their match counts from the end order (two-rank formula) instead of a sweep
+    const bool rank_counts = flat && capacity >= 8 * n;
+    if (rank_counts) IVJ_TRY(build_end_order(ctx, ix));
     const int64_t tiles = flat ? (n + FLAT_TILE - 1) / FLAT_TILE : (n + PROBE_TILE - 1) / PROBE_TILE;
     unsigned long long* state = (unsigned long long*)ctx->ov_tile;   // [0] cursor, [1] overflow
     const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *ids = probe->row_id;
@@ -727,9 +730,9 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     IndexView v = view_of(ix);
     if (flat) {
         if (opts->filter_op == IVJ_FILTER_STRICT)
-            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<true>), tiles, FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<true>), tiles, FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
         else
-            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<false>), tiles, FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<false>), tiles, FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
     } else if (opts->filter_op == IVJ_FILTER_STRICT)
         LAUNCH(ctx, "overlap_fused", (k_overlap_fused<true>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
     else

@@ -639,3 +639,32 @@ def test_sweep_only_index_refuses_join_calls(eng):
     ix.close()
     for p in ptrs + out:
         eng.dev_free(p)
+
+
+def test_flat_kernel_dense_counts_by_rank_and_fallbacks(eng):
+    """Dense results through ivj_overlap_fused_dev (capacity >= 8 pairs per probe -> flat kernel): tiles larger than
+    one chunk take their match counts from the two-rank formula; a degenerate probe in the tile or an inverted
+    build row anywhere sends them back to the counting sweep.  All three must give the oracle's pairs."""
+    rng = np.random.default_rng(77)
+    nc = 3
+    n, m = 40_000, 150_000
+    build = list(synth.make_side(m, 43, (20_000, 90_000), nc))
+    probe = list(synth.make_side(n, 42, synth.PROBE_LEN, nc))
+    variants = []
+    variants.append(("plain", tuple(probe), tuple(build)))
+    pz = [a.copy() for a in probe]
+    z = rng.integers(0, n, 200)
+    pz[2][z] = pz[1][z]                                        # zero-length probes sprinkled over the tiles
+    variants.append(("degenerate probes", tuple(pz), tuple(build)))
+    bi = [a.copy() for a in build]
+    f = rng.integers(0, m, 200)
+    bi[1][f], bi[2][f] = build[2][f], build[1][f]              # inverted build rows
+    variants.append(("inverted build rows", tuple(probe), tuple(bi)))
+    for name, p, b in variants:
+        for strict in (True, False):
+            ep, eb = O.overlap_fast(O.Index(O.Side(*b), nc), O.Side(*p), strict)
+            assert len(ep) >= 8 * n, (name, len(ep))           # dense enough for the automatic choice
+            hp, hb = _fused_overlap(eng, p, b, strict, nc, 0, len(ep))
+            assert int((np.diff(hp) != 0).sum()) + 1 == len(np.unique(hp)), name
+            gp, gb = _canon(hp, hb)
+            assert (gp == ep).all() and (gb == eb).all(), (name, strict)
