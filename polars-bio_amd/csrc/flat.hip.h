@@ -190,9 +190,9 @@ __global__ __launch_bounds__(FLAT_THREADS, 6) void k_overlap_flat(IndexView ix, 
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
     const int64_t i0 = (int64_t)blockIdx.x * FLAT_TILE + (int64_t)threadIdx.x * FLAT_ITEMS;
     int32_t c[FLAT_ITEMS], s[FLAT_ITEMS], e[FLAT_ITEMS], row[FLAT_ITEMS];
-    load_items(pc, i0, n, vec_ok, -1, c);
-    load_items(ps, i0, n, vec_ok, 0, s);
-    load_items(pe, i0, n, vec_ok, 0, e);
+    load_items_nt(pc, i0, n, vec_ok, -1, c);
+    load_items_nt(ps, i0, n, vec_ok, 0, s);
+    load_items_nt(pe, i0, n, vec_ok, 0, e);
     if (probe_ids) load_items(probe_ids, i0, n, vec_ok, 0, row);
     else {
 #pragma unroll
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(FLAT_THREADS, 6) void k_overlap_flat(IndexView ix, 
         const int per = ((nC + FLAT_THREADS - 1) / FLAT_THREADS) * kWave;
         const int wb = w * per;
         for (int j = lane; j < (int)wcnt; j += kWave) {
-            out_probe[tbase + pre + j] = l_row[marks[wb + j]];
-            out_build[tbase + pre + j] = st_b[wb + j];
+            __builtin_nontemporal_store(l_row[marks[wb + j]], out_probe + tbase + pre + j);
+            __builtin_nontemporal_store(st_b[wb + j], out_build + tbase + pre + j);
         }
         return;
     }
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(FLAT_THREADS, 6) void k_overlap_flat(IndexView ix, 
         for (int k = 0; k < FLAT_THREADS / kWave; ++k) { const long long x = s_wtot[k]; if (k < w) cpre += x; ctot += x; }
         const int wb = w * per;
         for (int j = lane; j < cnt; j += kWave) {
-            out_probe[running + cpre + j] = l_row[marks[wb + j]];
-            out_build[running + cpre + j] = st_b[wb + j];
+            __builtin_nontemporal_store(l_row[marks[wb + j]], out_probe + running + cpre + j);
+            __builtin_nontemporal_store(st_b[wb + j], out_build + running + cpre + j);
         }
         running += ctot;
     }

@@ -299,13 +299,14 @@ struct RowsOut {
     const int32_t *l_row, *l_c, *l_s, *l_e;   // LDS tables of the tile, by tile-local probe slot
     __device__ __forceinline__ void operator()(long long o, int32_t q, int32_t pos) const {
         const int4 r = rec4[pos];
-        if (c.probe_idx) c.probe_idx[o] = l_row[q];
-        if (c.build_idx) c.build_idx[o] = r.z;
-        if (c.contig) c.contig[o] = l_c[q];
-        if (c.start_1) c.start_1[o] = l_s[q];
-        if (c.end_1) c.end_1[o] = l_e[q];
-        if (c.start_2) c.start_2[o] = r.x;
-        if (c.end_2) c.end_2[o] = r.y;
+        // write-once result streams: non-temporal stores keep them from displacing the index slices in the L2
+        if (c.probe_idx) __builtin_nontemporal_store(l_row[q], c.probe_idx + o);
+        if (c.build_idx) __builtin_nontemporal_store(r.z, c.build_idx + o);
+        if (c.contig) __builtin_nontemporal_store(l_c[q], c.contig + o);
+        if (c.start_1) __builtin_nontemporal_store(l_s[q], c.start_1 + o);
+        if (c.end_1) __builtin_nontemporal_store(l_e[q], c.end_1 + o);
+        if (c.start_2) __builtin_nontemporal_store(r.x, c.start_2 + o);
+        if (c.end_2) __builtin_nontemporal_store(r.y, c.end_2 + o);
     }
 };
 
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_fill_dense(IndexView 
         __syncthreads();
         const int t = (int)((tot - w0) < (long long)DENSE_STAGE ? (tot - w0) : (long long)DENSE_STAGE);
         for (int i = threadIdx.x; i < t; i += PROBE_THREADS) {
-            out_probe[tbase + w0 + i] = st_p[i];
-            out_build[tbase + w0 + i] = st_b[i];
+            __builtin_nontemporal_store(st_p[i], out_probe + tbase + w0 + i);
+            __builtin_nontemporal_store(st_b[i], out_build + tbase + w0 + i);
         }
         __syncthreads();
     }

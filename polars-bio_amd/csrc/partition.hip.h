@@ -297,10 +297,10 @@ __global__ __launch_bounds__(UNP_THREADS) void k_unpermute(const int32_t* __rest
             stage[r] = wide ? s8[p] : (unsigned long long)s4[p];
         }
         __syncthreads();
-        if (wide) for (int i = threadIdx.x; i < t_all; i += UNP_THREADS) reinterpret_cast<unsigned long long*>(cols.dst[c])[r0 + i] = stage[i];
-        else for (int i = threadIdx.x; i < t_all; i += UNP_THREADS) reinterpret_cast<uint32_t*>(cols.dst[c])[r0 + i] = (uint32_t)stage[i];
+        if (wide) for (int i = threadIdx.x; i < t_all; i += UNP_THREADS) __builtin_nontemporal_store(stage[i], reinterpret_cast<unsigned long long*>(cols.dst[c]) + r0 + i);
+        else for (int i = threadIdx.x; i < t_all; i += UNP_THREADS) __builtin_nontemporal_store((uint32_t)stage[i], reinterpret_cast<uint32_t*>(cols.dst[c]) + r0 + i);
         if (c == 0 && cols.flag_dst)
-            for (int i = threadIdx.x; i < t_all; i += UNP_THREADS) cols.flag_dst[r0 + i] = ((int32_t)(uint32_t)stage[i] >= 0) ? 1 : 0;
+            for (int i = threadIdx.x; i < t_all; i += UNP_THREADS) __builtin_nontemporal_store(((int32_t)(uint32_t)stage[i] >= 0) ? 1 : 0, cols.flag_dst + r0 + i);
         __syncthreads();
     }
 }
