@@ -178,9 +178,9 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
     __shared__ long long lds[PROBE_THREADS / kWave];
     const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
     int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
-    load_items(pc, i0, n, vec_ok, -1, c);
-    load_items(ps, i0, n, vec_ok, 0, s);
-    load_items(pe, i0, n, vec_ok, 0, e);
+    load_items_nt(pc, i0, n, vec_ok, -1, c);
+    load_items_nt(ps, i0, n, vec_ok, 0, s);
+    load_items_nt(pe, i0, n, vec_ok, 0, e);
     int hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS];
     bool valid[PROBE_ITEMS];
 #pragma unroll
@@ -324,9 +324,9 @@ __global__ __launch_bounds__(PROBE_THREADS, 4) void k_overlap_fused_rows(IndexVi
     __shared__ int32_t l_row[PROBE_TILE], l_c[PROBE_TILE], l_s[PROBE_TILE], l_e[PROBE_TILE];
     const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
     int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS], row[PROBE_ITEMS];
-    load_items(pc, i0, n, vec_ok, -1, c);
-    load_items(ps, i0, n, vec_ok, 0, s);
-    load_items(pe, i0, n, vec_ok, 0, e);
+    load_items_nt(pc, i0, n, vec_ok, -1, c);
+    load_items_nt(ps, i0, n, vec_ok, 0, s);
+    load_items_nt(pe, i0, n, vec_ok, 0, e);
     if (probe_ids) load_items(probe_ids, i0, n, vec_ok, 0, row);
     else {
 #pragma unroll

@@ -91,8 +91,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_hist(IndexView ix, const 
     for (int g = 0; g < PART_ITEMS / 4; ++g) {
         const int64_t i0 = base + (int64_t)g * (PART_THREADS * 4) + (int64_t)threadIdx.x * 4;
         int32_t c[4], e[4];
-        load_items(pc, i0, n, vec_ok, -1, c);
-        load_items(pe, i0, n, vec_ok, 0, e);
+        load_items_nt(pc, i0, n, vec_ok, -1, c);
+        load_items_nt(pe, i0, n, vec_ok, 0, e);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (i0 + k >= n) continue;
