@@ -71,6 +71,7 @@ def gen_workload(name, scale):
         "overlap_10M_1M_1contig": (10_000_000, 1_000_000, 1, synth.BUILD_LEN, "overlap"),
         "overlap_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "overlap"),
         "overlap_100M_5M_24contig_dense": (100_000_000, 5_000_000, 24, synth.DENSE_BUILD_LEN, "overlap"),
+        "overlap_100M_5M_24contig_mid": (100_000_000, 5_000_000, 24, (1000, 9000), "overlap"),      # ~8.3 pairs per probe
         "nearest_50M_2M_24contig": (50_000_000, 2_000_000, 24, synth.BUILD_LEN, "nearest"),
         "count_200M_200k_24contig": (200_000_000, 200_000, 24, synth.BUILD_LEN, "count_overlaps"),
         # sort-scan family; not headline workloads

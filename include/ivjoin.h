@@ -80,7 +80,7 @@ typedef struct {
                                   ivj_overlap_fused_dev, the count/fill pair treats it as 1), 4 two-level
                                   (two stable 256-way passes -> 65536 buckets, deterministic), 5 flat (256-way buckets +
                                   load-balanced candidate test, ivj_overlap_fused_dev only; with 0 the fused entry point
-                                  picks it by itself when capacity >= 8 pairs per probe row, i.e. for dense results) */
+                                  picks it by itself when capacity >= 16 pairs per probe row, i.e. for dense results) */
     int32_t table_mode;        /* direct-address table form: 0 auto (16-byte records for build sides >= 2^20 rows),
                                   1 records, 2 plain 4-byte bins */
     int32_t reserved[2];       /* must be zero */

@@ -711,12 +711,13 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     if (opts->partition_mode == 3 && fine_available(ix)) return overlap_fused_fine(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
     const bool part = want_partition(ix, n, opts);
     IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
-    // dense results (the caller expects >= 8 pairs per probe): the flat kernel spreads every window over the whole
+    // dense results (the caller expects >= 16 pairs per probe; at ~8 the two kernels tie and the flat one still has
+    // to fill its arrays and the end order): the flat kernel spreads every window over the whole
     // workgroup (1.8x the count + dense-fill pair on 37 pairs per probe); sparse ones keep the window-scan kernel
-    const bool flat = opts->partition_mode == 5 || (opts->partition_mode == 0 && capacity >= 8 * n && ix->n_contigs > 0);
+    const bool flat = opts->partition_mode == 5 || (opts->partition_mode == 0 && capacity >= 16 * n && ix->n_contigs > 0);
     if (flat) IVJ_TRY(build_flat(ctx, ix));
     // dense tiles of the flat kernel get their match counts from the end order (two-rank formula) instead of a sweep
-    const bool rank_counts = flat && capacity >= 8 * n;
+    const bool rank_counts = flat && capacity >= 16 * n;
     if (rank_counts) IVJ_TRY(build_end_order(ctx, ix));
     const int64_t tiles = flat ? (n + FLAT_TILE - 1) / FLAT_TILE : (n + PROBE_TILE - 1) / PROBE_TILE;
     unsigned long long* state = (unsigned long long*)ctx->ov_tile;   // [0] cursor, [1] overflow

@@ -62,7 +62,7 @@ class DeviceJoin:
             side = probe.as_c()
             if out is not None and fused:
                 # single fused pass into the caller's buffers (the library picks the window-scan kernel for
-                # sparse results and the flat candidate kernel when the buffers say >= 8 pairs per probe)
+                # sparse results and the flat candidate kernel when the buffers say >= 16 pairs per probe)
                 cap = min(out[0].numel(), out[1].numel())
                 total, fits = self.engine.overlap_fused_dev(ix, side, opts, out[0].data_ptr(), out[1].data_ptr(), cap)
                 if fits:

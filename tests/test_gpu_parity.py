@@ -642,12 +642,12 @@ def test_sweep_only_index_refuses_join_calls(eng):
 
 
 def test_flat_kernel_dense_counts_by_rank_and_fallbacks(eng):
-    """Dense results through ivj_overlap_fused_dev (capacity >= 8 pairs per probe -> flat kernel): tiles larger than
+    """Dense results through ivj_overlap_fused_dev (capacity >= 16 pairs per probe -> flat kernel): tiles larger than
     one chunk take their match counts from the two-rank formula; a degenerate probe in the tile or an inverted
     build row anywhere sends them back to the counting sweep.  All three must give the oracle's pairs."""
     rng = np.random.default_rng(77)
     nc = 3
-    n, m = 40_000, 150_000
+    n, m = 40_000, 260_000
     build = list(synth.make_side(m, 43, (20_000, 90_000), nc))
     probe = list(synth.make_side(n, 42, synth.PROBE_LEN, nc))
     variants = []
@@ -663,7 +663,7 @@ def test_flat_kernel_dense_counts_by_rank_and_fallbacks(eng):
     for name, p, b in variants:
         for strict in (True, False):
             ep, eb = O.overlap_fast(O.Index(O.Side(*b), nc), O.Side(*p), strict)
-            assert len(ep) >= 8 * n, (name, len(ep))           # dense enough for the automatic choice
+            assert len(ep) >= 16 * n, (name, len(ep))          # dense enough for the automatic choice
             hp, hb = _fused_overlap(eng, p, b, strict, nc, 0, len(ep))
             assert int((np.diff(hp) != 0).sum()) + 1 == len(np.unique(hp)), name
             gp, gb = _canon(hp, hb)
