@@ -74,6 +74,7 @@ def gen_workload(name, scale):
         "overlap_100M_5M_24contig_mid": (100_000_000, 5_000_000, 24, (1000, 9000), "overlap"),      # ~8.3 pairs per probe
         "nearest_50M_2M_24contig": (50_000_000, 2_000_000, 24, synth.BUILD_LEN, "nearest"),
         "count_200M_200k_24contig": (200_000_000, 200_000, 24, synth.BUILD_LEN, "count_overlaps"),
+        "count_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "count_overlaps"),   # large build side
         # sort-scan family; not headline workloads
         "coverage_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "coverage"),
         "subtract_20M_5M_24contig": (20_000_000, 5_000_000, 24, synth.BUILD_LEN, "subtract"),
@@ -204,7 +205,7 @@ def main():
                 state.setdefault("gather_events", []).append(ev)
             return local, (p, b)
         if op == "count_overlaps":
-            return d_probe.n, join.count_overlaps(d_probe, d_build, True, nc)
+            return d_probe.n, join.count_overlaps(d_probe, d_build, True, nc, partition_mode=args.partition_mode)
         if op == "coverage":
             if "cov" not in state:
                 state["cov"] = torch.empty(d_probe.n, dtype=torch.int64, device=dev)

@@ -972,15 +972,37 @@ int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
     if (n == 0) return IVJ_OK;
     if (ix->n == 0) { HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
     IVJ_TRY(build_end_order(ctx, ix));
+    // partition_mode 1 only: bucket the probes by genomic position, count in bucket order into scratch, bring the
+    // counts back to probe order with the coalesced inverse permutation.  Not the default: with ONE record gather per
+    // probe the bucketing + inverse permutation cost more than the L2 locality buys (100M x 5M: 4.1 ms plain, 5.2 ms
+    // bucketed; nearest and coverage, with 3+ gathers per probe, do gain).
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end;
+    long long* o_counts = (long long*)counts;
+    const bool bucketed = opts->partition_mode == 1 && ix->n > 0;
+    if (bucketed) {
+        ivj_side plain = *probe;
+        plain.row_id = nullptr;
+        IVJ_TRY(ensure_ov(ctx, n, 1));
+        ctx->ov_n = -1;
+        ivj_opts popts = *opts; popts.partition_mode = 1;
+        IVJ_TRY(partition_probes(ctx, ix, &plain, &popts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e;
+        IVJ_TRY(arena_reserve(ctx, align_up((size_t)n * 8) + 4096));
+        o_counts = arena_take<long long>(ctx, n);
+    }
     constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT;
     const int64_t tiles = (n + NT - 1) / NT;
-    const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
     IndexView v = view_of(ix);
     if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, (long long*)counts);
+        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts);
     else
-        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, probe->contig, probe->start, probe->end, n, vec, (long long*)counts);
+        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts);
     HIP_TRY(hipGetLastError());
+    if (bucketed) {
+        UnpermuteCols uc{{o_counts, nullptr, nullptr}, {counts, nullptr, nullptr}, {8, 0, 0}, 1, nullptr};
+        IVJ_TRY(unpermute(ctx, n, uc));
+    }
     return IVJ_OK;
 }
 

@@ -340,10 +340,10 @@ class Engine:
         """pb.complement: the gaps of ``frame`` inside every view interval -> (view row, start, end)."""
         return self._pieces(self.L.ivj_complement, "ivj_complement", frame, view, strict, n_contigs, partition_mode)
 
-    def count_overlaps(self, probe, build, strict: bool, n_contigs: int, table_mode: int = 0) -> np.ndarray:
+    def count_overlaps(self, probe, build, strict: bool, n_contigs: int, table_mode: int = 0, partition_mode: int = 0) -> np.ndarray:
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
-        o = make_opts(strict, n_contigs, table_mode=table_mode)
+        o = make_opts(strict, n_contigs, table_mode=table_mode, partition_mode=partition_mode)
         counts = np.empty(ps.n, np.int64)
         _check(self.L, self.L.ivj_count_overlaps(self.h, C.byref(ps), C.byref(bs), C.byref(o), counts.ctypes.data),
                "ivj_count_overlaps")

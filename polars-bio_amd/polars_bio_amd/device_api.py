@@ -121,9 +121,10 @@ class DeviceJoin:
                              val.data_ptr() if val is not None else 0)
         return (dst, val) if with_validity else dst
 
-    def count_overlaps(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None):
+    def count_overlaps(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, index=None,
+                       partition_mode: int = 0):
         torch = self.torch
-        opts = make_opts(strict, n_contigs)
+        opts = make_opts(strict, n_contigs, partition_mode=partition_mode)
         own = index is None
         ix = self.engine.index_build_dev(build.as_c(), opts, True) if own else index
         try:

@@ -73,8 +73,8 @@ def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1
             p, b = _canon(hp, hb)
             assert (p == ep).all() and (b == eb).all(), ("fused", pm)
     ec = O.count_overlaps_brute(ps, bs, strict) if brute else O.count_overlaps_fast(ix, ps, strict)
-    for tm in (2, 1):                                    # 4-byte bins / 16-byte records
-        assert (eng.count_overlaps(probe, build, strict, n_contigs, table_mode=tm) == ec).all(), tm
+    for tm, pm in ((2, 2), (1, 2), (1, 1)):              # 4-byte bins / 16-byte records, probe order / bucketed probes
+        assert (eng.count_overlaps(probe, build, strict, n_contigs, table_mode=tm, partition_mode=pm) == ec).all(), (tm, pm)
     for k, inc in nearest_cfgs:
         ei, ed, en = (O.nearest_brute(ps, bs, strict, k, inc) if brute else O.nearest_fast(ix, ps, strict, k, inc))
         for tm, pm in ((2, 2), (1, 2), (1, 1)):         # bins / records, probe order / bucketed probes
