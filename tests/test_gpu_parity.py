@@ -668,3 +668,32 @@ def test_flat_kernel_dense_counts_by_rank_and_fallbacks(eng):
             assert int((np.diff(hp) != 0).sum()) + 1 == len(np.unique(hp)), name
             gp, gb = _canon(hp, hb)
             assert (gp == ep).all() and (gb == eb).all(), (name, strict)
+
+
+def test_repeated_joins_on_one_context_with_changing_inputs():
+    """One context, many joins with changing inputs, sizes, filter ops and paths (fused into caller buffers, two-pass
+    when they are too small, another operation in between): stale scratch or a stale count -> fill hand-over would
+    show up here.  Every result must be the oracle's."""
+    import torch
+    from polars_bio_amd.device_api import DeviceJoin, DeviceSide
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    join = DeviceJoin(0)
+    rng = np.random.default_rng(99)
+    for it, (npr, nb, nc, strict) in enumerate(((400_000, 90_000, 24, True), (50_000, 300_000, 5, False), (1_000_003, 40_000, 24, True),
+                                               (400_000, 90_000, 24, True), (7, 3, 1, True))):
+        probe = synth.make_side(npr, 100 + it, synth.PROBE_LEN, nc)
+        build = synth.make_side(nb, 200 + it, synth.BUILD_LEN if it % 2 == 0 else synth.DENSE_BUILD_LEN, nc)
+        ep, eb = O.overlap_fast(O.Index(O.Side(*build), nc), O.Side(*probe), strict)
+        dp, db = DeviceSide(*map(up, probe)), DeviceSide(*map(up, build))
+        out = (torch.full((len(ep) + 5,), -1, dtype=torch.int32, device=dev), torch.full((len(ep) + 5,), -1, dtype=torch.int32, device=dev))
+        for pm in (1, 0):
+            p, b = join.overlap(dp, db, strict, nc, out=out, partition_mode=pm)          # fused into the caller's buffers
+            assert p.shape[0] == len(ep), (it, pm)
+            gp, gb = _canon(p.cpu().numpy(), b.cpu().numpy())
+            assert (gp == ep).all() and (gb == eb).all(), (it, pm)
+        small = (torch.empty(max(len(ep) // 3, 1), dtype=torch.int32, device=dev),) * 2
+        p, b = join.overlap(dp, db, strict, nc, out=(small[0], small[1].clone()), partition_mode=1)   # too small -> two-pass
+        assert p.shape[0] == len(ep)
+        c = join.count_overlaps(dp, db, strict, nc)                                   # another op in between
+        assert int(c.sum().item()) == len(ep)
