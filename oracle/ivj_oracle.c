@@ -120,6 +120,7 @@ struct orc_index {
     int32_t* pmax;        /* prefix max of s_end inside the contig segment */
     int32_t* e_end;       /* ends sorted by (contig, end, position in start order) */
     int32_t* e_pos;       /* position in start order of that end */
+    int32_t* tmax;        /* implicit interval tree: max end in the subtree whose root is this position */
 };
 
 /* LSD radix sort of 64-bit keys with a 32-bit payload, 16-bit digits. */
@@ -146,6 +147,53 @@ static void radix_sort_u64(uint64_t* keys, int32_t* vals, int64_t n, int key_bit
 
 static inline uint64_t compose(int32_t contig, int32_t coord) {
     return ((uint64_t)(uint32_t)contig << 32) | (uint64_t)((uint32_t)coord ^ 0x80000000u);
+}
+
+/* ---- implicit augmented interval tree (the closest stand-in for the reference's index) -----------------
+ * The reference joins through COITrees (coitrees 0.4.0 behind datafusion-bio-function-ranges,
+ * /root/reference/Cargo.lock:1090-1094, docs/developers.md:629-639): the build intervals of a contig sorted by
+ * start, laid out as a balanced binary tree, every node augmented with the maximum end of its subtree; a query
+ * descends, pruning subtrees whose max end cannot reach the query and right subtrees whose starts lie past it.
+ * Here the tree is implicit in the sorted array: the root of [lo, hi) is its midpoint (COITrees uses a van Emde
+ * Boas layout of the same tree for cache behaviour; pruning rules and results are the same).  In-order traversal
+ * emits the matches in (start, row) order, i.e. the order of orc_overlap_fast.                              */
+static int32_t tree_build(orc_index* ix, int64_t lo, int64_t hi) {
+    if (lo >= hi) return INT32_MIN;
+    int64_t mid = lo + ((hi - lo) >> 1);
+    int32_t m = ix->s_end[mid];
+    int32_t l = tree_build(ix, lo, mid), r = tree_build(ix, mid + 1, hi);
+    if (l > m) m = l;
+    if (r > m) m = r;
+    ix->tmax[mid] = m;
+    return m;
+}
+
+/* visits the matches of one probe in order; emit == NULL only counts */
+static int64_t tree_query(const orc_index* ix, int64_t a, int64_t b, int32_t qs, int32_t qe, int strict, int32_t pi,
+                          int32_t* out_probe, int32_t* out_build, int64_t w, int64_t cap) {
+    /* explicit stack of (lo, hi, state): state 0 = visit left subtree first, 1 = node itself then right subtree */
+    int64_t st_lo[64], st_hi[64]; int st_s[64]; int sp = 0;
+    int64_t found = 0;
+    st_lo[0] = a; st_hi[0] = b; st_s[0] = 0; sp = 1;
+    while (sp > 0) {
+        int64_t lo = st_lo[sp - 1], hi = st_hi[sp - 1]; int state = st_s[sp - 1];
+        --sp;
+        if (lo >= hi) continue;
+        int64_t mid = lo + ((hi - lo) >> 1);
+        if (state == 0) {
+            if (!cond_b(qs, ix->tmax[mid], strict)) continue;            /* nothing in this subtree ends late enough */
+            st_lo[sp] = lo; st_hi[sp] = hi; st_s[sp] = 1; ++sp;          /* come back for the node and the right side */
+            st_lo[sp] = lo; st_hi[sp] = mid; st_s[sp] = 0; ++sp;         /* left subtree first (in-order) */
+        } else {
+            if (!cond_a(ix->s_start[mid], qe, strict)) continue;         /* this start and all to the right are too late */
+            if (cond_b(qs, ix->s_end[mid], strict)) {
+                if (out_probe && w + found < cap) { out_probe[w + found] = pi; out_build[w + found] = ix->s_row[mid]; }
+                ++found;
+            }
+            st_lo[sp] = mid + 1; st_hi[sp] = hi; st_s[sp] = 0; ++sp;
+        }
+    }
+    return found;
 }
 
 orc_index* orc_index_build(const orc_side* build, int n_contigs) {
@@ -195,13 +243,15 @@ orc_index* orc_index_build(const orc_side* build, int n_contigs) {
     radix_sort_u64(keys, ix->e_pos, n_valid, 64);
     for (int64_t p = 0; p < n_valid; ++p) ix->e_end[p] = ix->s_end[ix->e_pos[p]];
     free(keys);
+    ix->tmax = (int32_t*)malloc(4 * nn);
+    for (int c = 0; c < n_contigs; ++c) tree_build(ix, ix->seg[c], ix->seg[c + 1]);
     return ix;
 }
 
 void orc_index_free(orc_index* ix) {
     if (!ix) return;
     free(ix->seg); free(ix->s_start); free(ix->s_end); free(ix->s_row);
-    free(ix->pmax); free(ix->e_end); free(ix->e_pos); free(ix);
+    free(ix->pmax); free(ix->e_end); free(ix->e_pos); free(ix->tmax); free(ix);
 }
 
 /* first p in [lo,hi) with a[p] >= x */
@@ -371,4 +421,40 @@ void orc_nearest_fast(const orc_index* ix, const orc_side* probe, int strict,
     for (int64_t i = 0; i < probe->n; ++i)
         nearest_one(ix, probe->contig[i], probe->start[i], probe->end[i], strict, k,
                     include_overlaps, out_idx + i * k, out_dist + i * k, out_n + i);
+}
+
+int64_t orc_overlap_tree(const orc_index* ix, const orc_side* probe, int strict,
+                         int32_t* out_probe, int32_t* out_build, int64_t cap, int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    int nt = omp_get_max_threads();
+#else
+    int nt = 1;
+#endif
+    (void)threads;
+    int64_t np = probe->n;
+    int64_t* part = (int64_t*)calloc((size_t)nt + 1, sizeof(int64_t));
+    for (int pass = 0; pass < (out_probe ? 2 : 1); ++pass) {
+#pragma omp parallel num_threads(nt)
+        {
+#ifdef _OPENMP
+            int t = omp_get_thread_num();
+#else
+            int t = 0;
+#endif
+            int64_t lo_i = np * t / nt, hi_i = np * (t + 1) / nt, w = pass ? part[t] : 0, s = 0;
+            for (int64_t i = lo_i; i < hi_i; ++i) {
+                int64_t a, b;
+                if (!seg_of(ix, probe->contig[i], &a, &b)) continue;
+                int64_t f = tree_query(ix, a, b, probe->start[i], probe->end[i], strict, (int32_t)i,
+                                       pass ? out_probe : NULL, out_build, w, cap);
+                s += f; w += f;
+            }
+            if (!pass) part[t + 1] = s;
+        }
+        if (!pass) for (int t = 0; t < nt; ++t) part[t + 1] += part[t];
+    }
+    int64_t total = part[nt];
+    free(part);
+    return total;
 }

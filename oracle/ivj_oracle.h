@@ -85,6 +85,12 @@ void orc_count_overlaps_fast(const orc_index* ix, const orc_side* probe, int str
 int64_t orc_overlap_fast(const orc_index* ix, const orc_side* probe, int strict,
                          int32_t* out_probe, int32_t* out_build, int64_t cap, int threads);
 
+/* The same pairs in the same order through an implicit augmented interval tree over the sorted build side -- the
+ * closest stand-in for the reference's COITrees index (pruning by subtree max end and by start); second timed CPU
+ * baseline and a third independent implementation for the cross-checks. */
+int64_t orc_overlap_tree(const orc_index* ix, const orc_side* probe, int strict,
+                         int32_t* out_probe, int32_t* out_build, int64_t cap, int threads);
+
 void orc_nearest_fast(const orc_index* ix, const orc_side* probe, int strict,
                       int k, int include_overlaps,
                       int32_t* out_idx, int64_t* out_dist, int32_t* out_n, int threads);

@@ -73,6 +73,8 @@ def lib() -> C.CDLL:
         L.orc_count_overlaps_fast.argtypes = [C.c_void_p, P, C.c_int, C.c_void_p, C.c_int]
         L.orc_overlap_fast.restype = C.c_int64
         L.orc_overlap_fast.argtypes = [C.c_void_p, P, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.orc_overlap_tree.restype = C.c_int64
+        L.orc_overlap_tree.argtypes = [C.c_void_p, P, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.orc_nearest_fast.restype = None
         L.orc_nearest_fast.argtypes = [C.c_void_p, P, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _LIB = L
@@ -154,6 +156,19 @@ def overlap_fast(ix: Index, probe: Side, strict: bool, threads: int = 0, count_o
     p = np.empty(n, np.int32)
     b = np.empty(n, np.int32)
     L.orc_overlap_fast(ix.h, probe.ref(), int(strict), p.ctypes.data, b.ctypes.data, n, threads)
+    return p, b
+
+
+def overlap_tree(ix: Index, probe: Side, strict: bool, threads: int = 0, count_only: bool = False):
+    """Same pairs, same order as overlap_fast, through the implicit augmented interval tree (the stand-in for the
+    reference's COITrees index)."""
+    L = lib()
+    n = L.orc_overlap_tree(ix.h, probe.ref(), int(strict), None, None, 0, threads)
+    if count_only:
+        return n
+    p = np.empty(n, np.int32)
+    b = np.empty(n, np.int32)
+    L.orc_overlap_tree(ix.h, probe.ref(), int(strict), p.ctypes.data, b.ctypes.data, n, threads)
     return p, b
 
 

@@ -278,3 +278,28 @@ def test_coverage_fast_equals_definition(strict):
     # a probe inside one build interval is fully covered; Weak counts both end positions
     one = O.np_coverage_brute(O.Side([0], [10], [20]), O.Side([0], [0], [100]), strict)
     assert one.tolist() == [10 if strict else 11]
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_interval_tree_equals_sort_search_and_brute(strict, real_sides):
+    """Third implementation of overlap (implicit augmented interval tree, the stand-in for the reference's COITrees
+    index): same pairs in the same order as the sort + bound-search oracle, same count as the brute force; also on
+    inverted rows, absent contigs, empty sides and the real fixture (54,246 pairs, 0-based)."""
+    rng = np.random.default_rng(31)
+    for _ in range(40):
+        nc = int(rng.integers(1, 4))
+        b = random_side(rng, int(rng.integers(0, 300)), nc, int(rng.choice([50, 5000])), int(rng.choice([3, 300])))
+        p = random_side(rng, int(rng.integers(1, 300)), nc + 1, int(rng.choice([50, 5000])), int(rng.choice([3, 300])))
+        if len(b[0]) > 5:
+            f = rng.random(len(b[0])) < 0.1
+            b = (b[0], np.where(f, b[2], b[1]).astype(np.int32), np.where(f, b[1], b[2]).astype(np.int32))
+        ix = O.Index(O.Side(*b), nc)
+        fp, fb = O.overlap_fast(ix, O.Side(*p), strict)
+        tp, tb = O.overlap_tree(ix, O.Side(*p), strict)
+        bp, _ = O.overlap_brute(O.Side(*p), O.Side(*b), strict)
+        assert len(fp) == len(tp) == len(bp)
+        assert (fp == tp).all() and (fb == tb).all()
+    _, _, (p, b, n) = real_sides
+    ix = O.Index(b, n)
+    assert O.overlap_tree(ix, p, strict, count_only=True) == (54246 if strict else 54343)
+    assert O.overlap_tree(ix, p, strict, threads=3, count_only=True) == O.overlap_fast(ix, p, strict, count_only=True)
