@@ -188,7 +188,10 @@ __global__ __launch_bounds__(FLAT_THREADS, 6) void k_overlap_flat(IndexView ix, 
     __shared__ __align__(16) uint16_t marks[FLAT_CH];
     __shared__ int32_t st_b[FLAT_CH];
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    const int64_t i0 = (int64_t)blockIdx.x * FLAT_TILE + (int64_t)threadIdx.x * FLAT_ITEMS;
+    const long long ntiles = (n + FLAT_TILE - 1) / FLAT_TILE;
+    const long long tile = xcd_tile64(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;                            // uniform
+    const int64_t i0 = (int64_t)tile * FLAT_TILE + (int64_t)threadIdx.x * FLAT_ITEMS;
     int32_t c[FLAT_ITEMS], s[FLAT_ITEMS], e[FLAT_ITEMS], row[FLAT_ITEMS];
     load_items_nt(pc, i0, n, vec_ok, -1, c);
     load_items_nt(ps, i0, n, vec_ok, 0, s);

@@ -65,6 +65,14 @@ __device__ __forceinline__ int32_t unflip(uint32_t v) { return (int32_t)(v ^ 0x8
 template <bool STRICT>
 __device__ __forceinline__ bool lt_op(int32_t x, int32_t y) { return STRICT ? (x < y) : (x <= y); }
 
+// Workgroup b is observed to run on XCD b % 8.  Giving every XCD one CONTIGUOUS eighth of the (bucket-ordered) tiles
+// means its L2 only ever holds the index slices of its own buckets, instead of all eight L2s fetching every slice.
+// Launch 8 * ceil(ntiles / 8) workgroups; a tile index >= ntiles has nothing to do.  Speed only, never the result.
+__device__ __forceinline__ long long xcd_tile64(long long block, long long ntiles) {
+    const long long per = (ntiles + 7) / 8;
+    return (block & 7) * per + (block >> 3);
+}
+
 __device__ __forceinline__ long long gap_dist(int32_t qs, int32_t qe, int32_t bs, int32_t be) {
     const long long d1 = (long long)bs - (long long)qe;
     const long long d2 = (long long)qs - (long long)be;

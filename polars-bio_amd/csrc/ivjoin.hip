@@ -599,10 +599,10 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
     IndexView v = view_of(ix);
     if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "overlap_count", (k_overlap_count<true>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec,
+        LAUNCH(ctx, "overlap_count", (k_overlap_count<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, n, vec,
                ctx->ov_hi, ctx->ov_cnt, tile);
     else
-        LAUNCH(ctx, "overlap_count", (k_overlap_count<false>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec,
+        LAUNCH(ctx, "overlap_count", (k_overlap_count<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, n, vec,
                ctx->ov_hi, ctx->ov_cnt, tile);
     device_scan<long long, SumOp, false>(ctx, "tile_scan", tile, tile, tiles, 0ll, partials, tile + tiles);
     HIP_TRY(hipMemcpyAsync(ctx->h_total, tile + tiles, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -636,9 +636,9 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         else LAUNCH(ctx, "overlap_fill_dense", (k_overlap_fill_dense<false, PROBE_ITEMS>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
                     (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
     } else {
-        if (strict) LAUNCH(ctx, "overlap_fill", (k_overlap_fill<true>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+        if (strict) LAUNCH(ctx, "overlap_fill", (k_overlap_fill<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
                            (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
-        else LAUNCH(ctx, "overlap_fill", (k_overlap_fill<false>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+        else LAUNCH(ctx, "overlap_fill", (k_overlap_fill<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
                     (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
     }
     HIP_TRY(hipGetLastError());
@@ -731,13 +731,13 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     IndexView v = view_of(ix);
     if (flat) {
         if (opts->filter_op == IVJ_FILTER_STRICT)
-            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<true>), tiles, FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
+            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<true>), 8 * ((tiles + 7) / 8), FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
         else
-            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<false>), tiles, FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
+            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<false>), 8 * ((tiles + 7) / 8), FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
     } else if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<true>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
     else
-        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<false>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
     HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
@@ -954,9 +954,9 @@ int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
     IndexView v = view_of(ix);
     RowColumns cols{rows->probe_idx, rows->build_idx, rows->contig, rows->start_1, rows->end_1, rows->start_2, rows->end_2};
     if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "overlap_fused_rows", (k_overlap_fused_rows<true>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, cols);
+        LAUNCH(ctx, "overlap_fused_rows", (k_overlap_fused_rows<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, cols);
     else
-        LAUNCH(ctx, "overlap_fused_rows", (k_overlap_fused_rows<false>), tiles, PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, cols);
+        LAUNCH(ctx, "overlap_fused_rows", (k_overlap_fused_rows<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, cols);
     HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());

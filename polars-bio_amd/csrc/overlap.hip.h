@@ -176,7 +176,10 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
                                                                  int32_t* __restrict__ hi_out, int32_t* __restrict__ cnt_out,
                                                                  long long* __restrict__ tile_tot) {
     __shared__ long long lds[PROBE_THREADS / kWave];
-    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    const long long ntiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    const long long tile = xcd_tile64(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;                            // uniform
+    const int64_t i0 = (int64_t)tile * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
     int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
     load_items_nt(pc, i0, n, vec_ok, -1, c);
     load_items_nt(ps, i0, n, vec_ok, 0, s);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
     store_items(cnt_out, i0, n, vec_ok, x);
     long long tot;
     block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
-    if (threadIdx.x == 0) tile_tot[blockIdx.x] = tot;
+    if (threadIdx.x == 0) tile_tot[tile] = tot;
 }
 
 // Pass 2.  tile_base = exclusive scan of tile_tot.
@@ -208,7 +211,10 @@ __global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fill(IndexView ix,
     __shared__ long long lds[PROBE_THREADS / kWave];
     __shared__ int32_t st_p[FILL_STAGE];
     __shared__ int32_t st_b[FILL_STAGE];
-    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    const long long ntiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    const long long tile = xcd_tile64(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;                            // uniform
+    const int64_t i0 = (int64_t)tile * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
     int32_t hi[PROBE_ITEMS], x[PROBE_ITEMS], cnt[PROBE_ITEMS], row[PROBE_ITEMS], qs[PROBE_ITEMS];
     load_items(hi_in, i0, n, vec_ok, 0, hi);
     load_items(cnt_in, i0, n, vec_ok, 0, x);
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fill(IndexView ix,
     for (int k = 0; k < PROBE_ITEMS; ++k) qs[k] = (hi[k] < 0 && cnt[k] != 0) ? ps[i0 + k] : 0;
     long long tot;
     const long long loc0 = block_exclusive_scan(tsum, SumOp(), 0ll, lds, &tot);
-    emit_tile<STRICT>(ix, hi, x, cnt, row, qs, loc0, tot, tile_base[blockIdx.x], st_p, st_b, out_probe, out_build);
+    emit_tile<STRICT>(ix, hi, x, cnt, row, qs, loc0, tot, tile_base[tile], st_p, st_b, out_probe, out_build);
 }
 
 // Fused single pass (count + fill) for callers that bring an output buffer of known capacity
@@ -250,7 +256,10 @@ __global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fused(IndexView ix
     __shared__ long long s_base;
     __shared__ int32_t st_p[FILL_STAGE];
     __shared__ int32_t st_b[FILL_STAGE];
-    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    const long long ntiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    const long long tile = xcd_tile64(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;                            // uniform
+    const int64_t i0 = (int64_t)tile * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
     int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS];
     load_items_nt(pc, i0, n, vec_ok, -1, c);
     load_items_nt(ps, i0, n, vec_ok, 0, s);
@@ -322,7 +331,10 @@ __global__ __launch_bounds__(PROBE_THREADS, 4) void k_overlap_fused_rows(IndexVi
     __shared__ int32_t st_p[ROWS_STAGE];
     __shared__ int32_t st_b[ROWS_STAGE];
     __shared__ int32_t l_row[PROBE_TILE], l_c[PROBE_TILE], l_s[PROBE_TILE], l_e[PROBE_TILE];
-    const int64_t i0 = (int64_t)blockIdx.x * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
+    const long long ntiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    const long long tile = xcd_tile64(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;                            // uniform
+    const int64_t i0 = (int64_t)tile * PROBE_TILE + (int64_t)threadIdx.x * PROBE_ITEMS;
     int32_t c[PROBE_ITEMS], s[PROBE_ITEMS], e[PROBE_ITEMS], row[PROBE_ITEMS];
     load_items_nt(pc, i0, n, vec_ok, -1, c);
     load_items_nt(ps, i0, n, vec_ok, 0, s);
