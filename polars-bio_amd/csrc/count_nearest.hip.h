@@ -102,7 +102,10 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
                                                               int32_t* __restrict__ out_idx, long long* __restrict__ out_dist,
                                                               int32_t* __restrict__ out_n) {
     // out_row: the probes are a bucketed permutation (partition.hip.h); results go to the original rows
-    const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
+    const long long ntiles = (n + PROBE_THREADS * N - 1) / (PROBE_THREADS * N);
+    const long long tile = xcd_tile64(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int64_t i0 = (int64_t)tile * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
     int32_t c[N], s[N], e[N];
     load_items(pc, i0, n, vec_ok, -1, c);
     load_items(ps, i0, n, vec_ok, 0, s);

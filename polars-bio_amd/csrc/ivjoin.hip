@@ -826,9 +826,9 @@ int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     const int64_t per = (int64_t)PROBE_THREADS * COV_ITEMS;
     long long* o_cov = bucketed ? arena_take<long long>(ctx, n) : (long long*)cov;    // bucket order, un-permuted below
     (void)qrow;
-    if (strict) LAUNCH(ctx, "coverage", (k_coverage<true>), (n + per - 1) / per, PROBE_THREADS, v, (const uint32_t*)cl.cid1,
+    if (strict) LAUNCH(ctx, "coverage", (k_coverage<true>), 8 * (((n + per - 1) / per + 7) / 8), PROBE_THREADS, v, (const uint32_t*)cl.cid1,
                        (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, qc, qs, qe, (const int32_t*)nullptr, n, vec, o_cov);
-    else LAUNCH(ctx, "coverage", (k_coverage<false>), (n + per - 1) / per, PROBE_THREADS, v, (const uint32_t*)cl.cid1,
+    else LAUNCH(ctx, "coverage", (k_coverage<false>), 8 * (((n + per - 1) / per + 7) / 8), PROBE_THREADS, v, (const uint32_t*)cl.cid1,
                 (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, (const long long*)pl, qc, qs, qe, (const int32_t*)nullptr, n, vec, o_cov);
     if (bucketed) {
         UnpermuteCols uc{{o_cov, nullptr, nullptr}, {cov, nullptr, nullptr}, {8, 0, 0}, 1, nullptr};
@@ -1039,8 +1039,8 @@ int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_op
             IVJ_TRY(arena_reserve(ctx, 2 * align_up((size_t)n * 4) + align_up((size_t)n * 8) + 4096));
             o_idx = arena_take<int32_t>(ctx, n); o_nf = arena_take<int32_t>(ctx, n); o_dist = arena_take<long long>(ctx, n);
         }
-        if (strict) LAUNCH(ctx, "nearest_k1", (k_nearest_k1<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, (const int32_t*)nullptr, o_idx, o_dist, o_nf);
-        else LAUNCH(ctx, "nearest_k1", (k_nearest_k1<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, (const int32_t*)nullptr, o_idx, o_dist, o_nf);
+        if (strict) LAUNCH(ctx, "nearest_k1", (k_nearest_k1<true, PROBE_ITEMS_LAT>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, n, vec, (const int32_t*)nullptr, o_idx, o_dist, o_nf);
+        else LAUNCH(ctx, "nearest_k1", (k_nearest_k1<false, PROBE_ITEMS_LAT>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, n, vec, (const int32_t*)nullptr, o_idx, o_dist, o_nf);
         if (qrow) {
             // n_found of k = 1 is "a row was found": derived from the row index while it is written
             UnpermuteCols uc{{o_idx, o_dist, nullptr}, {idx, dist, nullptr}, {4, 8, 0}, 2, nf};

@@ -91,7 +91,10 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_coverage(IndexView ix, const 
                                                             const int32_t* __restrict__ pe, const int32_t* __restrict__ out_row,
                                                             int64_t n, bool vec_ok, long long* __restrict__ cov) {
     // out_row: the probes are a bucketed permutation (partition.hip.h); the result goes to the original row
-    const int64_t i0 = ((int64_t)blockIdx.x * PROBE_THREADS + threadIdx.x) * COV_ITEMS;
+    const long long ntiles = (n + PROBE_THREADS * COV_ITEMS - 1) / (PROBE_THREADS * COV_ITEMS);
+    const long long tile = xcd_tile64(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int64_t i0 = ((int64_t)tile * PROBE_THREADS + threadIdx.x) * COV_ITEMS;
     if (i0 >= n) return;
     int32_t c[COV_ITEMS], s[COV_ITEMS], e[COV_ITEMS];
     load_items(pc, i0, n, vec_ok, -1, c);
