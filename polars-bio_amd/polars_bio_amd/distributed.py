@@ -102,3 +102,40 @@ def all_gatherv(tensors, group=None):
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return outs, counts
+
+
+def gather_per_probe(values, row_ids, n_total: int, fill=0, group=None):
+    """Exchange step of the per-probe operations (count_overlaps, coverage, nearest): every rank holds the
+    results of ITS probe rows (``values``: 1-D or 2-D tensors whose first axis is the local probe row) and their
+    global row ids; every rank ends up with full-length tensors in original probe order (SURVEY.md section 8e:
+    "the gather is of fixed-width per-probe results scattered back to original probe order").  Rows no rank owns
+    (probe rows whose contig is outside the dictionary under contig sharding) keep ``fill`` (one value, or one per
+    payload: e.g. ``[0, -1, -1]`` for counts / nearest row / distance).
+
+    One all-gatherv of the row ids and of every flattened value column, then a local indexed store."""
+    import torch
+
+    width = [int(v.shape[1]) if v.dim() == 2 else 1 for v in values]
+    flat = [v.reshape(-1).contiguous() for v in values]
+    (ids, *cols), counts = all_gatherv([row_ids.contiguous()] + flat, group=group) if all(w == 1 for w in width) else _gatherv_wide(
+        row_ids, flat, width, group)
+    ids = ids.to(torch.int64)
+    outs = []
+    fills = list(fill) if isinstance(fill, (list, tuple)) else [fill] * len(values)
+    for v, w, c, fv in zip(values, width, cols, fills):
+        shape = (n_total, w) if v.dim() == 2 else (n_total,)
+        out = torch.full(shape, fv, dtype=v.dtype, device=v.device)
+        out[ids] = c.reshape(-1, w) if v.dim() == 2 else c
+        outs.append(out)
+    return outs
+
+
+def _gatherv_wide(row_ids, flat, width, group):
+    """all-gatherv for payloads of different widths: the per-rank element counts differ per payload, so each
+    payload gets its own exchange (still one grouped batch of sends/receives each)."""
+    (ids,), counts = all_gatherv([row_ids.contiguous()], group=group)
+    cols = []
+    for f in flat:
+        (g,), _ = all_gatherv([f], group=group)
+        cols.append(g)
+    return [ids] + cols, counts

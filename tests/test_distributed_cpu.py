@@ -97,3 +97,53 @@ def test_two_rank_gloo_all_gatherv_equals_single_process(tmp_path, n_contigs):
         got = np.stack([np.load(tmp_path / f"p{r}.npy"), np.load(tmp_path / f"b{r}.npy")], 1)
         got = got[np.lexsort((got[:, 1], got[:, 0]))]
         assert got.shape == exp.shape and (got == exp).all()      # every rank holds the full result
+
+
+def _worker_per_probe(rank, world, port, n_contigs, out_dir):
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    probe = synth.make_side(20000, 42, synth.PROBE_LEN, n_contigs)
+    probe = (probe[0].copy(), probe[1], probe[2])
+    probe[0][:7] = -1                                        # rows outside the dictionary: owned by no contig shard
+    build = synth.make_side(5000, 43, synth.DENSE_BUILD_LEN, n_contigs)
+    lp, pi, lb, bi, mode = D.shard_sides(probe, build, n_contigs, rank, world)
+    ix = O.Index(O.Side(*lb), n_contigs)
+    counts = torch.from_numpy(O.count_overlaps_fast(ix, O.Side(*lp), True))
+    idx, dist_, nf = O.nearest_fast(ix, O.Side(*lp), True, 2, True)
+    gidx = np.where(idx >= 0, bi[np.maximum(idx, 0)], -1).astype(np.int32)     # what ivj_side.row_id does on the device
+    full = D.gather_per_probe([counts, torch.from_numpy(gidx), torch.from_numpy(dist_)], torch.from_numpy(pi), 20000, fill=[0, -1, -1])
+    full_nf, = D.gather_per_probe([torch.from_numpy(nf)], torch.from_numpy(pi), 20000)
+    np.save(os.path.join(out_dir, f"c{rank}.npy"), full[0].numpy())
+    np.save(os.path.join(out_dir, f"i{rank}.npy"), full[1].numpy())
+    np.save(os.path.join(out_dir, f"d{rank}.npy"), full[2].numpy())
+    np.save(os.path.join(out_dir, f"n{rank}.npy"), full_nf.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_contigs", [24, 1])
+def test_two_rank_gloo_per_probe_results_in_probe_order(tmp_path, n_contigs):
+    """count_overlaps / nearest sharded over two ranks: after gather_per_probe every rank holds the
+    single-process result in original probe order (contig sharding and, for one contig, probe-row split)."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    world = 2
+    mp.spawn(_worker_per_probe, args=(world, _free_port(), n_contigs, str(tmp_path)), nprocs=world, join=True)
+    probe = synth.make_side(20000, 42, synth.PROBE_LEN, n_contigs)
+    probe = (probe[0].copy(), probe[1], probe[2])
+    probe[0][:7] = -1
+    build = synth.make_side(5000, 43, synth.DENSE_BUILD_LEN, n_contigs)
+    ix = O.Index(O.Side(*build), n_contigs)
+    ec = O.count_overlaps_fast(ix, O.Side(*probe), True)
+    ei, ed, en = O.nearest_fast(ix, O.Side(*probe), True, 2, True)
+    for r in range(world):
+        assert (np.load(tmp_path / f"c{r}.npy") == ec).all()
+        gi, gd, gn = np.load(tmp_path / f"i{r}.npy"), np.load(tmp_path / f"d{r}.npy"), np.load(tmp_path / f"n{r}.npy")
+        owned = gn > 0
+        assert (gn[owned] == en[owned]).all() and (en[~owned] == 0).all()
+        assert (gi[owned] == ei[owned]).all() and (gd[owned] == ed[owned]).all()
+        assert (gi == ei).all() and (gd == ed).all()           # rows nobody owns read -1 like the single-process result
