@@ -283,6 +283,14 @@ int ivj_merge_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min
                   int32_t* contig_dev, int32_t* start_dev, int32_t* end_dev, int64_t* n_intervals_dev, int64_t* n_merged);
 int ivj_coverage_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* coverage_dev);
 
+/* Arrow C Data Interface IMPORT of one side (zero copy): `array` / `schema` describe a struct array (or record
+ * batch) whose children named contig / start / end (any order, other children ignored) are int32 without nulls --
+ * what the reference hands its executor as an ArrowArrayStream batch after the chrom column has been dictionary
+ * encoded (src/lib.rs:89-100 collects the stream; range_op_io.py:398-418 builds it).  Fills *out with pointers INTO
+ * the Arrow buffers (offset applied); nothing is copied and nothing is released: the caller keeps the ArrowArray
+ * alive for as long as *out is used.  Needs no device. */
+int ivj_side_from_arrow(const void* array, const void* schema, ivj_side* out);
+
 /* ---- device memory helpers for callers without a HIP binding ------------ */
 int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out);
 int ivj_dev_free(ivj_ctx* ctx, void* p);

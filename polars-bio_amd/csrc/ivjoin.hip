@@ -1601,6 +1601,37 @@ void release_rows_array(ArrowArray* a) {
 }
 }  // namespace
 
+int ivj_side_from_arrow(const void* array, const void* schema, ivj_side* out) {
+    if (!array || !schema || !out) return fail(IVJ_EINVAL, "import: NULL argument");
+    const auto* arr = static_cast<const ArrowArray*>(array);
+    const auto* sch = static_cast<const ArrowSchema*>(schema);
+    if (!sch->format || std::strcmp(sch->format, "+s") != 0) return fail(IVJ_EINVAL, "import: a struct array / record batch is expected");
+    if (arr->n_children != sch->n_children) return fail(IVJ_EINVAL, "import: array and schema disagree on the number of children");
+    if (arr->null_count > 0) return fail(IVJ_EINVAL, "import: the struct array has null rows");
+    const int32_t* cols[3] = {nullptr, nullptr, nullptr};
+    const char* names[3] = {"contig", "start", "end"};
+    for (int64_t k = 0; k < sch->n_children; ++k) {
+        const ArrowSchema* cs = sch->children[k];
+        const ArrowArray* ca = arr->children[k];
+        if (!cs || !ca || !cs->name) continue;
+        for (int j = 0; j < 3; ++j) {
+            if (std::strcmp(cs->name, names[j]) != 0) continue;
+            if (!cs->format || std::strcmp(cs->format, "i") != 0) return fail(IVJ_EINVAL, std::string("import: column ") + names[j] + " must be int32");
+            if (ca->null_count > 0) return fail(IVJ_EINVAL, std::string("import: column ") + names[j] + " contains nulls");
+            if (ca->length < arr->offset + arr->length) return fail(IVJ_EINVAL, std::string("import: column ") + names[j] + " is shorter than the struct");
+            if (ca->n_buffers < 2 || (!ca->buffers[1] && ca->length > 0)) return fail(IVJ_EINVAL, std::string("import: column ") + names[j] + " has no value buffer");
+            cols[j] = static_cast<const int32_t*>(ca->buffers[1]) + ca->offset + arr->offset;
+            if (ca->length == 0) cols[j] = nullptr;
+        }
+    }
+    for (int j = 0; j < 3; ++j)
+        if (!cols[j] && arr->length > 0) return fail(IVJ_EINVAL, std::string("import: no int32 column named ") + names[j]);
+    out->contig = cols[0]; out->start = cols[1]; out->end = cols[2];
+    out->n = arr->length;
+    out->row_id = nullptr;
+    return IVJ_OK;
+}
+
 int ivj_rows_export_arrow(ivj_rows* rows, void* out_array, void* out_schema) {
     if (!rows || !out_array || !out_schema) return fail(IVJ_EINVAL, "export: NULL argument");
     auto* arr = static_cast<ArrowArray*>(out_array);

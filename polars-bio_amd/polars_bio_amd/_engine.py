@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "ivj_overlap", "ivj_pairs_free", "ivj_count_overlaps", "ivj_nearest",
     "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev", "ivj_overlap_fused_dev",
     "ivj_count_overlaps_dev", "ivj_nearest_dev",
-    "ivj_materialize_dev", "ivj_overlap_fused_rows_dev", "ivj_take_dev", "ivj_overlap_rows", "ivj_rows_free", "ivj_rows_export_arrow",
+    "ivj_side_from_arrow", "ivj_materialize_dev", "ivj_overlap_fused_rows_dev", "ivj_take_dev", "ivj_overlap_rows", "ivj_rows_free", "ivj_rows_export_arrow",
     "ivj_subtract", "ivj_complement", "ivj_pieces_free", "ivj_subtract_dev",
     "ivj_merge", "ivj_merged_free", "ivj_cluster", "ivj_coverage", "ivj_cluster_dev", "ivj_merge_dev", "ivj_coverage_dev",
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
@@ -133,6 +133,7 @@ def load_library() -> C.CDLL:
         L.ivj_rows_free.argtypes = [C.POINTER(_Rows)]
         L.ivj_rows_free.restype = None
         L.ivj_rows_export_arrow.argtypes = [C.POINTER(_Rows), vp, vp]
+        L.ivj_side_from_arrow.argtypes = [vp, vp, P]
         L.ivj_subtract.argtypes = [vp, P, P, O, C.POINTER(_Pieces)]
         L.ivj_complement.argtypes = [vp, P, P, O, C.POINTER(_Pieces)]
         L.ivj_pieces_free.argtypes = [C.POINTER(_Pieces)]
@@ -179,6 +180,17 @@ def _host_side(contig, start, end) -> Tuple[_Side, tuple]:
     if not (c.shape == s.shape == e.shape and c.ndim == 1):
         raise ValueError("contig/start/end must be 1-D arrays of equal length")
     return _Side(c.ctypes.data, s.ctypes.data, e.ctypes.data, c.shape[0], None), (c, s, e)
+
+
+def side_from_arrow(batch) -> Tuple[_Side, tuple]:
+    """pyarrow.RecordBatch / StructArray with int32 children contig / start / end -> ivj_side viewing the Arrow
+    buffers (ivj_side_from_arrow, zero copy).  Returns (side, keep-alive); needs no device."""
+    L = load_library()
+    arr, sch = _ArrowArray(), _ArrowSchema()
+    batch._export_to_c(C.addressof(arr), C.addressof(sch))
+    side = _Side()
+    _check(L, L.ivj_side_from_arrow(C.addressof(arr), C.addressof(sch), C.byref(side)), "ivj_side_from_arrow")
+    return side, (batch, arr, sch)
 
 
 def make_opts(strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True, partition_mode: int = 0,

@@ -71,3 +71,34 @@ def test_error_codes_for_bad_arguments():
     assert L.ivj_device_count(None) == -1
     assert b"NULL" in L.ivj_last_error()
     assert L.ivj_ctx_sync(None) == -1
+
+
+def test_arrow_c_data_import_of_a_side_is_zero_copy():
+    """ivj_side_from_arrow: the three key columns of a record batch are viewed in place (offsets of sliced batches
+    applied), extra columns ignored, wrong types / nulls / missing columns refused.  Needs no device."""
+    import ctypes as C
+    import numpy as np
+    import pyarrow as pa
+    from polars_bio_amd import _engine
+    n = 1000
+    rng = np.random.default_rng(1)
+    cols = {"score": pa.array(rng.random(n)), "end": pa.array(rng.integers(0, 1 << 30, n).astype(np.int32)),
+            "contig": pa.array(rng.integers(0, 24, n).astype(np.int32)), "start": pa.array(rng.integers(0, 1 << 30, n).astype(np.int32))}
+    batch = pa.record_batch(cols)
+    for b in (batch, batch.slice(17, 400)):
+        side, keep = _engine.side_from_arrow(b)
+        assert side.n == b.num_rows
+        for name in ("contig", "start", "end"):
+            got = np.ctypeslib.as_array(C.cast(getattr(side, name), C.POINTER(C.c_int32)), shape=(b.num_rows,))
+            exp = b.column(name).to_numpy()
+            assert (got == exp).all()
+            assert got.ctypes.data == exp.ctypes.data          # same memory: nothing was copied
+        del keep
+    bad = [pa.record_batch({"contig": cols["contig"], "start": cols["start"]}),                                   # no end
+           pa.record_batch({"contig": cols["contig"], "start": cols["start"], "end": pa.array(np.arange(n, dtype=np.int64))}),
+           pa.record_batch({"contig": cols["contig"], "start": cols["start"], "end": pa.array([None] + [1] * (n - 1), type=pa.int32())})]
+    for b in bad:
+        with pytest.raises(_engine.EngineError):
+            _engine.side_from_arrow(b)
+    empty, _ = _engine.side_from_arrow(batch.slice(0, 0))
+    assert empty.n == 0
