@@ -1,5 +1,9 @@
 #!/bin/bash
-# GPU session driver.  usage: tools/gpu_call.sh [first] [pytest] [pytest-fast] [c2] [c3] [prof] [c4] [c5]
+# GPU session driver.  usage: tools/gpu_call.sh <stage>...   (run through gpurun; everything lands in gpurun_out/)
+#   tests:    first | pytest | pytest-fast | fusedtest
+#   benches:  c2 c3 c3two c3dense c3rows c3fine c2fine c3lvl2 c2lvl2 c3flat c2flat c4 c5 sortscan hostpath
+#   profiles: prof (rocprofv3 --kernel-trace --stats) | pmc (FETCH/WRITE_SIZE, config 3) | pmcx | pmcsq [PMODE= WL=] | pmcfine
+#   see also tools/pmc_traffic.sh <workload>, tools/pmc_summary.py, tools/atomic_bench.hip
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
