@@ -41,7 +41,7 @@ for stage in "$@"; do
     hostpath) echo "== host-buffer (PCIe-inclusive) path"; timeout 900 python tools/host_path_timing.py 2>&1 | tee gpurun_out/host_path.log | tail -5 ;;
     pmcx) echo "== rocprofv3 PMC deep-dive (config3)";
       i=0; dirs="";
-      for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum"; do
+      for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"; do   # (a TA_* counter set hangs rocprofv3 on this pool: "1 incomplete dispatches" -- never add one)
         i=$((i+1));
         (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $set -d "$OLDPWD/gpurun_out/pmcx_$i" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmcx_$i.out" 2> "$OLDPWD/gpurun_out/pmcx_$i.err");
         tail -1 gpurun_out/pmcx_$i.err | cut -c1-200; dirs="$dirs gpurun_out/pmcx_$i";
