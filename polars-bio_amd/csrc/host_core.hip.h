@@ -1,0 +1,256 @@
+// host_core.hip.h -- error state, scratch arena, context and index structs, timing, launch / scan / sort helpers of the host driver
+// Part of the single translation unit ivjoin.hip (included there, in this order); not a stand-alone header.
+#pragma once
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(IVJ_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    } while (0)
+
+#define IVJ_TRY(expr)                 \
+    do {                              \
+        int _r = (expr);              \
+        if (_r != IVJ_OK) return _r;  \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+};
+
+struct TimingRec {
+    const char* name;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct ivj_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    Arena arena;
+    // state handed from ivj_overlap_count_dev to ivj_overlap_fill_dev
+    char* ov_buf = nullptr;
+    size_t ov_cap = 0;
+    int64_t ov_n = -1;
+    const void* ov_probe_start = nullptr;
+    const ivj_index* ov_ix = nullptr;
+    int32_t ov_filter = -1;
+    int32_t* ov_hi = nullptr;
+    int32_t* ov_cnt = nullptr;
+    long long* ov_tile = nullptr;   // ntiles + 1: tile bases, last = total
+    long long* h_total = nullptr;   // pinned
+    // one released index slab kept for reuse (bench/streaming loops rebuild the index every call)
+    char* ix_cache = nullptr;
+    size_t ix_cache_cap = 0;
+    int64_t ov_total = 0;
+    // bucketed (partitioned) copies of the probe columns + their row ids, when the partition path ran
+    bool ov_part = false;
+    int32_t *pt_c = nullptr, *pt_s = nullptr, *pt_e = nullptr, *pt_row = nullptr;
+    int32_t *pu_c = nullptr, *pu_s = nullptr, *pu_e = nullptr, *pu_row = nullptr;   // second set (two-level bucketing)
+    uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
+    bool part_attr_set = false;
+    // timing
+    int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
+    bool t_open = false;
+    std::vector<TimingRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+};
+
+struct ivj_index {
+    ivj_ctx* ctx = nullptr;
+    int32_t table_mode = 0;
+    int64_t n = 0;
+    int32_t n_contigs = 0;
+    int32_t* b_start = nullptr;
+    int2* ep = nullptr;
+    int4* rec4 = nullptr;
+    uint32_t* lot = nullptr;
+    uint2* tab2 = nullptr;
+    int32_t* b_row = nullptr;
+    int32_t* b_contig = nullptr;
+    int32_t* seg = nullptr;
+    int32_t* flags = nullptr;
+    int32_t* e_end = nullptr;
+    int32_t* e_pos = nullptr;
+    int4* cmeta = nullptr;
+    uint32_t* bins = nullptr;
+    int4* cmeta_e = nullptr;
+    uint32_t* bins_e = nullptr;
+    int4* brec = nullptr;
+    int4* brec_e = nullptr;
+    int32_t* pargmax = nullptr;
+    int4* nrec = nullptr;
+    int4* cmeta_j = nullptr;
+    int4* crec = nullptr;
+    int64_t bins_len = 0;
+    bool has_end_order = false;
+    bool has_argmax = false;
+    bool has_flat = false;
+    bool has_rec4 = false;
+    bool has_tables = true;    // false: built for merge / cluster only (with_end_order & 2)     // rec4 is filled on demand (join + materialisation path, flat path)
+    char* slab = nullptr;      // single allocation holding every array above
+    size_t slab_cap = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int arena_reserve(ivj_ctx* ctx, size_t bytes) {
+    Arena& A = ctx->arena;
+    A.off = 0;
+    if (bytes <= A.cap) return IVJ_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (A.base) HIP_TRY(hipFree(A.base));
+    A.base = nullptr; A.cap = 0;
+    size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    hipError_t e = hipMalloc((void**)&A.base, want);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, "arena hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e));
+    A.cap = want;
+    return IVJ_OK;
+}
+
+template <class T>
+T* arena_take(ivj_ctx* ctx, size_t count) {
+    Arena& A = ctx->arena;
+    size_t bytes = align_up(count * sizeof(T));
+    if (A.off + bytes > A.cap) return nullptr;   // reserve() sized wrongly: programming error
+    T* p = reinterpret_cast<T*>(A.base + A.off);
+    A.off += bytes;
+    return p;
+}
+
+bool is_probe_kernel(const char* name) {
+    return !std::strncmp(name, "overlap_", 8) || !std::strncmp(name, "count_overlaps", 14) || !std::strncmp(name, "nearest", 7) ||
+           !std::strncmp(name, "materialize", 11) || !std::strncmp(name, "take", 4) || !std::strncmp(name, "coverage", 8) ||
+           !std::strncmp(name, "subtract_", 9) || !std::strncmp(name, "cluster_", 8);
+}
+void t_begin(ivj_ctx* ctx, const char* name) {
+    ctx->t_open = false;
+    if (!ctx->timing) return;
+    if (ctx->timing == 1 && !is_probe_kernel(name)) return;
+    if (ctx->pool_used + 2 > ctx->pool.size()) {
+        for (int i = 0; i < 64; ++i) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return; ctx->pool.push_back(ev); }
+    }
+    TimingRec r{name, ctx->pool[ctx->pool_used], ctx->pool[ctx->pool_used + 1]};
+    ctx->pool_used += 2;
+    (void)hipEventRecord(r.a, ctx->stream);
+    ctx->recs.push_back(r);
+    ctx->t_open = true;
+}
+void t_end(ivj_ctx* ctx) {
+    if (!ctx->t_open) return;
+    (void)hipEventRecord(ctx->recs.back().b, ctx->stream);
+    ctx->t_open = false;
+}
+
+#define LAUNCH(ctx, name, kernel, grid, block, ...)                                   \
+    do {                                                                              \
+        t_begin(ctx, name);                                                           \
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, (ctx)->stream, __VA_ARGS__); \
+        t_end(ctx);                                                                   \
+    } while (0)
+
+inline unsigned grid1d(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+// device-wide scan: three launches (reduce, partials, apply)
+template <class T, class Op, bool INCLUSIVE>
+void device_scan(ivj_ctx* ctx, const char* name, const T* in, T* out, int64_t n, T identity, T* partials, T* total_out) {
+    const int64_t tiles = scan_num_tiles(n);
+    LAUNCH(ctx, name, (k_scan_reduce<T, Op>), tiles, SCAN_THREADS, in, n, identity, partials);
+    LAUNCH(ctx, name, (k_scan_partials<T, Op>), 1, SCAN_THREADS, partials, tiles, identity, total_out);
+    LAUNCH(ctx, name, (k_scan_apply<T, Op, INCLUSIVE>), tiles, SCAN_THREADS, in, out, n, identity, (const T*)partials);
+}
+
+struct SortBufs {
+    uint32_t *kA, *vA, *kB, *vB, *hist, *partials;
+};
+
+size_t sort_scratch_elems_hist(int64_t n) { return (size_t)RS_RADIX * (size_t)rs_num_blocks(n); }
+
+// LSD passes over `bits` low bits of the keys in (kA,vA); returns true when the result is in (kB,vB).
+bool radix_sort_pairs(ivj_ctx* ctx, const SortBufs& sb, int64_t n, int bits) {
+    const int nblocks = rs_num_blocks(n);
+    uint32_t *kin = sb.kA, *vin = sb.vA, *kout = sb.kB, *vout = sb.vB;
+    bool flipped = false;
+    for (int shift = 0; shift < bits; shift += 8) {
+        LAUNCH(ctx, "rs_hist", k_rs_hist, nblocks, RS_THREADS, (const uint32_t*)kin, n, shift, sb.hist, nblocks);
+        device_scan<uint32_t, SumOp, false>(ctx, "rs_scan", sb.hist, sb.hist, (int64_t)RS_RADIX * nblocks, 0u, sb.partials,
+                                             (uint32_t*)nullptr);
+        LAUNCH(ctx, "rs_scatter", k_rs_scatter, nblocks, RS_THREADS, (const uint32_t*)kin, (const uint32_t*)vin, kout, vout,
+               n, shift, (const uint32_t*)sb.hist, nblocks);
+        std::swap(kin, kout); std::swap(vin, vout);
+        flipped = !flipped;
+    }
+    return flipped;
+}
+
+int bits_for(uint32_t max_value) {
+    int b = 0;
+    while (b < 32 && (max_value >> b) != 0) ++b;
+    return b == 0 ? 1 : b;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_opts(const ivj_opts* o) {
+    if (!o) return fail(IVJ_EINVAL, "opts is NULL");
+    if (o->filter_op != IVJ_FILTER_WEAK && o->filter_op != IVJ_FILTER_STRICT) return fail(IVJ_EINVAL, "filter_op must be 0 (Weak) or 1 (Strict)");
+    if (o->n_contigs < 0) return fail(IVJ_EINVAL, "n_contigs < 0");
+    if (o->table_mode < 0 || o->table_mode > 2) return fail(IVJ_EINVAL, "table_mode must be 0 (auto), 1 (records) or 2 (bins)");
+    if (o->partition_mode < 0 || o->partition_mode > 5) return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (256-way), 2 (never), 3 (fine, fused path only), 4 (two-level) or 5 (flat, fused path only)");
+    return IVJ_OK;
+}
+int check_side(const ivj_side* s, const char* what) {
+    if (!s) return fail(IVJ_EINVAL, std::string(what) + " is NULL");
+    if (s->n < 0) return fail(IVJ_EINVAL, std::string(what) + ".n < 0");
+    if (s->n > 0 && (!s->contig || !s->start || !s->end)) return fail(IVJ_EINVAL, std::string(what) + " has a NULL column");
+    if (s->n > 0x7fff0000ll) return fail(IVJ_EINVAL, std::string(what) + ".n exceeds the int32 row-index range");
+    return IVJ_OK;
+}
+
+IndexView view_of(const ivj_index* ix) {
+    IndexView v;
+    v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
+    v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
+    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec; v.cmeta_j = ix->cmeta_j; v.crec = ix->crec;
+    v.bins = ix->bins; v.bins_e = ix->bins_e; v.rec4 = ix->rec4; v.tab2 = ix->tab2;
+    // 16-byte bin records once the 4-byte tables + key arrays no longer fit the XCD L2s anyway
+    v.use_rec = ix->table_mode == 1 ? 1 : (ix->table_mode == 2 ? 0 : (ix->n >= (1ll << 20) ? 1 : 0));
+    return v;
+}
+
+size_t sort_scratch_bytes(int64_t n) {
+    const size_t hist = sort_scratch_elems_hist(n);
+    return 4 * align_up((size_t)n * 4) + align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4);
+}
+void take_sort_bufs(ivj_ctx* ctx, int64_t n, SortBufs& sb) {
+    const size_t hist = sort_scratch_elems_hist(n);
+    sb.kA = arena_take<uint32_t>(ctx, n); sb.vA = arena_take<uint32_t>(ctx, n);
+    sb.kB = arena_take<uint32_t>(ctx, n); sb.vB = arena_take<uint32_t>(ctx, n);
+    sb.hist = arena_take<uint32_t>(ctx, hist);
+    sb.partials = arena_take<uint32_t>(ctx, scan_num_tiles((int64_t)hist) + 1);
+}
+
+}  // namespace

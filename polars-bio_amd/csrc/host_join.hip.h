@@ -1,0 +1,438 @@
+// host_join.hip.h -- probe bucketing and the overlap / count_overlaps / nearest drivers, host <-> device staging of the host-buffer entry points
+// Part of the single translation unit ivjoin.hip (included there, in this order); not a stand-alone header.
+#pragma once
+
+namespace {
+
+int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one permuted column set, 2: two
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    const size_t col = align_up((size_t)n * 4);
+    const size_t need = (size_t)(2 + 4 * with_part) * col + align_up((size_t)(tiles + 2) * 8) +
+                        align_up((size_t)(scan_num_tiles(tiles) + 2) * 8) + align_up((PART_BUCKETS + 1) * 4) + 1024;
+    if (need > ctx->ov_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->ov_buf) HIP_TRY(hipFree(ctx->ov_buf));
+        ctx->ov_buf = nullptr; ctx->ov_cap = 0;
+        size_t want = align_up(need + need / 8, 1 << 20);
+        hipError_t e = hipMalloc((void**)&ctx->ov_buf, want);
+        if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("overlap state hipMalloc: ") + hipGetErrorString(e));
+        ctx->ov_cap = want;
+    }
+    char* p = ctx->ov_buf;
+    ctx->ov_hi = (int32_t*)p; p += col;
+    ctx->ov_cnt = (int32_t*)p; p += col;
+    if (with_part) {
+        ctx->pt_c = (int32_t*)p; p += col;
+        ctx->pt_s = (int32_t*)p; p += col;
+        ctx->pt_e = (int32_t*)p; p += col;
+        ctx->pt_row = (int32_t*)p; p += col;
+    }
+    if (with_part > 1) {
+        ctx->pu_c = (int32_t*)p; p += col;
+        ctx->pu_s = (int32_t*)p; p += col;
+        ctx->pu_e = (int32_t*)p; p += col;
+        ctx->pu_row = (int32_t*)p; p += col;
+    }
+    ctx->pt_bstart = (uint32_t*)p; p += align_up((PART_BUCKETS + 1) * 4);
+    ctx->ov_tile = (long long*)p;
+    return IVJ_OK;
+}
+
+// Probe bucketing pays once the index no longer fits the L2s and there are enough probes to
+// amortise the two extra passes.  opts->partition_mode: 0 auto, 1 always, 2 never.
+bool want_partition(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts) {
+    if (opts->partition_mode == 1 || opts->partition_mode >= 3) return true;
+    if (opts->partition_mode == 2) return false;
+    return n_probe >= (4ll << 20) && ix->n >= (256ll << 10);
+}
+
+// one stable 256-way pass: src columns -> dst columns
+int partition_pass(ivj_ctx* ctx, ivj_index* ix, bool strict, const int32_t* sc, const int32_t* ss, const int32_t* se,
+                   const int32_t* srow, int64_t n, int packed, int32_t* dc, int32_t* ds, int32_t* de, int32_t* drow) {
+    const int ntiles = (int)((n + PART_TILE - 1) / PART_TILE);
+    const int grid = 8 * ((ntiles + 7) / 8);
+    const size_t hist = (size_t)PART_BUCKETS * (size_t)ntiles;
+    IVJ_TRY(arena_reserve(ctx, align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4) + 4096));
+    uint32_t* blk = arena_take<uint32_t>(ctx, hist);
+    uint32_t* partials = arena_take<uint32_t>(ctx, scan_num_tiles((int64_t)hist) + 1);
+    if (!ctx->part_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
+        ctx->part_attr_set = true;
+    }
+    IndexView v = view_of(ix);
+    const bool hvec = aligned16(sc) && aligned16(se);
+    if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, sc, se, n, packed, blk, ntiles, hvec);
+    else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, sc, se, n, packed, blk, ntiles, hvec);
+    device_scan<uint32_t, SumOp, false>(ctx, "part_scan", blk, blk, (int64_t)hist, 0u, partials, (uint32_t*)nullptr);
+    // bucket b starts at blk[b * ntiles] (bucket-major scan); kept for the inverse permutation (k_unpermute)
+    HIP_TRY(hipMemcpy2DAsync(ctx->pt_bstart, 4, blk, (size_t)ntiles * 4, 4, PART_BUCKETS, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->pt_bstart + PART_BUCKETS), (int)n, 1, ctx->stream));
+    t_begin(ctx, "part_scatter");
+    if (strict)
+        hipLaunchKernelGGL((k_part_scatter<true>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, sc, ss, se, srow, n, packed,
+                           (const uint32_t*)blk, ntiles, dc, ds, de, drow);
+    else
+        hipLaunchKernelGGL((k_part_scatter<false>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, sc, ss, se, srow, n, packed,
+                           (const uint32_t*)blk, ntiles, dc, ds, de, drow);
+    t_end(ctx);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+// partition_mode 4 (or auto for very large probe sides): two stable passes -> 65536 buckets of ~76
+// build rows: the 64 probes of a wavefront then look at the same few cache lines.
+bool want_two_level(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts) {
+    (void)ix; (void)n_probe;
+    return opts->partition_mode == 4;
+}
+
+int partition_probes(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts) {
+    const int64_t n = probe->n;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    if (want_two_level(ix, n, opts)) {
+        int bs = 0;
+        while ((ix->bins_len >> bs) > 65533ll) ++bs;
+        IVJ_TRY(partition_pass(ctx, ix, strict, probe->contig, probe->start, probe->end, probe->row_id, n, part_pack(bs, 0, true),
+                               ctx->pu_c, ctx->pu_s, ctx->pu_e, ctx->pu_row));
+        return partition_pass(ctx, ix, strict, ctx->pu_c, ctx->pu_s, ctx->pu_e, ctx->pu_row, n, part_pack(bs, 8, true),
+                              ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
+    }
+    int bshift = 0;
+    while ((ix->bins_len >> bshift) > (int64_t)(PART_BUCKETS - 3)) ++bshift;
+    return partition_pass(ctx, ix, strict, probe->contig, probe->start, probe->end, probe->row_id, n, part_pack(bshift, 0, false),
+                          ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
+}
+
+int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* n_pairs) {
+    IVJ_TRY(need_tables(ix));
+    const int64_t n = probe->n;
+    ctx->ov_n = -1;
+    if (n == 0 || ix->n == 0) {
+        ctx->ov_n = n; ctx->ov_total = 0; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
+        *n_pairs = 0;
+        return IVJ_OK;
+    }
+    const bool part = want_partition(ix, n, opts);
+    IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
+    ctx->ov_part = part;
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    long long* tile = ctx->ov_tile;                       // tiles + 1
+    long long* partials = tile + align_up((size_t)(tiles + 2) * 8) / 8;
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end;
+    if (part) {
+        IVJ_TRY(partition_probes(ctx, ix, probe, opts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e;
+    }
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+    IndexView v = view_of(ix);
+    if (opts->filter_op == IVJ_FILTER_STRICT)
+        LAUNCH(ctx, "overlap_count", (k_overlap_count<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, n, vec,
+               ctx->ov_hi, ctx->ov_cnt, tile);
+    else
+        LAUNCH(ctx, "overlap_count", (k_overlap_count<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, n, vec,
+               ctx->ov_hi, ctx->ov_cnt, tile);
+    device_scan<long long, SumOp, false>(ctx, "tile_scan", tile, tile, tiles, 0ll, partials, tile + tiles);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, tile + tiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    ctx->ov_total = *ctx->h_total;
+    ctx->ov_n = n; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
+    *n_pairs = ctx->ov_total;
+    return IVJ_OK;
+}
+
+int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
+                 int64_t capacity) {
+    if (ctx->ov_n != probe->n || ctx->ov_probe_start != probe->start || ctx->ov_ix != ix || ctx->ov_filter != opts->filter_op)
+        return fail(IVJ_ESTATE, "ivj_overlap_fill_dev must follow ivj_overlap_count_dev with the same index, probe and filter_op");
+    if (capacity < ctx->ov_total) return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->ov_total) + " pairs");
+    if (ctx->ov_total == 0) return IVJ_OK;
+    if (!out_p || !out_b) return fail(IVJ_EINVAL, "output buffers are NULL");
+    const int64_t n = probe->n;
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    const int32_t* qs = ctx->ov_part ? ctx->pt_s : probe->start;
+    const int32_t* ids = ctx->ov_part ? ctx->pt_row : probe->row_id;
+    const bool vec = aligned16(qs);
+    IndexView v = view_of(ix);
+    // dense results (>= 8 pairs per probe on average): windows shared out over all wavefronts
+    const bool dense = ctx->ov_total >= 8 * n;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    if (dense) {
+        if (strict) LAUNCH(ctx, "overlap_fill_dense", (k_overlap_fill_dense<true, PROBE_ITEMS>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+                           (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
+        else LAUNCH(ctx, "overlap_fill_dense", (k_overlap_fill_dense<false, PROBE_ITEMS>), tiles, PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+                    (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
+    } else {
+        if (strict) LAUNCH(ctx, "overlap_fill", (k_overlap_fill<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+                           (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
+        else LAUNCH(ctx, "overlap_fill", (k_overlap_fill<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qs, n, vec, (const int32_t*)ctx->ov_hi,
+                    (const int32_t*)ctx->ov_cnt, (const long long*)ctx->ov_tile, ids, out_p, out_b);
+    }
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+// "fine" single pass: 8192-way bucketing (atomics) + join kernel with LDS-resident index slices.
+// Available when a bucket spans at most FINE_SLOTS table slots.
+bool fine_available(const ivj_index* ix) { return (ix->bins_len >> FINE_SLOT_BITS) <= (int64_t)(FINE_BUCKETS - 2); }
+
+int overlap_fused_fine(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
+                       int64_t capacity, int64_t* n_pairs) {
+    const int64_t n = probe->n;
+    ctx->ov_n = -1;
+    *n_pairs = 0;
+    if (n == 0 || ix->n == 0) return IVJ_OK;
+    IVJ_TRY(ensure_ov(ctx, n, 1));
+    int bshift = 0;
+    while ((ix->bins_len >> bshift) > (int64_t)(FINE_BUCKETS - 2)) ++bshift;
+    const int64_t jgrid = (n + FINE_TILE - 1) / FINE_TILE + FINE_BUCKETS;      // upper bound on the number of tiles
+    IVJ_TRY(arena_reserve(ctx, 4 * align_up((size_t)(FINE_BUCKETS + 1) * 4) + align_up((size_t)FINE_BUCKETS * 8) +
+                               align_up((size_t)jgrid * 4) + 4096));
+    uint32_t* gcount = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
+    uint32_t* gstart = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
+    uint32_t* cursor = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
+    uint32_t* tprefix = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
+    int2* brange = arena_take<int2>(ctx, FINE_BUCKETS);
+    uint32_t* tbucket = arena_take<uint32_t>(ctx, jgrid);
+    int4* prec = reinterpret_cast<int4*>(ctx->pt_c);          // the four permuted columns' space holds the 16-byte records
+    unsigned long long* state = (unsigned long long*)ctx->ov_tile;
+    HIP_TRY(hipMemsetAsync(gcount, 0, (size_t)(FINE_BUCKETS + 1) * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(state, 0, 16, ctx->stream));
+    IndexView v = view_of(ix);
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
+    const int hgrid = 1024;
+    if (strict) LAUNCH(ctx, "fine_hist", (k_fine_hist<true>), hgrid, 1024, v, probe->contig, probe->end, n, bshift, vec, gcount);
+    else LAUNCH(ctx, "fine_hist", (k_fine_hist<false>), hgrid, 1024, v, probe->contig, probe->end, n, bshift, vec, gcount);
+    LAUNCH(ctx, "fine_offsets", k_fine_offsets, 1, 1024, (const uint32_t*)gcount, gstart, cursor, tprefix);
+    LAUNCH(ctx, "fine_tilemap", k_fine_tilemap, grid1d(FINE_BUCKETS, 256), 256, (const uint32_t*)ix->bins, (long long)ix->bins_len, bshift,
+           (const uint32_t*)tprefix, brange, tbucket);
+    const int64_t sgrid = (n + 8192 - 1) / 8192;
+    if (strict) LAUNCH(ctx, "fine_scatter", (k_fine_scatter<true>), sgrid, 1024, v, probe->contig, probe->start, probe->end, probe->row_id, n, bshift, vec,
+                       cursor, prec);
+    else LAUNCH(ctx, "fine_scatter", (k_fine_scatter<false>), sgrid, 1024, v, probe->contig, probe->start, probe->end, probe->row_id, n, bshift, vec,
+                cursor, prec);
+    if (strict) LAUNCH(ctx, "overlap_fused_fine", (k_overlap_fused_fine<true>), jgrid, FINE_THREADS, v, (const int4*)prec, (const uint32_t*)gstart,
+                       (const uint32_t*)tprefix, (const uint32_t*)tbucket, (const int2*)brange, bshift, (long long)ix->bins_len, (long long)capacity,
+                       state, out_p, out_b);
+    else LAUNCH(ctx, "overlap_fused_fine", (k_overlap_fused_fine<false>), jgrid, FINE_THREADS, v, (const int4*)prec, (const uint32_t*)gstart,
+                (const uint32_t*)tprefix, (const uint32_t*)tbucket, (const int2*)brange, bshift, (long long)ix->bins_len, (long long)capacity,
+                state, out_p, out_b);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    *n_pairs = ctx->h_total[0];
+    if (ctx->h_total[1] != 0)
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");
+    return IVJ_OK;
+}
+
+// single pass: (bucketing +) fused count/fill into a caller buffer of known capacity
+int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
+                  int64_t capacity, int64_t* n_pairs) {
+    IVJ_TRY(need_tables(ix));
+    const int64_t n = probe->n;
+    ctx->ov_n = -1;                                   // invalidates a pending count -> fill hand-over
+    *n_pairs = 0;
+    if (n == 0 || ix->n == 0) return IVJ_OK;
+    if (opts->partition_mode == 3 && fine_available(ix)) return overlap_fused_fine(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
+    const bool part = want_partition(ix, n, opts);
+    IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
+    // dense results (the caller expects >= 16 pairs per probe; at ~8 the two kernels tie and the flat one still has
+    // to fill its arrays and the end order): the flat kernel spreads every window over the whole
+    // workgroup (1.8x the count + dense-fill pair on 37 pairs per probe); sparse ones keep the window-scan kernel
+    const bool flat = opts->partition_mode == 5 || (opts->partition_mode == 0 && capacity >= 16 * n && ix->n_contigs > 0);
+    if (flat) IVJ_TRY(build_flat(ctx, ix));
+    // dense tiles of the flat kernel get their match counts from the end order (two-rank formula) instead of a sweep
+    const bool rank_counts = flat && capacity >= 16 * n;
+    if (rank_counts) IVJ_TRY(build_end_order(ctx, ix));
+    const int64_t tiles = flat ? (n + FLAT_TILE - 1) / FLAT_TILE : (n + PROBE_TILE - 1) / PROBE_TILE;
+    unsigned long long* state = (unsigned long long*)ctx->ov_tile;   // [0] cursor, [1] overflow
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *ids = probe->row_id;
+    if (part) {
+        IVJ_TRY(partition_probes(ctx, ix, probe, opts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e; ids = ctx->pt_row;
+    }
+    HIP_TRY(hipMemsetAsync(state, 0, 16, ctx->stream));
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+    IndexView v = view_of(ix);
+    if (flat) {
+        if (opts->filter_op == IVJ_FILTER_STRICT)
+            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<true>), 8 * ((tiles + 7) / 8), FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
+        else
+            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<false>), 8 * ((tiles + 7) / 8), FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
+    } else if (opts->filter_op == IVJ_FILTER_STRICT)
+        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+    else
+        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    *n_pairs = ctx->h_total[0];
+    if (ctx->h_total[1] != 0)
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");
+    return IVJ_OK;
+}
+
+struct DevBuf {                   // owning device allocation of the host-buffer entry points
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+// per-probe results of a kernel that ran over the bucketed probes (pt_*) -> original row order
+int unpermute(ivj_ctx* ctx, int64_t n, const UnpermuteCols& cols) {
+    LAUNCH(ctx, "unpermute", k_unpermute, (n + UNP_TILE - 1) / UNP_TILE, UNP_THREADS, (const int32_t*)ctx->pt_row, (const uint32_t*)ctx->pt_bstart, n, cols);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+// fused join + key-column materialisation (k_overlap_fused_rows); same partitioning as overlap_fused
+int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const ivj_rows* rows, int64_t* n_pairs) {
+    IVJ_TRY(need_tables(ix));
+    const int64_t n = probe->n;
+    const int64_t capacity = rows->n_pairs;
+    ctx->ov_n = -1;
+    *n_pairs = 0;
+    if (n == 0 || ix->n == 0) return IVJ_OK;
+    IVJ_TRY(build_rec4(ctx, ix));
+    const bool part = want_partition(ix, n, opts);
+    IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
+    const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
+    unsigned long long* state = (unsigned long long*)ctx->ov_tile;
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *ids = probe->row_id;
+    if (part) {
+        IVJ_TRY(partition_probes(ctx, ix, probe, opts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e; ids = ctx->pt_row;
+    }
+    HIP_TRY(hipMemsetAsync(state, 0, 16, ctx->stream));
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe) && aligned16(ids);
+    IndexView v = view_of(ix);
+    RowColumns cols{rows->probe_idx, rows->build_idx, rows->contig, rows->start_1, rows->end_1, rows->start_2, rows->end_2};
+    if (opts->filter_op == IVJ_FILTER_STRICT)
+        LAUNCH(ctx, "overlap_fused_rows", (k_overlap_fused_rows<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, cols);
+    else
+        LAUNCH(ctx, "overlap_fused_rows", (k_overlap_fused_rows<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, cols);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    *n_pairs = ctx->h_total[0];
+    if (ctx->h_total[1] != 0)
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " rows");
+    return IVJ_OK;
+}
+
+int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* counts) {
+    IVJ_TRY(need_tables(ix));
+    const int64_t n = probe->n;
+    if (n == 0) return IVJ_OK;
+    if (ix->n == 0) { HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
+    IVJ_TRY(build_end_order(ctx, ix));
+    // partition_mode 1 only: bucket the probes by genomic position, count in bucket order into scratch, bring the
+    // counts back to probe order with the coalesced inverse permutation.  Not the default: with ONE record gather per
+    // probe the bucketing + inverse permutation cost more than the L2 locality buys (100M x 5M: 4.1 ms plain, 5.2 ms
+    // bucketed; nearest and coverage, with 3+ gathers per probe, do gain).
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end;
+    long long* o_counts = (long long*)counts;
+    const bool bucketed = opts->partition_mode == 1 && ix->n > 0;
+    if (bucketed) {
+        ivj_side plain = *probe;
+        plain.row_id = nullptr;
+        IVJ_TRY(ensure_ov(ctx, n, 1));
+        ctx->ov_n = -1;
+        ivj_opts popts = *opts; popts.partition_mode = 1;
+        IVJ_TRY(partition_probes(ctx, ix, &plain, &popts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e;
+        IVJ_TRY(arena_reserve(ctx, align_up((size_t)n * 8) + 4096));
+        o_counts = arena_take<long long>(ctx, n);
+    }
+    constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT;
+    const int64_t tiles = (n + NT - 1) / NT;
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+    IndexView v = view_of(ix);
+    if (opts->filter_op == IVJ_FILTER_STRICT)
+        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts);
+    else
+        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts);
+    HIP_TRY(hipGetLastError());
+    if (bucketed) {
+        UnpermuteCols uc{{o_counts, nullptr, nullptr}, {counts, nullptr, nullptr}, {8, 0, 0}, 1, nullptr};
+        IVJ_TRY(unpermute(ctx, n, uc));
+    }
+    return IVJ_OK;
+}
+
+int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* idx, int64_t* dist, int32_t* nf) {
+    IVJ_TRY(need_tables(ix));
+    const int64_t n = probe->n;
+    const int k = opts->nearest_k < 1 ? 1 : opts->nearest_k;
+    if (n == 0) return IVJ_OK;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    const bool k1 = k == 1 && opts->include_overlaps;
+    if (k1) IVJ_TRY(build_argmax(ctx, ix));
+    else IVJ_TRY(build_end_order(ctx, ix));
+    // large probe sides: bucket them by genomic position first (every gather of the kernel then stays in the
+    // XCD L2s); the kernels write each result to the probe's original row
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *qrow = nullptr;
+    if (want_partition(ix, n, opts) && ix->n > 0) {
+        ivj_side plain = *probe;
+        plain.row_id = nullptr;
+        IVJ_TRY(ensure_ov(ctx, n, 1));
+        ctx->ov_n = -1;
+        ivj_opts popts = *opts; popts.partition_mode = 1;
+        IVJ_TRY(partition_probes(ctx, ix, &plain, &popts));
+        qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e; qrow = ctx->pt_row;
+    }
+    IndexView v = view_of(ix);
+    if (k1) {
+        constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT;
+        const int64_t tiles = (n + NT - 1) / NT;
+        const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+        int32_t *o_idx = idx, *o_nf = nf;
+        long long* o_dist = (long long*)dist;
+        if (qrow) {
+            // bucket-order results in scratch, then ONE coalesced inverse permutation of the three columns
+            IVJ_TRY(arena_reserve(ctx, 2 * align_up((size_t)n * 4) + align_up((size_t)n * 8) + 4096));
+            o_idx = arena_take<int32_t>(ctx, n); o_nf = arena_take<int32_t>(ctx, n); o_dist = arena_take<long long>(ctx, n);
+        }
+        if (strict) LAUNCH(ctx, "nearest_k1", (k_nearest_k1<true, PROBE_ITEMS_LAT>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, n, vec, (const int32_t*)nullptr, o_idx, o_dist, o_nf);
+        else LAUNCH(ctx, "nearest_k1", (k_nearest_k1<false, PROBE_ITEMS_LAT>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, n, vec, (const int32_t*)nullptr, o_idx, o_dist, o_nf);
+        if (qrow) {
+            // n_found of k = 1 is "a row was found": derived from the row index while it is written
+            UnpermuteCols uc{{o_idx, o_dist, nullptr}, {idx, dist, nullptr}, {4, 8, 0}, 2, nf};
+            IVJ_TRY(unpermute(ctx, n, uc));
+        }
+    } else {
+        if (strict) LAUNCH(ctx, "nearest_general", (k_nearest_general<true>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, qc, qs, qe, n, k, (int)opts->include_overlaps, qrow, idx, (long long*)dist, nf);
+        else LAUNCH(ctx, "nearest_general", (k_nearest_general<false>), grid1d(n, PROBE_THREADS), PROBE_THREADS, v, qc, qs, qe, n, k, (int)opts->include_overlaps, qrow, idx, (long long*)dist, nf);
+    }
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+// host side -> device copies of one side
+struct DevSide {
+    ivj_side s{nullptr, nullptr, nullptr, 0, nullptr};
+    int32_t* buf = nullptr;
+    ~DevSide() { if (buf) (void)hipFree(buf); }
+};
+int upload_side(ivj_ctx* ctx, const ivj_side* h, DevSide& d) {
+    d.s.n = h->n;
+    if (h->n == 0) return IVJ_OK;
+    const size_t col = align_up((size_t)h->n * 4);
+    hipError_t e = hipMalloc((void**)&d.buf, 3 * col);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(side): ") + hipGetErrorString(e));
+    int32_t* c = d.buf; int32_t* s = (int32_t*)((char*)d.buf + col); int32_t* en = (int32_t*)((char*)d.buf + 2 * col);
+    HIP_TRY(hipMemcpyAsync(c, h->contig, (size_t)h->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(s, h->start, (size_t)h->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(en, h->end, (size_t)h->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    d.s.contig = c; d.s.start = s; d.s.end = en;
+    return IVJ_OK;
+}
+
+struct IndexHolder {
+    ivj_index* ix = nullptr;
+    ~IndexHolder() { if (ix) ivj_index_free(ix); }
+};
+
+}  // namespace
