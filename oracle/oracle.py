@@ -263,8 +263,10 @@ def encode_contigs(*cols):
 #                (tests/test_bioframe.py:398-419 compares the id column with bioframe's)
 #   complement . EXPECTED_COMPLEMENT (:33-39), subtract: EXPECTED_SUBTRACT (:41-47)
 #   coverage ... bases of every df1 interval covered by the union of df2 (tests/test_bioframe.py:302-340)
+#   Weak vs Strict .. merge of adjacent intervals (2 rows 0-based, 1 row 1-based) and coverage of [100,200] by
+#                [200,300] (0 / 1 positions): tests/test_coordinate_system_metadata.py:1032-1055, 1577-1623
 # PARITY UNPINNED in the reference (no test fixes it; the choices below follow the Strict/Weak
-# definition of range_op.py:75-84): min_dist > 0, every one of these operations under Weak
+# definition of range_op.py:75-84): min_dist > 0, cluster / complement / subtract under Weak
 # (1-based closed) coordinates, rows with start > end, rows with a null chrom.
 # Rule used throughout: a Weak (closed) interval [s, e] is the half-open interval [s, e + 1).
 

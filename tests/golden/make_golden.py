@@ -12,6 +12,7 @@ Sources (all under /root/reference):
   tests/_expected.py:174-181  PD_DF_MERGE           -> expected_merge.csv
   tests/data/merge/input.csv, tests/data/coverage/{reads,targets}.csv -> inputs, copied
   tests/test_partitioned_range_operation_regressions.py:24-59,128-190 -> cases.json (sort_scan)
+  tests/test_coordinate_system_metadata.py:1032-1055,1577-1623 -> cases.json (sort_scan_boundary)
   tests/data/exons/*.parquet, tests/data/fBrain-DS14718/*.parquet -> copied
       (known answer 54,246 overlaps 0-based: docs/supplement.md:108,111,149)
   tests/test_coordinate_system_metadata.py:738-819,1172-1191,1482-1506 -> cases.json (boundary)
@@ -146,6 +147,18 @@ def write_cases():
             "cluster": {"start": [0, 8, 20], "end": [10, 25, 30], "cluster": [0, 0, 0], "cluster_start": [0, 0, 0],
                         "cluster_end": [30, 30, 30]},
         },
+        "sort_scan_boundary": [
+            # tests/test_coordinate_system_metadata.py:1032-1055 (merge: adjacent intervals) and :1577-1623
+            # (coverage: UInt32 boundary) -- the reference's own pins of the Weak / Strict rule for these operations
+            {"name": "merge_adjacent_zero_based", "op": "merge", "zero_based": True,
+             "df": iv([("chr1", 100, 150), ("chr1", 150, 200)]), "n_rows": 2},
+            {"name": "merge_adjacent_one_based", "op": "merge", "zero_based": False,
+             "df": iv([("chr1", 100, 150), ("chr1", 150, 200)]), "n_rows": 1},
+            {"name": "coverage_boundary_zero_based", "op": "coverage", "zero_based": True, "dtype": "uint32",
+             "df1": one(100, 200), "df2": one(200, 300), "coverage": [0]},
+            {"name": "coverage_boundary_one_based", "op": "coverage", "zero_based": False, "dtype": "uint32",
+             "df1": one(100, 200), "df2": one(200, 300), "coverage": [1]},
+        ],
         "known_answers": {
             # docs/supplement.md:108,111,149 -- exons (df1) x fBrain (df2), 0-based
             "exons_x_fbrain_strict_pairs": 54246,

@@ -351,3 +351,16 @@ def test_complement_and_subtract_regression_case(engine):
         d.attrs["coordinate_system_zero_based"] = False     # closed: [0,40] minus [10,20] u [20,30] -> [0,9], [31,40]
     sub = pb.subtract(df1, df2, output_type="pandas.DataFrame")
     assert sorted(zip(sub["name"], sub["start"], sub["end"])) == [("a", 0, 9), ("a", 31, 40), ("d", 5, 9)]
+
+
+@pytest.mark.parametrize("case", load_cases()["sort_scan_boundary"], ids=lambda c: c["name"])
+def test_sort_scan_boundary_cases(engine, case):
+    """tests/test_coordinate_system_metadata.py:1032-1055 (merge of adjacent intervals: 2 rows 0-based, 1 row
+    1-based) and :1577-1623 (coverage of [100,200] by [200,300]: 0 positions 0-based, 1 position 1-based; UInt32)."""
+    if case["op"] == "merge":
+        res = pb.merge(_frame(case["df"], case["zero_based"]), output_type="pandas.DataFrame")
+        assert len(res) == case["n_rows"]
+    else:
+        res = pb.coverage(_frame(case["df1"], case["zero_based"], case.get("dtype")), _frame(case["df2"], case["zero_based"], case.get("dtype")),
+                          output_type="pandas.DataFrame")
+        assert res["coverage"].tolist() == case["coverage"] and res["coverage"].dtype == np.int64

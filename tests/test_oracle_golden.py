@@ -303,3 +303,18 @@ def test_interval_tree_equals_sort_search_and_brute(strict, real_sides):
     ix = O.Index(b, n)
     assert O.overlap_tree(ix, p, strict, count_only=True) == (54246 if strict else 54343)
     assert O.overlap_tree(ix, p, strict, threads=3, count_only=True) == O.overlap_fast(ix, p, strict, count_only=True)
+
+
+@pytest.mark.parametrize("case", load_cases()["sort_scan_boundary"], ids=lambda c: c["name"])
+def test_sort_scan_boundary_cases(case):
+    """The reference's own Weak / Strict pins for merge and coverage
+    (tests/test_coordinate_system_metadata.py:1032-1055, 1577-1623)."""
+    strict = case["zero_based"]
+    if case["op"] == "merge":
+        side, _ = _one_frame(_case_side(case["df"]))
+        _, _, _, (mc, ms, me, mn) = O.np_cluster(side, strict, 0)
+        assert len(mc) == case["n_rows"]
+    else:
+        p, b, _ = _sides(_case_side(case["df1"]), _case_side(case["df2"]))
+        assert O.np_coverage_brute(p, b, strict).tolist() == case["coverage"]
+        assert O.np_coverage_fast(p, b, strict).tolist() == case["coverage"]
