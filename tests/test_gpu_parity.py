@@ -697,3 +697,36 @@ def test_repeated_joins_on_one_context_with_changing_inputs():
         assert p.shape[0] == len(ep)
         c = join.count_overlaps(dp, db, strict, nc)                                   # another op in between
         assert int(c.sum().item()) == len(ep)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_sort_scan_conservation_laws_on_real_data(eng, strict):
+    """Size-independent cross-checks between independent kernels on the reference's real fixtures (exons x fBrain):
+    for every df1 row  coverage + sum(lengths of its subtract pieces) == its length;  inside a per-contig view
+    sum(merged lengths) + sum(complement gaps) == sum(view lengths);  and all of it equals the oracle."""
+    from _util import load_parquet_intervals
+    exons = load_parquet_intervals("exons")
+    fbrain = load_parquet_intervals("fBrain-DS14718")
+    (c1, c2), nc = O.encode_contigs(exons[0], fbrain[0])
+    p = (c1, exons[1].astype(np.int32), exons[2].astype(np.int32))
+    b = (c2, fbrain[1].astype(np.int32), fbrain[2].astype(np.int32))
+    one = 0 if strict else 1
+    cov = eng.coverage(p, b, strict, nc)
+    row, s, e = eng.subtract(p, b, strict, nc)
+    left = np.bincount(row, weights=(e.astype(np.int64) - s + one), minlength=len(p[0])).astype(np.int64)
+    length = p[2].astype(np.int64) - p[1] + one
+    assert (cov + left == length).all() and cov.sum() > 0 and left.sum() > 0
+    assert (cov == O.np_coverage_fast(O.Side(*p), O.Side(*b), strict)).all()
+    # complement of df2 inside [min start, max end] of every contig that has df2 rows
+    cs = np.unique(b[0])
+    vs = np.array([b[1][b[0] == c].min() for c in cs], np.int32)
+    ve = np.array([b[2][b[0] == c].max() for c in cs], np.int32)
+    view = (cs.astype(np.int32), vs, ve)
+    mc, ms, me, mn = eng.merge(b, strict, nc, 1)          # min_dist = 1: the union components (bookended runs joined)
+    vrow, gs, ge = eng.complement(b, view, strict, nc)
+    merged = (me.astype(np.int64) - ms + one).sum()
+    gaps = (ge.astype(np.int64) - gs + one).sum()
+    assert merged + gaps == (ve.astype(np.int64) - vs + one).sum()
+    assert int(mn.sum()) == len(b[0])
+    ec, es, ee = O.np_complement(O.Side(*b), O.Side(*view), strict)
+    assert (view[0][vrow] == ec).all() and (gs == es).all() and (ge == ee).all()
