@@ -318,3 +318,21 @@ def test_sort_scan_boundary_cases(case):
         p, b, _ = _sides(_case_side(case["df1"]), _case_side(case["df2"]))
         assert O.np_coverage_brute(p, b, strict).tolist() == case["coverage"]
         assert O.np_coverage_fast(p, b, strict).tolist() == case["coverage"]
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_oracle_conservation_laws_on_real_data(strict, real_sides):
+    """coverage + remaining pieces == length for every exon; merged + gaps == view, on the real fixtures: the
+    oracle's restatements of coverage / subtract / merge / complement are mutually consistent."""
+    _, _, (p, b, n) = real_sides
+    one = 0 if strict else 1
+    cov = O.np_coverage_fast(p, b, strict)
+    row, s, e = O.np_subtract(p, b, strict)
+    left = np.bincount(row, weights=(e - s + one), minlength=p.n).astype(np.int64)
+    assert (cov + left == p.end.astype(np.int64) - p.start + one).all() and cov.sum() > 0
+    cs = np.unique(b.contig)
+    view = O.Side(cs.astype(np.int32), np.array([b.start[b.contig == c].min() for c in cs], np.int32),
+                  np.array([b.end[b.contig == c].max() for c in cs], np.int32))
+    _, _, _, (mc, ms, me, mn) = O.np_cluster(b, strict, 1)
+    gc, gs, ge = O.np_complement(b, view, strict)
+    assert (me - ms + one).sum() + (ge - gs + one).sum() == (view.end.astype(np.int64) - view.start + one).sum()
