@@ -14,6 +14,10 @@
  *       /root/reference/src/operation.rs:146-158, 253-263, 331-340
  *   RangeOptions / FilterOp
  *       /root/reference/src/option.rs:6-41, 95-100
+ * and, built on the same sorted index:
+ *   the renaming SELECT over the joined batches = row materialisation   src/operation.rs:272-301
+ *   do_merge / do_cluster / do_complement / do_subtract / coverage       src/operation.rs:352-510, 86-96
+ *       (MergeProvider, ClusterProvider, ComplementProvider, SubtractProvider, CountOverlapsProvider(coverage))
  *
  * Contract: plain pointers and sizes only.  The join keys cross the ABI as
  * three int32 columns per side: `contig` (dictionary id of the chrom string,
@@ -48,7 +52,7 @@ extern "C" {
 #define IVJ_EHIP         -2   /* HIP runtime error (message has the hipError string) */
 #define IVJ_ENOMEM       -3   /* device or host allocation failed */
 #define IVJ_ECAPACITY    -4   /* caller-provided output capacity too small */
-#define IVJ_ESTATE       -5   /* fill called without a matching count */
+#define IVJ_ESTATE       -5   /* fill called without a matching count; index lacks what the call needs */
 
 /* FilterOp of the reference (src/option.rs:95-100) */
 #define IVJ_FILTER_WEAK   0   /* 1-based closed:    a.start <= b.end && b.start <= a.end */
