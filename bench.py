@@ -13,15 +13,30 @@ torch.distributed.run, one rank per GPU): the SAME 100M x 5M job is contig-shard
 ranks (LPT), every rank joins its contigs, and the result batches are exchanged with an RCCL
 all-gatherv inside the timed region ("scaling": "strong": total work is fixed as N grows).
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under
+torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous); under an external launcher the ranks are used
+as given and `n_gpus` must equal --gpus.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      -- dominant kernel: algorithmic bytes / live HIP-event kernel time vs 8 TB/s
-  cpu_baseline  -- the oracle's sort + bound-search port timed on the host cores (N=1 only),
-                   on a bounded sample of the same workload.
+  roofline      -- dominant kernel: algorithmic bytes / live HIP-event kernel time vs 8 TB/s; `traffic` = HBM
+                   bytes per launch of that kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) that
+                   this run makes over itself (N=1; null when rocprofv3 is unavailable or --no-pmc)
+  cpu_baseline  -- the oracle's CPU port timed on the host cores (N=1 only) on a bounded sample of the same
+                   workload: 1 thread and all cores, best of 3, one pass per probe row.
+and, for overlap: `two_pass_ms_per_step` (the deterministic count -> scan -> fill pair, cold-capacity path) and
+`host_path_s` (numpy columns in pageable host memory -> pb.overlap's C entry point -> numpy pairs, PCIe inclusive).
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -49,13 +64,16 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gatherv (reported in config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the all-core CPU-baseline sample (the 1-thread sample is a tenth of it)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--no-extras", action="store_true", help="skip two_pass_ms_per_step / host_path_s")
+    ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps: timed steps only
     ap.add_argument("--kernel-table", action="store_true", help="print a per-kernel HIP-event table to stderr")
     ap.add_argument("--two-pass", action="store_true",
                     help="overlap: always use the deterministic count -> fill pair (default: the fused single pass "
                          "into the preallocated result buffers once the warmup has sized them)")
     ap.add_argument("--partition-mode", type=int, default=0,
-                    help="ivj_opts.partition_mode: 0 auto, 1 256-way, 2 none, 3 fine (8192-way + LDS-resident slices), 4 two-level (65536 buckets), 5 flat (load-balanced candidates)")
+                    help="ivj_opts.partition_mode: 0 auto, 1 256-way buckets + window scan, 2 none, 5 flat (load-balanced candidates), 6 LDS-resident index slices")
     ap.add_argument("--materialize", action="store_true",
                     help="overlap workloads: also gather the key columns of both sides for every pair in HBM "
                          "(ivj_materialize_dev, SURVEY.md 8f row 1) inside the step")
@@ -105,48 +123,150 @@ def algorithmic_bytes(op, n_p, n_b, n_out):
 
 
 def cpu_baseline(op, probe, build, nc, sample_rows):
-    """Oracle 'port' (sort + bound search, OpenMP) on the host cores, bounded sample."""
+    """The oracle's CPU port on the host cores, bounded sample: first `sample_rows` probe rows (a tenth of that
+    for the 1-thread runs) against the FULL build side.  overlap: ONE pass per probe row (orc_overlap_baseline:
+    matches appended to recycled per-thread batches, like a streaming executor), both index forms (bound search
+    over the sorted arrays; implicit augmented interval tree = the stand-in for the reference's COITrees), probe
+    rows as given and sorted per thread share (sort inside the timed call); 1 thread and all cores; best of 3.
+    `value` = best all-core rate, with the (1-thread) index build charged in proportion to the sample."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    n = min(sample_rows, len(probe[0]))
-    ps = O.Side(probe[0][:n], probe[1][:n], probe[2][:n])
+    n_total = len(probe[0])
+    n = min(sample_rows, n_total)
+    n1 = max(1, min(n, sample_rows // 10))
     bs = O.Side(*build)
-    t0 = time.time()
+    t0 = time.perf_counter()
     ix = O.Index(bs, nc)
-    t_index = time.time() - t0
-    t0 = time.time()
-    tree = None
+    t_index = time.perf_counter() - t0
+    ps_all = O.Side(probe[0][:n], probe[1][:n], probe[2][:n])
+    ps_one = O.Side(probe[0][:n1], probe[1][:n1], probe[2][:n1])
+
+    def best_of(fn, reps=3):
+        best, units = None, 0
+        for _ in range(reps):
+            t = time.perf_counter()
+            units = fn()
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        return best, units
+
+    runs = {}
     if op == "overlap":
-        p, b = O.overlap_fast(ix, ps, True, threads=cores)
-        units = len(p)
-        # second baseline: implicit augmented interval tree = the closest stand-in for the reference's COITrees index
-        t1 = time.time()
-        tp, tb = O.overlap_tree(ix, ps, True, threads=cores)
-        t_tree = time.time() - t1
-        assert len(tp) == units
-        tree = {"value": units / (t_index + t_tree), "probe_s": round(t_tree, 3),
-                "what": "implicit augmented interval tree over the sorted build side (stand-in for COITrees), same threads and sample"}
-    elif op == "count_overlaps":
-        O.count_overlaps_fast(ix, ps, True, threads=cores)
-        units = n
+        for label, side, thr in (("all_cores", ps_all, cores), ("one_thread", ps_one, 1)):
+            for tree in (False, True):
+                for srt in (False, True):
+                    dt, units = best_of(lambda: O.overlap_baseline(ix, side, True, thr, tree, srt)[0])
+                    runs[f"{label}/{'tree' if tree else 'bsearch'}/{'sorted' if srt else 'unsorted'}"] = {
+                        "probe_s": round(dt, 4), "units": units, "rate": units / dt}
+        unit = "overlap-pairs/s"
     else:
-        O.nearest_fast(ix, ps, True, 1, True, threads=cores)
-        units = n
-    t_probe = time.time() - t0 - (tree["probe_s"] if tree else 0.0)
-    unit = "overlap-pairs/s" if op == "overlap" else "probe-rows/s"
-    return {"value": units / (t_index + t_probe), "unit": unit, "cores": cores, "kind": "port",
-            "sample": f"first {n:,} probe rows x full build ({len(build[0]):,} rows), index build (1 thread) "
-                      f"{t_index:.2f}s + probe ({cores} threads) {t_probe:.2f}s, {units:,} units",
-            "index_s": round(t_index, 3), "probe_s": round(t_probe, 3), "tree": tree}
+        fn_all = (lambda s, t: (O.count_overlaps_fast(ix, s, True, threads=t), s.n)[1]) if op == "count_overlaps" else \
+                 (lambda s, t: (O.nearest_fast(ix, s, True, 1, True, threads=t), s.n)[1])
+        for label, side, thr in (("all_cores", ps_all, cores), ("one_thread", ps_one, 1)):
+            dt, units = best_of(lambda: fn_all(side, thr))
+            runs[f"{label}/bsearch/unsorted"] = {"probe_s": round(dt, 4), "units": units, "rate": units / dt}
+        unit = "probe-rows/s"
+    best_all = max((k for k in runs if k.startswith("all_cores")), key=lambda k: runs[k]["rate"])
+    best_one = max((k for k in runs if k.startswith("one_thread")), key=lambda k: runs[k]["rate"])
+    ra, r1 = runs[best_all], runs[best_one]
+    value = ra["units"] / (ra["probe_s"] + t_index * n / n_total)
+    return {"value": value, "unit": unit, "cores": cores, "kind": "port",
+            "sample": f"first {n:,} probe rows (1-thread runs: {n1:,}) x full build ({len(build[0]):,} rows); best of 3; "
+                      f"all-core best = {best_all} {ra['probe_s']:.3f}s for {ra['units']:,} units; index build (1 thread) "
+                      f"{t_index:.2f}s charged x{n / n_total:.2f}",
+            "one_thread": {"value": r1["rate"], "variant": best_one, "note": "probe only (index build excluded), 1 thread; "
+                           "compare with the reference's published 7.6e7 pairs/s @ 1 thread on other hardware/data (BASELINE.md)"},
+            "index_s": round(t_index, 3), "variants": {k: round(v["rate"], 1) for k, v in runs.items()}}
+
+
+def source_sha16():
+    """Hash of the engine sources: ties a committed profile / bench line to the code it was made from (the GPU box
+    has no .git)."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "polars-bio_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def in_profiler():
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprofiler" in pre or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
+def pmc_traffic(args, kernel_short):
+    """Two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; kernel trace only, as the guide prescribes) over
+    this same command with --pmc-inner (timed steps only).  -> (HBM bytes per launch of `kernel_short`, detail).
+    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B streaming requests at 64 B, so the read
+    side is 2 x FETCH_SIZE; WRITE_SIZE as reported; both in KiB."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, {"error": "rocprofv3 not found"}
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="ivj_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [rocprof, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "pmc", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-inner", "--workload", args.workload, "--steps", "3",
+                   "--warmup", "1", "--partition-mode", str(args.partition_mode), "--scale", str(args.scale)]
+            if args.two_pass:
+                cmd.append("--two-pass")
+            if args.materialize:
+                cmd.append("--materialize")
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"error": f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})", "stderr_tail": r.stderr[-400:]}
+            for f in files:
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        name = (row.get("Kernel_Name") or row.get("Kernel Name") or "").split("(")[0].replace("void ", "").strip()
+                        if (row.get("Counter_Name") or row.get("Counter Name")) != ctr:
+                            continue
+                        did = row.get("Dispatch_Id") or row.get("Dispatch Id") or ""
+                        e = per.setdefault(name, {}).setdefault(ctr, {})
+                        e[did] = e.get(did, 0.0) + float(row.get("Counter_Value") or row.get("Counter Value") or 0.0)
+    except Exception as e:   # profiling must never take the bench line down
+        return None, {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    table = {}
+    for name, c in per.items():
+        f = c.get("FETCH_SIZE", {}); w = c.get("WRITE_SIZE", {})
+        fk = sum(f.values()) / max(len(f), 1); wk = sum(w.values()) / max(len(w), 1)
+        table[name] = {"launches": max(len(f), len(w)), "FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1),
+                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    hit = [k for k in table if kernel_short and ("k_" + kernel_short) in k]
+    traffic = table[hit[0]]["hbm_bytes_per_launch"] if hit else None
+    step_total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in table.values()) / 4.0   # 1 warmup + 3 steps
+    return traffic, {"source": "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over this command (3 steps)",
+                     "correction": "2 x FETCH_SIZE + WRITE_SIZE (KiB)", "step_hbm_bytes": int(step_total),
+                     "kernels": {k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]}}
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script, one per GPU."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks under torch.distributed.run")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     n_gpus = world
 
     import torch
@@ -271,23 +391,21 @@ def main():
     if args.materialize and op == "overlap":
         alg_bytes += 20 * local_units      # per pair: five more int32 output columns (the key values are already counted as inputs)
     roofline = None
-    traffic = None
-    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (same command)
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_traffic*.json")), reverse=True):
-            pm = json.load(open(f))
-            if pm.get("workload") == args.workload and n_gpus == 1 and args.scale == 1.0:
-                for kname, kv in pm["kernels"].items():
-                    if dom_name and ("k_" + dom_name) in kname:
-                        traffic = kv["hbm_bytes_per_launch_corrected"]
-                break
-    except Exception:
-        traffic = None
+    traffic, traffic_detail = None, None
+    if args.pmc_inner:
+        return                                   # the run rocprofv3 wraps ends here: no extras, no line
+    if rank == 0 and n_gpus == 1 and not args.no_pmc and dom_name:
+        if in_profiler():
+            traffic_detail = {"skipped": "already running under a profiler"}
+        else:
+            t_p = time.perf_counter()
+            traffic, traffic_detail = pmc_traffic(args, dom_name)
+            log(f"[bench] PMC traffic passes: {time.perf_counter() - t_p:.1f}s -> {traffic}")
     if dom is not None and dom["launches"] > 0:
         avg_ms = dom["ms"] / dom["launches"]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
                     "kernel_avg_ms": round(avg_ms, 4), "algorithmic_bytes": int(alg_bytes),
                     "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in ktimes.items()}}
@@ -302,6 +420,36 @@ def main():
         log("[bench] per-kernel HIP-event table (3 steps):")
         for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["ms"]):
             log(f"    {k:18s} launches/step {v['launches'] / 3:6.1f}  ms/step {v['ms'] / 3:9.4f}")
+
+    # overlap: the deterministic count -> scan -> fill pair (what a cold call with unknown capacity runs) ...
+    two_pass_ms = None
+    if op == "overlap" and not args.no_extras and not args.two_pass:
+        k2 = max(1, min(args.steps, 5))
+        join.overlap(d_probe, d_build, True, nc, out=state.get("out"), fused=False, partition_mode=args.partition_mode)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            join.overlap(d_probe, d_build, True, nc, out=state.get("out"), fused=False, partition_mode=args.partition_mode)
+        barrier()
+        tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if multi:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        two_pass_ms = float(tp.item()) / k2 * 1e3
+    # ... and the PCIe-inclusive host-buffer path (numpy in pageable memory -> ivj_overlap -> numpy pairs)
+    host_path = None
+    if op == "overlap" and not args.no_extras and rank == 0 and n_gpus == 1:
+        try:
+            best = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                hp, hb = join.engine.overlap(probe, build, True, nc, partition_mode=args.partition_mode)
+                dt = time.perf_counter() - t1
+                best = dt if best is None else min(best, dt)
+            host_path = {"s": round(best, 4), "pairs_per_s": len(hp) / best, "bytes_h2d": 12 * (n_p_total + n_b_total),
+                         "bytes_d2h": 8 * len(hp), "what": "Engine.overlap: numpy columns (pageable host memory) in, numpy pairs out, best of 2"}
+            del hp, hb
+        except Exception as e:
+            host_path = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and op in ("overlap", "nearest", "count_overlaps"):
@@ -328,7 +476,7 @@ def main():
                        "parallelism": ("single GPU" if not multi else
                                        f"{mode}-sharded x{n_gpus}, " + ("RCCL all-gatherv in timed region" if gather else "no gather")),
                        "step": ("index build (radix sort) + probe bucketing + " +
-                                ("count + scan + fill" if (args.two_pass or not any(k.startswith(("overlap_fused", "overlap_flat")) for k in ktimes)) else
+                                ("count + scan + fill" if (args.two_pass or not any(k.startswith(("overlap_fused", "overlap_flat", "slice_join_fused")) for k in ktimes)) else
                                  "fused count/fill into the preallocated result buffers") +
                                 (" + key-column materialisation of every pair" if args.materialize else "") +
                                 ", inputs and outputs in HBM") if op == "overlap" else
@@ -337,6 +485,10 @@ def main():
                           if gather_ms is not None else None),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "two_pass_ms_per_step": None if two_pass_ms is None else round(two_pass_ms, 4),
+            "host_path_s": None if not host_path else host_path.get("s"),
+            "host_path": host_path,
+            "source_sha16": source_sha16(),
         }
         print(json.dumps(line), flush=True)
     if multi:

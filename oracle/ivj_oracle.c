@@ -458,3 +458,75 @@ int64_t orc_overlap_tree(const orc_index* ix, const orc_side* probe, int strict,
     free(part);
     return total;
 }
+
+/* ---- timed CPU baseline: ONE call, ONE pass per probe row ------------------------------------------------
+ * What a streaming CPU executor does (the reference's IntervalJoinExec queries its index once per probe row and
+ * appends the matches to the current output batch, docs/developers.md:641-646): every thread walks its static
+ * share of the probe rows once and appends (probe row, build row) pairs to its own output batch of BATCH pairs,
+ * which is recycled when full (the consumer of a stream has taken it).  use_tree = 0: bound search + window scan
+ * over the sorted arrays; 1: the implicit augmented interval tree.  sort_chunks != 0: every thread first sorts
+ * its share by (contig, start) -- the sort is inside the timed call -- so that consecutive queries touch
+ * neighbouring index rows.  Returns the number of pairs; *checksum = sum of the emitted build rows (compared with
+ * the two-pass result by tests/test_oracle_golden.py). */
+int64_t orc_overlap_baseline(const orc_index* ix, const orc_side* probe, int strict, int threads, int use_tree,
+                             int sort_chunks, int64_t* checksum) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    int nt = omp_get_max_threads();
+#else
+    int nt = 1;
+#endif
+    (void)threads;
+    enum { BATCH = 1 << 16 };
+    const int64_t np = probe->n;
+    int64_t total = 0, csum = 0;
+#pragma omp parallel num_threads(nt) reduction(+ : total, csum)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num();
+#else
+        int t = 0;
+#endif
+        const int64_t lo_i = np * t / nt, hi_i = np * (t + 1) / nt, m = hi_i - lo_i;
+        int32_t* op = (int32_t*)malloc(sizeof(int32_t) * BATCH);
+        int32_t* ob = (int32_t*)malloc(sizeof(int32_t) * BATCH);
+        int32_t* order = NULL;
+        if (sort_chunks && m > 0) {
+            uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)m);
+            order = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
+            for (int64_t k = 0; k < m; ++k) { keys[k] = compose(probe->contig[lo_i + k], probe->start[lo_i + k]); order[k] = (int32_t)(lo_i + k); }
+            radix_sort_u64(keys, order, m, 48);
+            free(keys);
+        }
+        int64_t w = 0;
+        for (int64_t k = 0; k < m; ++k) {
+            const int64_t i = order ? order[k] : lo_i + k;
+            int64_t a, b;
+            if (!seg_of(ix, probe->contig[i], &a, &b)) continue;
+            const int32_t qs = probe->start[i], qe = probe->end[i];
+            int64_t f = 0;
+            if (use_tree) {
+                f = tree_query(ix, a, b, qs, qe, strict, (int32_t)i, op, ob, w, BATCH);
+                if (w + f > BATCH) {        /* batch full: hand it over, redo this row into the fresh one */
+                    for (int64_t j = 0; j < w; ++j) csum += ob[j];
+                    w = 0;
+                    f = tree_query(ix, a, b, qs, qe, strict, (int32_t)i, op, ob, 0, BATCH);
+                }
+                w += f < BATCH ? f : BATCH;
+            } else {
+                const int64_t hi = bound_hi(ix, a, b, qe, strict);
+                for (int64_t p = hi - 1; p >= a && cond_b(qs, ix->pmax[p], strict); --p) {
+                    if (cond_b(qs, ix->s_end[p], strict)) {
+                        if (w == BATCH) { for (int64_t j = 0; j < w; ++j) csum += ob[j]; w = 0; }
+                        op[w] = (int32_t)i; ob[w] = ix->s_row[p]; ++w; ++f;
+                    }
+                }
+            }
+            total += f;
+        }
+        for (int64_t j = 0; j < w; ++j) csum += ob[j];
+        free(op); free(ob); free(order);
+    }
+    if (checksum) *checksum = csum;
+    return total;
+}

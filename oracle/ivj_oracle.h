@@ -91,6 +91,12 @@ int64_t orc_overlap_fast(const orc_index* ix, const orc_side* probe, int strict,
 int64_t orc_overlap_tree(const orc_index* ix, const orc_side* probe, int strict,
                          int32_t* out_probe, int32_t* out_build, int64_t cap, int threads);
 
+/* Timed CPU baseline: one call, one pass over the probe rows, matches appended to recycled per-thread batches
+ * (see the .c file).  use_tree: 0 bound search + window scan, 1 interval tree; sort_chunks: every thread sorts
+ * its share of the probe rows first (inside the timed call).  *checksum = sum of the emitted build rows. */
+int64_t orc_overlap_baseline(const orc_index* ix, const orc_side* probe, int strict, int threads, int use_tree,
+                             int sort_chunks, int64_t* checksum);
+
 void orc_nearest_fast(const orc_index* ix, const orc_side* probe, int strict,
                       int k, int include_overlaps,
                       int32_t* out_idx, int64_t* out_dist, int32_t* out_n, int threads);

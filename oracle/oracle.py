@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
         L.orc_overlap_fast.argtypes = [C.c_void_p, P, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.orc_overlap_tree.restype = C.c_int64
         L.orc_overlap_tree.argtypes = [C.c_void_p, P, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.orc_overlap_baseline.restype = C.c_int64
+        L.orc_overlap_baseline.argtypes = [C.c_void_p, P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
         L.orc_nearest_fast.restype = None
         L.orc_nearest_fast.argtypes = [C.c_void_p, P, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _LIB = L
@@ -170,6 +172,14 @@ def overlap_tree(ix: Index, probe: Side, strict: bool, threads: int = 0, count_o
     b = np.empty(n, np.int32)
     L.orc_overlap_tree(ix.h, probe.ref(), int(strict), p.ctypes.data, b.ctypes.data, n, threads)
     return p, b
+
+
+def overlap_baseline(ix: Index, probe: Side, strict: bool, threads: int, use_tree: bool = False, sort_chunks: bool = False):
+    """Timed CPU baseline (bench.py): ONE call, one pass over the probe rows, pairs appended to recycled
+    per-thread batches.  -> (number of pairs, sum of the emitted build rows)."""
+    cs = C.c_int64(0)
+    n = lib().orc_overlap_baseline(ix.h, probe.ref(), int(strict), int(threads), int(use_tree), int(sort_chunks), C.byref(cs))
+    return int(n), int(cs.value)
 
 
 def nearest_fast(ix: Index, probe: Side, strict: bool, k: int = 1, include_overlaps: bool = True,

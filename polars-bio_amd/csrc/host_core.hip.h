@@ -58,7 +58,6 @@ struct ivj_ctx {
     // bucketed (partitioned) copies of the probe columns + their row ids, when the partition path ran
     bool ov_part = false;
     int32_t *pt_c = nullptr, *pt_s = nullptr, *pt_e = nullptr, *pt_row = nullptr;
-    int32_t *pu_c = nullptr, *pu_s = nullptr, *pu_e = nullptr, *pu_row = nullptr;   // second set (two-level bucketing)
     uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
     bool part_attr_set = false;
     // timing
@@ -67,10 +66,14 @@ struct ivj_ctx {
     std::vector<TimingRec> recs;
     std::vector<hipEvent_t> pool;
     size_t pool_used = 0;
+    // indexes built on this context that are still alive: ivj_ctx_destroy detaches them (ix->ctx = nullptr), so an
+    // ivj_index_free that comes after the context is gone only releases the index's own slab
+    std::vector<ivj_index*> live;
 };
 
 struct ivj_index {
     ivj_ctx* ctx = nullptr;
+    int device = 0;
     int32_t table_mode = 0;
     int64_t n = 0;
     int32_t n_contigs = 0;
@@ -144,7 +147,8 @@ T* arena_take(ivj_ctx* ctx, size_t count) {
 bool is_probe_kernel(const char* name) {
     return !std::strncmp(name, "overlap_", 8) || !std::strncmp(name, "count_overlaps", 14) || !std::strncmp(name, "nearest", 7) ||
            !std::strncmp(name, "materialize", 11) || !std::strncmp(name, "take", 4) || !std::strncmp(name, "coverage", 8) ||
-           !std::strncmp(name, "subtract_", 9) || !std::strncmp(name, "cluster_", 8);
+           !std::strncmp(name, "subtract_", 9) || !std::strncmp(name, "cluster_", 8) || !std::strncmp(name, "part_scatter", 12) ||
+           !std::strncmp(name, "slice_", 6);
 }
 void t_begin(ivj_ctx* ctx, const char* name) {
     ctx->t_open = false;
@@ -219,7 +223,8 @@ int check_opts(const ivj_opts* o) {
     if (o->filter_op != IVJ_FILTER_WEAK && o->filter_op != IVJ_FILTER_STRICT) return fail(IVJ_EINVAL, "filter_op must be 0 (Weak) or 1 (Strict)");
     if (o->n_contigs < 0) return fail(IVJ_EINVAL, "n_contigs < 0");
     if (o->table_mode < 0 || o->table_mode > 2) return fail(IVJ_EINVAL, "table_mode must be 0 (auto), 1 (records) or 2 (bins)");
-    if (o->partition_mode < 0 || o->partition_mode > 5) return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (256-way), 2 (never), 3 (fine, fused path only), 4 (two-level) or 5 (flat, fused path only)");
+    if (o->partition_mode < 0 || o->partition_mode > 6 || o->partition_mode == 3 || o->partition_mode == 4)
+        return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (256-way buckets), 2 (never), 5 (flat, fused path only) or 6 (LDS-resident index slices)");
     return IVJ_OK;
 }
 int check_side(const ivj_side* s, const char* what) {

@@ -106,7 +106,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
     if (2 * build->n + 2 * (int64_t)opts->n_contigs + 64 > 0x7fffffffll)
         return fail(IVJ_EINVAL, "build side too large for the int32 direct-address table (2*rows + 2*contigs must be < 2^31)");
     ivj_index* ix = new ivj_index();
-    ix->ctx = ctx; ix->n = build->n; ix->n_contigs = opts->n_contigs; ix->table_mode = opts->table_mode;
+    ix->ctx = ctx; ix->device = ctx->device; ix->n = build->n; ix->n_contigs = opts->n_contigs; ix->table_mode = opts->table_mode;
     const int64_t n = build->n;
     const size_t nn = (size_t)(n > 0 ? n : 1);
     auto cleanup = [&](int code) { ivj_index_free(ix); return code; };
@@ -201,6 +201,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("index build launch: ") + hipGetErrorString(e)));
+    ctx->live.push_back(ix);
     *out = ix;
     return IVJ_OK;
 }

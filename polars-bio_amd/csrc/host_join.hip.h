@@ -4,7 +4,7 @@
 
 namespace {
 
-int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one permuted column set, 2: two
+int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one permuted column set
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     const size_t col = align_up((size_t)n * 4);
     const size_t need = (size_t)(2 + 4 * with_part) * col + align_up((size_t)(tiles + 2) * 8) +
@@ -27,12 +27,6 @@ int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one 
         ctx->pt_e = (int32_t*)p; p += col;
         ctx->pt_row = (int32_t*)p; p += col;
     }
-    if (with_part > 1) {
-        ctx->pu_c = (int32_t*)p; p += col;
-        ctx->pu_s = (int32_t*)p; p += col;
-        ctx->pu_e = (int32_t*)p; p += col;
-        ctx->pu_row = (int32_t*)p; p += col;
-    }
     ctx->pt_bstart = (uint32_t*)p; p += align_up((PART_BUCKETS + 1) * 4);
     ctx->ov_tile = (long long*)p;
     return IVJ_OK;
@@ -41,14 +35,14 @@ int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one 
 // Probe bucketing pays once the index no longer fits the L2s and there are enough probes to
 // amortise the two extra passes.  opts->partition_mode: 0 auto, 1 always, 2 never.
 bool want_partition(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts) {
-    if (opts->partition_mode == 1 || opts->partition_mode >= 3) return true;
+    if (opts->partition_mode == 1 || opts->partition_mode >= 5) return true;
     if (opts->partition_mode == 2) return false;
     return n_probe >= (4ll << 20) && ix->n >= (256ll << 10);
 }
 
 // one stable 256-way pass: src columns -> dst columns
 int partition_pass(ivj_ctx* ctx, ivj_index* ix, bool strict, const int32_t* sc, const int32_t* ss, const int32_t* se,
-                   const int32_t* srow, int64_t n, int packed, int32_t* dc, int32_t* ds, int32_t* de, int32_t* drow) {
+                   const int32_t* srow, int64_t n, int bshift, int32_t* dc, int32_t* ds, int32_t* de, int32_t* drow) {
     const int ntiles = (int)((n + PART_TILE - 1) / PART_TILE);
     const int grid = 8 * ((ntiles + 7) / 8);
     const size_t hist = (size_t)PART_BUCKETS * (size_t)ntiles;
@@ -62,45 +56,30 @@ int partition_pass(ivj_ctx* ctx, ivj_index* ix, bool strict, const int32_t* sc, 
     }
     IndexView v = view_of(ix);
     const bool hvec = aligned16(sc) && aligned16(se);
-    if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, sc, se, n, packed, blk, ntiles, hvec);
-    else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, sc, se, n, packed, blk, ntiles, hvec);
+    if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, sc, se, n, bshift, blk, ntiles, hvec);
+    else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, sc, se, n, bshift, blk, ntiles, hvec);
     device_scan<uint32_t, SumOp, false>(ctx, "part_scan", blk, blk, (int64_t)hist, 0u, partials, (uint32_t*)nullptr);
     // bucket b starts at blk[b * ntiles] (bucket-major scan); kept for the inverse permutation (k_unpermute)
     HIP_TRY(hipMemcpy2DAsync(ctx->pt_bstart, 4, blk, (size_t)ntiles * 4, 4, PART_BUCKETS, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->pt_bstart + PART_BUCKETS), (int)n, 1, ctx->stream));
     t_begin(ctx, "part_scatter");
     if (strict)
-        hipLaunchKernelGGL((k_part_scatter<true>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, sc, ss, se, srow, n, packed,
+        hipLaunchKernelGGL((k_part_scatter<true>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, sc, ss, se, srow, n, bshift,
                            (const uint32_t*)blk, ntiles, dc, ds, de, drow);
     else
-        hipLaunchKernelGGL((k_part_scatter<false>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, sc, ss, se, srow, n, packed,
+        hipLaunchKernelGGL((k_part_scatter<false>), dim3(grid), dim3(PART_THREADS), PART_LDS_BYTES, ctx->stream, v, sc, ss, se, srow, n, bshift,
                            (const uint32_t*)blk, ntiles, dc, ds, de, drow);
     t_end(ctx);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
 }
 
-// partition_mode 4 (or auto for very large probe sides): two stable passes -> 65536 buckets of ~76
-// build rows: the 64 probes of a wavefront then look at the same few cache lines.
-bool want_two_level(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts) {
-    (void)ix; (void)n_probe;
-    return opts->partition_mode == 4;
-}
-
 int partition_probes(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts) {
     const int64_t n = probe->n;
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
-    if (want_two_level(ix, n, opts)) {
-        int bs = 0;
-        while ((ix->bins_len >> bs) > 65533ll) ++bs;
-        IVJ_TRY(partition_pass(ctx, ix, strict, probe->contig, probe->start, probe->end, probe->row_id, n, part_pack(bs, 0, true),
-                               ctx->pu_c, ctx->pu_s, ctx->pu_e, ctx->pu_row));
-        return partition_pass(ctx, ix, strict, ctx->pu_c, ctx->pu_s, ctx->pu_e, ctx->pu_row, n, part_pack(bs, 8, true),
-                              ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
-    }
     int bshift = 0;
     while ((ix->bins_len >> bshift) > (int64_t)(PART_BUCKETS - 3)) ++bshift;
-    return partition_pass(ctx, ix, strict, probe->contig, probe->start, probe->end, probe->row_id, n, part_pack(bshift, 0, false),
+    return partition_pass(ctx, ix, strict, probe->contig, probe->start, probe->end, probe->row_id, n, bshift,
                           ctx->pt_c, ctx->pt_s, ctx->pt_e, ctx->pt_row);
 }
 
@@ -114,7 +93,7 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         return IVJ_OK;
     }
     const bool part = want_partition(ix, n, opts);
-    IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
+    IVJ_TRY(ensure_ov(ctx, n, part ? 1 : 0));
     ctx->ov_part = part;
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     long long* tile = ctx->ov_tile;                       // tiles + 1
@@ -173,61 +152,6 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     return IVJ_OK;
 }
 
-// "fine" single pass: 8192-way bucketing (atomics) + join kernel with LDS-resident index slices.
-// Available when a bucket spans at most FINE_SLOTS table slots.
-bool fine_available(const ivj_index* ix) { return (ix->bins_len >> FINE_SLOT_BITS) <= (int64_t)(FINE_BUCKETS - 2); }
-
-int overlap_fused_fine(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
-                       int64_t capacity, int64_t* n_pairs) {
-    const int64_t n = probe->n;
-    ctx->ov_n = -1;
-    *n_pairs = 0;
-    if (n == 0 || ix->n == 0) return IVJ_OK;
-    IVJ_TRY(ensure_ov(ctx, n, 1));
-    int bshift = 0;
-    while ((ix->bins_len >> bshift) > (int64_t)(FINE_BUCKETS - 2)) ++bshift;
-    const int64_t jgrid = (n + FINE_TILE - 1) / FINE_TILE + FINE_BUCKETS;      // upper bound on the number of tiles
-    IVJ_TRY(arena_reserve(ctx, 4 * align_up((size_t)(FINE_BUCKETS + 1) * 4) + align_up((size_t)FINE_BUCKETS * 8) +
-                               align_up((size_t)jgrid * 4) + 4096));
-    uint32_t* gcount = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
-    uint32_t* gstart = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
-    uint32_t* cursor = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
-    uint32_t* tprefix = arena_take<uint32_t>(ctx, FINE_BUCKETS + 1);
-    int2* brange = arena_take<int2>(ctx, FINE_BUCKETS);
-    uint32_t* tbucket = arena_take<uint32_t>(ctx, jgrid);
-    int4* prec = reinterpret_cast<int4*>(ctx->pt_c);          // the four permuted columns' space holds the 16-byte records
-    unsigned long long* state = (unsigned long long*)ctx->ov_tile;
-    HIP_TRY(hipMemsetAsync(gcount, 0, (size_t)(FINE_BUCKETS + 1) * 4, ctx->stream));
-    HIP_TRY(hipMemsetAsync(state, 0, 16, ctx->stream));
-    IndexView v = view_of(ix);
-    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
-    const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end);
-    const int hgrid = 1024;
-    if (strict) LAUNCH(ctx, "fine_hist", (k_fine_hist<true>), hgrid, 1024, v, probe->contig, probe->end, n, bshift, vec, gcount);
-    else LAUNCH(ctx, "fine_hist", (k_fine_hist<false>), hgrid, 1024, v, probe->contig, probe->end, n, bshift, vec, gcount);
-    LAUNCH(ctx, "fine_offsets", k_fine_offsets, 1, 1024, (const uint32_t*)gcount, gstart, cursor, tprefix);
-    LAUNCH(ctx, "fine_tilemap", k_fine_tilemap, grid1d(FINE_BUCKETS, 256), 256, (const uint32_t*)ix->bins, (long long)ix->bins_len, bshift,
-           (const uint32_t*)tprefix, brange, tbucket);
-    const int64_t sgrid = (n + 8192 - 1) / 8192;
-    if (strict) LAUNCH(ctx, "fine_scatter", (k_fine_scatter<true>), sgrid, 1024, v, probe->contig, probe->start, probe->end, probe->row_id, n, bshift, vec,
-                       cursor, prec);
-    else LAUNCH(ctx, "fine_scatter", (k_fine_scatter<false>), sgrid, 1024, v, probe->contig, probe->start, probe->end, probe->row_id, n, bshift, vec,
-                cursor, prec);
-    if (strict) LAUNCH(ctx, "overlap_fused_fine", (k_overlap_fused_fine<true>), jgrid, FINE_THREADS, v, (const int4*)prec, (const uint32_t*)gstart,
-                       (const uint32_t*)tprefix, (const uint32_t*)tbucket, (const int2*)brange, bshift, (long long)ix->bins_len, (long long)capacity,
-                       state, out_p, out_b);
-    else LAUNCH(ctx, "overlap_fused_fine", (k_overlap_fused_fine<false>), jgrid, FINE_THREADS, v, (const int4*)prec, (const uint32_t*)gstart,
-                (const uint32_t*)tprefix, (const uint32_t*)tbucket, (const int2*)brange, bshift, (long long)ix->bins_len, (long long)capacity,
-                state, out_p, out_b);
-    HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipGetLastError());
-    *n_pairs = ctx->h_total[0];
-    if (ctx->h_total[1] != 0)
-        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");
-    return IVJ_OK;
-}
-
 // single pass: (bucketing +) fused count/fill into a caller buffer of known capacity
 int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
                   int64_t capacity, int64_t* n_pairs) {
@@ -236,9 +160,8 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     ctx->ov_n = -1;                                   // invalidates a pending count -> fill hand-over
     *n_pairs = 0;
     if (n == 0 || ix->n == 0) return IVJ_OK;
-    if (opts->partition_mode == 3 && fine_available(ix)) return overlap_fused_fine(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
     const bool part = want_partition(ix, n, opts);
-    IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
+    IVJ_TRY(ensure_ov(ctx, n, part ? 1 : 0));
     // dense results (the caller expects >= 16 pairs per probe; at ~8 the two kernels tie and the flat one still has
     // to fill its arrays and the end order): the flat kernel spreads every window over the whole
     // workgroup (1.8x the count + dense-fill pair on 37 pairs per probe); sparse ones keep the window-scan kernel
@@ -297,7 +220,7 @@ int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
     if (n == 0 || ix->n == 0) return IVJ_OK;
     IVJ_TRY(build_rec4(ctx, ix));
     const bool part = want_partition(ix, n, opts);
-    IVJ_TRY(ensure_ov(ctx, n, part ? (want_two_level(ix, n, opts) ? 2 : 1) : 0));
+    IVJ_TRY(ensure_ov(ctx, n, part ? 1 : 0));
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     unsigned long long* state = (unsigned long long*)ctx->ov_tile;
     const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *ids = probe->row_id;

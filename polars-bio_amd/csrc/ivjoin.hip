@@ -18,7 +18,6 @@
 #include <vector>
 
 #include "probe.hip.h"
-#include "fine.hip.h"
 #include "radix_sort.hip.h"
 #include "scan.hip.h"
 
@@ -66,6 +65,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (ivj_index* ix : ctx->live) ix->ctx = nullptr;          // detached: they keep (and later free) their slabs
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->ov_buf) (void)hipFree(ctx->ov_buf);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
@@ -133,7 +133,11 @@ int ivj_index_build_dev(ivj_ctx* ctx, const ivj_side* build_dev, const ivj_opts*
 void ivj_index_free(ivj_index* ix) {
     if (!ix) return;
     ivj_ctx* ctx = ix->ctx;
-    if (ctx && ctx->ov_ix == ix) { ctx->ov_ix = nullptr; ctx->ov_n = -1; }
+    if (ctx) {
+        if (ctx->ov_ix == ix) { ctx->ov_ix = nullptr; ctx->ov_n = -1; }
+        for (size_t k = 0; k < ctx->live.size(); ++k)
+            if (ctx->live[k] == ix) { ctx->live[k] = ctx->live.back(); ctx->live.pop_back(); break; }
+    }
     if (ix->slab) {
         if (ctx && ix->slab_cap > ctx->ix_cache_cap) {
             // keep the larger slab for the next index on this context (same stream => ordered reuse)
@@ -141,7 +145,7 @@ void ivj_index_free(ivj_index* ix) {
             ctx->ix_cache = ix->slab; ctx->ix_cache_cap = ix->slab_cap;
             if (old) { DeviceGuard g(ctx->device); (void)hipFree(old); }
         } else {
-            DeviceGuard g(ctx ? ctx->device : 0);
+            DeviceGuard g(ix->device);
             (void)hipFree(ix->slab);
         }
     }
@@ -181,7 +185,7 @@ int ivj_overlap_fused_rows_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* prob
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
     if (rows_dev->n_pairs < 0) return fail(IVJ_EINVAL, "capacity (rows->n_pairs) < 0");
-    if (opts->partition_mode == 3 || opts->partition_mode == 5) return fail(IVJ_EINVAL, "partition_mode 3 / 5 are not available for the rows path");
+    if (opts->partition_mode == 5) return fail(IVJ_EINVAL, "partition_mode 5 is not available for the rows path");
     DeviceGuard g(ctx->device);
     return overlap_fused_rows(ctx, ix, probe_dev, opts, rows_dev, n_pairs);
 }
@@ -231,9 +235,10 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     out->probe_idx = (int32_t*)std::malloc((size_t)total * 4);
     out->build_idx = (int32_t*)std::malloc((size_t)total * 4);
     if (!out->probe_idx || !out->build_idx) { ivj_pairs_free(out); return fail(IVJ_ENOMEM, "host malloc(pairs)"); }
-    HIP_TRY(hipMemcpyAsync(out->probe_idx, op.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(out->build_idx, ob.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipError_t ce = hipMemcpyAsync(out->probe_idx, op.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (ce == hipSuccess) ce = hipMemcpyAsync(out->build_idx, ob.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+    if (ce != hipSuccess) { ivj_pairs_free(out); return fail(IVJ_EHIP, std::string("D2H(pairs): ") + hipGetErrorString(ce)); }
     out->n_pairs = total;
     return IVJ_OK;
 }

@@ -20,19 +20,10 @@ constexpr int PART_BUCKETS = 256;   // bucket 255 = probes without any candidate
 constexpr size_t PART_LDS_BYTES = (size_t)PART_TILE * 4 /* one column at a time */ + (size_t)PART_TILE /* bucket ids */ +
                                   (size_t)PART_WAVES * PART_BUCKETS * 4 + 3 * PART_BUCKETS * 4 + 16;
 
-// `bshift` packs the digit of this pass: bits 0-5 = table-slot shift, bits 8-11 = digit shift,
-// bit 16 = two-level (65536 buckets, two stable 256-way passes: low digit first, then high digit;
-// the result is ordered by the 16-bit bucket id).  Single level: 254 buckets.  Digit 255 of every
-// pass = probes without any candidate row (they end up at the very end).
-__host__ __device__ __forceinline__ int part_pack(int slot_shift, int digit_shift, bool two_level) {
-    return slot_shift | (digit_shift << 8) | ((two_level ? 1 : 0) << 16);
-}
-__device__ __forceinline__ uint32_t part_digit(uint32_t slot, int packed) {
-    const uint32_t id = slot >> (packed & 63);
-    if ((packed >> 16) & 1) {
-        const uint32_t cl = id < 65533u ? id : 65533u;
-        return (cl >> ((packed >> 8) & 15)) & 255u;
-    }
+// `bshift` = table-slot shift of the bucket id: 254 buckets over the table slots; bucket 255 = probes without
+// any candidate row (they end up at the very end).
+__device__ __forceinline__ uint32_t part_digit(uint32_t slot, int bshift) {
+    const uint32_t id = slot >> bshift;
     return id < (uint32_t)(PART_BUCKETS - 2) ? id : (uint32_t)(PART_BUCKETS - 2);
 }
 

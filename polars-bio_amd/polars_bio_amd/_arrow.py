@@ -172,8 +172,12 @@ def from_arrow(t: pa.Table, output_type: str, zero_based: bool):
         return set_coordinate_system(t.to_pandas(), zero_based)
     if output_type in ("polars.DataFrame", "polars.LazyFrame"):
         if pl is None:
-            raise ImportError("polars is not installed in this environment; use output_type='pandas.DataFrame' "
-                              "or 'pyarrow.Table'")
+            # the reference's default output kind needs polars; without it the Arrow table itself is handed back
+            # (same columns, same metadata) instead of failing the default call
+            import warnings
+            warnings.warn(f"polars is not installed: output_type='{output_type}' falls back to 'pyarrow.Table' "
+                          "(pass output_type='pandas.DataFrame' or 'pyarrow.Table' to silence this)", RuntimeWarning, stacklevel=3)
+            return set_coordinate_system(t, zero_based)
         df = pl.from_arrow(t)
         if output_type == "polars.LazyFrame":
             df = df.lazy()

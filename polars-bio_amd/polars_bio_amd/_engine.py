@@ -205,6 +205,29 @@ def make_opts(strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool =
     return o
 
 
+class _LockedLib:
+    """The native library as one Engine sees it: every call is made under that engine's lock.
+
+    An ivj_ctx is not thread-safe (include/ivjoin.h: arena, count -> fill state, pinned totals and the index
+    cache are per context) and ctypes releases the GIL during a call, so two Python threads sharing an Engine
+    would otherwise race inside the library.  Multi-call sequences (count -> fill, streaming tiles) take
+    ``Engine.lock`` around the whole sequence as well (it is re-entrant)."""
+
+    def __init__(self, lib: C.CDLL, lock):
+        self._lib, self._lock = lib, lock
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        lock = self._lock
+
+        def call(*args):
+            with lock:
+                return fn(*args)
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
+
+
 class DeviceIndex:
     """Sorted build side resident in HBM (ivj_index)."""
 
@@ -227,16 +250,20 @@ class Engine:
     """One HIP device + stream + scratch arena (ivj_ctx)."""
 
     def __init__(self, device: int = 0):
-        self.L = load_library()
+        self.lock = threading.RLock()
+        self.L = _LockedLib(load_library(), self.lock)
         h = C.c_void_p()
         _check(self.L, self.L.ivj_ctx_create(int(device), C.byref(h)), "ivj_ctx_create")
         self.h = h
         self.device = device
 
     def close(self):
-        if getattr(self, "h", None):
-            self.L.ivj_ctx_destroy(self.h)
-            self.h = None
+        """Destroys the context.  Indexes built on it stay valid handles (the library detaches them) and are
+        released by their own close()."""
+        with self.lock:
+            if getattr(self, "h", None):
+                self.L.ivj_ctx_destroy(self.h)
+                self.h = None
 
     def __del__(self):
         try:
@@ -580,9 +607,23 @@ _default_lock = threading.Lock()
 
 
 def default_engine() -> Engine:
-    """Process-wide engine on device LOCAL_RANK (or 0)."""
+    """Process-wide engine (its native calls are serialised by Engine.lock; use one Engine per thread for
+    concurrent joins).  Device: the ``ivj.device`` option when it was set explicitly, else LOCAL_RANK (one
+    process per GPU under torch.distributed.run), else 0."""
     global _default_engine
     with _default_lock:
         if _default_engine is None:
-            _default_engine = Engine(int(os.environ.get("LOCAL_RANK", "0")))
+            from .context import get_option
+            opt = get_option("ivj.device")
+            dev = int(opt) if opt not in (None, "", "auto") else int(os.environ.get("LOCAL_RANK", "0"))
+            _default_engine = Engine(dev)
         return _default_engine
+
+
+def reset_default_engine():
+    """Drop the process-wide engine (the next call creates a new one, e.g. after ``ivj.device`` changed)."""
+    global _default_engine
+    with _default_lock:
+        if _default_engine is not None:
+            _default_engine.close()
+        _default_engine = None

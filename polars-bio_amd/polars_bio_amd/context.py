@@ -20,7 +20,7 @@ class Context:
             POLARS_BIO_COORDINATE_SYSTEM_CHECK: "false",
             "bio.interval_join_algorithm": "hip",
             # engine options of this implementation
-            "ivj.device": "0",
+            "ivj.device": "auto",   # "auto": LOCAL_RANK (one process per GPU) or 0; a number pins the device
             "ivj.low_memory_batch_rows": "8000000",
             # "host": result rows are gathered with Arrow take on the host from the index pairs;
             # "device": the key columns of both sides are materialised in HBM (ivj_overlap_rows)

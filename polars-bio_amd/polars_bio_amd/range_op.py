@@ -320,14 +320,24 @@ def cluster(
     cols = list(DEFAULT_INTERVAL_COLUMNS if cols is None else cols)
     t = A.to_arrow(df)
     side, n_contigs, _ = A.encode_frame(t, cols)
-    cid, cs, ce, _ = default_engine().cluster(side, strict=zero_based, n_contigs=n_contigs, min_dist=int(min_dist))
+    keep = side[0] >= 0                                   # rows with a null chrom belong to no contig: null cluster columns
+    null_mask = None
+    if keep.all():
+        cid, cs, ce, _ = default_engine().cluster(side, strict=zero_based, n_contigs=n_contigs, min_dist=int(min_dist))
+    else:
+        kc, ks, ke, _ = default_engine().cluster(tuple(a[keep] for a in side), strict=zero_based, n_contigs=n_contigs,
+                                                 min_dist=int(min_dist))
+        n_all = len(keep)
+        cid, cs, ce = np.zeros(n_all, np.int64), np.zeros(n_all, np.int32), np.zeros(n_all, np.int32)
+        cid[keep], cs[keep], ce[keep] = kc, ks, ke
+        null_mask = ~keep
     res = t
     if t.num_columns == 3:                                # the classic triplet comes back with Int64 coordinates
         res = pa.table({cols[0]: t.column(cols[0]), cols[1]: pc.cast(t.column(cols[1]), pa.int64()),
                         cols[2]: pc.cast(t.column(cols[2]), pa.int64())})
-    res = res.append_column("cluster", pa.array(cid, type=pa.int64()))
-    res = res.append_column("cluster_start", pa.array(cs.astype(np.int64)))
-    res = res.append_column("cluster_end", pa.array(ce.astype(np.int64)))
+    res = res.append_column("cluster", pa.array(cid, type=pa.int64(), mask=null_mask))
+    res = res.append_column("cluster_start", pa.array(cs.astype(np.int64), mask=null_mask))
+    res = res.append_column("cluster_end", pa.array(ce.astype(np.int64), mask=null_mask))
     return A.from_arrow(res, output_type, zero_based)
 
 
@@ -364,6 +374,9 @@ def complement(
     else:
         tv = A.to_arrow(view_df)
     frame, view, n_contigs, dictionary = A.encode_keys(t, cols, tv, view_cols, with_dictionary=True)
+    vkeep = view[0] >= 0                                  # view rows with a null chrom name no contig: dropped (as merge does)
+    if not vkeep.all():
+        view = tuple(a[vkeep] for a in view)
     row, s, e = default_engine().complement(frame, view, strict=zero_based, n_contigs=n_contigs)
     e64 = e.astype(np.int64)
     if open_ended:

@@ -26,6 +26,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Fast parity tests first, the full-size configs after them, the multi-GPU tests last (a -x run then reports
+    the cheap failures before it spends minutes on 100M-row inputs)."""
+    def weight(item):
+        name = item.nodeid
+        if "two_rank_hip" in name or "self_spawn" in name:
+            return 2
+        if "full_size" in name:
+            return 1
+        return 0
+    items.sort(key=weight)          # stable: the order inside a class of tests is kept
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -353,6 +353,22 @@ def test_complement_and_subtract_regression_case(engine):
     assert sorted(zip(sub["name"], sub["start"], sub["end"])) == [("a", 0, 9), ("a", 31, 40), ("d", 5, 9)]
 
 
+def test_null_chrom_rows_in_cluster_and_complement(engine):
+    """Rows whose chrom is null belong to no contig (unpinned in the reference): cluster gives them null cluster
+    columns and numbers the other rows as if they were absent; complement ignores view rows without a chrom."""
+    df = pd.DataFrame({"chrom": ["chr1", None, "chr1", "chr2", None], "start": np.array([5, 1, 8, 3, 100], np.int32),
+                       "end": np.array([9, 4, 20, 7, 200], np.int32)})
+    df.attrs["coordinate_system_zero_based"] = True
+    cl = pb.cluster(df, output_type="pandas.DataFrame")
+    assert cl["cluster"].isna().tolist() == [False, True, False, False, True]
+    assert cl["cluster"].dropna().astype(int).tolist() == [0, 0, 1]
+    assert cl["cluster_start"].dropna().astype(int).tolist() == [5, 5, 3] and cl["cluster_end"].dropna().astype(int).tolist() == [20, 20, 7]
+    view = pd.DataFrame({"chrom": ["chr1", None, "chr2"], "start": np.array([0, 0, 0], np.int32), "end": np.array([30, 50, 10], np.int32)})
+    view.attrs["coordinate_system_zero_based"] = True
+    comp = pb.complement(df, view_df=view, output_type="pandas.DataFrame")
+    assert sorted(zip(comp["chrom"], comp["start"], comp["end"])) == [("chr1", 0, 5), ("chr1", 20, 30), ("chr2", 0, 3), ("chr2", 7, 10)]
+
+
 @pytest.mark.parametrize("case", load_cases()["sort_scan_boundary"], ids=lambda c: c["name"])
 def test_sort_scan_boundary_cases(engine, case):
     """tests/test_coordinate_system_metadata.py:1032-1055 (merge of adjacent intervals: 2 rows 0-based, 1 row

@@ -1,0 +1,217 @@
+"""BASELINE.json configs 3, 4 and 5 at their STATED sizes on the GPU (config 2: tests/test_gpu_parity.py).
+
+The small-size parity tests cannot reach the code these sizes hit (bucketing thresholds, 16-byte record tables,
+row counts and table offsets near 2^28..2^30, 64-bit pair offsets), so every config is run once at full size through
+the C ABI and compared with the CPU oracle (256 host threads on the GPU box):
+
+  config 3  pb.overlap        100M x 5M, 24 contigs   exact pair list (two-pass path) + size-independent properties
+                                                      of every other code path (fused, 256-bucket window scan)
+  config 4  pb.nearest        50M x 2M, 24 contigs    exact (row, distance, n_found) for every probe row
+  config 5  pb.count_overlaps 200M x 200k, 24 contigs exact counts for every probe row
+
+Also: two ranks of the HIP engine + RCCL all-gatherv / gather_per_probe == the single-GPU result (needs 2 GPUs).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from polars_bio_amd import _engine, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return _engine.Engine(0)
+
+
+class _Dev:
+    """Columns of both sides resident in HBM for the duration of a test."""
+
+    def __init__(self, eng, probe, build):
+        self.eng, self.ptrs, self.sides = eng, [], []
+        for side in (probe, build):
+            n = len(side[0])
+            ps = []
+            for col in side:
+                p = eng.dev_alloc(max(4 * n, 16))
+                eng.h2d(p, np.ascontiguousarray(col, np.int32))
+                ps.append(p)
+            self.ptrs += ps
+            self.sides.append(eng.dev_side(ps[0], ps[1], ps[2], n))
+        self.probe, self.build = self.sides
+
+    def alloc(self, nbytes):
+        p = self.eng.dev_alloc(max(int(nbytes), 16))
+        self.ptrs.append(p)
+        return p
+
+    def close(self):
+        for p in self.ptrs:
+            self.eng.dev_free(p)
+        self.ptrs = []
+
+
+def _check_pair_properties(hp, hb, probe, build, counts, checksum, what):
+    """Size-independent properties that pin the pair SET and the emission order without a sort:
+    P = sum of the oracle's counts; per-probe multiplicities = counts; every pair satisfies the predicate; the
+    pairs of one probe row are contiguous and strictly ascending in (build.start, build row) -- so no pair is
+    emitted twice, hence every probe row got exactly its matches; checksum of the build rows = the oracle's."""
+    assert len(hp) == int(counts.sum()), what
+    assert (np.bincount(hp, minlength=len(probe[0])) == counts).all(), what
+    assert (probe[1][hp] < build[2][hb]).all() and (build[1][hb] < probe[2][hp]).all(), what
+    same = hp[1:] == hp[:-1]
+    assert int((~same).sum()) + 1 == int((counts > 0).sum()), (what, "pairs of one probe row are not contiguous")
+    s0, s1 = build[1][hb[:-1]], build[1][hb[1:]]
+    asc = (s0 < s1) | ((s0 == s1) & (hb[:-1] < hb[1:]))
+    assert (asc | ~same).all(), (what, "order inside a probe row")
+    assert int(hb.astype(np.int64).sum()) == checksum, what
+
+
+def test_full_size_config3_overlap_100M_x_5M(eng):
+    probe, build, nc = synth.workload("overlap_100M_5M_24contig")
+    n = len(probe[0])
+    ps, bs = O.Side(*probe), O.Side(*build)
+    ix = O.Index(bs, nc)
+    cores = os.cpu_count() or 1
+    counts = O.count_overlaps_fast(ix, ps, True, threads=cores)
+    total, checksum = O.overlap_baseline(ix, ps, True, cores)
+    assert total == int(counts.sum())
+    assert abs(total / synth.expected_pairs(n, len(build[0]), nc) - 1) < 0.02
+    d = _Dev(eng, probe, build)
+    try:
+        op, ob = d.alloc(4 * total), d.alloc(4 * total)
+        hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
+        # 1. the deterministic two-pass path (auto mode): EXACT pair list after a stable sort by probe row
+        opts = _engine.make_opts(True, nc)
+        ixd = eng.index_build_dev(d.build, opts)
+        assert eng.overlap_count_dev(ixd, d.probe, opts) == total
+        eng.overlap_fill_dev(ixd, d.probe, opts, op, ob, total)
+        eng.d2h(hp, op)
+        eng.d2h(hb, ob)
+        _check_pair_properties(hp, hb, probe, build, counts, checksum, "two-pass auto")
+        ep, eb = O.overlap_fast(ix, ps, True, threads=cores)
+        o = np.argsort(hp, kind="stable")
+        assert (hp[o] == ep).all() and (hb[o] == eb).all()
+        del ep, eb, o
+        # count_overlaps on the same index, 100M probes
+        cp = d.alloc(8 * n)
+        eng.count_overlaps_dev(ixd, d.probe, opts, cp)
+        got = np.empty(n, np.int64)
+        eng.d2h(got, cp)
+        assert (got == counts).all()
+        del got
+        # 2. the fused single pass (what bench.py times), auto mode and the 256-bucket window-scan path
+        for pm in (0, 1):
+            o2 = _engine.make_opts(True, nc, partition_mode=pm)
+            small, fits = eng.overlap_fused_dev(ixd, d.probe, o2, op, ob, total // 2)
+            assert not fits and small == total, pm
+            got_n, fits = eng.overlap_fused_dev(ixd, d.probe, o2, op, ob, total)
+            assert fits and got_n == total, pm
+            eng.d2h(hp, op)
+            eng.d2h(hb, ob)
+            _check_pair_properties(hp, hb, probe, build, counts, checksum, f"fused mode {pm}")
+        ixd.close()
+    finally:
+        d.close()
+
+
+def test_full_size_config4_nearest_50M_x_2M(eng):
+    probe, build, nc = synth.workload("nearest_50M_2M_24contig")
+    n = len(probe[0])
+    ix = O.Index(O.Side(*build), nc)
+    ei, ed, en = O.nearest_fast(ix, O.Side(*probe), True, 1, True, threads=os.cpu_count() or 1)
+    d = _Dev(eng, probe, build)
+    try:
+        opts = _engine.make_opts(True, nc)
+        ixd = eng.index_build_dev(d.build, opts)
+        pi, pd, pn = d.alloc(4 * n), d.alloc(8 * n), d.alloc(4 * n)
+        eng.nearest_dev(ixd, d.probe, opts, pi, pd, pn)
+        gi, gd, gn = np.empty((n, 1), np.int32), np.empty((n, 1), np.int64), np.empty(n, np.int32)
+        eng.d2h(gi, pi)
+        eng.d2h(gd, pd)
+        eng.d2h(gn, pn)
+        ixd.close()
+    finally:
+        d.close()
+    assert (gn == en).all() and (gd == ed).all() and (gi == ei).all()
+    assert int((gd == 0).sum()) > n // 3 and int(gd.max()) > 0          # both regimes are present at this density
+
+
+def test_full_size_config5_count_overlaps_200M_x_200k(eng):
+    probe, build, nc = synth.workload("count_200M_200k_24contig")
+    n = len(probe[0])
+    ix = O.Index(O.Side(*build), nc)
+    ec = O.count_overlaps_fast(ix, O.Side(*probe), True, threads=os.cpu_count() or 1)
+    d = _Dev(eng, probe, build)
+    try:
+        opts = _engine.make_opts(True, nc)
+        ixd = eng.index_build_dev(d.build, opts, with_end_order=True)
+        cp = d.alloc(8 * n)
+        eng.count_overlaps_dev(ixd, d.probe, opts, cp)
+        got = np.empty(n, np.int64)
+        eng.d2h(got, cp)
+        ixd.close()
+    finally:
+        d.close()
+    assert (got == ec).all()
+    assert abs(int(got.sum()) / synth.expected_pairs(n, len(build[0]), nc) - 1) < 0.03
+
+
+# ---- N > 1: two ranks of the HIP engine over RCCL ------------------------------------------------------------------
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _torchrun(nproc, script_args, timeout=900):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args,
+                          capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_two_rank_hip_rccl_equals_single_gpu(tmp_path):
+    """Two ranks, one GPU each: contig-sharded pb.overlap through libivjoin_hip.so + RCCL all-gatherv, and
+    count_overlaps / nearest + gather_per_probe, against the single-process oracle result (tests/_dist_hip_worker.py)."""
+    if _device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    out = _torchrun(2, [os.path.join(ROOT, "tests", "_dist_hip_worker.py"), str(tmp_path)])
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.load(open(tmp_path / "result.json"))
+    assert res["ok"] and res["world"] == 2 and res["pairs"] > 1000
+
+
+def test_bench_gpus_2_self_spawn():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself and reports n_gpus = 2."""
+    if _device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.05", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "all-gatherv" in j["config"]["parallelism"]
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.01", "--steps", "1"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)

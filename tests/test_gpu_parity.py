@@ -64,8 +64,6 @@ def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1
     assert (p == ep).all() and (b == eb).all(), "partitioned path"
     p, b = _canon(*eng.overlap(probe, build, strict, n_contigs, partition_mode=1, table_mode=1))   # 16-byte bin records
     assert len(p) == len(ep) and (p == ep).all() and (b == eb).all(), "record table"
-    p, b = _canon(*eng.overlap(probe, build, strict, n_contigs, partition_mode=4))   # two-level buckets
-    assert len(p) == len(ep) and (p == ep).all() and (b == eb).all(), "two-level partition"
     if len(probe[0]) and len(build[0]):
         for pm in (0, 5):                                # fused single pass: window scan / flat candidates
             hp, hb = _fused_overlap(eng, probe, build, strict, n_contigs, pm, len(ep))
@@ -143,7 +141,7 @@ def test_inverted_rows_follow_the_inequality(eng):
         probe = (c, np.where(f, e, s).astype(np.int32), np.where(f, s, e).astype(np.int32))
         ps, bs = O.Side(*probe), O.Side(*build)
         ep, eb = O.overlap_brute(ps, bs, strict)
-        for mode in (2, 1, 4):
+        for mode in (2, 1, 6):
             p, b = _canon(*eng.overlap(probe, build, strict, 2, partition_mode=mode))
             assert (p == ep).all() and (b == eb).all(), mode
         assert (eng.count_overlaps(probe, build, strict, 2) == O.count_overlaps_brute(ps, bs, strict)).all()
@@ -160,7 +158,7 @@ def test_empty_and_absent(eng):
         assert n.tolist() == [0] and i.tolist() == [[-1]] and d.tolist() == [[-1]]
         # empty dictionary (every chrom null on both sides): nothing can match
         nul = (np.full(3, -1, np.int32), np.array([1, 5, 9], np.int32), np.array([4, 8, 12], np.int32))
-        for pm in (1, 2, 4):
+        for pm in (1, 2, 6):
             assert len(eng.overlap(nul, nul, strict, 0, partition_mode=pm)[0]) == 0
         assert eng.count_overlaps(nul, nul, strict, 0).tolist() == [0, 0, 0]
         assert eng.nearest(nul, nul, strict, 0)[2].tolist() == [0, 0, 0]
@@ -236,7 +234,7 @@ def test_device_resident_api_matches_host_api(eng):
     probe = synth.make_side(300_001, 42, synth.PROBE_LEN, 24)
     build = synth.make_side(50_003, 43, synth.BUILD_LEN, 24)
     p, b = eng.overlap(probe, build, True, 24, partition_mode=2)
-    for mode in (2, 1, 4):
+    for mode in (2, 1, 6):
         hp, hb, counts = _device_overlap(eng, probe, build, True, 24, partition_mode=mode)
         hp, hb = _canon(hp, hb)
         assert (hp == p).all() and (hb == b).all(), mode
@@ -305,8 +303,7 @@ def test_fused_single_pass_matches_two_pass(eng):
     """ivj_overlap_fused_dev: same pair set; the pairs of one probe row stay contiguous and ordered
     (a stable sort by probe row gives the oracle's exact sequence); a too-small buffer is refused."""
     for (npr, nb, nc, pm) in ((300_001, 50_003, 24, 1), (300_001, 50_003, 24, 2), (5000, 700, 3, 1),
-                              (300_001, 50_003, 24, 3), (5000, 700, 3, 3), (777_777, 1_300_000, 24, 3),
-                              (300_001, 50_003, 24, 4), (5000, 700, 3, 4), (777_777, 1_300_000, 24, 4),
+                              (300_001, 50_003, 24, 6), (5000, 700, 3, 6), (777_777, 1_300_000, 24, 6),
                               (300_001, 50_003, 24, 5), (5000, 700, 3, 5), (777_777, 1_300_000, 24, 5)):
         probe = synth.make_side(npr, 42, synth.PROBE_LEN, nc)
         build = synth.make_side(nb, 43, synth.DENSE_BUILD_LEN if npr < 10000 else synth.BUILD_LEN, nc)
@@ -453,14 +450,14 @@ def test_materialize_and_take_dev():
 
 def test_fused_rows_join_and_materialise_in_one_pass():
     """ivj_overlap_fused_rows_dev == the pair list of the oracle with the key columns taken on the host;
-    global row ids (contig shard), skipped columns, Weak, unpartitioned / two-level, too-small capacity."""
+    global row ids (contig shard), skipped columns, Weak, unpartitioned / slice path, too-small capacity."""
     import torch
     from polars_bio_amd.device_api import DeviceJoin, DeviceSide
     dev = torch.device("cuda", 0)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     join = DeviceJoin(0)
     for (npr, nb, nc, strict, pm, blen) in ((300_001, 50_003, 24, True, 1, synth.BUILD_LEN), (120_000, 30_000, 24, False, 2, synth.DENSE_BUILD_LEN),
-                                            (5000, 700, 3, True, 4, synth.DENSE_BUILD_LEN), (777_777, 1_300_000, 24, True, 0, synth.BUILD_LEN)):
+                                            (5000, 700, 3, True, 6, synth.DENSE_BUILD_LEN), (777_777, 1_300_000, 24, True, 0, synth.BUILD_LEN)):
         probe = synth.make_side(npr, 42, synth.PROBE_LEN, nc)
         build = synth.make_side(nb, 43, blen, nc)
         ep, eb = O.overlap_fast(O.Index(O.Side(*build), nc), O.Side(*probe), strict)

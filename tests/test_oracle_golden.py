@@ -303,6 +303,12 @@ def test_interval_tree_equals_sort_search_and_brute(strict, real_sides):
     ix = O.Index(b, n)
     assert O.overlap_tree(ix, p, strict, count_only=True) == (54246 if strict else 54343)
     assert O.overlap_tree(ix, p, strict, threads=3, count_only=True) == O.overlap_fast(ix, p, strict, count_only=True)
+    # the timed single-pass baseline (bench.py cpu_baseline) emits the same pairs: count and checksum of build rows
+    fp, fb = O.overlap_fast(ix, p, strict)
+    for threads in (1, 3):
+        for tree in (False, True):
+            for srt in (False, True):
+                assert O.overlap_baseline(ix, p, strict, threads, tree, srt) == (len(fp), int(fb.astype(np.int64).sum()))
 
 
 @pytest.mark.parametrize("case", load_cases()["sort_scan_boundary"], ids=lambda c: c["name"])
