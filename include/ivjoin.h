@@ -79,15 +79,18 @@ typedef struct {
     int32_t n_contigs;         /* size of the shared chrom dictionary */
     int32_t nearest_k;         /* RangeOptions.nearest_k, >= 1 (default 1) */
     int32_t include_overlaps;  /* RangeOptions.include_overlaps (default 1) */
-    int32_t partition_mode;    /* overlap: bucket the probe side first. 0 auto (large inputs), 1 always (256-way,
-                                  deterministic), 2 never, 3 fine (8192-way + LDS-resident index slices; used by
-                                  ivj_overlap_fused_dev, the count/fill pair treats it as 1), 4 two-level
-                                  (two stable 256-way passes -> 65536 buckets, deterministic), 5 flat (256-way buckets +
-                                  load-balanced candidate test, ivj_overlap_fused_dev only; with 0 the fused entry point
-                                  picks it by itself when capacity >= 16 pairs per probe row, i.e. for dense results) */
+    int32_t partition_mode;    /* how the probe side is ordered before the join kernels run.  0 auto: large inputs take the
+                                  slice path (6) for the overlap pair kernels and the 256-bucket path (1) for the per-probe
+                                  kernels; 1 256 genomic buckets + window-scan kernels (deterministic); 2 never (probe order);
+                                  5 flat (256 buckets + load-balanced candidate test, ivj_overlap_fused_dev only; with 0 the
+                                  fused entry point picks it by itself when capacity >= 16 pairs per probe row, i.e. for dense
+                                  results); 6 LDS-resident index slices: one stable partition into <= 1536 slices of equal
+                                  row count + join on the slice held in LDS (overlap count / fill / fused; falls back to 1
+                                  when the build side exceeds 1536 x 5120 rows or for the other operations) */
     int32_t table_mode;        /* direct-address table form: 0 auto (16-byte records for build sides >= 2^20 rows),
                                   1 records, 2 plain 4-byte bins */
-    int32_t reserved[2];       /* must be zero */
+    int32_t slice_rows;        /* slice path: build rows per slice, 0 = auto (rows / 1024, rounded up to 64, <= 5120) */
+    int32_t slice_chunk;       /* slice path: probes per join workgroup, 0 = auto (multiple of 4096) */
 } ivj_opts;
 
 /* Result of overlap on the host path: library-owned host buffers. */

@@ -35,6 +35,16 @@ struct TimingRec {
 
 }  // namespace
 
+struct SlicePlan {                     // slice path: launch geometry of one call (host_slice.hip.h fills it)
+    SliceGeom g{0, 0, 0, 0, 0};
+    int chunk = 0, nchunks = 0;        // partition: probes per workgroup, workgroups
+    int jchunk = 0, gmax = 0;          // join: probes per workgroup, upper bound on the workgroups
+    int tiles_per_chunk = 0;
+    int64_t ntiles = 0;                // gmax * tiles_per_chunk
+    int stage = 0, lds_seg = 0, items = 4;
+    size_t part_lds = 0, join_lds = 0, join_lds_count = 0;
+};
+
 struct ivj_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -60,6 +70,19 @@ struct ivj_ctx {
     int32_t *pt_c = nullptr, *pt_s = nullptr, *pt_e = nullptr, *pt_row = nullptr;
     uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
     bool part_attr_set = false;
+    // slice path (host_slice.hip.h): bucket-ordered probe records, histogram, chunk table, tile totals
+    char* sl_buf = nullptr;
+    size_t sl_cap = 0;
+    int4* sl_rec = nullptr;
+    uint32_t *sl_blk = nullptr, *sl_part = nullptr, *sl_bstart = nullptr;
+    int32_t* sl_meta = nullptr;
+    int2* sl_map = nullptr;
+    long long *sl_tile = nullptr, *sl_tpart = nullptr;
+    bool ov_slice = false;             // the pending count -> fill hand-over went through the slice path
+    bool sl_plan_valid = false;
+    int sl_items = 2;                  // probes per thread of the slice join (IVJ_SLICE_ITEMS = 2 | 4: tuning knob)
+    int sl_env_rows = 0, sl_env_chunk = 0;   // IVJ_SLICE_ROWS / IVJ_SLICE_CHUNK: tuning knobs used when the opts fields are 0
+    SlicePlan sl_plan;
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
     bool t_open = false;
@@ -103,6 +126,8 @@ struct ivj_index {
     bool has_argmax = false;
     bool has_flat = false;
     bool has_rec4 = false;
+    unsigned long long* spl = nullptr;   // slice path: composite key of the first row of every slice
+    int sl_R = 0, sl_nb = 0;             //   geometry the splitters were made for (0: none yet)
     bool has_tables = true;    // false: built for merge / cluster only (with_end_order & 2)     // rec4 is filled on demand (join + materialisation path, flat path)
     char* slab = nullptr;      // single allocation holding every array above
     size_t slab_cap = 0;
@@ -225,6 +250,7 @@ int check_opts(const ivj_opts* o) {
     if (o->table_mode < 0 || o->table_mode > 2) return fail(IVJ_EINVAL, "table_mode must be 0 (auto), 1 (records) or 2 (bins)");
     if (o->partition_mode < 0 || o->partition_mode > 6 || o->partition_mode == 3 || o->partition_mode == 4)
         return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (256-way buckets), 2 (never), 5 (flat, fused path only) or 6 (LDS-resident index slices)");
+    if (o->slice_rows < 0 || o->slice_chunk < 0) return fail(IVJ_EINVAL, "slice_rows / slice_chunk must be >= 0");
     return IVJ_OK;
 }
 int check_side(const ivj_side* s, const char* what) {

@@ -87,9 +87,20 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     IVJ_TRY(need_tables(ix));
     const int64_t n = probe->n;
     ctx->ov_n = -1;
+    ctx->ov_slice = false;
     if (n == 0 || ix->n == 0) {
         ctx->ov_n = n; ctx->ov_total = 0; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
         *n_pairs = 0;
+        return IVJ_OK;
+    }
+    SliceGeom sg;
+    if (want_slices(ix, n, opts, sg)) {
+        int64_t total = 0;
+        IVJ_TRY(slice_overlap_count(ctx, ix, probe, opts, sg, &total));
+        ctx->ov_slice = true;
+        ctx->ov_total = total;
+        ctx->ov_n = n; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
+        *n_pairs = total;
         return IVJ_OK;
     }
     const bool part = want_partition(ix, n, opts);
@@ -128,6 +139,7 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     if (capacity < ctx->ov_total) return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->ov_total) + " pairs");
     if (ctx->ov_total == 0) return IVJ_OK;
     if (!out_p || !out_b) return fail(IVJ_EINVAL, "output buffers are NULL");
+    if (ctx->ov_slice) return slice_overlap_fill(ctx, ix, opts, out_p, out_b);
     const int64_t n = probe->n;
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     const int32_t* qs = ctx->ov_part ? ctx->pt_s : probe->start;
@@ -160,6 +172,12 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     ctx->ov_n = -1;                                   // invalidates a pending count -> fill hand-over
     *n_pairs = 0;
     if (n == 0 || ix->n == 0) return IVJ_OK;
+    {
+        // sparse results of large inputs: LDS-resident index slices; dense ones (capacity says >= 16 pairs per probe) keep the flat kernel
+        SliceGeom sg;
+        const bool dense = opts->partition_mode == 0 && capacity >= 16 * n && ix->n_contigs > 0;
+        if (!dense && want_slices(ix, n, opts, sg)) return slice_overlap_fused(ctx, ix, probe, opts, sg, out_p, out_b, capacity, n_pairs);
+    }
     const bool part = want_partition(ix, n, opts);
     IVJ_TRY(ensure_ov(ctx, n, part ? 1 : 0));
     // dense results (the caller expects >= 16 pairs per probe; at ~8 the two kernels tie and the flat one still has

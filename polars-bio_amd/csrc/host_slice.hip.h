@@ -1,0 +1,215 @@
+// host_slice.hip.h -- driver of the slice path (slice.hip.h): geometry, splitters, probe partition, join launches
+// Part of the single translation unit ivjoin.hip (included there, in this order); not a stand-alone header.
+#pragma once
+
+namespace {
+
+inline int pow2_floor(int x) { int p = 1; while (2 * p <= x) p *= 2; return p; }
+
+// Geometry of the slice path for this index; false when the build side does not fit (more than SL_MAX_BUCKETS
+// slices of SL_MAX_ROWS rows) -- the callers then keep the 256-bucket window-scan path.
+// opts->slice_rows (0 = auto) pins the rows per slice (tests drive many slices on small inputs with it).
+bool slice_geom(const ivj_index* ix, const ivj_opts* opts, SliceGeom& g) {
+    const int64_t nbuild = ix->n;
+    if (nbuild <= 0) return false;
+    const int env_rows = ix->ctx ? ix->ctx->sl_env_rows : 0;
+    int64_t R = opts->slice_rows > 0 ? opts->slice_rows : (env_rows > 0 ? env_rows : (nbuild + 1023) / 1024);
+    R = (R + 63) / 64 * 64;
+    if ((nbuild + R - 1) / R > SL_MAX_BUCKETS) R = ((nbuild + SL_MAX_BUCKETS - 1) / SL_MAX_BUCKETS + 63) / 64 * 64;
+    if (R > SL_MAX_ROWS) return false;
+    g.R = (int)R;
+    g.nb = (int)((nbuild + R - 1) / R);
+    g.nbits = bits_for((uint32_t)g.nb);
+    g.p2 = pow2_floor(g.nb);
+    g.p2r = pow2_floor(g.R);
+    return true;
+}
+
+// the slice path serves the overlap pair kernels (count / fill / fused) of large inputs; explicit with partition_mode 6
+bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, SliceGeom& g) {
+    if (opts->partition_mode != 0 && opts->partition_mode != 6) return false;
+    if (opts->partition_mode == 0 && !(n_probe >= (4ll << 20) && ix->n >= (256ll << 10))) return false;
+    return slice_geom(ix, opts, g);
+}
+
+int ensure_splitters(ivj_ctx* ctx, ivj_index* ix, const SliceGeom& g) {
+    if (ix->sl_R == g.R && ix->sl_nb == g.nb) return IVJ_OK;
+    LAUNCH(ctx, "slice_splitters", k_slice_splitters, grid1d(g.nb, 256), 256, (const int32_t*)ix->b_contig, (const int32_t*)ix->b_start, ix->n,
+           g.R, g.nb, ix->spl);
+    HIP_TRY(hipGetLastError());
+    ix->sl_R = g.R; ix->sl_nb = g.nb;
+    return IVJ_OK;
+}
+
+int slice_plan(const ivj_index* ix, int64_t n, const ivj_opts* opts, const SliceGeom& g, int ctx_items, SlicePlan& P) {
+    P.g = g;
+    int64_t chunk = ((n + 2047) / 2048 + SL_TILE - 1) / SL_TILE * SL_TILE;
+    if (chunk < SL_TILE) chunk = SL_TILE;
+    if (chunk > 16 * SL_TILE) chunk = 16 * SL_TILE;
+    P.chunk = (int)chunk;
+    P.nchunks = (int)((n + chunk - 1) / chunk);
+    P.items = ctx_items == 2 ? 2 : 4;
+    const int64_t jtile = (int64_t)SL_THREADS * P.items;
+    const int want_chunk = opts->slice_chunk > 0 ? opts->slice_chunk : (ix->ctx ? ix->ctx->sl_env_chunk : 0);
+    int64_t jchunk = want_chunk > 0 ? ((int64_t)want_chunk + jtile - 1) / jtile * jtile
+                                           : (n >= (32ll << 20) ? 4 * SL_TILE : (n >= (8ll << 20) ? 2 * SL_TILE : SL_TILE));
+    if (jchunk > 64 * SL_TILE) jchunk = 64 * SL_TILE;
+    P.jchunk = (int)jchunk;
+    P.gmax = (int)(g.nb + (n + jchunk - 1) / jchunk);
+    P.tiles_per_chunk = (int)(jchunk / jtile);
+    P.ntiles = (int64_t)P.gmax * P.tiles_per_chunk;
+    P.lds_seg = ix->n_contigs <= SL_LDS_CONTIGS ? 1 : 0;
+    P.part_lds = (size_t)slice_part_lds(g.nb).total;
+    const size_t fixed = (size_t)16 * g.R + (P.lds_seg ? (size_t)4 * ((ix->n_contigs + 2 + 1) & ~1) : 0) + 8 * (SL_WAVES + 1) + 64;
+    const size_t lds_cap = 160 * 1024;
+    if (fixed + 8 * 1024 > lds_cap || P.part_lds > lds_cap) return fail(IVJ_EINVAL, "slice geometry does not fit the LDS");
+    size_t stage = (lds_cap - fixed) / 8 / SL_THREADS * SL_THREADS;
+    if (stage > 12 * 1024) stage = 12 * 1024;
+    P.stage = (int)stage;
+    P.join_lds = fixed + 8 * stage;
+    P.join_lds_count = fixed;
+    return IVJ_OK;
+}
+
+// scratch of the slice path, owned by the context (kept between count and fill)
+int ensure_sl(ivj_ctx* ctx, int64_t n, const SlicePlan& P) {
+    const size_t hist = (size_t)(P.g.nb + 1) * (size_t)P.nchunks;
+    const size_t need = align_up((size_t)n * 16) + align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4) +
+                        align_up((size_t)(P.g.nb + 2) * 4) + align_up(64) + align_up((size_t)P.gmax * 8) +
+                        align_up((size_t)(P.ntiles + 2) * 8) + align_up((size_t)(scan_num_tiles(P.ntiles) + 2) * 8) + 4096;
+    if (need > ctx->sl_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->sl_buf) HIP_TRY(hipFree(ctx->sl_buf));
+        ctx->sl_buf = nullptr; ctx->sl_cap = 0;
+        const size_t want = align_up(need + need / 8, 1 << 20);
+        hipError_t e = hipMalloc((void**)&ctx->sl_buf, want);
+        if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("slice scratch hipMalloc: ") + hipGetErrorString(e));
+        ctx->sl_cap = want;
+    }
+    char* p = ctx->sl_buf;
+    ctx->sl_rec = (int4*)p; p += align_up((size_t)n * 16);
+    ctx->sl_blk = (uint32_t*)p; p += align_up(hist * 4);
+    ctx->sl_part = (uint32_t*)p; p += align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4);
+    ctx->sl_bstart = (uint32_t*)p; p += align_up((size_t)(P.g.nb + 2) * 4);
+    ctx->sl_meta = (int32_t*)p; p += align_up(64);                 // [0] join workgroups; bytes 16.. = fused cursor + overflow flag
+    ctx->sl_map = (int2*)p; p += align_up((size_t)P.gmax * 8);
+    ctx->sl_tile = (long long*)p; p += align_up((size_t)(P.ntiles + 2) * 8);
+    ctx->sl_tpart = (long long*)p;
+    return IVJ_OK;
+}
+
+template <class K>
+int set_dyn_lds(K kernel, size_t bytes) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return IVJ_OK;
+}
+
+// probe side -> bucket-ordered 16-byte records + chunk table of the join
+int slice_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const SlicePlan& P) {
+    const int64_t n = probe->n;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    IVJ_TRY(ensure_splitters(ctx, ix, P.g));
+    const bool vec = aligned16(probe->contig) && aligned16(probe->end);
+    const size_t hist_lds = (size_t)8 * P.g.nb + 4 * (P.g.nb + 1);
+    const size_t hist = (size_t)(P.g.nb + 1) * (size_t)P.nchunks;
+    t_begin(ctx, "slice_hist");
+    if (strict) {
+        hipLaunchKernelGGL((k_slice_hist<true>), dim3(P.nchunks), dim3(SL_THREADS), hist_lds, ctx->stream, (const unsigned long long*)ix->spl, P.g,
+                           ix->n_contigs, probe->contig, probe->end, n, P.chunk, P.nchunks, vec, ctx->sl_blk);
+    } else {
+        hipLaunchKernelGGL((k_slice_hist<false>), dim3(P.nchunks), dim3(SL_THREADS), hist_lds, ctx->stream, (const unsigned long long*)ix->spl, P.g,
+                           ix->n_contigs, probe->contig, probe->end, n, P.chunk, P.nchunks, vec, ctx->sl_blk);
+    }
+    t_end(ctx);
+    device_scan<uint32_t, SumOp, false>(ctx, "slice_scan", ctx->sl_blk, ctx->sl_blk, (int64_t)hist, 0u, ctx->sl_part, (uint32_t*)nullptr);
+    LAUNCH(ctx, "slice_chunks", k_slice_chunks, 1, SL_THREADS, (const uint32_t*)ctx->sl_blk, P.nchunks, P.g.nb, n, P.jchunk, ctx->sl_bstart,
+           ctx->sl_meta, ctx->sl_map);
+    if (strict) IVJ_TRY(set_dyn_lds(&k_slice_scatter<true>, P.part_lds)); else IVJ_TRY(set_dyn_lds(&k_slice_scatter<false>, P.part_lds));
+    t_begin(ctx, "slice_scatter");
+    if (strict) {
+        hipLaunchKernelGGL((k_slice_scatter<true>), dim3(P.nchunks), dim3(SL_THREADS), P.part_lds, ctx->stream, (const unsigned long long*)ix->spl, P.g,
+                           ix->n_contigs, probe->contig, probe->start, probe->end, probe->row_id, n, P.chunk, P.nchunks,
+                           (const uint32_t*)ctx->sl_blk, ctx->sl_rec);
+    } else {
+        hipLaunchKernelGGL((k_slice_scatter<false>), dim3(P.nchunks), dim3(SL_THREADS), P.part_lds, ctx->stream, (const unsigned long long*)ix->spl, P.g,
+                           ix->n_contigs, probe->contig, probe->start, probe->end, probe->row_id, n, P.chunk, P.nchunks,
+                           (const uint32_t*)ctx->sl_blk, ctx->sl_rec);
+    }
+    t_end(ctx);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+template <int MODE, int ITEMS>
+int slice_join_launch_n(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const SlicePlan& P, long long capacity, int32_t* out_p, int32_t* out_b) {
+    SliceJoinArgs A;
+    A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.seg = ix->seg; A.n_contigs = ix->n_contigs;
+    A.rec = ctx->sl_rec; A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
+    A.jchunk = P.jchunk; A.stage = P.stage; A.lds_seg = P.lds_seg; A.capacity = capacity;
+    A.tile_tot = ctx->sl_tile; A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
+    A.out_probe = out_p; A.out_build = out_b;
+    const size_t lds = MODE == SL_COUNT ? P.join_lds_count : P.join_lds;
+    const unsigned grid = 8u * (unsigned)((P.gmax + 7) / 8);
+    const char* name = MODE == SL_COUNT ? "slice_join_count" : (MODE == SL_FILL ? "slice_join_fill" : "slice_join_fused");
+    if (opts->filter_op == IVJ_FILTER_STRICT) {
+        IVJ_TRY(set_dyn_lds(&k_slice_join<true, MODE, ITEMS>, lds));
+        t_begin(ctx, name);
+        hipLaunchKernelGGL((k_slice_join<true, MODE, ITEMS>), dim3(grid), dim3(SL_THREADS), lds, ctx->stream, P.g, ix->n, A);
+        t_end(ctx);
+    } else {
+        IVJ_TRY(set_dyn_lds(&k_slice_join<false, MODE, ITEMS>, lds));
+        t_begin(ctx, name);
+        hipLaunchKernelGGL((k_slice_join<false, MODE, ITEMS>), dim3(grid), dim3(SL_THREADS), lds, ctx->stream, P.g, ix->n, A);
+        t_end(ctx);
+    }
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+template <int MODE>
+int slice_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const SlicePlan& P, long long capacity, int32_t* out_p, int32_t* out_b) {
+    return P.items == 2 ? slice_join_launch_n<MODE, 2>(ctx, ix, opts, P, capacity, out_p, out_b)
+                        : slice_join_launch_n<MODE, 4>(ctx, ix, opts, P, capacity, out_p, out_b);
+}
+
+// count pass of the two-pass pair: partition + join<COUNT> + scan of the tile totals
+int slice_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const SliceGeom& g, int64_t* n_pairs) {
+    SlicePlan P;
+    IVJ_TRY(slice_plan(ix, probe->n, opts, g, ctx->sl_items, P));
+    IVJ_TRY(ensure_sl(ctx, probe->n, P));
+    IVJ_TRY(slice_partition(ctx, ix, probe, opts, P));
+    HIP_TRY(hipMemsetAsync(ctx->sl_tile, 0, (size_t)(P.ntiles + 2) * 8, ctx->stream));
+    IVJ_TRY(slice_join_launch<SL_COUNT>(ctx, ix, opts, P, 0, nullptr, nullptr));
+    device_scan<long long, SumOp, false>(ctx, "tile_scan", ctx->sl_tile, ctx->sl_tile, P.ntiles, 0ll, ctx->sl_tpart, ctx->sl_tile + P.ntiles);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_tile + P.ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    ctx->sl_plan_valid = true;
+    ctx->sl_plan = P;
+    *n_pairs = *ctx->h_total;
+    return IVJ_OK;
+}
+
+int slice_overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int32_t* out_p, int32_t* out_b) {
+    if (!ctx->sl_plan_valid) return fail(IVJ_ESTATE, "slice fill without a matching count");
+    return slice_join_launch<SL_FILL>(ctx, ix, opts, ctx->sl_plan, 0, out_p, out_b);
+}
+
+int slice_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const SliceGeom& g, int32_t* out_p,
+                        int32_t* out_b, int64_t capacity, int64_t* n_pairs) {
+    SlicePlan P;
+    IVJ_TRY(slice_plan(ix, probe->n, opts, g, ctx->sl_items, P));
+    IVJ_TRY(ensure_sl(ctx, probe->n, P));
+    ctx->sl_plan_valid = false;
+    IVJ_TRY(slice_partition(ctx, ix, probe, opts, P));
+    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
+    IVJ_TRY(slice_join_launch<SL_FUSED>(ctx, ix, opts, P, (long long)capacity, out_p, out_b));
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_meta + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    *n_pairs = ctx->h_total[0];
+    if (ctx->h_total[1] != 0)
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");
+    return IVJ_OK;
+}
+
+}  // namespace

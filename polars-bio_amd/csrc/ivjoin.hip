@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "probe.hip.h"
+#include "slice.hip.h"
 #include "radix_sort.hip.h"
 #include "scan.hip.h"
 
@@ -25,6 +26,7 @@ using namespace ivj;
 
 #include "host_core.hip.h"
 #include "host_index.hip.h"
+#include "host_slice.hip.h"
 #include "host_join.hip.h"
 #include "host_sortscan.hip.h"
 
@@ -55,6 +57,9 @@ int ivj_ctx_create(int device, ivj_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(IVJ_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     ctx->stream = ctx->own_stream;
+    if (const char* ev = std::getenv("IVJ_SLICE_ITEMS")) ctx->sl_items = std::atoi(ev) == 4 ? 4 : 2;
+    if (const char* ev = std::getenv("IVJ_SLICE_ROWS")) ctx->sl_env_rows = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_SLICE_CHUNK")) ctx->sl_env_chunk = std::atoi(ev);
     e = hipHostMalloc((void**)&ctx->h_total, 64, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(IVJ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
     *out = ctx;
@@ -68,6 +73,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     for (ivj_index* ix : ctx->live) ix->ctx = nullptr;          // detached: they keep (and later free) their slabs
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->ov_buf) (void)hipFree(ctx->ov_buf);
+    if (ctx->sl_buf) (void)hipFree(ctx->sl_buf);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);

@@ -1,0 +1,538 @@
+// slice.hip.h -- pb.overlap on LDS-resident index slices (the round-2 hot path).
+//
+// The 256-bucket window-scan kernels (overlap.hip.h) are bound by the vector L1's miss queue: ~5 L1-missing 64-byte
+// lines per probe (table record, window rows, build rows) at ~64 outstanding requests per CU.  This path removes the
+// per-probe gathers from global memory altogether:
+//
+//   * the sorted build side is cut into `nb` SLICES of R consecutive rows (equal ROW COUNT, so a slice always fits
+//     the LDS whatever the genomic density: clustered real data cannot overflow it);
+//   * one stable, LDS-staged partition pass (k_slice_hist / k_slice_scatter) sends every probe to the slice that holds
+//     its hi-bound -- the bucket of a probe is the number of slice boundaries ("splitters", 8 bytes each, in LDS)
+//     below its (contig, end) key -- and writes ONE 16-byte record {start, end, row, contig} per probe, so a bucket
+//     run of four probes is a full 64-byte line even at > 1000 buckets;
+//   * the join kernel (k_slice_join) gives a workgroup one bucket chunk: it loads the slice (start / (end, pmax) / row
+//     of R rows, coalesced) into LDS ONCE and streams tiles of 4096 probe records through it.  The hi-bound is a
+//     fixed-trip-count bound search in LDS, the window scan and the build rows of the matches come from LDS; the only
+//     global accesses are the coalesced record stream, the coalesced slice load and the coalesced result stream.
+//     Windows that reach below the slice (rare: a few rows per slice boundary) read the global arrays.
+//
+// Count / fill / fused are ONE kernel template: COUNT writes tile totals, FILL emits at scanned tile bases
+// (deterministic), FUSED reserves the tile's output range with one atomic (single pass, tile order not reproducible).
+#pragma once
+#include "index_view.hip.h"
+
+namespace ivj {
+
+constexpr int SL_THREADS = 1024;
+constexpr int SL_WAVES = SL_THREADS / kWave;
+constexpr int SL_ITEMS = 4;
+constexpr int SL_TILE = SL_THREADS * SL_ITEMS;       // probes per tile of the partition and of the join
+constexpr int SL_MAX_BUCKETS = 1536;                  // slices (+ 1 bucket for probes without any candidate row)
+constexpr int SL_MAX_ROWS = 5120;                     // rows per slice (16 bytes of LDS each)
+constexpr int SL_LDS_CONTIGS = 1022;                  // segment offsets are staged in LDS up to this many contigs
+
+struct SliceGeom {
+    int nb;            // number of slices = buckets 0 .. nb-1; bucket nb = probes that cannot match
+    int R;             // rows per slice (multiple of 64); the last slice may be shorter
+    int nbits;         // bits of a bucket id (match-any ranking)
+    int p2;            // largest power of two <= nb   (fixed-trip-count bucket search)
+    int p2r;           // largest power of two <= R    (fixed-trip-count hi-bound search)
+};
+
+// ---- workgroup scan over SL_THREADS threads ---------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T sl_block_exclusive_sum(T v, T* wsum /* SL_WAVES */, T* total) {
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const T inc = wave_inclusive_scan(v, SumOp());
+    if (lane == kWave - 1) wsum[w] = inc;
+    __syncthreads();
+    T pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SL_WAVES; ++k) { const T x = wsum[k]; if (k < w) pre += x; tot += x; }
+    __syncthreads();
+    *total = tot;
+    return pre + inc - v;
+}
+
+// ---- splitters ---------------------------------------------------------------------------------------------------
+// spl[j] = composite key (contig, start) of sorted row j * R: the first row of slice j.
+__global__ void k_slice_splitters(const int32_t* __restrict__ b_contig, const int32_t* __restrict__ b_start, int64_t n, int R, int nb,
+                                  unsigned long long* __restrict__ spl) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    const int64_t p = (int64_t)j * R;
+    spl[j] = p < n ? (((unsigned long long)(uint32_t)b_contig[p] << 32) | (unsigned long long)flip(b_start[p])) : ~0ull;
+}
+
+// Bucket of a probe: hi = number of build rows whose (contig, start) key lies below the probe's (contig, end) key
+// [+1 for Weak: start <= end counts]; rows are sorted by that key, so row p is below the key iff p < hi, and the
+// number of splitters (rows 0, R, 2R, ...) below the key is ceil(hi / R): hi lies in (kR, (k+1)R] for bucket
+// k = ceil(hi / R) - 1.  hi = 0 (k = -1) or a contig outside the dictionary: no candidate row at all -> bucket nb.
+template <bool STRICT>
+__device__ __forceinline__ uint32_t slice_bucket(const unsigned long long* __restrict__ l_spl, const SliceGeom& g, int32_t n_contigs,
+                                                 int32_t c, int32_t qe) {
+    const unsigned long long key = (((unsigned long long)(uint32_t)c << 32) | (unsigned long long)flip(qe)) + (STRICT ? 0ull : 1ull);
+    int pos = 0;                                             // number of splitters < key
+    for (int step = g.p2; step > 0; step >>= 1) {
+        const int t = pos + step;
+        if (t <= g.nb && l_spl[t - 1] < key) pos = t;
+    }
+    return ((uint32_t)c >= (uint32_t)n_contigs || pos == 0) ? (uint32_t)g.nb : (uint32_t)(pos - 1);
+}
+
+// lanes of this wavefront that are valid and hold the same bucket id (nbits <= 11)
+__device__ __forceinline__ uint64_t wave_match_n(uint32_t d, bool valid, int nbits) {
+    uint64_t peers = __ballot(valid);
+    for (int b = 0; b < nbits; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+// ---- partition, pass 1: per-chunk bucket histogram -----------------------------------------------------------------
+// Workgroup g owns the probes [g * chunk, (g + 1) * chunk); blk_hist is bucket-major: blk_hist[b * nchunks + g].
+template <bool STRICT>
+__global__ __launch_bounds__(SL_THREADS) void k_slice_hist(const unsigned long long* __restrict__ spl, SliceGeom g, int32_t n_contigs,
+                                                          const int32_t* __restrict__ pc, const int32_t* __restrict__ pe, int64_t n,
+                                                          int chunk, int nchunks, bool vec_ok, uint32_t* __restrict__ blk_hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sl_lds[];
+    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(sl_lds);
+    uint32_t* h = reinterpret_cast<uint32_t*>(l_spl + g.nb);
+    for (int k = threadIdx.x; k < g.nb; k += SL_THREADS) l_spl[k] = spl[k];
+    for (int k = threadIdx.x; k <= g.nb; k += SL_THREADS) h[k] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * chunk;
+    const int64_t end = base + chunk < n ? base + chunk : n;
+    for (int64_t i0 = base + (int64_t)threadIdx.x * 4; i0 < end; i0 += (int64_t)SL_THREADS * 4) {
+        int32_t c[4], e[4];
+        load_items_nt(pc, i0, end, vec_ok, -1, c);
+        load_items_nt(pe, i0, end, vec_ok, 0, e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < end) atomicAdd(&h[slice_bucket<STRICT>(l_spl, g, n_contigs, c[k], e[k])], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= g.nb; k += SL_THREADS) blk_hist[(int64_t)k * nchunks + blockIdx.x] = h[k];
+}
+
+// ---- chunk table of the join ------------------------------------------------------------------------------------------
+// From the scanned histogram (blk_off[b * nchunks] = first probe of bucket b): bucket starts, the number of join
+// workgroups per bucket (chunks of `jchunk` probes) and the map workgroup -> (bucket, chunk inside the bucket).
+// meta[0] = number of join workgroups.  One workgroup.
+__global__ __launch_bounds__(SL_THREADS) void k_slice_chunks(const uint32_t* __restrict__ blk_off, int nchunks, int nb, int64_t n,
+                                                            int jchunk, uint32_t* __restrict__ bstart, int32_t* __restrict__ meta,
+                                                            int2* __restrict__ wg_map) {
+    __shared__ int l_cpre[SL_MAX_BUCKETS + 2];
+    __shared__ int wsum[SL_WAVES];
+    // two buckets per thread (nb + 1 <= 2 * SL_THREADS)
+    int cnt2[2];
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int b = 2 * threadIdx.x + k;
+        cnt2[k] = 0;
+        if (b <= nb) {
+            const uint32_t s = blk_off[(int64_t)b * nchunks];
+            const uint32_t e = b < nb ? blk_off[(int64_t)(b + 1) * nchunks] : (uint32_t)n;
+            bstart[b] = s;
+            if (b == nb) bstart[nb + 1] = (uint32_t)n;
+            if (b < nb) cnt2[k] = (int)((e - s + (uint32_t)jchunk - 1u) / (uint32_t)jchunk);
+        }
+        v += cnt2[k];
+    }
+    int total;
+    const int pre = sl_block_exclusive_sum(v, wsum, &total);
+    if (2 * threadIdx.x <= nb) l_cpre[2 * threadIdx.x] = pre;
+    if (2 * threadIdx.x + 1 <= nb) l_cpre[2 * threadIdx.x + 1] = pre + cnt2[0];
+    if (threadIdx.x == 0) { meta[0] = total; l_cpre[nb + 1] = total; }
+    __syncthreads();
+    for (int w = threadIdx.x; w < total; w += SL_THREADS) {
+        // last bucket b in [0, nb) with l_cpre[b] <= w  (buckets without probes repeat the prefix: take the last)
+        int lo = 0, hi = nb;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (l_cpre[m + 1] <= w) lo = m + 1; else hi = m; }
+        wg_map[w] = make_int2(lo, w - l_cpre[lo]);
+    }
+}
+
+// ---- partition, pass 2: stable scatter of 16-byte probe records ---------------------------------------------------
+// blk_off = exclusive scan of blk_hist (bucket-major).  The workgroup walks its chunk in tiles of SL_TILE probes:
+// bucket ids (splitter search in LDS) -> rank inside (wavefront, bucket) with match-any ballots against the
+// wavefront's PRIVATE counter row (no workgroup barrier inside the rounds) -> per-bucket prefix over the wavefronts
+// + tile-local bucket starts -> the records are placed in LDS at their sorted tile-local position and copied out as
+// contiguous bucket runs (consecutive threads -> consecutive records of one run: coalesced 16-byte stores).  The
+// running global offset of every bucket lives in LDS across the tiles of the chunk.
+struct SlicePartLds {
+    // byte offsets into the dynamic LDS block
+    int spl, base, lstart, tot, wcnt, rec, d, wsum, total;
+};
+__host__ __device__ inline SlicePartLds slice_part_lds(int nb) {
+    SlicePartLds L;
+    const int nbp = (nb + 2 + 1) & ~1;                          // counters per wavefront row, even
+    int o = 0;
+    L.spl = o; o += 8 * nb;
+    L.rec = (o + 15) & ~15; o = L.rec + 16 * SL_TILE;
+    L.base = o; o += 4 * (nb + 2);
+    L.lstart = o; o += 4 * (nb + 2);
+    L.tot = o; o += 4 * (nb + 2);
+    L.wcnt = (o + 3) & ~3; o = L.wcnt + 2 * nbp * SL_WAVES;
+    L.d = (o + 3) & ~3; o = L.d + 2 * SL_TILE;
+    L.wsum = (o + 3) & ~3; o = L.wsum + 4 * SL_WAVES;
+    L.total = o;
+    return L;
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(SL_THREADS) void k_slice_scatter(const unsigned long long* __restrict__ spl, SliceGeom g, int32_t n_contigs,
+                                                             const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                             const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
+                                                             int chunk, int nchunks, const uint32_t* __restrict__ blk_off,
+                                                             int4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sl_lds[];
+    const SlicePartLds L = slice_part_lds(g.nb);
+    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(sl_lds + L.spl);
+    int4* l_rec = reinterpret_cast<int4*>(sl_lds + L.rec);
+    uint32_t* base = reinterpret_cast<uint32_t*>(sl_lds + L.base);
+    uint32_t* lstart = reinterpret_cast<uint32_t*>(sl_lds + L.lstart);
+    uint32_t* tot = reinterpret_cast<uint32_t*>(sl_lds + L.tot);
+    unsigned short* wcnt = reinterpret_cast<unsigned short*>(sl_lds + L.wcnt);
+    unsigned short* l_d = reinterpret_cast<unsigned short*>(sl_lds + L.d);
+    uint32_t* wsum = reinterpret_cast<uint32_t*>(sl_lds + L.wsum);
+    const int nbp = (g.nb + 2 + 1) & ~1;
+    const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+    const int nbk = g.nb + 1;                                   // buckets incl. the "no candidate" one
+
+    for (int k = tid; k < g.nb; k += SL_THREADS) l_spl[k] = spl[k];
+    for (int k = tid; k < nbk; k += SL_THREADS) { base[k] = blk_off[(int64_t)k * nchunks + blockIdx.x]; tot[k] = 0; }
+    for (int k = tid; k < nbp * SL_WAVES / 2; k += SL_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
+    __syncthreads();
+
+    const int64_t cbase = (int64_t)blockIdx.x * chunk;
+    const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
+    const uint64_t lt = lanemask_lt();
+    unsigned short* my = wcnt + w * nbp;
+    // wavefront w owns the contiguous quarter-KiB [w * 256, (w + 1) * 256) of the tile: item j of lane l is tile
+    // element w * 256 + j * 64 + l (every load is one contiguous 256-byte segment)
+    const int el0 = w * (SL_ITEMS * kWave) + lane;
+
+    int32_t nc[SL_ITEMS], ns[SL_ITEMS], ne[SL_ITEMS], nr[SL_ITEMS];
+    auto load_tile = [&](int64_t tbase) {
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) {
+            const int64_t i = tbase + el0 + j * kWave;
+            const bool valid = i < cend;
+            nc[j] = valid ? __builtin_nontemporal_load(pc + i) : -1;
+            ns[j] = valid ? __builtin_nontemporal_load(ps + i) : 0;
+            ne[j] = valid ? __builtin_nontemporal_load(pe + i) : 0;
+            nr[j] = valid ? (row_id ? __builtin_nontemporal_load(row_id + i) : (int32_t)i) : -1;
+        }
+    };
+    load_tile(cbase);
+    for (int64_t tbase = cbase; tbase < cend; tbase += SL_TILE) {
+        int32_t c[SL_ITEMS], s[SL_ITEMS], e[SL_ITEMS], r[SL_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) { c[j] = nc[j]; s[j] = ns[j]; e[j] = ne[j]; r[j] = nr[j]; }
+        if (tbase + SL_TILE < cend) load_tile(tbase + SL_TILE);        // next tile's columns are in flight during this one
+        const int tile_n = (int)((cend - tbase) < (int64_t)SL_TILE ? (cend - tbase) : (int64_t)SL_TILE);
+        uint32_t d[SL_ITEMS], rank[SL_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) {
+            const bool valid = el0 + j * kWave < tile_n;
+            d[j] = valid ? slice_bucket<STRICT>(l_spl, g, n_contigs, c[j], e[j]) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) {
+            const bool valid = el0 + j * kWave < tile_n;
+            const uint64_t peers = wave_match_n(d[j], valid, g.nbits);
+            const uint32_t rk = (uint32_t)__popcll(peers & lt);
+            const uint32_t before = valid ? (uint32_t)my[d[j]] : 0u;
+            rank[j] = before + rk;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rk == 0) my[d[j]] = (unsigned short)(before + (uint32_t)__popcll(peers));
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();                                                        // (A) all wavefront rows counted
+        // thread t owns buckets 2t, 2t+1 (one 32-bit word of every wavefront row): advance the global offsets by
+        // the previous tile's totals, exclusive prefix over the wavefronts, tile totals, tile-local bucket starts
+        uint32_t x0 = 0, x1 = 0;
+        {
+            const int b0 = 2 * tid;
+            if (b0 < nbk) {
+                base[b0] += tot[b0];
+                if (b0 + 1 < nbk) base[b0 + 1] += tot[b0 + 1];
+                uint32_t* row32 = reinterpret_cast<uint32_t*>(wcnt) + tid;
+#pragma unroll
+                for (int k = 0; k < SL_WAVES; ++k) {
+                    const uint32_t v = row32[k * (nbp / 2)];
+                    row32[k * (nbp / 2)] = x0 | (x1 << 16);
+                    x0 += v & 0xffffu; x1 += v >> 16;
+                }
+                tot[b0] = x0;
+                if (b0 + 1 < nbk) tot[b0 + 1] = x1;
+            }
+        }
+        uint32_t tsum;
+        const uint32_t pre = sl_block_exclusive_sum(x0 + x1, wsum, &tsum);      // (B), (C)
+        if (2 * tid < nbk) { lstart[2 * tid] = pre; if (2 * tid + 1 < nbk) lstart[2 * tid + 1] = pre + x0; }
+        __syncthreads();                                                        // (D) lstart / prefixes visible
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) {
+            if (el0 + j * kWave < tile_n) {
+                const uint32_t pos = lstart[d[j]] + (uint32_t)my[d[j]] + rank[j];
+                l_rec[pos] = make_int4(s[j], e[j], r[j], c[j]);
+                l_d[pos] = (unsigned short)d[j];
+            }
+        }
+        __syncthreads();                                                        // (E) tile sorted in LDS
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) {
+            const int il = j * SL_THREADS + tid;
+            if (il < tile_n) {
+                const uint32_t dd = l_d[il];
+                out[(int64_t)base[dd] + ((uint32_t)il - lstart[dd])] = l_rec[il];
+            }
+        }
+        for (int k = tid; k < nbp * SL_WAVES / 2; k += SL_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
+        __syncthreads();                                                        // (F) counters clear, staging free
+    }
+}
+
+// ---- the join ---------------------------------------------------------------------------------------------------------
+enum { SL_COUNT = 0, SL_FILL = 1, SL_FUSED = 2 };
+
+// Row p of the sorted build side: from the slice in LDS, or -- a window reaching below the slice, rare -- from the
+// global array.  The LDS read is unconditional (clamped index) and the global read sits in its own branch: a
+// `cond ? lds[..] : global[..]` select of two address spaces trips hipcc 7.2 ("Operand has incorrect register class").
+__device__ __forceinline__ int2 slice_ep(const int2* l_ep, const int2* __restrict__ g_ep, int p, int r0) {
+    const int i = p - r0;
+    int2 v = l_ep[i < 0 ? 0 : i];
+    if (i < 0) v = g_ep[p];
+    return v;
+}
+__device__ __forceinline__ int32_t slice_row(const int32_t* l_row, const int32_t* __restrict__ g_row, int p, int r0) {
+    const int i = p - r0;
+    int32_t v = l_row[i < 0 ? 0 : i];
+    if (i < 0) v = g_row[p];
+    return v;
+}
+
+struct SliceJoinArgs {
+    // the build index as this kernel needs it (a slim copy: the full IndexView costs ~50 SGPRs of kernel arguments)
+    const int32_t* b_start;
+    const int2* ep;
+    const int32_t* b_row;
+    const int32_t* seg;
+    int32_t n_contigs;
+    const int4* rec;                  // bucket-ordered probe records {start, end, row, contig}
+    const uint32_t* bstart;           // nb + 2 bucket starts
+    const int32_t* meta;              // [0] = number of join workgroups
+    const int2* wg_map;               // workgroup -> (bucket, chunk inside the bucket)
+    int jchunk;                       // probes per join workgroup (multiple of SL_TILE)
+    int stage;                        // pairs of LDS staging (multiple of SL_THREADS)
+    int lds_seg;                      // 1: segment offsets staged in LDS
+    long long capacity;
+    long long* tile_tot;              // COUNT: out; FILL: scanned tile bases
+    unsigned long long* state;        // FUSED: [0] cursor, [1] overflow flag
+    int32_t* out_probe;
+    int32_t* out_build;
+};
+
+template <bool STRICT, int MODE, int ITEMS>
+__global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t nbuild, SliceJoinArgs A) {
+    constexpr int TILE = SL_THREADS * ITEMS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sl_lds[];
+    // dynamic LDS: start[R] | ep[R] | row[R] | staging | seg | scan scratch
+    int32_t* l_start = reinterpret_cast<int32_t*>(sl_lds);
+    int2* l_ep = reinterpret_cast<int2*>(l_start + g.R);
+    int32_t* l_row = reinterpret_cast<int32_t*>(l_ep + g.R);
+    int2* st = reinterpret_cast<int2*>(l_row + g.R);
+    int32_t* l_seg = reinterpret_cast<int32_t*>(st + (MODE == SL_COUNT ? 0 : A.stage));
+    long long* wsum = reinterpret_cast<long long*>(l_seg + (A.lds_seg ? ((A.n_contigs + 2 + 1) & ~1) : 0));
+    long long* s_base = wsum + SL_WAVES;
+
+    // XCD-affine order: workgroup b runs on XCD b % 8 (observed); XCD x takes the contiguous eighth
+    // [x * per, (x + 1) * per) of the (bucket, chunk) list, so its L2 only ever holds its own slices
+    const int total_wg = A.meta[0];
+    const int per = (total_wg + 7) / 8;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int v = (int)(blockIdx.x & 7) * per + slot;
+    if (slot >= per || v >= total_wg) return;                                  // uniform
+    const int2 bc = A.wg_map[v];
+    const int k = bc.x;
+    const int64_t q0 = (int64_t)A.bstart[k] + (int64_t)bc.y * A.jchunk;
+    const int64_t qend = (int64_t)A.bstart[k + 1];
+    const int64_t q1 = q0 + A.jchunk < qend ? q0 + A.jchunk : qend;
+    const int tid = threadIdx.x;
+
+    // slice k = sorted rows [r0, r0 + rk)
+    const int r0 = k * g.R;
+    const int rk = (int)((nbuild - r0) < (int64_t)g.R ? (nbuild - r0) : (int64_t)g.R);
+    for (int i = tid * 4; i < rk; i += SL_THREADS * 4) {
+        if (i + 4 <= rk) {
+            *reinterpret_cast<int4*>(l_start + i) = *reinterpret_cast<const int4*>(A.b_start + r0 + i);
+            *reinterpret_cast<int4*>(l_row + i) = *reinterpret_cast<const int4*>(A.b_row + r0 + i);
+            *reinterpret_cast<int4*>(l_ep + i) = *reinterpret_cast<const int4*>(A.ep + r0 + i);
+            *reinterpret_cast<int4*>(l_ep + i + 2) = *reinterpret_cast<const int4*>(A.ep + r0 + i + 2);
+        } else {
+            for (int j = i; j < rk; ++j) { l_start[j] = A.b_start[r0 + j]; l_row[j] = A.b_row[r0 + j]; l_ep[j] = A.ep[r0 + j]; }
+        }
+    }
+    if (A.lds_seg) for (int i = tid; i < A.n_contigs + 2; i += SL_THREADS) l_seg[i] = A.seg[i];
+    __syncthreads();
+
+    int4 nxt[ITEMS];
+    auto load_tile = [&](int64_t tb) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int64_t q = tb + j * SL_THREADS + tid;
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            if (q < q1) { const v4i t = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(A.rec + q)); nxt[j] = make_int4(t.x, t.y, t.z, t.w); }
+            else nxt[j] = make_int4(0, 0, 0, -1);
+        }
+    };
+    load_tile(q0);
+    const int tiles_per_chunk = A.jchunk / TILE;
+    int tix = 0;
+    for (int64_t tb = q0; tb < q1; tb += TILE, ++tix) {
+        int32_t qs[ITEMS], qe[ITEMS], qrow[ITEMS];
+        int seg_a[ITEMS], hi[ITEMS];
+        bool valid[ITEMS];
+        int lo_s[ITEMS], lb[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            qs[j] = nxt[j].x; qe[j] = nxt[j].y; qrow[j] = nxt[j].z;
+            const int32_t c = nxt[j].w;
+            valid[j] = (tb + j * SL_THREADS + tid < q1) && (uint32_t)c < (uint32_t)A.n_contigs;
+            int a = 0, b = 0;
+            if (valid[j]) {
+                if (A.lds_seg) { a = l_seg[c]; b = l_seg[c + 1]; }
+                else { a = A.seg[c]; b = A.seg[c + 1]; }
+            }
+            seg_a[j] = a;
+            // the contig's rows inside the slice, slice-local: [la, lb)
+            int la = a - r0; la = la < 0 ? 0 : (la > rk ? rk : la);
+            int lbb = b - r0; lbb = lbb < 0 ? 0 : (lbb > rk ? rk : lbb);
+            lo_s[j] = la; lb[j] = lbb < la ? la : lbb;
+        }
+        if (tb + TILE < q1) load_tile(tb + TILE);                        // next tile's records in flight
+        // hi-bound: number of rows of [la, lb) whose start fails to reach q.end, fixed trip count, four probes interleaved
+        for (int step = g.p2r; step > 0; step >>= 1) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int t = lo_s[j] + step;
+                if (t <= lb[j]) {
+                    const int32_t sv = l_start[t - 1];
+                    if (STRICT ? (sv < qe[j]) : (sv <= qe[j])) lo_s[j] = t;
+                }
+            }
+        }
+        // window below hi: 32-row match mask, all four probes of the thread in lockstep (trip count = the longest
+        // window of the wavefront, not the sum over the four); rows below the slice come from the global arrays
+        uint32_t mask[ITEMS];
+        int cnt[ITEMS];
+        int p[ITEMS];
+        bool act[ITEMS], lng[ITEMS];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            hi[j] = r0 + lo_s[j];
+            mask[j] = 0; cnt[j] = 0; lng[j] = false;
+            p[j] = hi[j] - 1;
+            act[j] = valid[j] && p[j] >= seg_a[j];
+            any |= act[j];
+        }
+        while (__any(any)) {
+            any = false;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                if (act[j]) {
+                    const int2 vv = slice_ep(l_ep, A.ep, p[j], r0);
+                    if (!lt_op<STRICT>(qs[j], vv.y)) act[j] = false;
+                    else {
+                        const int jj = hi[j] - 1 - p[j];
+                        const bool m = lt_op<STRICT>(qs[j], vv.x);
+                        // the mask serves windows of <= 32 rows that lie inside the slice; anything else is rescanned at
+                        // emission (that keeps global loads out of the mask loop, which also trips hipcc 7.2 otherwise)
+                        if (jj < 32 && p[j] >= r0) { if (m) mask[j] |= 1u << jj; }
+                        else lng[j] = true;
+                        cnt[j] += m ? 1 : 0;
+                        --p[j];
+                        if (p[j] < seg_a[j]) act[j] = false;
+                    }
+                    any |= act[j];
+                }
+            }
+        }
+        long long tsum = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) tsum += cnt[j];
+        long long tot;
+        const long long loc0 = sl_block_exclusive_sum(tsum, wsum, &tot);
+        const long long tile_id = (long long)v * tiles_per_chunk + tix;
+        if (MODE == SL_COUNT) {
+            if (tid == 0) A.tile_tot[tile_id] = tot;
+            continue;
+        }
+        long long tbase;
+        if (MODE == SL_FILL) tbase = A.tile_tot[tile_id];
+        else {
+            if (tid == 0) {
+                const long long bse = tot ? (long long)atomicAdd(&A.state[0], (unsigned long long)tot) : 0ll;
+                if (bse + tot > A.capacity) { atomicExch(&A.state[1], 1ull); *s_base = -1; }
+                else *s_base = bse;
+            }
+            __syncthreads();
+            tbase = *s_base;
+            __syncthreads();
+            if (tbase < 0) continue;                                           // uniform: over capacity, keep counting
+        }
+        if (tot == 0) continue;                                                // uniform
+        // emission: pairs staged in LDS at their tile-local offset (windows of A.stage pairs, usually one), then
+        // copied out with fully coalesced non-temporal stores.  Mask probes: bit j <=> row hi-1-j, ascending
+        // (start, row) order = descending j.  Long windows (> 32 rows) are rescanned by their lane.
+        for (long long w0 = 0; w0 < tot; w0 += A.stage) {
+            const long long w1 = w0 + A.stage;
+            long long off = loc0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const long long end = off + cnt[j];
+                if (cnt[j] != 0 && end > w0 && off < w1) {
+                    if (!lng[j]) {
+                        uint32_t m = mask[j];
+                        long long o = off;
+                        while (m) {
+                            const int jj = 31 - __clz(m);
+                            m &= ~(1u << jj);
+                            if (o >= w0 && o < w1) {
+                                st[o - w0] = make_int2(qrow[j], l_row[hi[j] - 1 - jj - r0]);
+                            }
+                            ++o;
+                        }
+                    } else {
+                        // the f-th match counted from the top of the window owns slot end - 1 - f
+                        long long o = end - 1;
+                        for (int pp = hi[j] - 1; o >= off; --pp) {
+                            const int2 vv = slice_ep(l_ep, A.ep, pp, r0);
+                            if (lt_op<STRICT>(qs[j], vv.x)) {
+                                if (o >= w0 && o < w1) st[o - w0] = make_int2(qrow[j], slice_row(l_row, A.b_row, pp, r0));
+                                --o;
+                            }
+                        }
+                    }
+                }
+                off = end;
+            }
+            __syncthreads();
+            const int t = (int)((tot - w0) < (long long)A.stage ? (tot - w0) : (long long)A.stage);
+            for (int i = tid; i < t; i += SL_THREADS) {
+                const int2 pr = st[i];
+                __builtin_nontemporal_store(pr.x, A.out_probe + tbase + w0 + i);
+                __builtin_nontemporal_store(pr.y, A.out_build + tbase + w0 + i);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace ivj

@@ -26,7 +26,7 @@ def _canon(p, b):
     return p[o], b[o]
 
 
-def _fused_overlap(eng, probe, build, strict, n_contigs, partition_mode, total):
+def _fused_overlap(eng, probe, build, strict, n_contigs, partition_mode, total, slice_rows=0):
     """ivj_overlap_fused_dev with device-resident columns; returns the raw (probe, build) pair arrays."""
     ptrs, sides = [], []
     for side in (probe, build):
@@ -38,11 +38,11 @@ def _fused_overlap(eng, probe, build, strict, n_contigs, partition_mode, total):
             ps.append(p)
         ptrs += ps
         sides.append(eng.dev_side(ps[0], ps[1], ps[2], n))
-    opts = _engine.make_opts(strict, n_contigs, partition_mode=partition_mode)
+    opts = _engine.make_opts(strict, n_contigs, partition_mode=partition_mode, slice_rows=slice_rows)
     ix = eng.index_build_dev(sides[1], opts)
     op, ob = eng.dev_alloc(max(4 * total, 16)), eng.dev_alloc(max(4 * total, 16))
     n_pairs, fits = eng.overlap_fused_dev(ix, sides[0], opts, op, ob, total)
-    assert fits and n_pairs == total, (partition_mode, n_pairs, total)
+    assert fits and n_pairs == total, (partition_mode, slice_rows, n_pairs, total)
     hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
     eng.d2h(hp, op)
     eng.d2h(hb, ob)
@@ -64,12 +64,15 @@ def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1
     assert (p == ep).all() and (b == eb).all(), "partitioned path"
     p, b = _canon(*eng.overlap(probe, build, strict, n_contigs, partition_mode=1, table_mode=1))   # 16-byte bin records
     assert len(p) == len(ep) and (p == ep).all() and (b == eb).all(), "record table"
+    for sr in (64, 192, 0):                              # slice path (LDS-resident index slices): many tiny slices / default geometry
+        p, b = _canon(*eng.overlap(probe, build, strict, n_contigs, partition_mode=6, slice_rows=sr))
+        assert len(p) == len(ep) and (p == ep).all() and (b == eb).all(), ("slice path", sr)
     if len(probe[0]) and len(build[0]):
-        for pm in (0, 5):                                # fused single pass: window scan / flat candidates
-            hp, hb = _fused_overlap(eng, probe, build, strict, n_contigs, pm, len(ep))
-            assert int((np.diff(hp) != 0).sum()) + 1 == len(np.unique(hp)) or len(hp) == 0, ("probe runs split", pm)
+        for pm, sr in ((0, 0), (5, 0), (6, 64), (6, 0)):   # fused single pass: window scan / flat candidates / slices
+            hp, hb = _fused_overlap(eng, probe, build, strict, n_contigs, pm, len(ep), slice_rows=sr)
+            assert int((np.diff(hp) != 0).sum()) + 1 == len(np.unique(hp)) or len(hp) == 0, ("probe runs split", pm, sr)
             p, b = _canon(hp, hb)
-            assert (p == ep).all() and (b == eb).all(), ("fused", pm)
+            assert (p == ep).all() and (b == eb).all(), ("fused", pm, sr)
     ec = O.count_overlaps_brute(ps, bs, strict) if brute else O.count_overlaps_fast(ix, ps, strict)
     for tm, pm in ((2, 2), (1, 2), (1, 1)):              # 4-byte bins / 16-byte records, probe order / bucketed probes
         assert (eng.count_overlaps(probe, build, strict, n_contigs, table_mode=tm, partition_mode=pm) == ec).all(), (tm, pm)
