@@ -36,12 +36,12 @@ struct TimingRec {
 }  // namespace
 
 struct SlicePlan {                     // slice path: launch geometry of one call (host_slice.hip.h fills it)
-    SliceGeom g{0, 0, 0, 0, 0};
+    SliceGeom g{0, 0, 0, 0, 0, 0, 0};
     int chunk = 0, nchunks = 0;        // partition: probes per workgroup, workgroups
     int jchunk = 0, gmax = 0;          // join: probes per workgroup, upper bound on the workgroups
     int tiles_per_chunk = 0;
     int64_t ntiles = 0;                // gmax * tiles_per_chunk
-    int stage = 0, lds_seg = 0, items = 4;
+    int stage = 0, lds_seg = 0, items = 4, use_bins = 1;
     size_t part_lds = 0, join_lds = 0, join_lds_count = 0;
 };
 
@@ -81,7 +81,7 @@ struct ivj_ctx {
     bool ov_slice = false;             // the pending count -> fill hand-over went through the slice path
     bool sl_plan_valid = false;
     int sl_items = 2;                  // probes per thread of the slice join (IVJ_SLICE_ITEMS = 2 | 4: tuning knob)
-    int sl_env_rows = 0, sl_env_chunk = 0;   // IVJ_SLICE_ROWS / IVJ_SLICE_CHUNK: tuning knobs used when the opts fields are 0
+    int sl_env_rows = 0, sl_env_chunk = 0, sl_env_notab = 0, sl_env_nobins = 0;   // IVJ_SLICE_ROWS / IVJ_SLICE_CHUNK: tuning knobs used when the opts fields are 0
     SlicePlan sl_plan;
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
@@ -127,7 +127,9 @@ struct ivj_index {
     bool has_flat = false;
     bool has_rec4 = false;
     unsigned long long* spl = nullptr;   // slice path: composite key of the first row of every slice
-    int sl_R = 0, sl_nb = 0;             //   geometry the splitters were made for (0: none yet)
+    int sl_R = 0, sl_nb = 0, sl_ncells = -1;   //   geometry the splitters were made for (0: none yet)
+    int4* sl_cm = nullptr;               //   direct-address table over the splitters: per-contig grid, cells
+    uint32_t* sl_cell = nullptr;
     bool has_tables = true;    // false: built for merge / cluster only (with_end_order & 2)     // rec4 is filled on demand (join + materialisation path, flat path)
     char* slab = nullptr;      // single allocation holding every array above
     size_t slab_cap = 0;

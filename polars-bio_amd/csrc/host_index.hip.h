@@ -116,7 +116,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
         const size_t small = align_up((nc + 2) * 4) + align_up(16) + 3 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e, cmeta_j
         const size_t flat_bytes = align_up((nn + 1) * 16) + 3 * align_up((size_t)ix->bins_len * 4);   // rec4, lot, tab2 (filled on demand)
-        const size_t spl_bytes = align_up((size_t)SL_MAX_BUCKETS * 8);
+        const size_t spl_bytes = align_up((size_t)SL_MAX_BUCKETS * 8) + align_up((size_t)SL_TAB_CONTIGS * 16) +
+                                 align_up((size_t)(4 * SL_MAX_BUCKETS + SL_TAB_CONTIGS) * 4);
         const size_t need = spl_bytes + flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 16) + 2 * align_up((size_t)ix->bins_len * 4) +
                             4 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
@@ -128,7 +129,10 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
             ix->slab_cap = need;
         }
         char* p = ix->slab;
-        ix->spl = (unsigned long long*)p; p += spl_bytes;
+        ix->spl = (unsigned long long*)p;
+        ix->sl_cm = (int4*)(p + align_up((size_t)SL_MAX_BUCKETS * 8));
+        ix->sl_cell = (uint32_t*)((char*)ix->sl_cm + align_up((size_t)SL_TAB_CONTIGS * 16));
+        p += spl_bytes;
         ix->ep = (int2*)p; p += align_up(nn * 8);
         ix->b_start = (int32_t*)p; p += col;
         ix->b_row = (int32_t*)p; p += col;

@@ -22,6 +22,14 @@ bool slice_geom(const ivj_index* ix, const ivj_opts* opts, SliceGeom& g) {
     g.nbits = bits_for((uint32_t)g.nb);
     g.p2 = pow2_floor(g.nb);
     g.p2r = pow2_floor(g.R);
+    // direct-address table over the splitters: four (or, for very many slices, two) cells per splitter; small dictionaries only
+    g.ncells = 0;
+    if (ix->n_contigs >= 1 && ix->n_contigs <= SL_TAB_CONTIGS && !(ix->ctx && ix->ctx->sl_env_notab)) {
+        for (int cps = 4; cps >= 2 && !g.ncells; cps -= 2) {
+            const int cells = cps * g.nb + ix->n_contigs;
+            if ((size_t)slice_part_lds(g.nb, cells).total <= 160 * 1024) { g.ncells = cells; g.cps = cps; }
+        }
+    }
     return true;
 }
 
@@ -33,11 +41,14 @@ bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, Sli
 }
 
 int ensure_splitters(ivj_ctx* ctx, ivj_index* ix, const SliceGeom& g) {
-    if (ix->sl_R == g.R && ix->sl_nb == g.nb) return IVJ_OK;
+    if (ix->sl_R == g.R && ix->sl_nb == g.nb && ix->sl_ncells == g.ncells) return IVJ_OK;
     LAUNCH(ctx, "slice_splitters", k_slice_splitters, grid1d(g.nb, 256), 256, (const int32_t*)ix->b_contig, (const int32_t*)ix->b_start, ix->n,
            g.R, g.nb, ix->spl);
+    if (g.ncells)
+        LAUNCH(ctx, "slice_tab", k_slice_tab, 1, SL_THREADS, (const unsigned long long*)ix->spl, g, g.cps, (const int32_t*)ix->seg,
+               (const int32_t*)ix->b_start, ix->n_contigs, ix->sl_cm, ix->sl_cell);
     HIP_TRY(hipGetLastError());
-    ix->sl_R = g.R; ix->sl_nb = g.nb;
+    ix->sl_R = g.R; ix->sl_nb = g.nb; ix->sl_ncells = g.ncells;
     return IVJ_OK;
 }
 
@@ -59,8 +70,9 @@ int slice_plan(const ivj_index* ix, int64_t n, const ivj_opts* opts, const Slice
     P.tiles_per_chunk = (int)(jchunk / jtile);
     P.ntiles = (int64_t)P.gmax * P.tiles_per_chunk;
     P.lds_seg = ix->n_contigs <= SL_LDS_CONTIGS ? 1 : 0;
-    P.part_lds = (size_t)slice_part_lds(g.nb).total;
-    const size_t fixed = (size_t)16 * g.R + (P.lds_seg ? (size_t)4 * ((ix->n_contigs + 2 + 1) & ~1) : 0) + 8 * (SL_WAVES + 1) + 64;
+    P.part_lds = (size_t)slice_part_lds(g.nb, g.ncells).total;
+    P.use_bins = (ix->ctx && ix->ctx->sl_env_nobins) ? 0 : 1;
+    const size_t fixed = (size_t)16 * g.R + (P.use_bins ? (size_t)2 * (2 * g.R + 8) : 0) + (P.lds_seg ? (size_t)4 * ((ix->n_contigs + 2 + 1) & ~1) : 0) + 8 * (SL_WAVES + 1) + 64;
     const size_t lds_cap = 160 * 1024;
     if (fixed + 8 * 1024 > lds_cap || P.part_lds > lds_cap) return fail(IVJ_EINVAL, "slice geometry does not fit the LDS");
     size_t stage = (lds_cap - fixed) / 8 / SL_THREADS * SL_THREADS;
@@ -110,14 +122,15 @@ int slice_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const iv
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
     IVJ_TRY(ensure_splitters(ctx, ix, P.g));
     const bool vec = aligned16(probe->contig) && aligned16(probe->end);
-    const size_t hist_lds = (size_t)8 * P.g.nb + 4 * (P.g.nb + 1);
+    const size_t hist_lds = (size_t)16 * SL_TAB_CONTIGS + (size_t)8 * P.g.nb + (size_t)4 * P.g.ncells + 4 * (P.g.nb + 1);
+    const SliceTab tab{ix->sl_cm, ix->sl_cell};
     const size_t hist = (size_t)(P.g.nb + 1) * (size_t)P.nchunks;
     t_begin(ctx, "slice_hist");
     if (strict) {
-        hipLaunchKernelGGL((k_slice_hist<true>), dim3(P.nchunks), dim3(SL_THREADS), hist_lds, ctx->stream, (const unsigned long long*)ix->spl, P.g,
+        hipLaunchKernelGGL((k_slice_hist<true>), dim3(P.nchunks), dim3(SL_THREADS), hist_lds, ctx->stream, (const unsigned long long*)ix->spl, tab, P.g,
                            ix->n_contigs, probe->contig, probe->end, n, P.chunk, P.nchunks, vec, ctx->sl_blk);
     } else {
-        hipLaunchKernelGGL((k_slice_hist<false>), dim3(P.nchunks), dim3(SL_THREADS), hist_lds, ctx->stream, (const unsigned long long*)ix->spl, P.g,
+        hipLaunchKernelGGL((k_slice_hist<false>), dim3(P.nchunks), dim3(SL_THREADS), hist_lds, ctx->stream, (const unsigned long long*)ix->spl, tab, P.g,
                            ix->n_contigs, probe->contig, probe->end, n, P.chunk, P.nchunks, vec, ctx->sl_blk);
     }
     t_end(ctx);
@@ -127,11 +140,11 @@ int slice_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const iv
     if (strict) IVJ_TRY(set_dyn_lds(&k_slice_scatter<true>, P.part_lds)); else IVJ_TRY(set_dyn_lds(&k_slice_scatter<false>, P.part_lds));
     t_begin(ctx, "slice_scatter");
     if (strict) {
-        hipLaunchKernelGGL((k_slice_scatter<true>), dim3(P.nchunks), dim3(SL_THREADS), P.part_lds, ctx->stream, (const unsigned long long*)ix->spl, P.g,
+        hipLaunchKernelGGL((k_slice_scatter<true>), dim3(P.nchunks), dim3(SL_THREADS), P.part_lds, ctx->stream, (const unsigned long long*)ix->spl, tab, P.g,
                            ix->n_contigs, probe->contig, probe->start, probe->end, probe->row_id, n, P.chunk, P.nchunks,
                            (const uint32_t*)ctx->sl_blk, ctx->sl_rec);
     } else {
-        hipLaunchKernelGGL((k_slice_scatter<false>), dim3(P.nchunks), dim3(SL_THREADS), P.part_lds, ctx->stream, (const unsigned long long*)ix->spl, P.g,
+        hipLaunchKernelGGL((k_slice_scatter<false>), dim3(P.nchunks), dim3(SL_THREADS), P.part_lds, ctx->stream, (const unsigned long long*)ix->spl, tab, P.g,
                            ix->n_contigs, probe->contig, probe->start, probe->end, probe->row_id, n, P.chunk, P.nchunks,
                            (const uint32_t*)ctx->sl_blk, ctx->sl_rec);
     }
@@ -143,7 +156,8 @@ int slice_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const iv
 template <int MODE, int ITEMS>
 int slice_join_launch_n(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const SlicePlan& P, long long capacity, int32_t* out_p, int32_t* out_b) {
     SliceJoinArgs A;
-    A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.seg = ix->seg; A.n_contigs = ix->n_contigs;
+    A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.b_contig = ix->b_contig; A.seg = ix->seg; A.n_contigs = ix->n_contigs;
+    A.use_bins = P.use_bins;
     A.rec = ctx->sl_rec; A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
     A.jchunk = P.jchunk; A.stage = P.stage; A.lds_seg = P.lds_seg; A.capacity = capacity;
     A.tile_tot = ctx->sl_tile; A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);

@@ -30,6 +30,8 @@ constexpr int SL_TILE = SL_THREADS * SL_ITEMS;       // probes per tile of the p
 constexpr int SL_MAX_BUCKETS = 1536;                  // slices (+ 1 bucket for probes without any candidate row)
 constexpr int SL_MAX_ROWS = 5120;                     // rows per slice (16 bytes of LDS each)
 constexpr int SL_LDS_CONTIGS = 1022;                  // segment offsets are staged in LDS up to this many contigs
+constexpr int SL_TAB_CONTIGS = 64;                    // the direct-address bucket table serves dictionaries up to this size
+constexpr int SL_WIN = 12;                            // rows below hi examined by the branch-free window code
 
 struct SliceGeom {
     int nb;            // number of slices = buckets 0 .. nb-1; bucket nb = probes that cannot match
@@ -37,6 +39,17 @@ struct SliceGeom {
     int nbits;         // bits of a bucket id (match-any ranking)
     int p2;            // largest power of two <= nb   (fixed-trip-count bucket search)
     int p2r;           // largest power of two <= R    (fixed-trip-count hi-bound search)
+    int ncells;        // cells of the direct-address bucket table (0: none, plain bound search over the splitters)
+    int cps;           // cells per splitter the table was sized with
+};
+
+// Direct-address table over the splitters: per contig a uniform grid over the starts of its rows, about four cells
+// per splitter; a cell holds the range [lo, hi] of "number of splitters below" values its keys can have, so the
+// bucket of a probe is one 16-byte contig record + one 4-byte cell read + (expected) one splitter compare instead
+// of an 11-step bound search of dependent LDS reads.
+struct SliceTab {
+    const int4* cm;          // per contig {ulo, uhi, shift, first cell}
+    const uint32_t* cell;    // per cell lo | hi << 16
 };
 
 // ---- workgroup scan over SL_THREADS threads ---------------------------------------------------------------------
@@ -80,6 +93,78 @@ __device__ __forceinline__ uint32_t slice_bucket(const unsigned long long* __res
     return ((uint32_t)c >= (uint32_t)n_contigs || pos == 0) ? (uint32_t)g.nb : (uint32_t)(pos - 1);
 }
 
+template <bool STRICT>
+__device__ __forceinline__ uint32_t slice_bucket_tab(const unsigned long long* __restrict__ l_spl, const int4* __restrict__ l_cm,
+                                                     const uint32_t* __restrict__ l_cell, const SliceGeom& g, int32_t n_contigs, int32_t c,
+                                                     int32_t qe) {
+    if ((uint32_t)c >= (uint32_t)n_contigs) return (uint32_t)g.nb;
+    const unsigned long long tu = (unsigned long long)flip(qe) + (STRICT ? 0ull : 1ull);
+    const unsigned long long key = ((unsigned long long)(uint32_t)c << 32) + tu;        // (c, INT32_MAX) + 1 carries into the contig
+    const int4 m = l_cm[c];
+    const uint32_t ulo = (uint32_t)m.x, uhi = (uint32_t)m.y;
+    uint32_t k;
+    if (tu <= ulo) k = 0;
+    else if (tu > uhi) k = (uhi - ulo) >> m.z;
+    else k = ((uint32_t)tu - ulo) >> m.z;
+    const uint32_t lh = l_cell[m.w + k];
+    int pos = (int)(lh & 0xffffu);
+    const int hi = (int)(lh >> 16);
+    while (pos < hi && l_spl[pos] < key) ++pos;
+    return pos == 0 ? (uint32_t)g.nb : (uint32_t)(pos - 1);
+}
+
+// One workgroup: per-contig grid metadata and the cells.  nspl_c = splitters inside contig c = ceil(seg[c+1] / R) -
+// ceil(seg[c] / R); cells_c = max(1, cps * nspl_c).
+__global__ __launch_bounds__(SL_THREADS) void k_slice_tab(const unsigned long long* __restrict__ spl, SliceGeom g, int cps,
+                                                         const int32_t* __restrict__ seg, const int32_t* __restrict__ b_start,
+                                                         int32_t n_contigs, int4* __restrict__ cm, uint32_t* __restrict__ cell) {
+    __shared__ int4 l_cm[SL_TAB_CONTIGS];
+    __shared__ int l_j[2 * SL_TAB_CONTIGS];
+    __shared__ int l_total;
+    if (threadIdx.x == 0) {
+        int tb = 0;
+        for (int c = 0; c < n_contigs; ++c) {
+            const int a = seg[c], b = seg[c + 1];
+            const int jlo = (a + g.R - 1) / g.R, jhi = (b + g.R - 1) / g.R;
+            int nc = cps * (jhi - jlo);
+            if (nc < 1) nc = 1;
+            uint32_t ulo = 0, uhi = 0;
+            int shift = 0;
+            if (b > a) {
+                ulo = flip(b_start[a]); uhi = flip(b_start[b - 1]);
+                while ((unsigned long long)((uhi - ulo) >> shift) + 1ull > (unsigned long long)nc) ++shift;
+            }
+            l_cm[c] = make_int4((int)ulo, (int)uhi, shift, tb);
+            l_j[2 * c] = jlo; l_j[2 * c + 1] = jhi;
+            tb += nc;
+        }
+        l_total = tb;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_contigs; c += SL_THREADS) cm[c] = l_cm[c];
+    const int total = l_total;
+    for (int i = threadIdx.x; i < total; i += SL_THREADS) {
+        int lo = 0, hi = n_contigs;                                   // last contig whose first cell is <= i
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (l_cm[m].w <= i) lo = m + 1; else hi = m; }
+        const int c = lo - 1;
+        const int4 m = l_cm[c];
+        const int k = i - m.w;
+        const int jlo = l_j[2 * c], jhi = l_j[2 * c + 1];
+        const int last = (c + 1 < n_contigs ? l_cm[c + 1].w : total) - 1;
+        auto below = [&](int kk) {                                   // splitters of contig c below the lower edge of cell kk
+            if (kk <= 0) return jlo;
+            const unsigned long long edge = ((unsigned long long)(uint32_t)c << 32) + (unsigned long long)(uint32_t)m.x +
+                                            ((unsigned long long)kk << m.z);
+            int a = jlo, b = jhi;
+            while (a < b) { const int mid = (a + b) >> 1; if (spl[mid] < edge) a = mid + 1; else b = mid; }
+            return a;
+        };
+        const int l = below(k);
+        const int h = i == last ? jhi : below(k + 1);
+        cell[i] = (uint32_t)l | ((uint32_t)h << 16);
+    }
+}
+
 // lanes of this wavefront that are valid and hold the same bucket id (nbits <= 11)
 __device__ __forceinline__ uint64_t wave_match_n(uint32_t d, bool valid, int nbits) {
     uint64_t peers = __ballot(valid);
@@ -94,13 +179,18 @@ __device__ __forceinline__ uint64_t wave_match_n(uint32_t d, bool valid, int nbi
 // ---- partition, pass 1: per-chunk bucket histogram -----------------------------------------------------------------
 // Workgroup g owns the probes [g * chunk, (g + 1) * chunk); blk_hist is bucket-major: blk_hist[b * nchunks + g].
 template <bool STRICT>
-__global__ __launch_bounds__(SL_THREADS) void k_slice_hist(const unsigned long long* __restrict__ spl, SliceGeom g, int32_t n_contigs,
+__global__ __launch_bounds__(SL_THREADS) void k_slice_hist(const unsigned long long* __restrict__ spl, SliceTab tab, SliceGeom g, int32_t n_contigs,
                                                           const int32_t* __restrict__ pc, const int32_t* __restrict__ pe, int64_t n,
                                                           int chunk, int nchunks, bool vec_ok, uint32_t* __restrict__ blk_hist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sl_lds[];
-    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(sl_lds);
-    uint32_t* h = reinterpret_cast<uint32_t*>(l_spl + g.nb);
+    // dynamic LDS: cm[SL_TAB_CONTIGS] | spl[nb] | cells[ncells] | hist[nb + 1]
+    int4* l_cm = reinterpret_cast<int4*>(sl_lds);
+    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(l_cm + SL_TAB_CONTIGS);
+    uint32_t* l_cell = reinterpret_cast<uint32_t*>(l_spl + g.nb);
+    uint32_t* h = l_cell + g.ncells;
     for (int k = threadIdx.x; k < g.nb; k += SL_THREADS) l_spl[k] = spl[k];
+    for (int k = threadIdx.x; k < g.ncells; k += SL_THREADS) l_cell[k] = tab.cell[k];
+    if (g.ncells) for (int k = threadIdx.x; k < n_contigs; k += SL_THREADS) l_cm[k] = tab.cm[k];
     for (int k = threadIdx.x; k <= g.nb; k += SL_THREADS) h[k] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * chunk;
@@ -111,7 +201,9 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_hist(const unsigned long l
         load_items_nt(pe, i0, end, vec_ok, 0, e);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (i0 + k < end) atomicAdd(&h[slice_bucket<STRICT>(l_spl, g, n_contigs, c[k], e[k])], 1u);
+            if (i0 + k < end)
+                atomicAdd(&h[g.ncells ? slice_bucket_tab<STRICT>(l_spl, l_cm, l_cell, g, n_contigs, c[k], e[k])
+                                      : slice_bucket<STRICT>(l_spl, g, n_contigs, c[k], e[k])], 1u);
     }
     __syncthreads();
     for (int k = threadIdx.x; k <= g.nb; k += SL_THREADS) blk_hist[(int64_t)k * nchunks + blockIdx.x] = h[k];
@@ -165,13 +257,15 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_chunks(const uint32_t* __r
 // running global offset of every bucket lives in LDS across the tiles of the chunk.
 struct SlicePartLds {
     // byte offsets into the dynamic LDS block
-    int spl, base, lstart, tot, wcnt, rec, d, wsum, total;
+    int cm, cell, spl, base, lstart, tot, wcnt, rec, d, wsum, total;
 };
-__host__ __device__ inline SlicePartLds slice_part_lds(int nb) {
+__host__ __device__ inline SlicePartLds slice_part_lds(int nb, int ncells) {
     SlicePartLds L;
     const int nbp = (nb + 2 + 1) & ~1;                          // counters per wavefront row, even
     int o = 0;
+    L.cm = o; o += ncells ? 16 * SL_TAB_CONTIGS : 0;
     L.spl = o; o += 8 * nb;
+    L.cell = o; o += 4 * ncells;
     L.rec = (o + 15) & ~15; o = L.rec + 16 * SL_TILE;
     L.base = o; o += 4 * (nb + 2);
     L.lstart = o; o += 4 * (nb + 2);
@@ -184,14 +278,16 @@ __host__ __device__ inline SlicePartLds slice_part_lds(int nb) {
 }
 
 template <bool STRICT>
-__global__ __launch_bounds__(SL_THREADS) void k_slice_scatter(const unsigned long long* __restrict__ spl, SliceGeom g, int32_t n_contigs,
+__global__ __launch_bounds__(SL_THREADS) void k_slice_scatter(const unsigned long long* __restrict__ spl, SliceTab tab, SliceGeom g, int32_t n_contigs,
                                                              const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
                                                              const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
                                                              int chunk, int nchunks, const uint32_t* __restrict__ blk_off,
                                                              int4* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sl_lds[];
-    const SlicePartLds L = slice_part_lds(g.nb);
+    const SlicePartLds L = slice_part_lds(g.nb, g.ncells);
     unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(sl_lds + L.spl);
+    int4* l_cm = reinterpret_cast<int4*>(sl_lds + L.cm);
+    uint32_t* l_cell = reinterpret_cast<uint32_t*>(sl_lds + L.cell);
     int4* l_rec = reinterpret_cast<int4*>(sl_lds + L.rec);
     uint32_t* base = reinterpret_cast<uint32_t*>(sl_lds + L.base);
     uint32_t* lstart = reinterpret_cast<uint32_t*>(sl_lds + L.lstart);
@@ -204,6 +300,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_scatter(const unsigned lon
     const int nbk = g.nb + 1;                                   // buckets incl. the "no candidate" one
 
     for (int k = tid; k < g.nb; k += SL_THREADS) l_spl[k] = spl[k];
+    for (int k = tid; k < g.ncells; k += SL_THREADS) l_cell[k] = tab.cell[k];
+    if (g.ncells) for (int k = tid; k < n_contigs; k += SL_THREADS) l_cm[k] = tab.cm[k];
     for (int k = tid; k < nbk; k += SL_THREADS) { base[k] = blk_off[(int64_t)k * nchunks + blockIdx.x]; tot[k] = 0; }
     for (int k = tid; k < nbp * SL_WAVES / 2; k += SL_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
     __syncthreads();
@@ -239,7 +337,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_scatter(const unsigned lon
 #pragma unroll
         for (int j = 0; j < SL_ITEMS; ++j) {
             const bool valid = el0 + j * kWave < tile_n;
-            d[j] = valid ? slice_bucket<STRICT>(l_spl, g, n_contigs, c[j], e[j]) : 0u;
+            d[j] = !valid ? 0u : (g.ncells ? slice_bucket_tab<STRICT>(l_spl, l_cm, l_cell, g, n_contigs, c[j], e[j])
+                                           : slice_bucket<STRICT>(l_spl, g, n_contigs, c[j], e[j]));
         }
 #pragma unroll
         for (int j = 0; j < SL_ITEMS; ++j) {
@@ -322,15 +421,17 @@ struct SliceJoinArgs {
     const int32_t* b_start;
     const int2* ep;
     const int32_t* b_row;
+    const int32_t* b_contig;
     const int32_t* seg;
     int32_t n_contigs;
     const int4* rec;                  // bucket-ordered probe records {start, end, row, contig}
     const uint32_t* bstart;           // nb + 2 bucket starts
     const int32_t* meta;              // [0] = number of join workgroups
     const int2* wg_map;               // workgroup -> (bucket, chunk inside the bucket)
-    int jchunk;                       // probes per join workgroup (multiple of SL_TILE)
+    int jchunk;                       // probes per join workgroup (multiple of the tile)
     int stage;                        // pairs of LDS staging (multiple of SL_THREADS)
     int lds_seg;                      // 1: segment offsets staged in LDS
+    int use_bins;                     // 1: direct-address table over the slice's starts (single-contig slices)
     long long capacity;
     long long* tile_tot;              // COUNT: out; FILL: scanned tile bases
     unsigned long long* state;        // FUSED: [0] cursor, [1] overflow flag
@@ -338,15 +439,36 @@ struct SliceJoinArgs {
     int32_t* out_build;
 };
 
+// suffix minimum over the SL_THREADS threads of the workgroup, exclusive (min over the threads AFTER this one)
+__device__ __forceinline__ uint32_t sl_block_suffix_min_excl(uint32_t v, uint32_t* wmin /* SL_WAVES */) {
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t o = __shfl_down(x, d, kWave);
+        if (lane + d < kWave) x = x < o ? x : o;
+    }
+    if (lane == 0) wmin[w] = x;                      // inclusive suffix min of the wavefront
+    uint32_t nxt = __shfl_down(x, 1, kWave);
+    if (lane == kWave - 1) nxt = 0xffffffffu;
+    __syncthreads();
+    uint32_t later = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < SL_WAVES; ++k) { const uint32_t y = wmin[k]; if (k > w) later = later < y ? later : y; }
+    __syncthreads();
+    return nxt < later ? nxt : later;
+}
+
 template <bool STRICT, int MODE, int ITEMS>
 __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t nbuild, SliceJoinArgs A) {
     constexpr int TILE = SL_THREADS * ITEMS;
     extern __shared__ __attribute__((aligned(16))) unsigned char sl_lds[];
-    // dynamic LDS: start[R] | ep[R] | row[R] | staging | seg | scan scratch
+    // dynamic LDS: start[R] | ep[R] | row[R] | bins[2R + 2 (u16)] | staging | seg | scan scratch
     int32_t* l_start = reinterpret_cast<int32_t*>(sl_lds);
     int2* l_ep = reinterpret_cast<int2*>(l_start + g.R);
     int32_t* l_row = reinterpret_cast<int32_t*>(l_ep + g.R);
-    int2* st = reinterpret_cast<int2*>(l_row + g.R);
+    unsigned short* l_bin = reinterpret_cast<unsigned short*>(l_row + g.R);
+    int2* st = reinterpret_cast<int2*>(l_bin + (A.use_bins ? 2 * g.R + 8 : 0));
     int32_t* l_seg = reinterpret_cast<int32_t*>(st + (MODE == SL_COUNT ? 0 : A.stage));
     long long* wsum = reinterpret_cast<long long*>(l_seg + (A.lds_seg ? ((A.n_contigs + 2 + 1) & ~1) : 0));
     long long* s_base = wsum + SL_WAVES;
@@ -379,7 +501,33 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
         }
     }
     if (A.lds_seg) for (int i = tid; i < A.n_contigs + 2; i += SL_THREADS) l_seg[i] = A.seg[i];
+    // direct-address table over the starts of the slice (all of one contig): two cells per row, cell -> first row at
+    // or above its lower edge; the hi-bound of a probe is then one 2-byte read + (expected) one compare
+    const bool bins = A.use_bins != 0 && rk >= 2 && A.b_contig[r0] == A.b_contig[r0 + rk - 1];      // uniform
+    uint32_t s0 = 0, s1 = 0;
+    int bshift = 0;
+    const int ncell = 2 * rk;
     __syncthreads();
+    if (bins) {
+        s0 = flip(l_start[0]); s1 = flip(l_start[rk - 1]);
+        while ((unsigned long long)((s1 - s0) >> bshift) + 1ull > (unsigned long long)ncell) ++bshift;
+        for (int i = tid; i <= ncell; i += SL_THREADS) l_bin[i] = i == ncell ? (unsigned short)rk : (unsigned short)0xffff;
+        __syncthreads();
+        for (int i = tid; i < rk; i += SL_THREADS) {
+            const uint32_t c1 = (flip(l_start[i]) - s0) >> bshift;
+            const bool head = i == 0 || ((flip(l_start[i - 1]) - s0) >> bshift) != c1;
+            if (head) l_bin[c1] = (unsigned short)i;
+        }
+        __syncthreads();
+        // empty cells take the next head: suffix minimum (heads ascend with the cell index)
+        const int per_t = (ncell + 1 + SL_THREADS - 1) / SL_THREADS;
+        const int c_lo = tid * per_t, c_hi = (c_lo + per_t) < (ncell + 1) ? (c_lo + per_t) : (ncell + 1);
+        uint32_t mn = 0xffffffffu;
+        for (int c = c_lo; c < c_hi; ++c) { const uint32_t x = l_bin[c]; mn = x < mn ? x : mn; }
+        uint32_t run = sl_block_suffix_min_excl(mn, reinterpret_cast<uint32_t*>(wsum));
+        for (int c = c_hi - 1; c >= c_lo; --c) { const uint32_t x = l_bin[c]; run = x < run ? x : run; l_bin[c] = (unsigned short)run; }
+        __syncthreads();
+    }
 
     int4 nxt[ITEMS];
     auto load_tile = [&](int64_t tb) {
@@ -416,51 +564,80 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             lo_s[j] = la; lb[j] = lbb < la ? la : lbb;
         }
         if (tb + TILE < q1) load_tile(tb + TILE);                        // next tile's records in flight
-        // hi-bound: number of rows of [la, lb) whose start fails to reach q.end, fixed trip count, four probes interleaved
-        for (int step = g.p2r; step > 0; step >>= 1) {
+        if (bins) {
+            // hi-bound through the table: first row whose start reaches q.end, clamped to the contig's rows [la, lb)
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
-                const int t = lo_s[j] + step;
-                if (t <= lb[j]) {
-                    const int32_t sv = l_start[t - 1];
-                    if (STRICT ? (sv < qe[j]) : (sv <= qe[j])) lo_s[j] = t;
+                const unsigned long long tu = (unsigned long long)flip(qe[j]) + (STRICT ? 0ull : 1ull);
+                int r;
+                if (tu <= s0) r = 0;
+                else if (tu > s1) r = rk;
+                else {
+                    const uint32_t cl = ((uint32_t)tu - s0) >> bshift;
+                    r = l_bin[cl];
+                    const int rend = l_bin[cl + 1];
+                    while (r < rend && (unsigned long long)flip(l_start[r]) < tu) ++r;
+                }
+                r = r < lo_s[j] ? lo_s[j] : r;
+                lo_s[j] = r > lb[j] ? lb[j] : r;
+            }
+        } else {
+            // hi-bound: number of rows of [la, lb) whose start fails to reach q.end, fixed trip count, probes interleaved
+            for (int step = g.p2r; step > 0; step >>= 1) {
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const int t = lo_s[j] + step;
+                    if (t <= lb[j]) {
+                        const int32_t sv = l_start[t - 1];
+                        if (STRICT ? (sv < qe[j]) : (sv <= qe[j])) lo_s[j] = t;
+                    }
                 }
             }
         }
-        // window below hi: 32-row match mask, all four probes of the thread in lockstep (trip count = the longest
-        // window of the wavefront, not the sum over the four); rows below the slice come from the global arrays
+        // window below hi, branch-free: the SL_WIN rows below hi are read unconditionally (clamped) and folded into a
+        // match mask; bit t <=> row hi-1-t.  The window closes at the first row whose prefix max fails q.start (<) pmax,
+        // or at the start of the contig's segment.  Windows that are still open after SL_WIN rows, or that reach below
+        // the slice, are redone by the exact per-lane loop (rare: a few percent of the wavefronts).
         uint32_t mask[ITEMS];
         int cnt[ITEMS];
-        int p[ITEMS];
-        bool act[ITEMS], lng[ITEMS];
-        bool any = false;
+        bool lng[ITEMS];
+        bool need = false;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             hi[j] = r0 + lo_s[j];
-            mask[j] = 0; cnt[j] = 0; lng[j] = false;
-            p[j] = hi[j] - 1;
-            act[j] = valid[j] && p[j] >= seg_a[j];
-            any |= act[j];
+            // per row two flag bits, no running state: passb bit t <=> q.start (<) pmax of row hi-1-t, matchb bit t <=> q.start (<) its end
+            uint32_t passb = 0, matchb = 0;
+#pragma unroll
+            for (int t = 0; t < SL_WIN; ++t) {
+                const int li = hi[j] - 1 - t - r0;
+                const int2 vv = l_ep[li < 0 ? 0 : li];
+                passb |= (lt_op<STRICT>(qs[j], vv.y) ? 1u : 0u) << t;
+                matchb |= (lt_op<STRICT>(qs[j], vv.x) ? 1u : 0u) << t;
+            }
+            // rows below the slice or below the contig's segment are not part of the (in-LDS) window
+            const int lowlim = seg_a[j] > r0 ? seg_a[j] : r0;
+            const int nrows = hi[j] - lowlim;                                  // rows of the window that exist in LDS
+            if (nrows < SL_WIN) passb &= nrows <= 0 ? 0u : ((1u << nrows) - 1u);
+            const uint32_t open = passb & ~(passb + 1u);                       // the run of set bits from bit 0: the open window
+            const int tl = __popc(open);
+            const int pstar = hi[j] - 1 - tl;                                  // first row that is not part of the window
+            // still open after SL_WIN rows, or cut off by the lower edge of the slice: redo exactly (rare)
+            lng[j] = valid[j] && pstar >= seg_a[j] && (tl == SL_WIN || pstar < r0);
+            mask[j] = valid[j] ? (matchb & open) : 0u;
+            need |= lng[j];
+            cnt[j] = __popc(mask[j]);
         }
-        while (__any(any)) {
-            any = false;
+        if (__any(need)) {
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
-                if (act[j]) {
-                    const int2 vv = slice_ep(l_ep, A.ep, p[j], r0);
-                    if (!lt_op<STRICT>(qs[j], vv.y)) act[j] = false;
-                    else {
-                        const int jj = hi[j] - 1 - p[j];
-                        const bool m = lt_op<STRICT>(qs[j], vv.x);
-                        // the mask serves windows of <= 32 rows that lie inside the slice; anything else is rescanned at
-                        // emission (that keeps global loads out of the mask loop, which also trips hipcc 7.2 otherwise)
-                        if (jj < 32 && p[j] >= r0) { if (m) mask[j] |= 1u << jj; }
-                        else lng[j] = true;
-                        cnt[j] += m ? 1 : 0;
-                        --p[j];
-                        if (p[j] < seg_a[j]) act[j] = false;
+                if (lng[j]) {
+                    int c2 = 0;
+                    for (int p = hi[j] - 1; p >= seg_a[j]; --p) {
+                        const int2 vv = slice_ep(l_ep, A.ep, p, r0);
+                        if (!lt_op<STRICT>(qs[j], vv.y)) break;
+                        c2 += lt_op<STRICT>(qs[j], vv.x) ? 1 : 0;
                     }
-                    any |= act[j];
+                    cnt[j] = c2;
                 }
             }
         }
@@ -474,23 +651,15 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             if (tid == 0) A.tile_tot[tile_id] = tot;
             continue;
         }
-        long long tbase;
-        if (MODE == SL_FILL) tbase = A.tile_tot[tile_id];
-        else {
-            if (tid == 0) {
-                const long long bse = tot ? (long long)atomicAdd(&A.state[0], (unsigned long long)tot) : 0ll;
-                if (bse + tot > A.capacity) { atomicExch(&A.state[1], 1ull); *s_base = -1; }
-                else *s_base = bse;
-            }
-            __syncthreads();
-            tbase = *s_base;
-            __syncthreads();
-            if (tbase < 0) continue;                                           // uniform: over capacity, keep counting
-        }
         if (tot == 0) continue;                                                // uniform
+        // FUSED: the tile reserves its output range with ONE atomic; its round trip overlaps the staging of the pairs
+        long long tbase = MODE == SL_FILL ? A.tile_tot[tile_id] : 0;
+        long long reserved = 0;
+        if (MODE == SL_FUSED && tid == 0) reserved = (long long)atomicAdd(&A.state[0], (unsigned long long)tot);
+        bool have_base = MODE == SL_FILL;
         // emission: pairs staged in LDS at their tile-local offset (windows of A.stage pairs, usually one), then
-        // copied out with fully coalesced non-temporal stores.  Mask probes: bit j <=> row hi-1-j, ascending
-        // (start, row) order = descending j.  Long windows (> 32 rows) are rescanned by their lane.
+        // copied out with fully coalesced non-temporal stores.  Mask probes: bit t <=> row hi-1-t, ascending
+        // (start, row) order = descending t.  Long windows are rescanned by their lane.
         for (long long w0 = 0; w0 < tot; w0 += A.stage) {
             const long long w1 = w0 + A.stage;
             long long off = loc0;
@@ -504,9 +673,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                         while (m) {
                             const int jj = 31 - __clz(m);
                             m &= ~(1u << jj);
-                            if (o >= w0 && o < w1) {
-                                st[o - w0] = make_int2(qrow[j], l_row[hi[j] - 1 - jj - r0]);
-                            }
+                            if (o >= w0 && o < w1) st[o - w0] = make_int2(qrow[j], l_row[hi[j] - 1 - jj - r0]);
                             ++o;
                         }
                     } else {
@@ -523,7 +690,16 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                 }
                 off = end;
             }
-            __syncthreads();
+            if (!have_base) {                                                  // FUSED, first window: now the range is needed
+                if (tid == 0) {
+                    if (reserved + tot > A.capacity) { atomicExch(&A.state[1], 1ull); *s_base = -1; }
+                    else *s_base = reserved;
+                }
+                have_base = true;
+                __syncthreads();
+                tbase = *s_base;
+                if (tbase < 0) { __syncthreads(); break; }                     // uniform: over capacity, nothing is written
+            } else __syncthreads();
             const int t = (int)((tot - w0) < (long long)A.stage ? (tot - w0) : (long long)A.stage);
             for (int i = tid; i < t; i += SL_THREADS) {
                 const int2 pr = st[i];
