@@ -29,6 +29,28 @@ for stage in "$@"; do
     prof) echo "== rocprofv3 --kernel-trace --stats (config 3)";
       (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OLDPWD/${o}_dir" -o c3 --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras > "$OLDPWD/$o.out" 2> "$OLDPWD/$o.err");
       tail -2 $o.out | cut -c1-400; f=$(find ${o}_dir -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { cp "$f" $o.kernel_stats.csv; head -25 "$f"; } ;;
+    pmcsq*) echo "== PMC SQ/TCP/LDS breakdown (config 3${stage#pmcsq}; extra bench args in \$PMCARGS)";
+      i=0; dirs="";
+      for set in "SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE"; do
+        i=$((i+1));
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set -d "$OLDPWD/${o}_$i" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extras $PMCARGS > "$OLDPWD/${o}_$i.out" 2> "$OLDPWD/${o}_$i.err");
+        tail -1 ${o}_$i.err | cut -c1-160; dirs="$dirs ${o}_$i";
+      done;
+      python tools/pmc_summary.py $dirs > $o.summary.json 2> $o.summary.err; tail -3 $o.summary.err;
+      python - "$o.summary.json" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for k, v in d.items():
+    if "slice" not in k and "overlap" not in k and "part_" not in k:
+        continue
+    g = lambda n: v.get(n, {}).get("sum", 0.0) / max(v.get(n, {}).get("rows", 1), 1)
+    wc = g("SQ_WAVE_CYCLES") or 1
+    print(k[:60])
+    print("   waves %.0f  VALU insts %.1fM SALU %.1fM LDS %.1fM VMEM_RD %.2fM VMEM_WR %.2fM BRANCH %.1fM" % (g("SQ_WAVES"), g("SQ_INSTS_VALU")/1e6, g("SQ_INSTS_SALU")/1e6, g("SQ_INSTS_LDS")/1e6, g("SQ_INSTS_VMEM_RD")/1e6, g("SQ_INSTS_VMEM_WR")/1e6, g("SQ_INSTS_BRANCH")/1e6))
+    print("   wave_cycles %.0fM busy_cycles %.1fM  wait_any/wave %.2f wait_inst_any/wave %.2f active_valu/wave %.3f active_lds/wave %.3f active_vmem/wave %.3f lanes/valu %.1f" % (wc/1e6, g("SQ_BUSY_CYCLES")/1e6, g("SQ_WAIT_ANY")/wc, g("SQ_WAIT_INST_ANY")/wc, g("SQ_ACTIVE_INST_VALU")/wc, g("SQ_ACTIVE_INST_LDS")/wc, g("SQ_ACTIVE_INST_VMEM")/wc, g("SQ_THREAD_CYCLES_VALU")/max(g("SQ_ACTIVE_INST_VALU"),1)*1.0))
+    print("   LDS idx_active %.1fM bank_conflict %.1fM wait_inst_lds/wave %.3f  TCP reads %.1fM accesses %.1fM GUI_ACTIVE %.2fM" % (g("SQ_LDS_IDX_ACTIVE")/1e6, g("SQ_LDS_BANK_CONFLICT")/1e6, g("SQ_WAIT_INST_LDS")/wc, g("TCP_TCC_READ_REQ_sum")/1e6, g("TCP_TOTAL_CACHE_ACCESSES_sum")/1e6, g("GRBM_GUI_ACTIVE")/1e6))
+PY
+      ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     *) echo "unknown stage $stage" ;;
   esac
