@@ -72,7 +72,7 @@ int slice_plan(const ivj_index* ix, int64_t n, const ivj_opts* opts, const Slice
     P.lds_seg = ix->n_contigs <= SL_LDS_CONTIGS ? 1 : 0;
     P.part_lds = (size_t)slice_part_lds(g.nb, g.ncells).total;
     P.use_bins = (ix->ctx && ix->ctx->sl_env_nobins) ? 0 : 1;
-    const size_t fixed = (size_t)16 * g.R + (P.use_bins ? (size_t)2 * (2 * g.R + 8) : 0) + (P.lds_seg ? (size_t)4 * ((ix->n_contigs + 2 + 1) & ~1) : 0) + 8 * (SL_WAVES + 1) + 64;
+    const size_t fixed = (size_t)16 * g.R + 4 * SL_PAD + (P.use_bins ? (size_t)2 * (2 * g.R + 8) : 0) + (P.lds_seg ? (size_t)4 * ((ix->n_contigs + 2 + 1) & ~1) : 0) + 8 * (SL_WAVES + 1) + 64;
     const size_t lds_cap = 160 * 1024;
     if (fixed + 8 * 1024 > lds_cap || P.part_lds > lds_cap) return fail(IVJ_EINVAL, "slice geometry does not fit the LDS");
     size_t stage = (lds_cap - fixed) / 8 / SL_THREADS * SL_THREADS;

@@ -403,9 +403,9 @@ enum { SL_COUNT = 0, SL_FILL = 1, SL_FUSED = 2 };
 // Row p of the sorted build side: from the slice in LDS, or -- a window reaching below the slice, rare -- from the
 // global array.  The LDS read is unconditional (clamped index) and the global read sits in its own branch: a
 // `cond ? lds[..] : global[..]` select of two address spaces trips hipcc 7.2 ("Operand has incorrect register class").
-__device__ __forceinline__ int2 slice_ep(const int2* l_ep, const int2* __restrict__ g_ep, int p, int r0) {
+__device__ __forceinline__ int2 slice_ep(const int32_t* l_end, const int32_t* l_pmax, const int2* __restrict__ g_ep, int p, int r0) {
     const int i = p - r0;
-    int2 v = l_ep[i < 0 ? 0 : i];
+    int2 v = make_int2(l_end[i < 0 ? 0 : i], l_pmax[i < 0 ? 0 : i]);
     if (i < 0) v = g_ep[p];
     return v;
 }
@@ -459,14 +459,18 @@ __device__ __forceinline__ uint32_t sl_block_suffix_min_excl(uint32_t v, uint32_
     return nxt < later ? nxt : later;
 }
 
+constexpr int SL_PAD = 16;       // ints in front of l_end: the branch-free window may read up to SL_WIN rows below the slice (ignored)
+
 template <bool STRICT, int MODE, int ITEMS>
 __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t nbuild, SliceJoinArgs A) {
     constexpr int TILE = SL_THREADS * ITEMS;
+    static_assert(SL_WIN < SL_PAD, "front padding must cover the window");
     extern __shared__ __attribute__((aligned(16))) unsigned char sl_lds[];
-    // dynamic LDS: start[R] | ep[R] | row[R] | bins[2R + 2 (u16)] | staging | seg | scan scratch
+    // dynamic LDS: start[R] | pad | end[R] | pmax[R] | row[R] | bins[2R + 8 (u16)] | staging | seg | scan scratch
     int32_t* l_start = reinterpret_cast<int32_t*>(sl_lds);
-    int2* l_ep = reinterpret_cast<int2*>(l_start + g.R);
-    int32_t* l_row = reinterpret_cast<int32_t*>(l_ep + g.R);
+    int32_t* l_end = l_start + g.R + SL_PAD;
+    int32_t* l_pmax = l_end + g.R;
+    int32_t* l_row = l_pmax + g.R;
     unsigned short* l_bin = reinterpret_cast<unsigned short*>(l_row + g.R);
     int2* st = reinterpret_cast<int2*>(l_bin + (A.use_bins ? 2 * g.R + 8 : 0));
     int32_t* l_seg = reinterpret_cast<int32_t*>(st + (MODE == SL_COUNT ? 0 : A.stage));
@@ -494,19 +498,36 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
         if (i + 4 <= rk) {
             *reinterpret_cast<int4*>(l_start + i) = *reinterpret_cast<const int4*>(A.b_start + r0 + i);
             *reinterpret_cast<int4*>(l_row + i) = *reinterpret_cast<const int4*>(A.b_row + r0 + i);
-            *reinterpret_cast<int4*>(l_ep + i) = *reinterpret_cast<const int4*>(A.ep + r0 + i);
-            *reinterpret_cast<int4*>(l_ep + i + 2) = *reinterpret_cast<const int4*>(A.ep + r0 + i + 2);
+            const int4 e01 = *reinterpret_cast<const int4*>(A.ep + r0 + i);
+            const int4 e23 = *reinterpret_cast<const int4*>(A.ep + r0 + i + 2);
+            *reinterpret_cast<int4*>(l_end + i) = make_int4(e01.x, e01.z, e23.x, e23.z);
+            *reinterpret_cast<int4*>(l_pmax + i) = make_int4(e01.y, e01.w, e23.y, e23.w);
         } else {
-            for (int j = i; j < rk; ++j) { l_start[j] = A.b_start[r0 + j]; l_row[j] = A.b_row[r0 + j]; l_ep[j] = A.ep[r0 + j]; }
+            for (int j = i; j < rk; ++j) {
+                l_start[j] = A.b_start[r0 + j]; l_row[j] = A.b_row[r0 + j];
+                const int2 e = A.ep[r0 + j];
+                l_end[j] = e.x; l_pmax[j] = e.y;
+            }
         }
     }
+    if (tid < SL_PAD) l_end[tid - SL_PAD] = 0;
     if (A.lds_seg) for (int i = tid; i < A.n_contigs + 2; i += SL_THREADS) l_seg[i] = A.seg[i];
     // direct-address table over the starts of the slice (all of one contig): two cells per row, cell -> first row at
     // or above its lower edge; the hi-bound of a probe is then one 2-byte read + (expected) one compare
-    const bool bins = A.use_bins != 0 && rk >= 2 && A.b_contig[r0] == A.b_contig[r0 + rk - 1];      // uniform
+    const int32_t cs = A.b_contig[r0];                                         // contig of the slice's first row
+    const bool bins = A.use_bins != 0 && rk >= 2 && cs == A.b_contig[r0 + rk - 1] && (uint32_t)cs < (uint32_t)A.n_contigs;      // uniform
     uint32_t s0 = 0, s1 = 0;
     int bshift = 0;
     const int ncell = 2 * rk;
+    // single-contig slice: the segment bounds are the same for every probe of the slice's contig (others cannot match here)
+    int u_a = 0, u_la = 0, u_lb = 0;
+    if (bins) {
+        u_a = A.seg[cs];
+        const int b = A.seg[cs + 1];
+        u_la = u_a - r0; u_la = u_la < 0 ? 0 : (u_la > rk ? rk : u_la);
+        u_lb = b - r0; u_lb = u_lb < 0 ? 0 : (u_lb > rk ? rk : u_lb);
+        if (u_lb < u_la) u_lb = u_la;
+    }
     __syncthreads();
     if (bins) {
         s0 = flip(l_start[0]); s1 = flip(l_start[rk - 1]);
@@ -551,17 +572,22 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
         for (int j = 0; j < ITEMS; ++j) {
             qs[j] = nxt[j].x; qe[j] = nxt[j].y; qrow[j] = nxt[j].z;
             const int32_t c = nxt[j].w;
-            valid[j] = (tb + j * SL_THREADS + tid < q1) && (uint32_t)c < (uint32_t)A.n_contigs;
-            int a = 0, b = 0;
-            if (valid[j]) {
-                if (A.lds_seg) { a = l_seg[c]; b = l_seg[c + 1]; }
-                else { a = A.seg[c]; b = A.seg[c + 1]; }
+            if (bins) {
+                valid[j] = (tb + j * SL_THREADS + tid < q1) && c == cs;
+                seg_a[j] = u_a; lo_s[j] = u_la; lb[j] = u_lb;
+            } else {
+                valid[j] = (tb + j * SL_THREADS + tid < q1) && (uint32_t)c < (uint32_t)A.n_contigs;
+                int a = 0, b = 0;
+                if (valid[j]) {
+                    if (A.lds_seg) { a = l_seg[c]; b = l_seg[c + 1]; }
+                    else { a = A.seg[c]; b = A.seg[c + 1]; }
+                }
+                seg_a[j] = a;
+                // the contig's rows inside the slice, slice-local: [la, lb)
+                int la = a - r0; la = la < 0 ? 0 : (la > rk ? rk : la);
+                int lbb = b - r0; lbb = lbb < 0 ? 0 : (lbb > rk ? rk : lbb);
+                lo_s[j] = la; lb[j] = lbb < la ? la : lbb;
             }
-            seg_a[j] = a;
-            // the contig's rows inside the slice, slice-local: [la, lb)
-            int la = a - r0; la = la < 0 ? 0 : (la > rk ? rk : la);
-            int lbb = b - r0; lbb = lbb < 0 ? 0 : (lbb > rk ? rk : lbb);
-            lo_s[j] = la; lb[j] = lbb < la ? la : lbb;
         }
         if (tb + TILE < q1) load_tile(tb + TILE);                        // next tile's records in flight
         if (bins) {
@@ -594,10 +620,12 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                 }
             }
         }
-        // window below hi, branch-free: the SL_WIN rows below hi are read unconditionally (clamped) and folded into a
-        // match mask; bit t <=> row hi-1-t.  The window closes at the first row whose prefix max fails q.start (<) pmax,
-        // or at the start of the contig's segment.  Windows that are still open after SL_WIN rows, or that reach below
-        // the slice, are redone by the exact per-lane loop (rare: a few percent of the wavefronts).
+        // window below hi, branch-free.  Every row below hi already satisfies start (<) q.end, so row p matches iff
+        // q.start (<) end[p] -- and then q.start (<) pmax[p] holds for it and for every row between it and hi (pmax is the
+        // prefix max of the ends): the prefix max is only needed to know whether rows BELOW the examined ones can still
+        // match.  The SL_WIN ends below hi are read unconditionally (front padding covers the slice's lower edge), bit t
+        // <=> row hi-1-t; one prefix-max read of the first row that was not examined decides whether the exact per-lane
+        // loop has to redo the probe (window longer than SL_WIN rows, or running on below the slice: rare).
         uint32_t mask[ITEMS];
         int cnt[ITEMS];
         bool lng[ITEMS];
@@ -605,25 +633,19 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             hi[j] = r0 + lo_s[j];
-            // per row two flag bits, no running state: passb bit t <=> q.start (<) pmax of row hi-1-t, matchb bit t <=> q.start (<) its end
-            uint32_t passb = 0, matchb = 0;
+            const int32_t* pe = l_end + (lo_s[j] - SL_WIN);                    // rows hi-SL_WIN .. hi-1 at pe[0 .. SL_WIN-1]
+            uint32_t m = 0;
 #pragma unroll
-            for (int t = 0; t < SL_WIN; ++t) {
-                const int li = hi[j] - 1 - t - r0;
-                const int2 vv = l_ep[li < 0 ? 0 : li];
-                passb |= (lt_op<STRICT>(qs[j], vv.y) ? 1u : 0u) << t;
-                matchb |= (lt_op<STRICT>(qs[j], vv.x) ? 1u : 0u) << t;
-            }
-            // rows below the slice or below the contig's segment are not part of the (in-LDS) window
+            for (int t = 0; t < SL_WIN; ++t) m |= (lt_op<STRICT>(qs[j], pe[SL_WIN - 1 - t]) ? 1u : 0u) << t;
             const int lowlim = seg_a[j] > r0 ? seg_a[j] : r0;
-            const int nrows = hi[j] - lowlim;                                  // rows of the window that exist in LDS
-            if (nrows < SL_WIN) passb &= nrows <= 0 ? 0u : ((1u << nrows) - 1u);
-            const uint32_t open = passb & ~(passb + 1u);                       // the run of set bits from bit 0: the open window
-            const int tl = __popc(open);
-            const int pstar = hi[j] - 1 - tl;                                  // first row that is not part of the window
-            // still open after SL_WIN rows, or cut off by the lower edge of the slice: redo exactly (rare)
-            lng[j] = valid[j] && pstar >= seg_a[j] && (tl == SL_WIN || pstar < r0);
-            mask[j] = valid[j] ? (matchb & open) : 0u;
+            int nrows = hi[j] - lowlim;                                        // rows of the window that exist in LDS
+            nrows = nrows < 0 ? 0 : (nrows > SL_WIN ? SL_WIN : nrows);
+            m &= (1u << nrows) - 1u;
+            const int below = hi[j] - 1 - nrows;                               // first row that was not examined
+            bool fb = false;
+            if (below >= seg_a[j]) fb = below < r0 ? true : lt_op<STRICT>(qs[j], l_pmax[below - r0]);
+            lng[j] = valid[j] && fb;
+            mask[j] = valid[j] ? m : 0u;
             need |= lng[j];
             cnt[j] = __popc(mask[j]);
         }
@@ -633,7 +655,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                 if (lng[j]) {
                     int c2 = 0;
                     for (int p = hi[j] - 1; p >= seg_a[j]; --p) {
-                        const int2 vv = slice_ep(l_ep, A.ep, p, r0);
+                        const int2 vv = slice_ep(l_end, l_pmax, A.ep, p, r0);
                         if (!lt_op<STRICT>(qs[j], vv.y)) break;
                         c2 += lt_op<STRICT>(qs[j], vv.x) ? 1 : 0;
                     }
@@ -657,9 +679,52 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
         long long reserved = 0;
         if (MODE == SL_FUSED && tid == 0) reserved = (long long)atomicAdd(&A.state[0], (unsigned long long)tot);
         bool have_base = MODE == SL_FILL;
-        // emission: pairs staged in LDS at their tile-local offset (windows of A.stage pairs, usually one), then
-        // copied out with fully coalesced non-temporal stores.  Mask probes: bit t <=> row hi-1-t, ascending
-        // (start, row) order = descending t.  Long windows are rescanned by their lane.
+        // emission: pairs staged in LDS at their tile-local offset, then copied out with fully coalesced non-temporal
+        // stores.  Mask probes: bit t <=> row hi-1-t, ascending (start, row) order = descending t.  Long windows are
+        // rescanned by their lane.  Usual case: the tile's pairs fit ONE staging window (32-bit offsets, no range checks).
+        if (tot <= (long long)A.stage) {
+            int off = (int)loc0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                if (cnt[j] != 0) {
+                    if (!lng[j]) {
+                        uint32_t m = mask[j];
+                        int o = off;
+                        const int32_t* pr = l_row + (lo_s[j] - 1);
+                        while (m) {
+                            const int jj = 31 - __clz(m);
+                            m &= ~(1u << jj);
+                            st[o++] = make_int2(qrow[j], pr[-jj]);
+                        }
+                    } else {
+                        int o = off + cnt[j] - 1;
+                        for (int pp = hi[j] - 1; o >= off; --pp) {
+                            const int2 vv = slice_ep(l_end, l_pmax, A.ep, pp, r0);
+                            if (lt_op<STRICT>(qs[j], vv.x)) { st[o] = make_int2(qrow[j], slice_row(l_row, A.b_row, pp, r0)); --o; }
+                        }
+                    }
+                }
+                off += cnt[j];
+            }
+            if (!have_base) {                                                  // FUSED: now the reserved range is needed
+                if (tid == 0) {
+                    if (reserved + tot > A.capacity) { atomicExch(&A.state[1], 1ull); *s_base = -1; }
+                    else *s_base = reserved;
+                }
+                __syncthreads();
+                tbase = *s_base;
+                if (tbase < 0) { __syncthreads(); continue; }                  // uniform: over capacity, nothing is written
+            } else __syncthreads();
+            const int t = (int)tot;
+            for (int i = tid; i < t; i += SL_THREADS) {
+                const int2 pr = st[i];
+                __builtin_nontemporal_store(pr.x, A.out_probe + tbase + i);
+                __builtin_nontemporal_store(pr.y, A.out_build + tbase + i);
+            }
+            __syncthreads();
+            continue;
+        }
+        // dense tile: several staging windows
         for (long long w0 = 0; w0 < tot; w0 += A.stage) {
             const long long w1 = w0 + A.stage;
             long long off = loc0;
@@ -680,7 +745,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                         // the f-th match counted from the top of the window owns slot end - 1 - f
                         long long o = end - 1;
                         for (int pp = hi[j] - 1; o >= off; --pp) {
-                            const int2 vv = slice_ep(l_ep, A.ep, pp, r0);
+                            const int2 vv = slice_ep(l_end, l_pmax, A.ep, pp, r0);
                             if (lt_op<STRICT>(qs[j], vv.x)) {
                                 if (o >= w0 && o < w1) st[o - w0] = make_int2(qrow[j], slice_row(l_row, A.b_row, pp, r0));
                                 --o;
