@@ -35,8 +35,10 @@ bool slice_geom(const ivj_index* ix, const ivj_opts* opts, SliceGeom& g) {
 
 // the slice path serves the overlap pair kernels (count / fill / fused) of large inputs; explicit with partition_mode 6
 bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, SliceGeom& g) {
+    // explicit (partition_mode 6), or auto when the context says so (IVJ_SLICE_AUTO=1: the measured step times of the two
+    // paths are within a few percent of each other on config 3; the 256-bucket path stays the default)
     if (opts->partition_mode != 0 && opts->partition_mode != 6) return false;
-    if (opts->partition_mode == 0 && !(n_probe >= (4ll << 20) && ix->n >= (256ll << 10))) return false;
+    if (opts->partition_mode == 0 && !(ix->ctx && ix->ctx->sl_env_auto && n_probe >= (4ll << 20) && ix->n >= (256ll << 10))) return false;
     return slice_geom(ix, opts, g);
 }
 
@@ -72,7 +74,7 @@ int slice_plan(const ivj_index* ix, int64_t n, const ivj_opts* opts, const Slice
     P.lds_seg = ix->n_contigs <= SL_LDS_CONTIGS ? 1 : 0;
     P.part_lds = (size_t)slice_part_lds(g.nb, g.ncells).total;
     P.use_bins = (ix->ctx && ix->ctx->sl_env_nobins) ? 0 : 1;
-    const size_t fixed = (size_t)16 * g.R + 4 * SL_PAD + (P.use_bins ? (size_t)2 * (2 * g.R + 8) : 0) + (P.lds_seg ? (size_t)4 * ((ix->n_contigs + 2 + 1) & ~1) : 0) + 8 * (SL_WAVES + 1) + 64;
+    const size_t fixed = (size_t)16 * g.R + 4 * SL_PAD + (P.use_bins ? (size_t)2 * (2 * g.R + 8) : 0) + (P.lds_seg ? (size_t)4 * ((ix->n_contigs + 2 + 3) & ~3) : 0) + 8 * (2 * SL_WAVES + 1) + 64;
     const size_t lds_cap = 160 * 1024;
     if (fixed + 8 * 1024 > lds_cap || P.part_lds > lds_cap) return fail(IVJ_EINVAL, "slice geometry does not fit the LDS");
     size_t stage = (lds_cap - fixed) / 8 / SL_THREADS * SL_THREADS;
@@ -158,6 +160,7 @@ int slice_join_launch_n(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const
     SliceJoinArgs A;
     A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.b_contig = ix->b_contig; A.seg = ix->seg; A.n_contigs = ix->n_contigs;
     A.use_bins = P.use_bins;
+    A.ablate = ctx->sl_env_ablate;
     A.rec = ctx->sl_rec; A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
     A.jchunk = P.jchunk; A.stage = P.stage; A.lds_seg = P.lds_seg; A.capacity = capacity;
     A.tile_tot = ctx->sl_tile; A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);

@@ -67,6 +67,26 @@ __device__ __forceinline__ T sl_block_exclusive_sum(T v, T* wsum /* SL_WAVES */,
     return pre + inc - v;
 }
 
+// One-barrier variant for per-thread values whose WAVEFRONT sums fit 32 bits (the slice join: a probe matches at most
+// nbuild <= SL_MAX_BUCKETS * SL_MAX_ROWS rows, times 128 probes per wavefront < 2^31); the cross-wavefront part is 64-bit.
+// The caller alternates between two partial arrays (`wsum` = parity-selected SL_WAVES ints, 16-byte aligned), so the
+// next scan may start before the slowest wavefront has read this one's partials.
+__device__ __forceinline__ long long sl_block_exclusive_sum_i32(int v, int* wsum, long long* total) {
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const int inc = wave_inclusive_scan(v, SumOp());
+    if (lane == kWave - 1) wsum[w] = inc;
+    __syncthreads();
+    long long pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SL_WAVES; k += 4) {
+        const int4 x = *reinterpret_cast<const int4*>(wsum + k);
+        pre += (long long)(k < w ? x.x : 0) + (k + 1 < w ? x.y : 0) + (k + 2 < w ? x.z : 0) + (k + 3 < w ? x.w : 0);
+        tot += (long long)x.x + x.y + x.z + x.w;
+    }
+    *total = tot;
+    return pre + (inc - v);
+}
+
 // ---- splitters ---------------------------------------------------------------------------------------------------
 // spl[j] = composite key (contig, start) of sorted row j * R: the first row of slice j.
 __global__ void k_slice_splitters(const int32_t* __restrict__ b_contig, const int32_t* __restrict__ b_start, int64_t n, int R, int nb,
@@ -432,6 +452,7 @@ struct SliceJoinArgs {
     int stage;                        // pairs of LDS staging (multiple of SL_THREADS)
     int lds_seg;                      // 1: segment offsets staged in LDS
     int use_bins;                     // 1: direct-address table over the slice's starts (single-contig slices)
+    int ablate;                       // profiling only (IVJ_SLICE_ABLATE): 1 skip the hi lookup, 2 skip the window, 4 skip the tile scan, 8 no slice load, 16 no staging writes, 32 no copy-out
     long long capacity;
     long long* tile_tot;              // COUNT: out; FILL: scanned tile bases
     unsigned long long* state;        // FUSED: [0] cursor, [1] overflow flag
@@ -474,8 +495,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
     unsigned short* l_bin = reinterpret_cast<unsigned short*>(l_row + g.R);
     int2* st = reinterpret_cast<int2*>(l_bin + (A.use_bins ? 2 * g.R + 8 : 0));
     int32_t* l_seg = reinterpret_cast<int32_t*>(st + (MODE == SL_COUNT ? 0 : A.stage));
-    long long* wsum = reinterpret_cast<long long*>(l_seg + (A.lds_seg ? ((A.n_contigs + 2 + 1) & ~1) : 0));
-    long long* s_base = wsum + SL_WAVES;
+    long long* wsum = reinterpret_cast<long long*>(l_seg + (A.lds_seg ? ((A.n_contigs + 2 + 3) & ~3) : 0));     // 16-byte aligned
+    long long* s_base = wsum + 2 * SL_WAVES;
 
     // XCD-affine order: workgroup b runs on XCD b % 8 (observed); XCD x takes the contiguous eighth
     // [x * per, (x + 1) * per) of the (bucket, chunk) list, so its L2 only ever holds its own slices
@@ -494,7 +515,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
     // slice k = sorted rows [r0, r0 + rk)
     const int r0 = k * g.R;
     const int rk = (int)((nbuild - r0) < (int64_t)g.R ? (nbuild - r0) : (int64_t)g.R);
-    for (int i = tid * 4; i < rk; i += SL_THREADS * 4) {
+    for (int i = tid * 4; i < ((A.ablate & 8) ? 0 : rk); i += SL_THREADS * 4) {
         if (i + 4 <= rk) {
             *reinterpret_cast<int4*>(l_start + i) = *reinterpret_cast<const int4*>(A.b_start + r0 + i);
             *reinterpret_cast<int4*>(l_row + i) = *reinterpret_cast<const int4*>(A.b_row + r0 + i);
@@ -560,14 +581,19 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             else nxt[j] = make_int4(0, 0, 0, -1);
         }
     };
-    load_tile(q0);
-    const int tiles_per_chunk = A.jchunk / TILE;
-    int tix = 0;
-    for (int64_t tb = q0; tb < q1; tb += TILE, ++tix) {
-        int32_t qs[ITEMS], qe[ITEMS], qrow[ITEMS];
-        int seg_a[ITEMS], hi[ITEMS];
+    // per-probe state of the tile whose matches are known but not yet emitted
+    int32_t qs[ITEMS], qrow[ITEMS];
+    int seg_a[ITEMS], hi[ITEMS], lo_s[ITEMS];
+    uint32_t mask[ITEMS];
+    int cnt[ITEMS];
+    bool lng[ITEMS];
+
+    // Phase A of a tile: hi-bound + window of every probe -> cnt / mask / lng.  Consumes the prefetched records and
+    // puts the next tile's records in flight.  Touches only the slice in LDS, never the staging buffer.
+    auto match_tile = [&](int64_t tb) {
+        int32_t qe[ITEMS];
         bool valid[ITEMS];
-        int lo_s[ITEMS], lb[ITEMS];
+        int lb[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             qs[j] = nxt[j].x; qe[j] = nxt[j].y; qrow[j] = nxt[j].z;
@@ -590,7 +616,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             }
         }
         if (tb + TILE < q1) load_tile(tb + TILE);                        // next tile's records in flight
-        if (bins) {
+        if (A.ablate & 1) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) lo_s[j] = lb[j] > 20 ? 20 + (qe[j] & 1023) % (lb[j] - 19) : lb[j];
+        } else if (bins) {
             // hi-bound through the table: first row whose start reaches q.end, clamped to the contig's rows [la, lb)
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
@@ -626,24 +655,24 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
         // match.  The SL_WIN ends below hi are read unconditionally (front padding covers the slice's lower edge), bit t
         // <=> row hi-1-t; one prefix-max read of the first row that was not examined decides whether the exact per-lane
         // loop has to redo the probe (window longer than SL_WIN rows, or running on below the slice: rare).
-        uint32_t mask[ITEMS];
-        int cnt[ITEMS];
-        bool lng[ITEMS];
         bool need = false;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             hi[j] = r0 + lo_s[j];
             const int32_t* pe = l_end + (lo_s[j] - SL_WIN);                    // rows hi-SL_WIN .. hi-1 at pe[0 .. SL_WIN-1]
             uint32_t m = 0;
+            if (A.ablate & 2) m = (uint32_t)qs[j] & 3u;
+            else {
 #pragma unroll
-            for (int t = 0; t < SL_WIN; ++t) m |= (lt_op<STRICT>(qs[j], pe[SL_WIN - 1 - t]) ? 1u : 0u) << t;
+                for (int t = 0; t < SL_WIN; ++t) m |= (lt_op<STRICT>(qs[j], pe[SL_WIN - 1 - t]) ? 1u : 0u) << t;
+            }
             const int lowlim = seg_a[j] > r0 ? seg_a[j] : r0;
             int nrows = hi[j] - lowlim;                                        // rows of the window that exist in LDS
             nrows = nrows < 0 ? 0 : (nrows > SL_WIN ? SL_WIN : nrows);
             m &= (1u << nrows) - 1u;
             const int below = hi[j] - 1 - nrows;                               // first row that was not examined
             bool fb = false;
-            if (below >= seg_a[j]) fb = below < r0 ? true : lt_op<STRICT>(qs[j], l_pmax[below - r0]);
+            if (below >= seg_a[j] && !(A.ablate & 2)) fb = below < r0 ? true : lt_op<STRICT>(qs[j], l_pmax[below - r0]);
             lng[j] = valid[j] && fb;
             mask[j] = valid[j] ? m : 0u;
             need |= lng[j];
@@ -663,22 +692,42 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                 }
             }
         }
-        long long tsum = 0;
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) tsum += cnt[j];
-        long long tot;
-        const long long loc0 = sl_block_exclusive_sum(tsum, wsum, &tot);
+    };
+
+    load_tile(q0);
+    match_tile(q0);
+    const int tiles_per_chunk = A.jchunk / TILE;
+    int tix = 0;
+    for (int64_t tb = q0; tb < q1; tb += TILE, ++tix) {
+        const bool have_next = tb + TILE < q1;                                 // uniform
         const long long tile_id = (long long)v * tiles_per_chunk + tix;
         if (MODE == SL_COUNT) {
-            if (tid == 0) A.tile_tot[tile_id] = tot;
+            // only the tile total is needed: wavefront sums go straight to the (zeroed) tile slot, no workgroup barrier
+            long long wsum_c = 0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) wsum_c += cnt[j];
+#pragma unroll
+            for (int d = kWave / 2; d > 0; d >>= 1) wsum_c += __shfl_xor(wsum_c, d, kWave);
+            if ((tid & (kWave - 1)) == 0 && wsum_c) atomicAdd(reinterpret_cast<unsigned long long*>(A.tile_tot + tile_id), (unsigned long long)wsum_c);
+            if (have_next) match_tile(tb + TILE);
             continue;
         }
-        if (tot == 0) continue;                                                // uniform
-        // FUSED: the tile reserves its output range with ONE atomic; its round trip overlaps the staging of the pairs
+        // exclusive offsets of the tile's pairs (one barrier)
+        long long tot, loc0;
+        {
+            int tsum32 = 0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) tsum32 += cnt[j];
+            if (A.ablate & 4) { loc0 = (long long)tsum32 * tid; tot = (long long)tsum32 * SL_THREADS; }
+            else loc0 = sl_block_exclusive_sum_i32(tsum32, reinterpret_cast<int*>(wsum) + (tix & 1) * SL_WAVES, &tot);
+        }
+        if (tot == 0) { if (have_next) match_tile(tb + TILE); continue; }     // uniform
+        // FUSED: the tile reserves its output range with ONE atomic.  Its round trip (microseconds under load) is hidden
+        // behind the staging of this tile's pairs AND the matching of the next tile: the reserved base is only read
+        // right before the copy-out.
         long long tbase = MODE == SL_FILL ? A.tile_tot[tile_id] : 0;
         long long reserved = 0;
         if (MODE == SL_FUSED && tid == 0) reserved = (long long)atomicAdd(&A.state[0], (unsigned long long)tot);
-        bool have_base = MODE == SL_FILL;
         // emission: pairs staged in LDS at their tile-local offset, then copied out with fully coalesced non-temporal
         // stores.  Mask probes: bit t <=> row hi-1-t, ascending (start, row) order = descending t.  Long windows are
         // rescanned by their lane.  Usual case: the tile's pairs fit ONE staging window (32-bit offsets, no range checks).
@@ -694,7 +743,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                         while (m) {
                             const int jj = 31 - __clz(m);
                             m &= ~(1u << jj);
-                            st[o++] = make_int2(qrow[j], pr[-jj]);
+                            if (!(A.ablate & 16)) st[o] = make_int2(qrow[j], pr[-jj]);
+                            ++o;
                         }
                     } else {
                         int o = off + cnt[j] - 1;
@@ -706,25 +756,30 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                 }
                 off += cnt[j];
             }
-            if (!have_base) {                                                  // FUSED: now the reserved range is needed
+            if (have_next) match_tile(tb + TILE);                              // overwrites the per-probe state: this tile lives in `st` now
+            bool skip = false;
+            if (MODE == SL_FUSED) {
                 if (tid == 0) {
                     if (reserved + tot > A.capacity) { atomicExch(&A.state[1], 1ull); *s_base = -1; }
                     else *s_base = reserved;
                 }
-                __syncthreads();
+                __syncthreads();                                               // staging + base visible
                 tbase = *s_base;
-                if (tbase < 0) { __syncthreads(); continue; }                  // uniform: over capacity, nothing is written
+                skip = tbase < 0;                                              // uniform: over capacity, nothing is written
             } else __syncthreads();
-            const int t = (int)tot;
-            for (int i = tid; i < t; i += SL_THREADS) {
-                const int2 pr = st[i];
-                __builtin_nontemporal_store(pr.x, A.out_probe + tbase + i);
-                __builtin_nontemporal_store(pr.y, A.out_build + tbase + i);
+            if (!skip && !(A.ablate & 32)) {
+                const int t = (int)tot;
+                for (int i = tid; i < t; i += SL_THREADS) {
+                    const int2 pr = st[i];
+                    __builtin_nontemporal_store(pr.x, A.out_probe + tbase + i);
+                    __builtin_nontemporal_store(pr.y, A.out_build + tbase + i);
+                }
             }
-            __syncthreads();
+            __syncthreads();                                                   // staging buffer (and s_base) free again
             continue;
         }
-        // dense tile: several staging windows
+        // dense tile: several staging windows, no overlap with the next tile
+        bool have_base = MODE == SL_FILL;
         for (long long w0 = 0; w0 < tot; w0 += A.stage) {
             const long long w1 = w0 + A.stage;
             long long off = loc0;
@@ -773,6 +828,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             }
             __syncthreads();
         }
+        if (have_next) match_tile(tb + TILE);
     }
 }
 
