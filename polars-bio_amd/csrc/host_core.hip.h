@@ -70,6 +70,8 @@ struct ivj_ctx {
     int32_t *pt_c = nullptr, *pt_s = nullptr, *pt_e = nullptr, *pt_row = nullptr;
     uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
     bool part_attr_set = false;
+    bool os_attr_set = false;
+    bool ix_v1 = false;                // IVJ_INDEX_V1=1: the round-1 index build (A/B runs)
     // slice path (host_slice.hip.h): bucket-ordered probe records, histogram, chunk table, tile totals
     char* sl_buf = nullptr;
     size_t sl_cap = 0;

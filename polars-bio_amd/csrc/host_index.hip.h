@@ -101,6 +101,122 @@ int build_flat(ivj_ctx* ctx, ivj_index* ix) {
     return IVJ_OK;
 }
 
+// round-1 build (IVJ_INDEX_V1=1): 8-bit LSD passes over (key, row) pairs + gathers + 3-launch scans.  Kept for A/B runs.
+int index_sort_v1(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_opts* opts) {
+    const int64_t n = build->n;
+    {
+        const size_t comp_bytes = 2 * align_up((size_t)n * 8) + align_up((size_t)(scan_num_tiles(n) + 1) * 8) +
+                                  align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4);
+        IVJ_TRY(arena_reserve(ctx, sort_scratch_bytes(n) + comp_bytes + 4096));
+        SortBufs sb; take_sort_bufs(ctx, n, sb);
+        unsigned long long* comp = arena_take<unsigned long long>(ctx, n);
+        unsigned long long* comp_max = arena_take<unsigned long long>(ctx, n);
+        unsigned long long* comp_part = arena_take<unsigned long long>(ctx, scan_num_tiles(n) + 1);
+        uint32_t* bins_part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
+        // 1. stable sort by start (row ids as payload), 2. stable sort by contig id
+        LAUNCH(ctx, "sort_keys", k_iota_flip, grid1d(n, 256), 256, build->start, n, sb.kA, sb.vA);
+        bool fl = radix_sort_pairs(ctx, sb, n, 32);
+        if (fl) { std::swap(sb.kA, sb.kB); std::swap(sb.vA, sb.vB); }
+        LAUNCH(ctx, "gather", k_gather_contig, grid1d(n, 256), 256, build->contig, (const uint32_t*)sb.vA, n, opts->n_contigs, sb.kA);
+        fl = radix_sort_pairs(ctx, sb, n, bits_for((uint32_t)opts->n_contigs));
+        const uint32_t* ckeys = fl ? sb.kB : sb.kA;
+        const uint32_t* rows = fl ? sb.vB : sb.vA;
+        // 3. sorted columns, segment offsets, (contig,end) composites; 4. prefix max; 5. interleave (end, pmax)
+        LAUNCH(ctx, "index_finalize", k_index_finalize, grid1d(n, 256), 256, build->start, build->end, rows, ckeys, build->row_id, n,
+               opts->n_contigs, ix->b_start, ix->b_row, ix->b_contig, comp, ix->seg, ix->flags);
+        device_scan<unsigned long long, MaxOp, true>(ctx, "pmax_scan", comp, comp_max, n, 0ull, comp_part,
+                                                      (unsigned long long*)nullptr);
+        LAUNCH(ctx, "emit_ep", k_emit_ep, grid1d(n, 256), 256, (const unsigned long long*)comp,
+               (const unsigned long long*)comp_max, n, ix->ep);
+        // 6. direct-address table over start
+        if (opts->n_contigs > 0 && ix->has_tables) {
+            LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(opts->n_contigs, 256), 256, (const int32_t*)ix->seg,
+                   (const int32_t*)ix->b_start, opts->n_contigs, ix->cmeta);
+            hipError_t me = hipMemsetAsync(ix->bins, 0, (size_t)ix->bins_len * 4, ctx->stream);
+            if (me != hipSuccess) return fail(IVJ_EHIP, std::string("hipMemsetAsync(bins): ") + hipGetErrorString(me));
+            LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int32_t*)ix->b_contig, n,
+                   opts->n_contigs, (const int4*)ix->cmeta, ix->bins);
+            device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", ix->bins, ix->bins, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
+            LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
+                   (const int32_t*)ix->b_start, (const int4*)ix->cmeta, opts->n_contigs, ix->brec);
+        }
+    }
+    return IVJ_OK;
+}
+
+// round-2 build (onesweep.hip.h): min / max -> per pass [look-back scan of the (digit, chunk) histogram, LDS-staged stable scatter
+// of 16-byte records that also feeds the next pass's histogram] -> index arrays (look-back prefix max) -> segment offsets and
+// table geometry -> head marks -> look-back max-scan -> bin records.
+int index_sort_v2(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_opts* opts) {
+    const int64_t n = build->n;
+    const int nc = opts->n_contigs;
+    const int cbits = os_bits_for((uint32_t)nc);                      // contig ids 0 .. nc (nc = rows outside the dictionary)
+    const int passes_max = (32 + cbits + OS_BITS - 1) / OS_BITS;
+    const int64_t tiles = (n + OS_TILE - 1) / OS_TILE;
+    // chunks of the passes: about 512 workgroups, whole sub-tiles
+    int64_t chunk = ((n + 511) / 512 + OS_TILE - 1) / OS_TILE * OS_TILE;
+    if (chunk < OS_TILE) chunk = OS_TILE;
+    const int nchunks = (int)((n + chunk - 1) / chunk);
+    const int64_t hist_len = (int64_t)OS_RADIX * nchunks;
+    const int64_t lb_tiles = (ix->bins_len + LB_TILE - 1) / LB_TILE, hs_tiles = (hist_len + LB_TILE - 1) / LB_TILE;
+    const size_t z_meta = align_up(sizeof(OsMeta)), z_fin = align_up((size_t)tiles * 8), z_lb = align_up((size_t)lb_tiles * 8),
+                 z_hs = align_up((size_t)hs_tiles * 8) * (size_t)passes_max, z_hist = align_up((size_t)hist_len * 4) * (size_t)passes_max,
+                 z_tick = align_up((size_t)(passes_max + 2) * 4);
+    const size_t zero_bytes = z_meta + z_fin + z_lb + z_hs + z_hist + z_tick;
+    IVJ_TRY(arena_reserve(ctx, zero_bytes + 2 * align_up((size_t)n * 16) + 4096));
+    char* z = arena_take<char>(ctx, zero_bytes);
+    int4* recA = arena_take<int4>(ctx, n);
+    int4* recB = arena_take<int4>(ctx, n);
+    OsMeta* meta = (OsMeta*)z;
+    unsigned long long* st_fin = (unsigned long long*)(z + z_meta);
+    unsigned long long* st_lb = (unsigned long long*)(z + z_meta + z_fin);
+    char* st_hs = z + z_meta + z_fin + z_lb;
+    char* hists = st_hs + z_hs;
+    uint32_t* tickets = (uint32_t*)(hists + z_hist);                 // look-back scan tickets: one per pass + the table scan
+    HIP_TRY(hipMemsetAsync(z, 0, zero_bytes, ctx->stream));
+    const bool tables = ix->has_tables && nc > 0;
+    if (tables) HIP_TRY(hipMemsetAsync(ix->bins, 0, (size_t)ix->bins_len * 4, ctx->stream));
+    const unsigned sgrid = (unsigned)(tiles < 512 ? tiles : 512);
+    LAUNCH(ctx, "ix_minmax", k_ix_minmax, sgrid, OS_THREADS, build->start, build->end, build->contig, n, nc, meta);
+    auto hist_of = [&](int p) { return (uint32_t*)(hists + (size_t)p * align_up((size_t)hist_len * 4)); };
+    const size_t pass_lds = (size_t)os_pass_lds().total;
+    if (!ctx->os_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_os_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_os_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
+        ctx->os_attr_set = true;
+    }
+    for (int p = 0; p < passes_max; ++p) {
+        // a pass whose digit lies beyond the key bits exits at once (device-side decision: the key width depends on the data);
+        // its scan then runs over a zero histogram
+        const int4* src = (p & 1) ? recA : recB;                     // pass p writes buffer p & 1 (A, B, A, ...), reads the other
+        int4* dst = (p & 1) ? recB : recA;
+        if (p == 0) LAUNCH(ctx, "ix_hist", (k_os_hist<true>), nchunks, OS_THREADS, build->contig, build->start, src, n, nc, cbits, p, (const OsMeta*)meta, (int)chunk, nchunks, hist_of(p));
+        else LAUNCH(ctx, "ix_hist", (k_os_hist<false>), nchunks, OS_THREADS, build->contig, build->start, src, n, nc, cbits, p, (const OsMeta*)meta, (int)chunk, nchunks, hist_of(p));
+        LAUNCH(ctx, "ix_scan", (k_scan_lb_u32<SumOp, true>), hs_tiles, OS_THREADS, hist_of(p), hist_len, 0u, tickets + p,
+               (unsigned long long*)(st_hs + (size_t)p * align_up((size_t)hs_tiles * 8)));
+        t_begin(ctx, "ix_pass");
+        if (p == 0)
+            hipLaunchKernelGGL((k_os_scatter<true>), dim3((unsigned)nchunks), dim3(OS_THREADS), pass_lds, ctx->stream, build->contig, build->start, build->end,
+                               build->row_id, src, dst, n, nc, cbits, p, (const OsMeta*)meta, (int)chunk, nchunks, (const uint32_t*)hist_of(p));
+        else
+            hipLaunchKernelGGL((k_os_scatter<false>), dim3((unsigned)nchunks), dim3(OS_THREADS), pass_lds, ctx->stream, build->contig, build->start, build->end,
+                               build->row_id, src, dst, n, nc, cbits, p, (const OsMeta*)meta, (int)chunk, nchunks, (const uint32_t*)hist_of(p));
+        t_end(ctx);
+    }
+    LAUNCH(ctx, "ix_final", k_ix_final, tiles, OS_THREADS, (const int4*)recA, (const int4*)recB, n, nc, cbits, meta, st_fin, ix->b_start, ix->ep, ix->b_row,
+           ix->b_contig, ix->seg, ix->flags);
+    if (tables) {
+        LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(nc, 256), 256, (const int32_t*)ix->seg, (const int32_t*)ix->b_start, nc, ix->cmeta);
+        LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int32_t*)ix->b_contig, n, nc,
+               (const int4*)ix->cmeta, ix->bins);
+        LAUNCH(ctx, "bins_scan", (k_scan_lb_u32<MaxOp, false>), lb_tiles, OS_THREADS, ix->bins, ix->bins_len, 0u, tickets + passes_max, st_lb);
+        LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
+               (const int32_t*)ix->b_start, (const int4*)ix->cmeta, nc, ix->brec);
+    }
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
 int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int with_end_order, ivj_index** out) {
     // table offsets (2 a + 2 c) and slot counts are int32: 2 Nb + 2 n_contigs must stay below 2^31
     if (2 * build->n + 2 * (int64_t)opts->n_contigs + 64 > 0x7fffffffll)
@@ -162,43 +278,9 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(index meta): ") + hipGetErrorString(e)));
     }
     if (n > 0) {
-        const size_t comp_bytes = 2 * align_up((size_t)n * 8) + align_up((size_t)(scan_num_tiles(n) + 1) * 8) +
-                                  align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4);
-        int r = arena_reserve(ctx, sort_scratch_bytes(n) + comp_bytes + 4096);
-        if (r != IVJ_OK) return cleanup(r);
-        SortBufs sb; take_sort_bufs(ctx, n, sb);
-        unsigned long long* comp = arena_take<unsigned long long>(ctx, n);
-        unsigned long long* comp_max = arena_take<unsigned long long>(ctx, n);
-        unsigned long long* comp_part = arena_take<unsigned long long>(ctx, scan_num_tiles(n) + 1);
-        uint32_t* bins_part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
-        // 1. stable sort by start (row ids as payload), 2. stable sort by contig id
-        LAUNCH(ctx, "sort_keys", k_iota_flip, grid1d(n, 256), 256, build->start, n, sb.kA, sb.vA);
-        bool fl = radix_sort_pairs(ctx, sb, n, 32);
-        if (fl) { std::swap(sb.kA, sb.kB); std::swap(sb.vA, sb.vB); }
-        LAUNCH(ctx, "gather", k_gather_contig, grid1d(n, 256), 256, build->contig, (const uint32_t*)sb.vA, n, opts->n_contigs, sb.kA);
-        fl = radix_sort_pairs(ctx, sb, n, bits_for((uint32_t)opts->n_contigs));
-        const uint32_t* ckeys = fl ? sb.kB : sb.kA;
-        const uint32_t* rows = fl ? sb.vB : sb.vA;
-        // 3. sorted columns, segment offsets, (contig,end) composites; 4. prefix max; 5. interleave (end, pmax)
-        LAUNCH(ctx, "index_finalize", k_index_finalize, grid1d(n, 256), 256, build->start, build->end, rows, ckeys, build->row_id, n,
-               opts->n_contigs, ix->b_start, ix->b_row, ix->b_contig, comp, ix->seg, ix->flags);
-        device_scan<unsigned long long, MaxOp, true>(ctx, "pmax_scan", comp, comp_max, n, 0ull, comp_part,
-                                                      (unsigned long long*)nullptr);
-        LAUNCH(ctx, "emit_ep", k_emit_ep, grid1d(n, 256), 256, (const unsigned long long*)comp,
-               (const unsigned long long*)comp_max, n, ix->ep);
-        // 6. direct-address table over start
         ix->has_tables = !(with_end_order & 2);
-        if (opts->n_contigs > 0 && ix->has_tables) {
-            LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(opts->n_contigs, 256), 256, (const int32_t*)ix->seg,
-                   (const int32_t*)ix->b_start, opts->n_contigs, ix->cmeta);
-            hipError_t me = hipMemsetAsync(ix->bins, 0, (size_t)ix->bins_len * 4, ctx->stream);
-            if (me != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(bins): ") + hipGetErrorString(me)));
-            LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int32_t*)ix->b_contig, n,
-                   opts->n_contigs, (const int4*)ix->cmeta, ix->bins);
-            device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", ix->bins, ix->bins, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
-            LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
-                   (const int32_t*)ix->b_start, (const int4*)ix->cmeta, opts->n_contigs, ix->brec);
-        }
+        int r = ctx->ix_v1 ? index_sort_v1(ctx, ix, build, opts) : index_sort_v2(ctx, ix, build, opts);
+        if (r != IVJ_OK) return cleanup(r);
         // 7. the flat overlap path's arrays (lot / tab2 / rec4) are filled on first use: build_flat
         if (opts->partition_mode == 5) { r = build_flat(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
         if (with_end_order & 1) { r = build_end_order(ctx, ix); if (r != IVJ_OK) return cleanup(r); }
