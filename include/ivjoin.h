@@ -298,6 +298,41 @@ int ivj_coverage_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, con
  * alive for as long as *out is used.  Needs no device. */
 int ivj_side_from_arrow(const void* array, const void* schema, ivj_side* out);
 
+/* ---- streaming probe side ----------------------------------------------------- *
+ * The reference streams df1 through its executor as an Arrow C stream and yields result batches lazily            *
+ * (polars_bio/range_op_io.py:100-174, src/lib.rs:154-214, fan-out with back-pressure src/scan.rs:294-357).         *
+ * Here the build side (df2) is indexed once and stays in HBM; the probe side is SUBMITTED batch by batch (e.g. the *
+ * record batches of an ArrowArrayStream, columns viewed with ivj_side_from_arrow).  Every submit overlaps the H2D   *
+ * copy of the batch it was given (pinned staging slot, copy stream), the join of the batch before it (compute       *
+ * stream) and the D2H copy of the batch before that (pinned result slot, copy-back stream), and hands out the        *
+ * results of the batch submitted two calls earlier.  ivj_stream_flush drains what is left.                            */
+#define IVJ_STREAM_OVERLAP  0   /* pairs (probe row of the batch, build row)                  */
+#define IVJ_STREAM_COUNT    1   /* count_overlaps: int64 count per probe row of the batch      */
+#define IVJ_STREAM_NEAREST  2   /* nearest: opts->nearest_k build rows, distances, n_found     */
+
+typedef struct ivj_stream ivj_stream;
+
+/* Results of ONE earlier batch; the buffers are pinned host memory owned by the stream, valid until the next call
+ * on the stream.  batch = -1: nothing was ready. */
+typedef struct {
+    int64_t batch;          /* 0-based index of the submitted batch these results belong to, -1 = none      */
+    int64_t n_probe;        /* probe rows of that batch                                                     */
+    int64_t n;              /* overlap: pairs; count / nearest: n_probe                                     */
+    int32_t* probe_idx;     /* overlap: probe row INSIDE the batch                                          */
+    int32_t* build_idx;     /* overlap: build row; nearest: n_probe * k build rows (-1 = no candidate)      */
+    int64_t* counts;        /* count_overlaps                                                               */
+    int64_t* dist;          /* nearest: n_probe * k distances                                               */
+    int32_t* n_found;       /* nearest: filled slots per probe row                                          */
+} ivj_stream_result;
+
+/* build: host columns (borrowed for the call).  max_batch_rows bounds the probe batches (pinned staging is sized by it). */
+int ivj_stream_open(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int op, int64_t max_batch_rows, ivj_stream** out);
+/* batch: host columns of the next probe batch (borrowed for the call; copied into the pinned staging slot). */
+int ivj_stream_submit(ivj_stream* st, const ivj_side* batch, ivj_stream_result* done);
+/* no more input: call until done->batch == -1 */
+int ivj_stream_flush(ivj_stream* st, ivj_stream_result* done);
+void ivj_stream_close(ivj_stream* st);
+
 /* ---- device memory helpers for callers without a HIP binding ------------ */
 int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out);
 int ivj_dev_free(ivj_ctx* ctx, void* p);

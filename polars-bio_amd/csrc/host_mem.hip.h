@@ -1,0 +1,58 @@
+// host_mem.hip.h -- host <-> HBM traffic of the host-buffer entry points: registered inputs, pre-faulted registered results
+// Part of the single translation unit ivjoin.hip (included there, in this order); not a stand-alone header.
+//
+// Measured on the MI355X box (tools/pcie_probe.py, profiles/r02): pageable and registered host memory both move at
+// ~57 GB/s over PCIe Gen5, hipHostRegister of 1.2 GB costs ~3 ms -- but a D2H copy into FRESH (never touched) host pages
+// runs at 7 GB/s, because every 4-KiB page faults under the DMA.  The round-1 host path paid that twice (library malloc +
+// numpy copy): 0.36 s for config 3, of which the join was 4 ms.  Here result buffers are 2-MiB aligned, advised to huge
+// pages, first-touched by a few host threads and registered, and the caller's input columns are registered in place
+// (zero copy: the DMA engine reads the Arrow / numpy buffers directly).
+#pragma once
+
+#include <sys/mman.h>
+
+#include <thread>
+
+namespace {
+
+// host memory for a result column: huge-page friendly, pre-faulted in parallel.  Free with std::free.
+void* host_result_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    const size_t huge = (size_t)2 << 20;
+    const size_t sz = bytes >= huge ? (bytes + huge - 1) / huge * huge : (bytes + 4095) / 4096 * 4096;
+    void* p = nullptr;
+    if (posix_memalign(&p, bytes >= huge ? huge : 4096, sz) != 0) return nullptr;
+    if (bytes >= huge) (void)madvise(p, sz, MADV_HUGEPAGE);
+    if (bytes >= ((size_t)8 << 20)) {
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned nt = hw >= 16 ? 16u : (hw ? hw : 1u);
+        std::vector<std::thread> th;
+        const size_t per = (sz / nt + 4095) / 4096 * 4096;
+        for (unsigned t = 0; t < nt; ++t) {
+            const size_t lo = (size_t)t * per, hi = lo + per < sz ? lo + per : sz;
+            if (lo >= hi) break;
+            th.emplace_back([p, lo, hi] { volatile char* c = (volatile char*)p; for (size_t o = lo; o < hi; o += 4096) c[o] = 0; });
+        }
+        for (auto& x : th) x.join();
+    }
+    return p;
+}
+
+// registers a host range for the lifetime of the object (failure is not an error: the copy then goes the pageable way)
+struct HostPin {
+    void* p = nullptr;
+    bool ok = false;
+    HostPin(const void* ptr, size_t bytes) {
+        if (ptr && bytes >= ((size_t)1 << 20)) {
+            p = const_cast<void*>(ptr);
+            ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+        }
+    }
+    ~HostPin() { if (ok) (void)hipHostUnregister(p); }
+    HostPin(const HostPin&) = delete;
+    HostPin& operator=(const HostPin&) = delete;
+};
+
+}  // namespace
+

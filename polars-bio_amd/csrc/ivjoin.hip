@@ -26,10 +26,12 @@
 using namespace ivj;
 
 #include "host_core.hip.h"
+#include "host_mem.hip.h"
 #include "host_index.hip.h"
 #include "host_slice.hip.h"
 #include "host_join.hip.h"
 #include "host_sortscan.hip.h"
+#include "host_stream.hip.h"
 
 // =============================================================================== C ABI
 
@@ -244,9 +246,10 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     if (e == hipSuccess) e = hipMalloc(&ob.p, (size_t)total * 4);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(pairs): ") + hipGetErrorString(e));
     IVJ_TRY(overlap_fill(ctx, h.ix, &dp.s, opts, (int32_t*)op.p, (int32_t*)ob.p, total));
-    out->probe_idx = (int32_t*)std::malloc((size_t)total * 4);
-    out->build_idx = (int32_t*)std::malloc((size_t)total * 4);
+    out->probe_idx = (int32_t*)host_result_alloc((size_t)total * 4);
+    out->build_idx = (int32_t*)host_result_alloc((size_t)total * 4);
     if (!out->probe_idx || !out->build_idx) { ivj_pairs_free(out); return fail(IVJ_ENOMEM, "host malloc(pairs)"); }
+    HostPin pin_p(out->probe_idx, (size_t)total * 4), pin_b(out->build_idx, (size_t)total * 4);
     hipError_t ce = hipMemcpyAsync(out->probe_idx, op.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (ce == hipSuccess) ce = hipMemcpyAsync(out->build_idx, ob.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
@@ -590,6 +593,81 @@ int ivj_nearest(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     HIP_TRY(hipMemcpyAsync(n_found, dn.p, (size_t)probe->n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return IVJ_OK;
+}
+
+// ---------------------------------------------------------------- streaming probe session
+
+int ivj_stream_open(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int op, int64_t max_batch_rows, ivj_stream** out) {
+    if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
+    *out = nullptr;
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(build, "build"));
+    if (op < IVJ_STREAM_OVERLAP || op > IVJ_STREAM_NEAREST) return fail(IVJ_EINVAL, "op must be IVJ_STREAM_OVERLAP, _COUNT or _NEAREST");
+    if (max_batch_rows < 1 || max_batch_rows > 0x7fff0000ll) return fail(IVJ_EINVAL, "max_batch_rows out of range");
+    const int k = opts->nearest_k < 1 ? 1 : opts->nearest_k;
+    if (op == IVJ_STREAM_NEAREST && k > 1024) return fail(IVJ_EINVAL, "nearest_k > 1024");
+    DeviceGuard g(ctx->device);
+    ivj_stream* st = new ivj_stream();
+    st->ctx = ctx; st->opts = *opts; st->op = op; st->k = k; st->max_rows = max_batch_rows;
+    auto bail = [&](int rc) { ivj_stream_close(st); return rc; };
+    {
+        DevSide db;
+        int rc = upload_side(ctx, build, db);
+        if (rc != IVJ_OK) return bail(rc);
+        const int general = op == IVJ_STREAM_NEAREST && !(k == 1 && opts->include_overlaps);
+        rc = index_build(ctx, &db.s, opts, (op == IVJ_STREAM_COUNT || general) ? 1 : 0, &st->ix);
+        if (rc != IVJ_OK) return bail(rc);
+        hipError_t e = hipStreamSynchronize(ctx->stream);                      // the index copied what it needs: the upload may go
+        if (e != hipSuccess) return bail(fail(IVJ_EHIP, std::string("sync(stream open): ") + hipGetErrorString(e)));
+    }
+    hipError_t e = hipStreamCreateWithFlags(&st->s_h2d, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->s_d2h, hipStreamNonBlocking);
+    const size_t col = align_up((size_t)max_batch_rows * 4);
+    for (int s = 0; s < 3 && e == hipSuccess; ++s) {
+        e = hipHostMalloc((void**)&st->slot[s].h_in, 3 * col, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void**)&st->slot[s].d_in, 3 * col);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&st->slot[s].ev_h2d, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&st->slot[s].ev_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&st->slot[s].ev_d2h, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) return bail(fail(IVJ_ENOMEM, std::string("stream slots: ") + hipGetErrorString(e)));
+    *out = st;
+    return IVJ_OK;
+}
+
+int ivj_stream_submit(ivj_stream* st, const ivj_side* batch, ivj_stream_result* done) {
+    if (!st || !done) return fail(IVJ_EINVAL, "stream or done is NULL");
+    IVJ_TRY(check_side(batch, "batch"));
+    if (batch->n > st->max_rows) return fail(IVJ_EINVAL, "batch has more rows than max_batch_rows");
+    if (batch->row_id) return fail(IVJ_EINVAL, "stream batches report rows inside the batch: row_id must be NULL");
+    return stream_turn(st, batch, done);
+}
+
+int ivj_stream_flush(ivj_stream* st, ivj_stream_result* done) {
+    if (!st || !done) return fail(IVJ_EINVAL, "stream or done is NULL");
+    return stream_turn(st, nullptr, done);
+}
+
+void ivj_stream_close(ivj_stream* st) {
+    if (!st) return;
+    DeviceGuard g(st->ctx->device);
+    if (st->s_h2d) (void)hipStreamSynchronize(st->s_h2d);
+    if (st->s_d2h) (void)hipStreamSynchronize(st->s_d2h);
+    (void)hipStreamSynchronize(st->ctx->stream);
+    for (int s = 0; s < 3; ++s) {
+        ivj_stream::Slot& S = st->slot[s];
+        if (S.h_in) (void)hipHostFree(S.h_in);
+        if (S.d_in) (void)hipFree(S.d_in);
+        if (S.d_out) (void)hipFree(S.d_out);
+        if (S.h_out) (void)hipHostFree(S.h_out);
+        if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
+        if (S.ev_join) (void)hipEventDestroy(S.ev_join);
+        if (S.ev_d2h) (void)hipEventDestroy(S.ev_d2h);
+    }
+    if (st->s_h2d) (void)hipStreamDestroy(st->s_h2d);
+    if (st->s_d2h) (void)hipStreamDestroy(st->s_d2h);
+    if (st->ix) ivj_index_free(st->ix);
+    delete st;
 }
 
 // ---------------------------------------------------------------- memory helpers

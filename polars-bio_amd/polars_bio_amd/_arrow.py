@@ -27,7 +27,8 @@ try:
 except ImportError:
     pl = None
 
-OUTPUT_TYPES = ("polars.LazyFrame", "polars.DataFrame", "pandas.DataFrame", "datafusion.DataFrame", "pyarrow.Table")
+# "pyarrow.RecordBatchReader": the lazy result as an ArrowArrayStream (the streaming path; see _streaming.py)
+OUTPUT_TYPES = ("polars.LazyFrame", "polars.DataFrame", "pandas.DataFrame", "datafusion.DataFrame", "pyarrow.Table", "pyarrow.RecordBatchReader")
 
 
 def to_arrow(df) -> pa.Table:

@@ -32,8 +32,11 @@ ABI_SYMBOLS = [
     "ivj_side_from_arrow", "ivj_materialize_dev", "ivj_overlap_fused_rows_dev", "ivj_take_dev", "ivj_overlap_rows", "ivj_rows_free", "ivj_rows_export_arrow",
     "ivj_subtract", "ivj_complement", "ivj_pieces_free", "ivj_subtract_dev",
     "ivj_merge", "ivj_merged_free", "ivj_cluster", "ivj_coverage", "ivj_cluster_dev", "ivj_merge_dev", "ivj_coverage_dev",
+    "ivj_stream_open", "ivj_stream_submit", "ivj_stream_flush", "ivj_stream_close",
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
 ]
+
+STREAM_OVERLAP, STREAM_COUNT, STREAM_NEAREST = 0, 1, 2
 
 ROW_COLUMNS = ("probe_idx", "build_idx", "contig", "start_1", "end_1", "start_2", "end_2")
 
@@ -80,6 +83,12 @@ class _ArrowArray(C.Structure):
     _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
                 ("n_children", C.c_int64), ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p),
                 ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class _StreamResult(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("n_probe", C.c_int64), ("n", C.c_int64), ("probe_idx", C.POINTER(C.c_int32)),
+                ("build_idx", C.POINTER(C.c_int32)), ("counts", C.POINTER(C.c_int64)), ("dist", C.POINTER(C.c_int64)),
+                ("n_found", C.POINTER(C.c_int32))]
 
 
 class _Timing(C.Structure):
@@ -147,6 +156,11 @@ def load_library() -> C.CDLL:
         L.ivj_cluster_dev.argtypes = [vp, vp, O, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64)]
         L.ivj_merge_dev.argtypes = [vp, vp, O, C.c_int64, C.c_int64, vp, vp, vp, vp, C.POINTER(C.c_int64)]
         L.ivj_coverage_dev.argtypes = [vp, vp, P, O, vp]
+        L.ivj_stream_open.argtypes = [vp, P, O, C.c_int, C.c_int64, C.POINTER(vp)]
+        L.ivj_stream_submit.argtypes = [vp, P, C.POINTER(_StreamResult)]
+        L.ivj_stream_flush.argtypes = [vp, C.POINTER(_StreamResult)]
+        L.ivj_stream_close.argtypes = [vp]
+        L.ivj_stream_close.restype = None
         L.ivj_dev_alloc.argtypes = [vp, C.c_int64, C.POINTER(vp)]
         L.ivj_dev_free.argtypes = [vp, vp]
         L.ivj_memcpy_h2d.argtypes = [vp, vp, vp, C.c_int64]
@@ -230,6 +244,107 @@ class _LockedLib:
         return call
 
 
+class _PairsOwner:
+    """Keeps an ivj_pairs result alive for the numpy arrays that view its buffers."""
+
+    def __init__(self, lib, pairs):
+        self.lib, self.pairs = lib, pairs
+
+    def __del__(self):
+        try:
+            self.lib.ivj_pairs_free(C.byref(self.pairs))
+        except Exception:
+            pass
+
+
+def _owned_view(ptr, n, owner) -> np.ndarray:
+    """numpy view of `n` int32 at `ptr` whose base object keeps `owner` alive (views of the view chain back to it)."""
+    buf = (C.c_int32 * n).from_address(C.addressof(ptr.contents))
+    buf._owner = owner                       # the ctypes array is the numpy array's base: its attribute pins the owner
+    return np.frombuffer(buf, dtype=np.int32)
+
+
+class ProbeStream:
+    """Streaming probe session (ivj_stream_*): the build side is indexed once, probe batches are submitted one at a time;
+    every submit overlaps the H2D copy of its batch, the join of the previous batch and the D2H copy of the one before.
+
+    submit() / flush() return None or a dict: ``batch`` (index of the batch the results belong to), ``n_probe`` and
+        overlap         ``probe_idx`` (rows INSIDE that batch), ``build_idx``
+        count_overlaps  ``counts``
+        nearest         ``build_idx`` (n_probe x k, -1 = none), ``dist`` (n_probe x k), ``n_found``
+    The arrays are copies unless ``copy=False`` (then they view the stream's pinned result slot and are valid until the
+    next call on the stream)."""
+
+    def __init__(self, engine: "Engine", build, strict: bool, n_contigs: int, op: int, max_batch_rows: int, k: int = 1,
+                 include_overlaps: bool = True, partition_mode: int = 0, copy: bool = True):
+        self.engine, self.op, self.k, self.copy = engine, int(op), int(k), copy
+        self.opts = make_opts(strict, n_contigs, k, include_overlaps, partition_mode=partition_mode)
+        bs, keep = _host_side(*build)
+        h = C.c_void_p()
+        _check(engine.L, engine.L.ivj_stream_open(engine.h, C.byref(bs), C.byref(self.opts), self.op, int(max_batch_rows), C.byref(h)),
+               "ivj_stream_open")
+        del keep
+        self.h = h
+        self.max_batch_rows = int(max_batch_rows)
+
+    def _result(self, r: _StreamResult):
+        if r.batch < 0:
+            return None
+        def arr(ptr, n, dtype, shape=None):
+            if n == 0:
+                a = np.empty(0, dtype)
+            else:
+                a = np.ctypeslib.as_array(ptr, shape=(n,))
+                a = a.copy() if self.copy else a
+            return a.reshape(shape) if shape else a
+        out = {"batch": int(r.batch), "n_probe": int(r.n_probe)}
+        n, k = int(r.n_probe), self.k
+        if self.op == STREAM_OVERLAP:
+            out["probe_idx"] = arr(r.probe_idx, int(r.n), np.int32)
+            out["build_idx"] = arr(r.build_idx, int(r.n), np.int32)
+        elif self.op == STREAM_COUNT:
+            out["counts"] = arr(r.counts, n, np.int64)
+        else:
+            out["build_idx"] = arr(r.build_idx, n * k, np.int32, (n, k))
+            out["dist"] = arr(r.dist, n * k, np.int64, (n, k))
+            out["n_found"] = arr(r.n_found, n, np.int32)
+        return out
+
+    def submit(self, batch):
+        """batch: (contig, start, end) int32 arrays, or an ivj_side made by side_from_arrow (zero copy from Arrow)."""
+        keep = None
+        if isinstance(batch, _Side):
+            side = batch
+        else:
+            side, keep = _host_side(*batch)
+        r = _StreamResult()
+        _check(self.engine.L, self.engine.L.ivj_stream_submit(self.h, C.byref(side), C.byref(r)), "ivj_stream_submit")
+        del keep
+        return self._result(r)
+
+    def flush(self):
+        r = _StreamResult()
+        _check(self.engine.L, self.engine.L.ivj_stream_flush(self.h, C.byref(r)), "ivj_stream_flush")
+        return self._result(r)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.engine.L.ivj_stream_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceIndex:
     """Sorted build side resident in HBM (ivj_index)."""
 
@@ -283,16 +398,15 @@ class Engine:
         o = make_opts(strict, n_contigs, partition_mode=partition_mode, table_mode=table_mode, slice_rows=slice_rows, slice_chunk=slice_chunk)
         out = _Pairs()
         _check(self.L, self.L.ivj_overlap(self.h, C.byref(ps), C.byref(bs), C.byref(o), C.byref(out)), "ivj_overlap")
-        try:
-            n = out.n_pairs
-            if n == 0:
-                return np.empty(0, np.int32), np.empty(0, np.int32)
-            p = np.ctypeslib.as_array(out.probe_idx, shape=(n,)).copy()
-            b = np.ctypeslib.as_array(out.build_idx, shape=(n,)).copy()
-            return p, b
-        finally:
+        del keep_p, keep_b
+        n = out.n_pairs
+        if n == 0:
             self.L.ivj_pairs_free(C.byref(out))
-            del keep_p, keep_b
+            return np.empty(0, np.int32), np.empty(0, np.int32)
+        # no copy: the arrays view the library's (pre-faulted, huge-page) result buffers, which are freed when the last
+        # view of either array is gone
+        owner = _PairsOwner(load_library(), out)
+        return _owned_view(out.probe_idx, n, owner), _owned_view(out.build_idx, n, owner)
 
     def overlap_rows(self, probe, build, strict: bool, n_contigs: int, partition_mode: int = 0, as_arrow: bool = False):
         """overlap + row materialisation on the device (ivj_overlap_rows): the pair indices AND the key
@@ -532,60 +646,38 @@ class Engine:
         _check(self.L, self.L.ivj_nearest_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), C.c_void_p(idx_ptr),
                                                C.c_void_p(dist_ptr), C.c_void_p(nf_ptr)), "ivj_nearest_dev")
 
-    # ---- streaming: build side resident, probe side in bounded tiles ---------
-    def overlap_batches(self, probe, build, strict: bool, n_contigs: int, batch_rows: int = 8_000_000):
-        """Generator of (probe_idx, build_idx) numpy batches.
+    # ---- streaming: build side resident, probe side in bounded batches ---------
+    def probe_stream(self, build, strict: bool, n_contigs: int, op: int = STREAM_OVERLAP, max_batch_rows: int = 8_000_000, k: int = 1,
+                     include_overlaps: bool = True, partition_mode: int = 0, copy: bool = True) -> ProbeStream:
+        """Open a streaming probe session (ivj_stream_open): see ProbeStream."""
+        return ProbeStream(self, build, strict, n_contigs, op, max_batch_rows, k, include_overlaps, partition_mode, copy)
 
-        The build side is sorted once and stays in HBM; the probe side goes through the device in
-        tiles of ``batch_rows`` rows, so device memory and the size of every result batch are bounded
-        (the reference's streaming probe side + ``low_memory``: docs/developers.md:641-646,
-        polars_bio/range_op.py:168).  probe_idx are rows of the WHOLE probe side."""
+    def overlap_batches(self, probe, build, strict: bool, n_contigs: int, batch_rows: int = 8_000_000):
+        """Generator of (probe_idx, build_idx) numpy batches over a probe side that is already in host arrays.
+
+        The build side is sorted once and stays in HBM; the probe side goes through the device in batches of
+        ``batch_rows`` rows with H2D / join / D2H of consecutive batches overlapped (ProbeStream), so device memory and
+        the size of every result batch are bounded (the reference's streaming probe side + ``low_memory``:
+        docs/developers.md:641-646, polars_bio/range_op.py:168).  probe_idx are rows of the WHOLE probe side."""
         pc, ps, pe = (_i32(a) for a in probe)
-        bc, bs, be = (_i32(a) for a in build)
-        n, nb = pc.shape[0], bc.shape[0]
-        if n == 0 or nb == 0:
+        n = pc.shape[0]
+        if n == 0 or len(build[0]) == 0:
             return
-        opts = make_opts(strict, n_contigs)
-        ptrs = []
-        try:
-            bp = [self.dev_alloc(4 * nb) for _ in range(3)]
-            ptrs += bp
-            for p, col in zip(bp, (bc, bs, be)):
-                self.h2d(p, col)
-            ix = self.index_build_dev(self.dev_side(bp[0], bp[1], bp[2], nb), opts)
-            rows = int(min(batch_rows, n))
-            pp = [self.dev_alloc(4 * rows) for _ in range(4)]       # contig, start, end, row ids of the tile
-            ptrs += pp
-            cap, op, ob = 0, 0, 0
+        rows = int(min(batch_rows, n))
+        with self.probe_stream(build, strict, n_contigs, STREAM_OVERLAP, rows, copy=False) as st:
+            def emit(res):
+                lo = res["batch"] * rows
+                return (res["probe_idx"] + np.int32(lo)), res["build_idx"].copy()
             for lo in range(0, n, rows):
                 hi = min(lo + rows, n)
-                m = hi - lo
-                for p, col in zip(pp[:3], (pc, ps, pe)):
-                    self.h2d(p, col[lo:hi])
-                self.h2d(pp[3], np.arange(lo, hi, dtype=np.int32))
-                side = self.dev_side(pp[0], pp[1], pp[2], m, pp[3])
-                total = self.overlap_count_dev(ix, side, opts)
-                if total > cap:
-                    for q in (op, ob):
-                        if q:
-                            self.dev_free(q)
-                    cap = int(total * 1.25) + 1024
-                    op, ob = self.dev_alloc(4 * cap), self.dev_alloc(4 * cap)
-                if total:
-                    self.overlap_fill_dev(ix, side, opts, op, ob, total)
-                hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
-                if total:
-                    self.d2h(hp, op)
-                    self.d2h(hb, ob)
-                yield hp, hb
-            ix.close()
-            ptrs += [q for q in (op, ob) if q]
-        finally:
-            for q in ptrs:
-                try:
-                    self.dev_free(q)
-                except Exception:
-                    pass
+                res = st.submit((pc[lo:hi], ps[lo:hi], pe[lo:hi]))
+                if res is not None:
+                    yield emit(res)
+            while True:
+                res = st.flush()
+                if res is None:
+                    break
+                yield emit(res)
 
     # ---- raw device memory (callers without torch) --------------------------
     def dev_alloc(self, nbytes: int) -> int:

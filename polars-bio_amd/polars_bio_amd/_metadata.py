@@ -43,7 +43,7 @@ def get_coordinate_system(df) -> Optional[bool]:
     """True = 0-based half-open, False = 1-based closed, None = no metadata."""
     if pd is not None and isinstance(df, pd.DataFrame):
         return _parse_bool(df.attrs.get(COORDINATE_SYSTEM_KEY))
-    if isinstance(df, (pa.Table, pa.RecordBatch)):
+    if isinstance(df, (pa.Table, pa.RecordBatch, pa.RecordBatchReader)):
         md = df.schema.metadata or {}
         return _parse_bool(md.get(COORDINATE_SYSTEM_KEY.encode()))
     if pl is not None and isinstance(df, (pl.DataFrame, pl.LazyFrame)):

@@ -26,7 +26,7 @@ from .constants import DEFAULT_INTERVAL_COLUMNS
 
 logger = logging.getLogger("polars_bio_amd")
 
-__all__ = ["overlap", "overlap_batches", "nearest", "count_overlaps", "coverage", "merge", "cluster", "complement", "subtract",
+__all__ = ["overlap", "overlap_batches", "count_overlaps_batches", "nearest_batches", "nearest", "count_overlaps", "coverage", "merge", "cluster", "complement", "subtract",
            "FilterOp", "RangeOp", "OverlapOutputMode"]
 
 
@@ -115,17 +115,108 @@ def _overlap_device_rows(t1, t2, cols1, cols2, suffixes, zero_based) -> pa.Table
     return A.hconcat(A.with_suffix(res1, suffixes[0]), A.with_suffix(res2, suffixes[1]))
 
 
-def overlap_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, batch_rows: int = 8_000_000):
-    """Streaming form of ``overlap``: yields pyarrow.Table batches of joined rows; the build side
-    (df2) is indexed once on the device, the probe side (df1) streams through it in tiles of
-    ``batch_rows`` rows.  Counterpart of the reference's lazy ``range_lazy_scan`` generator
-    (/root/reference/polars_bio/range_op_io.py:100-174) for Arrow consumers."""
+# ---- result assembly (shared by the eager and the streaming paths) ------------------------------------------------
+
+def _assemble_overlap(t1, t2, p_idx, b_idx, mode, distinct_output, suffixes) -> pa.Table:
+    """src/operation.rs:272-301: df1 columns + suffixes[0], df2 columns + suffixes[1]; "left": df1 columns only."""
+    if mode == OverlapOutputMode.Left:
+        if distinct_output:
+            p_idx = np.unique(p_idx)
+        return A.take_rows(t1, p_idx)
+    return A.hconcat(A.with_suffix(A.take_rows(t1, p_idx), suffixes[0]), A.with_suffix(A.take_rows(t2, b_idx), suffixes[1]))
+
+
+def _assemble_nearest(t1, t2, idx, dist, nf, suffixes, distance) -> pa.Table:
+    """src/operation.rs:170-197: one output row per filled slot; rows without any candidate keep a single null slot."""
+    n1 = t1.num_rows
+    slots = np.maximum(nf, 1)
+    rep = np.repeat(np.arange(n1, dtype=np.int32), slots)
+    first = np.cumsum(slots) - slots
+    within = np.arange(rep.shape[0], dtype=np.int64) - np.repeat(first, slots)
+    b_sel = idx[rep, within] if n1 else np.empty(0, np.int32)
+    d_sel = dist[rep, within] if n1 else np.empty(0, np.int64)
+    res = A.hconcat(A.with_suffix(A.take_rows(t1, rep), suffixes[0]), A.with_suffix(A.take_rows(t2, b_sel, nullable=True), suffixes[1]))
+    if distance:
+        res = res.append_column("distance", pa.array(d_sel, type=pa.int64(), mask=(b_sel < 0)))
+    return res
+
+
+def _assemble_count(t1, counts, naive_query, cols1, suffixes) -> pa.Table:
+    if naive_query:
+        return t1.append_column("count", pa.array(counts, type=pa.int64()))
+    res = pa.table({f"{c}{suffixes[0]}": t1.column(c) for c in cols1})
+    return res.append_column("count", pa.array(counts, type=pa.int64()))
+
+
+# ---- streaming / lazy front end (SURVEY.md section 8f row 3) ----------------------------------------------------
+
+def _stream(op, df1, df2, cols1, cols2, assemble, batch_rows, limit, k=1, include_overlaps=True):
+    from . import _streaming as S
     zero_based = validate_coordinate_systems(df1, df2)
-    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
-    for p_idx, b_idx in default_engine().overlap_batches(probe, build, strict=zero_based, n_contigs=n_contigs,
-                                                         batch_rows=batch_rows):
-        yield A.hconcat(A.with_suffix(A.take_rows(t1, p_idx), suffixes[0]),
-                        A.with_suffix(A.take_rows(t2, b_idx), suffixes[1]))
+    cols1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
+    cols2 = list(DEFAULT_INTERVAL_COLUMNS if cols2 is None else cols2)
+    rows = int(batch_rows) if batch_rows else _low_memory_batch_rows()
+    return zero_based, S.range_batches(default_engine(), op, df1, df2, cols1, cols2, zero_based, assemble, batch_rows=rows, limit=limit,
+                                       k=k, include_overlaps=include_overlaps)
+
+
+def _lazy_reader(df1, df2, zero_based, batches, assemble_empty):
+    """The streaming result as a pyarrow.RecordBatchReader (= an ArrowArrayStream, ``__arrow_c_stream__``); its schema comes
+    from assembling an EMPTY result, so nothing is read or joined before the consumer pulls."""
+    from . import _streaming as S
+    from ._metadata import set_coordinate_system
+    sch1 = S.source_schema(df1)
+    if sch1 is None:                                      # a producer that only reveals its schema with its first batch
+        batches = iter(batches)
+        first = next(batches, None)
+        schema = first.schema if first is not None else pa.schema([])
+        import itertools
+        batches = itertools.chain([first] if first is not None else [], batches)
+    else:
+        t2 = A.to_arrow(df2) if not isinstance(df2, pa.Table) else df2
+        schema = assemble_empty(sch1.empty_table(), t2.slice(0, 0)).schema
+    schema = set_coordinate_system(schema.empty_table(), zero_based).schema
+    return S.range_reader(schema, batches)
+
+
+def overlap_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, batch_rows: int = 8_000_000, limit=None,
+                    overlap_output: str = "join", distinct_output: bool = False, as_reader: bool = False):
+    """Streaming form of ``overlap``: df2 is indexed once on the device, df1 is CONSUMED batch by batch -- an Arrow C stream
+    producer (``__arrow_c_stream__`` / ``pyarrow.RecordBatchReader``), a Parquet / CSV / BED path, or an in-memory frame --
+    and one pyarrow.Table of joined rows is yielded per probe batch (H2D, join and D2H of consecutive batches overlap).
+    ``limit`` bounds the number of result rows and stops reading df1 early.  ``as_reader=True`` returns a
+    pyarrow.RecordBatchReader instead of a generator.  Counterpart of the reference's lazy ``range_lazy_scan`` generator
+    (/root/reference/polars_bio/range_op_io.py:100-174) and ``range_operation_lazy`` (src/lib.rs:154-214)."""
+    mode = _parse_overlap_output_mode(overlap_output)
+    asm = lambda bt, t2, res: _assemble_overlap(bt, t2, res["probe_idx"], res["build_idx"], mode, distinct_output, suffixes)
+    zero_based, gen = _stream("overlap", df1, df2, cols1, cols2, asm, batch_rows, limit)
+    if as_reader:
+        e = np.empty(0, np.int32)
+        return _lazy_reader(df1, df2, zero_based, gen, lambda a, b: _assemble_overlap(a, b, e, e, mode, distinct_output, suffixes))
+    return gen
+
+
+def count_overlaps_batches(df1, df2, suffixes=("", "_"), cols1=None, cols2=None, batch_rows: int = 8_000_000, limit=None,
+                           naive_query: bool = True, as_reader: bool = False):
+    """Streaming form of ``count_overlaps`` (see ``overlap_batches``): df1 rows + ``count`` per probe batch, df1 order kept."""
+    c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
+    asm = lambda bt, t2, res: _assemble_count(bt, res["counts"], naive_query, c1, suffixes)
+    zero_based, gen = _stream("count_overlaps", df1, df2, cols1, cols2, asm, batch_rows, limit)
+    if as_reader:
+        return _lazy_reader(df1, df2, zero_based, gen, lambda a, b: _assemble_count(a, np.empty(0, np.int64), naive_query, c1, suffixes))
+    return gen
+
+
+def nearest_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, k: int = 1, overlap: bool = True, distance: bool = True,
+                    batch_rows: int = 8_000_000, limit=None, as_reader: bool = False):
+    """Streaming form of ``nearest`` (see ``overlap_batches``)."""
+    asm = lambda bt, t2, res: _assemble_nearest(bt, t2, res["build_idx"], res["dist"], res["n_found"], suffixes, distance)
+    zero_based, gen = _stream("nearest", df1, df2, cols1, cols2, asm, batch_rows, limit, k=int(k), include_overlaps=bool(overlap))
+    if as_reader:
+        kk = int(k)
+        return _lazy_reader(df1, df2, zero_based, gen, lambda a, b: _assemble_nearest(a, b, np.empty((0, kk), np.int32), np.empty((0, kk), np.int64),
+                                                                                     np.empty(0, np.int32), suffixes, distance))
+    return gen
 
 
 def _prepare(df1, df2, cols1, cols2):
@@ -151,8 +242,13 @@ def overlap(
     read_options1=None,
     read_options2=None,
     projection_pushdown: bool = True,
+    limit: Union[int, None] = None,
 ):
     """Find pairs of overlapping genomic intervals (reference: range_op.py:117-256).
+
+    ``output_type="pyarrow.RecordBatchReader"`` returns the LAZY result (an ArrowArrayStream: df1 is streamed through the
+    device batch by batch when the consumer pulls); ``limit`` (the reference carries it through its FFI, src/lib.rs:80-88,
+    125-130) bounds the number of result rows -- both take the streaming path (``overlap_batches``).
 
     ``algorithm`` / ``low_memory`` are accepted for call compatibility; the result is
     algorithm-invariant in the reference (tests/test_overlap_algorithms.py:128-171) and the
@@ -164,6 +260,10 @@ def overlap(
     zero_based = validate_coordinate_systems(df1, df2)
     mode = _parse_overlap_output_mode(overlap_output)
     logger.info("Optimizing into IntervalJoinExec using %s algorithm (executed by the HIP engine)", algorithm)
+    if output_type == "pyarrow.RecordBatchReader" or limit is not None:
+        lazy = overlap_batches(df1, df2, suffixes, cols1, cols2, batch_rows=_low_memory_batch_rows(), limit=limit,
+                               overlap_output=overlap_output, distinct_output=distinct_output, as_reader=True)
+        return lazy if output_type == "pyarrow.RecordBatchReader" else A.from_arrow(lazy.read_all(), output_type, zero_based)
     t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
     if mode == OverlapOutputMode.Join and not low_memory and _materialize_on_device():
         return A.from_arrow(_overlap_device_rows(t1, t2, cols1, cols2, suffixes, zero_based), output_type, zero_based)
@@ -176,14 +276,7 @@ def overlap(
         b_idx = np.concatenate([b for _, b in parts]) if parts else np.empty(0, np.int32)
     else:
         p_idx, b_idx = default_engine().overlap(probe, build, strict=zero_based, n_contigs=n_contigs)
-    if mode == OverlapOutputMode.Left:
-        if distinct_output:
-            p_idx = np.unique(p_idx)
-        res = A.take_rows(t1, p_idx)
-    else:
-        res = A.hconcat(A.with_suffix(A.take_rows(t1, p_idx), suffixes[0]),
-                        A.with_suffix(A.take_rows(t2, b_idx), suffixes[1]))
-    return A.from_arrow(res, output_type, zero_based)
+    return A.from_arrow(_assemble_overlap(t1, t2, p_idx, b_idx, mode, distinct_output, suffixes), output_type, zero_based)
 
 
 def nearest(
@@ -199,6 +292,7 @@ def nearest(
     output_type: str = "polars.LazyFrame",
     read_options=None,
     projection_pushdown: bool = True,
+    limit: Union[int, None] = None,
 ):
     """Find the k closest df2 intervals of every df1 interval (reference: range_op.py:259-340;
     column order df1+suffix[0], df2+suffix[1], distance: src/operation.rs:170-197).
@@ -207,23 +301,14 @@ def nearest(
     distance (unpinned in the reference; tests/test_native.py:133-140 drops such rows)."""
     _validate_overlap_input(cols1, cols2, on_cols, suffixes, output_type)
     zero_based = validate_coordinate_systems(df1, df2)
+    if output_type == "pyarrow.RecordBatchReader" or limit is not None:
+        lazy = nearest_batches(df1, df2, suffixes, cols1, cols2, k=k, overlap=overlap, distance=distance,
+                               batch_rows=_low_memory_batch_rows(), limit=limit, as_reader=True)
+        return lazy if output_type == "pyarrow.RecordBatchReader" else A.from_arrow(lazy.read_all(), output_type, zero_based)
     t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
     idx, dist, nf = default_engine().nearest(probe, build, strict=zero_based, n_contigs=n_contigs, k=int(k),
                                              include_overlaps=bool(overlap))
-    n1 = t1.num_rows
-    # one output row per filled slot; rows without any candidate keep a single null slot
-    slots = np.maximum(nf, 1)
-    rep = np.repeat(np.arange(n1, dtype=np.int32), slots)
-    first = np.cumsum(slots) - slots
-    within = np.arange(rep.shape[0], dtype=np.int64) - np.repeat(first, slots)
-    b_sel = idx[rep, within] if n1 else np.empty(0, np.int32)
-    d_sel = dist[rep, within] if n1 else np.empty(0, np.int64)
-    parts = [A.with_suffix(A.take_rows(t1, rep), suffixes[0]),
-             A.with_suffix(A.take_rows(t2, b_sel, nullable=True), suffixes[1])]
-    res = A.hconcat(*parts)
-    if distance:
-        res = res.append_column("distance", pa.array(d_sel, type=pa.int64(), mask=(b_sel < 0)))
-    return A.from_arrow(res, output_type, zero_based)
+    return A.from_arrow(_assemble_nearest(t1, t2, idx, dist, nf, suffixes, distance), output_type, zero_based)
 
 
 def count_overlaps(
@@ -236,6 +321,7 @@ def count_overlaps(
     output_type: str = "polars.LazyFrame",
     naive_query: bool = True,
     projection_pushdown: bool = True,
+    limit: Union[int, None] = None,
 ):
     """Count the df2 intervals overlapping every df1 interval (reference: range_op.py:418-597).
     Output = df1 columns + ``count`` (Int64), df1 row order kept
@@ -245,15 +331,14 @@ def count_overlaps(
     (key columns + suffixes[0]) is honoured."""
     _validate_overlap_input(cols1, cols2, on_cols, suffixes, output_type)
     zero_based = validate_coordinate_systems(df1, df2)
+    if output_type == "pyarrow.RecordBatchReader" or limit is not None:
+        lazy = count_overlaps_batches(df1, df2, suffixes, cols1, cols2, batch_rows=_low_memory_batch_rows(), limit=limit,
+                                      naive_query=naive_query, as_reader=True)
+        return lazy if output_type == "pyarrow.RecordBatchReader" else A.from_arrow(lazy.read_all(), output_type, zero_based)
     t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
     counts = default_engine().count_overlaps(probe, build, strict=zero_based, n_contigs=n_contigs)
-    if naive_query:
-        res = t1.append_column("count", pa.array(counts, type=pa.int64()))
-    else:
-        c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
-        res = pa.table({f"{c}{suffixes[0]}": t1.column(c) for c in c1})
-        res = res.append_column("count", pa.array(counts, type=pa.int64()))
-    return A.from_arrow(res, output_type, zero_based)
+    c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
+    return A.from_arrow(_assemble_count(t1, counts, naive_query, c1, suffixes), output_type, zero_based)
 
 
 # ---- sort-scan family (SURVEY.md section 8f row 2) ----------------------------------------------------

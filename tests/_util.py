@@ -104,6 +104,9 @@ class OracleEngine:
             p, b = O.overlap_fast(ix, O.Side(probe[0][lo:hi], probe[1][lo:hi], probe[2][lo:hi]), strict)
             yield (p + lo).astype(np.int32), b
 
+    def probe_stream(self, build, strict, n_contigs, op=0, max_batch_rows=8_000_000, k=1, include_overlaps=True, partition_mode=0, copy=True):
+        return _OracleStream(build, strict, n_contigs, op, k, include_overlaps)
+
     def count_overlaps(self, probe, build, strict, n_contigs):
         from oracle import oracle as O
         b = O.Side(*build)
@@ -113,3 +116,36 @@ class OracleEngine:
         from oracle import oracle as O
         b = O.Side(*build)
         return O.nearest_fast(O.Index(b, n_contigs), O.Side(*probe), strict, k, include_overlaps)
+
+
+class _OracleStream:
+    """Test double of _engine.ProbeStream: same protocol (results of a batch arrive two calls after its submit), the
+    per-batch answers come from the CPU oracle."""
+
+    def __init__(self, build, strict, n_contigs, op, k, include_overlaps):
+        from oracle import oracle as O
+        self.O, self.ix = O, O.Index(O.Side(*build), n_contigs)
+        self.strict, self.op, self.k, self.inc = strict, op, k, include_overlaps
+        self.queue, self.n = [], 0
+
+    def _answer(self, batch):
+        O, side = self.O, self.O.Side(*batch)
+        out = {"batch": self.n, "n_probe": side.n}
+        if self.op == 0:
+            out["probe_idx"], out["build_idx"] = O.overlap_fast(self.ix, side, self.strict)
+        elif self.op == 1:
+            out["counts"] = O.count_overlaps_fast(self.ix, side, self.strict)
+        else:
+            out["build_idx"], out["dist"], out["n_found"] = O.nearest_fast(self.ix, side, self.strict, self.k, self.inc)
+        self.n += 1
+        return out
+
+    def submit(self, batch):
+        self.queue.append(self._answer(batch))
+        return self.queue.pop(0) if len(self.queue) > 2 else None
+
+    def flush(self):
+        return self.queue.pop(0) if self.queue else None
+
+    def close(self):
+        self.queue = []

@@ -202,7 +202,7 @@ def test_validation_errors(engine):
 
 
 def test_low_memory_and_streaming_batches(engine):
-    """low_memory=True and overlap_batches give the same rows as the one-shot call, in bounded batches."""
+    """low_memory=True and overlap_batches against the ORACLE's pair list (not the one-shot engine call), in bounded batches."""
     rng = np.random.default_rng(3)
     n1, n2 = 5000, 800
     df1 = pd.DataFrame({"chrom": rng.choice(["chr1", "chr2", "chrX"], n1), "start": rng.integers(0, 100000, n1)})
@@ -212,7 +212,12 @@ def test_low_memory_and_streaming_batches(engine):
     df2["end"] = df2["start"] + rng.integers(1, 3000, n2)
     for d in (df1, df2):
         d.attrs["coordinate_system_zero_based"] = True
-    full = pb.overlap(df1, df2, output_type="pandas.DataFrame")
+    from oracle import oracle as O
+    (c1, c2), nc = O.encode_contigs(df1["chrom"].tolist(), df2["chrom"].tolist())
+    ep, eb = O.overlap_fast(O.Index(O.Side(c2, df2["start"].to_numpy(), df2["end"].to_numpy()), nc),
+                            O.Side(c1, df1["start"].to_numpy(), df1["end"].to_numpy()), True)
+    full = pd.concat([df1.iloc[ep].reset_index(drop=True).add_suffix("_1"), df2.iloc[eb].reset_index(drop=True).add_suffix("_2")], axis=1)
+    assert len(full) > 1000
     pb.set_option("ivj.low_memory_batch_rows", 1500)
     try:
         low = pb.overlap(df1, df2, low_memory=True, output_type="pandas.DataFrame")
@@ -220,7 +225,7 @@ def test_low_memory_and_streaming_batches(engine):
         pb.set_option("ivj.low_memory_batch_rows", 8000000)
     pd.testing.assert_frame_equal(_sorted(low), _sorted(full))
     batches = list(pb.overlap_batches(df1, df2, batch_rows=1024))
-    assert len(batches) == 5 and all(isinstance(b, pa.Table) for b in batches)
+    assert len(batches) >= 5 and all(isinstance(b, pa.Table) for b in batches)
     cat = pa.concat_tables(batches).to_pandas()
     pd.testing.assert_frame_equal(_sorted(cat), _sorted(full))
 
