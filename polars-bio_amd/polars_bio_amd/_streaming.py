@@ -150,7 +150,10 @@ def range_batches(engine, op: str, df1, df2, cols1, cols2, zero_based: bool, ass
         return
     batch_rows = int(max(1, batch_rows))
     pending = {}
-    stream = engine.probe_stream(build, zero_based, n_contigs, code, batch_rows, k=k, include_overlaps=include_overlaps, copy=False)
+    # overlap / nearest results are only used as gather indices (the assembled tables own fresh buffers); the counts column
+    # would be wrapped zero-copy by pyarrow and must therefore not view the stream's recycled pinned slot
+    stream = engine.probe_stream(build, zero_based, n_contigs, code, batch_rows, k=k, include_overlaps=include_overlaps,
+                                 copy=(op == "count_overlaps"))
     try:
         def deliver(res):
             nonlocal left
