@@ -94,7 +94,7 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         return IVJ_OK;
     }
     SliceGeom sg;
-    if (want_slices(ix, n, opts, sg)) {
+    if (want_slices(ix, n, opts, sg, false)) {
         int64_t total = 0;
         IVJ_TRY(slice_overlap_count(ctx, ix, probe, opts, sg, &total));
         ctx->ov_slice = true;
@@ -176,7 +176,7 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         // sparse results of large inputs: LDS-resident index slices; dense ones (capacity says >= 16 pairs per probe) keep the flat kernel
         SliceGeom sg;
         const bool dense = opts->partition_mode == 0 && capacity >= 16 * n && ix->n_contigs > 0;
-        if (!dense && want_slices(ix, n, opts, sg)) return slice_overlap_fused(ctx, ix, probe, opts, sg, out_p, out_b, capacity, n_pairs);
+        if (!dense && want_slices(ix, n, opts, sg, true)) return slice_overlap_fused(ctx, ix, probe, opts, sg, out_p, out_b, capacity, n_pairs);
     }
     const bool part = want_partition(ix, n, opts);
     IVJ_TRY(ensure_ov(ctx, n, part ? 1 : 0));

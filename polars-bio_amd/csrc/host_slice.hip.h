@@ -33,12 +33,17 @@ bool slice_geom(const ivj_index* ix, const ivj_opts* opts, SliceGeom& g) {
     return true;
 }
 
-// the slice path serves the overlap pair kernels (count / fill / fused) of large inputs; explicit with partition_mode 6
-bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, SliceGeom& g) {
-    // explicit (partition_mode 6), or auto when the context says so (IVJ_SLICE_AUTO=1: the measured step times of the two
-    // paths are within a few percent of each other on config 3; the 256-bucket path stays the default)
+// The slice path serves the overlap pair kernels: always with partition_mode 6; in auto mode for the FUSED single pass of
+// large inputs (config 3: 3.41 ms per step against 3.65 ms on the 256-bucket path).  The deterministic count -> fill pair
+// keeps the 256-bucket path in auto mode (its stable scatter and the second matching pass make the slice pair slower:
+// 4.9 against 4.5 ms).  IVJ_SLICE_AUTO=0 / 2 switches the auto choice off / on for both (A/B runs).
+bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, SliceGeom& g, bool fused) {
     if (opts->partition_mode != 0 && opts->partition_mode != 6) return false;
-    if (opts->partition_mode == 0 && !(ix->ctx && ix->ctx->sl_env_auto && n_probe >= (4ll << 20) && ix->n >= (256ll << 10))) return false;
+    if (opts->partition_mode == 0) {
+        const int mode = ix->ctx ? ix->ctx->sl_env_auto : 1;
+        const bool on = mode == 2 || (mode == 1 && fused);
+        if (!(on && n_probe >= (4ll << 20) && ix->n >= (256ll << 10))) return false;
+    }
     return slice_geom(ix, opts, g);
 }
 
@@ -119,7 +124,7 @@ int set_dyn_lds(K kernel, size_t bytes) {
 }
 
 // probe side -> bucket-ordered 16-byte records + chunk table of the join
-int slice_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const SlicePlan& P) {
+int slice_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const SlicePlan& P, bool ordered) {
     const int64_t n = probe->n;
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
     IVJ_TRY(ensure_splitters(ctx, ix, P.g));
@@ -139,6 +144,22 @@ int slice_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const iv
     device_scan<uint32_t, SumOp, false>(ctx, "slice_scan", ctx->sl_blk, ctx->sl_blk, (int64_t)hist, 0u, ctx->sl_part, (uint32_t*)nullptr);
     LAUNCH(ctx, "slice_chunks", k_slice_chunks, 1, SL_THREADS, (const uint32_t*)ctx->sl_blk, P.nchunks, P.g.nb, n, P.jchunk, ctx->sl_bstart,
            ctx->sl_meta, ctx->sl_map);
+    if (!ordered && !ctx->sl_env_stable) {                            // IVJ_SLICE_STABLE=1 forces the stable scatter (A/B runs)
+        const size_t ulds = (size_t)slice_part_u_lds(P.g.nb, P.g.ncells).total;
+        if (strict) IVJ_TRY(set_dyn_lds(&k_slice_scatter_u<true>, ulds)); else IVJ_TRY(set_dyn_lds(&k_slice_scatter_u<false>, ulds));
+        t_begin(ctx, "slice_scatter_u");
+        if (strict)
+            hipLaunchKernelGGL((k_slice_scatter_u<true>), dim3(P.nchunks), dim3(SL_THREADS), ulds, ctx->stream, (const unsigned long long*)ix->spl, tab, P.g,
+                               ix->n_contigs, probe->contig, probe->start, probe->end, probe->row_id, n, P.chunk, P.nchunks,
+                               (const uint32_t*)ctx->sl_blk, ctx->sl_rec);
+        else
+            hipLaunchKernelGGL((k_slice_scatter_u<false>), dim3(P.nchunks), dim3(SL_THREADS), ulds, ctx->stream, (const unsigned long long*)ix->spl, tab, P.g,
+                               ix->n_contigs, probe->contig, probe->start, probe->end, probe->row_id, n, P.chunk, P.nchunks,
+                               (const uint32_t*)ctx->sl_blk, ctx->sl_rec);
+        t_end(ctx);
+        HIP_TRY(hipGetLastError());
+        return IVJ_OK;
+    }
     if (strict) IVJ_TRY(set_dyn_lds(&k_slice_scatter<true>, P.part_lds)); else IVJ_TRY(set_dyn_lds(&k_slice_scatter<false>, P.part_lds));
     t_begin(ctx, "slice_scatter");
     if (strict) {
@@ -193,7 +214,7 @@ int slice_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, cons
     SlicePlan P;
     IVJ_TRY(slice_plan(ix, probe->n, opts, g, ctx->sl_items, P));
     IVJ_TRY(ensure_sl(ctx, probe->n, P));
-    IVJ_TRY(slice_partition(ctx, ix, probe, opts, P));
+    IVJ_TRY(slice_partition(ctx, ix, probe, opts, P, true));
     HIP_TRY(hipMemsetAsync(ctx->sl_tile, 0, (size_t)(P.ntiles + 2) * 8, ctx->stream));
     IVJ_TRY(slice_join_launch<SL_COUNT>(ctx, ix, opts, P, 0, nullptr, nullptr));
     device_scan<long long, SumOp, false>(ctx, "tile_scan", ctx->sl_tile, ctx->sl_tile, P.ntiles, 0ll, ctx->sl_tpart, ctx->sl_tile + P.ntiles);
@@ -217,7 +238,7 @@ int slice_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, cons
     IVJ_TRY(slice_plan(ix, probe->n, opts, g, ctx->sl_items, P));
     IVJ_TRY(ensure_sl(ctx, probe->n, P));
     ctx->sl_plan_valid = false;
-    IVJ_TRY(slice_partition(ctx, ix, probe, opts, P));
+    IVJ_TRY(slice_partition(ctx, ix, probe, opts, P, false));
     HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
     IVJ_TRY(slice_join_launch<SL_FUSED>(ctx, ix, opts, P, (long long)capacity, out_p, out_b));
     HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_meta + 4, 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -417,6 +417,118 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_scatter(const unsigned lon
     }
 }
 
+// ---- partition, pass 2, unordered variant (fused single-pass join only) ---------------------------------------------
+// Same tiles, same output layout, but the rank of a record inside (tile, bucket) comes from ONE returning LDS atomic instead
+// of match-any ballots + per-wavefront counter rows + a prefix over the wavefronts: less than half the instructions.  The
+// order of the records inside a bucket then depends on the timing of the wavefronts, i.e. is not reproducible from run to
+// run -- which the fused join's output is not either (its tiles land in reservation order); the pairs of one probe row stay
+// contiguous because a probe is one record.  The count -> fill pair keeps the stable scatter above.
+// (Writing the records straight from registers to their global slot -- no staging, two barriers per tile, 32 KB of LDS -- was
+// measured as well: 1.38 ms against 0.99 ms for config 3; scattered 16-byte stores cost more than the staging they save.)
+struct SlicePartULds { int cm, cell, spl, base, lstart, delta, cnt, rec, d, wsum, total; };
+__host__ __device__ inline SlicePartULds slice_part_u_lds(int nb, int ncells) {
+    SlicePartULds L;
+    int o = 0;
+    L.cm = o; o += ncells ? 16 * SL_TAB_CONTIGS : 0;
+    L.spl = o; o += 8 * nb;
+    L.cell = o; o += 4 * ncells;
+    L.rec = (o + 15) & ~15; o = L.rec + 16 * SL_TILE;
+    L.base = o; o += 4 * (nb + 2);
+    L.lstart = o; o += 4 * (nb + 2);
+    L.delta = o; o += 4 * (nb + 2);
+    L.cnt = o; o += 4 * (nb + 2);
+    L.d = (o + 3) & ~3; o = L.d + 2 * SL_TILE;
+    L.wsum = (o + 15) & ~15; o = L.wsum + 4 * 2 * SL_WAVES;
+    L.total = o;
+    return L;
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(SL_THREADS) void k_slice_scatter_u(const unsigned long long* __restrict__ spl, SliceTab tab, SliceGeom g, int32_t n_contigs,
+                                                               const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                               const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
+                                                               int chunk, int nchunks, const uint32_t* __restrict__ blk_off,
+                                                               int4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sl_lds[];
+    const SlicePartULds L = slice_part_u_lds(g.nb, g.ncells);
+    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(sl_lds + L.spl);
+    int4* l_cm = reinterpret_cast<int4*>(sl_lds + L.cm);
+    uint32_t* l_cell = reinterpret_cast<uint32_t*>(sl_lds + L.cell);
+    int4* l_rec = reinterpret_cast<int4*>(sl_lds + L.rec);
+    uint32_t* base = reinterpret_cast<uint32_t*>(sl_lds + L.base);
+    uint32_t* lstart = reinterpret_cast<uint32_t*>(sl_lds + L.lstart);
+    uint32_t* delta = reinterpret_cast<uint32_t*>(sl_lds + L.delta);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(sl_lds + L.cnt);
+    unsigned short* l_d = reinterpret_cast<unsigned short*>(sl_lds + L.d);
+    int* wsum = reinterpret_cast<int*>(sl_lds + L.wsum);
+    const int tid = threadIdx.x;
+    const int nbk = g.nb + 1;
+    for (int k = tid; k < g.nb; k += SL_THREADS) l_spl[k] = spl[k];
+    for (int k = tid; k < g.ncells; k += SL_THREADS) l_cell[k] = tab.cell[k];
+    if (g.ncells) for (int k = tid; k < n_contigs; k += SL_THREADS) l_cm[k] = tab.cm[k];
+    for (int k = tid; k < nbk + 1; k += SL_THREADS) { base[k] = k < nbk ? blk_off[(int64_t)k * nchunks + blockIdx.x] : 0u; cnt[k] = 0; }
+    __syncthreads();
+    const int64_t cbase = (int64_t)blockIdx.x * chunk;
+    const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
+    int32_t nc[SL_ITEMS], ns[SL_ITEMS], ne[SL_ITEMS], nr[SL_ITEMS];
+    auto load_tile = [&](int64_t tbase) {
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) {
+            const int64_t i = tbase + j * SL_THREADS + tid;
+            const bool valid = i < cend;
+            nc[j] = valid ? __builtin_nontemporal_load(pc + i) : -1;
+            ns[j] = valid ? __builtin_nontemporal_load(ps + i) : 0;
+            ne[j] = valid ? __builtin_nontemporal_load(pe + i) : 0;
+            nr[j] = valid ? (row_id ? __builtin_nontemporal_load(row_id + i) : (int32_t)i) : -1;
+        }
+    };
+    load_tile(cbase);
+    int tix = 0;
+    for (int64_t tbase = cbase; tbase < cend; tbase += SL_TILE, ++tix) {
+        int32_t c[SL_ITEMS], s[SL_ITEMS], e[SL_ITEMS], r[SL_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) { c[j] = nc[j]; s[j] = ns[j]; e[j] = ne[j]; r[j] = nr[j]; }
+        if (tbase + SL_TILE < cend) load_tile(tbase + SL_TILE);
+        const int tile_n = (int)((cend - tbase) < (int64_t)SL_TILE ? (cend - tbase) : (int64_t)SL_TILE);
+        uint32_t d[SL_ITEMS], rank[SL_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) {
+            const bool valid = j * SL_THREADS + tid < tile_n;
+            d[j] = !valid ? 0u : (g.ncells ? slice_bucket_tab<STRICT>(l_spl, l_cm, l_cell, g, n_contigs, c[j], e[j])
+                                           : slice_bucket<STRICT>(l_spl, g, n_contigs, c[j], e[j]));
+            rank[j] = valid ? atomicAdd(&cnt[d[j]], 1u) : 0u;
+        }
+        __syncthreads();                                                        // (A) bucket counts of the tile complete
+        // thread t owns buckets 2t, 2t+1: advance the global offsets by the previous tile's totals (kept in `lstart` deltas),
+        // tile-local starts, copy-out deltas; the counters are cleared for the next tile
+        int x0 = 0, x1 = 0;
+        const int b0 = 2 * tid;
+        if (b0 < nbk) { x0 = (int)cnt[b0]; cnt[b0] = 0; if (b0 + 1 < nbk) { x1 = (int)cnt[b0 + 1]; cnt[b0 + 1] = 0; } }
+        long long tsum;
+        const int pre = (int)sl_block_exclusive_sum_i32(x0 + x1, wsum + (tix & 1) * SL_WAVES, &tsum);      // (B)
+        if (b0 < nbk) {
+            lstart[b0] = (uint32_t)pre; delta[b0] = base[b0] - (uint32_t)pre; base[b0] += (uint32_t)x0;
+            if (b0 + 1 < nbk) { lstart[b0 + 1] = (uint32_t)(pre + x0); delta[b0 + 1] = base[b0 + 1] - (uint32_t)(pre + x0); base[b0 + 1] += (uint32_t)x1; }
+        }
+        __syncthreads();                                                        // (C)
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) {
+            if (j * SL_THREADS + tid < tile_n) {
+                const uint32_t pos = lstart[d[j]] + rank[j];
+                l_rec[pos] = make_int4(s[j], e[j], r[j], c[j]);
+                l_d[pos] = (unsigned short)d[j];
+            }
+        }
+        __syncthreads();                                                        // (D) tile sorted in LDS
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; ++j) {
+            const int il = j * SL_THREADS + tid;
+            if (il < tile_n) out[(int64_t)((uint32_t)il + delta[l_d[il]])] = l_rec[il];
+        }
+        // no barrier here: the next tile's barrier (A) separates this copy-out from the next placement
+    }
+}
+
 // ---- the join ---------------------------------------------------------------------------------------------------------
 enum { SL_COUNT = 0, SL_FILL = 1, SL_FUSED = 2 };
 
@@ -694,12 +806,163 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
         }
     };
 
+    if constexpr (MODE == SL_FUSED) {
+        // ---- fused single pass, barrier-free tile loop ------------------------------------------------------------------
+        // A workgroup barrier per tile costs this kernel ~0.3 ms on config 3 (16 wavefronts with data-dependent timing wait
+        // for the slowest one, and nothing else is resident on the CU).  Here the wavefronts run the tile loop independently:
+        //   * a wavefront's pairs of a tile are contiguous in the tile's output range, at the offset a returning LDS atomic on
+        //     the tile's cursor gives it (arrival order: the fused output order is not reproducible anyway);
+        //   * the LAST wavefront to arrive at a tile reserves the tile's range with the one global atomic and publishes the
+        //     base in LDS; the others only look at it one iteration later, after they have staged their pairs (wavefront-
+        //     private staging region) and matched the next tile -- by then it is there (split-phase: arrive early, wait late);
+        //   * two control blocks {cursor, base; arrived, done, ready, seq} alternate; a block is recycled by the last
+        //     wavefront that finishes its tile.
+        // Every wait is for an event of an EARLIER tile, and all 16 wavefronts of the workgroup are resident: no deadlock.
+        // two control blocks: 64-bit {cursor, base} and 32-bit {arrived, done, ready, seq}
+        unsigned long long* lc = reinterpret_cast<unsigned long long*>(wsum);  // [2][2]
+        int* li = reinterpret_cast<int*>(wsum + 4);                            // [2][4]
+        if (tid < 4) lc[tid] = 0;
+        if (tid < 8) li[tid] = (tid == 7) ? 1 : 0;                             // block 1 serves tile 1 first (seq = li[1][3])
+        __syncthreads();
+        const int lane = tid & (kWave - 1), wv = tid / kWave;
+        const int wcap = A.stage / SL_WAVES;                                   // pairs of wavefront-private staging
+        int2* stw = st + wv * wcap;
+        auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+        auto stv = [](int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+        load_tile(q0);
+        const int ntile = (int)((q1 - q0 + TILE - 1) / TILE);
+        int pend_wtot = -1;                                                    // this wavefront's staged pairs of the previous tile
+        long long pend_woff = 0;
+        for (int tix = 0; tix <= ntile; ++tix) {
+            if (tix < ntile) match_tile(q0 + (int64_t)tix * TILE);
+            if (tix > 0) {
+                // finish tile tix - 1: its base was requested one iteration ago
+                int* c = li + ((tix - 1) & 1) * 4;
+                unsigned long long* c64 = lc + ((tix - 1) & 1) * 2;
+                for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
+                const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tb >= 0 && pend_wtot > 0 && pend_wtot <= wcap && !(A.ablate & 32)) {
+                    for (int i = lane; i < pend_wtot; i += kWave) {
+                        const int2 pr = stw[i];
+                        __builtin_nontemporal_store(pr.x, A.out_probe + tb + pend_woff + i);
+                        __builtin_nontemporal_store(pr.y, A.out_build + tb + pend_woff + i);
+                    }
+                }
+                if (lane == 0) {
+                    if (atomicAdd(c + 1, 1) == SL_WAVES - 1) {                 // last wavefront out: recycle the block for tile tix + 1
+                        __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        stv(c + 0, 0); stv(c + 1, 0); stv(c + 2, 0);
+                        stv(c + 3, tix + 1);
+                    }
+                }
+            }
+            if (tix == ntile) break;
+            int* c = li + (tix & 1) * 4;
+            unsigned long long* c64 = lc + (tix & 1) * 2;
+            for (int spin = 0; ld(c + 3) != tix && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // the block is ours (recycled after tile tix - 2)
+            int lsum = 0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) lsum += cnt[j];
+            const int linc = wave_inclusive_scan(lsum, SumOp());
+            const int wtot = __shfl(linc, kWave - 1, kWave);
+            long long woff = 0;
+            if (lane == 0) {
+                woff = (long long)atomicAdd(c64, (unsigned long long)wtot);
+                if (atomicAdd(c + 0, 1) == SL_WAVES - 1) {                     // last wavefront in: the tile's total is complete
+                    const long long total = (long long)__hip_atomic_load(c64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    long long base = 0;
+                    if (total > 0) {
+                        base = (long long)atomicAdd(&A.state[0], (unsigned long long)total);
+                        if (base + total > A.capacity) { atomicExch(&A.state[1], 1ull); base = -1; }
+                    }
+                    __hip_atomic_store(c64 + 1, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    stv(c + 2, 1);
+                }
+            }
+            woff = ((long long)__shfl((int)(woff >> 32), 0, kWave) << 32) | (unsigned long long)(unsigned int)__shfl((int)(woff & 0xffffffffll), 0, kWave);
+            if (wtot > 0 && wtot <= wcap) {
+                int off = linc - lsum;                                         // this lane's first slot in the wavefront's region
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    if (cnt[j] != 0 && !(A.ablate & 128)) {
+                        if (!lng[j]) {
+                            uint32_t m = mask[j];
+                            int o = off;
+                            const int32_t* pr = l_row + (lo_s[j] - 1);
+                            while (m) {
+                                const int jj = 31 - __clz(m);
+                                m &= ~(1u << jj);
+                                if (!(A.ablate & 16)) stw[o] = make_int2(qrow[j], pr[-jj]);
+                                ++o;
+                            }
+                        } else {
+                            int o = off + cnt[j] - 1;
+                            for (int pp = hi[j] - 1; o >= off; --pp) {
+                                const int2 vv = slice_ep(l_end, l_pmax, A.ep, pp, r0);
+                                if (lt_op<STRICT>(qs[j], vv.x)) { stw[o] = make_int2(qrow[j], slice_row(l_row, A.b_row, pp, r0)); --o; }
+                            }
+                        }
+                    }
+                    off += cnt[j];
+                }
+            } else if (wtot > wcap) {
+                // dense wavefront: its pairs do not fit the staging region -- wait for the base now and write them from the lanes
+                for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
+                const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tb >= 0) {
+                    long long off = tb + woff + (linc - lsum);
+#pragma unroll
+                    for (int j = 0; j < ITEMS; ++j) {
+                        long long o = off + cnt[j] - 1;                        // the f-th match from the top of the window owns slot end - 1 - f
+                        for (int pp = hi[j] - 1; o >= off; --pp) {
+                            const int2 vv = slice_ep(l_end, l_pmax, A.ep, pp, r0);
+                            if (lt_op<STRICT>(qs[j], vv.x)) { A.out_probe[o] = qrow[j]; A.out_build[o] = slice_row(l_row, A.b_row, pp, r0); --o; }
+                        }
+                        off += cnt[j];
+                    }
+                }
+            }
+            pend_wtot = wtot; pend_woff = woff;
+        }
+        return;
+    }
+    // Tile loop, rotated so that the matching code exists once: iteration t matches tile t, THEN finishes tile t - 1 (reads
+    // the output base its atomic reserved one iteration ago, copies its staged pairs out), then scans / reserves / stages
+    // tile t.  The atomic's round trip (microseconds under load) is thus hidden behind the staging of its own tile and the
+    // matching of the next one.
     load_tile(q0);
-    match_tile(q0);
     const int tiles_per_chunk = A.jchunk / TILE;
-    int tix = 0;
-    for (int64_t tb = q0; tb < q1; tb += TILE, ++tix) {
-        const bool have_next = tb + TILE < q1;                                 // uniform
+    const int ntile = (int)((q1 - q0 + TILE - 1) / TILE);
+    long long pend_tot = 0, pend_reserved = 0, pend_base = 0;                  // tile whose pairs sit in `st`, waiting for copy-out
+    bool pending = false;
+    auto finish_pending = [&]() {
+        if (!pending) return;                                                  // uniform
+        long long tbase = pend_base;
+        bool skip = false;
+        if (MODE == SL_FUSED) {
+            if (tid == 0) {
+                if (pend_reserved + pend_tot > A.capacity) { atomicExch(&A.state[1], 1ull); *s_base = -1; }
+                else *s_base = pend_reserved;
+            }
+            __syncthreads();                                                   // staging + base visible
+            tbase = *s_base;
+            skip = tbase < 0;                                                  // uniform: over capacity, nothing is written
+        } else if (!(A.ablate & 64)) __syncthreads();
+        if (!skip && !(A.ablate & 32)) {
+            const int t = (int)pend_tot;
+            for (int i = tid; i < t; i += SL_THREADS) {
+                const int2 pr = st[i];
+                __builtin_nontemporal_store(pr.x, A.out_probe + tbase + i);
+                __builtin_nontemporal_store(pr.y, A.out_build + tbase + i);
+            }
+        }
+        if (!(A.ablate & 64)) __syncthreads();                                 // staging buffer (and s_base) free again
+        pending = false;
+    };
+    for (int tix = 0; tix <= ntile; ++tix) {
+        if (tix < ntile) match_tile(q0 + (int64_t)tix * TILE);
+        if (MODE != SL_COUNT) finish_pending();
+        if (tix == ntile) break;
         const long long tile_id = (long long)v * tiles_per_chunk + tix;
         if (MODE == SL_COUNT) {
             // only the tile total is needed: wavefront sums go straight to the (zeroed) tile slot, no workgroup barrier
@@ -709,7 +972,6 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
 #pragma unroll
             for (int d = kWave / 2; d > 0; d >>= 1) wsum_c += __shfl_xor(wsum_c, d, kWave);
             if ((tid & (kWave - 1)) == 0 && wsum_c) atomicAdd(reinterpret_cast<unsigned long long*>(A.tile_tot + tile_id), (unsigned long long)wsum_c);
-            if (have_next) match_tile(tb + TILE);
             continue;
         }
         // exclusive offsets of the tile's pairs (one barrier)
@@ -721,10 +983,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             if (A.ablate & 4) { loc0 = (long long)tsum32 * tid; tot = (long long)tsum32 * SL_THREADS; }
             else loc0 = sl_block_exclusive_sum_i32(tsum32, reinterpret_cast<int*>(wsum) + (tix & 1) * SL_WAVES, &tot);
         }
-        if (tot == 0) { if (have_next) match_tile(tb + TILE); continue; }     // uniform
-        // FUSED: the tile reserves its output range with ONE atomic.  Its round trip (microseconds under load) is hidden
-        // behind the staging of this tile's pairs AND the matching of the next tile: the reserved base is only read
-        // right before the copy-out.
+        if (tot == 0) continue;                                                // uniform
+        // FUSED: the tile reserves its output range with ONE atomic; the value is only read in finish_pending()
         long long tbase = MODE == SL_FILL ? A.tile_tot[tile_id] : 0;
         long long reserved = 0;
         if (MODE == SL_FUSED && tid == 0) reserved = (long long)atomicAdd(&A.state[0], (unsigned long long)tot);
@@ -735,7 +995,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             int off = (int)loc0;
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
-                if (cnt[j] != 0) {
+                if (cnt[j] != 0 && !(A.ablate & 128)) {
                     if (!lng[j]) {
                         uint32_t m = mask[j];
                         int o = off;
@@ -756,29 +1016,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                 }
                 off += cnt[j];
             }
-            if (have_next) match_tile(tb + TILE);                              // overwrites the per-probe state: this tile lives in `st` now
-            bool skip = false;
-            if (MODE == SL_FUSED) {
-                if (tid == 0) {
-                    if (reserved + tot > A.capacity) { atomicExch(&A.state[1], 1ull); *s_base = -1; }
-                    else *s_base = reserved;
-                }
-                __syncthreads();                                               // staging + base visible
-                tbase = *s_base;
-                skip = tbase < 0;                                              // uniform: over capacity, nothing is written
-            } else __syncthreads();
-            if (!skip && !(A.ablate & 32)) {
-                const int t = (int)tot;
-                for (int i = tid; i < t; i += SL_THREADS) {
-                    const int2 pr = st[i];
-                    __builtin_nontemporal_store(pr.x, A.out_probe + tbase + i);
-                    __builtin_nontemporal_store(pr.y, A.out_build + tbase + i);
-                }
-            }
-            __syncthreads();                                                   // staging buffer (and s_base) free again
+            pending = true; pend_tot = tot; pend_reserved = reserved; pend_base = tbase;
             continue;
         }
-        // dense tile: several staging windows, no overlap with the next tile
+        // dense tile: several staging windows, emitted at once
         bool have_base = MODE == SL_FILL;
         for (long long w0 = 0; w0 < tot; w0 += A.stage) {
             const long long w1 = w0 + A.stage;
@@ -828,7 +1069,6 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             }
             __syncthreads();
         }
-        if (have_next) match_tile(tb + TILE);
     }
 }
 
