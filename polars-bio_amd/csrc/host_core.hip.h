@@ -132,6 +132,7 @@ struct ivj_index {
     int sl_R = 0, sl_nb = 0, sl_ncells = -1;   //   geometry the splitters were made for (0: none yet)
     int4* sl_cm = nullptr;               //   direct-address table over the splitters: per-contig grid, cells
     uint32_t* sl_cell = nullptr;
+    bool tables_built = false;   // the direct-address tables exist (built on first use)
     bool has_tables = true;    // false: built for merge / cluster only (with_end_order & 2)     // rec4 is filled on demand (join + materialisation path, flat path)
     char* slab = nullptr;      // single allocation holding every array above
     size_t slab_cap = 0;

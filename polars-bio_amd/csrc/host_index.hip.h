@@ -4,9 +4,14 @@
 
 namespace {
 
-int need_tables(const ivj_index* ix) {
-    if (ix->has_tables) return IVJ_OK;
-    return fail(IVJ_ESTATE, "this index was built for merge / cluster only (with_end_order & 2): it has no lookup tables");
+int build_tables(ivj_ctx* ctx, ivj_index* ix);
+
+// The direct-address tables (bins / brec over the starts) are built on first use: the slice path of pb.overlap never needs
+// them, the window-scan kernels, nearest, count_overlaps, coverage and subtract do.
+int need_tables(ivj_ctx* ctx, ivj_index* ix) {
+    if (!ix->has_tables) return fail(IVJ_ESTATE, "this index was built for merge / cluster only (with_end_order & 2): it has no lookup tables");
+    if (ix->tables_built) return IVJ_OK;
+    return build_tables(ctx, ix);
 }
 
 int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
@@ -87,7 +92,7 @@ int build_rec4(ivj_ctx* ctx, ivj_index* ix) {
 // bin table; rec4.  Filled on first use (dense results, partition_mode 5).
 int build_flat(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->has_flat || ix->n == 0 || ix->n_contigs <= 0) return IVJ_OK;
-    IVJ_TRY(need_tables(ix));
+    IVJ_TRY(need_tables(ctx, ix));
     IVJ_TRY(arena_reserve(ctx, align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4) + 4096));
     uint32_t* part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
     HIP_TRY(hipMemsetAsync(ix->lot, 0, (size_t)ix->bins_len * 4, ctx->stream));
@@ -140,6 +145,7 @@ int index_sort_v1(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
             LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
                    (const int32_t*)ix->b_start, (const int4*)ix->cmeta, opts->n_contigs, ix->brec);
         }
+        ix->tables_built = true;
     }
     return IVJ_OK;
 }
@@ -158,8 +164,8 @@ int index_sort_v2(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     if (chunk < OS_TILE) chunk = OS_TILE;
     const int nchunks = (int)((n + chunk - 1) / chunk);
     const int64_t hist_len = (int64_t)OS_RADIX * nchunks;
-    const int64_t lb_tiles = (ix->bins_len + LB_TILE - 1) / LB_TILE, hs_tiles = (hist_len + LB_TILE - 1) / LB_TILE;
-    const size_t z_meta = align_up(sizeof(OsMeta)), z_fin = align_up((size_t)tiles * 8), z_lb = align_up((size_t)lb_tiles * 8),
+    const int64_t hs_tiles = (hist_len + LB_TILE - 1) / LB_TILE;
+    const size_t z_meta = align_up(sizeof(OsMeta)), z_fin = align_up((size_t)tiles * 8), z_lb = 0,
                  z_hs = align_up((size_t)hs_tiles * 8) * (size_t)passes_max, z_hist = align_up((size_t)hist_len * 4) * (size_t)passes_max,
                  z_tick = align_up((size_t)(passes_max + 2) * 4);
     const size_t zero_bytes = z_meta + z_fin + z_lb + z_hs + z_hist + z_tick;
@@ -169,13 +175,10 @@ int index_sort_v2(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     int4* recB = arena_take<int4>(ctx, n);
     OsMeta* meta = (OsMeta*)z;
     unsigned long long* st_fin = (unsigned long long*)(z + z_meta);
-    unsigned long long* st_lb = (unsigned long long*)(z + z_meta + z_fin);
     char* st_hs = z + z_meta + z_fin + z_lb;
     char* hists = st_hs + z_hs;
-    uint32_t* tickets = (uint32_t*)(hists + z_hist);                 // look-back scan tickets: one per pass + the table scan
+    uint32_t* tickets = (uint32_t*)(hists + z_hist);                 // look-back scan tickets: one per pass
     HIP_TRY(hipMemsetAsync(z, 0, zero_bytes, ctx->stream));
-    const bool tables = ix->has_tables && nc > 0;
-    if (tables) HIP_TRY(hipMemsetAsync(ix->bins, 0, (size_t)ix->bins_len * 4, ctx->stream));
     const unsigned sgrid = (unsigned)(tiles < 512 ? tiles : 512);
     LAUNCH(ctx, "ix_minmax", k_ix_minmax, sgrid, OS_THREADS, build->start, build->end, build->contig, n, nc, meta);
     auto hist_of = [&](int p) { return (uint32_t*)(hists + (size_t)p * align_up((size_t)hist_len * 4)); };
@@ -205,15 +208,32 @@ int index_sort_v2(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     }
     LAUNCH(ctx, "ix_final", k_ix_final, tiles, OS_THREADS, (const int4*)recA, (const int4*)recB, n, nc, cbits, meta, st_fin, ix->b_start, ix->ep, ix->b_row,
            ix->b_contig, ix->seg, ix->flags);
-    if (tables) {
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+// direct-address table over the starts (lazily, on the sorted index): per-contig geometry, head marks, look-back max-scan,
+// 16-byte bin records
+int build_tables(ivj_ctx* ctx, ivj_index* ix) {
+    const int nc = ix->n_contigs;
+    const int64_t n = ix->n;
+    if (n > 0 && nc > 0) {
+        const int64_t lb_tiles = (ix->bins_len + LB_TILE - 1) / LB_TILE;
+        const size_t zb = align_up((size_t)lb_tiles * 8) + align_up(16);
+        IVJ_TRY(arena_reserve(ctx, zb + 4096));
+        char* z = arena_take<char>(ctx, zb);
+        HIP_TRY(hipMemsetAsync(z, 0, zb, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ix->bins, 0, (size_t)ix->bins_len * 4, ctx->stream));
         LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(nc, 256), 256, (const int32_t*)ix->seg, (const int32_t*)ix->b_start, nc, ix->cmeta);
         LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int32_t*)ix->b_contig, n, nc,
                (const int4*)ix->cmeta, ix->bins);
-        LAUNCH(ctx, "bins_scan", (k_scan_lb_u32<MaxOp, false>), lb_tiles, OS_THREADS, ix->bins, ix->bins_len, 0u, tickets + passes_max, st_lb);
+        LAUNCH(ctx, "bins_scan", (k_scan_lb_u32<MaxOp, false>), lb_tiles, OS_THREADS, ix->bins, ix->bins_len, 0u,
+               (uint32_t*)(z + align_up((size_t)lb_tiles * 8)), (unsigned long long*)z);
         LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
                (const int32_t*)ix->b_start, (const int4*)ix->cmeta, nc, ix->brec);
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
+    ix->tables_built = true;
     return IVJ_OK;
 }
 

@@ -84,7 +84,6 @@ int partition_probes(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
 }
 
 int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* n_pairs) {
-    IVJ_TRY(need_tables(ix));
     const int64_t n = probe->n;
     ctx->ov_n = -1;
     ctx->ov_slice = false;
@@ -103,6 +102,7 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         *n_pairs = total;
         return IVJ_OK;
     }
+    IVJ_TRY(need_tables(ctx, ix));
     const bool part = want_partition(ix, n, opts);
     IVJ_TRY(ensure_ov(ctx, n, part ? 1 : 0));
     ctx->ov_part = part;
@@ -167,7 +167,6 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
 // single pass: (bucketing +) fused count/fill into a caller buffer of known capacity
 int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
                   int64_t capacity, int64_t* n_pairs) {
-    IVJ_TRY(need_tables(ix));
     const int64_t n = probe->n;
     ctx->ov_n = -1;                                   // invalidates a pending count -> fill hand-over
     *n_pairs = 0;
@@ -178,6 +177,7 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         const bool dense = opts->partition_mode == 0 && capacity >= 16 * n && ix->n_contigs > 0;
         if (!dense && want_slices(ix, n, opts, sg, true)) return slice_overlap_fused(ctx, ix, probe, opts, sg, out_p, out_b, capacity, n_pairs);
     }
+    IVJ_TRY(need_tables(ctx, ix));
     const bool part = want_partition(ix, n, opts);
     IVJ_TRY(ensure_ov(ctx, n, part ? 1 : 0));
     // dense results (the caller expects >= 16 pairs per probe; at ~8 the two kernels tie and the flat one still has
@@ -230,7 +230,7 @@ int unpermute(ivj_ctx* ctx, int64_t n, const UnpermuteCols& cols) {
 
 // fused join + key-column materialisation (k_overlap_fused_rows); same partitioning as overlap_fused
 int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const ivj_rows* rows, int64_t* n_pairs) {
-    IVJ_TRY(need_tables(ix));
+    IVJ_TRY(need_tables(ctx, ix));
     const int64_t n = probe->n;
     const int64_t capacity = rows->n_pairs;
     ctx->ov_n = -1;
@@ -264,7 +264,7 @@ int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
 }
 
 int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* counts) {
-    IVJ_TRY(need_tables(ix));
+    IVJ_TRY(need_tables(ctx, ix));
     const int64_t n = probe->n;
     if (n == 0) return IVJ_OK;
     if (ix->n == 0) { HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
@@ -304,7 +304,7 @@ int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
 }
 
 int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* idx, int64_t* dist, int32_t* nf) {
-    IVJ_TRY(need_tables(ix));
+    IVJ_TRY(need_tables(ctx, ix));
     const int64_t n = probe->n;
     const int k = opts->nearest_k < 1 ? 1 : opts->nearest_k;
     if (n == 0) return IVJ_OK;

@@ -38,7 +38,7 @@ int cluster_core(ivj_ctx* ctx, ivj_index* ix, bool strict, long long min_dist, s
 }
 
 int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* cov) {
-    IVJ_TRY(need_tables(ix));
+    IVJ_TRY(need_tables(ctx, ix));
     const int64_t n = probe->n;
     if (n == 0) return IVJ_OK;
     if (ix->n == 0) { HIP_TRY(hipMemsetAsync(cov, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
@@ -117,7 +117,7 @@ int union_core(ivj_ctx* ctx, ivj_index* ix, bool strict, size_t extra_bytes, Uni
 // caller's buffers; *n_pieces always receives the total.
 int subtract_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* left, const ivj_opts* opts, int64_t capacity, int32_t** o_row,
                   int32_t** o_start, int32_t** o_end, DevBuf* own, int64_t* n_pieces) {
-    IVJ_TRY(need_tables(ix));
+    IVJ_TRY(need_tables(ctx, ix));
     const int64_t n = left->n;
     *n_pieces = 0;
     if (n == 0) return IVJ_OK;
