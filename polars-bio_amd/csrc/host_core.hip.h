@@ -83,7 +83,7 @@ struct ivj_ctx {
     bool ov_slice = false;             // the pending count -> fill hand-over went through the slice path
     bool sl_plan_valid = false;
     int sl_items = 2;                  // probes per thread of the slice join (IVJ_SLICE_ITEMS = 2 | 4: tuning knob)
-    int sl_env_rows = 0, sl_env_chunk = 0, sl_env_notab = 0, sl_env_nobins = 0, sl_env_ablate = 0, sl_env_auto = 1, sl_env_stable = 0;   // IVJ_SLICE_ROWS / IVJ_SLICE_CHUNK: tuning knobs used when the opts fields are 0
+    int sl_env_rows = 0, sl_env_chunk = 0, sl_env_notab = 0, sl_env_nobins = 0, sl_env_ablate = 0, sl_env_auto = 1, sl_env_stable = 0, sl_env_sthreads = 1024;   // IVJ_SLICE_ROWS / IVJ_SLICE_CHUNK: tuning knobs used when the opts fields are 0
     SlicePlan sl_plan;
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel

@@ -71,6 +71,7 @@ __device__ __forceinline__ T sl_block_exclusive_sum(T v, T* wsum /* SL_WAVES */,
 // nbuild <= SL_MAX_BUCKETS * SL_MAX_ROWS rows, times 128 probes per wavefront < 2^31); the cross-wavefront part is 64-bit.
 // The caller alternates between two partial arrays (`wsum` = parity-selected SL_WAVES ints, 16-byte aligned), so the
 // next scan may start before the slowest wavefront has read this one's partials.
+template <int WAVES = SL_WAVES>
 __device__ __forceinline__ long long sl_block_exclusive_sum_i32(int v, int* wsum, long long* total) {
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
     const int inc = wave_inclusive_scan(v, SumOp());
@@ -78,7 +79,7 @@ __device__ __forceinline__ long long sl_block_exclusive_sum_i32(int v, int* wsum
     __syncthreads();
     long long pre = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < SL_WAVES; k += 4) {
+    for (int k = 0; k < WAVES; k += 4) {
         const int4 x = *reinterpret_cast<const int4*>(wsum + k);
         pre += (long long)(k < w ? x.x : 0) + (k + 1 < w ? x.y : 0) + (k + 2 < w ? x.z : 0) + (k + 3 < w ? x.w : 0);
         tot += (long long)x.x + x.y + x.z + x.w;
@@ -426,31 +427,33 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_scatter(const unsigned lon
 // (Writing the records straight from registers to their global slot -- no staging, two barriers per tile, 32 KB of LDS -- was
 // measured as well: 1.38 ms against 0.99 ms for config 3; scattered 16-byte stores cost more than the staging they save.)
 struct SlicePartULds { int cm, cell, spl, base, lstart, delta, cnt, rec, d, wsum, total; };
-__host__ __device__ inline SlicePartULds slice_part_u_lds(int nb, int ncells) {
+__host__ __device__ inline SlicePartULds slice_part_u_lds(int nb, int ncells, int threads) {
+    const int tile = threads * SL_ITEMS;
     SlicePartULds L;
     int o = 0;
     L.cm = o; o += ncells ? 16 * SL_TAB_CONTIGS : 0;
     L.spl = o; o += 8 * nb;
     L.cell = o; o += 4 * ncells;
-    L.rec = (o + 15) & ~15; o = L.rec + 16 * SL_TILE;
+    L.rec = (o + 15) & ~15; o = L.rec + 16 * tile;
     L.base = o; o += 4 * (nb + 2);
     L.lstart = o; o += 4 * (nb + 2);
     L.delta = o; o += 4 * (nb + 2);
     L.cnt = o; o += 4 * (nb + 2);
-    L.d = (o + 3) & ~3; o = L.d + 2 * SL_TILE;
+    L.d = (o + 3) & ~3; o = L.d + 2 * tile;
     L.wsum = (o + 15) & ~15; o = L.wsum + 4 * 2 * SL_WAVES;
     L.total = o;
     return L;
 }
 
-template <bool STRICT>
-__global__ __launch_bounds__(SL_THREADS) void k_slice_scatter_u(const unsigned long long* __restrict__ spl, SliceTab tab, SliceGeom g, int32_t n_contigs,
+template <bool STRICT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_slice_scatter_u(const unsigned long long* __restrict__ spl, SliceTab tab, SliceGeom g, int32_t n_contigs,
                                                                const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
                                                                const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
                                                                int chunk, int nchunks, const uint32_t* __restrict__ blk_off,
                                                                int4* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sl_lds[];
-    const SlicePartULds L = slice_part_u_lds(g.nb, g.ncells);
+    constexpr int TILE = THREADS * SL_ITEMS;
+    const SlicePartULds L = slice_part_u_lds(g.nb, g.ncells, THREADS);
     unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(sl_lds + L.spl);
     int4* l_cm = reinterpret_cast<int4*>(sl_lds + L.cm);
     uint32_t* l_cell = reinterpret_cast<uint32_t*>(sl_lds + L.cell);
@@ -463,10 +466,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_scatter_u(const unsigned l
     int* wsum = reinterpret_cast<int*>(sl_lds + L.wsum);
     const int tid = threadIdx.x;
     const int nbk = g.nb + 1;
-    for (int k = tid; k < g.nb; k += SL_THREADS) l_spl[k] = spl[k];
-    for (int k = tid; k < g.ncells; k += SL_THREADS) l_cell[k] = tab.cell[k];
-    if (g.ncells) for (int k = tid; k < n_contigs; k += SL_THREADS) l_cm[k] = tab.cm[k];
-    for (int k = tid; k < nbk + 1; k += SL_THREADS) { base[k] = k < nbk ? blk_off[(int64_t)k * nchunks + blockIdx.x] : 0u; cnt[k] = 0; }
+    for (int k = tid; k < g.nb; k += THREADS) l_spl[k] = spl[k];
+    for (int k = tid; k < g.ncells; k += THREADS) l_cell[k] = tab.cell[k];
+    if (g.ncells) for (int k = tid; k < n_contigs; k += THREADS) l_cm[k] = tab.cm[k];
+    for (int k = tid; k < nbk + 1; k += THREADS) { base[k] = k < nbk ? blk_off[(int64_t)k * nchunks + blockIdx.x] : 0u; cnt[k] = 0; }
     __syncthreads();
     const int64_t cbase = (int64_t)blockIdx.x * chunk;
     const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_scatter_u(const unsigned l
     auto load_tile = [&](int64_t tbase) {
 #pragma unroll
         for (int j = 0; j < SL_ITEMS; ++j) {
-            const int64_t i = tbase + j * SL_THREADS + tid;
+            const int64_t i = tbase + j * THREADS + tid;
             const bool valid = i < cend;
             nc[j] = valid ? __builtin_nontemporal_load(pc + i) : -1;
             ns[j] = valid ? __builtin_nontemporal_load(ps + i) : 0;
@@ -484,16 +487,16 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_scatter_u(const unsigned l
     };
     load_tile(cbase);
     int tix = 0;
-    for (int64_t tbase = cbase; tbase < cend; tbase += SL_TILE, ++tix) {
+    for (int64_t tbase = cbase; tbase < cend; tbase += TILE, ++tix) {
         int32_t c[SL_ITEMS], s[SL_ITEMS], e[SL_ITEMS], r[SL_ITEMS];
 #pragma unroll
         for (int j = 0; j < SL_ITEMS; ++j) { c[j] = nc[j]; s[j] = ns[j]; e[j] = ne[j]; r[j] = nr[j]; }
-        if (tbase + SL_TILE < cend) load_tile(tbase + SL_TILE);
-        const int tile_n = (int)((cend - tbase) < (int64_t)SL_TILE ? (cend - tbase) : (int64_t)SL_TILE);
+        if (tbase + TILE < cend) load_tile(tbase + TILE);
+        const int tile_n = (int)((cend - tbase) < (int64_t)TILE ? (cend - tbase) : (int64_t)TILE);
         uint32_t d[SL_ITEMS], rank[SL_ITEMS];
 #pragma unroll
         for (int j = 0; j < SL_ITEMS; ++j) {
-            const bool valid = j * SL_THREADS + tid < tile_n;
+            const bool valid = j * THREADS + tid < tile_n;
             d[j] = !valid ? 0u : (g.ncells ? slice_bucket_tab<STRICT>(l_spl, l_cm, l_cell, g, n_contigs, c[j], e[j])
                                            : slice_bucket<STRICT>(l_spl, g, n_contigs, c[j], e[j]));
             rank[j] = valid ? atomicAdd(&cnt[d[j]], 1u) : 0u;
@@ -501,19 +504,28 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_scatter_u(const unsigned l
         __syncthreads();                                                        // (A) bucket counts of the tile complete
         // thread t owns buckets 2t, 2t+1: advance the global offsets by the previous tile's totals (kept in `lstart` deltas),
         // tile-local starts, copy-out deltas; the counters are cleared for the next tile
-        int x0 = 0, x1 = 0;
-        const int b0 = 2 * tid;
-        if (b0 < nbk) { x0 = (int)cnt[b0]; cnt[b0] = 0; if (b0 + 1 < nbk) { x1 = (int)cnt[b0 + 1]; cnt[b0 + 1] = 0; } }
+        constexpr int OWN = (SL_MAX_BUCKETS + 1 + THREADS - 1) / THREADS;      // consecutive buckets per thread
+        int x[OWN];
+        int xs = 0;
+#pragma unroll
+        for (int q = 0; q < OWN; ++q) {
+            const int b = OWN * tid + q;
+            x[q] = 0;
+            if (b < nbk) { x[q] = (int)cnt[b]; cnt[b] = 0; }
+            xs += x[q];
+        }
         long long tsum;
-        const int pre = (int)sl_block_exclusive_sum_i32(x0 + x1, wsum + (tix & 1) * SL_WAVES, &tsum);      // (B)
-        if (b0 < nbk) {
-            lstart[b0] = (uint32_t)pre; delta[b0] = base[b0] - (uint32_t)pre; base[b0] += (uint32_t)x0;
-            if (b0 + 1 < nbk) { lstart[b0 + 1] = (uint32_t)(pre + x0); delta[b0 + 1] = base[b0 + 1] - (uint32_t)(pre + x0); base[b0 + 1] += (uint32_t)x1; }
+        int pre = (int)sl_block_exclusive_sum_i32<THREADS / kWave>(xs, wsum + (tix & 1) * SL_WAVES, &tsum);      // (B)
+#pragma unroll
+        for (int q = 0; q < OWN; ++q) {
+            const int b = OWN * tid + q;
+            if (b < nbk) { lstart[b] = (uint32_t)pre; delta[b] = base[b] - (uint32_t)pre; base[b] += (uint32_t)x[q]; }
+            pre += x[q];
         }
         __syncthreads();                                                        // (C)
 #pragma unroll
         for (int j = 0; j < SL_ITEMS; ++j) {
-            if (j * SL_THREADS + tid < tile_n) {
+            if (j * THREADS + tid < tile_n) {
                 const uint32_t pos = lstart[d[j]] + rank[j];
                 l_rec[pos] = make_int4(s[j], e[j], r[j], c[j]);
                 l_d[pos] = (unsigned short)d[j];
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_scatter_u(const unsigned l
         __syncthreads();                                                        // (D) tile sorted in LDS
 #pragma unroll
         for (int j = 0; j < SL_ITEMS; ++j) {
-            const int il = j * SL_THREADS + tid;
+            const int il = j * THREADS + tid;
             if (il < tile_n) out[(int64_t)((uint32_t)il + delta[l_d[il]])] = l_rec[il];
         }
         // no barrier here: the next tile's barrier (A) separates this copy-out from the next placement
@@ -771,12 +783,25 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             hi[j] = r0 + lo_s[j];
-            const int32_t* pe = l_end + (lo_s[j] - SL_WIN);                    // rows hi-SL_WIN .. hi-1 at pe[0 .. SL_WIN-1]
+            // sixteen ends from the 16-byte aligned address at or below row hi-SL_WIN: four ds_read_b128 instead of twelve
+            // ds_read_b32 (random lanes: ~7 LDS cycles per b32 instruction against ~10 per b128 one).  Element i <=> slice row
+            // al + i; rows at or above hi are shifted out, bit reversal turns "ascending row" into "bit t <=> row hi-1-t".
+            const int al = (lo_s[j] - SL_WIN) & ~3;
+            const int dd = lo_s[j] - al;                                       // SL_WIN .. SL_WIN + 3 rows of the sixteen lie below hi
             uint32_t m = 0;
             if (A.ablate & 2) m = (uint32_t)qs[j] & 3u;
             else {
+                const int4* p4 = reinterpret_cast<const int4*>(l_end + al);
+                uint32_t m16 = 0;
 #pragma unroll
-                for (int t = 0; t < SL_WIN; ++t) m |= (lt_op<STRICT>(qs[j], pe[SL_WIN - 1 - t]) ? 1u : 0u) << t;
+                for (int q = 0; q < 4; ++q) {
+                    const int4 v = p4[q];
+                    m16 |= (lt_op<STRICT>(qs[j], v.x) ? 1u : 0u) << (4 * q);
+                    m16 |= (lt_op<STRICT>(qs[j], v.y) ? 1u : 0u) << (4 * q + 1);
+                    m16 |= (lt_op<STRICT>(qs[j], v.z) ? 1u : 0u) << (4 * q + 2);
+                    m16 |= (lt_op<STRICT>(qs[j], v.w) ? 1u : 0u) << (4 * q + 3);
+                }
+                m = __brev(m16 << (32 - dd));
             }
             const int lowlim = seg_a[j] > r0 ? seg_a[j] : r0;
             int nrows = hi[j] - lowlim;                                        // rows of the window that exist in LDS
