@@ -475,7 +475,8 @@ def main():
                        "filter_op": "Strict", "units_per_step": total_units,
                        "parallelism": ("single GPU" if not multi else
                                        f"{mode}-sharded x{n_gpus}, " + ("RCCL all-gatherv in timed region" if gather else "no gather")),
-                       "step": ("index build (radix sort) + probe bucketing + " +
+                       "step": ("index build (radix sort) + probe partition (" +
+                                ("equal-row-count index slices, 16-byte records" if any(k.startswith("slice_") for k in ktimes) else "256 genomic buckets") + ") + " +
                                 ("count + scan + fill" if (args.two_pass or not any(k.startswith(("overlap_fused", "overlap_flat", "slice_join_fused")) for k in ktimes)) else
                                  "fused count/fill into the preallocated result buffers") +
                                 (" + key-column materialisation of every pair" if args.materialize else "") +

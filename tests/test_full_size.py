@@ -108,8 +108,15 @@ def test_full_size_config3_overlap_100M_x_5M(eng):
         eng.d2h(got, cp)
         assert (got == counts).all()
         del got
-        # 2. the fused single pass (what bench.py times), auto mode and the 256-bucket window-scan path
-        for pm in (0, 1):
+        # 2. the slice path's deterministic pair (partition_mode 6: stable scatter, count pass, fill pass)
+        o6 = _engine.make_opts(True, nc, partition_mode=6)
+        assert eng.overlap_count_dev(ixd, d.probe, o6) == total
+        eng.overlap_fill_dev(ixd, d.probe, o6, op, ob, total)
+        eng.d2h(hp, op)
+        eng.d2h(hb, ob)
+        _check_pair_properties(hp, hb, probe, build, counts, checksum, "two-pass slices")
+        # 3. the fused single pass (what bench.py times): auto mode (slice path), the 256-bucket window-scan path, explicit slices
+        for pm in (0, 1, 6):
             o2 = _engine.make_opts(True, nc, partition_mode=pm)
             small, fits = eng.overlap_fused_dev(ixd, d.probe, o2, op, ob, total // 2)
             assert not fits and small == total, pm
