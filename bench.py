@@ -240,11 +240,19 @@ def pmc_traffic(args, kernel_short):
         fk = sum(f.values()) / max(len(f), 1); wk = sum(w.values()) / max(len(w), 1)
         table[name] = {"launches": max(len(f), len(w)), "FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1),
                        "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
-    hit = [k for k in table if kernel_short and ("k_" + kernel_short) in k]
+    # timing label -> kernel symbol: "overlap_fused" is ivj::k_overlap_fused<..>, "slice_join_fused" is one instantiation of
+    # ivj::k_slice_join<STRICT, MODE, ITEMS> (the label's last word names the template mode), so trailing words are dropped
+    # until a symbol matches; of several instantiations the one launched in every timed step wins
+    hit, stem = [], kernel_short or ""
+    while stem and not hit:
+        hit = [k for k in table if ("k_" + stem + "<") in k or k.endswith("k_" + stem)] or [k for k in table if ("k_" + stem) in k]
+        stem = stem.rpartition("_")[0]
+    hit.sort(key=lambda k: (-table[k]["launches"], -table[k]["hbm_bytes_per_launch"]))
     traffic = table[hit[0]]["hbm_bytes_per_launch"] if hit else None
     step_total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in table.values()) / 4.0   # 1 warmup + 3 steps
     return traffic, {"source": "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over this command (3 steps)",
                      "correction": "2 x FETCH_SIZE + WRITE_SIZE (KiB)", "step_hbm_bytes": int(step_total),
+                     "kernel_symbol": hit[0] if hit else None,
                      "kernels": {k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]}}
 
 

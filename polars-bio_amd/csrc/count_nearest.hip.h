@@ -9,71 +9,100 @@ namespace ivj {
 // count = #{b.start (<) q.end} - #{!(q.start (<) b.end)}  (two-rank formula of the reference's
 // SQL sweep, polars_bio/range_op.py:548-595); the bounded scan replaces it for rows where the
 // formula is not exact (zero-length/inverted probe, or any inverted build row).
-// rank of a target inside one joint-grid slot: rec = {p0, key[p0], key[p0+1], key[p0+2]} (keys past the
-// segment are INT32_MAX); the number of leading keys below the target is the offset of the bound, and only a
-// bin with more than three rows below the target needs a bound search up to the next bin's first position
-__device__ __forceinline__ int joint_rank(const int32_t* __restrict__ keys, const int4& rec, unsigned long long t,
-                                          const int4* __restrict__ crec, uint32_t slot, bool end_table) {
-    const bool n0 = (unsigned long long)flip(rec.y) < t;
-    const bool n1 = n0 && (unsigned long long)flip(rec.z) < t;
-    const bool n2 = n1 && (unsigned long long)flip(rec.w) < t;
-    int lo = rec.x + (n0 ? 1 : 0) + (n1 ? 1 : 0) + (n2 ? 1 : 0);
-    if (n2) {
-        int hi = crec[2 * (slot + 1) + (end_table ? 1 : 0)].x;
-        while (lo < hi) {
-            const int m = lo + ((hi - lo) >> 1);
-            if ((unsigned long long)flip(keys[m]) < t) lo = m + 1; else hi = m;
-        }
+// Rank of a target t inside its joint-grid bin from the bin's record word pw = first position | more << 31 and its two
+// inline key offsets (index_build.hip.h, k_joint_records): toff = t - lower edge of the bin.  Only a bin with a third row
+// whose second row is still below the target (or any non-empty bin of a grid wider than 2^16 per bin) touches the key
+// array: gallop up from the rows already counted, bounded by the contig segment, then a bound search.
+// The kernel's speed is set by the number of L2 requests in flight per CU (the vector L1 holds ~90 outstanding, PMC:
+// profiles/r02/pmc_sq_tcp_count_200M_200k.json), so every key-array touch that the record answers instead is time.
+__device__ __forceinline__ int joint_rank(const int32_t* __restrict__ keys, int pw, uint32_t offs, uint32_t toff, bool wide,
+                                          unsigned long long t, int seg_end) {
+    int lo = pw & 0x7fffffff;
+    if (!wide) {
+        const bool b0 = (offs & 0xffffu) < toff, b1 = (offs >> 16) < toff;
+        lo += (b0 ? 1 : 0) + (b1 ? 1 : 0);
+        if (!(pw < 0 && b1)) return lo;
+    } else if (pw >= 0) return lo;
+    int step = 1;
+    while (lo + step - 1 < seg_end && (unsigned long long)flip(keys[lo + step - 1]) < t) { lo += step; step <<= 1; }
+    int hi = lo + step - 1 < seg_end ? lo + step - 1 : seg_end;
+    while (lo < hi) {
+        const int m = lo + ((hi - lo) >> 1);
+        if ((unsigned long long)flip(keys[m]) < t) lo = m + 1; else hi = m;
     }
     return lo;
 }
 
-template <bool STRICT, int N>
+// LM: the per-contig grid metadata is copied to LDS once per workgroup (n_contigs <= CM_LDS).  Read from global memory the
+// two 16-byte metadata loads of a probe are L1 hits, but with a random contig per lane every lane is its own L1 access:
+// they were HALF of the kernel's 4.1 L1 accesses per probe (profiles/r01/v17_pmc_sq_tcp_count_200M_200k.json).
+constexpr int CM_LDS = 256;
+constexpr int COUNT_TILES_PER_WG = 4;
+
+template <bool STRICT, int N, bool LM>
 __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, const int32_t* __restrict__ pc,
                                                                   const int32_t* __restrict__ ps,
                                                                   const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
-                                                                  long long* __restrict__ counts) {
-    const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
+                                                                  long long* __restrict__ counts, int ablate) {
+    __shared__ int4 l_cm[LM ? 2 * CM_LDS : 1];
+    if (LM) {
+        for (int i = threadIdx.x; i < 2 * ix.n_contigs; i += PROBE_THREADS) l_cm[i] = ix.cmeta_j[i];
+        __syncthreads();
+    }
+    const bool inv = ix.flags[0] != 0;
+#pragma unroll 1
+  for (int t = 0; t < COUNT_TILES_PER_WG; ++t) {
+    const int64_t i0 = ((int64_t)blockIdx.x * COUNT_TILES_PER_WG + t) * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
+    if (i0 - (int64_t)threadIdx.x * N >= n) break;
     int32_t c[N], s[N], e[N];
     load_items_nt(pc, i0, n, vec_ok, -1, c);
     load_items_nt(ps, i0, n, vec_ok, 0, s);
     load_items_nt(pe, i0, n, vec_ok, 0, e);
-    const bool inv = ix.flags[0] != 0;
     // phase 1: metadata and the (usually single) record gather of every probe, issued together
     int a[N], b[N];
     unsigned long long te[N], ts[N];
-    uint32_t se[N], ss[N];
     int he[N], hs[N];          // 0: rank = a, 1: rank = b, 2: table
+    bool same[N], wide[N];
+    uint32_t oe[N], os[N];     // offset of the target inside its bin
     int4 re[N], rs[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const bool ok = i0 + k < n && (uint32_t)c[k] < (uint32_t)ix.n_contigs;
         int4 m0 = make_int4(0, 0, 0, 0), m1 = make_int4(0, 0, 0, 0);
-        if (ok) { m0 = ix.cmeta_j[2 * c[k]]; m1 = ix.cmeta_j[2 * c[k] + 1]; }
+        if (ok) {
+            if (LM) { m0 = l_cm[2 * c[k]]; m1 = l_cm[2 * c[k] + 1]; }
+            else { m0 = ix.cmeta_j[2 * c[k]]; m1 = ix.cmeta_j[2 * c[k] + 1]; }
+        }
         a[k] = m0.x; b[k] = m0.y;
         const uint32_t ulo = (uint32_t)m0.z, uhi = (uint32_t)m0.w;
         te[k] = (unsigned long long)flip(e[k]) + (STRICT ? 0ull : 1ull);   // first start >= / > q.end
         ts[k] = (unsigned long long)flip(s[k]) + (STRICT ? 1ull : 0ull);   // first end > / >= q.start
         he[k] = (b[k] <= a[k] || te[k] <= ulo) ? 0 : (te[k] > uhi ? 1 : 2);
         hs[k] = (b[k] <= a[k] || ts[k] <= ulo) ? 0 : (ts[k] > uhi ? 1 : 2);
-        se[k] = he[k] == 2 ? (uint32_t)m1.y + (((uint32_t)te[k] - ulo) >> m1.x) : 0u;
-        ss[k] = hs[k] == 2 ? (uint32_t)m1.y + (((uint32_t)ts[k] - ulo) >> m1.x) : 0u;
+        if (ablate & 1) { he[k] = 0; hs[k] = 0; }
+        const uint32_t de = (uint32_t)te[k] - ulo, ds = (uint32_t)ts[k] - ulo, bmask = (1u << m1.x) - 1u;   // shift <= 31
+        const uint32_t se = he[k] == 2 ? (uint32_t)m1.y + (de >> m1.x) : 0u;
+        const uint32_t ss = hs[k] == 2 ? (uint32_t)m1.y + (ds >> m1.x) : 0u;
+        oe[k] = de & bmask; os[k] = ds & bmask; wide[k] = m1.x > 16;
+        same[k] = he[k] == 2 && hs[k] == 2 && se == ss;                   // a probe is short against a bin: the usual case
         re[k] = make_int4(0, 0, 0, 0); rs[k] = make_int4(0, 0, 0, 0);
-        if (he[k] == 2) re[k] = ix.crec[2 * se[k]];              // start half of the slot's record
-        if (hs[k] == 2) rs[k] = ix.crec[2 * ss[k] + 1];          // end half (the same 32-byte record when ss == se)
+        if (he[k] == 2) re[k] = ix.crec[se];
+        if (hs[k] == 2 && !same[k]) rs[k] = ix.crec[ss];
     }
     long long cnt[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const int hi = he[k] == 0 ? a[k] : (he[k] == 1 ? b[k] : joint_rank(ix.b_start, re[k], te[k], ix.crec, se[k], false));
+        if (same[k]) rs[k] = re[k];
+        const int hi = he[k] == 0 ? a[k] : (he[k] == 1 ? b[k] : joint_rank(ix.b_start, re[k].x, (uint32_t)re[k].z, oe[k], wide[k], te[k], b[k]));
         const bool degenerate = inv || (STRICT ? (s[k] >= e[k]) : (s[k] > e[k]));
         if (!degenerate) {
-            const int r = hs[k] == 0 ? a[k] : (hs[k] == 1 ? b[k] : joint_rank(ix.e_end, rs[k], ts[k], ix.crec, ss[k], true));
+            const int r = hs[k] == 0 ? a[k] : (hs[k] == 1 ? b[k] : joint_rank(ix.e_end, rs[k].y, (uint32_t)rs[k].w, os[k], wide[k], ts[k], b[k]));
             cnt[k] = (long long)hi - (long long)r;
         } else {
             cnt[k] = scan_count<STRICT>(ix, a[k], hi, s[k]);
         }
     }
+    if ((ablate & 2) && cnt[0] != 123456789) continue;
     if (i0 + N <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0 && (N % 2) == 0) {
 #pragma unroll
         for (int k = 0; k < N; k += 2)
@@ -86,6 +115,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
 #pragma unroll
         for (int k = 0; k < N; ++k) if (i0 + k < n) counts[i0 + k] = cnt[k];
     }
+  }
 }
 
 // ------------------------------------------------------------------ nearest

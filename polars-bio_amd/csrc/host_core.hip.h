@@ -68,6 +68,7 @@ struct ivj_ctx {
     // bucketed (partitioned) copies of the probe columns + their row ids, when the partition path ran
     bool ov_part = false;
     int32_t *pt_c = nullptr, *pt_s = nullptr, *pt_e = nullptr, *pt_row = nullptr;
+    uint32_t* pt_off = nullptr; int pt_ntiles = 0;   // bucket-major scanned tile histogram of the last one-level partition
     uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
     bool part_attr_set = false;
     bool os_attr_set = false;
@@ -83,6 +84,7 @@ struct ivj_ctx {
     bool ov_slice = false;             // the pending count -> fill hand-over went through the slice path
     bool sl_plan_valid = false;
     int sl_items = 2;                  // probes per thread of the slice join (IVJ_SLICE_ITEMS = 2 | 4: tuning knob)
+    int env_joint_bins = 0, env_count_nolds = 0, env_count_ablate = 0;     // IVJ_JOINT_BINS (1|2), IVJ_COUNT_NOLDS: tuning knobs of count_overlaps
     int sl_env_rows = 0, sl_env_chunk = 0, sl_env_notab = 0, sl_env_nobins = 0, sl_env_ablate = 0, sl_env_auto = 1, sl_env_stable = 0, sl_env_sthreads = 1024;   // IVJ_SLICE_ROWS / IVJ_SLICE_CHUNK: tuning knobs used when the opts fields are 0
     SlicePlan sl_plan;
     // timing

@@ -44,9 +44,10 @@ int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
         LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins_e, ix->bins_len,
                (const int32_t*)ix->e_end, (const int4*)ix->cmeta_e, ix->n_contigs, ix->brec_e);
         // joint grid for count_overlaps: the same bins for the start order and the end order
-        // joint grid: two bins per build row, or ONE when that is what keeps the 32-byte records of a small build
-        // side near an XCD's 4-MiB L2 (measured on 200 k rows: 3.11 -> 2.76 ms for 200 M probes)
-        const int bins_per_row = ((size_t)n * 64 > (3u << 20) && (size_t)n * 32 <= (7u << 20)) ? 1 : 2;
+        // joint grid of 16-byte records: two bins per build row (200 k rows, 200 M probes: 1.96 ms against 2.07 ms with one
+        // bin per row, although only the latter table fits an XCD's L2: fewer third-row searches matter more)
+        int bins_per_row = 2;
+        if (ctx->env_joint_bins == 1 || ctx->env_joint_bins == 2) bins_per_row = ctx->env_joint_bins;
         LAUNCH(ctx, "contig_meta", k_contig_meta_joint, grid1d(ix->n_contigs, 256), 256, (const int32_t*)ix->seg,
                (const int32_t*)ix->b_start, (const int32_t*)ix->e_end, ix->n_contigs, bins_per_row, ix->cmeta_j);
         HIP_TRY(hipMemsetAsync(jb_s, 0, (size_t)ix->bins_len * 4, ctx->stream));
@@ -255,7 +256,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t spl_bytes = align_up((size_t)SL_MAX_BUCKETS * 8) + align_up((size_t)SL_TAB_CONTIGS * 16) +
                                  align_up((size_t)(4 * SL_MAX_BUCKETS + SL_TAB_CONTIGS) * 4);
         const size_t need = spl_bytes + flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 16) + 2 * align_up((size_t)ix->bins_len * 4) +
-                            4 * align_up((size_t)ix->bins_len * 16) + small + 256;
+                            3 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
             ctx->ix_cache = nullptr; ctx->ix_cache_cap = 0;
@@ -281,7 +282,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->bins_e = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
         ix->brec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
         ix->brec_e = (int4*)p; p += align_up((size_t)ix->bins_len * 16);
-        ix->crec = (int4*)p; p += align_up((size_t)ix->bins_len * 32);     // 32-byte joint records
+        ix->crec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);     // 16-byte joint records
         ix->rec4 = (int4*)p; p += align_up((nn + 1) * 16);
         {
             ix->lot = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);

@@ -7,7 +7,9 @@ namespace {
 int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one permuted column set
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     const size_t col = align_up((size_t)n * 4);
-    const size_t need = (size_t)(2 + 4 * with_part) * col + align_up((size_t)(tiles + 2) * 8) +
+    const size_t ptiles = (size_t)((n + PART_TILE - 1) / PART_TILE);
+    const size_t off_bytes = with_part ? align_up((size_t)PART_BUCKETS * ptiles * 4 + 64) : 0;
+    const size_t need = (size_t)(2 + 4 * with_part) * col + off_bytes + align_up((size_t)(tiles + 2) * 8) +
                         align_up((size_t)(scan_num_tiles(tiles) + 2) * 8) + align_up((PART_BUCKETS + 1) * 4) + 1024;
     if (need > ctx->ov_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -26,6 +28,7 @@ int ensure_ov(ivj_ctx* ctx, int64_t n, int with_part) {      // 0: none, 1: one 
         ctx->pt_s = (int32_t*)p; p += col;
         ctx->pt_e = (int32_t*)p; p += col;
         ctx->pt_row = (int32_t*)p; p += col;
+        ctx->pt_off = (uint32_t*)p; p += off_bytes;            // scanned per-tile histogram of the partition (k_unpermute reads it)
     }
     ctx->pt_bstart = (uint32_t*)p; p += align_up((PART_BUCKETS + 1) * 4);
     ctx->ov_tile = (long long*)p;
@@ -46,8 +49,9 @@ int partition_pass(ivj_ctx* ctx, ivj_index* ix, bool strict, const int32_t* sc, 
     const int ntiles = (int)((n + PART_TILE - 1) / PART_TILE);
     const int grid = 8 * ((ntiles + 7) / 8);
     const size_t hist = (size_t)PART_BUCKETS * (size_t)ntiles;
-    IVJ_TRY(arena_reserve(ctx, align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4) + 4096));
-    uint32_t* blk = arena_take<uint32_t>(ctx, hist);
+    IVJ_TRY(arena_reserve(ctx, align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4) + 4096));
+    uint32_t* blk = ctx->pt_off;                               // outlives the arena: the inverse permutation reads it
+    ctx->pt_ntiles = ntiles;
     uint32_t* partials = arena_take<uint32_t>(ctx, scan_num_tiles((int64_t)hist) + 1);
     if (!ctx->part_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
@@ -223,7 +227,8 @@ struct DevBuf {                   // owning device allocation of the host-buffer
 
 // per-probe results of a kernel that ran over the bucketed probes (pt_*) -> original row order
 int unpermute(ivj_ctx* ctx, int64_t n, const UnpermuteCols& cols) {
-    LAUNCH(ctx, "unpermute", k_unpermute, (n + UNP_TILE - 1) / UNP_TILE, UNP_THREADS, (const int32_t*)ctx->pt_row, (const uint32_t*)ctx->pt_bstart, n, cols);
+    LAUNCH(ctx, "unpermute", k_unpermute, (n + UNP_TILE - 1) / UNP_TILE, UNP_THREADS, (const int32_t*)ctx->pt_row, (const uint32_t*)ctx->pt_bstart,
+           (const uint32_t*)ctx->pt_off, ctx->pt_ntiles, n, cols);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
 }
@@ -287,14 +292,18 @@ int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
         IVJ_TRY(arena_reserve(ctx, align_up((size_t)n * 8) + 4096));
         o_counts = arena_take<long long>(ctx, n);
     }
-    constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT;
+    constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT * COUNT_TILES_PER_WG;
     const int64_t tiles = (n + NT - 1) / NT;
     const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
     IndexView v = view_of(ix);
-    if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts);
-    else
-        LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts);
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    if (ix->n_contigs <= CM_LDS && !ctx->env_count_nolds) {
+        if (strict) LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT, true>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, ctx->env_count_ablate);
+        else LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT, true>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, ctx->env_count_ablate);
+    } else {
+        if (strict) LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT, false>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, ctx->env_count_ablate);
+        else LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT, false>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, ctx->env_count_ablate);
+    }
     HIP_TRY(hipGetLastError());
     if (bucketed) {
         UnpermuteCols uc{{o_counts, nullptr, nullptr}, {counts, nullptr, nullptr}, {8, 0, 0}, 1, nullptr};

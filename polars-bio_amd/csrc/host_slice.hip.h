@@ -42,7 +42,9 @@ bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, Sli
     if (opts->partition_mode == 0) {
         const int mode = ix->ctx ? ix->ctx->sl_env_auto : 1;
         const bool on = mode == 2 || (mode == 1 && fused);
-        if (!(on && n_probe >= (4ll << 20) && ix->n >= (256ll << 10))) return false;
+        // tools/policy_sweep.py (profiles/r02/policy_sweep.txt): against the 256-bucket window scan the slices only pay once the
+        // sorted build side is far larger than the L2s (5 M rows: -5 % at 30 M probes, -6 % at 100 M; 1-2 M rows: +2..+60 %)
+        if (!(on && n_probe >= (24ll << 20) && ix->n >= (4ll << 20))) return false;
     }
     return slice_geom(ix, opts, g);
 }

@@ -96,34 +96,52 @@ __global__ void k_contig_meta_joint(const int32_t* __restrict__ seg, const int32
     if (b > a) {
         const uint32_t s0 = flip(b_start[a]), e0 = flip(e_end[a]), s1 = flip(b_start[b - 1]), e1 = flip(e_end[b - 1]);
         ulo = s0 < e0 ? s0 : e0; uhi = s1 > e1 ? s1 : e1;
-        const unsigned long long span = (unsigned long long)(uhi - ulo), cap = (unsigned long long)bins_per_row * (unsigned long long)(b - a);
+        unsigned long long span = (unsigned long long)(uhi - ulo), cap = (unsigned long long)bins_per_row * (unsigned long long)(b - a);
+        if (cap < 2) cap = 2;                                  // the table has 2 (b - a) + 2 slots; keeps shift <= 31
         while ((span >> shift) + 1ull > cap) ++shift;
     }
     cmeta[2 * c] = make_int4(a, b, (int)ulo, (int)uhi);
     cmeta[2 * c + 1] = make_int4(shift, 2 * a + 2 * c, 0, 0);
 }
 
+// Joint-grid record of count_overlaps, 16 bytes per bin, so that BOTH ranks of a probe come out of ONE gather:
+//   {first start position | more << 31, first end position | more << 31, start offsets o0 | o1 << 16, end offsets o0 | o1 << 16}
+// o0, o1 = the first two keys of the bin as 16-bit offsets from the bin's lower edge (0xffff: no such row -- never below a
+// target, whose own offset is < 2^shift <= 0xffff); "more" = the bin holds a third row of that order, which the two
+// offsets cannot answer.  Bins wider than 2^16 (a build side of fewer than ~span / 2^17 rows per contig) carry no
+// offsets: "more" then means "the bin is not empty" and the rank is searched from the bin's first position.
+// bins_s / bins_e are the max-scanned first positions, so the difference of two neighbouring slots is the number of rows
+// in the bin (the slot after a contig's last bin holds the segment end).
 __global__ void k_joint_records(const uint32_t* __restrict__ bins_s, const uint32_t* __restrict__ bins_e, int64_t bins_len,
                                 const int32_t* __restrict__ b_start, const int32_t* __restrict__ e_end,
-                                const int4* __restrict__ cmeta, int32_t n_contigs, int4* __restrict__ crec) {
+                                const int4* __restrict__ cmeta, int32_t n_contigs, int4* __restrict__ jrec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= bins_len) return;
     int lo = 0, hi = n_contigs;
     while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= i) lo = m + 1; else hi = m; }
     const int c = lo - 1;
-    const int ps = (int)bins_s[i], pe = (int)bins_e[i];
-    int32_t ks[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, ke[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    const uint32_t ps = bins_s[i], pe = bins_e[i];
+    uint32_t ws = ps, we = pe, os = 0xffffffffu, oe = 0xffffffffu;
     if (c >= 0) {
-        const int bend = cmeta[2 * c].y;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (ps + j < bend) ks[j] = b_start[ps + j];
-            if (pe + j < bend) ke[j] = e_end[pe + j];
+        const int4 m0 = cmeta[2 * c], m1 = cmeta[2 * c + 1];
+        const uint32_t bend = (uint32_t)m0.y;
+        const int shift = m1.x;
+        const uint32_t edge = (uint32_t)m0.z + (uint32_t)(((unsigned long long)(i - (int64_t)m1.y)) << shift);   // never used past the contig's last bin
+        uint32_t ns = i + 1 < bins_len ? bins_s[i + 1] : bend, ne = i + 1 < bins_len ? bins_e[i + 1] : bend;
+        ns = ns < bend ? ns : bend; ne = ne < bend ? ne : bend;
+        const uint32_t cs = ns > ps ? ns - ps : 0u, ce = ne > pe ? ne - pe : 0u;
+        if (shift <= 16) {
+            const uint32_t s0 = cs >= 1 ? flip(b_start[ps]) - edge : 0xffffu, s1 = cs >= 2 ? flip(b_start[ps + 1]) - edge : 0xffffu;
+            const uint32_t e0 = ce >= 1 ? flip(e_end[pe]) - edge : 0xffffu, e1 = ce >= 2 ? flip(e_end[pe + 1]) - edge : 0xffffu;
+            os = (s0 & 0xffffu) | (s1 << 16); oe = (e0 & 0xffffu) | (e1 << 16);
+            if (cs >= 3) ws |= 0x80000000u;
+            if (ce >= 3) we |= 0x80000000u;
+        } else {
+            if (cs >= 1) ws |= 0x80000000u;
+            if (ce >= 1) we |= 0x80000000u;
         }
     }
-    // one 32-byte record per bin: {first start position, its three keys}, {first end position, its three keys}
-    crec[2 * i] = make_int4(ps, ks[0], ks[1], ks[2]);
-    crec[2 * i + 1] = make_int4(pe, ke[0], ke[1], ke[2]);
+    jrec[i] = make_int4((int)ws, (int)we, (int)os, (int)oe);
 }
 
 // nearest (k = 1): everything the no-overlap case needs about a bound position p in ONE 16-byte

@@ -52,7 +52,7 @@ struct IndexView {
     int32_t use_rec;       // 1: gather 16-byte records, 0: 4-byte bins + bound search on the key array
     const int32_t* pargmax; // position of the first row that attains ep[p].y (prefix max) -- nearest only
     const int4* cmeta_j;    // count_overlaps: ONE bin grid per contig shared by the start- and the end-sorted order
-    const int4* crec;       //   crec[2 slot] = {first start position, its 3 keys}, crec[2 slot + 1] = {first end position, its 3 keys}
+    const int4* crec;       //   crec[slot] = {first start position | more << 31, first end position | more << 31, 2 x 16-bit start offsets, 2 x 16-bit end offsets}
     const int4* nrec;       // nearest: nrec[p] = {pmax[p-1], row of its argmax, start[p], end[p]} (left / right candidate of hi = p)
     const int4* rec4;       // flat overlap path: {start, end, build row, prefix max} per sorted position
     const uint2* tab2;      //   tab2[slot] = {first position of start bin `slot`, first position whose prefix max reaches its lower edge}

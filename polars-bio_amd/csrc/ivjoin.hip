@@ -69,6 +69,9 @@ int ivj_ctx_create(int device, ivj_ctx** out) {
     if (const char* ev = std::getenv("IVJ_SLICE_AUTO")) ctx->sl_env_auto = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_SLICE_STABLE")) ctx->sl_env_stable = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_SLICE_SCATTER_THREADS")) ctx->sl_env_sthreads = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_JOINT_BINS")) ctx->env_joint_bins = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_COUNT_ABLATE")) ctx->env_count_ablate = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_COUNT_NOLDS")) ctx->env_count_nolds = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_INDEX_V1")) ctx->ix_v1 = std::atoi(ev) != 0;
     e = hipHostMalloc((void**)&ctx->h_total, 64, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(IVJ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }

@@ -231,6 +231,7 @@ struct UnpermuteCols {
 };
 
 __global__ __launch_bounds__(UNP_THREADS) void k_unpermute(const int32_t* __restrict__ rows, const uint32_t* __restrict__ bstart,
+                                                           const uint32_t* __restrict__ tile_off, int ntiles,
                                                            int64_t n, UnpermuteCols cols) {
     __shared__ int l_lo[PART_BUCKETS];
     __shared__ int l_pre[PART_BUCKETS + 1];
@@ -239,19 +240,20 @@ __global__ __launch_bounds__(UNP_THREADS) void k_unpermute(const int32_t* __rest
     __shared__ unsigned long long stage[UNP_TILE];
     static_assert(PART_BUCKETS == UNP_THREADS, "one thread per bucket");
     static_assert(UNP_TILE == UNP_THREADS * 32, "32 elements per thread");
+    static_assert(UNP_TILE % PART_TILE == 0, "an output tile is a whole number of partition tiles");
     const long long r0 = (long long)blockIdx.x * UNP_TILE;
     const long long r1 = (r0 + UNP_TILE) < n ? (r0 + UNP_TILE) : n;
     const int t_all = (int)(r1 - r0);                          // every row of the tile sits in exactly one bucket
     int cnt;
     {
+        // the rows [r0, r1) of bucket b are one run of the bucket-ordered arrays (the partition is stable), and the run
+        // starts where the partition's scanned histogram put the first of the partition tiles this output tile covers:
+        // tile_off[b * ntiles + t] -- two reads instead of two bound searches over the row ids
         const int b = threadIdx.x;
-        const int s = (int)bstart[b], e = (int)bstart[b + 1];
-        int lo = s, hi = e;
-        while (lo < hi) { const int m = lo + ((hi - lo) >> 1); if ((long long)rows[m] < r0) lo = m + 1; else hi = m; }
-        const int first = lo;
-        hi = e;
-        while (lo < hi) { const int m = lo + ((hi - lo) >> 1); if ((long long)rows[m] < r1) lo = m + 1; else hi = m; }
-        cnt = lo - first;
+        const int t0 = (int)(blockIdx.x * (UNP_TILE / PART_TILE)), t1 = t0 + UNP_TILE / PART_TILE;
+        const int first = (int)tile_off[(int64_t)b * ntiles + t0];
+        const int last = t1 < ntiles ? (int)tile_off[(int64_t)b * ntiles + t1] : (int)bstart[b + 1];
+        cnt = last - first;
         l_lo[b] = first;
     }
     // element t of the concatenated runs belongs to the last bucket whose prefix is <= t: mark + max-scan
