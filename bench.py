@@ -356,7 +356,7 @@ def main():
                 state["merged"] = tuple(torch.empty(d_build.n, dtype=dt, device=dev) for dt in (torch.int32, torch.int32, torch.int32, torch.int64))
             res = join.merge(d_build, True, nc, out=state["merged"])
             return int(res[0].shape[0]), res
-        return d_probe.n, join.nearest(d_probe, d_build, True, nc)
+        return d_probe.n, join.nearest(d_probe, d_build, True, nc, partition_mode=args.partition_mode)
 
     def barrier():
         if multi:

@@ -79,9 +79,9 @@ typedef struct {
     int32_t n_contigs;         /* size of the shared chrom dictionary */
     int32_t nearest_k;         /* RangeOptions.nearest_k, >= 1 (default 1) */
     int32_t include_overlaps;  /* RangeOptions.include_overlaps (default 1) */
-    int32_t partition_mode;    /* how the probe side is ordered before the join kernels run.  0 auto: large inputs take the
-                                  slice path (6) for the overlap pair kernels and the 256-bucket path (1) for the per-probe
-                                  kernels; 1 256 genomic buckets + window-scan kernels (deterministic); 2 never (probe order);
+    int32_t partition_mode;    /* how the probe side is ordered before the join kernels run.  0 auto: the fused overlap pass takes the
+                                  slice path (6) from 24 M probe rows against 4 M build rows on (tools/policy_sweep.py), large
+                                  inputs below that and the per-probe kernels the 256-bucket path (1), small ones none (2); 1 256 genomic buckets + window-scan kernels (deterministic); 2 never (probe order);
                                   5 flat (256 buckets + load-balanced candidate test, ivj_overlap_fused_dev only; with 0 the
                                   fused entry point picks it by itself when capacity >= 16 pairs per probe row, i.e. for dense
                                   results); 6 LDS-resident index slices: one stable partition into <= 1536 slices of equal

@@ -158,6 +158,26 @@ __global__ void k_nearest_records(const int32_t* __restrict__ b_start, const int
     nrec[p] = r;
 }
 
+// nearest (k = 1), overlapping case: the prefix max below position p is a staircase of levels (positions where it rises:
+// pargmax); the answer is the first row of the EARLIEST level whose value is still above q.start.  Level m (the current
+// one) is in nrec; orec[p] = {value, build row of the first row} of levels m-1 and m-2 (row -1: no such level inside the
+// contig segment), so a probe reads one more record instead of walking down the prefix max row by row.
+__global__ void k_nearest_levels(const int2* __restrict__ ep, const int32_t* __restrict__ b_row, const int32_t* __restrict__ b_contig,
+                                 const int32_t* __restrict__ pargmax, int64_t n, int4* __restrict__ orec) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n) return;
+    int4 r = make_int4(0, -1, 0, -1);
+    if (p >= 1) {
+        const int rm = pargmax[p - 1];
+        if (rm >= 1 && b_contig[rm - 1] == b_contig[rm]) {
+            const int r1 = pargmax[rm - 1];
+            r.x = ep[rm - 1].y; r.y = b_row[r1];
+            if (r1 >= 1 && b_contig[r1 - 1] == b_contig[r1]) { r.z = ep[r1 - 1].y; r.w = b_row[pargmax[r1 - 1]]; }
+        }
+    }
+    orec[p] = r;
+}
+
 // Per-contig metadata of the direct-address table: bin width 2^shift chosen so that the contig has
 // at most 2 n_c bins (about one build row per bin for evenly spread rows); its slice of the table
 // starts at tb = 2 a + 2 c.

@@ -54,6 +54,7 @@ struct IndexView {
     const int4* cmeta_j;    // count_overlaps: ONE bin grid per contig shared by the start- and the end-sorted order
     const int4* crec;       //   crec[slot] = {first start position | more << 31, first end position | more << 31, 2 x 16-bit start offsets, 2 x 16-bit end offsets}
     const int4* nrec;       // nearest: nrec[p] = {pmax[p-1], row of its argmax, start[p], end[p]} (left / right candidate of hi = p)
+    const int4* orec;       // nearest: orec[p] = {value, first row} of the two prefix-max levels below the one in nrec[p] (row -1: none)
     const int4* rec4;       // flat overlap path: {start, end, build row, prefix max} per sorted position
     const uint2* tab2;      //   tab2[slot] = {first position of start bin `slot`, first position whose prefix max reaches its lower edge}
     int32_t n_contigs;

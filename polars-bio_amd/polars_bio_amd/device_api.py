@@ -188,9 +188,9 @@ class DeviceJoin:
         return out
 
     def nearest(self, probe: DeviceSide, build: DeviceSide, strict: bool, n_contigs: int, k: int = 1,
-                include_overlaps: bool = True, index=None):
+                include_overlaps: bool = True, index=None, partition_mode: int = 0):
         torch = self.torch
-        opts = make_opts(strict, n_contigs, k, include_overlaps)
+        opts = make_opts(strict, n_contigs, k, include_overlaps, partition_mode=partition_mode)
         own = index is None
         general = not (k == 1 and include_overlaps)
         ix = self.engine.index_build_dev(build.as_c(), opts, general) if own else index

@@ -203,6 +203,39 @@ def test_dense_nested_build(eng):
     _cmp_all(eng, probe, (c, s, e), 1, True, nearest_cfgs=((1, True), (2, False)))
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_joint_grid_wide_and_crowded_bins_and_prefix_max_staircase(eng, strict):
+    """count_overlaps' 16-byte joint records and nearest's level records on the shapes their fast paths do NOT answer:
+    (a) bins wider than 2^16 (no inline key offsets: every non-empty bin searches), (b) bins with far more than two rows
+    (the gallop past the inline offsets), (c) a prefix max that rises at every row (more levels above q.start than the
+    level record holds: bound-search fallback)."""
+    rng = np.random.default_rng(91)
+    # (a) 300 rows over 2^31 coordinates, two contigs
+    nb = 300
+    bs = rng.integers(-(1 << 30), (1 << 30) - 70000, nb).astype(np.int32)
+    build = (rng.integers(0, 2, nb).astype(np.int32), bs, (bs + rng.integers(0, 60000, nb)).astype(np.int32))
+    ps = rng.integers(-(1 << 30), (1 << 30) - 70000, 6000).astype(np.int32)
+    ps[:300] = bs                                                   # probes on the rows themselves: the <= / < edge
+    probe = (rng.integers(0, 3, 6000).astype(np.int32), ps, (ps + rng.integers(0, 50000, 6000)).astype(np.int32))
+    _cmp_all(eng, probe, build, 2, strict, nearest_cfgs=((1, True),))
+    # (b) 60000 rows on 400 distinct starts (150 rows per key) and 300 distinct ends
+    keys = np.sort(rng.integers(0, 1_000_000, 400)).astype(np.int32)
+    bs = keys[rng.integers(0, 400, 60000)]
+    be = (bs + 10 * rng.integers(0, 300, 60000)).astype(np.int32)
+    build = (np.zeros(60000, np.int32), bs, be)
+    ps = rng.integers(-100, 1_000_100, 20000).astype(np.int32)
+    ps[:400] = keys
+    probe = (np.zeros(20000, np.int32), ps, (ps + rng.integers(0, 200, 20000)).astype(np.int32))
+    _cmp_all(eng, probe, build, 1, strict, nearest_cfgs=((1, True),))
+    # (c) every row ends later than all rows before it and all of them reach past every probe
+    n = 5000
+    bs = (10 * np.arange(n)).astype(np.int32)
+    build = (np.zeros(n, np.int32), bs, (1_000_000 + np.arange(n)).astype(np.int32))
+    ps = rng.integers(0, 60000, 4000).astype(np.int32)
+    probe = (np.zeros(4000, np.int32), ps, (ps + 25).astype(np.int32))
+    _cmp_all(eng, probe, build, 1, strict, nearest_cfgs=((1, True),))
+
+
 def _device_overlap(eng, probe, build, strict, n_contigs, partition_mode=0):
     """Device-resident entry points: what bench.py times."""
     ptrs, sides = [], []

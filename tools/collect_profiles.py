@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Copies the judged artefacts of one tools/gpu_r02.sh session (gpurun_out/<tag>_*) into profiles/r02/ under stable names
+and writes profiles/r02/MANIFEST.md (git commit the tree was built from, source hash stamped by bench.py, what each file is).
+usage: collect_profiles.py <tag> [<commit>]"""
+import glob, json, os, re, shutil, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC, DST = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", "r02")
+NAMES = {
+    "c3": "bench_overlap_100M_5M", "c3two": "bench_overlap_100M_5M_two_pass", "c3m1": "bench_overlap_100M_5M_mode1_window_scan",
+    "c3m6": "bench_overlap_100M_5M_mode6_slices", "c2": "bench_overlap_10M_1M", "c4": "bench_nearest_50M_2M", "c5": "bench_count_200M_200k",
+    "c3dense": "bench_overlap_100M_5M_dense", "c3rows": "bench_overlap_100M_5M_rows",
+    "sortscan_coverage_100M_5M_24contig": "bench_coverage_100M_5M", "sortscan_subtract_20M_5M_24contig": "bench_subtract_20M_5M",
+    "sortscan_merge_100M_24contig": "bench_merge_100M",
+}
+
+
+def main():
+    tag = sys.argv[1]
+    commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+    os.makedirs(DST, exist_ok=True)
+    lines = [f"# profiles/r02 -- artefacts of GPU session `{tag}`", "", f"Built from commit `{commit}` (+ the working tree at that time; "
+             "`source_sha16` in every bench line is the hash of the sources the run was made from).", "", "| file | what |", "|---|---|"]
+    tables = []
+    for stage, name in NAMES.items():
+        j = os.path.join(SRC, f"{tag}_{stage}.json")
+        if not os.path.exists(j):
+            continue
+        line = [l for l in open(j) if l.startswith("{")]
+        if not line:
+            continue
+        d = json.loads(line[-1])
+        with open(os.path.join(DST, name + ".json"), "w") as f:
+            json.dump(d, f, indent=1)
+            f.write("\n")
+        r = d.get("roofline") or {}
+        lines.append(f"| `{name}.json` | `bench.py` line: {d['ms_per_step']} ms/step, {d['value']:.4g} {d['unit']}; dominant kernel `{r.get('kernel')}` "
+                     f"{r.get('kernel_avg_ms')} ms, frac {r.get('frac')}, pipeline_frac {r.get('pipeline_frac')}, traffic {r.get('traffic')}; source {d.get('source_sha16')} |")
+        err = os.path.join(SRC, f"{tag}_{stage}.err")
+        if os.path.exists(err):
+            txt = open(err).read()
+            m = re.search(r"\[bench\] per-kernel HIP-event table.*?(?=\n\[|\Z)", txt, re.S)
+            if m:
+                tables.append(f"== {name}  ({d['ms_per_step']} ms/step)\n{m.group(0).strip()}\n")
+    if tables:
+        with open(os.path.join(DST, "kernel_tables_hipevents.txt"), "w") as f:
+            f.write("\n".join(tables))
+        lines.append("| `kernel_tables_hipevents.txt` | per-kernel HIP-event tables (`bench.py --kernel-table`, timing level 2) of the runs above |")
+    for src, dst, what in ((f"{tag}_prof.kernel_stats.csv", "rocprofv3_kernel_stats_overlap_100M_5M.csv", "`rocprofv3 --kernel-trace --stats` of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras` (config 3)"),
+                           (f"{tag}_fast.log", "pytest_gpu_fast.log", "`pytest -m gpu` without the full-size configs"),
+                           (f"{tag}_full.log", "pytest_gpu_full_size.log", "`pytest -m gpu -k 'full_size or two_rank or self_spawn'` (configs 3, 4, 5 at stated size; the 2-GPU tests skip on a 1-GPU box)")):
+        p = os.path.join(SRC, src)
+        if os.path.exists(p):
+            shutil.copyfile(p, os.path.join(DST, dst))
+            lines.append(f"| `{dst}` | {what} |")
+    keep = os.path.join(DST, "MANIFEST.extra.md")
+    if os.path.exists(keep):
+        lines += ["", open(keep).read().rstrip()]
+    with open(os.path.join(DST, "MANIFEST.md"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
