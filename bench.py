@@ -202,13 +202,14 @@ def pmc_traffic(args, kernel_short):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, {"error": "rocprofv3 not found"}
-    per = {}
+    rows = {}                        # counter -> [(dispatch id, kernel, value)]
     tmp = tempfile.mkdtemp(prefix="ivj_pmc_", dir="/tmp")
+    n_steps = 3
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [rocprof, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "pmc", "--output-format", "csv", "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-inner", "--workload", args.workload, "--steps", "3",
+                   sys.executable, os.path.abspath(__file__), "--pmc-inner", "--workload", args.workload, "--steps", str(n_steps),
                    "--warmup", "1", "--partition-mode", str(args.partition_mode), "--scale", str(args.scale)]
             if args.two_pass:
                 cmd.append("--two-pass")
@@ -221,39 +222,57 @@ def pmc_traffic(args, kernel_short):
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, {"error": f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})", "stderr_tail": r.stderr[-400:]}
+            acc = {}
             for f in files:
                 with open(f, newline="") as fh:
                     for row in csv.DictReader(fh):
-                        name = (row.get("Kernel_Name") or row.get("Kernel Name") or "").split("(")[0].replace("void ", "").strip()
                         if (row.get("Counter_Name") or row.get("Counter Name")) != ctr:
                             continue
-                        did = row.get("Dispatch_Id") or row.get("Dispatch Id") or ""
-                        e = per.setdefault(name, {}).setdefault(ctr, {})
-                        e[did] = e.get(did, 0.0) + float(row.get("Counter_Value") or row.get("Counter Value") or 0.0)
+                        name = (row.get("Kernel_Name") or row.get("Kernel Name") or "").split("(")[0].replace("void ", "").strip()
+                        did = int(row.get("Dispatch_Id") or row.get("Dispatch Id") or 0)
+                        e = acc.setdefault(did, [name, 0.0])
+                        e[1] += float(row.get("Counter_Value") or row.get("Counter Value") or 0.0)      # summed over the XCDs
+            rows[ctr] = sorted((did, v[0], v[1]) for did, v in acc.items())
     except Exception as e:   # profiling must never take the bench line down
         return None, {"error": repr(e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    table = {}
-    for name, c in per.items():
-        f = c.get("FETCH_SIZE", {}); w = c.get("WRITE_SIZE", {})
-        fk = sum(f.values()) / max(len(f), 1); wk = sum(w.values()) / max(len(w), 1)
-        table[name] = {"launches": max(len(f), len(w)), "FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1),
-                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    # the inner run launches ivj::k_profile_mark before every step and after the last one: the dispatches between the
+    # last n_steps + 1 marks are the timed steps (the warm-up step sizes the result buffers through other kernels)
+    table, step_bytes = {}, []
+    for ctr, lst in rows.items():
+        marks = [i for i, (_, name, _) in enumerate(lst) if "k_profile_mark" in name]
+        if len(marks) < n_steps + 1:
+            return None, {"error": f"step marks missing in the {ctr} pass ({len(marks)} found)"}
+        lo, hi = marks[-(n_steps + 1)], marks[-1]
+        for _, name, val in lst[lo:hi]:
+            if "k_profile_mark" in name:
+                continue
+            e = table.setdefault(name, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+            e[ctr][0] += val
+            e[ctr][1] += 1
+    out_tab = {}
+    for name, e in table.items():
+        (fs, fn), (ws, wn) = e["FETCH_SIZE"], e["WRITE_SIZE"]
+        launches = max(fn, wn)
+        fk, wk = fs / max(fn, 1), ws / max(wn, 1)
+        out_tab[name] = {"launches_per_step": round(launches / n_steps, 2), "FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1),
+                         "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    table = out_tab
     # timing label -> kernel symbol: "overlap_fused" is ivj::k_overlap_fused<..>, "slice_join_fused" is one instantiation of
     # ivj::k_slice_join<STRICT, MODE, ITEMS> (the label's last word names the template mode), so trailing words are dropped
-    # until a symbol matches; of several instantiations the one launched in every timed step wins
+    # until a symbol matches; of several instantiations the one launched most often wins
     hit, stem = [], kernel_short or ""
     while stem and not hit:
         hit = [k for k in table if ("k_" + stem + "<") in k or k.endswith("k_" + stem)] or [k for k in table if ("k_" + stem) in k]
         stem = stem.rpartition("_")[0]
-    hit.sort(key=lambda k: (-table[k]["launches"], -table[k]["hbm_bytes_per_launch"]))
+    hit.sort(key=lambda k: (-table[k]["launches_per_step"], -table[k]["hbm_bytes_per_launch"]))
     traffic = table[hit[0]]["hbm_bytes_per_launch"] if hit else None
-    step_total = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in table.values()) / 4.0   # 1 warmup + 3 steps
-    return traffic, {"source": "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over this command (3 steps)",
+    step_total = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in table.values())
+    return traffic, {"source": f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over this command; the {n_steps} timed steps, cut at the ivj::k_profile_mark dispatches",
                      "correction": "2 x FETCH_SIZE + WRITE_SIZE (KiB)", "step_hbm_bytes": int(step_total),
                      "kernel_symbol": hit[0] if hit else None,
-                     "kernels": {k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]}}
+                     "kernels": {k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_step"])[:12]}}
 
 
 def respawn_under_torchrun(args):
@@ -363,14 +382,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    mark = join.engine.profile_mark if args.pmc_inner else (lambda: None)   # step boundaries for the PMC attribution
     for _ in range(args.warmup):
+        mark()
         local_units, out = step()
     barrier()
     state.pop("gather_events", None)
     join.engine.enable_timing(1)          # HIP events around the probe kernels only, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        mark()
         local_units, out = step()
+    mark()
     barrier()
     elapsed = time.perf_counter() - t0
     ktimes = join.engine.timings()

@@ -122,6 +122,9 @@ int ivj_ctx_sync(ivj_ctx* ctx);
 int ivj_ctx_enable_timing(ivj_ctx* ctx, int level);
 /* Synchronises, then writes up to cap entries; *n = number of distinct kernels. */
 int ivj_ctx_get_timings(ivj_ctx* ctx, ivj_timing* out, int cap, int* n);
+/* Launches the empty kernel ivj::k_profile_mark on the context's stream: a step boundary a profiler's kernel trace /
+ * counter collection can be cut at (bench.py attributes the PMC bytes of its own run to the timed steps with it). */
+int ivj_ctx_profile_mark(ivj_ctx* ctx);
 
 /* ---- host-buffer entry points (what the reference FFI would bind) ------- *
  * Inputs are borrowed host buffers; results come back in host memory.       */

@@ -145,20 +145,12 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
 #pragma unroll
     for (int k = 0; k < N; ++k) valid[k] = i0 + k < n;
     bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
-    // the candidate record of every probe, then (overlapping probes only) the record of the earlier prefix-max levels: two
-    // batches of gathers per thread instead of a walk down the prefix max, one dependent load per row
-    int4 R[N], O[N];
-    bool ovl[N];
+    // ONE 32-byte record per probe (both halves requested together): no walk down the prefix max, no separate build-row gather
+    int4 R[N], Q[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        R[k] = make_int4(0, -1, 0, 0);
-        if (i0 + k < n && b[k] > a[k]) R[k] = ix.nrec[hi[k]];     // {pmax[hi-1], its build row, start[hi], end[hi]}
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        ovl[k] = i0 + k < n && b[k] > a[k] && hi[k] > a[k] && lt_op<STRICT>(s[k], R[k].x);
-        O[k] = make_int4(0, -1, 0, -1);
-        if (ovl[k]) O[k] = ix.orec[hi[k]];
+        R[k] = make_int4(0, -1, 0, 0); Q[k] = make_int4(-1, 0, -1, (int)0x80000000);
+        if (i0 + k < n && b[k] > a[k]) { R[k] = ix.nrec[2 * (int64_t)hi[k]]; Q[k] = ix.nrec[2 * (int64_t)hi[k] + 1]; }
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -166,19 +158,19 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
         int32_t idx = -1; long long dist = -1; int32_t found = 0;
         if (b[k] > a[k]) {
             const bool have_l = hi[k] > a[k], have_r = hi[k] < b[k];
-            if (ovl[k]) {
+            if (have_l && lt_op<STRICT>(s[k], R[k].x)) {
                 // some row below hi overlaps.  The overlapping row with the smallest (start,row) is the first position whose
                 // prefix max satisfies "q.start (<) pmax", i.e. the first row of the earliest prefix-max level above q.start:
-                // level m (R), m-1, m-2 (O) come with their build rows; deeper levels fall back to the bound search
-                if (!(O[k].y >= 0 && lt_op<STRICT>(s[k], O[k].x))) idx = R[k].y;
-                else if (!(O[k].w >= 0 && lt_op<STRICT>(s[k], O[k].z))) idx = O[k].y;
+                // level m (R), m-1 (Q) come with their build rows; a probe below level m-2 as well takes the bound search
+                if (!(Q[k].z >= 0 && lt_op<STRICT>(s[k], Q[k].y))) idx = R[k].y;
+                else if (!lt_op<STRICT>(s[k], Q[k].w)) idx = Q[k].z;
                 else idx = ix.b_row[bound_lo<STRICT>(ix, a[k], hi[k], s[k])];
                 dist = 0; found = 1;
             } else {
                 const long long dl = (long long)s[k] - (long long)R[k].x;
                 const long long dr = have_r ? gap_dist(s[k], e[k], R[k].z, R[k].w) : 0;
                 if (have_l && (!have_r || dl <= dr)) { idx = R[k].y; dist = dl; found = 1; }
-                else if (have_r) { idx = ix.b_row[hi[k]]; dist = dr; found = 1; }
+                else if (have_r) { idx = Q[k].x; dist = dr; found = 1; }
             }
         }
         const int64_t o = out_row ? (int64_t)out_row[i0 + k] : i0 + k;

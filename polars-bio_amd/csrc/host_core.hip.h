@@ -123,7 +123,6 @@ struct ivj_index {
     int4* brec_e = nullptr;
     int32_t* pargmax = nullptr;
     int4* nrec = nullptr;
-    int4* orec = nullptr;
     int4* cmeta_j = nullptr;
     int4* crec = nullptr;
     int64_t bins_len = 0;
@@ -273,7 +272,7 @@ IndexView view_of(const ivj_index* ix) {
     IndexView v;
     v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
     v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
-    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec; v.orec = ix->orec; v.cmeta_j = ix->cmeta_j; v.crec = ix->crec;
+    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec; v.cmeta_j = ix->cmeta_j; v.crec = ix->crec;
     v.bins = ix->bins; v.bins_e = ix->bins_e; v.rec4 = ix->rec4; v.tab2 = ix->tab2;
     // 16-byte bin records once the 4-byte tables + key arrays no longer fit the XCD L2s anyway
     v.use_rec = ix->table_mode == 1 ? 1 : (ix->table_mode == 2 ? 0 : (ix->n >= (1ll << 20) ? 1 : 0));

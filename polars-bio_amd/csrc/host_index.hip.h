@@ -75,9 +75,7 @@ int build_argmax(ivj_ctx* ctx, ivj_index* ix) {
     LAUNCH(ctx, "pmax_change", k_pmax_change, grid1d(n, 256), 256, (const int2*)ix->ep, (const int32_t*)ix->b_contig, n, (uint32_t*)ix->pargmax);
     device_scan<uint32_t, MaxOp, true>(ctx, "argmax_scan", (uint32_t*)ix->pargmax, (uint32_t*)ix->pargmax, n, 0u, part, (uint32_t*)nullptr);
     LAUNCH(ctx, "nearest_records", k_nearest_records, grid1d(n + 1, 256), 256, (const int32_t*)ix->b_start, (const int2*)ix->ep,
-           (const int32_t*)ix->b_row, (const int32_t*)ix->pargmax, n, ix->nrec);
-    LAUNCH(ctx, "nearest_levels", k_nearest_levels, grid1d(n + 1, 256), 256, (const int2*)ix->ep, (const int32_t*)ix->b_row,
-           (const int32_t*)ix->b_contig, (const int32_t*)ix->pargmax, n, ix->orec);
+           (const int32_t*)ix->b_row, (const int32_t*)ix->b_contig, (const int32_t*)ix->pargmax, n, ix->nrec);
     ix->has_argmax = true;
     return IVJ_OK;
 }
@@ -257,7 +255,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t flat_bytes = align_up((nn + 1) * 16) + 3 * align_up((size_t)ix->bins_len * 4);   // rec4, lot, tab2 (filled on demand)
         const size_t spl_bytes = align_up((size_t)SL_MAX_BUCKETS * 8) + align_up((size_t)SL_TAB_CONTIGS * 16) +
                                  align_up((size_t)(4 * SL_MAX_BUCKETS + SL_TAB_CONTIGS) * 4);
-        const size_t need = spl_bytes + flat_bytes + 6 * col + align_up(nn * 8) + 2 * align_up((nn + 1) * 16) + 2 * align_up((size_t)ix->bins_len * 4) +
+        const size_t need = spl_bytes + flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 32) + 2 * align_up((size_t)ix->bins_len * 4) +
                             3 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
@@ -279,8 +277,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->e_end = (int32_t*)p; p += col;
         ix->e_pos = (int32_t*)p; p += col;
         ix->pargmax = (int32_t*)p; p += col;
-        ix->nrec = (int4*)p; p += align_up((nn + 1) * 16);
-        ix->orec = (int4*)p; p += align_up((nn + 1) * 16);
+        ix->nrec = (int4*)p; p += align_up((nn + 1) * 32);           // 32-byte nearest records
         ix->bins = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
         ix->bins_e = (uint32_t*)p; p += align_up((size_t)ix->bins_len * 4);
         ix->brec = (int4*)p; p += align_up((size_t)ix->bins_len * 16);

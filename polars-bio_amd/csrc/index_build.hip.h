@@ -144,38 +144,33 @@ __global__ void k_joint_records(const uint32_t* __restrict__ bins_s, const uint3
     jrec[i] = make_int4((int)ws, (int)we, (int)os, (int)oe);
 }
 
-// nearest (k = 1): everything the no-overlap case needs about a bound position p in ONE 16-byte
-// record: the best row on the left (largest end among rows < p: value and build row) and the row
-// at p (start, end).  n + 1 records; the fields that do not exist (p = 0 / p = n) are never read.
+// nearest (k = 1): everything a probe needs about its bound position p in ONE 32-byte record (two 16-byte halves of one
+// line, requested together):
+//   nrec[2p]     = {pmax[p-1], build row of the first row attaining it, start[p], end[p]}   left / right candidate
+//   nrec[2p + 1] = {build row of row p (-1: p = n), v1, row1, v2}                            earlier prefix-max levels
+// The prefix max below p is a staircase of levels (positions where it rises: pargmax); for an overlapping probe the
+// answer is the first row of the EARLIEST level whose value is still above q.start.  Level m (the current one) is in the
+// first half; v1 / row1 = value and first row of level m-1 (row1 = -1: no such level inside the contig segment), v2 =
+// value of level m-2 (INT32_MIN: none) -- a probe below v2 too falls back to the bound search, which is always right.
+// n + 1 records; the fields that do not exist (p = 0 / p = n) are never read.
 __global__ void k_nearest_records(const int32_t* __restrict__ b_start, const int2* __restrict__ ep,
-                                  const int32_t* __restrict__ b_row, const int32_t* __restrict__ pargmax, int64_t n,
-                                  int4* __restrict__ nrec) {
+                                  const int32_t* __restrict__ b_row, const int32_t* __restrict__ b_contig,
+                                  const int32_t* __restrict__ pargmax, int64_t n, int4* __restrict__ nrec) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p > n) return;
-    int4 r = make_int4(0, -1, 0, 0);
-    if (p >= 1) { r.x = ep[p - 1].y; r.y = b_row[pargmax[p - 1]]; }
-    if (p < n) { r.z = b_start[p]; r.w = ep[p].x; }
-    nrec[p] = r;
-}
-
-// nearest (k = 1), overlapping case: the prefix max below position p is a staircase of levels (positions where it rises:
-// pargmax); the answer is the first row of the EARLIEST level whose value is still above q.start.  Level m (the current
-// one) is in nrec; orec[p] = {value, build row of the first row} of levels m-1 and m-2 (row -1: no such level inside the
-// contig segment), so a probe reads one more record instead of walking down the prefix max row by row.
-__global__ void k_nearest_levels(const int2* __restrict__ ep, const int32_t* __restrict__ b_row, const int32_t* __restrict__ b_contig,
-                                 const int32_t* __restrict__ pargmax, int64_t n, int4* __restrict__ orec) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > n) return;
-    int4 r = make_int4(0, -1, 0, -1);
+    int4 r = make_int4(0, -1, 0, 0), q = make_int4(-1, 0, -1, (int)0x80000000);
     if (p >= 1) {
         const int rm = pargmax[p - 1];
+        r.x = ep[p - 1].y; r.y = b_row[rm];
         if (rm >= 1 && b_contig[rm - 1] == b_contig[rm]) {
             const int r1 = pargmax[rm - 1];
-            r.x = ep[rm - 1].y; r.y = b_row[r1];
-            if (r1 >= 1 && b_contig[r1 - 1] == b_contig[r1]) { r.z = ep[r1 - 1].y; r.w = b_row[pargmax[r1 - 1]]; }
+            q.y = ep[rm - 1].y; q.z = b_row[r1];
+            if (r1 >= 1 && b_contig[r1 - 1] == b_contig[r1]) q.w = ep[r1 - 1].y;
         }
     }
-    orec[p] = r;
+    if (p < n) { r.z = b_start[p]; r.w = ep[p].x; q.x = b_row[p]; }
+    nrec[2 * p] = r;
+    nrec[2 * p + 1] = q;
 }
 
 // Per-contig metadata of the direct-address table: bin width 2^shift chosen so that the contig has
@@ -214,9 +209,12 @@ __global__ void k_bins_mark(const int32_t* __restrict__ b_start, const int32_t* 
     if (p == m0.x) bins[(uint32_t)m1.y] = (uint32_t)p;
 }
 
-// brec[i] = {p0, key[p0], key[p0+1], key[p0+2]} for table slot i (p0 = bins[i] after the max-scan);
-// keys past the end of the slot's contig segment are replaced by INT32_MAX (compares as "not below"
-// any reachable target).  The contig of a slot is found by a bound search over the table offsets.
+// brec[i] for table slot i (p0 = bins[i] after the max-scan; bins[i + 1] - bins[i] = rows in the bin; the slot after a
+// contig's last bin holds the segment end).  Bins at most 2^16 wide: {p0 | more << 31, o0 | o1 << 16, o2 | o3 << 16,
+// o4 | o5 << 16}, o_j = key of row p0 + j as an offset from the bin's lower edge, 0xffff when the bin has no such row
+// (a target's own offset is < 2^shift <= 0xffff + 1, so 0xffff never counts as below it); more = a seventh row exists.
+// Wider bins: {p0 | more << 31, key[p0], key[p0+1], key[p0+2]} (keys past the contig segment: INT32_MAX), more = the bin
+// holds a fourth row.  The contig of a slot is found by a bound search over the table offsets.
 __global__ void k_bins_records(const uint32_t* __restrict__ bins, int64_t bins_len, const int32_t* __restrict__ keys,
                                const int4* __restrict__ cmeta, int32_t n_contigs, int4* __restrict__ brec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,15 +223,28 @@ __global__ void k_bins_records(const uint32_t* __restrict__ bins, int64_t bins_l
     int lo = 0, hi = n_contigs;
     while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= i) lo = m + 1; else hi = m; }
     const int c = lo - 1;
-    const int p0 = (int)bins[i];
-    int32_t k0 = 0x7fffffff, k1 = 0x7fffffff, k2 = 0x7fffffff;
+    const uint32_t p0 = bins[i];
+    int4 r = make_int4((int)p0, 0x7fffffff, 0x7fffffff, 0x7fffffff);
     if (c >= 0) {
-        const int bend = cmeta[2 * c].y;
-        if (p0 < bend) k0 = keys[p0];
-        if (p0 + 1 < bend) k1 = keys[p0 + 1];
-        if (p0 + 2 < bend) k2 = keys[p0 + 2];
+        const int4 m0 = cmeta[2 * c], m1 = cmeta[2 * c + 1];
+        const uint32_t bend = (uint32_t)m0.y;
+        uint32_t nx = i + 1 < bins_len ? bins[i + 1] : bend;
+        nx = nx < bend ? nx : bend;
+        const uint32_t cnt = nx > p0 ? nx - p0 : 0u;
+        if (m1.x <= 16) {
+            const uint32_t edge = (uint32_t)m0.z + (uint32_t)(((unsigned long long)(i - (int64_t)m1.y)) << m1.x);
+            uint32_t o[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) o[j] = (uint32_t)j < cnt ? ((flip(keys[p0 + j]) - edge) & 0xffffu) : 0xffffu;
+            r = make_int4((int)(p0 | (cnt > 6u ? 0x80000000u : 0u)), (int)(o[0] | (o[1] << 16)), (int)(o[2] | (o[3] << 16)), (int)(o[4] | (o[5] << 16)));
+        } else {
+            if (p0 < bend) r.y = keys[p0];
+            if (p0 + 1 < bend) r.z = keys[p0 + 1];
+            if (p0 + 2 < bend) r.w = keys[p0 + 2];
+            r.x = (int)(p0 | (cnt > 3u ? 0x80000000u : 0u));
+        }
     }
-    brec[i] = make_int4(p0, k0, k1, k2);
+    brec[i] = r;
 }
 
 }  // namespace ivj

@@ -11,10 +11,12 @@
 //   rec4[Nb]     int4    {start, end, row, pmax}: the one read per candidate of the flat overlap path (flat.hip.h)
 //   tab2[2 Nb + 2 n_contigs] uint2 per start bin: {first position of the bin, first position whose prefix max
 //                        reaches the bin's lower edge}
-//   brec[2 Nb + 2 n_contigs] direct-address table over start, 16 B per bin: first position of the
-//                        bin and the keys of the next three rows; about one build row per bin, so
-//                        the hi-bound of a probe is ONE 16-byte gather (3 compares) instead of a
-//                        log2(Nb)-step binary search of dependent gathers
+//   brec[2 Nb + 2 n_contigs] direct-address table over start, 16 B per bin: first position of the bin (bit 31: the bin
+//                        holds more rows than the record shows) and the keys of its first SIX rows as 16-bit offsets
+//                        from the bin's lower edge (0xffff: no such row) -- bins wider than 2^16: the 32-bit keys of
+//                        rows p0 .. p0+2 instead; about one build row per bin, so the hi-bound of a probe is ONE
+//                        16-byte gather instead of a log2(Nb)-step binary search of dependent gathers, and a wavefront
+//                        practically never waits for a lane that has to search a crowded bin
 //
 // Predicate (polars_bio/range_op.py:75-84; src/option.rs:95-100):
 //   STRICT: q.start <  b.end && b.start <  q.end      WEAK: <=
@@ -42,8 +44,8 @@ struct IndexView {
     const int32_t* e_pos;
     const int32_t* flags;  // flags[0] != 0: some build row has start > end
     const int4* cmeta;     // per contig: {a, b, ulo, uhi} {shift, tb, 0, 0}  (two int4)
-    const int4* brec;      // direct-address table: brec[tb + j] = {p0, key[p0], key[p0+1], key[p0+2]} with
-                           // p0 = first position whose ustart >= ulo + (j << shift)
+    const int4* brec;      // direct-address table: brec[tb + j] = {p0 | more << 31, six 16-bit key offsets} (bins <= 2^16 wide)
+                           // or {p0 | more << 31, key[p0], key[p0+1], key[p0+2]}; p0 = first position whose ustart >= ulo + (j << shift)
     const uint32_t* bins;  // the same table as plain first positions (4 B per bin): used instead of brec for
                            // small build sides, whose 4-byte tables + key arrays stay L2-resident
     const int4* cmeta_e;   // the same pair of structures over the end-sorted order (e_end)
@@ -53,8 +55,8 @@ struct IndexView {
     const int32_t* pargmax; // position of the first row that attains ep[p].y (prefix max) -- nearest only
     const int4* cmeta_j;    // count_overlaps: ONE bin grid per contig shared by the start- and the end-sorted order
     const int4* crec;       //   crec[slot] = {first start position | more << 31, first end position | more << 31, 2 x 16-bit start offsets, 2 x 16-bit end offsets}
-    const int4* nrec;       // nearest: nrec[p] = {pmax[p-1], row of its argmax, start[p], end[p]} (left / right candidate of hi = p)
-    const int4* orec;       // nearest: orec[p] = {value, first row} of the two prefix-max levels below the one in nrec[p] (row -1: none)
+    const int4* nrec;       // nearest: nrec[2p] = {pmax[p-1], row of its argmax, start[p], end[p]}, nrec[2p+1] = {row of p, v1, row1, v2}
+                            // (left / right candidate of hi = p; the two prefix-max levels below the current one)
     const int4* rec4;       // flat overlap path: {start, end, build row, prefix max} per sorted position
     const uint2* tab2;      //   tab2[slot] = {first position of start bin `slot`, first position whose prefix max reaches its lower edge}
     int32_t n_contigs;
@@ -163,15 +165,33 @@ __device__ __forceinline__ void lb_tab4(const int4* __restrict__ cmeta, const in
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             if (!inb[k]) continue;
-            // rows p0, p0+1, p0+2 of the bin (or later bins / a sentinel past the segment): keys
-            // ascend, so the number of leading keys below the target is the offset of the bound
-            const bool n0 = (unsigned long long)flip(rec[k].y) < tu[k];
-            const bool n1 = n0 && (unsigned long long)flip(rec[k].z) < tu[k];
-            const bool n2 = n1 && (unsigned long long)flip(rec[k].w) < tu[k];
-            int lo = rec[k].x + (n0 ? 1 : 0) + (n1 ? 1 : 0) + (n2 ? 1 : 0);
-            if (n2) {
-                // crowded bin: finish with a bound search up to the first row of the next bin
-                int hi = brec[slot[k] + 1].x;
+            // the record answers the rank inside the bin without touching the key array: six inline 16-bit key offsets
+            // (narrow bins), or the keys of rows p0 .. p0+2 (bins wider than 2^16).  Keys of later bins are >= the bin's
+            // upper edge > target, so only rows of this bin count; "more" = the bin holds rows the record does not show.
+            const int p0 = rec[k].x & 0x7fffffff;
+            const bool more = rec[k].x < 0;
+            int lo;
+            bool full;
+            if (m1[k].x <= 16) {
+                const uint32_t toff = ((uint32_t)tu[k] - (uint32_t)m0[k].z) & ((1u << m1[k].x) - 1u);
+                const uint32_t w1 = (uint32_t)rec[k].y, w2 = (uint32_t)rec[k].z, w3 = (uint32_t)rec[k].w;
+                const int cnt = ((w1 & 0xffffu) < toff ? 1 : 0) + ((w1 >> 16) < toff ? 1 : 0) + ((w2 & 0xffffu) < toff ? 1 : 0) +
+                                ((w2 >> 16) < toff ? 1 : 0) + ((w3 & 0xffffu) < toff ? 1 : 0) + ((w3 >> 16) < toff ? 1 : 0);
+                lo = p0 + cnt;
+                full = cnt == 6;
+            } else {
+                const bool n0 = (unsigned long long)flip(rec[k].y) < tu[k];
+                const bool n1 = n0 && (unsigned long long)flip(rec[k].z) < tu[k];
+                const bool n2 = n1 && (unsigned long long)flip(rec[k].w) < tu[k];
+                lo = p0 + (n0 ? 1 : 0) + (n1 ? 1 : 0) + (n2 ? 1 : 0);
+                full = n2;
+            }
+            if (full && more) {
+                // crowded bin: gallop up the key array from the rows already counted (bounded by the contig segment; the
+                // rows of the bin end before the first key >= target), then a bound search
+                int step = 1;
+                while (lo + step - 1 < b[k] && (unsigned long long)flip(keys[lo + step - 1]) < tu[k]) { lo += step; step <<= 1; }
+                int hi = lo + step - 1 < b[k] ? lo + step - 1 : b[k];
                 while (lo < hi) {
                     const int m = lo + ((hi - lo) >> 1);
                     if ((unsigned long long)flip(keys[m]) < tu[k]) lo = m + 1; else hi = m;

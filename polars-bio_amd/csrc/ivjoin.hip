@@ -107,6 +107,16 @@ int ivj_ctx_sync(ivj_ctx* ctx) {
     return IVJ_OK;
 }
 
+namespace ivj { __global__ void k_profile_mark() {} }
+
+int ivj_ctx_profile_mark(ivj_ctx* ctx) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(ivj::k_profile_mark, dim3(1), dim3(1), 0, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
 int ivj_ctx_enable_timing(ivj_ctx* ctx, int on) {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -219,8 +219,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(IndexView ix, con
 // output rows [r0, r0 + UNP_TILE) are 256 short CONTIGUOUS runs (one per bucket, found by two bound searches
 // on the row-id column).  A workgroup reads those runs coalesced, places them in LDS by row and writes the
 // tile out coalesced.  Up to three columns of 4- or 8-byte values share the searches.
-constexpr int UNP_THREADS = 256;
+constexpr int UNP_THREADS = 1024;   // 16 wavefronts per 72-KiB workgroup, two workgroups per CU: the gathers of a tile are latency-bound
 constexpr int UNP_TILE = 8192;
+constexpr int UNP_PER = UNP_TILE / UNP_THREADS;
 
 struct UnpermuteCols {
     const void* src[3];
@@ -230,6 +231,28 @@ struct UnpermuteCols {
     int32_t* flag_dst;   // optional: flag_dst[row] = (int32 value of column 0 >= 0), written with column 0
 };
 
+// exclusive scan over the UNP_THREADS threads of the workgroup (lds: UNP_THREADS / 64 entries)
+template <class Op>
+__device__ __forceinline__ int unp_block_exclusive_scan(int v, Op op, int identity, int* lds, int* total) {
+    constexpr int NW = UNP_THREADS / kWave;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const int inc = wave_inclusive_scan(v, op);
+    if (lane == kWave - 1) lds[w] = inc;
+    __syncthreads();
+    int wprefix = identity, tot = identity;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int x = lds[i];
+        if (i < w) wprefix = op(wprefix, x);
+        tot = op(tot, x);
+    }
+    int exc = __shfl_up(inc, 1, kWave);
+    if (lane == 0) exc = identity;
+    __syncthreads();
+    *total = tot;
+    return op(wprefix, exc);
+}
+
 __global__ __launch_bounds__(UNP_THREADS) void k_unpermute(const int32_t* __restrict__ rows, const uint32_t* __restrict__ bstart,
                                                            const uint32_t* __restrict__ tile_off, int ntiles,
                                                            int64_t n, UnpermuteCols cols) {
@@ -238,14 +261,14 @@ __global__ __launch_bounds__(UNP_THREADS) void k_unpermute(const int32_t* __rest
     __shared__ int lds_i[UNP_THREADS / kWave];
     __shared__ __align__(16) uint8_t l_bucket[UNP_TILE];      // bucket of the t-th element of the concatenated runs
     __shared__ unsigned long long stage[UNP_TILE];
-    static_assert(PART_BUCKETS == UNP_THREADS, "one thread per bucket");
-    static_assert(UNP_TILE == UNP_THREADS * 32, "32 elements per thread");
+    static_assert(PART_BUCKETS <= UNP_THREADS && PART_BUCKETS <= 256, "one thread per bucket, bucket ids in a byte");
+    static_assert(UNP_TILE == UNP_THREADS * UNP_PER && UNP_PER == 8, "8 elements per thread (one 8-byte LDS word of bucket ids)");
     static_assert(UNP_TILE % PART_TILE == 0, "an output tile is a whole number of partition tiles");
     const long long r0 = (long long)blockIdx.x * UNP_TILE;
     const long long r1 = (r0 + UNP_TILE) < n ? (r0 + UNP_TILE) : n;
     const int t_all = (int)(r1 - r0);                          // every row of the tile sits in exactly one bucket
-    int cnt;
-    {
+    int cnt = 0;
+    if (threadIdx.x < PART_BUCKETS) {
         // the rows [r0, r1) of bucket b are one run of the bucket-ordered arrays (the partition is stable), and the run
         // starts where the partition's scanned histogram put the first of the partition tiles this output tile covers:
         // tile_off[b * ntiles + t] -- two reads instead of two bound searches over the row ids
@@ -258,24 +281,22 @@ __global__ __launch_bounds__(UNP_THREADS) void k_unpermute(const int32_t* __rest
     }
     // element t of the concatenated runs belongs to the last bucket whose prefix is <= t: mark + max-scan
     int tot;
-    const int pre = block_exclusive_scan(cnt, SumOp(), 0, lds_i, &tot);
-    l_pre[threadIdx.x] = pre;
-    uint4* lb4 = reinterpret_cast<uint4*>(l_bucket);
-    lb4[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
-    lb4[threadIdx.x + UNP_THREADS] = make_uint4(0u, 0u, 0u, 0u);
+    const int pre = unp_block_exclusive_scan(cnt, SumOp(), 0, lds_i, &tot);
+    if (threadIdx.x < PART_BUCKETS) l_pre[threadIdx.x] = pre;
+    reinterpret_cast<unsigned long long*>(l_bucket)[threadIdx.x] = 0ull;
     __syncthreads();
     if (cnt > 0) l_bucket[pre] = (uint8_t)threadIdx.x;
     __syncthreads();
     {
-        // thread owns 32 consecutive entries; the running max starts from the buckets before them
+        // thread owns 8 consecutive entries; the running max starts from the buckets before them
         uint32_t own = 0;
-        uint8_t* mine = l_bucket + threadIdx.x * 32;
+        uint8_t* mine = l_bucket + threadIdx.x * UNP_PER;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) own = own > mine[j] ? own : mine[j];
+        for (int j = 0; j < UNP_PER; ++j) own = own > mine[j] ? own : mine[j];
         int dummy;
-        uint32_t run = (uint32_t)block_exclusive_scan((int)own, MaxOp(), 0, lds_i, &dummy);
+        uint32_t run = (uint32_t)unp_block_exclusive_scan((int)own, MaxOp(), 0, lds_i, &dummy);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) { run = run > mine[j] ? run : mine[j]; mine[j] = (uint8_t)run; }
+        for (int j = 0; j < UNP_PER; ++j) { run = run > mine[j] ? run : mine[j]; mine[j] = (uint8_t)run; }
     }
     __syncthreads();
     for (int c = 0; c < cols.ncols; ++c) {

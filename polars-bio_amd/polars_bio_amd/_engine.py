@@ -25,7 +25,7 @@ FILTER_STRICT = 1  # FilterOp.Strict (0-based half-open)
 # every symbol include/ivjoin.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "ivj_last_error", "ivj_version", "ivj_device_count", "ivj_ctx_create", "ivj_ctx_destroy",
-    "ivj_ctx_set_stream", "ivj_ctx_sync", "ivj_ctx_enable_timing", "ivj_ctx_get_timings",
+    "ivj_ctx_set_stream", "ivj_ctx_sync", "ivj_ctx_enable_timing", "ivj_ctx_get_timings", "ivj_ctx_profile_mark",
     "ivj_overlap", "ivj_pairs_free", "ivj_count_overlaps", "ivj_nearest",
     "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev", "ivj_overlap_fused_dev",
     "ivj_count_overlaps_dev", "ivj_nearest_dev",
@@ -121,6 +121,7 @@ def load_library() -> C.CDLL:
         L.ivj_ctx_set_stream.argtypes = [vp, vp]
         L.ivj_ctx_sync.argtypes = [vp]
         L.ivj_ctx_enable_timing.argtypes = [vp, C.c_int]
+        L.ivj_ctx_profile_mark.argtypes = [vp]
         L.ivj_ctx_get_timings.argtypes = [vp, C.POINTER(_Timing), C.c_int, C.POINTER(C.c_int)]
         L.ivj_overlap.argtypes = [vp, P, P, O, C.POINTER(_Pairs)]
         L.ivj_pairs_free.argtypes = [C.POINTER(_Pairs)]
@@ -535,6 +536,10 @@ class Engine:
     def enable_timing(self, level: int = 2):
         """0 off, 1 probe kernels only, 2 every kernel (HIP events on the launch stream)."""
         _check(self.L, self.L.ivj_ctx_enable_timing(self.h, int(level)), "ivj_ctx_enable_timing")
+
+    def profile_mark(self):
+        """An empty marker kernel on the context's stream (step boundary for a profiler)."""
+        _check(self.L, self.L.ivj_ctx_profile_mark(self.h), "ivj_ctx_profile_mark")
 
     def timings(self) -> dict:
         arr = (_Timing * 64)()
