@@ -130,7 +130,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
                                                               const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
                                                               const int32_t* __restrict__ out_row,
                                                               int32_t* __restrict__ out_idx, long long* __restrict__ out_dist,
-                                                              int32_t* __restrict__ out_n) {
+                                                              int32_t* __restrict__ out_n, int ablate) {
     // out_row: the probes are a bucketed permutation (partition.hip.h); results go to the original rows
     const long long ntiles = (n + PROBE_THREADS * N - 1) / (PROBE_THREADS * N);
     const long long tile = xcd_tile64(blockIdx.x, ntiles);
@@ -144,13 +144,16 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
     bool valid[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) valid[k] = i0 + k < n;
-    bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
+    if (ablate & 1) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) { a[k] = 0; b[k] = valid[k] ? 1 : 0; hi[k] = (s[k] >> 8) & 0xffff; }      // profiling: no table lookup
+    } else bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
     // ONE 32-byte record per probe (both halves requested together): no walk down the prefix max, no separate build-row gather
     int4 R[N], Q[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         R[k] = make_int4(0, -1, 0, 0); Q[k] = make_int4(-1, 0, -1, (int)0x80000000);
-        if (i0 + k < n && b[k] > a[k]) { R[k] = ix.nrec[2 * (int64_t)hi[k]]; Q[k] = ix.nrec[2 * (int64_t)hi[k] + 1]; }
+        if (i0 + k < n && b[k] > a[k] && !(ablate & 2)) { R[k] = ix.nrec[2 * (int64_t)hi[k]]; Q[k] = ix.nrec[2 * (int64_t)hi[k] + 1]; }
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
             }
         }
         const int64_t o = out_row ? (int64_t)out_row[i0 + k] : i0 + k;
+        if ((ablate & 4) && idx != 123456789) continue;
         out_idx[o] = idx; out_dist[o] = dist; out_n[o] = found;
     }
 }

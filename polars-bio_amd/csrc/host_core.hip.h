@@ -126,7 +126,7 @@ struct ivj_index {
     int4* cmeta_j = nullptr;
     int4* crec = nullptr;
     int64_t bins_len = 0;
-    bool has_end_order = false;
+    bool has_end_order = false, has_end_table = false;
     bool has_argmax = false;
     bool has_flat = false;
     bool has_rec4 = false;

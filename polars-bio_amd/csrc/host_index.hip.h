@@ -14,35 +14,111 @@ int need_tables(ivj_ctx* ctx, ivj_index* ix) {
     return build_tables(ctx, ix);
 }
 
+// ---- the 11-bit LSD sort of 16-byte records {key, payload, row, contig} by (contig, key - min key) (onesweep.hip.h) -------------
+// Geometry + scratch of one sort; the scratch lives in the context's arena (the caller reserves os_sort_bytes and more).
+struct OsSort {
+    int64_t n = 0, chunk = 0, hist_len = 0, hs_tiles = 0, tiles = 0;
+    int nc = 0, cbits = 0, passes_max = 0, nchunks = 0;
+    size_t z_meta = 0, z_fin = 0, z_hs = 0, z_hist = 0, z_tick = 0, zero_bytes = 0;
+    char* z = nullptr;
+    int4 *recA = nullptr, *recB = nullptr;
+    OsMeta* meta = nullptr;
+    unsigned long long* st_fin = nullptr;
+};
+size_t os_sort_plan(OsSort& S, int64_t n, int nc) {
+    S.n = n; S.nc = nc;
+    S.cbits = os_bits_for((uint32_t)nc);                              // contig ids 0 .. nc (nc = rows outside the dictionary)
+    S.passes_max = (32 + S.cbits + OS_BITS - 1) / OS_BITS;
+    S.tiles = (n + OS_TILE - 1) / OS_TILE;
+    // chunks of the passes: about 512 workgroups, whole sub-tiles
+    S.chunk = ((n + 511) / 512 + OS_TILE - 1) / OS_TILE * OS_TILE;
+    if (S.chunk < OS_TILE) S.chunk = OS_TILE;
+    S.nchunks = (int)((n + S.chunk - 1) / S.chunk);
+    S.hist_len = (int64_t)OS_RADIX * S.nchunks;
+    S.hs_tiles = (S.hist_len + LB_TILE - 1) / LB_TILE;
+    S.z_meta = align_up(sizeof(OsMeta)); S.z_fin = align_up((size_t)S.tiles * 8);
+    S.z_hs = align_up((size_t)S.hs_tiles * 8) * (size_t)S.passes_max; S.z_hist = align_up((size_t)S.hist_len * 4) * (size_t)S.passes_max;
+    S.z_tick = align_up((size_t)(S.passes_max + 2) * 4);
+    S.zero_bytes = S.z_meta + S.z_fin + S.z_hs + S.z_hist + S.z_tick;
+    return S.zero_bytes + 2 * align_up((size_t)n * 16);
+}
+void os_sort_take(ivj_ctx* ctx, OsSort& S) {
+    S.z = arena_take<char>(ctx, S.zero_bytes);
+    S.recA = arena_take<int4>(ctx, S.n);
+    S.recB = arena_take<int4>(ctx, S.n);
+    S.meta = (OsMeta*)S.z;
+    S.st_fin = (unsigned long long*)(S.z + S.z_meta);
+}
+// min / max -> per pass [digit histogram per chunk, look-back scan, LDS-staged stable scatter of the records].  The sorted
+// records end up in recA or recB depending on the number of passes the key width needs (decided on the device: the consumer
+// kernel picks the buffer from meta, like k_ix_final).  `payload` travels in the record's .y, the row id (or i) in .z.
+int os_sort_run(ivj_ctx* ctx, OsSort& S, const int32_t* contig, const int32_t* key, const int32_t* payload, const int32_t* row_id) {
+    const int64_t n = S.n;
+    char* st_hs = S.z + S.z_meta + S.z_fin;
+    char* hists = st_hs + S.z_hs;
+    uint32_t* tickets = (uint32_t*)(hists + S.z_hist);                // look-back scan tickets: one per pass
+    HIP_TRY(hipMemsetAsync(S.z, 0, S.zero_bytes, ctx->stream));
+    const unsigned sgrid = (unsigned)(S.tiles < 512 ? S.tiles : 512);
+    LAUNCH(ctx, "ix_minmax", k_ix_minmax, sgrid, OS_THREADS, key, payload, contig, n, S.nc, S.meta);
+    auto hist_of = [&](int p) { return (uint32_t*)(hists + (size_t)p * align_up((size_t)S.hist_len * 4)); };
+    const size_t pass_lds = (size_t)os_pass_lds().total;
+    if (!ctx->os_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_os_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_os_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
+        ctx->os_attr_set = true;
+    }
+    for (int p = 0; p < S.passes_max; ++p) {
+        // a pass whose digit lies beyond the key bits exits at once (device-side decision: the key width depends on the data);
+        // its scan then runs over a zero histogram
+        const int4* src = (p & 1) ? S.recA : S.recB;                 // pass p writes buffer p & 1 (A, B, A, ...), reads the other
+        int4* dst = (p & 1) ? S.recB : S.recA;
+        if (p == 0) LAUNCH(ctx, "ix_hist", (k_os_hist<true>), S.nchunks, OS_THREADS, contig, key, src, n, S.nc, S.cbits, p, (const OsMeta*)S.meta, (int)S.chunk, S.nchunks, hist_of(p));
+        else LAUNCH(ctx, "ix_hist", (k_os_hist<false>), S.nchunks, OS_THREADS, contig, key, src, n, S.nc, S.cbits, p, (const OsMeta*)S.meta, (int)S.chunk, S.nchunks, hist_of(p));
+        LAUNCH(ctx, "ix_scan", (k_scan_lb_u32<SumOp, true>), S.hs_tiles, OS_THREADS, hist_of(p), S.hist_len, 0u, tickets + p,
+               (unsigned long long*)(st_hs + (size_t)p * align_up((size_t)S.hs_tiles * 8)));
+        t_begin(ctx, "ix_pass");
+        if (p == 0)
+            hipLaunchKernelGGL((k_os_scatter<true>), dim3((unsigned)S.nchunks), dim3(OS_THREADS), pass_lds, ctx->stream, contig, key, payload,
+                               row_id, src, dst, n, S.nc, S.cbits, p, (const OsMeta*)S.meta, (int)S.chunk, S.nchunks, (const uint32_t*)hist_of(p));
+        else
+            hipLaunchKernelGGL((k_os_scatter<false>), dim3((unsigned)S.nchunks), dim3(OS_THREADS), pass_lds, ctx->stream, contig, key, payload,
+                               row_id, src, dst, n, S.nc, S.cbits, p, (const OsMeta*)S.meta, (int)S.chunk, S.nchunks, (const uint32_t*)hist_of(p));
+        t_end(ctx);
+    }
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
 int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->has_end_order) return IVJ_OK;
     const int64_t n = ix->n;
     if (n == 0) { ix->has_end_order = true; return IVJ_OK; }
-    IVJ_TRY(arena_reserve(ctx, sort_scratch_bytes(n) + align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4) +
+    // ends sorted by (contig, end, position): the same three 11-bit passes as the start order (keys relative to the smallest
+    // end; the record's row field carries the position), then ONE kernel unpacks e_end / e_pos / the contig per position.
+    // (Round 1: 4 + 1 eight-bit passes with 3-launch scans = 25 launches, 0.3 ms even for 200 k rows.)
+    OsSort S;
+    const int64_t lb_tiles = (ix->bins_len + LB_TILE - 1) / LB_TILE;
+    const size_t zb = align_up((size_t)lb_tiles * 8) + align_up(16);          // look-back scan status + ticket, per scan
+    IVJ_TRY(arena_reserve(ctx, os_sort_plan(S, n, ix->n_contigs) + align_up((size_t)n * 4) + 2 * zb +
                                2 * align_up((size_t)ix->bins_len * 4) + 4096));
-    SortBufs sb; take_sort_bufs(ctx, n, sb);
-    uint32_t* bins_part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
+    os_sort_take(ctx, S);
+    int32_t* ekey = arena_take<int32_t>(ctx, n);
+    char* zscan = arena_take<char>(ctx, 2 * zb);
     uint32_t* jb_s = arena_take<uint32_t>(ctx, ix->bins_len);
     uint32_t* jb_e = arena_take<uint32_t>(ctx, ix->bins_len);
-    LAUNCH(ctx, "end_keys", k_end_keys, grid1d(n, 256), 256, (const int2*)ix->ep, n, sb.kA, sb.vA);
-    bool fl = radix_sort_pairs(ctx, sb, n, 32);
-    if (fl) { std::swap(sb.kA, sb.kB); std::swap(sb.vA, sb.vB); }
-    // contig of each sorted position, then the contig passes
-    LAUNCH(ctx, "gather", k_gather_u32, grid1d(n, 256), 256, (const int32_t*)ix->b_contig, (const uint32_t*)sb.vA, n, sb.kA);
-    fl = radix_sort_pairs(ctx, sb, n, bits_for((uint32_t)ix->n_contigs));
-    const uint32_t* pos = fl ? sb.vB : sb.vA;
-    const uint32_t* ckeys = fl ? sb.kB : sb.kA;
-    LAUNCH(ctx, "end_finalize", k_end_finalize, grid1d(n, 256), 256, (const int2*)ix->ep, pos, n, ix->e_end, ix->e_pos);
-    // direct-address table over the sorted ends (same segments as the start order)
+    HIP_TRY(hipMemsetAsync(zscan, 0, 2 * zb, ctx->stream));
+    auto lb_max_scan = [&](uint32_t* data, int k) {
+        char* z = zscan + (size_t)k * zb;
+        LAUNCH(ctx, "bins_scan", (k_scan_lb_u32<MaxOp, false>), lb_tiles, OS_THREADS, data, ix->bins_len, 0u,
+               (uint32_t*)(z + align_up((size_t)lb_tiles * 8)), (unsigned long long*)z);
+    };
+    LAUNCH(ctx, "end_keys", k_end_column, grid1d(n, 256), 256, (const int2*)ix->ep, n, ekey);
+    IVJ_TRY(os_sort_run(ctx, S, (const int32_t*)ix->b_contig, ekey, ekey, nullptr));
+    LAUNCH(ctx, "end_finalize", k_end_unpack, grid1d(n, 256), 256, (const int4*)S.recA, (const int4*)S.recB, n, S.cbits, (const OsMeta*)S.meta,
+           ix->e_end, ix->e_pos);
+    // (both orders are sorted by contig first and share the segment offsets: the contig of end-sorted position p is b_contig[p])
+    const int32_t* ckeys = ix->b_contig;
     if (ix->n_contigs > 0) {
-        LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(ix->n_contigs, 256), 256, (const int32_t*)ix->seg,
-               (const int32_t*)ix->e_end, ix->n_contigs, ix->cmeta_e);
-        HIP_TRY(hipMemsetAsync(ix->bins_e, 0, (size_t)ix->bins_len * 4, ctx->stream));
-        LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->e_end, (const int32_t*)ckeys, n,
-               ix->n_contigs, (const int4*)ix->cmeta_e, ix->bins_e);
-        device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", ix->bins_e, ix->bins_e, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
-        LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins_e, ix->bins_len,
-               (const int32_t*)ix->e_end, (const int4*)ix->cmeta_e, ix->n_contigs, ix->brec_e);
         // joint grid for count_overlaps: the same bins for the start order and the end order
         // joint grid of 16-byte records: two bins per build row (200 k rows, 200 M probes: 1.96 ms against 2.07 ms with one
         // bin per row, although only the latter table fits an XCD's L2: fewer third-row searches matter more)
@@ -56,12 +132,37 @@ int build_end_order(ivj_ctx* ctx, ivj_index* ix) {
                ix->n_contigs, (const int4*)ix->cmeta_j, jb_s);
         LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->e_end, (const int32_t*)ckeys, n,
                ix->n_contigs, (const int4*)ix->cmeta_j, jb_e);
-        device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", jb_s, jb_s, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
-        device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", jb_e, jb_e, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
+        lb_max_scan(jb_s, 0);
+        lb_max_scan(jb_e, 1);
         LAUNCH(ctx, "joint_records", k_joint_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)jb_s, (const uint32_t*)jb_e,
                ix->bins_len, (const int32_t*)ix->b_start, (const int32_t*)ix->e_end, (const int4*)ix->cmeta_j, ix->n_contigs, ix->crec);
     }
     ix->has_end_order = true;
+    return IVJ_OK;
+}
+
+// direct-address table over the sorted ends (same segments as the start order): only the flat overlap kernel's rank formula
+// reads it, so it is built on that kernel's first use
+int build_end_table(ivj_ctx* ctx, ivj_index* ix) {
+    IVJ_TRY(build_end_order(ctx, ix));
+    if (ix->has_end_table || ix->n == 0 || ix->n_contigs <= 0) { ix->has_end_table = true; return IVJ_OK; }
+    const int64_t n = ix->n;
+    const int64_t lb_tiles = (ix->bins_len + LB_TILE - 1) / LB_TILE;
+    const size_t zb = align_up((size_t)lb_tiles * 8) + align_up(16);
+    IVJ_TRY(arena_reserve(ctx, zb + 4096));
+    char* z = arena_take<char>(ctx, zb);
+    HIP_TRY(hipMemsetAsync(z, 0, zb, ctx->stream));
+    LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(ix->n_contigs, 256), 256, (const int32_t*)ix->seg,
+           (const int32_t*)ix->e_end, ix->n_contigs, ix->cmeta_e);
+    HIP_TRY(hipMemsetAsync(ix->bins_e, 0, (size_t)ix->bins_len * 4, ctx->stream));
+    LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->e_end, (const int32_t*)ix->b_contig, n,
+           ix->n_contigs, (const int4*)ix->cmeta_e, ix->bins_e);
+    LAUNCH(ctx, "bins_scan", (k_scan_lb_u32<MaxOp, false>), lb_tiles, OS_THREADS, ix->bins_e, ix->bins_len, 0u,
+           (uint32_t*)(z + align_up((size_t)lb_tiles * 8)), (unsigned long long*)z);
+    LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins_e, ix->bins_len,
+           (const int32_t*)ix->e_end, (const int4*)ix->cmeta_e, ix->n_contigs, ix->brec_e);
+    HIP_TRY(hipGetLastError());
+    ix->has_end_table = true;
     return IVJ_OK;
 }
 
@@ -151,63 +252,13 @@ int index_sort_v1(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     return IVJ_OK;
 }
 
-// round-2 build (onesweep.hip.h): min / max -> per pass [look-back scan of the (digit, chunk) histogram, LDS-staged stable scatter
-// of 16-byte records that also feeds the next pass's histogram] -> index arrays (look-back prefix max) -> segment offsets and
-// table geometry -> head marks -> look-back max-scan -> bin records.
+// round-2 build: sort of {start, end, row, contig} -> index arrays (look-back prefix max), segment offsets
 int index_sort_v2(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_opts* opts) {
-    const int64_t n = build->n;
-    const int nc = opts->n_contigs;
-    const int cbits = os_bits_for((uint32_t)nc);                      // contig ids 0 .. nc (nc = rows outside the dictionary)
-    const int passes_max = (32 + cbits + OS_BITS - 1) / OS_BITS;
-    const int64_t tiles = (n + OS_TILE - 1) / OS_TILE;
-    // chunks of the passes: about 512 workgroups, whole sub-tiles
-    int64_t chunk = ((n + 511) / 512 + OS_TILE - 1) / OS_TILE * OS_TILE;
-    if (chunk < OS_TILE) chunk = OS_TILE;
-    const int nchunks = (int)((n + chunk - 1) / chunk);
-    const int64_t hist_len = (int64_t)OS_RADIX * nchunks;
-    const int64_t hs_tiles = (hist_len + LB_TILE - 1) / LB_TILE;
-    const size_t z_meta = align_up(sizeof(OsMeta)), z_fin = align_up((size_t)tiles * 8), z_lb = 0,
-                 z_hs = align_up((size_t)hs_tiles * 8) * (size_t)passes_max, z_hist = align_up((size_t)hist_len * 4) * (size_t)passes_max,
-                 z_tick = align_up((size_t)(passes_max + 2) * 4);
-    const size_t zero_bytes = z_meta + z_fin + z_lb + z_hs + z_hist + z_tick;
-    IVJ_TRY(arena_reserve(ctx, zero_bytes + 2 * align_up((size_t)n * 16) + 4096));
-    char* z = arena_take<char>(ctx, zero_bytes);
-    int4* recA = arena_take<int4>(ctx, n);
-    int4* recB = arena_take<int4>(ctx, n);
-    OsMeta* meta = (OsMeta*)z;
-    unsigned long long* st_fin = (unsigned long long*)(z + z_meta);
-    char* st_hs = z + z_meta + z_fin + z_lb;
-    char* hists = st_hs + z_hs;
-    uint32_t* tickets = (uint32_t*)(hists + z_hist);                 // look-back scan tickets: one per pass
-    HIP_TRY(hipMemsetAsync(z, 0, zero_bytes, ctx->stream));
-    const unsigned sgrid = (unsigned)(tiles < 512 ? tiles : 512);
-    LAUNCH(ctx, "ix_minmax", k_ix_minmax, sgrid, OS_THREADS, build->start, build->end, build->contig, n, nc, meta);
-    auto hist_of = [&](int p) { return (uint32_t*)(hists + (size_t)p * align_up((size_t)hist_len * 4)); };
-    const size_t pass_lds = (size_t)os_pass_lds().total;
-    if (!ctx->os_attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_os_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_os_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
-        ctx->os_attr_set = true;
-    }
-    for (int p = 0; p < passes_max; ++p) {
-        // a pass whose digit lies beyond the key bits exits at once (device-side decision: the key width depends on the data);
-        // its scan then runs over a zero histogram
-        const int4* src = (p & 1) ? recA : recB;                     // pass p writes buffer p & 1 (A, B, A, ...), reads the other
-        int4* dst = (p & 1) ? recB : recA;
-        if (p == 0) LAUNCH(ctx, "ix_hist", (k_os_hist<true>), nchunks, OS_THREADS, build->contig, build->start, src, n, nc, cbits, p, (const OsMeta*)meta, (int)chunk, nchunks, hist_of(p));
-        else LAUNCH(ctx, "ix_hist", (k_os_hist<false>), nchunks, OS_THREADS, build->contig, build->start, src, n, nc, cbits, p, (const OsMeta*)meta, (int)chunk, nchunks, hist_of(p));
-        LAUNCH(ctx, "ix_scan", (k_scan_lb_u32<SumOp, true>), hs_tiles, OS_THREADS, hist_of(p), hist_len, 0u, tickets + p,
-               (unsigned long long*)(st_hs + (size_t)p * align_up((size_t)hs_tiles * 8)));
-        t_begin(ctx, "ix_pass");
-        if (p == 0)
-            hipLaunchKernelGGL((k_os_scatter<true>), dim3((unsigned)nchunks), dim3(OS_THREADS), pass_lds, ctx->stream, build->contig, build->start, build->end,
-                               build->row_id, src, dst, n, nc, cbits, p, (const OsMeta*)meta, (int)chunk, nchunks, (const uint32_t*)hist_of(p));
-        else
-            hipLaunchKernelGGL((k_os_scatter<false>), dim3((unsigned)nchunks), dim3(OS_THREADS), pass_lds, ctx->stream, build->contig, build->start, build->end,
-                               build->row_id, src, dst, n, nc, cbits, p, (const OsMeta*)meta, (int)chunk, nchunks, (const uint32_t*)hist_of(p));
-        t_end(ctx);
-    }
-    LAUNCH(ctx, "ix_final", k_ix_final, tiles, OS_THREADS, (const int4*)recA, (const int4*)recB, n, nc, cbits, meta, st_fin, ix->b_start, ix->ep, ix->b_row,
+    OsSort S;
+    IVJ_TRY(arena_reserve(ctx, os_sort_plan(S, build->n, opts->n_contigs) + 4096));
+    os_sort_take(ctx, S);
+    IVJ_TRY(os_sort_run(ctx, S, build->contig, build->start, build->end, build->row_id));
+    LAUNCH(ctx, "ix_final", k_ix_final, S.tiles, OS_THREADS, (const int4*)S.recA, (const int4*)S.recB, S.n, S.nc, S.cbits, S.meta, S.st_fin, ix->b_start, ix->ep, ix->b_row,
            ix->b_contig, ix->seg, ix->flags);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;

@@ -415,4 +415,20 @@ __global__ __launch_bounds__(OS_THREADS) void k_scan_lb_u32(uint32_t* __restrict
     }
 }
 
+// ---- end order: the same sort over (contig, end) with the position as the record's row --------------------------------------
+__global__ void k_end_column(const int2* __restrict__ ep, int64_t n, int32_t* __restrict__ ends) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ends[i] = ep[i].x;
+}
+// sorted records {end, -, position in the start order, contig} -> e_end / e_pos
+__global__ void k_end_unpack(const int4* __restrict__ recA, const int4* __restrict__ recB, int64_t n, int cbits, const OsMeta* __restrict__ meta,
+                             int32_t* __restrict__ e_end, int32_t* __restrict__ e_pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const OsKey kg = os_key_geom(meta, cbits);
+    const int passes = (kg.total + OS_BITS - 1) / OS_BITS;
+    const int4 r = (((passes - 1) & 1) ? recB : recA)[i];                      // pass p writes buffer p & 1 (A, B, A, ...)
+    e_end[i] = r.x; e_pos[i] = r.z;
+}
+
 }  // namespace ivj
