@@ -74,6 +74,7 @@ struct ivj_ctx {
     bool os_attr_set = false;
     bool ix_v1 = false;                // IVJ_INDEX_V1=1: the round-1 index build (A/B runs)
     // slice path (host_slice.hip.h): bucket-ordered probe records, histogram, chunk table, tile totals
+    char* lb_buf = nullptr; size_t lb_cap = 0;        // status words + ticket of the single-launch look-back scans (lb_scan_u32)
     char* sl_buf = nullptr;
     size_t sl_cap = 0;
     int4* sl_rec = nullptr;
@@ -209,6 +210,29 @@ void t_end(ivj_ctx* ctx) {
     } while (0)
 
 inline unsigned grid1d(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+// Single-launch (decoupled look-back) scan of a u32 array in place: one memset of the status words + one kernel instead of the
+// three launches of device_scan.  The status buffer is owned by the context and reused by successive scans (stream order).
+template <class Op, bool EXCLUSIVE>
+int lb_scan_u32(ivj_ctx* ctx, const char* name, uint32_t* data, int64_t n, uint32_t identity) {
+    if (n <= 0) return IVJ_OK;
+    const int64_t tiles = (n + LB_TILE - 1) / LB_TILE;
+    const size_t need = align_up((size_t)tiles * 8) + align_up(16);
+    if (need > ctx->lb_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->lb_buf) HIP_TRY(hipFree(ctx->lb_buf));
+        ctx->lb_buf = nullptr; ctx->lb_cap = 0;
+        const size_t want = align_up(need + need / 2, 1 << 16);
+        hipError_t e = hipMalloc((void**)&ctx->lb_buf, want);
+        if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("look-back scan status hipMalloc: ") + hipGetErrorString(e));
+        ctx->lb_cap = want;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->lb_buf, 0, need, ctx->stream));
+    LAUNCH(ctx, name, (k_scan_lb_u32<Op, EXCLUSIVE>), tiles, OS_THREADS, data, n, identity,
+           (uint32_t*)(ctx->lb_buf + align_up((size_t)tiles * 8)), (unsigned long long*)ctx->lb_buf);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
 
 // device-wide scan: three launches (reduce, partials, apply)
 template <class T, class Op, bool INCLUSIVE>

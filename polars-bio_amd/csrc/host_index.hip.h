@@ -171,10 +171,8 @@ int build_argmax(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->has_argmax) return IVJ_OK;
     const int64_t n = ix->n;
     if (n == 0) { ix->has_argmax = true; return IVJ_OK; }
-    IVJ_TRY(arena_reserve(ctx, align_up((size_t)(scan_num_tiles(n) + 1) * 4) + 4096));
-    uint32_t* part = arena_take<uint32_t>(ctx, scan_num_tiles(n) + 1);
     LAUNCH(ctx, "pmax_change", k_pmax_change, grid1d(n, 256), 256, (const int2*)ix->ep, (const int32_t*)ix->b_contig, n, (uint32_t*)ix->pargmax);
-    device_scan<uint32_t, MaxOp, true>(ctx, "argmax_scan", (uint32_t*)ix->pargmax, (uint32_t*)ix->pargmax, n, 0u, part, (uint32_t*)nullptr);
+    IVJ_TRY((lb_scan_u32<MaxOp, false>(ctx, "argmax_scan", (uint32_t*)ix->pargmax, n, 0u)));
     LAUNCH(ctx, "nearest_records", k_nearest_records, grid1d(n + 1, 256), 256, (const int32_t*)ix->b_start, (const int2*)ix->ep,
            (const int32_t*)ix->b_row, (const int32_t*)ix->b_contig, (const int32_t*)ix->pargmax, n, ix->nrec);
     ix->has_argmax = true;
@@ -195,12 +193,10 @@ int build_rec4(ivj_ctx* ctx, ivj_index* ix) {
 int build_flat(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->has_flat || ix->n == 0 || ix->n_contigs <= 0) return IVJ_OK;
     IVJ_TRY(need_tables(ctx, ix));
-    IVJ_TRY(arena_reserve(ctx, align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4) + 4096));
-    uint32_t* part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
     HIP_TRY(hipMemsetAsync(ix->lot, 0, (size_t)ix->bins_len * 4, ctx->stream));
     LAUNCH(ctx, "lot_mark", k_lot_mark, grid1d(ix->n, 256), 256, (const int2*)ix->ep, (const int32_t*)ix->b_contig, ix->n,
            ix->n_contigs, (const int4*)ix->cmeta, ix->lot);
-    device_scan<uint32_t, MaxOp, true>(ctx, "lot_scan", ix->lot, ix->lot, ix->bins_len, 0u, part, (uint32_t*)nullptr);
+    IVJ_TRY((lb_scan_u32<MaxOp, false>(ctx, "lot_scan", ix->lot, ix->bins_len, 0u)));
     LAUNCH(ctx, "tab2", k_tab2, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, (const uint32_t*)ix->lot, ix->bins_len, ix->tab2);
     HIP_TRY(hipGetLastError());
     IVJ_TRY(build_rec4(ctx, ix));

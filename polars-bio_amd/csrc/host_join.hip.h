@@ -49,10 +49,8 @@ int partition_pass(ivj_ctx* ctx, ivj_index* ix, bool strict, const int32_t* sc, 
     const int ntiles = (int)((n + PART_TILE - 1) / PART_TILE);
     const int grid = 8 * ((ntiles + 7) / 8);
     const size_t hist = (size_t)PART_BUCKETS * (size_t)ntiles;
-    IVJ_TRY(arena_reserve(ctx, align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4) + 4096));
     uint32_t* blk = ctx->pt_off;                               // outlives the arena: the inverse permutation reads it
     ctx->pt_ntiles = ntiles;
-    uint32_t* partials = arena_take<uint32_t>(ctx, scan_num_tiles((int64_t)hist) + 1);
     if (!ctx->part_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES));
@@ -62,7 +60,7 @@ int partition_pass(ivj_ctx* ctx, ivj_index* ix, bool strict, const int32_t* sc, 
     const bool hvec = aligned16(sc) && aligned16(se);
     if (strict) LAUNCH(ctx, "part_hist", (k_part_hist<true>), grid, PART_THREADS, v, sc, se, n, bshift, blk, ntiles, hvec);
     else LAUNCH(ctx, "part_hist", (k_part_hist<false>), grid, PART_THREADS, v, sc, se, n, bshift, blk, ntiles, hvec);
-    device_scan<uint32_t, SumOp, false>(ctx, "part_scan", blk, blk, (int64_t)hist, 0u, partials, (uint32_t*)nullptr);
+    IVJ_TRY((lb_scan_u32<SumOp, true>(ctx, "part_scan", blk, (int64_t)hist, 0u)));
     // bucket b starts at blk[b * ntiles] (bucket-major scan); kept for the inverse permutation (k_unpermute)
     HIP_TRY(hipMemcpy2DAsync(ctx->pt_bstart, 4, blk, (size_t)ntiles * 4, 4, PART_BUCKETS, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->pt_bstart + PART_BUCKETS), (int)n, 1, ctx->stream));

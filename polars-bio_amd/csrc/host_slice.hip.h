@@ -102,10 +102,13 @@ int ensure_sl(ivj_ctx* ctx, int64_t n, const SlicePlan& P) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->sl_buf) HIP_TRY(hipFree(ctx->sl_buf));
         ctx->sl_buf = nullptr; ctx->sl_cap = 0;
+        // (the scatter's speed depends on where this buffer lands physically: 0.93 .. 1.19 ms on config 3 for the same virtual
+        // addresses, tools/scatter_layout_probe*.py; one power-of-two block is not better: 1.07 .. 1.14 ms)
         const size_t want = align_up(need + need / 8, 1 << 20);
         hipError_t e = hipMalloc((void**)&ctx->sl_buf, want);
         if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("slice scratch hipMalloc: ") + hipGetErrorString(e));
         ctx->sl_cap = want;
+        if (std::getenv("IVJ_DEBUG_ALLOC")) std::fprintf(stderr, "[ivj] slice scratch %zu bytes at %p\n", want, (void*)ctx->sl_buf);
     }
     char* p = ctx->sl_buf;
     ctx->sl_rec = (int4*)p; p += align_up((size_t)n * 16);
@@ -143,7 +146,7 @@ int slice_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const iv
                            ix->n_contigs, probe->contig, probe->end, n, P.chunk, P.nchunks, vec, ctx->sl_blk);
     }
     t_end(ctx);
-    device_scan<uint32_t, SumOp, false>(ctx, "slice_scan", ctx->sl_blk, ctx->sl_blk, (int64_t)hist, 0u, ctx->sl_part, (uint32_t*)nullptr);
+    IVJ_TRY((lb_scan_u32<SumOp, true>(ctx, "slice_scan", ctx->sl_blk, (int64_t)hist, 0u)));
     LAUNCH(ctx, "slice_chunks", k_slice_chunks, 1, SL_THREADS, (const uint32_t*)ctx->sl_blk, P.nchunks, P.g.nb, n, P.jchunk, ctx->sl_bstart,
            ctx->sl_meta, ctx->sl_map);
     if (!ordered && !ctx->sl_env_stable) {                            // IVJ_SLICE_STABLE=1 forces the stable scatter (A/B runs)

@@ -87,6 +87,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->ov_buf) (void)hipFree(ctx->ov_buf);
     if (ctx->sl_buf) (void)hipFree(ctx->sl_buf);
+    if (ctx->lb_buf) (void)hipFree(ctx->lb_buf);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);
