@@ -36,7 +36,6 @@ __device__ __forceinline__ int joint_rank(const int32_t* __restrict__ keys, int 
 // LM: the per-contig grid metadata is copied to LDS once per workgroup (n_contigs <= CM_LDS).  Read from global memory the
 // two 16-byte metadata loads of a probe are L1 hits, but with a random contig per lane every lane is its own L1 access:
 // they were HALF of the kernel's 4.1 L1 accesses per probe (profiles/r01/v17_pmc_sq_tcp_count_200M_200k.json).
-constexpr int CM_LDS = 256;
 constexpr int COUNT_TILES_PER_WG = 4;
 
 template <bool STRICT, int N, bool LM>

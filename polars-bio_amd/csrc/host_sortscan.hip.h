@@ -37,11 +37,61 @@ int cluster_core(ivj_ctx* ctx, ivj_index* ix, bool strict, long long min_dist, s
     return IVJ_OK;
 }
 
+// pb.coverage through the union grid (sortscan.hip.h, k_coverage_grid): cluster sweep -> clipped lengths + prefix -> grid
+// metadata + one 16-byte record per bin -> ONE kernel over the probes in their own order (no bucketing, no inverse
+// permutation, no start table).  partition_mode 1 keeps the round-1 path (bucketed probes, table lookups) for A/B runs.
+int coverage_grid(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* cov) {
+    const int64_t n = probe->n;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    const int nc = ix->n_contigs;
+    Clusters cl;
+    const int64_t max_slots = 2 * (ix->n + 1) + 2 * (int64_t)nc + 16;
+    const size_t extra = 2 * align_up((size_t)(ix->n + 2) * 8) + align_up((size_t)(scan_num_tiles(ix->n + 1) + 1) * 8) +
+                         align_up((size_t)(nc + 1) * 32) + align_up((size_t)max_slots * 16);
+    IVJ_TRY(cluster_core(ctx, ix, strict, 0, extra, cl));
+    long long* len = arena_take<long long>(ctx, ix->n + 2);
+    long long* pl = arena_take<long long>(ctx, ix->n + 2);
+    long long* partials = arena_take<long long>(ctx, scan_num_tiles(ix->n + 1) + 1);
+    int4* cm = arena_take<int4>(ctx, 2 * (size_t)(nc + 1));
+    int4* rec = arena_take<int4>(ctx, (size_t)max_slots);
+    if (strict) LAUNCH(ctx, "merged_lengths", (k_merged_lengths<true>), grid1d(cl.n, 256), 256, (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, cl.n, len);
+    else LAUNCH(ctx, "merged_lengths", (k_merged_lengths<false>), grid1d(cl.n, 256), 256, (const int32_t*)cl.m_start, (const int32_t*)cl.m_end, cl.n, len);
+    HIP_TRY(hipMemsetAsync(len + cl.n, 0, 8, ctx->stream));      // one padding element: pl[n_clusters] = total
+    device_scan<long long, SumOp, false>(ctx, "merged_scan", len, pl, cl.n + 1, 0ll, partials, (long long*)nullptr);
+    const int64_t n_slots = 2 * cl.n + 2 * (int64_t)nc + 2;
+    if (strict) {
+        LAUNCH(ctx, "coverage_meta", (k_cov_meta<true>), grid1d(nc, 256), 256, (const int32_t*)ix->seg, (const uint32_t*)cl.cid1, (const int32_t*)cl.m_start,
+               (const int32_t*)cl.m_end, (const long long*)pl, nc, cm);
+        LAUNCH(ctx, "coverage_records", (k_cov_records<true>), grid1d(n_slots, 256), 256, (const int4*)cm, nc, n_slots, (const int32_t*)cl.m_start,
+               (const int32_t*)cl.m_end, (const long long*)pl, rec);
+    } else {
+        LAUNCH(ctx, "coverage_meta", (k_cov_meta<false>), grid1d(nc, 256), 256, (const int32_t*)ix->seg, (const uint32_t*)cl.cid1, (const int32_t*)cl.m_start,
+               (const int32_t*)cl.m_end, (const long long*)pl, nc, cm);
+        LAUNCH(ctx, "coverage_records", (k_cov_records<false>), grid1d(n_slots, 256), 256, (const int4*)cm, nc, n_slots, (const int32_t*)cl.m_start,
+               (const int32_t*)cl.m_end, (const long long*)pl, rec);
+    }
+    const CovMeta g{cm, rec};
+    const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end;
+    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+    const int64_t per = (int64_t)PROBE_THREADS * COV2_ITEMS * COV2_TILES_PER_WG;
+    const unsigned grid = (unsigned)((n + per - 1) / per);
+    const bool lm = nc <= CM_LDS;
+#define IVJ_COV_LAUNCH(S, L) LAUNCH(ctx, "coverage", (k_coverage_grid<S, L>), grid, PROBE_THREADS, g, nc, (const int32_t*)cl.m_start, \
+                                    (const int32_t*)cl.m_end, (const long long*)pl, qc, qs, qe, n, vec, (long long*)cov)
+    if (strict) { if (lm) IVJ_COV_LAUNCH(true, true); else IVJ_COV_LAUNCH(true, false); }
+    else { if (lm) IVJ_COV_LAUNCH(false, true); else IVJ_COV_LAUNCH(false, false); }
+#undef IVJ_COV_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
 int coverage_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* cov) {
-    IVJ_TRY(need_tables(ctx, ix));
+    if (!ix->has_tables) IVJ_TRY(need_tables(ctx, ix));          // refuses a sweep-only index
     const int64_t n = probe->n;
     if (n == 0) return IVJ_OK;
     if (ix->n == 0) { HIP_TRY(hipMemsetAsync(cov, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
+    if (opts->partition_mode != 1 && ix->n_contigs > 0) return coverage_grid(ctx, ix, probe, opts, cov);
+    IVJ_TRY(need_tables(ctx, ix));
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
     const bool bucketed = want_partition(ix, n, opts) && !probe->row_id;
     if (bucketed) {                                          // before cluster_core: the partition uses the arena too

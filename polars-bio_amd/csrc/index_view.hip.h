@@ -34,6 +34,7 @@ constexpr int PROBE_THREADS = 256;
 constexpr int PROBE_ITEMS = 4;   // probes per thread of the overlap count / fill / fused kernels
 constexpr int PROBE_ITEMS_LAT = 2;   // nearest and the dense fill: shorter per-thread chains, full occupancy
 constexpr int PROBE_TILE = PROBE_THREADS * PROBE_ITEMS;
+constexpr int CM_LDS = 256;      // per-contig grid metadata is copied to LDS by the per-probe kernels up to this many contigs
 
 struct IndexView {
     const int32_t* b_start;

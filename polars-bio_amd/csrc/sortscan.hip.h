@@ -138,6 +138,202 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_coverage(IndexView ix, const 
     }
 }
 
+// ---- coverage from a grid over the UNION intervals (round 2) ------------------------------------------------------------
+// k_coverage above needs ~10 dependent gathers per probe (two table lookups, cluster ids, cluster bounds, prefix sums) and
+// therefore bucketed probes + an inverse permutation.  The per-probe kernels are priced per L2 request (~6.5 ps per gather
+// level and probe), so the coverage is restated as ONE function C(x) = covered positions below x, answered
+// by ONE 16-byte record per endpoint:  coverage([s, e')) = C(e') - C(s).
+//   The clusters of a contig (min_dist 0) are disjoint and sorted: S_k = start, E_k = max(start, end') (a cluster that holds no
+//   position covers nothing), E_k <= S_(k+1).  Coordinates are handled as ux = x + 2^31 (0 .. 2^32).  Per contig a uniform grid
+//   over [S_first, E_last] with <= 2 bins per cluster; the record of the bin at x0:
+//     {C(x0) mod 2^32, t1 | t2 << 16, t3 | flags << 16, k0}     k0 = first cluster with E > x0
+//   t1..t3 = the first three positions inside the bin where "covered" toggles, as 16-bit offsets from x0 (0xffff: none);
+//   flags: 1 = x0 is covered, 2 = the bin has a fourth toggle, 4 = bins wider than 2^16 (no offsets: always search).
+//   C(x) for x in the bin = C(x0) + the covered part of [x0, x) from the toggles; only a bin with more than three toggles
+//   below x (or a wide grid) searches the cluster arrays from k0.
+struct CovMeta { const int4* cm; const int4* rec; };        // cm[2c] = {ulo, uhi, shift, tb}, cm[2c+1] = {C(lo), C(hi), ca, cb}
+
+__device__ __forceinline__ unsigned long long cov_ux(long long x) { return (unsigned long long)(x + 2147483648ll); }
+
+template <bool STRICT>
+__device__ __forceinline__ unsigned long long cov_E(const int32_t* __restrict__ m_start, const int32_t* __restrict__ m_end, int k) {
+    const long long s = m_start[k], e = (long long)m_end[k] + (STRICT ? 0 : 1);
+    return cov_ux(e > s ? e : s);
+}
+
+// exact C(x) by search over the clusters [k_lo, cb) of the contig (64-bit): fallback of the grid and the builder's definition
+template <bool STRICT>
+__device__ __forceinline__ unsigned long long cov_search(const int32_t* __restrict__ m_start, const int32_t* __restrict__ m_end,
+                                                         const long long* __restrict__ pl, int k_lo, int cb, unsigned long long x, int* k_out) {
+    int lo = k_lo, step = 1;                                                   // first k in [k_lo, cb) with E_k > x: gallop, then bound search
+    while (lo + step - 1 < cb && cov_E<STRICT>(m_start, m_end, lo + step - 1) <= x) { lo += step; step <<= 1; }
+    int hi = lo + step - 1 < cb ? lo + step - 1 : cb;
+    while (lo < hi) { const int m = lo + ((hi - lo) >> 1); if (cov_E<STRICT>(m_start, m_end, m) <= x) lo = m + 1; else hi = m; }
+    if (k_out) *k_out = lo;
+    if (lo >= cb) return (unsigned long long)pl[cb];
+    const unsigned long long S = cov_ux(m_start[lo]);
+    return (unsigned long long)pl[lo] + (x > S ? x - S : 0ull);
+}
+
+// one thread per contig: cluster range, grid geometry, C at both ends
+template <bool STRICT>
+__global__ void k_cov_meta(const int32_t* __restrict__ seg, const uint32_t* __restrict__ cid1, const int32_t* __restrict__ m_start,
+                           const int32_t* __restrict__ m_end, const long long* __restrict__ pl, int32_t n_contigs, int4* __restrict__ cm) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_contigs) return;
+    const int a = seg[c], b = seg[c + 1];
+    int ca = 0, cb = 0, shift = 0;
+    uint32_t ulo = 0, uhi = 0;
+    if (b > a) {
+        ca = (int)cid1[a] - 1; cb = (int)cid1[b - 1];
+        const unsigned long long lo = cov_ux(m_start[ca]), hi = cov_E<STRICT>(m_start, m_end, cb - 1);
+        ulo = (uint32_t)lo; uhi = hi > 0xffffffffull ? 0xffffffffu : (uint32_t)hi;
+        unsigned long long cap = 2ull * (unsigned long long)(cb - ca);
+        if (cap < 2) cap = 2;
+        while ((((unsigned long long)uhi - ulo) >> shift) + 1ull > cap) ++shift;
+    }
+    cm[2 * c] = make_int4((int)ulo, (int)uhi, shift, 2 * ca + 2 * c);
+    cm[2 * c + 1] = make_int4(b > a ? (int)(uint32_t)pl[ca] : 0, b > a ? (int)(uint32_t)pl[cb] : 0, ca, cb);
+}
+
+// one thread per grid slot
+template <bool STRICT>
+__global__ void k_cov_records(const int4* __restrict__ cm, int32_t n_contigs, int64_t n_slots, const int32_t* __restrict__ m_start,
+                              const int32_t* __restrict__ m_end, const long long* __restrict__ pl, int4* __restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    int lo = 0, hi = n_contigs;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cm[2 * m].w <= i) lo = m + 1; else hi = m; }
+    const int c = lo - 1;
+    int4 r = make_int4(0, -1, 0xffff | (4 << 16), 0);
+    if (c >= 0) {
+        const int4 m0 = cm[2 * c], m1 = cm[2 * c + 1];
+        const int ca = m1.z, cb = m1.w, shift = m0.z;
+        const unsigned long long x0 = (unsigned long long)(uint32_t)m0.x + ((unsigned long long)(i - (int64_t)m0.w) << shift);
+        if (cb > ca && x0 <= (unsigned long long)(uint32_t)m0.y) {
+            int k0;
+            const unsigned long long c0 = cov_search<STRICT>(m_start, m_end, pl, ca, cb, x0, &k0);
+            uint32_t flags = 0, t[3] = {0xffffu, 0xffffu, 0xffffu};
+            if (shift > 16) flags = 4;
+            else {
+                const unsigned long long W = 1ull << shift;
+                const bool inside = k0 < cb && cov_ux(m_start[k0]) <= x0;
+                if (inside) flags |= 1;
+                int nt = 0;
+                // toggles after x0: (the end of the covering cluster,) then start / end of the following clusters
+                for (int k = k0; k < cb && nt < 4; ++k) {
+                    const unsigned long long S = cov_ux(m_start[k]), E = cov_E<STRICT>(m_start, m_end, k);
+                    if (!(k == k0 && inside)) {
+                        if (S - x0 >= W) break;
+                        if (nt < 3) t[nt] = (uint32_t)(S - x0);
+                        ++nt;
+                    }
+                    if (E - x0 >= W) break;
+                    if (nt < 3) t[nt] = (uint32_t)(E - x0);
+                    ++nt;
+                }
+                if (nt > 3) flags |= 2;
+            }
+            r = make_int4((int)(uint32_t)c0, (int)(t[0] | (t[1] << 16)), (int)(t[2] | (flags << 16)), k0);
+        }
+    }
+    rec[i] = r;
+}
+
+constexpr int COV2_ITEMS = 2;
+constexpr int COV2_TILES_PER_WG = 4;
+
+template <bool STRICT, bool LM>
+__global__ __launch_bounds__(PROBE_THREADS) void k_coverage_grid(CovMeta g, int32_t n_contigs, const int32_t* __restrict__ m_start,
+                                                                 const int32_t* __restrict__ m_end, const long long* __restrict__ pl,
+                                                                 const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                                 const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
+                                                                 long long* __restrict__ cov) {
+    constexpr int N = COV2_ITEMS;
+    __shared__ int4 l_cm[LM ? 2 * CM_LDS : 1];
+    if (LM) {
+        for (int i = threadIdx.x; i < 2 * n_contigs; i += PROBE_THREADS) l_cm[i] = g.cm[i];
+        __syncthreads();
+    }
+#pragma unroll 1
+  for (int t = 0; t < COV2_TILES_PER_WG; ++t) {
+    const int64_t i0 = ((int64_t)blockIdx.x * COV2_TILES_PER_WG + t) * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
+    if (i0 - (int64_t)threadIdx.x * N >= n) break;
+    int32_t c[N], s[N], e[N];
+    load_items_nt(pc, i0, n, vec_ok, -1, c);
+    load_items_nt(ps, i0, n, vec_ok, 0, s);
+    load_items_nt(pe, i0, n, vec_ok, 0, e);
+    // both endpoints of every probe: state 0 = C(lo), 1 = C(hi), 2 = grid record
+    unsigned long long x[2 * N];
+    int st[2 * N];
+    uint32_t slot[2 * N], dd[2 * N];
+    int4 m1[N], rec[2 * N];
+    bool wide[N], live[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const bool ok = i0 + k < n && (uint32_t)c[k] < (uint32_t)n_contigs;
+        int4 m0 = make_int4(0, 0, 0, 0);
+        m1[k] = make_int4(0, 0, 0, 0);
+        if (ok) {
+            if (LM) { m0 = l_cm[2 * c[k]]; m1[k] = l_cm[2 * c[k] + 1]; }
+            else { m0 = g.cm[2 * c[k]]; m1[k] = g.cm[2 * c[k] + 1]; }
+        }
+        x[2 * k] = cov_ux(s[k]);
+        x[2 * k + 1] = cov_ux((long long)e[k] + (STRICT ? 0 : 1));
+        live[k] = ok && m1[k].w > m1[k].z && x[2 * k + 1] > x[2 * k];
+        wide[k] = m0.z > 16;
+        const uint32_t ulo = (uint32_t)m0.x, uhi = (uint32_t)m0.y;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned long long xx = x[2 * k + h];
+            st[2 * k + h] = (!live[k] || xx <= ulo) ? 0 : (xx > uhi ? 1 : 2);
+            const uint32_t off = (uint32_t)xx - ulo;
+            slot[2 * k + h] = (uint32_t)m0.w + (off >> m0.z);
+            dd[2 * k + h] = off & ((1u << m0.z) - 1u);                          // shift <= 31 (cap >= 2)
+        }
+        const bool same = st[2 * k] == 2 && st[2 * k + 1] == 2 && slot[2 * k] == slot[2 * k + 1];
+        rec[2 * k] = make_int4(0, 0, 0, 0); rec[2 * k + 1] = make_int4(0, 0, 0, 0);
+        if (st[2 * k + 1] == 2) rec[2 * k + 1] = g.rec[slot[2 * k + 1]];
+        if (st[2 * k] == 2 && !same) rec[2 * k] = g.rec[slot[2 * k]];
+        if (same) st[2 * k] = 3;                                                 // copy of the other endpoint's record
+    }
+    long long out[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (st[2 * k] == 3) { rec[2 * k] = rec[2 * k + 1]; st[2 * k] = 2; }
+        uint32_t cv[2];
+        bool slow = live[k] && (x[2 * k + 1] - x[2 * k]) > 0xffffffffull;       // the whole int32 range under Weak: 64-bit path
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = 2 * k + h;
+            if (st[q] == 0) cv[h] = (uint32_t)m1[k].x;
+            else if (st[q] == 1) cv[h] = (uint32_t)m1[k].y;
+            else {
+                const uint32_t w1 = (uint32_t)rec[q].y, w2 = (uint32_t)rec[q].z, fl = w2 >> 16, d = dd[q];
+                const uint32_t t1 = w1 & 0xffffu, t2 = w1 >> 16, t3 = w2 & 0xffffu;
+                const uint32_t a0 = t1 < d ? t1 : d, a1 = t2 < d ? t2 : d, a2 = t3 < d ? t3 : d;
+                const uint32_t part = (fl & 1u) ? a0 + (a2 - a1) : (a1 - a0) + (d - a2);
+                cv[h] = (uint32_t)rec[q].x + part;
+                if ((fl & 4u) || ((fl & 2u) && d > t3))
+                    cv[h] = (uint32_t)cov_search<STRICT>(m_start, m_end, pl, rec[q].w > m1[k].z ? rec[q].w : m1[k].z, m1[k].w, x[q], nullptr);
+            }
+        }
+        out[k] = live[k] ? (long long)(uint32_t)(cv[1] - cv[0]) : 0ll;
+        if (slow) out[k] = (long long)(cov_search<STRICT>(m_start, m_end, pl, m1[k].z, m1[k].w, x[2 * k + 1], nullptr) -
+                                       cov_search<STRICT>(m_start, m_end, pl, m1[k].z, m1[k].w, x[2 * k], nullptr));
+        (void)wide;
+    }
+    if (i0 + N <= n && (reinterpret_cast<uintptr_t>(cov) & 15u) == 0 && N == 2) {
+        typedef long long v2ll __attribute__((ext_vector_type(2)));
+        v2ll v; v.x = out[0]; v.y = out[1];
+        __builtin_nontemporal_store(v, reinterpret_cast<v2ll*>(cov + i0));
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) if (i0 + k < n) cov[i0 + k] = out[k];
+    }
+  }
+}
+
 // ---- subtract / complement -------------------------------------------------------------------------
 // Both are "an interval minus the union of the other side": subtract(df1, df2) per df1 row,
 // complement(df, view) = subtract(view, df).  The union is the cluster sweep with min_dist = 1 (bookended

@@ -568,6 +568,55 @@ def test_merge_cluster_coverage_parity(eng, strict):
     assert eng.coverage(one, one, strict, 1).tolist() == ([4, 23] if strict else [5, 24])
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_coverage_union_grid_edge_shapes(eng, strict):
+    """pb.coverage through the union grid (one 16-byte record per endpoint) on the shapes its fast path does not answer
+    or that stress its arithmetic: bins wider than 2^16 (search path), clumped clusters (more than three toggles per bin),
+    zero-length / inverted / negative rows, more contigs than the LDS metadata holds, coordinates at the int32 limits."""
+    rng = np.random.default_rng(5151)
+    I32 = np.iinfo(np.int32)
+
+    def check(probe, build, nc, brute=False):
+        exp = O.np_coverage_fast(O.Side(*probe), O.Side(*build), strict)
+        got = eng.coverage(probe, build, strict, nc)                 # union grid
+        assert (got == exp).all(), int((got != exp).sum())
+        assert (eng.coverage(probe, build, strict, nc, partition_mode=1) == exp).all()      # round-1 path, bucketed probes
+        if brute:
+            assert (exp == O.np_coverage_brute(O.Side(*probe), O.Side(*build), strict)).all()
+
+    # (a) 60 rows over the whole int32 range, two contigs: bins of ~2^25 positions
+    bs = rng.integers(I32.min, I32.max - 100_000, 60).astype(np.int64)
+    be = bs + rng.integers(0, 100_000, 60)
+    build = (rng.integers(0, 2, 60).astype(np.int32), bs.astype(np.int32), be.astype(np.int32))
+    ps = rng.integers(I32.min, I32.max - 300_000, 4000).astype(np.int64)
+    pe = ps + rng.integers(0, 300_000, 4000)
+    ps[:60] = bs; pe[:60] = be
+    ps[60], pe[60] = I32.min, I32.max                                # the whole range: 64-bit path under Weak
+    probe = (rng.integers(0, 3, 4000).astype(np.int32), ps.astype(np.int32), pe.astype(np.int32))
+    check(probe, build, 2, brute=True)
+    # (b) 60000 tiny intervals, 95 % of them inside 0.5 % of the span: many toggles per bin there, empty bins elsewhere
+    n = 60000
+    bs = np.where(rng.random(n) < 0.95, rng.integers(500_000, 505_000, n), rng.integers(0, 1_000_000, n)).astype(np.int64)
+    be = bs + rng.integers(0, 3, n)
+    be[::17] = bs[::17] - rng.integers(0, 3, len(bs[::17]))           # zero-length and inverted rows
+    build = (np.zeros(n, np.int32), (bs - 400_000).astype(np.int32), (be - 400_000).astype(np.int32))
+    ps = rng.integers(-450_000, 650_000, 30000).astype(np.int64)
+    pe = ps + rng.choice([0, 1, 5, 700, 200_000], 30000)
+    pe[::13] = ps[::13] - 1                                           # probes holding no position
+    probe = (np.zeros(30000, np.int32), ps.astype(np.int32), pe.astype(np.int32))
+    check(probe, build, 1)
+    # (c) 300 contigs (per-contig metadata read from global memory), a few rows each, some contigs empty
+    nc = 300
+    build = random_side(rng, 4000, nc - 20, 50_000, 3000)
+    probe = random_side(rng, 9000, nc + 3, 50_000, 9000)
+    check(probe, build, nc, brute=True)
+    # (d) intervals ending at INT32_MAX, probes reaching it
+    build = (np.zeros(3, np.int32), np.array([I32.max - 50, I32.max - 10, I32.min], np.int32), np.array([I32.max - 20, I32.max, I32.min + 5], np.int32))
+    probe = (np.zeros(4, np.int32), np.array([I32.max - 60, I32.max - 5, I32.min, I32.max], np.int32),
+             np.array([I32.max, I32.max, I32.min + 9, I32.max], np.int32))
+    check(probe, build, 1, brute=True)
+
+
 def test_sort_scan_device_entry_points():
     """ivj_merge_dev / ivj_cluster_dev / ivj_coverage_dev on torch tensors against the host entry points."""
     import torch
