@@ -163,14 +163,68 @@ int union_core(ivj_ctx* ctx, ivj_index* ix, bool strict, size_t extra_bytes, Uni
     return IVJ_OK;
 }
 
+// subtract / complement through the union grid (sortscan.hip.h, k_subtract_grid): union -> grid metadata + one 16-byte
+// record per bin -> count pass, scan, fill pass over the left rows in their own order (no bucketing, no start table).
+int subtract_grid(ivj_ctx* ctx, ivj_index* ix, const ivj_side* left, const ivj_opts* opts, int64_t capacity, int32_t** o_row,
+                  int32_t** o_start, int32_t** o_end, DevBuf* own, int64_t* n_pieces) {
+    const int64_t n = left->n;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    const int nc = ix->n_contigs;
+    const int64_t max_slots = 2 * (ix->n + 1) + 2 * (int64_t)nc + 16;
+    const size_t extra = 2 * align_up((size_t)(n + 1) * 8) + align_up((size_t)(scan_num_tiles(n) + 2) * 8) + 256 +
+                         align_up((size_t)(nc + 1) * 32) + align_up((size_t)max_slots * 16);
+    UnionView u;
+    IVJ_TRY(union_core(ctx, ix, strict, extra, u));
+    long long* cnt = arena_take<long long>(ctx, n + 1);
+    long long* off = arena_take<long long>(ctx, n + 1);
+    long long* partials = arena_take<long long>(ctx, scan_num_tiles(n) + 2);
+    int4* cm = arena_take<int4>(ctx, 2 * (size_t)(nc + 1));
+    int4* rec = arena_take<int4>(ctx, (size_t)max_slots);
+    const int64_t n_slots = 2 * u.cl.n + 2 * (int64_t)nc + 2;
+    LAUNCH(ctx, "subtract_meta", k_sub_meta, grid1d(nc, 256), 256, (const int32_t*)ix->seg, (const uint32_t*)u.cl.cid1, (const uint32_t*)u.newidx,
+           (const long long*)u.u_start, (const long long*)u.u_end, nc, cm);
+    LAUNCH(ctx, "subtract_records", k_sub_records, grid1d(n_slots, 256), 256, (const int4*)cm, nc, n_slots, (const long long*)u.u_start,
+           (const long long*)u.u_end, rec);
+    const SubGrid g{cm, rec};
+    if (strict) LAUNCH(ctx, "subtract_count", (k_subtract_grid<true, 0>), grid1d(n, PROBE_THREADS), PROBE_THREADS, g, nc, (const long long*)u.u_start, (const long long*)u.u_end,
+                       left->contig, left->start, left->end, left->row_id, n, cnt, (const long long*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+    else LAUNCH(ctx, "subtract_count", (k_subtract_grid<false, 0>), grid1d(n, PROBE_THREADS), PROBE_THREADS, g, nc, (const long long*)u.u_start, (const long long*)u.u_end,
+                left->contig, left->start, left->end, left->row_id, n, cnt, (const long long*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+    long long* total_dev = partials + scan_num_tiles(n) + 1;
+    device_scan<long long, SumOp, false>(ctx, "subtract_scan", cnt, off, n, 0ll, partials, total_dev);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, total_dev, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int64_t total = ctx->h_total[0];
+    *n_pieces = total;
+    if (total == 0) return IVJ_OK;
+    if (capacity < 0) {
+        const size_t col = align_up((size_t)total * 4);
+        hipError_t e = hipMalloc(&own->p, 3 * col);
+        if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(pieces): ") + hipGetErrorString(e));
+        *o_row = (int32_t*)own->p; *o_start = (int32_t*)((char*)own->p + col); *o_end = (int32_t*)((char*)own->p + 2 * col);
+    } else if (total > capacity) {
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(total) + " pieces");
+    } else if (!*o_row || !*o_start || !*o_end) {
+        return fail(IVJ_EINVAL, "subtract output buffers are NULL");
+    }
+    if (strict) LAUNCH(ctx, "subtract_fill", (k_subtract_grid<true, 1>), grid1d(n, PROBE_THREADS), PROBE_THREADS, g, nc, (const long long*)u.u_start, (const long long*)u.u_end,
+                       left->contig, left->start, left->end, left->row_id, n, (long long*)nullptr, (const long long*)off, *o_row, *o_start, *o_end);
+    else LAUNCH(ctx, "subtract_fill", (k_subtract_grid<false, 1>), grid1d(n, PROBE_THREADS), PROBE_THREADS, g, nc, (const long long*)u.u_start, (const long long*)u.u_end,
+                left->contig, left->start, left->end, left->row_id, n, (long long*)nullptr, (const long long*)off, *o_row, *o_start, *o_end);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
 // left minus the union of the index.  capacity < 0: library-allocated device outputs (host path), otherwise the
 // caller's buffers; *n_pieces always receives the total.
 int subtract_core(ivj_ctx* ctx, ivj_index* ix, const ivj_side* left, const ivj_opts* opts, int64_t capacity, int32_t** o_row,
                   int32_t** o_start, int32_t** o_end, DevBuf* own, int64_t* n_pieces) {
-    IVJ_TRY(need_tables(ctx, ix));
+    if (!ix->has_tables) IVJ_TRY(need_tables(ctx, ix));          // refuses a sweep-only index
     const int64_t n = left->n;
     *n_pieces = 0;
     if (n == 0) return IVJ_OK;
+    if (opts->partition_mode != 1 && ix->n > 0 && ix->n_contigs > 0) return subtract_grid(ctx, ix, left, opts, capacity, o_row, o_start, o_end, own, n_pieces);
+    IVJ_TRY(need_tables(ctx, ix));
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
     const bool bucketed = want_partition(ix, n, opts) && ix->n > 0;
     if (bucketed) {                                          // before union_core: the partition uses the arena too

@@ -433,4 +433,165 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_subtract_fill(IndexView ix, c
     if (u_end[last - 1] < le) emit(u_end[last - 1], le);
 }
 
+// ---- subtract / complement on a grid over the union intervals (round 2) ---------------------------------------------------
+// subtract_span above makes ~10 dependent gathers per left row (two table lookups, cluster ids, kept-cluster indices, interval
+// bounds), twice (count pass, fill pass), on bucketed rows.  The same restatement as for coverage: ONE 16-byte record per
+// point gives  K(x) = first union interval (u_start / u_end: compacted, disjoint, sorted, non-empty) whose end' is > x,  and
+// IN(x) = "x is covered".  For a left row [ls, le') with y = le' - 1:
+//     first = K(ls),  last = K(y) + IN(y)      (intervals [first, last) touch the row)
+//     pieces = 1 if last <= first, else  !IN(ls) + (last - first - 1) + !IN(y)
+// Grid per contig over [S_first, E_last) with <= 2 bins per union interval; record of the bin at x0:
+//     {K(x0), t1 | t2 << 16, t3 | flags << 16, -}   t = offsets of the first three toggles inside the bin,
+//     flags 1: x0 covered, 2: a fourth toggle exists, 4: bins wider than 2^16 (search from K(x0)).
+struct SubGrid { const int4* cm; const int4* rec; };     // cm[2c] = {lo, span lo, span hi, shift}, cm[2c+1] = {tb, ua, ub, 0}
+
+__device__ __forceinline__ void sub_search(const long long* __restrict__ u_start, const long long* __restrict__ u_end, int k_lo, int ub,
+                                           long long x, int& K, bool& in) {
+    int lo = k_lo, step = 1;
+    while (lo + step - 1 < ub && u_end[lo + step - 1] <= x) { lo += step; step <<= 1; }
+    int hi = lo + step - 1 < ub ? lo + step - 1 : ub;
+    while (lo < hi) { const int m = lo + ((hi - lo) >> 1); if (u_end[m] <= x) lo = m + 1; else hi = m; }
+    K = lo;
+    in = lo < ub && u_start[lo] <= x;
+}
+
+__global__ void k_sub_meta(const int32_t* __restrict__ seg, const uint32_t* __restrict__ cid1, const uint32_t* __restrict__ newidx,
+                           const long long* __restrict__ u_start, const long long* __restrict__ u_end, int32_t n_contigs, int4* __restrict__ cm) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_contigs) return;
+    const int a = seg[c], b = seg[c + 1];
+    int ua = 0, ub = 0, shift = 0;
+    long long lo = 0;
+    unsigned long long span = 0;
+    if (b > a) {
+        ua = (int)newidx[cid1[a] - 1u]; ub = (int)newidx[cid1[b - 1]];
+        if (ub > ua) {
+            lo = u_start[ua];
+            span = (unsigned long long)(u_end[ub - 1] - lo);
+            unsigned long long cap = 2ull * (unsigned long long)(ub - ua);
+            if (cap < 2) cap = 2;
+            while (((span - 1ull) >> shift) + 1ull > cap) ++shift;               // points lo .. lo + span - 1
+        }
+    }
+    cm[2 * c] = make_int4((int)lo, (int)(uint32_t)span, (int)(uint32_t)(span >> 32), shift);
+    cm[2 * c + 1] = make_int4(2 * ua + 2 * c, ua, ub, 0);
+}
+
+__global__ void k_sub_records(const int4* __restrict__ cm, int32_t n_contigs, int64_t n_slots, const long long* __restrict__ u_start,
+                              const long long* __restrict__ u_end, int4* __restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    int lo = 0, hi = n_contigs;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cm[2 * m + 1].x <= i) lo = m + 1; else hi = m; }
+    const int c = lo - 1;
+    int4 r = make_int4(0, -1, 0xffff | (4 << 16), 0);
+    if (c >= 0) {
+        const int4 m0 = cm[2 * c], m1 = cm[2 * c + 1];
+        const int ua = m1.y, ub = m1.z, shift = m0.w;
+        const unsigned long long span = (unsigned long long)(uint32_t)m0.y | ((unsigned long long)(uint32_t)m0.z << 32);
+        const unsigned long long off0 = (unsigned long long)(i - (int64_t)m1.x) << shift;
+        if (ub > ua && off0 < span) {
+            const long long x0 = (long long)m0.x + (long long)off0;
+            int k0; bool inside;
+            sub_search(u_start, u_end, ua, ub, x0, k0, inside);
+            uint32_t flags = inside ? 1u : 0u, t[3] = {0xffffu, 0xffffu, 0xffffu};
+            if (shift > 16) flags |= 4u;
+            else {
+                const long long W = 1ll << shift;
+                int nt = 0;
+                for (int k = k0; k < ub && nt < 4; ++k) {
+                    if (!(k == k0 && inside)) {
+                        if (u_start[k] - x0 >= W) break;
+                        if (nt < 3) t[nt] = (uint32_t)(u_start[k] - x0);
+                        ++nt;
+                    }
+                    if (u_end[k] - x0 >= W) break;
+                    if (nt < 3) t[nt] = (uint32_t)(u_end[k] - x0);
+                    ++nt;
+                }
+                if (nt > 3) flags |= 2u;
+            }
+            r = make_int4(k0, (int)(t[0] | (t[1] << 16)), (int)(t[2] | (flags << 16)), 0);
+        }
+    }
+    rec[i] = r;
+}
+
+// K and IN of one point from its record: walk the (at most three) toggles at or below the point
+__device__ __forceinline__ void sub_eval(const int4& r, uint32_t d, const long long* __restrict__ u_start, const long long* __restrict__ u_end,
+                                         int ua, int ub, long long x, int& K, bool& in) {
+    const uint32_t w1 = (uint32_t)r.y, w2 = (uint32_t)r.z, fl = w2 >> 16;
+    const uint32_t t1 = w1 & 0xffffu, t2 = w1 >> 16, t3 = w2 & 0xffffu;
+    if ((fl & 4u) || ((fl & 2u) && d >= t3)) { sub_search(u_start, u_end, r.x > ua ? r.x : ua, ub, x, K, in); return; }
+    // toggles alternate end / start beginning with "end" when x0 is covered; an "end" toggle at or below the point moves K on
+    const int n_le = (t1 <= d ? 1 : 0) + (t2 <= d ? 1 : 0) + (t3 <= d ? 1 : 0);   // 0xffff > d always
+    const bool in0 = (fl & 1u) != 0;
+    const int ends = in0 ? (n_le + 1) / 2 : n_le / 2;
+    K = r.x + ends;
+    in = in0 ^ ((n_le & 1) != 0);
+}
+
+// MODE 0: piece count per row; MODE 1: the pieces, at off[row]
+template <bool STRICT, int MODE>
+__global__ __launch_bounds__(PROBE_THREADS) void k_subtract_grid(SubGrid g, int32_t n_contigs, const long long* __restrict__ u_start,
+                                                                 const long long* __restrict__ u_end, const int32_t* __restrict__ lc,
+                                                                 const int32_t* __restrict__ lstart, const int32_t* __restrict__ lend,
+                                                                 const int32_t* __restrict__ row_id, int64_t n, long long* __restrict__ cnt,
+                                                                 const long long* __restrict__ off, int32_t* __restrict__ o_row,
+                                                                 int32_t* __restrict__ o_start, int32_t* __restrict__ o_end) {
+    const int64_t i = (int64_t)blockIdx.x * PROBE_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int32_t c = lc[i];
+    const long long ls = lstart[i], le = (long long)lend[i] + (STRICT ? 0 : 1);
+    long long pieces = 0;
+    int first = 0, last = 0;
+    bool in_s = false, in_y = false;
+    if (le > ls) {
+        pieces = 1;                                                              // nothing of the union on this contig: the row stays whole
+        if ((uint32_t)c < (uint32_t)n_contigs) {
+            const int4 m0 = g.cm[2 * c], m1 = g.cm[2 * c + 1];
+            const int ua = m1.y, ub = m1.z;
+            if (ub > ua) {
+                const long long lo = m0.x;
+                const unsigned long long span = (unsigned long long)(uint32_t)m0.y | ((unsigned long long)(uint32_t)m0.z << 32);
+                const long long pt[2] = {ls, le - 1};
+                int K[2]; bool IN[2];
+                int4 r[2];
+                uint32_t slot[2], d[2];
+                int st[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    st[h] = pt[h] < lo ? 0 : ((unsigned long long)(pt[h] - lo) >= span ? 1 : 2);
+                    const uint32_t o = (uint32_t)(pt[h] - lo);
+                    slot[h] = (uint32_t)m1.x + (o >> m0.w);
+                    d[h] = o & ((1u << m0.w) - 1u);
+                }
+                r[0] = make_int4(0, 0, 0, 0); r[1] = make_int4(0, 0, 0, 0);
+                if (st[1] == 2) r[1] = g.rec[slot[1]];
+                if (st[0] == 2) r[0] = (st[1] == 2 && slot[0] == slot[1]) ? r[1] : g.rec[slot[0]];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (st[h] == 0) { K[h] = ua; IN[h] = false; }
+                    else if (st[h] == 1) { K[h] = ub; IN[h] = false; }
+                    else sub_eval(r[h], d[h], u_start, u_end, ua, ub, pt[h], K[h], IN[h]);
+                }
+                first = K[0]; in_s = IN[0]; in_y = IN[1];
+                last = K[1] + (in_y ? 1 : 0);
+                if (last > first) pieces = (in_s ? 0 : 1) + (long long)(last - first - 1) + (in_y ? 0 : 1);
+            }
+        }
+    }
+    if (MODE == 0) { cnt[i] = pieces; return; }
+    if (pieces == 0) return;
+    long long o = off[i];
+    const int32_t rr = row_id ? row_id[i] : (int32_t)i;
+    auto emit = [&](long long s, long long e) {
+        o_row[o] = rr; o_start[o] = (int32_t)s; o_end[o] = (int32_t)(e - (STRICT ? 0 : 1)); ++o;
+    };
+    if (last <= first) { emit(ls, le); return; }
+    if (!in_s) emit(ls, u_start[first]);
+    for (int j = first; j + 1 < last; ++j) emit(u_end[j], u_start[j + 1]);
+    if (!in_y) emit(u_end[last - 1], le);
+}
+
 }  // namespace ivj

@@ -669,13 +669,60 @@ def test_subtract_complement_parity(eng, strict):
             assert (gr == er).all() and (gs == es).all() and (ge == ee).all(), (n, m, pm)
         view = (np.arange(nc, dtype=np.int32), np.zeros(nc, np.int32), np.full(nc, span, np.int32))
         ec, es, ee = O.np_complement(O.Side(*right), O.Side(*view), strict)
-        gr, gs, ge = eng.complement(right, view, strict, nc + 1, partition_mode=1)
-        assert (view[0][gr] == ec).all() and (gs == es).all() and (ge == ee).all(), (n, m)
+        for pm in (0, 1):                                    # union grid / round-1 span lookup on bucketed rows
+            gr, gs, ge = eng.complement(right, view, strict, nc + 1, partition_mode=pm)
+            assert (view[0][gr] == ec).all() and (gs == es).all() and (ge == ee).all(), (n, m, pm)
     e0 = (np.empty(0, np.int32),) * 3
     one = (np.zeros(2, np.int32), np.array([5, 7], np.int32), np.array([9, 30], np.int32))
     r, s, e = eng.subtract(one, e0, strict, 1)               # nothing to subtract: rows come back whole
     assert r.tolist() == [0, 1] and s.tolist() == [5, 7] and e.tolist() == [9, 30]
     assert len(eng.subtract(e0, one, strict, 1)[0]) == 0 and len(eng.subtract(one, one, strict, 1)[0]) == 0
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_subtract_union_grid_edge_shapes(eng, strict):
+    """pb.subtract through the union grid on the shapes its record does not answer inline or that stress its arithmetic:
+    bins wider than 2^16, clumped intervals (more than three toggles per bin), rows starting / ending exactly on interval
+    bounds, more contigs than usual, coordinates at the int32 limits."""
+    rng = np.random.default_rng(6161)
+    I32 = np.iinfo(np.int32)
+
+    def check(left, right, nc):
+        er, es, ee = O.np_subtract(O.Side(*left), O.Side(*right), strict)
+        for pm in (0, 1):
+            gr, gs, ge = eng.subtract(left, right, strict, nc, partition_mode=pm)
+            assert len(gr) == len(er), (pm, len(gr), len(er))
+            assert (gr == er).all() and (gs == es).all() and (ge == ee).all(), pm
+
+    # (a) 50 right rows over the whole int32 range
+    rs = rng.integers(I32.min, I32.max - 200_000, 50).astype(np.int64)
+    re = rs + rng.integers(1, 200_000, 50)
+    right = (rng.integers(0, 2, 50).astype(np.int32), rs.astype(np.int32), re.astype(np.int32))
+    ls = rng.integers(I32.min, I32.max - 600_000, 3000).astype(np.int64)
+    le = ls + rng.integers(0, 600_000, 3000)
+    ls[:50] = rs; le[:50] = re                                        # rows equal to an interval
+    ls[50:100] = re[:50]; le[50:100] = re[:50] + 1000                 # rows starting where an interval ends
+    ls[100], le[100] = I32.min, I32.max
+    left = (rng.integers(0, 3, 3000).astype(np.int32), ls.astype(np.int32), le.astype(np.int32))
+    check(left, right, 2)
+    # (b) 40000 short intervals, 95 % of them inside 0.5 % of the span
+    m = 40000
+    rs = np.where(rng.random(m) < 0.95, rng.integers(100_000, 105_000, m), rng.integers(-400_000, 600_000, m)).astype(np.int64)
+    re = rs + rng.integers(0, 4, m)
+    right = (np.zeros(m, np.int32), rs.astype(np.int32), re.astype(np.int32))
+    ls = rng.integers(-450_000, 650_000, 20000).astype(np.int64)
+    le = ls + rng.choice([0, 1, 7, 900, 100_000], 20000)
+    left = (np.zeros(20000, np.int32), ls.astype(np.int32), le.astype(np.int32))
+    check(left, right, 1)
+    # (c) 300 contigs, some without right rows
+    right = random_side(rng, 5000, 280, 40_000, 2000)
+    left = random_side(rng, 7000, 303, 40_000, 8000)
+    check(left, right, 300)
+    # (d) the int32 limits
+    right = (np.zeros(3, np.int32), np.array([I32.max - 50, I32.max - 10, I32.min], np.int32), np.array([I32.max - 20, I32.max, I32.min + 5], np.int32))
+    left = (np.zeros(4, np.int32), np.array([I32.max - 60, I32.max - 5, I32.min, I32.max - 15], np.int32),
+            np.array([I32.max, I32.max, I32.min + 9, I32.max - 12], np.int32))
+    check(left, right, 1)
 
 
 def test_subtract_device_entry_point():
