@@ -226,6 +226,15 @@ int ivj_overlap_fused_rows_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* prob
 int ivj_take_dev(ivj_ctx* ctx, const void* src_dev, int32_t elem_bytes, const int32_t* idx_dev, int64_t n,
                  void* dst_dev, uint64_t* validity_dev);
 
+/* Host-buffer form of the same `take` for several columns that share ONE index column (the non-key columns of a joined
+ * frame: src/operation.rs:272-301 gathers every column of both sides for every pair).  idx (n int32, host) is uploaded
+ * once; every column c -- src[c]: src_rows[c] values of elem_bytes[c] = 4 or 8 bytes, host -- is uploaded, gathered in
+ * HBM and downloaded into the caller's dst[c] (n values); validity[c] (may be NULL; ceil(n / 64) words) receives the
+ * Arrow validity bitmap of the negative-index slots.  The caller's buffers are registered in place for the copies and
+ * dst is first-touched by a few threads (a D2H into untouched pages runs at 7 GB/s).  idx values must be < src_rows[c]. */
+int ivj_take(ivj_ctx* ctx, const int32_t* idx, int64_t n, int32_t n_cols, const void* const* src, const int64_t* src_rows,
+             const int32_t* elem_bytes, void* const* dst, uint64_t* const* validity);
+
 /* Host-buffer form of overlap + materialisation: index pairs AND the five key columns come back
  * (one H2D of the inputs, join and gathers in HBM, one D2H per column). */
 int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, ivj_rows* out);

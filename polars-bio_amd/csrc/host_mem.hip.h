@@ -38,6 +38,21 @@ void* host_result_alloc(size_t bytes) {
     return p;
 }
 
+// first touch of a caller-provided result range by a few threads (a DMA write into never-touched pages faults page by page)
+void host_prefault(void* p, size_t bytes) {
+    if (!p || bytes < ((size_t)8 << 20)) return;
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = hw >= 16 ? 16u : (hw ? hw : 1u);
+    std::vector<std::thread> th;
+    const size_t per = (bytes / nt + 4095) / 4096 * 4096;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
+        if (lo >= hi) break;
+        th.emplace_back([p, lo, hi] { volatile char* c = (volatile char*)p; for (size_t o = lo; o < hi; o += 4096) c[o] = c[o]; c[hi - 1] = c[hi - 1]; });
+    }
+    for (auto& x : th) x.join();
+}
+
 // registers a host range for the lifetime of the object (failure is not an error: the copy then goes the pageable way)
 struct HostPin {
     void* p = nullptr;

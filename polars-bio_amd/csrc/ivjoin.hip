@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -501,6 +502,49 @@ int ivj_take_dev(ivj_ctx* ctx, const void* src_dev, int32_t elem_bytes, const in
         LAUNCH(ctx, "take", (k_take<unsigned long long>), grid1d(n, MAT_THREADS), MAT_THREADS, (const unsigned long long*)src_dev, idx_dev, n,
                (unsigned long long*)dst_dev, (unsigned long long*)validity_dev);
     HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+int ivj_take(ivj_ctx* ctx, const int32_t* idx, int64_t n, int32_t n_cols, const void* const* src, const int64_t* src_rows,
+             const int32_t* elem_bytes, void* const* dst, uint64_t* const* validity) {
+    if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
+    if (n < 0 || n_cols < 0) return fail(IVJ_EINVAL, "take: negative size");
+    if (n == 0 || n_cols == 0) return IVJ_OK;
+    if (!idx || !src || !src_rows || !elem_bytes || !dst) return fail(IVJ_EINVAL, "take: NULL argument");
+    size_t max_src = 0, max_dst = 0;
+    bool any_valid = false;
+    for (int c = 0; c < n_cols; ++c) {
+        if (elem_bytes[c] != 4 && elem_bytes[c] != 8) return fail(IVJ_EINVAL, "take: elem_bytes must be 4 or 8");
+        if (src_rows[c] < 0 || !dst[c] || (src_rows[c] > 0 && !src[c])) return fail(IVJ_EINVAL, "take: bad column");
+        max_src = std::max(max_src, (size_t)src_rows[c] * (size_t)elem_bytes[c]);
+        max_dst = std::max(max_dst, (size_t)n * (size_t)elem_bytes[c]);
+        any_valid |= validity && validity[c];
+    }
+    DeviceGuard g(ctx->device);
+    const size_t words = (size_t)((n + 63) / 64);
+    DevBuf d_idx, d_src, d_dst, d_val;
+    hipError_t e = hipMalloc(&d_idx.p, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_src.p, max_src ? max_src : 16);
+    if (e == hipSuccess) e = hipMalloc(&d_dst.p, max_dst);
+    if (e == hipSuccess && any_valid) e = hipMalloc(&d_val.p, words * 8);
+    if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(take): ") + hipGetErrorString(e));
+    {
+        HostPin pin(idx, (size_t)n * 4);
+        HIP_TRY(hipMemcpyAsync(d_idx.p, idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    for (int c = 0; c < n_cols; ++c) {
+        const size_t sb = (size_t)src_rows[c] * (size_t)elem_bytes[c], db = (size_t)n * (size_t)elem_bytes[c];
+        uint64_t* val = validity ? validity[c] : nullptr;
+        host_prefault(dst[c], db);
+        HostPin ps(src[c], sb), pd(dst[c], db);
+        if (sb) HIP_TRY(hipMemcpyAsync(d_src.p, src[c], sb, hipMemcpyHostToDevice, ctx->stream));
+        int rc = ivj_take_dev(ctx, d_src.p, elem_bytes[c], (const int32_t*)d_idx.p, n, d_dst.p, val ? (uint64_t*)d_val.p : nullptr);
+        if (rc != IVJ_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(dst[c], d_dst.p, db, hipMemcpyDeviceToHost, ctx->stream));
+        if (val) HIP_TRY(hipMemcpyAsync(val, d_val.p, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));                          // before the ranges are unregistered / the buffers reused
+    }
     return IVJ_OK;
 }
 

@@ -149,6 +149,43 @@ def take_rows(t: pa.Table, idx: np.ndarray, nullable: bool = False) -> pa.Table:
     return t.take(arr)
 
 
+def _device_takeable(col: pa.ChunkedArray) -> bool:
+    t = col.type
+    if col.null_count:
+        return False
+    if not (pa.types.is_integer(t) or pa.types.is_floating(t) or pa.types.is_temporal(t)):
+        return False
+    return t.bit_width in (32, 64)
+
+
+def take_rows_device(engine, t: pa.Table, idx: np.ndarray, nullable: bool = False) -> pa.Table:
+    """take_rows with the fixed-width null-free columns (4- or 8-byte integers, floats, dates / timestamps) gathered in HBM
+    (Engine.take_columns = ivj_take; reference: the executor gathers every column of both sides, src/operation.rs:272-301);
+    strings, booleans, narrow integers and columns with nulls keep the host take."""
+    if t.num_rows == 0 or len(idx) == 0:
+        return take_rows(t, idx, nullable)
+    dev = [n for n in t.column_names if _device_takeable(t.column(n))]
+    if not dev:
+        return take_rows(t, idx, nullable)
+    host = [n for n in t.column_names if n not in dev]
+    srcs = []
+    for n in dev:
+        a = t.column(n).combine_chunks()
+        a = a.chunk(0) if isinstance(a, pa.ChunkedArray) else a
+        width = a.type.bit_width // 8
+        buf = a.buffers()[1]
+        srcs.append(np.frombuffer(buf, dtype=np.dtype(f"i{width}"), count=len(a), offset=a.offset * width))
+    taken = engine.take_columns(idx, srcs, nullable=nullable)
+    host_part = take_rows(t.select(host), idx, nullable) if host else None
+    arrays = {}
+    n_out = len(idx)
+    for name, (vals, validity) in zip(dev, taken):
+        typ = t.schema.field(name).type
+        vbuf = pa.py_buffer(validity) if validity is not None else None
+        arrays[name] = pa.Array.from_buffers(typ, n_out, [vbuf, pa.py_buffer(vals)])
+    return pa.table({n: (arrays[n] if n in arrays else host_part.column(n)) for n in t.column_names})
+
+
 def with_suffix(t: pa.Table, suffix: str) -> pa.Table:
     return t.rename_columns([f"{n}{suffix}" for n in t.column_names])
 

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "ivj_overlap", "ivj_pairs_free", "ivj_count_overlaps", "ivj_nearest",
     "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev", "ivj_overlap_fused_dev",
     "ivj_count_overlaps_dev", "ivj_nearest_dev",
-    "ivj_side_from_arrow", "ivj_materialize_dev", "ivj_overlap_fused_rows_dev", "ivj_take_dev", "ivj_overlap_rows", "ivj_rows_free", "ivj_rows_export_arrow",
+    "ivj_side_from_arrow", "ivj_materialize_dev", "ivj_overlap_fused_rows_dev", "ivj_take_dev", "ivj_take", "ivj_overlap_rows", "ivj_rows_free", "ivj_rows_export_arrow",
     "ivj_subtract", "ivj_complement", "ivj_pieces_free", "ivj_subtract_dev",
     "ivj_merge", "ivj_merged_free", "ivj_cluster", "ivj_coverage", "ivj_cluster_dev", "ivj_merge_dev", "ivj_coverage_dev",
     "ivj_stream_open", "ivj_stream_submit", "ivj_stream_flush", "ivj_stream_close",
@@ -139,6 +139,7 @@ def load_library() -> C.CDLL:
         L.ivj_materialize_dev.argtypes = [vp, P, P, C.POINTER(_Rows)]
         L.ivj_overlap_fused_rows_dev.argtypes = [vp, vp, P, O, C.POINTER(_Rows), C.POINTER(C.c_int64)]
         L.ivj_take_dev.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, vp, vp]
+        L.ivj_take.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp]
         L.ivj_overlap_rows.argtypes = [vp, P, P, O, C.POINTER(_Rows)]
         L.ivj_rows_free.argtypes = [C.POINTER(_Rows)]
         L.ivj_rows_free.restype = None
@@ -408,6 +409,29 @@ class Engine:
         # view of either array is gone
         owner = _PairsOwner(load_library(), out)
         return _owned_view(out.probe_idx, n, owner), _owned_view(out.build_idx, n, owner)
+
+    def take_columns(self, idx: np.ndarray, columns, nullable: bool = False):
+        """Arrow ``take`` of fixed-width host columns through HBM (ivj_take): ``columns`` = numpy arrays of 4- or 8-byte
+        items sharing the int32 index column ``idx``.  -> list of (values, validity) with validity = None, or (nullable) a
+        uint64 bitmap (Arrow layout) whose cleared bits mark the negative-index slots."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        n, k = int(idx.shape[0]), len(columns)
+        cols = [np.ascontiguousarray(c) for c in columns]
+        for c in cols:
+            if c.dtype.itemsize not in (4, 8) or c.ndim != 1:
+                raise ValueError("take_columns: 1-d columns of 4- or 8-byte items only")
+        outs = [np.empty(n, c.dtype) for c in cols]
+        vals = [np.empty((n + 63) // 64, np.uint64) if nullable else None for _ in cols]
+        if n == 0 or k == 0:
+            return list(zip(outs, vals))
+        VP = C.c_void_p * k
+        src = VP(*[c.ctypes.data for c in cols])
+        dst = VP(*[o.ctypes.data for o in outs])
+        val = VP(*[(v.ctypes.data if v is not None else None) for v in vals])
+        rows = (C.c_int64 * k)(*[int(c.shape[0]) for c in cols])
+        eb = (C.c_int32 * k)(*[int(c.dtype.itemsize) for c in cols])
+        _check(self.L, self.L.ivj_take(self.h, C.c_void_p(idx.ctypes.data), n, k, src, rows, eb, dst, val if nullable else None), "ivj_take")
+        return list(zip(outs, vals))
 
     def overlap_rows(self, probe, build, strict: bool, n_contigs: int, partition_mode: int = 0, as_arrow: bool = False):
         """overlap + row materialisation on the device (ivj_overlap_rows): the pair indices AND the key

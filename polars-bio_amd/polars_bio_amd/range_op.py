@@ -91,9 +91,13 @@ def _overlap_device_rows(t1, t2, cols1, cols2, suffixes, zero_based) -> pa.Table
     p_idx, b_idx = rows.column("probe_idx"), rows.column("build_idx")
     other1 = [n for n in t1.column_names if n not in c1]
     other2 = [n for n in t2.column_names if n not in c2]
-    # non-key columns: host take; key columns: placeholders that are replaced below
-    left = t1.select(other1).take(p_idx) if other1 else None
-    right = t2.select(other2).take(b_idx) if other2 else None
+    # non-key columns: fixed-width null-free ones are gathered in HBM as well (ivj_take), the rest by the host take;
+    # key columns: placeholders that are replaced below
+    eng = default_engine()
+    pi = p_idx.to_numpy(zero_copy_only=False) if other1 else None
+    bi = b_idx.to_numpy(zero_copy_only=False) if other2 else None
+    left = A.take_rows_device(eng, t1.select(other1), pi) if other1 else None
+    right = A.take_rows_device(eng, t2.select(other2), bi) if other2 else None
 
     def assemble(src, names_other, taken_other, cols, contig, start, end):
         arrays = {}

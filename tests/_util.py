@@ -60,6 +60,21 @@ class OracleEngine:
         b = O.Side(*build)
         return O.overlap_fast(O.Index(b, n_contigs), O.Side(*probe), strict)
 
+    def take_columns(self, idx, columns, nullable=False):
+        import numpy as np
+        idx = np.asarray(idx, np.int32)
+        out = []
+        for c in columns:
+            c = np.asarray(c)
+            v = np.where(idx >= 0, c[np.where(idx >= 0, idx, 0)], 0).astype(c.dtype) if len(c) else np.zeros(len(idx), c.dtype)
+            val = None
+            if nullable:
+                bits = np.zeros(((len(idx) + 63) // 64) * 64, np.uint8)
+                bits[:len(idx)] = idx >= 0
+                val = np.packbits(bits, bitorder="little").view(np.uint64)
+            out.append((v, val))
+        return out
+
     def overlap_rows(self, probe, build, strict, n_contigs, partition_mode=0, as_arrow=False):
         import numpy as np
         import pyarrow as pa

@@ -484,6 +484,27 @@ def test_materialize_and_take_dev():
     assert (v32.cpu().numpy() == np.where(hflat >= 0, build[2][np.maximum(hflat, 0)], 0)).all()
 
 
+def test_take_columns_through_hbm(eng):
+    """ivj_take: several fixed-width host columns gathered in HBM by one index column == numpy take; negative indices give
+    0 and a cleared validity bit; sizes around the 64-bit bitmap words and the registration / pre-fault thresholds."""
+    rng = np.random.default_rng(404)
+    for n_src, n in ((1000, 0), (1, 5), (5000, 64), (5000, 65), (300_000, 3_000_001)):
+        cols = [rng.integers(-2**62, 2**62, n_src, dtype=np.int64), rng.random(n_src).astype(np.float32),
+                rng.integers(0, 2**32, n_src, dtype=np.uint32), rng.random(n_src)]
+        idx = rng.integers(0, n_src, n).astype(np.int32)
+        got = eng.take_columns(idx, cols)
+        for c, (v, val) in zip(cols, got):
+            assert val is None and v.dtype == c.dtype and (v == c[idx]).all()
+        if n:
+            idx[rng.random(n) < 0.2] = -1
+            idx[0] = -1
+            for c, (v, val) in zip(cols, eng.take_columns(idx, cols, nullable=True)):
+                ok = idx >= 0
+                assert (v[ok] == c[idx[ok]]).all() and (v[~ok] == 0).all()
+                bits = np.unpackbits(val.view(np.uint8), bitorder="little")[:n].astype(bool)
+                assert (bits == ok).all()
+
+
 def test_fused_rows_join_and_materialise_in_one_pass():
     """ivj_overlap_fused_rows_dev == the pair list of the oracle with the key columns taken on the host;
     global row ids (contig shard), skipped columns, Weak, unpartitioned / slice path, too-small capacity."""
