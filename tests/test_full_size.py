@@ -179,10 +179,10 @@ def _device_count():
     return torch.cuda.device_count()
 
 
-def _torchrun(nproc, script_args, timeout=900):
+def _torchrun(nproc, script_args, timeout=900, extra_env=None):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
@@ -196,6 +196,15 @@ def test_two_rank_hip_rccl_equals_single_gpu(tmp_path):
     if _device_count() < 2:
         pytest.skip("needs 2 GPUs")
     out = _torchrun(2, [os.path.join(ROOT, "tests", "_dist_hip_worker.py"), str(tmp_path)])
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.load(open(tmp_path / "result.json"))
+    assert res["ok"] and res["world"] == 2 and res["pairs"] > 1000
+
+
+def test_two_rank_hip_engine_on_one_gpu_over_gloo(tmp_path):
+    """The same worker with both ranks on GPU 0 and the exchange over gloo (host tensors): two ranks of libivjoin_hip.so +
+    contig sharding + all-gatherv / gather_per_probe == the single-process oracle result, on a single-GPU box."""
+    out = _torchrun(2, [os.path.join(ROOT, "tests", "_dist_hip_worker.py"), str(tmp_path)], extra_env={"IVJ_DIST_BACKEND": "gloo"})
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.load(open(tmp_path / "result.json"))
     assert res["ok"] and res["world"] == 2 and res["pairs"] > 1000
