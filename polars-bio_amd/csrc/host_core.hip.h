@@ -74,6 +74,9 @@ struct ivj_ctx {
     bool os_attr_set = false;
     bool ix_v1 = false;                // IVJ_INDEX_V1=1: the round-1 index build (A/B runs)
     // slice path (host_slice.hip.h): bucket-ordered probe records, histogram, chunk table, tile totals
+    // staging of the last closed streaming session, kept for the next one (pinned allocations cost ~70 ms per GB)
+    struct StreamBufs { int32_t* h_in = nullptr; int32_t* d_in = nullptr; size_t in_cap = 0; char* d_out = nullptr; size_t d_out_cap = 0;
+                        char* h_out = nullptr; size_t h_out_cap = 0; } st_cache[3];
     char* lb_buf = nullptr; size_t lb_cap = 0;        // status words + ticket of the single-launch look-back scans (lb_scan_u32)
     char* sl_buf = nullptr;
     size_t sl_cap = 0;

@@ -53,6 +53,20 @@ void host_prefault(void* p, size_t bytes) {
     for (auto& x : th) x.join();
 }
 
+// copy into a pinned staging slot with a few threads (one thread moves ~31 GB/s, four ~95 GB/s: tools/pcie_probe.py)
+void host_copy_parallel(void* dst, const void* src, size_t bytes) {
+    if (bytes < ((size_t)8 << 20)) { std::memcpy(dst, src, bytes); return; }
+    constexpr unsigned nt = 4;
+    std::thread th[nt - 1];
+    const size_t per = (bytes / nt + 4095) / 4096 * 4096;
+    for (unsigned t = 1; t < nt; ++t) {
+        const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
+        th[t - 1] = std::thread([=] { if (lo < hi) std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, per < bytes ? per : bytes);
+    for (auto& x : th) x.join();
+}
+
 // registers a host range for the lifetime of the object (failure is not an error: the copy then goes the pageable way)
 struct HostPin {
     void* p = nullptr;

@@ -22,6 +22,7 @@ struct ivj_stream {
         int64_t id = -1, n = 0, n_out = 0, off2 = 0;        // off2: overlap, device offset (elements) of the build_idx column
         int32_t* h_in = nullptr;             // pinned: contig | start | end, max_rows each
         int32_t* d_in = nullptr;
+        size_t in_cap = 0;                   // bytes of h_in / d_in
         char* d_out = nullptr; size_t d_out_cap = 0;
         char* h_out = nullptr; size_t h_out_cap = 0;     // pinned
         hipEvent_t ev_h2d = nullptr, ev_join = nullptr, ev_d2h = nullptr;
@@ -124,9 +125,9 @@ int stream_turn(ivj_stream* st, const ivj_side* batch, ivj_stream_result* done) 
         const size_t col = align_up((size_t)st->max_rows * 4);
         const size_t nb = (size_t)batch->n * 4;
         if (batch->n > 0) {
-            std::memcpy((char*)S.h_in, batch->contig, nb);
-            std::memcpy((char*)S.h_in + col, batch->start, nb);
-            std::memcpy((char*)S.h_in + 2 * col, batch->end, nb);
+            host_copy_parallel((char*)S.h_in, batch->contig, nb);
+            host_copy_parallel((char*)S.h_in + col, batch->start, nb);
+            host_copy_parallel((char*)S.h_in + 2 * col, batch->end, nb);
             for (int c = 0; c < 3; ++c)
                 HIP_TRY(hipMemcpyAsync((char*)S.d_in + c * col, (char*)S.h_in + c * col, nb, hipMemcpyHostToDevice, st->s_h2d));
         }

@@ -80,6 +80,16 @@ int ivj_ctx_create(int device, ivj_ctx** out) {
     return IVJ_OK;
 }
 
+namespace {
+void free_stream_bufs(ivj_ctx::StreamBufs& b) {
+    if (b.h_in) (void)hipHostFree(b.h_in);
+    if (b.d_in) (void)hipFree(b.d_in);
+    if (b.d_out) (void)hipFree(b.d_out);
+    if (b.h_out) (void)hipHostFree(b.h_out);
+    b = ivj_ctx::StreamBufs();
+}
+}  // namespace
+
 void ivj_ctx_destroy(ivj_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
@@ -89,6 +99,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     if (ctx->ov_buf) (void)hipFree(ctx->ov_buf);
     if (ctx->sl_buf) (void)hipFree(ctx->sl_buf);
     if (ctx->lb_buf) (void)hipFree(ctx->lb_buf);
+    for (auto& cb : ctx->st_cache) free_stream_bufs(cb);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);
@@ -684,8 +695,16 @@ int ivj_stream_open(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, i
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->s_d2h, hipStreamNonBlocking);
     const size_t col = align_up((size_t)max_batch_rows * 4);
     for (int s = 0; s < 3 && e == hipSuccess; ++s) {
-        e = hipHostMalloc((void**)&st->slot[s].h_in, 3 * col, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void**)&st->slot[s].d_in, 3 * col);
+        ivj_ctx::StreamBufs& cb = ctx->st_cache[s];                            // the staging of the previous session, if it is large enough
+        if (cb.h_in && cb.d_in && cb.in_cap >= 3 * col) {
+            st->slot[s].h_in = cb.h_in; st->slot[s].d_in = cb.d_in; st->slot[s].in_cap = cb.in_cap;
+            st->slot[s].d_out = cb.d_out; st->slot[s].d_out_cap = cb.d_out_cap; st->slot[s].h_out = cb.h_out; st->slot[s].h_out_cap = cb.h_out_cap;
+            cb = ivj_ctx::StreamBufs();
+        } else {
+            e = hipHostMalloc((void**)&st->slot[s].h_in, 3 * col, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc((void**)&st->slot[s].d_in, 3 * col);
+            st->slot[s].in_cap = 3 * col;
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&st->slot[s].ev_h2d, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&st->slot[s].ev_join, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&st->slot[s].ev_d2h, hipEventDisableTiming);
@@ -716,10 +735,16 @@ void ivj_stream_close(ivj_stream* st) {
     (void)hipStreamSynchronize(st->ctx->stream);
     for (int s = 0; s < 3; ++s) {
         ivj_stream::Slot& S = st->slot[s];
-        if (S.h_in) (void)hipHostFree(S.h_in);
-        if (S.d_in) (void)hipFree(S.d_in);
-        if (S.d_out) (void)hipFree(S.d_out);
-        if (S.h_out) (void)hipHostFree(S.h_out);
+        ivj_ctx::StreamBufs& cb = st->ctx->st_cache[s];                        // keep the (larger) staging for the next session
+        if (S.h_in && S.d_in && S.in_cap >= cb.in_cap) {
+            free_stream_bufs(cb);
+            cb.h_in = S.h_in; cb.d_in = S.d_in; cb.in_cap = S.in_cap; cb.d_out = S.d_out; cb.d_out_cap = S.d_out_cap; cb.h_out = S.h_out; cb.h_out_cap = S.h_out_cap;
+        } else {
+            if (S.h_in) (void)hipHostFree(S.h_in);
+            if (S.d_in) (void)hipFree(S.d_in);
+            if (S.d_out) (void)hipFree(S.d_out);
+            if (S.h_out) (void)hipHostFree(S.h_out);
+        }
         if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
         if (S.ev_join) (void)hipEventDestroy(S.ev_join);
         if (S.ev_d2h) (void)hipEventDestroy(S.ev_d2h);
