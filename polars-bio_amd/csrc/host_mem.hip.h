@@ -10,10 +10,24 @@
 #pragma once
 
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <thread>
 
 namespace {
+
+// physical host memory that is free right now (bytes); 0 when it cannot be told
+size_t host_mem_available() {
+    const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+    return (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz : 0;
+}
+
+// A result that cannot fit the host is refused with an error instead of being first-touched into the OOM killer (an
+// all-against-all join of 400 k x 600 k rows is 1.7e10 pairs = 139 GB: that took two GPU boxes down in round 2).
+bool host_result_fits(size_t bytes) {
+    const size_t avail = host_mem_available();
+    return avail == 0 || bytes <= avail - avail / 8;
+}
 
 // host memory for a result column: huge-page friendly, pre-faulted in parallel.  Free with std::free.
 void* host_result_alloc(size_t bytes) {

@@ -269,6 +269,8 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     int64_t total = 0;
     IVJ_TRY(overlap_count(ctx, h.ix, &dp.s, opts, &total));
     if (total == 0) return IVJ_OK;
+    if (!host_result_fits((size_t)total * 8))
+        return fail(IVJ_ENOMEM, "the result (" + std::to_string(total) + " pairs, " + std::to_string((size_t)total * 8 >> 20) + " MiB) does not fit the free host memory; use the streaming entry points (ivj_stream_*) or the *_dev ones");
     DevBuf op, ob;
     hipError_t e = hipMalloc(&op.p, (size_t)total * 4);
     if (e == hipSuccess) e = hipMalloc(&ob.p, (size_t)total * 4);
@@ -582,6 +584,8 @@ int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
     int64_t total = 0;
     IVJ_TRY(overlap_count(ctx, h.ix, &dp.s, opts, &total));
     if (total == 0) return IVJ_OK;
+    if (!host_result_fits((size_t)total * 28))
+        return fail(IVJ_ENOMEM, "the result (" + std::to_string(total) + " rows x 7 columns) does not fit the free host memory");
     DevBuf cols;                                            // 7 columns in one allocation
     const size_t col = align_up((size_t)total * 4);
     hipError_t e = hipMalloc(&cols.p, 7 * col);
