@@ -72,7 +72,6 @@ struct ivj_ctx {
     uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
     bool part_attr_set = false;
     bool os_attr_set = false;
-    bool ix_v1 = false;                // IVJ_INDEX_V1=1: the round-1 index build (A/B runs)
     // slice path (host_slice.hip.h): bucket-ordered probe records, histogram, chunk table, tile totals
     // staging of the last closed streaming session, kept for the next one (pinned allocations cost ~70 ms per GB)
     struct StreamBufs { int32_t* h_in = nullptr; int32_t* d_in = nullptr; size_t in_cap = 0; char* d_out = nullptr; size_t d_out_cap = 0;
@@ -246,28 +245,6 @@ void device_scan(ivj_ctx* ctx, const char* name, const T* in, T* out, int64_t n,
     LAUNCH(ctx, name, (k_scan_apply<T, Op, INCLUSIVE>), tiles, SCAN_THREADS, in, out, n, identity, (const T*)partials);
 }
 
-struct SortBufs {
-    uint32_t *kA, *vA, *kB, *vB, *hist, *partials;
-};
-
-size_t sort_scratch_elems_hist(int64_t n) { return (size_t)RS_RADIX * (size_t)rs_num_blocks(n); }
-
-// LSD passes over `bits` low bits of the keys in (kA,vA); returns true when the result is in (kB,vB).
-bool radix_sort_pairs(ivj_ctx* ctx, const SortBufs& sb, int64_t n, int bits) {
-    const int nblocks = rs_num_blocks(n);
-    uint32_t *kin = sb.kA, *vin = sb.vA, *kout = sb.kB, *vout = sb.vB;
-    bool flipped = false;
-    for (int shift = 0; shift < bits; shift += 8) {
-        LAUNCH(ctx, "rs_hist", k_rs_hist, nblocks, RS_THREADS, (const uint32_t*)kin, n, shift, sb.hist, nblocks);
-        device_scan<uint32_t, SumOp, false>(ctx, "rs_scan", sb.hist, sb.hist, (int64_t)RS_RADIX * nblocks, 0u, sb.partials,
-                                             (uint32_t*)nullptr);
-        LAUNCH(ctx, "rs_scatter", k_rs_scatter, nblocks, RS_THREADS, (const uint32_t*)kin, (const uint32_t*)vin, kout, vout,
-               n, shift, (const uint32_t*)sb.hist, nblocks);
-        std::swap(kin, kout); std::swap(vin, vout);
-        flipped = !flipped;
-    }
-    return flipped;
-}
 
 int bits_for(uint32_t max_value) {
     int b = 0;
@@ -306,16 +283,5 @@ IndexView view_of(const ivj_index* ix) {
     return v;
 }
 
-size_t sort_scratch_bytes(int64_t n) {
-    const size_t hist = sort_scratch_elems_hist(n);
-    return 4 * align_up((size_t)n * 4) + align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4);
-}
-void take_sort_bufs(ivj_ctx* ctx, int64_t n, SortBufs& sb) {
-    const size_t hist = sort_scratch_elems_hist(n);
-    sb.kA = arena_take<uint32_t>(ctx, n); sb.vA = arena_take<uint32_t>(ctx, n);
-    sb.kB = arena_take<uint32_t>(ctx, n); sb.vB = arena_take<uint32_t>(ctx, n);
-    sb.hist = arena_take<uint32_t>(ctx, hist);
-    sb.partials = arena_take<uint32_t>(ctx, scan_num_tiles((int64_t)hist) + 1);
-}
 
 }  // namespace

@@ -204,50 +204,6 @@ int build_flat(ivj_ctx* ctx, ivj_index* ix) {
     return IVJ_OK;
 }
 
-// round-1 build (IVJ_INDEX_V1=1): 8-bit LSD passes over (key, row) pairs + gathers + 3-launch scans.  Kept for A/B runs.
-int index_sort_v1(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_opts* opts) {
-    const int64_t n = build->n;
-    {
-        const size_t comp_bytes = 2 * align_up((size_t)n * 8) + align_up((size_t)(scan_num_tiles(n) + 1) * 8) +
-                                  align_up((size_t)(scan_num_tiles(ix->bins_len) + 1) * 4);
-        IVJ_TRY(arena_reserve(ctx, sort_scratch_bytes(n) + comp_bytes + 4096));
-        SortBufs sb; take_sort_bufs(ctx, n, sb);
-        unsigned long long* comp = arena_take<unsigned long long>(ctx, n);
-        unsigned long long* comp_max = arena_take<unsigned long long>(ctx, n);
-        unsigned long long* comp_part = arena_take<unsigned long long>(ctx, scan_num_tiles(n) + 1);
-        uint32_t* bins_part = arena_take<uint32_t>(ctx, scan_num_tiles(ix->bins_len) + 1);
-        // 1. stable sort by start (row ids as payload), 2. stable sort by contig id
-        LAUNCH(ctx, "sort_keys", k_iota_flip, grid1d(n, 256), 256, build->start, n, sb.kA, sb.vA);
-        bool fl = radix_sort_pairs(ctx, sb, n, 32);
-        if (fl) { std::swap(sb.kA, sb.kB); std::swap(sb.vA, sb.vB); }
-        LAUNCH(ctx, "gather", k_gather_contig, grid1d(n, 256), 256, build->contig, (const uint32_t*)sb.vA, n, opts->n_contigs, sb.kA);
-        fl = radix_sort_pairs(ctx, sb, n, bits_for((uint32_t)opts->n_contigs));
-        const uint32_t* ckeys = fl ? sb.kB : sb.kA;
-        const uint32_t* rows = fl ? sb.vB : sb.vA;
-        // 3. sorted columns, segment offsets, (contig,end) composites; 4. prefix max; 5. interleave (end, pmax)
-        LAUNCH(ctx, "index_finalize", k_index_finalize, grid1d(n, 256), 256, build->start, build->end, rows, ckeys, build->row_id, n,
-               opts->n_contigs, ix->b_start, ix->b_row, ix->b_contig, comp, ix->seg, ix->flags);
-        device_scan<unsigned long long, MaxOp, true>(ctx, "pmax_scan", comp, comp_max, n, 0ull, comp_part,
-                                                      (unsigned long long*)nullptr);
-        LAUNCH(ctx, "emit_ep", k_emit_ep, grid1d(n, 256), 256, (const unsigned long long*)comp,
-               (const unsigned long long*)comp_max, n, ix->ep);
-        // 6. direct-address table over start
-        if (opts->n_contigs > 0 && ix->has_tables) {
-            LAUNCH(ctx, "contig_meta", k_contig_meta, grid1d(opts->n_contigs, 256), 256, (const int32_t*)ix->seg,
-                   (const int32_t*)ix->b_start, opts->n_contigs, ix->cmeta);
-            hipError_t me = hipMemsetAsync(ix->bins, 0, (size_t)ix->bins_len * 4, ctx->stream);
-            if (me != hipSuccess) return fail(IVJ_EHIP, std::string("hipMemsetAsync(bins): ") + hipGetErrorString(me));
-            LAUNCH(ctx, "bins_mark", k_bins_mark, grid1d(n, 256), 256, (const int32_t*)ix->b_start, (const int32_t*)ix->b_contig, n,
-                   opts->n_contigs, (const int4*)ix->cmeta, ix->bins);
-            device_scan<uint32_t, MaxOp, true>(ctx, "bins_scan", ix->bins, ix->bins, ix->bins_len, 0u, bins_part, (uint32_t*)nullptr);
-            LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
-                   (const int32_t*)ix->b_start, (const int4*)ix->cmeta, opts->n_contigs, ix->brec);
-        }
-        ix->tables_built = true;
-    }
-    return IVJ_OK;
-}
-
 // round-2 build: sort of {start, end, row, contig} -> index arrays (look-back prefix max), segment offsets
 int index_sort_v2(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_opts* opts) {
     OsSort S;
@@ -347,7 +303,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
     }
     if (n > 0) {
         ix->has_tables = !(with_end_order & 2);
-        int r = ctx->ix_v1 ? index_sort_v1(ctx, ix, build, opts) : index_sort_v2(ctx, ix, build, opts);
+        int r = index_sort_v2(ctx, ix, build, opts);
         if (r != IVJ_OK) return cleanup(r);
         // 7. the flat overlap path's arrays (lot / tab2 / rec4) are filled on first use: build_flat
         if (opts->partition_mode == 5) { r = build_flat(ctx, ix); if (r != IVJ_OK) return cleanup(r); }

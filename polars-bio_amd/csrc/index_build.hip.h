@@ -8,68 +8,6 @@ namespace ivj {
 
 // ------------------------------------------------------------------ index build
 
-__global__ void k_iota_flip(const int32_t* __restrict__ coord, int64_t n, uint32_t* __restrict__ keys,
-                            uint32_t* __restrict__ vals) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { keys[i] = flip(coord[i]); vals[i] = (uint32_t)i; }
-}
-
-// keys[i] = contig id of the row at sorted position i, clamped to n_contigs when outside the dictionary
-__global__ void k_gather_contig(const int32_t* __restrict__ contig, const uint32_t* __restrict__ rows, int64_t n,
-                                int32_t n_contigs, uint32_t* __restrict__ keys) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const int32_t c = contig[rows[i]];
-        keys[i] = ((uint32_t)c < (uint32_t)n_contigs) ? (uint32_t)c : (uint32_t)n_contigs;
-    }
-}
-
-// After the final pass: materialise the sorted columns, the (contig,end) composite for the
-// prefix-max scan, the segment offsets and the inverted-row flag.
-__global__ void k_index_finalize(const int32_t* __restrict__ start, const int32_t* __restrict__ end,
-                                 const uint32_t* __restrict__ rows, const uint32_t* __restrict__ ckeys,
-                                 const int32_t* __restrict__ row_id, int64_t n,
-                                 int32_t n_contigs, int32_t* __restrict__ b_start, int32_t* __restrict__ b_row,
-                                 int32_t* __restrict__ b_contig, unsigned long long* __restrict__ comp,
-                                 int32_t* __restrict__ seg, int32_t* __restrict__ flags) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t r = rows[i];
-    const uint32_t c = ckeys[i];
-    const int32_t s = start[r], e = end[r];
-    b_start[i] = s;
-    b_row[i] = row_id ? row_id[r] : (int32_t)r;
-    b_contig[i] = (int32_t)c;
-    comp[i] = ((unsigned long long)c << 32) | (unsigned long long)flip(e);
-    if (s > e && c < (uint32_t)n_contigs) flags[0] = 1;
-    // seg[k] = first position whose contig key is >= k, for k in (prev, c]
-    const int32_t prev = (i == 0) ? -1 : (int32_t)ckeys[i - 1];
-    for (int32_t k = prev + 1; k <= (int32_t)c; ++k) seg[k] = (int32_t)i;
-    if (i == n - 1)
-        for (int32_t k = (int32_t)c + 1; k <= n_contigs + 1; ++k) seg[k] = (int32_t)n;
-}
-
-__global__ void k_emit_ep(const unsigned long long* __restrict__ comp_raw, const unsigned long long* __restrict__ comp_max,
-                          int64_t n, int2* __restrict__ ep) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ep[i] = make_int2(unflip((uint32_t)comp_raw[i]), unflip((uint32_t)comp_max[i]));
-}
-
-__global__ void k_end_keys(const int2* __restrict__ ep, int64_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { keys[i] = flip(ep[i].x); vals[i] = (uint32_t)i; }
-}
-__global__ void k_gather_u32(const int32_t* __restrict__ src, const uint32_t* __restrict__ pos, int64_t n,
-                             uint32_t* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (uint32_t)src[pos[i]];
-}
-__global__ void k_end_finalize(const int2* __restrict__ ep, const uint32_t* __restrict__ pos, int64_t n,
-                               int32_t* __restrict__ e_end, int32_t* __restrict__ e_pos) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint32_t p = pos[i]; e_end[i] = ep[p].x; e_pos[i] = (int32_t)p; }
-}
-
 // change[p] = p where the prefix max changes (or the segment starts), else 0; an inclusive max-scan
 // turns it into pargmax[p] = position of the first row attaining the prefix max at p.
 __global__ void k_pmax_change(const int2* __restrict__ ep, const int32_t* __restrict__ b_contig, int64_t n,

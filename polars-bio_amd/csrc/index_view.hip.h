@@ -25,7 +25,6 @@
 //   matches = { p in [a,hi) : q.start (<) end[p] };  the prefix max bounds the backward scan:
 //   stop at the first p (going down) with !(q.start (<) pmax[p]).
 #pragma once
-#include "radix_sort.hip.h"
 #include "scan.hip.h"
 
 namespace ivj {

@@ -21,7 +21,6 @@
 #include "probe.hip.h"
 #include "slice.hip.h"
 #include "onesweep.hip.h"
-#include "radix_sort.hip.h"
 #include "scan.hip.h"
 
 using namespace ivj;
@@ -73,7 +72,6 @@ int ivj_ctx_create(int device, ivj_ctx** out) {
     if (const char* ev = std::getenv("IVJ_JOINT_BINS")) ctx->env_joint_bins = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_ABLATE")) ctx->env_count_ablate = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_NOLDS")) ctx->env_count_nolds = std::atoi(ev);
-    if (const char* ev = std::getenv("IVJ_INDEX_V1")) ctx->ix_v1 = std::atoi(ev) != 0;
     e = hipHostMalloc((void**)&ctx->h_total, 64, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(IVJ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
     *out = ctx;

@@ -1,7 +1,7 @@
 // scan.hip.h -- device-wide prefix scans for gfx950 (wave64), three launches:
 // tile reduce -> scan of tile partials (one workgroup) -> tile apply.
-// Used for: radix-sort digit offsets (u32 sum), output tile bases (i64 sum),
-// prefix-max of the build ends (u64 max over (contig,end) composites).
+// Used for: output tile bases (i64 sum), cluster ids and merged lengths of the sort-scan family; the sort and the
+// partition tables use the single-launch look-back scans of onesweep.hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -9,6 +9,23 @@
 namespace ivj {
 
 constexpr int kWave = 64;
+
+// ---- wavefront helpers shared by the partition / sort kernels ----
+// Lanes of this wavefront that are valid and hold the same 8-bit digit (match-any from eight 64-bit ballots).
+__device__ __forceinline__ uint64_t wave_match8(uint32_t digit, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (digit >> b) & 1u;
+        const uint64_t m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    return (1ull << (threadIdx.x & (kWave - 1))) - 1ull;
+}
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
