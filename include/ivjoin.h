@@ -18,13 +18,15 @@
  *   the renaming SELECT over the joined batches = row materialisation   src/operation.rs:272-301
  *   do_merge / do_cluster / do_complement / do_subtract / coverage       src/operation.rs:352-510, 86-96
  *       (MergeProvider, ClusterProvider, ComplementProvider, SubtractProvider, CountOverlapsProvider(coverage))
+ *   range_operation_lazy + the streaming scan (df1 as an Arrow C stream, lazy result batches, limit)
+ *       src/lib.rs:154-214, src/scan.rs:294-357, polars_bio/range_op_io.py:31-174           -> ivj_stream_*
  *
  * Contract: plain pointers and sizes only.  The join keys cross the ABI as
  * three int32 columns per side: `contig` (dictionary id of the chrom string,
  * one dictionary shared by both sides, assigned by the caller), `start`, `end`.
- * Every other column of the user's frames stays on the host and is gathered by
- * the returned row indices (what the reference's SELECT in
- * src/operation.rs:272-301 does with `left_*` / `right_*`).
+ * Every other column of the user's frames is gathered by the returned row indices
+ * (what the reference's SELECT in src/operation.rs:272-301 does with `left_*` /
+ * `right_*`): fixed-width columns through HBM (ivj_take, ivj_take_dev), the rest on the host.
  *
  * Side roles (Appendix A of SURVEY.md): probe = df1 (streamed side of the
  * reference), build = df2 (indexed side) for all three operations, i.e. after
