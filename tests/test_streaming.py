@@ -134,6 +134,48 @@ def test_nearest_streaming(engine, k, overlap):
     assert genes == [None if j < 0 else f"g{j}" for j in exp_g]
 
 
+# ---- the reference's own streaming tests (tests/test_streaming.py:132-226): the streamed result of the three operations on
+# the CSV fixtures is the same golden table as the eager one -- here with the probe side cut into 3-row batches so that
+# every batch boundary of the 11- / 16-row fixtures is crossed
+
+GOLD_COLS = ("contig", "pos_start", "pos_end")
+
+
+def _gold(path):
+    from _util import GOLDEN
+    df = pd.read_csv(f"{GOLDEN}/{path}")
+    df.attrs["coordinate_system_zero_based"] = False
+    return df
+
+
+def _read_all(reader):
+    assert isinstance(reader, pa.RecordBatchReader)
+    df = reader.read_all().to_pandas()
+    return df.sort_values(by=list(df.columns)).reset_index(drop=True)
+
+
+def _expected(name):
+    from _util import GOLDEN
+    df = pd.read_csv(f"{GOLDEN}/{name}")
+    return df.sort_values(by=list(df.columns)).reset_index(drop=True)
+
+
+def test_streamed_golden_tables_equal_the_eager_ones(engine):
+    ov = pb.overlap_batches(_gold("overlap/reads.csv"), _gold("overlap/targets.csv"), cols1=GOLD_COLS, cols2=GOLD_COLS, batch_rows=3, as_reader=True)
+    got = _read_all(ov)
+    assert len(got) == 16
+    pd.testing.assert_frame_equal(got, _expected("expected_overlap.csv"), check_dtype=False)
+    nr = pb.nearest_batches(_gold("nearest/targets.csv"), _gold("nearest/reads.csv"), cols1=GOLD_COLS, cols2=GOLD_COLS, batch_rows=3, as_reader=True)
+    pd.testing.assert_frame_equal(_read_all(nr), _expected("expected_nearest.csv"), check_dtype=False)
+    for naive in (True, False):
+        co = pb.count_overlaps_batches(_gold("count_overlaps/targets.csv"), _gold("count_overlaps/reads.csv"), cols1=GOLD_COLS, cols2=GOLD_COLS,
+                                       batch_rows=3, naive_query=naive, as_reader=True)
+        pd.testing.assert_frame_equal(_read_all(co), _expected("expected_count_overlaps.csv"), check_dtype=False)
+    # the eager entry points with the lazy output type go the same way (default batch size: one batch here)
+    ov = pb.overlap(_gold("overlap/reads.csv"), _gold("overlap/targets.csv"), cols1=GOLD_COLS, cols2=GOLD_COLS, output_type="pyarrow.RecordBatchReader")
+    pd.testing.assert_frame_equal(_read_all(ov), _expected("expected_overlap.csv"), check_dtype=False)
+
+
 def test_parquet_path_streams_row_groups(engine, tmp_path):
     t1, t2, probe, build, nc = _frames(extra=False)
     path = str(tmp_path / "reads.parquet")
