@@ -73,6 +73,34 @@ def test_count_overlaps_golden(engine, naive):
     pd.testing.assert_frame_equal(_sorted(res), _sorted(exp))
 
 
+def test_overlap_is_algorithm_invariant_on_the_real_fixtures(engine, caplog):
+    """tests/test_overlap_algorithms.py:18-200 of the reference: exons x fBrain (0-based) gives the same 54,246-row frame
+    (docs/supplement.md:108,149) whatever ``algorithm`` is named, with the requested suffixes, and the log line names it."""
+    import pyarrow.parquet as pq
+    import glob
+    def frame(name):
+        t = pa.concat_tables([pq.read_table(f) for f in sorted(glob.glob(f"{GOLDEN}/{name}/*.parquet"))])
+        df = t.to_pandas()
+        df.attrs["coordinate_system_zero_based"] = True
+        return df
+    df1, df2 = frame("exons"), frame("fBrain-DS14718")
+    ref = None
+    for algo in ("Coitrees", "Lapper", "IntervalTree", "ArrayIntervalTree", "SuperIntervals"):
+        with caplog.at_level("INFO"):
+            res = pb.overlap(df1, df2, cols1=COLS, cols2=COLS, suffixes=("_1", "_3"), algorithm=algo, output_type="pandas.DataFrame")
+        assert f"Optimizing into IntervalJoinExec using {algo} algorithm" in caplog.text
+        assert len(res) == 54246
+        assert list(res.columns) == ["contig_1", "pos_start_1", "pos_end_1", "contig_3", "pos_start_3", "pos_end_3"]
+        cur = _sorted(res)
+        if ref is None:
+            ref = cur
+            # the predicate holds on every row and both sides sit on the same contig
+            assert (cur["contig_1"] == cur["contig_3"]).all()
+            assert (cur["pos_start_1"] < cur["pos_end_3"]).all() and (cur["pos_start_3"] < cur["pos_end_1"]).all()
+        else:
+            pd.testing.assert_frame_equal(cur, ref)
+
+
 def test_nearest_k2_no_overlap_no_distance(engine):
     # tests/test_native.py:78-180 (shape-level properties only: the values are unpinned)
     df1, df2 = _csv(f"{GOLDEN}/nearest/targets.csv"), _csv(f"{GOLDEN}/nearest/reads.csv")
