@@ -229,6 +229,41 @@ def test_validation_errors(engine):
         assert len(r) == 1 and any("Coordinate system metadata is missing" in str(x.message) for x in w)
 
 
+def test_missing_metadata_falls_back_to_the_session_option_with_a_warning(engine):
+    """tests/test_warnings.py:100-330 of the reference: with datafusion.bio.coordinate_system_check = false (the default) a
+    frame without metadata takes the coordinate system from datafusion.bio.coordinate_system_zero_based, and a warning that
+    names the option and the system says so -- for overlap, nearest, count_overlaps and merge alike; frames WITH metadata
+    produce no such warning."""
+    a = pd.DataFrame({"chrom": ["chr1", "chr1"], "start": [100, 300], "end": [200, 400]})
+    b = pd.DataFrame({"chrom": ["chr1"], "start": [200], "end": [300]})           # bookended: matches under 1-based only
+
+    def messages(fn):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            res = fn()
+        return res, [str(x.message) for x in w]
+
+    res, msgs = messages(lambda: pb.overlap(a, b, output_type="pandas.DataFrame"))
+    assert any("Coordinate system metadata is missing" in m for m in msgs)
+    assert any("POLARS_BIO_COORDINATE_SYSTEM_ZERO_BASED" in m for m in msgs) and any("1-based" in m for m in msgs)
+    assert len(res) == 2                                                        # closed intervals: both bookended rows match
+    pb.set_option("datafusion.bio.coordinate_system_zero_based", True)
+    try:
+        res, msgs = messages(lambda: pb.overlap(a, b, output_type="pandas.DataFrame"))
+        assert any("0-based" in m for m in msgs) and len(res) == 0              # half-open: bookended rows do not match
+        for fn, n in ((lambda: pb.nearest(a, b, output_type="pandas.DataFrame"), 2),
+                      (lambda: pb.count_overlaps(a, b, output_type="pandas.DataFrame"), 2),
+                      (lambda: pb.merge(a, output_type="pandas.DataFrame"), 2)):
+            res, msgs = messages(fn)
+            assert len(res) == n and any("Coordinate system metadata is missing" in m for m in msgs)
+    finally:
+        pb.set_option("datafusion.bio.coordinate_system_zero_based", False)
+    a.attrs["coordinate_system_zero_based"] = False
+    b.attrs["coordinate_system_zero_based"] = False
+    res, msgs = messages(lambda: pb.overlap(a, b, output_type="pandas.DataFrame"))
+    assert len(res) == 2 and not any("Coordinate system metadata is missing" in m for m in msgs)
+
+
 def test_low_memory_and_streaming_batches(engine):
     """low_memory=True and overlap_batches against the ORACLE's pair list (not the one-shot engine call), in bounded batches."""
     rng = np.random.default_rng(3)
