@@ -26,7 +26,7 @@ bool slice_geom(const ivj_index* ix, const ivj_opts* opts, SliceGeom& g) {
     g.ncells = 0;
     if (ix->n_contigs >= 1 && ix->n_contigs <= SL_TAB_CONTIGS && !(ix->ctx && ix->ctx->sl_env_notab)) {
         for (int cps = 4; cps >= 2 && !g.ncells; cps -= 2) {
-            const int cells = cps * g.nb + ix->n_contigs;
+            const int cells = cps * g.nb + 2 * ix->n_contigs;      // k_slice_tab gives every contig at least two cells
             if ((size_t)slice_part_lds(g.nb, cells).total <= 160 * 1024) { g.ncells = cells; g.cps = cps; }
         }
     }

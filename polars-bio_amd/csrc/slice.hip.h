@@ -135,7 +135,7 @@ __device__ __forceinline__ uint32_t slice_bucket_tab(const unsigned long long* _
 }
 
 // One workgroup: per-contig grid metadata and the cells.  nspl_c = splitters inside contig c = ceil(seg[c+1] / R) -
-// ceil(seg[c] / R); cells_c = max(1, cps * nspl_c).
+// ceil(seg[c] / R); cells_c = max(2, cps * nspl_c).
 __global__ __launch_bounds__(SL_THREADS) void k_slice_tab(const unsigned long long* __restrict__ spl, SliceGeom g, int cps,
                                                          const int32_t* __restrict__ seg, const int32_t* __restrict__ b_start,
                                                          int32_t n_contigs, int4* __restrict__ cm, uint32_t* __restrict__ cell) {
@@ -148,12 +148,12 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_tab(const unsigned long lo
             const int a = seg[c], b = seg[c + 1];
             const int jlo = (a + g.R - 1) / g.R, jhi = (b + g.R - 1) / g.R;
             int nc = cps * (jhi - jlo);
-            if (nc < 1) nc = 1;
+            if (nc < 2) nc = 2;                                  // two cells keep shift <= 31 for any int32 span (a shift by 32 is undefined)
             uint32_t ulo = 0, uhi = 0;
             int shift = 0;
             if (b > a) {
                 ulo = flip(b_start[a]); uhi = flip(b_start[b - 1]);
-                while ((unsigned long long)((uhi - ulo) >> shift) + 1ull > (unsigned long long)nc) ++shift;
+                while (shift < 31 && ((unsigned long long)(uhi - ulo) >> shift) + 1ull > (unsigned long long)nc) ++shift;
             }
             l_cm[c] = make_int4((int)ulo, (int)uhi, shift, tb);
             l_j[2 * c] = jlo; l_j[2 * c + 1] = jhi;

@@ -183,6 +183,27 @@ def test_real_fixture_exons_x_fbrain(eng):
     assert int(d.sum()) == 15203982135 and int((d == 0).sum()) == 51521
 
 
+def test_tiny_contig_spanning_the_whole_int32_range(eng):
+    """A contig of three rows whose starts span more than 2^31 positions, lying INSIDE one index slice (no splitter of its
+    own): its grid of the slice path's bucket table gets the minimum of two cells, which keeps the cell shift at <= 31 (with
+    one cell the geometry loop needed a shift by 32 -- undefined, and endless on the device).  Every path against the oracle."""
+    rng = np.random.default_rng(77)
+    I32 = np.iinfo(np.int32)
+    c0 = random_side(rng, 100, 1, 50_000, 300)
+    c2 = random_side(rng, 6000, 1, 900_000, 500)
+    ts = np.array([I32.min + 10, 5, I32.max - 200], np.int32)
+    build = (np.concatenate([c0[0], np.full(3, 1, np.int32), c2[0] + 2]).astype(np.int32),
+             np.concatenate([c0[1], ts, c2[1]]).astype(np.int32),
+             np.concatenate([c0[2], ts + 50, c2[2]]).astype(np.int32))
+    pc = rng.integers(0, 4, 4000).astype(np.int32)
+    ps = rng.integers(0, 900_000, 4000).astype(np.int64)
+    ps[:300] = rng.choice([I32.min + 5, I32.min + 30, 0, 20, I32.max - 230, I32.max - 180], 300)
+    pc[:300] = 1
+    probe = (pc, ps.astype(np.int32), np.minimum(ps + rng.integers(0, 120, 4000), I32.max).astype(np.int32))
+    for strict in (True, False):
+        _cmp_all(eng, probe, build, 3, strict, nearest_cfgs=((1, True),))
+
+
 def test_synthetic_2M_x_200k_exact(eng):
     probe = synth.make_side(2_000_000, 42, synth.PROBE_LEN, 24)
     build = synth.make_side(200_000, 43, synth.BUILD_LEN, 24)
