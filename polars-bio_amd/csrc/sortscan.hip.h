@@ -442,7 +442,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_subtract_fill(IndexView ix, c
 //     pieces = 1 if last <= first, else  !IN(ls) + (last - first - 1) + !IN(y)
 // Grid per contig over [S_first, E_last) with <= 2 bins per union interval; record of the bin at x0:
 //     {K(x0), t1 | t2 << 16, t3 | flags << 16, -}   t = offsets of the first three toggles inside the bin,
-//     flags 1: x0 covered, 2: a fourth toggle exists, 4: bins wider than 2^16 (search from K(x0)).
+//     flags 1: x0 covered, 2: a fourth toggle exists, 4: bins wider than 2^15 (search from K(x0)).
 struct SubGrid { const int4* cm; const int4* rec; };     // cm[2c] = {lo, span lo, span hi, shift}, cm[2c+1] = {tb, ua, ub, 0}
 
 __device__ __forceinline__ void sub_search(const long long* __restrict__ u_start, const long long* __restrict__ u_end, int k_lo, int ub,
@@ -495,7 +495,7 @@ __global__ void k_sub_records(const int4* __restrict__ cm, int32_t n_contigs, in
             int k0; bool inside;
             sub_search(u_start, u_end, ua, ub, x0, k0, inside);
             uint32_t flags = inside ? 1u : 0u, t[3] = {0xffffu, 0xffffu, 0xffffu};
-            if (shift > 16) flags |= 4u;
+            if (shift > 15) flags |= 4u;                                         // offsets < 2^15: the 0xffff "none" mark stays above every point offset
             else {
                 const long long W = 1ll << shift;
                 int nt = 0;
@@ -524,7 +524,7 @@ __device__ __forceinline__ void sub_eval(const int4& r, uint32_t d, const long l
     const uint32_t t1 = w1 & 0xffffu, t2 = w1 >> 16, t3 = w2 & 0xffffu;
     if ((fl & 4u) || ((fl & 2u) && d >= t3)) { sub_search(u_start, u_end, r.x > ua ? r.x : ua, ub, x, K, in); return; }
     // toggles alternate end / start beginning with "end" when x0 is covered; an "end" toggle at or below the point moves K on
-    const int n_le = (t1 <= d ? 1 : 0) + (t2 <= d ? 1 : 0) + (t3 <= d ? 1 : 0);   // 0xffff > d always
+    const int n_le = (t1 <= d ? 1 : 0) + (t2 <= d ? 1 : 0) + (t3 <= d ? 1 : 0);   // "none" = 0xffff > d: inline offsets only for bins <= 2^15 wide
     const bool in0 = (fl & 1u) != 0;
     const int ends = in0 ? (n_le + 1) / 2 : n_le / 2;
     K = r.x + ends;

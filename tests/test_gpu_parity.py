@@ -767,6 +767,30 @@ def test_subtract_union_grid_edge_shapes(eng, strict):
     check(left, right, 1)
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_grids_with_bins_exactly_2_to_16_wide(eng, strict):
+    """Eight intervals over 2^20 - 1 positions: every per-contig grid (start table, joint grid, union grids) lands on a
+    cell width of 2^16, where a point offset can be 0xffff -- the value the 16-bit inline offsets use for "no such row".
+    Probes / left rows are placed on those offsets; every operation against the oracle."""
+    W = 1 << 16
+    starts = np.array([0, 2 * W, 4 * W + 17, 6 * W, 9 * W - 1, 11 * W + W - 1, 13 * W, 16 * W - 50], np.int64) + 1000
+    ends = starts + np.array([30, W - 1, 5, W, 2, 1, 40, 49], np.int64)
+    assert ends.max() - starts.min() == 16 * W - 1          # (span >> 16) + 1 == 16 cells == 2 per row: shift 16 exactly
+    build = (np.zeros(8, np.int32), starts.astype(np.int32), ends.astype(np.int32))
+    pts = np.concatenate([1000 + np.arange(17) * W - 1, 1000 + np.arange(17) * W, 1000 + np.arange(16) * W + W - 1,
+                          starts, ends, starts - 1, ends - 1, ends + 1])
+    pts = pts[(pts >= 0)]
+    ps = np.repeat(pts, 4)
+    ln = np.tile(np.array([0, 1, W - 1, W + 3]), len(pts))
+    probe = (np.zeros(len(ps), np.int32), ps.astype(np.int32), (ps + ln).astype(np.int32))
+    _cmp_all(eng, probe, build, 1, strict, nearest_cfgs=((1, True),))
+    exp = O.np_coverage_fast(O.Side(*probe), O.Side(*build), strict)
+    assert (eng.coverage(probe, build, strict, 1) == exp).all()
+    er, es, ee = O.np_subtract(O.Side(*probe), O.Side(*build), strict)
+    gr, gs, ge = eng.subtract(probe, build, strict, 1)
+    assert len(gr) == len(er) and (gr == er).all() and (gs == es).all() and (ge == ee).all()
+
+
 def test_subtract_device_entry_point():
     import torch
     from polars_bio_amd.device_api import DeviceJoin, DeviceSide
