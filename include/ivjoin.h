@@ -113,6 +113,9 @@ typedef struct {
 const char* ivj_last_error(void);
 const char* ivj_version(void);
 int ivj_device_count(int* n);
+/* Host memory (bytes) a result allocation may use right now: MemAvailable of /proc/meminfo (page cache counts as
+ * available), MemFree as fallback; the host entry points refuse a result larger than 7/8 of it with IVJ_ENOMEM. */
+int64_t ivj_host_mem_available(void);
 int ivj_ctx_create(int device, ivj_ctx** out);
 void ivj_ctx_destroy(ivj_ctx* ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream; NULL is the

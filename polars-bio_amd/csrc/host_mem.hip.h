@@ -16,8 +16,28 @@
 
 namespace {
 
-// physical host memory that is free right now (bytes); 0 when it cannot be told
+// Host memory a new allocation can use right now (bytes); 0 when it cannot be told.  MemAvailable of /proc/meminfo counts the
+// reclaimable page cache (a host that has just read large Parquet / CSV inputs has little MemFree but tens of GB available);
+// sysconf(_SC_AVPHYS_PAGES) = MemFree is only the fallback.  IVJ_HOST_MEM_AVAILABLE (bytes) overrides both (tests).
+size_t parse_meminfo_available(const char* text) {
+    const char* p = text ? std::strstr(text, "MemAvailable:") : nullptr;
+    if (!p) return 0;
+    p += 13;
+    while (*p == ' ' || *p == '\t') ++p;
+    char* end = nullptr;
+    const unsigned long long kb = std::strtoull(p, &end, 10);
+    return end == p ? 0 : (size_t)kb * 1024;
+}
 size_t host_mem_available() {
+    if (const char* o = std::getenv("IVJ_HOST_MEM_AVAILABLE")) { const unsigned long long v = std::strtoull(o, nullptr, 10); if (v) return (size_t)v; }
+    if (FILE* f = std::fopen("/proc/meminfo", "r")) {
+        char buf[2048];
+        const size_t n = std::fread(buf, 1, sizeof(buf) - 1, f);
+        std::fclose(f);
+        buf[n] = 0;
+        const size_t a = parse_meminfo_available(buf);
+        if (a) return a;
+    }
     const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
     return (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz : 0;
 }

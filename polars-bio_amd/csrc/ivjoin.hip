@@ -39,6 +39,7 @@ extern "C" {
 
 const char* ivj_last_error(void) { return g_err.c_str(); }
 const char* ivj_version(void) { return "ivjoin-hip 0.1 (gfx950)"; }
+int64_t ivj_host_mem_available(void) { return (int64_t)host_mem_available(); }
 
 int ivj_device_count(int* n) {
     if (!n) return fail(IVJ_EINVAL, "n is NULL");
@@ -268,7 +269,7 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     IVJ_TRY(overlap_count(ctx, h.ix, &dp.s, opts, &total));
     if (total == 0) return IVJ_OK;
     if (!host_result_fits((size_t)total * 8))
-        return fail(IVJ_ENOMEM, "the result (" + std::to_string(total) + " pairs, " + std::to_string((size_t)total * 8 >> 20) + " MiB) does not fit the free host memory; use the streaming entry points (ivj_stream_*) or the *_dev ones");
+        return fail(IVJ_ENOMEM, "the result (" + std::to_string(total) + " pairs, " + std::to_string((size_t)total * 8 >> 20) + " MiB) does not fit the available host memory; use the streaming entry points (ivj_stream_*) or the *_dev ones");
     DevBuf op, ob;
     hipError_t e = hipMalloc(&op.p, (size_t)total * 4);
     if (e == hipSuccess) e = hipMalloc(&ob.p, (size_t)total * 4);
@@ -583,7 +584,7 @@ int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
     IVJ_TRY(overlap_count(ctx, h.ix, &dp.s, opts, &total));
     if (total == 0) return IVJ_OK;
     if (!host_result_fits((size_t)total * 28))
-        return fail(IVJ_ENOMEM, "the result (" + std::to_string(total) + " rows x 7 columns) does not fit the free host memory");
+        return fail(IVJ_ENOMEM, "the result (" + std::to_string(total) + " rows x 7 columns) does not fit the available host memory");
     DevBuf cols;                                            // 7 columns in one allocation
     const size_t col = align_up((size_t)total * 4);
     hipError_t e = hipMalloc(&cols.p, 7 * col);

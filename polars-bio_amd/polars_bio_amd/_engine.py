@@ -24,7 +24,7 @@ FILTER_STRICT = 1  # FilterOp.Strict (0-based half-open)
 
 # every symbol include/ivjoin.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ivj_last_error", "ivj_version", "ivj_device_count", "ivj_ctx_create", "ivj_ctx_destroy",
+    "ivj_last_error", "ivj_version", "ivj_device_count", "ivj_host_mem_available", "ivj_ctx_create", "ivj_ctx_destroy",
     "ivj_ctx_set_stream", "ivj_ctx_sync", "ivj_ctx_enable_timing", "ivj_ctx_get_timings", "ivj_ctx_profile_mark",
     "ivj_overlap", "ivj_pairs_free", "ivj_count_overlaps", "ivj_nearest",
     "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev", "ivj_overlap_fused_dev",
@@ -114,6 +114,7 @@ def load_library() -> C.CDLL:
         vp = C.c_void_p
         L.ivj_last_error.restype = C.c_char_p
         L.ivj_version.restype = C.c_char_p
+        L.ivj_host_mem_available.restype = C.c_int64
         L.ivj_device_count.argtypes = [C.POINTER(C.c_int)]
         L.ivj_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.ivj_ctx_destroy.argtypes = [vp]

@@ -102,3 +102,17 @@ def test_arrow_c_data_import_of_a_side_is_zero_copy():
             _engine.side_from_arrow(b)
     empty, _ = _engine.side_from_arrow(batch.slice(0, 0))
     assert empty.n == 0
+
+
+def test_host_memory_probe_reads_memavailable(monkeypatch):
+    """The host entry points gate big results on MemAvailable (reclaimable page cache counts), not on MemFree; the
+    probe can be pinned through IVJ_HOST_MEM_AVAILABLE."""
+    from polars_bio_amd import _engine
+    L = _engine.load_library()
+    info = dict(l.split(":", 1) for l in open("/proc/meminfo").read().splitlines() if ":" in l)
+    avail = int(info["MemAvailable"].split()[0]) * 1024
+    free = int(info["MemFree"].split()[0]) * 1024
+    got = L.ivj_host_mem_available()
+    assert abs(got - avail) <= max(avail // 4, 1 << 30), (got, avail, free)
+    monkeypatch.setenv("IVJ_HOST_MEM_AVAILABLE", str(12345 << 20))
+    assert L.ivj_host_mem_available() == 12345 << 20

@@ -925,3 +925,19 @@ def test_sort_scan_conservation_laws_on_real_data(eng, strict):
     assert int(mn.sum()) == len(b[0])
     ec, es, ee = O.np_complement(O.Side(*b), O.Side(*view), strict)
     assert (view[0][vrow] == ec).all() and (gs == es).all() and (ge == ee).all()
+
+
+def test_host_result_larger_than_available_memory_is_refused(eng, monkeypatch):
+    """ivj_overlap refuses a result that exceeds 7/8 of the available host memory (MemAvailable, pinned here through
+    IVJ_HOST_MEM_AVAILABLE) with an error instead of first-touching it into the OOM killer; with the real figure it runs."""
+    rng = np.random.default_rng(31)
+    probe = random_side(rng, 20000, 1, 5000, 400)
+    build = random_side(rng, 2000, 1, 5000, 400)
+    p, b = eng.overlap(probe, build, True, 1)
+    assert len(p) * 8 > (1 << 20)
+    monkeypatch.setenv("IVJ_HOST_MEM_AVAILABLE", str(1 << 20))
+    with pytest.raises(_engine.EngineError, match="host memory"):
+        eng.overlap(probe, build, True, 1)
+    monkeypatch.delenv("IVJ_HOST_MEM_AVAILABLE")
+    p2, b2 = eng.overlap(probe, build, True, 1)
+    assert (p2 == p).all() and (b2 == b).all()
