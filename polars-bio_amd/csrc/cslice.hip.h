@@ -1,0 +1,761 @@
+// cslice.hip.h -- pb.overlap, fused single pass on CONTIG-ALIGNED index slices with 12-byte probe records (round 3).
+//
+// Same idea as slice.hip.h (probes partitioned by the slice of the sorted build side that holds their hi-bound, the
+// slice resident in LDS), rebuilt around what round 2's counters said about k_slice_join: it was not bandwidth-bound
+// but issue-bound -- 587 VALU + 392 SALU instructions per 64 probes, 60 % of a wavefront's life parked behind
+// dependent LDS reads in divergent loops.  This path removes work instead of hiding it:
+//
+//   * slices never cross a contig (k_cs_prep cuts every contig's segment into ceil(n_c / R) slices), so a bucket's
+//     probes all carry the slice's contig: the record is {start, end, row} = 12 bytes (-25 % scatter writes and join
+//     reads) and the join needs no per-probe contig test, segment lookup or row-limit arithmetic;
+//   * per-slice start bins are built ONCE per index (k_cs_bins) instead of by each of the ~7 workgroups that visit a slice;
+//   * hi-bound = one 2-byte bin read + four start compares, branch-free (a bin holds 0.5 rows on average; more than four
+//     rows below the probe's end inside its bin take a rare fallback);
+//   * window = sixteen ends as four ds_read_b128 + sixteen v_cmp / v_addc pairs that shift the match bits into a mask
+//     (two VALU instructions per row), one prefix-max read decides whether the window may run on;
+//   * emission stages ONE 4-byte entry {wave-local probe slot, slice-local row} per pair (no LDS read inside the
+//     per-lane bit loop); probe row and build row are resolved at copy-out, where the LDS reads are independent;
+//   * wavefront scans use DPP adds (no ds_bpermute), tiles are 4096 probes (24 k output reservations instead of 49 k
+//     on the one cursor), the tile loop is barrier-free as in slice.hip.h (split-phase reservation through LDS control
+//     blocks).
+//
+// Restrictions (the callers fall back to slice.hip.h otherwise): dictionaries of up to CS_MAX_CONTIGS contigs, at most
+// SL_MAX_BUCKETS slices.  Output order: as slice.hip.h's fused mode -- the pairs of one probe row are contiguous and
+// ordered by (build.start, build row); tiles land in reservation order.
+#pragma once
+#include "slice.hip.h"
+
+namespace ivj {
+
+constexpr int CS_THREADS = 1024;
+constexpr int CS_WAVES = CS_THREADS / kWave;
+constexpr int CS_ITEMS = 4;
+constexpr int CS_TILE = CS_THREADS * CS_ITEMS;          // probes per tile of the partition and of the join
+constexpr int CS_WTILE = kWave * CS_ITEMS;              // probes of one wavefront per tile (its private slot range)
+constexpr int CS_MAX_CONTIGS = 256;
+constexpr int CS_WIN = 12;                              // rows below hi the branch-free window is guaranteed to cover
+constexpr int CS_BIN_STRIDE_PAD = 2;                    // bins per slice in global memory: 2 R + 2 (u16)
+
+typedef int cs_rec __attribute__((ext_vector_type(3), aligned(4)));      // one probe record {start, end, row}: 12 bytes, 4-byte aligned
+
+struct CsGeom {
+    int nb;            // bucket SLOTS = upper bound on the number of slices (host-known); bucket nb = probes without a candidate row
+    int R;             // rows per slice (multiple of 64); a contig's last slice may be shorter
+    int ncells;        // cells of the direct-address bucket table (upper bound, host-known)
+    int cps;           // cells per slice
+    int n_contigs;
+};
+
+// per-slice metadata written by k_cs_bins (two int4 per slice)
+//   [0] = {min start, bin shift, number of cells, prefix max of the row below the slice (INT32_MIN: none)}
+//   [1] = {first row of the contig's segment, contig, rows, first row}
+
+__device__ __forceinline__ int wave_incl_sum_dpp(int v) {
+    // row_shr:1,2,4,8 inside the rows of 16 lanes, then row_bcast:15 / row_bcast:31 across the rows
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// gfx950 needs two wait states between a VALU write of an SGPR pair / VCC and a VALU that reads it as a carry or lane mask
+// (the compiler pads every v_cmp -> v_cndmask / v_addc pair with s_nop 1).  The two hot compare sequences of the join are
+// therefore written out with rotating SGPR pairs, every consumer three instructions behind its compare: no padding.
+//
+// Window mask: bit i <=> qs (<) e[i] for the sixteen ends e[0..15]; row 15 is shifted in first (m = m + m + carry).
+#define IVJ_CS_WINDOW_ASM(CMP)                                                                                                     \
+    asm("v_cmp_" CMP "_i32_e64 %1, %5, %21\n\tv_cmp_" CMP "_i32_e64 %2, %5, %20\n\tv_cmp_" CMP "_i32_e64 %3, %5, %19\n\t"     \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %18\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %17\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %16\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %15\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %14\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %13\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %12\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %11\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %10\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %9\n\t"                                        \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %8\n\t"                                        \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %7\n\t"                                        \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %6\n\t"                                        \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t"                                                                             \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"                                                                             \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1"                                                                                  \
+        : "+v"(m), "=&s"(ta), "=&s"(tb), "=&s"(tc), "=&s"(td)                                                                   \
+        : "v"(qs), "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w), "v"(v2.x), "v"(v2.y),  \
+          "v"(v2.z), "v"(v2.w), "v"(v3.x), "v"(v3.y), "v"(v3.z), "v"(v3.w))
+template <bool STRICT>
+__device__ __forceinline__ uint32_t cs_window_mask(int32_t qs, const int4& v0, const int4& v1, const int4& v2, const int4& v3) {
+    uint32_t m = 0;
+    unsigned long long ta, tb, tc, td;
+    if (STRICT) IVJ_CS_WINDOW_ASM("lt");
+    else IVJ_CS_WINDOW_ASM("le");
+    return m;
+}
+// h + number of the four starts below the probe's end (s (<) qe); *m4 = lanes whose fourth start is still below it
+#define IVJ_CS_COUNT4_ASM(CMP)                                                                                                     \
+    asm("v_cmp_" CMP "_i32_e64 %1, %6, %10\n\tv_cmp_" CMP "_i32_e64 %2, %7, %10\n\tv_cmp_" CMP "_i32_e64 %3, %8, %10\n\t"      \
+        "v_cmp_" CMP "_i32_e64 %4, %9, %10\n\t"                                                                                \
+        "v_addc_co_u32_e64 %0, %5, %0, 0, %1\n\tv_addc_co_u32_e64 %0, %5, %0, 0, %2\n\t"                                      \
+        "v_addc_co_u32_e64 %0, %5, %0, 0, %3\n\tv_addc_co_u32_e64 %0, %5, %0, 0, %4"                                           \
+        : "+v"(h), "=&s"(ta), "=&s"(tb), "=&s"(tc), "=&s"(td), "=&s"(te)                                                        \
+        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(qe))
+template <bool STRICT>
+__device__ __forceinline__ int cs_count4(int h, int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t qe, unsigned long long* m4) {
+    unsigned long long ta, tb, tc, td, te;
+    if (STRICT) IVJ_CS_COUNT4_ASM("lt");
+    else IVJ_CS_COUNT4_ASM("le");
+    *m4 = td;
+    return h;
+}
+
+// ---- slices, splitters, bucket table: ONE workgroup -------------------------------------------------------------------------
+// Contig c's segment [seg[c], seg[c+1]) is cut into ns_c = ceil(n_c / R) slices; fs_c = slices of the contigs before it.
+//   bound[j]  first sorted row of slice j (j >= number of slices: the number of valid rows), nb + 1 entries
+//   spl[j]    composite (contig, start) key of that row (~0 for the unused slots)
+//   cm[c]     {ulo, uhi, shift, first cell | fs_c << 16}: uniform grid over the starts of the contig's rows
+//   cell[i]   lo | hi << 16: range of "number of splitters below" a key of that cell can have
+__global__ __launch_bounds__(CS_THREADS) void k_cs_prep(const int32_t* __restrict__ seg, const int32_t* __restrict__ b_start, CsGeom g,
+                                                       int32_t* __restrict__ bound, unsigned long long* __restrict__ spl,
+                                                       int4* __restrict__ cm, uint32_t* __restrict__ cell) {
+    __shared__ int4 l_cm[CS_MAX_CONTIGS];
+    __shared__ int l_a[CS_MAX_CONTIGS + 1], l_fs[CS_MAX_CONTIGS + 1];
+    __shared__ uint32_t l_lo[CS_MAX_CONTIGS], l_hi[CS_MAX_CONTIGS];
+    __shared__ unsigned long long l_spl[SL_MAX_BUCKETS + 1];
+    __shared__ int l_cells;
+    const int tid = threadIdx.x, nc = g.n_contigs;
+    for (int c = tid; c <= nc; c += CS_THREADS) {
+        const int a = seg[c];
+        l_a[c] = a;
+        if (c < nc) {
+            const int b = seg[c + 1];
+            l_lo[c] = b > a ? flip(b_start[a]) : 0u;
+            l_hi[c] = b > a ? flip(b_start[b - 1]) : 0u;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int fs = 0, tb = 0;
+        for (int c = 0; c < nc; ++c) {
+            const int a = l_a[c], b = l_a[c + 1];
+            const int ns = (b - a + g.R - 1) / g.R;
+            int ncl = g.cps * ns;
+            if (ncl < 2) ncl = 2;                                  // two cells keep the shift <= 31 for any int32 span
+            const uint32_t ulo = l_lo[c], uhi = l_hi[c];
+            int shift = 0;
+            while (shift < 31 && ((unsigned long long)(uhi - ulo) >> shift) + 1ull > (unsigned long long)ncl) ++shift;
+            l_cm[c] = make_int4((int)ulo, (int)uhi, shift, tb | (fs << 16));
+            l_fs[c] = fs;
+            fs += ns; tb += ncl;
+        }
+        l_fs[nc] = fs;
+        l_cells = tb;
+    }
+    __syncthreads();
+    const int total = l_fs[nc];                                    // number of slices (<= g.nb by construction of R)
+    const int nvalid = l_a[nc];
+    for (int c = tid; c < nc; c += CS_THREADS) cm[c] = l_cm[c];
+    for (int j = tid; j <= g.nb; j += CS_THREADS) {
+        int row = nvalid;
+        unsigned long long key = ~0ull;
+        if (j < total) {
+            int lo = 0, hi = nc;                                   // last contig with fs <= j that owns slices
+            while (lo < hi) { const int m = (lo + hi) >> 1; if (l_fs[m + 1] <= j) lo = m + 1; else hi = m; }
+            row = l_a[lo] + (j - l_fs[lo]) * g.R;
+            key = ((unsigned long long)(uint32_t)lo << 32) | (unsigned long long)flip(b_start[row]);
+        }
+        bound[j] = row;
+        if (j < g.nb) { spl[j] = key; }
+        l_spl[j < SL_MAX_BUCKETS ? j : SL_MAX_BUCKETS] = key;
+    }
+    __syncthreads();
+    const int ncl_total = l_cells;
+    for (int i = tid; i < ncl_total; i += CS_THREADS) {
+        int lo = 0, hi = nc;                                       // contig of cell i: last one whose first cell is <= i
+        while (lo < hi) { const int m = (lo + hi) >> 1; if ((l_cm[m].w & 0xffff) <= i) lo = m + 1; else hi = m; }
+        const int c = lo - 1;
+        const int4 m = l_cm[c];
+        const int k = i - (m.w & 0xffff);
+        const int jlo = l_fs[c], jhi = l_fs[c + 1];
+        const int last = (c + 1 < nc ? (l_cm[c + 1].w & 0xffff) : ncl_total) - 1;
+        auto below = [&](int kk) {                                 // splitters of the dictionary below the lower edge of cell kk
+            if (kk <= 0) return jlo;
+            const unsigned long long edge = ((unsigned long long)(uint32_t)c << 32) + (unsigned long long)(uint32_t)m.x +
+                                            ((unsigned long long)kk << m.z);
+            int a = jlo, b = jhi;
+            while (a < b) { const int mid = (a + b) >> 1; if (l_spl[mid] < edge) a = mid + 1; else b = mid; }
+            return a;
+        };
+        const int l = below(k);
+        const int h = i == last ? jhi : below(k + 1);
+        cell[i] = (uint32_t)l | ((uint32_t)h << 16);
+    }
+}
+
+// Bucket of a probe (contig c, end qe): the slice of contig c that holds row hi - 1, hi = number of the contig's rows whose
+// start lies below the end [Weak: at or below]; no such row (or a contig outside the dictionary / without rows): bucket g.nb.
+template <bool STRICT>
+__device__ __forceinline__ uint32_t cs_bucket(const unsigned long long* __restrict__ l_spl, const int4* __restrict__ l_cm,
+                                              const uint32_t* __restrict__ l_cell, int nb, int32_t n_contigs, int32_t c, int32_t qe) {
+    if ((uint32_t)c >= (uint32_t)n_contigs) return (uint32_t)nb;
+    const unsigned long long tu = (unsigned long long)flip(qe) + (STRICT ? 0ull : 1ull);
+    const unsigned long long key = ((unsigned long long)(uint32_t)c << 32) + tu;        // (c, INT32_MAX) + 1 carries into the contig
+    const int4 m = l_cm[c];
+    const uint32_t ulo = (uint32_t)m.x, uhi = (uint32_t)m.y;
+    uint32_t k;
+    if (tu <= ulo) k = 0;
+    else if (tu > uhi) k = (uhi - ulo) >> m.z;
+    else k = ((uint32_t)tu - ulo) >> m.z;
+    const uint32_t lh = l_cell[(m.w & 0xffff) + k];
+    int pos = (int)(lh & 0xffffu);
+    const int hi = (int)(lh >> 16);
+    while (pos < hi && l_spl[pos] < key) ++pos;
+    return pos <= (int)((uint32_t)m.w >> 16) ? (uint32_t)nb : (uint32_t)(pos - 1);
+}
+
+// ---- per-slice start bins, built once per index: one workgroup per slice ---------------------------------------------------
+// bins[j * (2 R + 2) + cl] = first slice-local row whose (start - min start) >> shift reaches cell cl (two cells per row);
+// bins[.. + ncell] = rows of the slice.
+__global__ __launch_bounds__(CS_THREADS) void k_cs_bins(const int32_t* __restrict__ bound, const int32_t* __restrict__ b_start,
+                                                       const int2* __restrict__ ep, const int32_t* __restrict__ b_contig,
+                                                       const int32_t* __restrict__ seg, int R, unsigned short* __restrict__ bins,
+                                                       int4* __restrict__ smeta) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    int32_t* l_start = reinterpret_cast<int32_t*>(cs_lds);                     // R
+    unsigned short* l_bin = reinterpret_cast<unsigned short*>(l_start + R);    // 2 R + 2
+    __shared__ uint32_t wmin[CS_WAVES];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int r0 = bound[j];
+    const int rk = bound[j + 1] - r0;
+    if (rk <= 0) {                                                             // unused slot (uniform)
+        if (tid == 0) { smeta[2 * j] = make_int4(0, 0, 0, INT32_MIN); smeta[2 * j + 1] = make_int4(0, -1, 0, r0); }
+        return;
+    }
+    for (int i = tid; i < rk; i += CS_THREADS) l_start[i] = b_start[r0 + i];
+    __syncthreads();
+    const uint32_t s0 = flip(l_start[0]), s1 = flip(l_start[rk - 1]);
+    const int ncell = 2 * rk;
+    int bshift = 0;
+    while ((unsigned long long)((s1 - s0) >> bshift) + 1ull > (unsigned long long)ncell) ++bshift;
+    for (int i = tid; i <= ncell; i += CS_THREADS) l_bin[i] = i == ncell ? (unsigned short)rk : (unsigned short)0xffff;
+    __syncthreads();
+    for (int i = tid; i < rk; i += CS_THREADS) {
+        const uint32_t c1 = (flip(l_start[i]) - s0) >> bshift;
+        const bool head = i == 0 || ((flip(l_start[i - 1]) - s0) >> bshift) != c1;
+        if (head) l_bin[c1] = (unsigned short)i;
+    }
+    __syncthreads();
+    // empty cells take the next head: suffix minimum (heads ascend with the cell index)
+    const int per_t = (ncell + 1 + CS_THREADS - 1) / CS_THREADS;
+    const int c_lo = tid * per_t, c_hi = (c_lo + per_t) < (ncell + 1) ? (c_lo + per_t) : (ncell + 1);
+    uint32_t mn = 0xffffffffu;
+    for (int c = c_lo; c < c_hi; ++c) { const uint32_t x = l_bin[c]; mn = x < mn ? x : mn; }
+    uint32_t run = sl_block_suffix_min_excl(mn, wmin);
+    for (int c = c_hi - 1; c >= c_lo; --c) { const uint32_t x = l_bin[c]; run = x < run ? x : run; l_bin[c] = (unsigned short)run; }
+    __syncthreads();
+    unsigned short* out = bins + (size_t)j * (size_t)(2 * R + CS_BIN_STRIDE_PAD);
+    for (int i = tid; i <= ncell; i += CS_THREADS) out[i] = l_bin[i];
+    if (tid == 0) {
+        const int32_t c = b_contig[r0];
+        const int a = seg[c];
+        smeta[2 * j] = make_int4(l_start[0], bshift, ncell, r0 > a ? ep[r0 - 1].y : INT32_MIN);
+        smeta[2 * j + 1] = make_int4(a, c, rk, r0);
+    }
+}
+
+// ---- partition, pass 1: per-chunk bucket histogram -----------------------------------------------------------------------------
+struct CsTab {
+    const unsigned long long* spl;
+    const int4* cm;
+    const uint32_t* cell;
+};
+
+__device__ __forceinline__ void cs_load_tab(const CsTab& tab, const CsGeom& g, unsigned long long* l_spl, int4* l_cm, uint32_t* l_cell, int threads) {
+    for (int k = threadIdx.x; k < g.nb; k += threads) l_spl[k] = tab.spl[k];
+    for (int k = threadIdx.x; k < g.ncells; k += threads) l_cell[k] = tab.cell[k];
+    for (int k = threadIdx.x; k < g.n_contigs; k += threads) l_cm[k] = tab.cm[k];
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(CS_THREADS) void k_cs_hist(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ pe,
+                                                       int64_t n, int chunk, int nchunks, bool vec_ok, uint32_t* __restrict__ blk_hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    // dynamic LDS: cm[CS_MAX_CONTIGS] | spl[nb] | cells[ncells] | hist[nb + 1]
+    int4* l_cm = reinterpret_cast<int4*>(cs_lds);
+    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(l_cm + CS_MAX_CONTIGS);
+    uint32_t* l_cell = reinterpret_cast<uint32_t*>(l_spl + g.nb);
+    uint32_t* h = l_cell + g.ncells;
+    cs_load_tab(tab, g, l_spl, l_cm, l_cell, CS_THREADS);
+    for (int k = threadIdx.x; k <= g.nb; k += CS_THREADS) h[k] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * chunk;
+    const int64_t end = base + chunk < n ? base + chunk : n;
+    for (int64_t i0 = base + (int64_t)threadIdx.x * 4; i0 < end; i0 += (int64_t)CS_THREADS * 4) {
+        int32_t c[4], e[4];
+        load_items_nt(pc, i0, end, vec_ok, -1, c);
+        load_items_nt(pe, i0, end, vec_ok, 0, e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < end) atomicAdd(&h[cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, c[k], e[k])], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= g.nb; k += CS_THREADS) blk_hist[(int64_t)k * nchunks + blockIdx.x] = h[k];
+}
+
+// ---- partition, pass 2: unordered scatter of 12-byte records {start, end, row} --------------------------------------------------
+// As k_slice_scatter_u: rank inside (tile, bucket) from one returning LDS atomic, records staged in LDS (three 4-byte
+// planes: a 12-byte LDS store would need 16-byte alignment) at their bucket-sorted tile-local position, copied out as
+// contiguous bucket runs with 12-byte stores.  A thread loads FOUR consecutive probes of each column with one 16-byte load.
+struct CsPartLds { int cm, cell, spl, base, lstart, delta, cnt, rs, re, rr, d, wsum, total; };
+__host__ __device__ inline CsPartLds cs_part_lds(int nb, int ncells) {
+    CsPartLds L;
+    int o = 0;
+    L.cm = o; o += 16 * CS_MAX_CONTIGS;
+    L.spl = o; o += 8 * nb;
+    L.cell = o; o += 4 * ncells;
+    L.rs = (o + 15) & ~15; o = L.rs + 4 * CS_TILE;
+    L.re = o; o += 4 * CS_TILE;
+    L.rr = o; o += 4 * CS_TILE;
+    L.base = o; o += 4 * (nb + 2);
+    L.lstart = o; o += 4 * (nb + 2);
+    L.delta = o; o += 4 * (nb + 2);
+    L.cnt = o; o += 4 * (nb + 2);
+    L.d = (o + 3) & ~3; o = L.d + 2 * CS_TILE;
+    L.wsum = (o + 15) & ~15; o = L.wsum + 4 * 2 * CS_WAVES;
+    L.total = o;
+    return L;
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                          const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
+                                                          int chunk, int nchunks, bool vec_ok, const uint32_t* __restrict__ blk_off,
+                                                          int32_t* __restrict__ out /* 3 int32 per record */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    const CsPartLds L = cs_part_lds(g.nb, g.ncells);
+    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(cs_lds + L.spl);
+    int4* l_cm = reinterpret_cast<int4*>(cs_lds + L.cm);
+    uint32_t* l_cell = reinterpret_cast<uint32_t*>(cs_lds + L.cell);
+    int32_t* l_rs = reinterpret_cast<int32_t*>(cs_lds + L.rs);
+    int32_t* l_re = reinterpret_cast<int32_t*>(cs_lds + L.re);
+    int32_t* l_rr = reinterpret_cast<int32_t*>(cs_lds + L.rr);
+    uint32_t* base = reinterpret_cast<uint32_t*>(cs_lds + L.base);
+    uint32_t* lstart = reinterpret_cast<uint32_t*>(cs_lds + L.lstart);
+    uint32_t* delta = reinterpret_cast<uint32_t*>(cs_lds + L.delta);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(cs_lds + L.cnt);
+    unsigned short* l_d = reinterpret_cast<unsigned short*>(cs_lds + L.d);
+    int* wsum = reinterpret_cast<int*>(cs_lds + L.wsum);
+    const int tid = threadIdx.x;
+    const int nbk = g.nb + 1;
+    cs_load_tab(tab, g, l_spl, l_cm, l_cell, CS_THREADS);
+    for (int k = tid; k < nbk + 1; k += CS_THREADS) { base[k] = k < nbk ? blk_off[(int64_t)k * nchunks + blockIdx.x] : 0u; cnt[k] = 0; }
+    __syncthreads();
+    const int64_t cbase = (int64_t)blockIdx.x * chunk;
+    const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
+    int32_t nc[CS_ITEMS], ns[CS_ITEMS], ne[CS_ITEMS], nr[CS_ITEMS];
+    auto load_tile = [&](int64_t tbase) {
+        const int64_t i0 = tbase + (int64_t)tid * CS_ITEMS;
+        load_items_nt(pc, i0, cend, vec_ok, -1, nc);
+        load_items_nt(ps, i0, cend, vec_ok, 0, ns);
+        load_items_nt(pe, i0, cend, vec_ok, 0, ne);
+        if (row_id) load_items_nt(row_id, i0, cend, vec_ok, -1, nr);
+        else {
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) nr[j] = (int32_t)(i0 + j);
+        }
+    };
+    load_tile(cbase);
+    int tix = 0;
+    for (int64_t tbase = cbase; tbase < cend; tbase += CS_TILE, ++tix) {
+        int32_t c[CS_ITEMS], s[CS_ITEMS], e[CS_ITEMS], r[CS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) { c[j] = nc[j]; s[j] = ns[j]; e[j] = ne[j]; r[j] = nr[j]; }
+        if (tbase + CS_TILE < cend) load_tile(tbase + CS_TILE);                // next tile's columns in flight during this one
+        const int tile_n = (int)((cend - tbase) < (int64_t)CS_TILE ? (cend - tbase) : (int64_t)CS_TILE);
+        uint32_t d[CS_ITEMS], rank[CS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const bool valid = tid * CS_ITEMS + j < tile_n;
+            d[j] = !valid ? 0u : cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, c[j], e[j]);
+            rank[j] = valid ? atomicAdd(&cnt[d[j]], 1u) : 0u;
+        }
+        __syncthreads();                                                        // (A) bucket counts of the tile complete
+        // thread t owns OWN consecutive buckets: tile-local starts, copy-out deltas, running global offsets; counters cleared
+        constexpr int OWN = (SL_MAX_BUCKETS + 1 + CS_THREADS - 1) / CS_THREADS;
+        int x[OWN];
+        int xs = 0;
+#pragma unroll
+        for (int q = 0; q < OWN; ++q) {
+            const int b = OWN * tid + q;
+            x[q] = 0;
+            if (b < nbk) { x[q] = (int)cnt[b]; cnt[b] = 0; }
+            xs += x[q];
+        }
+        long long tsum;
+        int pre = (int)sl_block_exclusive_sum_i32<CS_WAVES>(xs, wsum + (tix & 1) * CS_WAVES, &tsum);      // (B)
+#pragma unroll
+        for (int q = 0; q < OWN; ++q) {
+            const int b = OWN * tid + q;
+            if (b < nbk) { lstart[b] = (uint32_t)pre; delta[b] = base[b] - (uint32_t)pre; base[b] += (uint32_t)x[q]; }
+            pre += x[q];
+        }
+        __syncthreads();                                                        // (C)
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            if (tid * CS_ITEMS + j < tile_n) {
+                const uint32_t pos = lstart[d[j]] + rank[j];
+                l_rs[pos] = s[j]; l_re[pos] = e[j]; l_rr[pos] = r[j];
+                l_d[pos] = (unsigned short)d[j];
+            }
+        }
+        __syncthreads();                                                        // (D) tile sorted in LDS
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const int il = j * CS_THREADS + tid;
+            if (il < tile_n) {
+                cs_rec v; v.x = l_rs[il]; v.y = l_re[il]; v.z = l_rr[il];
+                *reinterpret_cast<cs_rec*>(out + 3 * (int64_t)((uint32_t)il + delta[l_d[il]])) = v;
+            }
+        }
+        // no barrier here: the next tile's barrier (A) separates this copy-out from the next placement
+    }
+}
+
+// ---- the join ---------------------------------------------------------------------------------------------------------------------
+struct CsJoinArgs {
+    const int32_t* b_start;
+    const int2* ep;
+    const int32_t* b_row;
+    const unsigned short* bins;       // per-slice start bins (k_cs_bins)
+    const int4* smeta;                // per-slice metadata (two int4)
+    const int32_t* rec;               // bucket-ordered probe records {start, end, row}
+    const uint32_t* bstart;           // nb + 2 bucket starts
+    const int32_t* meta;              // [0] = number of join workgroups
+    const int2* wg_map;               // workgroup -> (bucket, chunk inside the bucket)
+    int R;
+    int jchunk;                       // probes per join workgroup (multiple of the tile)
+    int wcap;                         // staging entries per wavefront
+    int ablate;                       // profiling only (IVJ_SLICE_ABLATE): 32 no copy-out
+    long long capacity;
+    unsigned long long* state;        // [0] cursor, [1] overflow flag
+    int32_t* out_probe;
+    int32_t* out_build;
+};
+
+struct CsJoinLds { int end, pmx, start, row, bin, qrow, stage, ctl, total; };
+__host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
+    CsJoinLds L;
+    int o = 0;
+    L.end = o; o += 4 * (R + 16);                      // sixteen ends are read from any aligned row <= rk
+    L.pmx = o; o += 4 * (R + 4);                       // [0] = prefix max below the slice, [i + 1] = prefix max of row i
+    L.start = o; o += 4 * (R + 4);                     // four pad rows (INT32_MAX) behind the last one
+    L.row = o; o += 4 * R;
+    L.bin = o; o += 2 * (2 * R + 8);
+    L.qrow = (o + 15) & ~15; o = L.qrow + 4 * CS_TILE;
+    L.stage = o; o += 4 * wcap * CS_WAVES;
+    L.ctl = (o + 15) & ~15; o = L.ctl + 64;
+    L.total = o;
+    return L;
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    const CsJoinLds L = cs_join_lds(A.R, A.wcap);
+    int32_t* l_end = reinterpret_cast<int32_t*>(cs_lds + L.end);
+    int32_t* l_pmx = reinterpret_cast<int32_t*>(cs_lds + L.pmx);
+    int32_t* l_start = reinterpret_cast<int32_t*>(cs_lds + L.start);
+    int32_t* l_row = reinterpret_cast<int32_t*>(cs_lds + L.row);
+    unsigned short* l_bin = reinterpret_cast<unsigned short*>(cs_lds + L.bin);
+    int32_t* l_qrow = reinterpret_cast<int32_t*>(cs_lds + L.qrow);
+    uint32_t* l_stage = reinterpret_cast<uint32_t*>(cs_lds + L.stage);
+    unsigned long long* lc = reinterpret_cast<unsigned long long*>(cs_lds + L.ctl);     // [2][2] {cursor, base}
+    int* li = reinterpret_cast<int*>(lc + 4);                                           // [2][4] {arrived, done, ready, seq}
+
+    // XCD-affine order: workgroup b runs on XCD b % 8 (observed); XCD x takes the contiguous eighth of the (bucket, chunk) list
+    const int total_wg = A.meta[0];
+    const int per = (total_wg + 7) / 8;
+    const int wslot = (int)(blockIdx.x >> 3);
+    const int v = (int)(blockIdx.x & 7) * per + wslot;
+    if (wslot >= per || v >= total_wg) return;                                 // uniform
+    const int2 bc = A.wg_map[v];
+    const int k = bc.x;
+    const int64_t q0 = (int64_t)A.bstart[k] + (int64_t)bc.y * A.jchunk;
+    const int64_t qend = (int64_t)A.bstart[k + 1];
+    const int64_t q1 = q0 + A.jchunk < qend ? q0 + A.jchunk : qend;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+
+    const int4 sm0 = A.smeta[2 * k], sm1 = A.smeta[2 * k + 1];
+    const int32_t smin = sm0.x;
+    const int bshift = sm0.y, ncell = sm0.z;
+    const int seg_a = sm1.x, rk = sm1.z, r0 = sm1.w;
+    // slice k = sorted rows [r0, r0 + rk): ends / prefix maxima / starts / build rows / bins -> LDS
+    for (int i = tid * 4; i < rk; i += CS_THREADS * 4) {
+        if (i + 4 <= rk && ((r0 & 3) == 0)) {
+            *reinterpret_cast<int4*>(l_start + i) = *reinterpret_cast<const int4*>(A.b_start + r0 + i);
+            *reinterpret_cast<int4*>(l_row + i) = *reinterpret_cast<const int4*>(A.b_row + r0 + i);
+            const int4 e01 = *reinterpret_cast<const int4*>(A.ep + r0 + i);
+            const int4 e23 = *reinterpret_cast<const int4*>(A.ep + r0 + i + 2);
+            *reinterpret_cast<int4*>(l_end + i) = make_int4(e01.x, e01.z, e23.x, e23.z);
+            l_pmx[i + 1] = e01.y; l_pmx[i + 2] = e01.w; l_pmx[i + 3] = e23.y; l_pmx[i + 4] = e23.w;
+        } else {
+            for (int j = i; j < rk && j < i + 4; ++j) {
+                l_start[j] = A.b_start[r0 + j]; l_row[j] = A.b_row[r0 + j];
+                const int2 e = A.ep[r0 + j];
+                l_end[j] = e.x; l_pmx[j + 1] = e.y;
+            }
+        }
+    }
+    if (tid < 4) l_start[rk + tid] = INT32_MAX;
+    if (tid < 16) l_end[rk + tid] = INT32_MIN;
+    if (tid == 0) l_pmx[0] = sm0.w;
+    {
+        const unsigned short* gb = A.bins + (size_t)k * (size_t)(2 * A.R + CS_BIN_STRIDE_PAD);
+        // 2 R + 2 entries per slice: the stride is even, so pairs of bins are 4-byte aligned
+        const uint32_t* gb32 = reinterpret_cast<const uint32_t*>(gb);
+        uint32_t* lb32 = reinterpret_cast<uint32_t*>(l_bin);
+        for (int i = tid; i < (ncell + 2) / 2; i += CS_THREADS) lb32[i] = gb32[i];
+    }
+    if (tid < 4) lc[tid] = 0;
+    if (tid < 8) li[tid] = (tid == 7) ? 1 : 0;                                 // block 1 serves tile 1 first (seq = li[1][3])
+    __syncthreads();
+
+    uint32_t* stw = l_stage + wv * A.wcap;                                     // this wavefront's staging entries
+    int32_t* qrw = l_qrow + wv * CS_WTILE;                                     // this wavefront's probe rows of the tile
+    auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto stv = [](int* p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+
+    // records of the tile: wavefront wv owns the contiguous probes [wv * 256, (wv + 1) * 256), item j of lane l = wv * 256 + j * 64 + l
+    cs_rec nxt[CS_ITEMS];
+    auto load_tile = [&](int64_t tb) {
+        const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
+        const int32_t* tp = A.rec + 3 * tb;                                    // uniform
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const int il = wv * CS_WTILE + j * kWave + lane;
+            if (il < rem) nxt[j] = __builtin_nontemporal_load(reinterpret_cast<const cs_rec*>(tp + 3 * il));
+            else { nxt[j].x = 0; nxt[j].y = 0; nxt[j].z = -1; }
+        }
+    };
+    // per-probe state of the tile whose matches are known but not yet emitted
+    int32_t qs[CS_ITEMS], qrow[CS_ITEMS];
+    int al[CS_ITEMS], hi[CS_ITEMS];                                            // slice-local: first examined row, hi-bound
+    uint32_t mask[CS_ITEMS];                                                   // bit t <=> row al + t matches
+    int cnt[CS_ITEMS];
+    bool lng[CS_ITEMS];
+    bool any_lng = false;
+
+    auto match_tile = [&](int64_t tb) {
+        int32_t qe[CS_ITEMS];
+        bool valid[CS_ITEMS];
+        const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            qs[j] = nxt[j].x; qe[j] = nxt[j].y; qrow[j] = nxt[j].z;
+            valid[j] = wv * CS_WTILE + j * kWave + lane < rem;
+        }
+        if (tb + CS_TILE < q1) load_tile(tb + CS_TILE);                        // next tile's records in flight
+        // hi-bound: bin of the end, then the (at most four) rows of the bin that start below it.  Rows before the bin's first
+        // row start below the bin's lower edge <= end; rows of later bins start above the end: no range checks needed.
+        int first[CS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            uint32_t cl = ((uint32_t)qe[j] - (uint32_t)smin) >> bshift;
+            cl = cl < (uint32_t)(ncell - 1) ? cl : (uint32_t)(ncell - 1);
+            first[j] = l_bin[cl];
+        }
+        int32_t s4[CS_ITEMS][4];
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const int32_t* sp = l_start + first[j];
+            s4[j][0] = sp[0]; s4[j][1] = sp[1]; s4[j][2] = sp[2]; s4[j][3] = sp[3];
+        }
+        unsigned long long more = 0;
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            unsigned long long m4;
+            hi[j] = cs_count4<STRICT>(first[j], s4[j][0], s4[j][1], s4[j][2], s4[j][3], qe[j], &m4);
+            more |= m4;
+        }
+        if (__builtin_expect(more != 0, 0)) {                                  // uniform: some probe may have more than four rows of its bin below its end
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                if (valid[j] && hi[j] == first[j] + 4) {
+                    uint32_t cl = ((uint32_t)qe[j] - (uint32_t)smin) >> bshift;
+                    cl = cl < (uint32_t)(ncell - 1) ? cl : (uint32_t)(ncell - 1);
+                    int lo = hi[j], hh = l_bin[cl + 1];                        // first row of [hi, rend) that does not start below the end
+                    while (lo < hh) { const int mid = (lo + hh) >> 1; if (lt_op<STRICT>(l_start[mid], qe[j])) lo = mid + 1; else hh = mid; }
+                    hi[j] = lo;
+                }
+            }
+        }
+        // window below hi, branch-free: sixteen ends from the 16-byte aligned row at or below hi - CS_WIN (never below row 0);
+        // bit t <=> row al + t, rows at or above hi are cut off.  One prefix-max read of the row below the examined ones
+        // (l_pmx[0] = the row below the slice, INT32_MIN when the contig starts here) tells whether the window runs on: those
+        // probes are redone exactly.
+        unsigned long long lmask = 0;
+#pragma unroll
+        for (int jj = 0; jj < CS_ITEMS; jj += 2) {
+            int4 w[2][4];
+            int32_t pm[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = jj + u;
+                const int h = hi[j] < rk ? hi[j] : rk;
+                hi[j] = h;
+                int a0 = (h - CS_WIN) & ~3;
+                a0 = a0 > 0 ? a0 : 0;
+                al[j] = a0;
+                const int4* p4 = reinterpret_cast<const int4*>(l_end + a0);
+                w[u][0] = p4[0]; w[u][1] = p4[1]; w[u][2] = p4[2]; w[u][3] = p4[3];
+                pm[u] = l_pmx[a0];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = jj + u;
+                uint32_t m = cs_window_mask<STRICT>(qs[j], w[u][0], w[u][1], w[u][2], w[u][3]);
+                m = __builtin_amdgcn_ubfe(m, 0u, (uint32_t)(hi[j] - al[j]));    // rows al .. hi - 1
+                lng[j] = valid[j] && lt_op<STRICT>(qs[j], pm[u]);
+                mask[j] = valid[j] ? m : 0u;
+                cnt[j] = __popc(mask[j]);
+                lmask |= __ballot(lng[j]);
+            }
+        }
+        any_lng = lmask != 0;
+        if (any_lng) {
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                if (lng[j]) {
+                    int c2 = 0;
+                    for (int p = r0 + hi[j] - 1; p >= seg_a; --p) {
+                        const int i = p - r0;
+                        int2 vv = make_int2(l_end[i < 0 ? 0 : i], l_pmx[i < 0 ? 1 : i + 1]);
+                        if (i < 0) vv = A.ep[p];
+                        if (!lt_op<STRICT>(qs[j], vv.y)) break;
+                        c2 += lt_op<STRICT>(qs[j], vv.x) ? 1 : 0;
+                    }
+                    cnt[j] = c2;
+                }
+            }
+        }
+    };
+
+    // Barrier-free tile loop (protocol of slice.hip.h's fused mode): a wavefront's pairs of a tile are contiguous in the
+    // tile's output range at the offset a returning LDS atomic on the tile's cursor gives it; the LAST wavefront to arrive
+    // reserves the range with the one global atomic and publishes the base in LDS; the others look at it one iteration later.
+    load_tile(q0);
+    const int ntile = (int)((q1 - q0 + CS_TILE - 1) / CS_TILE);
+    int pend_wtot = -1;                                                        // this wavefront's staged pairs of the previous tile
+    long long pend_woff = 0;
+    for (int tix = 0; tix <= ntile; ++tix) {
+        if (tix < ntile) match_tile(q0 + (int64_t)tix * CS_TILE);
+        if (tix > 0) {
+            // finish tile tix - 1: its base was requested one iteration ago
+            __builtin_amdgcn_wave_barrier();
+            int* c = li + ((tix - 1) & 1) * 4;
+            unsigned long long* c64 = lc + ((tix - 1) & 1) * 2;
+            for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
+            const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
+                int32_t* op = A.out_probe + tb + pend_woff;
+                int32_t* ob = A.out_build + tb + pend_woff;
+#pragma unroll 4
+                for (int i = lane; i < pend_wtot; i += kWave) {
+                    const uint32_t e = stw[i];
+                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                }
+            }
+            if (lane == 0) {
+                if (atomicAdd(c + 1, 1) == CS_WAVES - 1) {                     // last wavefront out: recycle the block for tile tix + 1
+                    __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    stv(c + 0, 0); stv(c + 1, 0); stv(c + 2, 0);
+                    stv(c + 3, tix + 1);
+                }
+            }
+        }
+        if (tix == ntile) break;
+        int* c = li + (tix & 1) * 4;
+        unsigned long long* c64 = lc + (tix & 1) * 2;
+        for (int spin = 0; ld(c + 3) != tix && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // the block is ours (recycled after tile tix - 2)
+        int lsum = 0;
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) lsum += cnt[j];
+        const int linc = wave_incl_sum_dpp(lsum);
+        const int wtot = __builtin_amdgcn_readlane(linc, kWave - 1);
+        long long woff = 0;
+        if (lane == 0) {
+            woff = (long long)atomicAdd(c64, (unsigned long long)wtot);
+            if (atomicAdd(c + 0, 1) == CS_WAVES - 1) {                         // last wavefront in: the tile's total is complete
+                const long long total = (long long)__hip_atomic_load(c64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                long long base = 0;
+                if (total > 0) {
+                    base = (long long)atomicAdd(&A.state[0], (unsigned long long)total);
+                    if (base + total > A.capacity) { atomicExch(&A.state[1], 1ull); base = -1; }
+                }
+                __hip_atomic_store(c64 + 1, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                stv(c + 2, 1);
+            }
+        }
+        woff = ((long long)__builtin_amdgcn_readfirstlane((int)(woff >> 32)) << 32) | (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(woff & 0xffffffffll));
+        if (wtot > 0 && wtot <= A.wcap && !any_lng) {
+            // usual case: entries {wave-local probe slot << 16 | slice-local row} into the wavefront's staging region
+            int off = linc - lsum;
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                qrw[j * kWave + lane] = qrow[j];
+                uint32_t m = mask[j];
+                uint32_t ent = ((uint32_t)(j * kWave + lane) << 16) | (uint32_t)al[j];
+                int o = off;
+                while (m) {
+                    const int t = __builtin_ctz(m);
+                    m &= m - 1;
+                    stw[o] = ent + (uint32_t)t;
+                    ++o;
+                }
+                off += cnt[j];
+            }
+            pend_wtot = wtot;
+        } else if (wtot > 0) {
+            // dense wavefront or windows running on below the examined rows: wait for the base now, write from the lanes
+            for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
+            const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tb >= 0) {
+                long long off = tb + woff + (linc - lsum);
+#pragma unroll
+                for (int j = 0; j < CS_ITEMS; ++j) {
+                    if (!lng[j]) {
+                        uint32_t m = mask[j];
+                        long long o = off;
+                        while (m) {
+                            const int t = __builtin_ctz(m);
+                            m &= m - 1;
+                            A.out_probe[o] = qrow[j]; A.out_build[o] = l_row[al[j] + t];
+                            ++o;
+                        }
+                    } else {
+                        long long o = off + cnt[j] - 1;                        // the f-th match from the top of the window owns slot end - 1 - f
+                        for (int p = r0 + hi[j] - 1; o >= off; --p) {
+                            const int i = p - r0;
+                            int32_t ev = l_end[i < 0 ? 0 : i];
+                            if (i < 0) ev = A.ep[p].x;
+                            if (lt_op<STRICT>(qs[j], ev)) {
+                                int32_t rv = l_row[i < 0 ? 0 : i];
+                                if (i < 0) rv = A.b_row[p];
+                                A.out_probe[o] = qrow[j]; A.out_build[o] = rv; --o;
+                            }
+                        }
+                    }
+                    off += cnt[j];
+                }
+            }
+            pend_wtot = 0;
+        } else pend_wtot = 0;
+        pend_woff = woff;
+    }
+}
+
+}  // namespace ivj

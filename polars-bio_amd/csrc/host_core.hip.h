@@ -90,6 +90,8 @@ struct ivj_ctx {
     int env_joint_bins = 0, env_count_nolds = 0, env_count_ablate = 0;     // IVJ_JOINT_BINS (1|2), IVJ_COUNT_NOLDS: tuning knobs of count_overlaps
     int sl_env_rows = 0, sl_env_chunk = 0, sl_env_notab = 0, sl_env_nobins = 0, sl_env_ablate = 0, sl_env_auto = 1, sl_env_stable = 0, sl_env_sthreads = 1024;   // IVJ_SLICE_ROWS / IVJ_SLICE_CHUNK: tuning knobs used when the opts fields are 0
     SlicePlan sl_plan;
+    bool cs_attr_set = false;          // contig-aligned slice path (cslice.hip.h): LDS attributes set once
+    int cs_env_off = 0;                // IVJ_CS=0: keep the round-2 slice kernels (A/B runs)
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
     bool t_open = false;
@@ -137,6 +139,15 @@ struct ivj_index {
     int sl_R = 0, sl_nb = 0, sl_ncells = -1;   //   geometry the splitters were made for (0: none yet)
     int4* sl_cm = nullptr;               //   direct-address table over the splitters: per-contig grid, cells
     uint32_t* sl_cell = nullptr;
+    // contig-aligned slice path (cslice.hip.h): geometry fixed at build time, arrays in the slab, filled on first use
+    CsGeom cs_g{0, 0, 0, 0, 0};
+    bool cs_ok = false, cs_built = false;
+    int32_t* cs_bound = nullptr;
+    unsigned long long* cs_spl = nullptr;
+    int4* cs_cm = nullptr;
+    uint32_t* cs_cell = nullptr;
+    unsigned short* cs_bins = nullptr;
+    int4* cs_smeta = nullptr;
     bool tables_built = false;   // the direct-address tables exist (built on first use)
     bool has_tables = true;    // false: built for merge / cluster only (with_end_order & 2)     // rec4 is filled on demand (join + materialisation path, flat path)
     char* slab = nullptr;      // single allocation holding every array above
@@ -183,7 +194,7 @@ bool is_probe_kernel(const char* name) {
     return !std::strncmp(name, "overlap_", 8) || !std::strncmp(name, "count_overlaps", 14) || !std::strncmp(name, "nearest", 7) ||
            !std::strncmp(name, "materialize", 11) || !std::strncmp(name, "take", 4) || !std::strncmp(name, "coverage", 8) ||
            !std::strncmp(name, "subtract_", 9) || !std::strncmp(name, "cluster_", 8) || !std::strncmp(name, "part_scatter", 12) ||
-           !std::strncmp(name, "slice_", 6);
+           !std::strncmp(name, "slice_", 6) || !std::strncmp(name, "cs_", 3);
 }
 void t_begin(ivj_ctx* ctx, const char* name) {
     ctx->t_open = false;

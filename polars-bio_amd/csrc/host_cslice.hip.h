@@ -1,0 +1,150 @@
+// host_cslice.hip.h -- driver of the contig-aligned slice path (cslice.hip.h): geometry, per-index tables, partition, fused join
+// Part of the single translation unit ivjoin.hip (included there, in this order); not a stand-alone header.
+#pragma once
+
+namespace {
+
+// Geometry for an index of n rows over nc contigs; false when the path does not apply (the callers keep slice.hip.h /
+// the 256-bucket kernels).  Known on the host without looking at the data: the bucket SLOTS are an upper bound on the
+// slices (sum over contigs of ceil(n_c / R) <= n / R + min(nc, n)).
+bool cs_geom(int64_t n, int nc, int want_rows, CsGeom& g) {
+    if (n <= 0 || nc < 1 || nc > CS_MAX_CONTIGS) return false;
+    const int64_t extra = (nc < n ? nc : n) + 1;
+    int64_t R = want_rows > 0 ? want_rows : (n + 1023) / 1024;
+    R = (R + 63) / 64 * 64;
+    if (n / R + extra > SL_MAX_BUCKETS) {
+        if (extra + 8 >= SL_MAX_BUCKETS) return false;
+        R = ((n + (SL_MAX_BUCKETS - extra) - 1) / (SL_MAX_BUCKETS - extra) + 63) / 64 * 64;
+    }
+    if (R > SL_MAX_ROWS) return false;
+    g.R = (int)R;
+    g.nb = (int)(n / R + extra);
+    g.n_contigs = nc;
+    g.cps = 0; g.ncells = 0;
+    for (int cps = 4; cps >= 1 && !g.ncells; cps >>= 1) {
+        const int cells = cps * g.nb + 2 * nc;
+        if ((size_t)cs_part_lds(g.nb, cells).total <= 160 * 1024) { g.ncells = cells; g.cps = cps; }
+    }
+    return g.ncells != 0;
+}
+
+// bytes of the per-index arrays of this path (part of the index slab)
+size_t cs_index_bytes(const CsGeom& g) {
+    return align_up((size_t)(g.nb + 2) * 4) + align_up((size_t)g.nb * 8) + align_up((size_t)CS_MAX_CONTIGS * 16) + align_up((size_t)g.ncells * 4) +
+           align_up((size_t)g.nb * (size_t)(2 * g.R + CS_BIN_STRIDE_PAD) * 2) + align_up((size_t)g.nb * 32);
+}
+void cs_index_carve(ivj_index* ix, char* p) {
+    const CsGeom& g = ix->cs_g;
+    ix->cs_bound = (int32_t*)p; p += align_up((size_t)(g.nb + 2) * 4);
+    ix->cs_spl = (unsigned long long*)p; p += align_up((size_t)g.nb * 8);
+    ix->cs_cm = (int4*)p; p += align_up((size_t)CS_MAX_CONTIGS * 16);
+    ix->cs_cell = (uint32_t*)p; p += align_up((size_t)g.ncells * 4);
+    ix->cs_bins = (unsigned short*)p; p += align_up((size_t)g.nb * (size_t)(2 * g.R + CS_BIN_STRIDE_PAD) * 2);
+    ix->cs_smeta = (int4*)p;
+}
+
+// The path serves the FUSED single pass wherever the slice path is wanted (host_slice.hip.h::want_slices) and the index has
+// its arrays; IVJ_CS=0 switches it off (A/B runs against slice.hip.h).
+bool cs_wanted(const ivj_ctx* ctx, const ivj_index* ix, const ivj_opts* opts) {
+    if (!ix->cs_ok || ctx->cs_env_off) return false;
+    // a caller that pins the rows per slice gets the geometry it asked for
+    if (opts->slice_rows > 0 && ((opts->slice_rows + 63) / 64 * 64) != ix->cs_g.R) return false;
+    return true;
+}
+
+int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix) {
+    if (ix->cs_built) return IVJ_OK;
+    const CsGeom& g = ix->cs_g;
+    LAUNCH(ctx, "cs_prep", k_cs_prep, 1, CS_THREADS, (const int32_t*)ix->seg, (const int32_t*)ix->b_start, g, ix->cs_bound, ix->cs_spl, ix->cs_cm, ix->cs_cell);
+    const size_t lds = (size_t)4 * g.R + (size_t)2 * (2 * g.R + 8);
+    t_begin(ctx, "cs_bins");
+    hipLaunchKernelGGL(k_cs_bins, dim3(g.nb), dim3(CS_THREADS), lds, ctx->stream, (const int32_t*)ix->cs_bound, (const int32_t*)ix->b_start, (const int2*)ix->ep,
+                       (const int32_t*)ix->b_contig, (const int32_t*)ix->seg, g.R, ix->cs_bins, ix->cs_smeta);
+    t_end(ctx);
+    HIP_TRY(hipGetLastError());
+    ix->cs_built = true;
+    return IVJ_OK;
+}
+
+int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* opts, SlicePlan& P, int& wcap) {
+    const CsGeom& g = ix->cs_g;
+    P.g.nb = g.nb; P.g.R = g.R; P.g.ncells = g.ncells; P.g.cps = g.cps;
+    int64_t chunk = ((n + 2047) / 2048 + CS_TILE - 1) / CS_TILE * CS_TILE;
+    if (chunk < CS_TILE) chunk = CS_TILE;
+    if (chunk > 16 * CS_TILE) chunk = 16 * CS_TILE;
+    P.chunk = (int)chunk;
+    P.nchunks = (int)((n + chunk - 1) / chunk);
+    P.items = CS_ITEMS;
+    const int want_chunk = opts->slice_chunk > 0 ? opts->slice_chunk : ctx->sl_env_chunk;
+    int64_t jchunk = want_chunk > 0 ? ((int64_t)want_chunk + CS_TILE - 1) / CS_TILE * CS_TILE
+                                    : (n >= (32ll << 20) ? 4 * CS_TILE : (n >= (8ll << 20) ? 2 * CS_TILE : CS_TILE));
+    if (jchunk > 64 * CS_TILE) jchunk = 64 * CS_TILE;
+    P.jchunk = (int)jchunk;
+    P.gmax = (int)(g.nb + (n + jchunk - 1) / jchunk);
+    P.tiles_per_chunk = (int)(jchunk / CS_TILE);
+    P.ntiles = (int64_t)P.gmax * P.tiles_per_chunk;
+    P.part_lds = (size_t)cs_part_lds(g.nb, g.ncells).total;
+    const size_t lds_cap = 160 * 1024;
+    const size_t fixed = (size_t)cs_join_lds(g.R, 0).total;
+    if (fixed + 16 * 1024 > lds_cap || P.part_lds > lds_cap) return fail(IVJ_EINVAL, "slice geometry does not fit the LDS");
+    wcap = (int)((lds_cap - fixed) / (4 * CS_WAVES)) & ~3;
+    P.join_lds = (size_t)cs_join_lds(g.R, wcap).total;
+    return IVJ_OK;
+}
+
+int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
+                     int64_t capacity, int64_t* n_pairs) {
+    const int64_t n = probe->n;
+    const CsGeom& g = ix->cs_g;
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    SlicePlan P;
+    int wcap = 0;
+    IVJ_TRY(cs_plan(ctx, ix, n, opts, P, wcap));
+    IVJ_TRY(ensure_sl(ctx, n, P));
+    ctx->sl_plan_valid = false;
+    IVJ_TRY(cs_ensure_tables(ctx, ix));
+    const CsTab tab{ix->cs_spl, ix->cs_cm, ix->cs_cell};
+    const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end) && (!probe->row_id || aligned16(probe->row_id));
+    const size_t hist_lds = (size_t)16 * CS_MAX_CONTIGS + (size_t)8 * g.nb + (size_t)4 * g.ncells + 4 * (g.nb + 1);
+    const size_t hist = (size_t)(g.nb + 1) * (size_t)P.nchunks;
+    if (!ctx->cs_attr_set) {
+        IVJ_TRY(set_dyn_lds(&k_cs_hist<true>, 96 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_hist<false>, 96 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_scatter<true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter<false>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_join<true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false>, 160 * 1024));
+        ctx->cs_attr_set = true;
+    }
+    int32_t* rec = reinterpret_cast<int32_t*>(ctx->sl_rec);
+    t_begin(ctx, "cs_hist");
+    if (strict) hipLaunchKernelGGL((k_cs_hist<true>), dim3(P.nchunks), dim3(CS_THREADS), hist_lds, ctx->stream, tab, g, probe->contig, probe->end, n, P.chunk, P.nchunks, vec, ctx->sl_blk);
+    else hipLaunchKernelGGL((k_cs_hist<false>), dim3(P.nchunks), dim3(CS_THREADS), hist_lds, ctx->stream, tab, g, probe->contig, probe->end, n, P.chunk, P.nchunks, vec, ctx->sl_blk);
+    t_end(ctx);
+    IVJ_TRY((lb_scan_u32<SumOp, true>(ctx, "cs_scan", ctx->sl_blk, (int64_t)hist, 0u)));
+    LAUNCH(ctx, "cs_chunks", k_slice_chunks, 1, SL_THREADS, (const uint32_t*)ctx->sl_blk, P.nchunks, g.nb, n, P.jchunk, ctx->sl_bstart, ctx->sl_meta, ctx->sl_map);
+    t_begin(ctx, "cs_scatter");
+    if (strict) hipLaunchKernelGGL((k_cs_scatter<true>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, probe->end, probe->row_id, n,
+                                   P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, rec);
+    else hipLaunchKernelGGL((k_cs_scatter<false>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, probe->end, probe->row_id, n,
+                            P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, rec);
+    t_end(ctx);
+    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
+    CsJoinArgs A;
+    A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta;
+    A.rec = rec; A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
+    A.R = g.R; A.jchunk = P.jchunk; A.wcap = wcap; A.ablate = ctx->sl_env_ablate; A.capacity = (long long)capacity;
+    A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
+    A.out_probe = out_p; A.out_build = out_b;
+    const unsigned grid = 8u * (unsigned)((P.gmax + 7) / 8);
+    t_begin(ctx, "cs_join_fused");
+    if (strict) hipLaunchKernelGGL((k_cs_join<true>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
+    else hipLaunchKernelGGL((k_cs_join<false>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
+    t_end(ctx);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_meta + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    *n_pairs = ctx->h_total[0];
+    if (ctx->h_total[1] != 0)
+        return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");
+    return IVJ_OK;
+}
+
+}  // namespace

@@ -5,6 +5,10 @@
 namespace {
 
 int build_tables(ivj_ctx* ctx, ivj_index* ix);
+// contig-aligned slice path (host_cslice.hip.h): geometry and per-index arrays
+bool cs_geom(int64_t n, int nc, int want_rows, CsGeom& g);
+size_t cs_index_bytes(const CsGeom& g);
+void cs_index_carve(ivj_index* ix, char* p);
 
 // The direct-address tables (bins / brec over the starts) are built on first use: the slice path of pb.overlap never needs
 // them, the window-scan kernels, nearest, count_overlaps, coverage and subtract do.
@@ -258,7 +262,9 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t flat_bytes = align_up((nn + 1) * 16) + 3 * align_up((size_t)ix->bins_len * 4);   // rec4, lot, tab2 (filled on demand)
         const size_t spl_bytes = align_up((size_t)SL_MAX_BUCKETS * 8) + align_up((size_t)SL_TAB_CONTIGS * 16) +
                                  align_up((size_t)(4 * SL_MAX_BUCKETS + 2 * SL_TAB_CONTIGS) * 4);
-        const size_t need = spl_bytes + flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 32) + 2 * align_up((size_t)ix->bins_len * 4) +
+        ix->cs_ok = n > 0 && cs_geom(n, opts->n_contigs, opts->slice_rows > 0 ? opts->slice_rows : ctx->sl_env_rows, ix->cs_g);
+        const size_t cs_bytes = ix->cs_ok ? cs_index_bytes(ix->cs_g) : 0;
+        const size_t need = cs_bytes + spl_bytes + flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 32) + 2 * align_up((size_t)ix->bins_len * 4) +
                             3 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
@@ -296,7 +302,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->flags = (int32_t*)p; p += align_up(16);
         ix->cmeta = (int4*)p; p += align_up((nc + 1) * 32);
         ix->cmeta_e = (int4*)p; p += align_up((nc + 1) * 32);
-        ix->cmeta_j = (int4*)p;
+        ix->cmeta_j = (int4*)p; p += align_up((nc + 1) * 32);
+        if (ix->cs_ok) cs_index_carve(ix, p);
         // seg, flags and cmeta start zeroed: an empty index answers every probe with "no rows"
         hipError_t e = hipMemsetAsync(small_base, 0, small, ctx->stream);
         if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(index meta): ") + hipGetErrorString(e)));

@@ -177,7 +177,11 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         // sparse results of large inputs: LDS-resident index slices; dense ones (capacity says >= 16 pairs per probe) keep the flat kernel
         SliceGeom sg;
         const bool dense = opts->partition_mode == 0 && capacity >= 16 * n && ix->n_contigs > 0;
-        if (!dense && want_slices(ix, n, opts, sg, true)) return slice_overlap_fused(ctx, ix, probe, opts, sg, out_p, out_b, capacity, n_pairs);
+        if (!dense && want_slices(ix, n, opts, sg, true)) {
+            // contig-aligned slices + 12-byte records (round 3) where the dictionary allows, the round-2 slice kernels otherwise
+            if (cs_wanted(ctx, ix, opts)) return cs_overlap_fused(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
+            return slice_overlap_fused(ctx, ix, probe, opts, sg, out_p, out_b, capacity, n_pairs);
+        }
     }
     IVJ_TRY(need_tables(ctx, ix));
     const bool part = want_partition(ix, n, opts);

@@ -20,6 +20,7 @@
 
 #include "probe.hip.h"
 #include "slice.hip.h"
+#include "cslice.hip.h"
 #include "onesweep.hip.h"
 #include "scan.hip.h"
 
@@ -29,6 +30,7 @@ using namespace ivj;
 #include "host_mem.hip.h"
 #include "host_index.hip.h"
 #include "host_slice.hip.h"
+#include "host_cslice.hip.h"
 #include "host_join.hip.h"
 #include "host_sortscan.hip.h"
 #include "host_stream.hip.h"
@@ -70,6 +72,7 @@ int ivj_ctx_create(int device, ivj_ctx** out) {
     if (const char* ev = std::getenv("IVJ_SLICE_AUTO")) ctx->sl_env_auto = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_SLICE_STABLE")) ctx->sl_env_stable = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_SLICE_SCATTER_THREADS")) ctx->sl_env_sthreads = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_CS")) ctx->cs_env_off = std::atoi(ev) == 0 ? 1 : 0;
     if (const char* ev = std::getenv("IVJ_JOINT_BINS")) ctx->env_joint_bins = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_ABLATE")) ctx->env_count_ablate = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_NOLDS")) ctx->env_count_nolds = std::atoi(ev);
