@@ -310,32 +310,36 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_hist(CsTab tab, CsGeom g, con
 // planes: a 12-byte LDS store would need 16-byte alignment) at their bucket-sorted tile-local position, copied out as
 // contiguous bucket runs with 12-byte stores.  A thread loads FOUR consecutive probes of each column with one 16-byte load.
 struct CsPartLds { int cm, cell, spl, base, lstart, delta, cnt, rs, re, rr, d, wsum, total; };
-__host__ __device__ inline CsPartLds cs_part_lds(int nb, int ncells) {
+__host__ __device__ inline CsPartLds cs_part_lds(int nb, int ncells, int n_contigs, int items) {
+    const int tile = CS_THREADS * items;
     CsPartLds L;
     int o = 0;
-    L.cm = o; o += 16 * CS_MAX_CONTIGS;
+    L.cm = o; o += 16 * ((n_contigs + 3) & ~3);
     L.spl = o; o += 8 * nb;
     L.cell = o; o += 4 * ncells;
-    L.rs = (o + 15) & ~15; o = L.rs + 4 * CS_TILE;
-    L.re = o; o += 4 * CS_TILE;
-    L.rr = o; o += 4 * CS_TILE;
+    L.rs = (o + 15) & ~15; o = L.rs + 4 * tile;
+    L.re = o; o += 4 * tile;
+    L.rr = o; o += 4 * tile;
     L.base = o; o += 4 * (nb + 2);
     L.lstart = o; o += 4 * (nb + 2);
     L.delta = o; o += 4 * (nb + 2);
     L.cnt = o; o += 4 * (nb + 2);
-    L.d = (o + 3) & ~3; o = L.d + 2 * CS_TILE;
+    L.d = (o + 3) & ~3; o = L.d + 2 * tile;
     L.wsum = (o + 15) & ~15; o = L.wsum + 4 * 2 * CS_WAVES;
     L.total = o;
     return L;
 }
 
-template <bool STRICT>
+// PITEMS probes per thread: tiles of 4096 (4) or 8192 (8) probes.  The record stores are what the scatter pays for (0.50 ms
+// of 1.04 for config 3: ~25 M bucket runs of 48 bytes each); a tile twice as large makes every run twice as long.
+template <bool STRICT, int PITEMS>
 __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
                                                           const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
                                                           int chunk, int nchunks, bool vec_ok, const uint32_t* __restrict__ blk_off,
-                                                          int32_t* __restrict__ out /* 3 int32 per record */) {
+                                                          int32_t* __restrict__ out /* 3 int32 per record */, int ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
-    const CsPartLds L = cs_part_lds(g.nb, g.ncells);
+    constexpr int TILE = CS_THREADS * PITEMS;
+    const CsPartLds L = cs_part_lds(g.nb, g.ncells, g.n_contigs, PITEMS);
     unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(cs_lds + L.spl);
     int4* l_cm = reinterpret_cast<int4*>(cs_lds + L.cm);
     uint32_t* l_cell = reinterpret_cast<uint32_t*>(cs_lds + L.cell);
@@ -355,31 +359,37 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
     __syncthreads();
     const int64_t cbase = (int64_t)blockIdx.x * chunk;
     const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
-    int32_t nc[CS_ITEMS], ns[CS_ITEMS], ne[CS_ITEMS], nr[CS_ITEMS];
+    // thread t holds the probes t * 4 .. t * 4 + 3 of every 4096-probe half of the tile (16-byte column loads)
+    int32_t nc[PITEMS], ns[PITEMS], ne[PITEMS], nr[PITEMS];
     auto load_tile = [&](int64_t tbase) {
-        const int64_t i0 = tbase + (int64_t)tid * CS_ITEMS;
-        load_items_nt(pc, i0, cend, vec_ok, -1, nc);
-        load_items_nt(ps, i0, cend, vec_ok, 0, ns);
-        load_items_nt(pe, i0, cend, vec_ok, 0, ne);
-        if (row_id) load_items_nt(row_id, i0, cend, vec_ok, -1, nr);
-        else {
 #pragma unroll
-            for (int j = 0; j < CS_ITEMS; ++j) nr[j] = (int32_t)(i0 + j);
+        for (int h = 0; h < PITEMS / 4; ++h) {
+            const int64_t i0 = tbase + (int64_t)h * (CS_THREADS * 4) + (int64_t)tid * 4;
+            load_items_nt(pc, i0, cend, vec_ok, -1, *reinterpret_cast<int32_t(*)[4]>(nc + 4 * h));
+            load_items_nt(ps, i0, cend, vec_ok, 0, *reinterpret_cast<int32_t(*)[4]>(ns + 4 * h));
+            load_items_nt(pe, i0, cend, vec_ok, 0, *reinterpret_cast<int32_t(*)[4]>(ne + 4 * h));
+            if (row_id) load_items_nt(row_id, i0, cend, vec_ok, -1, *reinterpret_cast<int32_t(*)[4]>(nr + 4 * h));
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nr[4 * h + j] = (int32_t)(i0 + j);
+            }
         }
     };
     load_tile(cbase);
     int tix = 0;
-    for (int64_t tbase = cbase; tbase < cend; tbase += CS_TILE, ++tix) {
-        int32_t c[CS_ITEMS], s[CS_ITEMS], e[CS_ITEMS], r[CS_ITEMS];
+    for (int64_t tbase = cbase; tbase < cend; tbase += TILE, ++tix) {
+        int32_t c[PITEMS], s[PITEMS], e[PITEMS], r[PITEMS];
 #pragma unroll
-        for (int j = 0; j < CS_ITEMS; ++j) { c[j] = nc[j]; s[j] = ns[j]; e[j] = ne[j]; r[j] = nr[j]; }
-        if (tbase + CS_TILE < cend) load_tile(tbase + CS_TILE);                // next tile's columns in flight during this one
-        const int tile_n = (int)((cend - tbase) < (int64_t)CS_TILE ? (cend - tbase) : (int64_t)CS_TILE);
-        uint32_t d[CS_ITEMS], rank[CS_ITEMS];
+        for (int j = 0; j < PITEMS; ++j) { c[j] = nc[j]; s[j] = ns[j]; e[j] = ne[j]; r[j] = nr[j]; }
+        if (tbase + TILE < cend) load_tile(tbase + TILE);                      // next tile's columns in flight during this one
+        const int tile_n = (int)((cend - tbase) < (int64_t)TILE ? (cend - tbase) : (int64_t)TILE);
+        uint32_t d[PITEMS], rank[PITEMS];
 #pragma unroll
-        for (int j = 0; j < CS_ITEMS; ++j) {
-            const bool valid = tid * CS_ITEMS + j < tile_n;
-            d[j] = !valid ? 0u : cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, c[j], e[j]);
+        for (int j = 0; j < PITEMS; ++j) {
+            const bool valid = (j / 4) * (CS_THREADS * 4) + tid * 4 + (j & 3) < tile_n;
+            // (profiling only, IVJ_SLICE_ABLATE: 256 no record stores, 1024 hashed bucket ids instead of the table lookup; results are wrong)
+            if (ablate & 1024) d[j] = !valid ? 0u : (uint32_t)(((uint32_t)e[j] * 2654435761u) >> 12) % (uint32_t)g.nb;
+            else d[j] = !valid ? 0u : cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, c[j], e[j]);
             rank[j] = valid ? atomicAdd(&cnt[d[j]], 1u) : 0u;
         }
         __syncthreads();                                                        // (A) bucket counts of the tile complete
@@ -404,8 +414,8 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
         }
         __syncthreads();                                                        // (C)
 #pragma unroll
-        for (int j = 0; j < CS_ITEMS; ++j) {
-            if (tid * CS_ITEMS + j < tile_n) {
+        for (int j = 0; j < PITEMS; ++j) {
+            if ((j / 4) * (CS_THREADS * 4) + tid * 4 + (j & 3) < tile_n) {
                 const uint32_t pos = lstart[d[j]] + rank[j];
                 l_rs[pos] = s[j]; l_re[pos] = e[j]; l_rr[pos] = r[j];
                 l_d[pos] = (unsigned short)d[j];
@@ -413,9 +423,9 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
         }
         __syncthreads();                                                        // (D) tile sorted in LDS
 #pragma unroll
-        for (int j = 0; j < CS_ITEMS; ++j) {
+        for (int j = 0; j < PITEMS; ++j) {
             const int il = j * CS_THREADS + tid;
-            if (il < tile_n) {
+            if (il < tile_n && !(ablate & 256)) {
                 cs_rec v; v.x = l_rs[il]; v.y = l_re[il]; v.z = l_rr[il];
                 *reinterpret_cast<cs_rec*>(out + 3 * (int64_t)((uint32_t)il + delta[l_d[il]])) = v;
             }
@@ -493,16 +503,19 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     const int bshift = sm0.y, ncell = sm0.z;
     const int seg_a = sm1.x, rk = sm1.z, r0 = sm1.w;
     // slice k = sorted rows [r0, r0 + rk): ends / prefix maxima / starts / build rows / bins -> LDS
+    typedef int v4u __attribute__((ext_vector_type(4), aligned(4)));             // 16-byte global loads at any 4-byte aligned row
     for (int i = tid * 4; i < rk; i += CS_THREADS * 4) {
-        if (i + 4 <= rk && ((r0 & 3) == 0)) {
-            *reinterpret_cast<int4*>(l_start + i) = *reinterpret_cast<const int4*>(A.b_start + r0 + i);
-            *reinterpret_cast<int4*>(l_row + i) = *reinterpret_cast<const int4*>(A.b_row + r0 + i);
-            const int4 e01 = *reinterpret_cast<const int4*>(A.ep + r0 + i);
-            const int4 e23 = *reinterpret_cast<const int4*>(A.ep + r0 + i + 2);
+        if (i + 4 <= rk) {
+            const v4u s4 = *reinterpret_cast<const v4u*>(A.b_start + r0 + i);
+            const v4u r4 = *reinterpret_cast<const v4u*>(A.b_row + r0 + i);
+            const v4u e01 = *reinterpret_cast<const v4u*>(reinterpret_cast<const int32_t*>(A.ep + r0 + i));
+            const v4u e23 = *reinterpret_cast<const v4u*>(reinterpret_cast<const int32_t*>(A.ep + r0 + i + 2));
+            *reinterpret_cast<int4*>(l_start + i) = make_int4(s4.x, s4.y, s4.z, s4.w);
+            *reinterpret_cast<int4*>(l_row + i) = make_int4(r4.x, r4.y, r4.z, r4.w);
             *reinterpret_cast<int4*>(l_end + i) = make_int4(e01.x, e01.z, e23.x, e23.z);
             l_pmx[i + 1] = e01.y; l_pmx[i + 2] = e01.w; l_pmx[i + 3] = e23.y; l_pmx[i + 4] = e23.w;
         } else {
-            for (int j = i; j < rk && j < i + 4; ++j) {
+            for (int j = i; j < rk; ++j) {
                 l_start[j] = A.b_start[r0 + j]; l_row[j] = A.b_row[r0 + j];
                 const int2 e = A.ep[r0 + j];
                 l_end[j] = e.x; l_pmx[j + 1] = e.y;
@@ -709,12 +722,13 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
                 qrw[j * kWave + lane] = qrow[j];
                 uint32_t m = mask[j];
                 uint32_t ent = ((uint32_t)(j * kWave + lane) << 16) | (uint32_t)al[j];
-                int o = off;
-                while (m) {
+                uint32_t* so = stw + off;
+                while (m) {                                                    // two matches per trip: half the loop overhead
                     const int t = __builtin_ctz(m);
                     m &= m - 1;
-                    stw[o] = ent + (uint32_t)t;
-                    ++o;
+                    so[0] = ent + (uint32_t)t;
+                    if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
+                    so += 2;
                 }
                 off += cnt[j];
             }

@@ -41,7 +41,7 @@ struct SlicePlan {                     // slice path: launch geometry of one cal
     int jchunk = 0, gmax = 0;          // join: probes per workgroup, upper bound on the workgroups
     int tiles_per_chunk = 0;
     int64_t ntiles = 0;                // gmax * tiles_per_chunk
-    int stage = 0, lds_seg = 0, items = 4, use_bins = 1;
+    int stage = 0, lds_seg = 0, items = 4, use_bins = 1, part_items = 4;
     size_t part_lds = 0, join_lds = 0, join_lds_count = 0;
 };
 
@@ -92,6 +92,7 @@ struct ivj_ctx {
     SlicePlan sl_plan;
     bool cs_attr_set = false;          // contig-aligned slice path (cslice.hip.h): LDS attributes set once
     int cs_env_off = 0;                // IVJ_CS=0: keep the round-2 slice kernels (A/B runs)
+    int cs_env_ptile = 0;              // IVJ_CS_PTILE=4096: partition tiles of 4096 probes even where 8192 fit
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
     bool t_open = false;

@@ -23,7 +23,7 @@ bool cs_geom(int64_t n, int nc, int want_rows, CsGeom& g) {
     g.cps = 0; g.ncells = 0;
     for (int cps = 4; cps >= 1 && !g.ncells; cps >>= 1) {
         const int cells = cps * g.nb + 2 * nc;
-        if ((size_t)cs_part_lds(g.nb, cells).total <= 160 * 1024) { g.ncells = cells; g.cps = cps; }
+        if ((size_t)cs_part_lds(g.nb, cells, nc, 4).total <= 160 * 1024) { g.ncells = cells; g.cps = cps; }
     }
     return g.ncells != 0;
 }
@@ -69,8 +69,8 @@ int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix) {
 int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* opts, SlicePlan& P, int& wcap) {
     const CsGeom& g = ix->cs_g;
     P.g.nb = g.nb; P.g.R = g.R; P.g.ncells = g.ncells; P.g.cps = g.cps;
-    int64_t chunk = ((n + 2047) / 2048 + CS_TILE - 1) / CS_TILE * CS_TILE;
-    if (chunk < CS_TILE) chunk = CS_TILE;
+    int64_t chunk = ((n + 2047) / 2048 + 2 * CS_TILE - 1) / (2 * CS_TILE) * (2 * CS_TILE);     // whole tiles of either size
+    if (chunk < 2 * CS_TILE) chunk = 2 * CS_TILE;
     if (chunk > 16 * CS_TILE) chunk = 16 * CS_TILE;
     P.chunk = (int)chunk;
     P.nchunks = (int)((n + chunk - 1) / chunk);
@@ -83,7 +83,9 @@ int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* 
     P.gmax = (int)(g.nb + (n + jchunk - 1) / jchunk);
     P.tiles_per_chunk = (int)(jchunk / CS_TILE);
     P.ntiles = (int64_t)P.gmax * P.tiles_per_chunk;
-    P.part_lds = (size_t)cs_part_lds(g.nb, g.ncells).total;
+    // partition tiles of 8192 probes where the staging fits the LDS (IVJ_CS_PTILE=4096 pins the small tile: A/B runs)
+    P.part_items = ((size_t)cs_part_lds(g.nb, g.ncells, g.n_contigs, 8).total <= 160 * 1024 && ctx->cs_env_ptile != 4096 && n >= (1ll << 20)) ? 8 : 4;
+    P.part_lds = (size_t)cs_part_lds(g.nb, g.ncells, g.n_contigs, P.part_items).total;
     const size_t lds_cap = 160 * 1024;
     const size_t fixed = (size_t)cs_join_lds(g.R, 0).total;
     if (fixed + 16 * 1024 > lds_cap || P.part_lds > lds_cap) return fail(IVJ_EINVAL, "slice geometry does not fit the LDS");
@@ -109,7 +111,8 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     const size_t hist = (size_t)(g.nb + 1) * (size_t)P.nchunks;
     if (!ctx->cs_attr_set) {
         IVJ_TRY(set_dyn_lds(&k_cs_hist<true>, 96 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_hist<false>, 96 * 1024));
-        IVJ_TRY(set_dyn_lds(&k_cs_scatter<true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter<false>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_scatter<true, 4>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter<false, 4>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_scatter<true, 8>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter<false, 8>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join<true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false>, 160 * 1024));
         ctx->cs_attr_set = true;
     }
@@ -121,11 +124,14 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     IVJ_TRY((lb_scan_u32<SumOp, true>(ctx, "cs_scan", ctx->sl_blk, (int64_t)hist, 0u)));
     LAUNCH(ctx, "cs_chunks", k_slice_chunks, 1, SL_THREADS, (const uint32_t*)ctx->sl_blk, P.nchunks, g.nb, n, P.jchunk, ctx->sl_bstart, ctx->sl_meta, ctx->sl_map);
     t_begin(ctx, "cs_scatter");
-    if (strict) hipLaunchKernelGGL((k_cs_scatter<true>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, probe->end, probe->row_id, n,
-                                   P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, rec);
-    else hipLaunchKernelGGL((k_cs_scatter<false>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, probe->end, probe->row_id, n,
-                            P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, rec);
+#define IVJ_CS_SCATTER(S, I)                                                                                                            \
+    hipLaunchKernelGGL((k_cs_scatter<S, I>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, \
+                       probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, rec, ctx->sl_env_ablate)
+    if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER(true, 8); else IVJ_CS_SCATTER(true, 4); }
+    else { if (P.part_items == 8) IVJ_CS_SCATTER(false, 8); else IVJ_CS_SCATTER(false, 4); }
+#undef IVJ_CS_SCATTER
     t_end(ctx);
+    if (ctx->sl_env_ablate & (256 | 1024)) { *n_pairs = 0; HIP_TRY(hipStreamSynchronize(ctx->stream)); return IVJ_OK; }   // profiling: the records are not usable
     HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
     CsJoinArgs A;
     A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta;
