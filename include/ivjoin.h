@@ -350,6 +350,40 @@ int ivj_stream_submit(ivj_stream* st, const ivj_side* batch, ivj_stream_result* 
 int ivj_stream_flush(ivj_stream* st, ivj_stream_result* done);
 void ivj_stream_close(ivj_stream* st);
 
+/* ---- multi-GPU: one rank per GPU, contig sharding, all-gatherv of the result batches over RCCL (xGMI) ---------------- *
+ * Replaces the reference's only parallelism -- DataFusion target_partitions over probe rows (src/scan.rs:233-277,
+ * polars_bio/context.py:36) -- for a host that drives several GPUs: intervals on different contigs never interact
+ * (the reference builds one tree per contig, range_op.py:550), so every rank joins the rows of ITS contigs (global row
+ * ids in ivj_side.row_id) with no collective on the data path, and the variable-length results are exchanged with one
+ * ncclAllGather of the counts + ONE grouped batch of ncclSend / ncclRecv (every GPU pair on its own xGMI link).
+ * RCCL is loaded on first use (librccl.so.1); nothing here needs PyTorch.  A communicator of world 1 never touches RCCL. */
+typedef struct ivj_comm ivj_comm;
+#define IVJ_UNIQUE_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any channel the host has */
+int ivj_comm_unique_id(void* id_out);
+/* one process per GPU: ncclCommInitRank on the context's device (collective: every rank calls it) */
+int ivj_comm_create(ivj_ctx* ctx, const void* unique_id, int rank, int world, ivj_comm** out);
+/* one process, one context per device: ncclCommInitAll; out[i] = communicator of ctxs[i] (rank i).  Calls on the n
+ * communicators that belong together (ivj_allgather_counts, ivj_allgatherv_dev, ivj_overlap_allgather_dev) must then
+ * come from n host threads, one per rank. */
+int ivj_comm_create_local(ivj_ctx* const* ctxs, int n, ivj_comm** out);
+void ivj_comm_destroy(ivj_comm* comm);
+int ivj_comm_info(const ivj_comm* comm, int* rank, int* world);
+/* counts[r] = n_local of rank r, on every rank (host array of `world` entries) */
+int ivj_allgather_counts(ivj_comm* comm, int64_t n_local, int64_t* counts);
+/* all-gatherv of n_cols device columns of elem_bytes-wide elements: recv_cols[k] (capacity = sum of counts) receives
+ * the concatenation over ranks, in rank order, of every rank's send_cols[k][0 .. counts[rank]).  Ordered after the work
+ * queued on the context's stream; returns when the exchange is complete. */
+int ivj_allgatherv_dev(ivj_comm* comm, const void* const* send_cols, void* const* recv_cols, int n_cols, int elem_bytes,
+                       const int64_t* counts);
+/* pb.overlap of this rank's shard + the all-gatherv of the pairs, with the exchange OVERLAPPING the join: the rank's
+ * probe rows are cut into n_chunks contiguous chunks (the same number on every rank, 1 .. 64); while chunk i is joined
+ * (fused single pass) a helper thread exchanges chunk i - 1 straight into the caller's columns.  Every rank ends up with
+ * all *n_total pairs (layout: chunk after chunk, inside a chunk rank after rank; the pairs of one probe row contiguous);
+ * *n_local = this rank's share.  IVJ_ECAPACITY when capacity < *n_total (nothing is written past it). */
+int ivj_overlap_allgather_dev(ivj_comm* comm, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int n_chunks,
+                              int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_total, int64_t* n_local);
+
 /* ---- device memory helpers for callers without a HIP binding ------------ */
 int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out);
 int ivj_dev_free(ivj_ctx* ctx, void* p);

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
 
 #include "probe.hip.h"
 #include "slice.hip.h"
@@ -34,6 +35,7 @@ using namespace ivj;
 #include "host_join.hip.h"
 #include "host_sortscan.hip.h"
 #include "host_stream.hip.h"
+#include "host_comm.hip.h"
 
 // =============================================================================== C ABI
 
@@ -222,6 +224,109 @@ int ivj_overlap_fused_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev
     if (capacity < 0 || (capacity > 0 && (!probe_idx_dev || !build_idx_dev))) return fail(IVJ_EINVAL, "bad output buffers");
     DeviceGuard g(ctx->device);
     return overlap_fused(ctx, ix, probe_dev, opts, probe_idx_dev, build_idx_dev, capacity, n_pairs);
+}
+
+// ---- multi-GPU: communicator, all-gatherv, sharded overlap with the exchange overlapping the join (host_comm.hip.h) ----
+
+int ivj_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(IVJ_EINVAL, "id_out is NULL");
+    const RcclApi* api = rccl_api();
+    if (!api) return fail(IVJ_EHIP, g_rccl.error);
+    RcclUniqueId id;
+    RCCL_TRY(api, api->GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return IVJ_OK;
+}
+
+int ivj_comm_create(ivj_ctx* ctx, const void* unique_id, int rank, int world, ivj_comm** out) {
+    if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return fail(IVJ_EINVAL, "rank / world out of range");
+    if (world > 1 && !unique_id) return fail(IVJ_EINVAL, "unique_id is NULL");
+    DeviceGuard g(ctx->device);
+    ivj_comm* c = new ivj_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    if (world > 1) {
+        const RcclApi* api = rccl_api();
+        if (!api) { delete c; return fail(IVJ_EHIP, g_rccl.error); }
+        RcclUniqueId id;
+        std::memcpy(&id, unique_id, sizeof(id));
+        const int r = api->CommInitRank(&c->comm, world, id, rank);
+        if (r != 0) { delete c; return fail(IVJ_EHIP, std::string("ncclCommInitRank: ") + api->GetErrorString(r)); }
+    }
+    const int rc = comm_finish_create(c);
+    if (rc != IVJ_OK) { ivj_comm_destroy(c); return rc; }
+    *out = c;
+    return IVJ_OK;
+}
+
+int ivj_comm_create_local(ivj_ctx* const* ctxs, int n, ivj_comm** out) {
+    if (!ctxs || !out || n < 1) return fail(IVJ_EINVAL, "ctxs / out is NULL or n < 1");
+    std::vector<RcclComm> comms((size_t)n, nullptr);
+    if (n > 1) {
+        const RcclApi* api = rccl_api();
+        if (!api) return fail(IVJ_EHIP, g_rccl.error);
+        std::vector<int> devs((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            if (!ctxs[i]) return fail(IVJ_EINVAL, "a context is NULL");
+            devs[i] = ctxs[i]->device;
+            for (int j = 0; j < i; ++j) if (devs[j] == devs[i]) return fail(IVJ_EINVAL, "RCCL needs one device per rank: two contexts share device " + std::to_string(devs[i]));
+        }
+        RCCL_TRY(api, api->CommInitAll(comms.data(), n, devs.data()));
+    }
+    for (int i = 0; i < n; ++i) {
+        ivj_comm* c = new ivj_comm();
+        c->ctx = ctxs[i]; c->rank = i; c->world = n; c->comm = comms[i];
+        const int rc = comm_finish_create(c);
+        if (rc != IVJ_OK) { ivj_comm_destroy(c); for (int j = 0; j < i; ++j) { ivj_comm_destroy(out[j]); out[j] = nullptr; } return rc; }
+        out[i] = c;
+    }
+    return IVJ_OK;
+}
+
+void ivj_comm_destroy(ivj_comm* c) {
+    if (!c) return;
+    DeviceGuard g(c->ctx ? c->ctx->device : 0);
+    if (c->xstream) { (void)hipStreamSynchronize(c->xstream); }
+    if (c->comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
+    for (auto& b : c->stage) if (b) (void)hipFree(b);
+    if (c->iota) (void)hipFree(c->iota);
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    delete c;
+}
+
+int ivj_comm_info(const ivj_comm* c, int* rank, int* world) {
+    if (!c) return fail(IVJ_EINVAL, "comm is NULL");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return IVJ_OK;
+}
+
+int ivj_allgather_counts(ivj_comm* c, int64_t n_local, int64_t* counts) {
+    if (!c || !counts || n_local < 0) return fail(IVJ_EINVAL, "comm / counts is NULL or n_local < 0");
+    DeviceGuard g(c->ctx->device);
+    return comm_allgather_counts(c, n_local, counts);
+}
+
+int ivj_allgatherv_dev(ivj_comm* c, const void* const* send_cols, void* const* recv_cols, int n_cols, int elem_bytes, const int64_t* counts) {
+    if (!c || !send_cols || !recv_cols || !counts || n_cols < 1 || elem_bytes < 1) return fail(IVJ_EINVAL, "bad all-gatherv arguments");
+    DeviceGuard g(c->ctx->device);
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));                   // the payload is whatever the context's stream produced
+    IVJ_TRY(comm_exchange(c, send_cols, recv_cols, n_cols, elem_bytes, counts, 0));
+    HIP_TRY(hipStreamSynchronize(c->xstream));
+    return IVJ_OK;
+}
+
+int ivj_overlap_allgather_dev(ivj_comm* c, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int n_chunks,
+                              int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_total, int64_t* n_local) {
+    if (!c || !ix || !n_total) return fail(IVJ_EINVAL, "comm, index or n_total is NULL");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    if (n_chunks < 1 || n_chunks > 64) return fail(IVJ_EINVAL, "n_chunks must be in 1 .. 64");
+    if (capacity < 0 || (capacity > 0 && (!probe_idx_dev || !build_idx_dev))) return fail(IVJ_EINVAL, "bad output buffers");
+    DeviceGuard g(c->ctx->device);
+    return overlap_allgather(c, ix, probe_dev, opts, n_chunks, probe_idx_dev, build_idx_dev, capacity, n_total, n_local);
 }
 
 int ivj_overlap_fused_rows_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, const ivj_rows* rows_dev,

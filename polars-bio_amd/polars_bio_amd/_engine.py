@@ -34,6 +34,8 @@ ABI_SYMBOLS = [
     "ivj_merge", "ivj_merged_free", "ivj_cluster", "ivj_coverage", "ivj_cluster_dev", "ivj_merge_dev", "ivj_coverage_dev",
     "ivj_stream_open", "ivj_stream_submit", "ivj_stream_flush", "ivj_stream_close",
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
+    "ivj_comm_unique_id", "ivj_comm_create", "ivj_comm_create_local", "ivj_comm_destroy", "ivj_comm_info",
+    "ivj_allgather_counts", "ivj_allgatherv_dev", "ivj_overlap_allgather_dev",
 ]
 
 STREAM_OVERLAP, STREAM_COUNT, STREAM_NEAREST = 0, 1, 2
@@ -168,6 +170,15 @@ def load_library() -> C.CDLL:
         L.ivj_dev_free.argtypes = [vp, vp]
         L.ivj_memcpy_h2d.argtypes = [vp, vp, vp, C.c_int64]
         L.ivj_memcpy_d2h.argtypes = [vp, vp, vp, C.c_int64]
+        L.ivj_comm_unique_id.argtypes = [vp]
+        L.ivj_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+        L.ivj_comm_create_local.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+        L.ivj_comm_destroy.argtypes = [vp]
+        L.ivj_comm_destroy.restype = None
+        L.ivj_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ivj_allgather_counts.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64)]
+        L.ivj_allgatherv_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_int64)]
+        L.ivj_overlap_allgather_dev.argtypes = [vp, vp, P, O, C.c_int, vp, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _lib = L
         return L
 
@@ -725,6 +736,81 @@ class Engine:
     def d2h(self, arr: np.ndarray, src_ptr: int):
         assert arr.flags.c_contiguous
         _check(self.L, self.L.ivj_memcpy_d2h(self.h, arr.ctypes.data, C.c_void_p(src_ptr), arr.nbytes), "ivj_memcpy_d2h")
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: rank 0 makes it, every other rank receives the 128 bytes by whatever channel
+    the host has (a file, MPI, a torch.distributed object broadcast ...)."""
+    L = load_library()
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    _check(L, L.ivj_comm_unique_id(buf), "ivj_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the library (include/ivjoin.h, ivj_comm_*): one rank per GPU; the all-gatherv of result batches
+    and the sharded overlap with the exchange overlapping the join run inside libivjoin_hip.so, no PyTorch on the data path."""
+
+    def __init__(self, engine: Engine, unique_id: Optional[bytes], rank: int, world: int, _handle=None):
+        self.engine, self.rank, self.world = engine, rank, world
+        self.L = load_library()
+        if _handle is not None:
+            self.h = _handle
+            return
+        h = C.c_void_p()
+        idbuf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES) if unique_id is not None else None
+        _check(self.L, self.L.ivj_comm_create(engine.h, idbuf, int(rank), int(world), C.byref(h)), "ivj_comm_create")
+        self.h = h
+
+    @staticmethod
+    def create_local(engines):
+        """One process, one Engine per device: ncclCommInitAll.  Collective calls on the returned communicators must come
+        from one host thread per rank."""
+        L = load_library()
+        n = len(engines)
+        ctxs = (C.c_void_p * n)(*[e.h for e in engines])
+        out = (C.c_void_p * n)()
+        _check(L, L.ivj_comm_create_local(ctxs, n, out), "ivj_comm_create_local")
+        return [Comm(e, None, i, n, _handle=C.c_void_p(out[i])) for i, e in enumerate(engines)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ivj_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allgather_counts(self, n_local: int):
+        counts = (C.c_int64 * self.world)()
+        _check(self.L, self.L.ivj_allgather_counts(self.h, int(n_local), counts), "ivj_allgather_counts")
+        return [int(x) for x in counts]
+
+    def allgatherv_dev(self, send_ptrs, recv_ptrs, elem_bytes: int, counts):
+        n = len(send_ptrs)
+        sp = (C.c_void_p * n)(*[C.c_void_p(p) for p in send_ptrs])
+        rp = (C.c_void_p * n)(*[C.c_void_p(p) for p in recv_ptrs])
+        cn = (C.c_int64 * self.world)(*[int(x) for x in counts])
+        with self.engine.lock:
+            _check(self.L, self.L.ivj_allgatherv_dev(self.h, sp, rp, n, int(elem_bytes), cn), "ivj_allgatherv_dev")
+
+    def overlap_allgather_dev(self, ix: "DeviceIndex", probe: _Side, opts: _Opts, n_chunks: int, probe_idx_ptr: int, build_idx_ptr: int,
+                              capacity: int):
+        """-> (n_total, n_local, fits): this rank's shard joined and all-gathered, the exchange overlapping the join."""
+        nt, nl = C.c_int64(0), C.c_int64(0)
+        with self.engine.lock:
+            rc = self.L.ivj_overlap_allgather_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), int(n_chunks), C.c_void_p(probe_idx_ptr),
+                                                  C.c_void_p(build_idx_ptr), int(capacity), C.byref(nt), C.byref(nl))
+        if rc == -4:
+            return nt.value, nl.value, False
+        _check(self.L, rc, "ivj_overlap_allgather_dev")
+        return nt.value, nl.value, True
 
 
 _default_engine: Optional[Engine] = None

@@ -1,0 +1,165 @@
+"""Multi-GPU entry points of the C ABI (include/ivjoin.h: ivj_comm_*, ivj_allgatherv_dev, ivj_overlap_allgather_dev): the
+RCCL communicator lives inside libivjoin_hip.so, no PyTorch on the data path.
+
+A 1-GPU box can run a communicator of world 1 (chunked join + exchange thread + staging growth, everything but the peer
+transfers); the world-2 tests (one process with two contexts / two processes) run wherever two devices are visible.
+Replaces the reference's target_partitions parallelism (src/scan.rs:233-277) for a multi-GPU host.
+"""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from _util import random_side
+from oracle import oracle as O
+from polars_bio_amd import _engine, distributed as D, synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _Dev:
+    def __init__(self, eng, probe, build, probe_ids=None):
+        self.eng, self.ptrs = eng, []
+        self.probe = self._side(probe, probe_ids)
+        self.build = self._side(build, None)
+
+    def _side(self, side, ids):
+        n = len(side[0])
+        ps = []
+        for col in list(side) + ([ids] if ids is not None else []):
+            p = self.eng.dev_alloc(max(4 * n, 16))
+            self.eng.h2d(p, np.ascontiguousarray(col, np.int32))
+            ps.append(p)
+        self.ptrs += ps
+        return self.eng.dev_side(ps[0], ps[1], ps[2], n, ps[3] if ids is not None else 0)
+
+    def alloc(self, nbytes):
+        p = self.eng.dev_alloc(max(nbytes, 16))
+        self.ptrs.append(p)
+        return p
+
+    def close(self):
+        for p in self.ptrs:
+            self.eng.dev_free(p)
+
+
+def _canon(p, b):
+    o = np.lexsort((b, p))
+    return p[o], b[o]
+
+
+def test_world1_chunked_overlap_allgather_matches_oracle():
+    eng = _engine.Engine(0)
+    rng = np.random.default_rng(5)
+    probe = random_side(rng, 60000, 4, 300000, 300)
+    build = random_side(rng, 20000, 3, 300000, 300)
+    probe[0][:30000].sort()                                   # skew: the first chunks carry most pairs -> the staging has to grow
+    ep, eb = O.overlap_fast(O.Index(O.Side(*build), 3), O.Side(*probe), True)
+    ep, eb = _canon(ep, eb)
+    total = len(ep)
+    comm = _engine.Comm(eng, None, 0, 1)
+    for ids in (None, np.arange(len(probe[0]), dtype=np.int32)[::-1].copy()):
+        d = _Dev(eng, probe, build, ids)
+        try:
+            opts = _engine.make_opts(True, 3)
+            ix = eng.index_build_dev(d.build, opts)
+            op, ob = d.alloc(4 * total), d.alloc(4 * total)
+            for chunks in (1, 3, 7):
+                nt, nl, fits = comm.overlap_allgather_dev(ix, d.probe, opts, chunks, op, ob, total)
+                assert fits and nt == total and nl == total, (chunks, nt, nl, total)
+                hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
+                eng.d2h(hp, op)
+                eng.d2h(hb, ob)
+                if ids is not None:
+                    hp = (len(probe[0]) - 1 - hp).astype(np.int32)    # the reversed global ids back to local rows
+                gp, gb = _canon(hp, hb)
+                assert (gp == ep).all() and (gb == eb).all(), chunks
+            nt, nl, fits = comm.overlap_allgather_dev(ix, d.probe, opts, 3, op, ob, total - 1)
+            assert not fits and nt == total
+            ix.close()
+        finally:
+            d.close()
+    assert comm.allgather_counts(17) == [17]
+    comm.close()
+    eng.close()
+
+
+def test_world1_allgatherv_copies_the_local_columns():
+    eng = _engine.Engine(0)
+    comm = _engine.Comm(eng, None, 0, 1)
+    a = np.arange(1000, dtype=np.int64)
+    src, dst = eng.dev_alloc(8000), eng.dev_alloc(8000)
+    eng.h2d(src, a)
+    comm.allgatherv_dev([src], [dst], 8, [1000])
+    got = np.empty(1000, np.int64)
+    eng.d2h(got, dst)
+    assert (got == a).all()
+    eng.dev_free(src); eng.dev_free(dst)
+    comm.close()
+    eng.close()
+
+
+def test_create_local_refuses_two_ranks_on_one_device():
+    e0, e1 = _engine.Engine(0), _engine.Engine(0)
+    with pytest.raises(_engine.EngineError, match="one device per rank"):
+        _engine.Comm.create_local([e0, e1])
+    e0.close(); e1.close()
+
+
+def _shard_job(eng, comm, probe, build, nc, rank, world, total, chunks, out):
+    (lp, pid, lb, bid, _mode) = D.shard_sides(probe, build, nc, rank, world)
+    d = _Dev(eng, lp, lb, pid)
+    try:
+        bptr = d.alloc(4 * len(bid)); eng.h2d(bptr, bid)
+        bside = eng.dev_side(d.build.contig, d.build.start, d.build.end, len(bid), bptr)
+        opts = _engine.make_opts(True, nc)
+        ix = eng.index_build_dev(bside, opts)
+        op, ob = d.alloc(4 * total), d.alloc(4 * total)
+        nt, nl, fits = comm.overlap_allgather_dev(ix, d.probe, opts, chunks, op, ob, total)
+        hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
+        eng.d2h(hp, op); eng.d2h(hb, ob)
+        ix.close()
+        out[rank] = (nt, nl, fits, hp, hb)
+    finally:
+        d.close()
+
+
+@pytest.mark.skipif(_engine.device_count() < 2, reason="needs two GPUs")
+def test_two_contexts_two_devices_one_process_over_rccl():
+    """ncclCommInitAll inside the library: one host thread per rank, contig sharding, every rank ends up with every pair."""
+    rng = np.random.default_rng(9)
+    nc = 6
+    probe = random_side(rng, 200000, nc, 2_000_000, 400)
+    build = random_side(rng, 60000, nc, 2_000_000, 400)
+    ep, eb = _canon(*O.overlap_fast(O.Index(O.Side(*build), nc), O.Side(*probe), True))
+    engines = [_engine.Engine(0), _engine.Engine(1)]
+    comms = _engine.Comm.create_local(engines)
+    out = {}
+    th = [threading.Thread(target=_shard_job, args=(engines[r], comms[r], probe, build, nc, r, 2, len(ep), 4, out)) for r in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert sorted(out) == [0, 1]
+    for r in range(2):
+        nt, nl, fits, hp, hb = out[r]
+        assert fits and nt == len(ep)
+        gp, gb = _canon(hp, hb)
+        assert (gp == ep).all() and (gb == eb).all(), r
+    assert out[0][1] + out[1][1] == len(ep)
+    for c in comms: c.close()
+    for e in engines: e.close()
+
+
+@pytest.mark.skipif(_engine.device_count() < 2, reason="needs two GPUs")
+def test_two_processes_over_the_library_communicator(tmp_path):
+    """Two processes, no torch anywhere: the unique id travels through a file, the pairs through ivj_overlap_allgather_dev."""
+    idf = tmp_path / "id.bin"
+    worker = os.path.join(os.path.dirname(__file__), "_comm_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(idf), str(tmp_path / f"out{r}.npz")]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a, b = np.load(tmp_path / "out0.npz"), np.load(tmp_path / "out1.npz")
+    assert int(a["ok"]) == 1 and int(b["ok"]) == 1
+    assert (a["p"] == b["p"]).all() and (a["b"] == b["b"]).all()
