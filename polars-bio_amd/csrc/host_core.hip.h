@@ -102,6 +102,8 @@ struct ivj_ctx {
     // indexes built on this context that are still alive: ivj_ctx_destroy detaches them (ix->ctx = nullptr), so an
     // ivj_index_free that comes after the context is gone only releases the index's own slab
     std::vector<ivj_index*> live;
+    // streaming sessions opened on this context that are still alive: ivj_ctx_destroy releases and detaches them
+    std::vector<struct ivj_stream*> streams;
 };
 
 struct ivj_index {

@@ -86,6 +86,7 @@ int ivj_ctx_create(int device, ivj_ctx** out) {
 }
 
 namespace {
+void stream_release(ivj_stream* st, bool keep_cache);
 void free_stream_bufs(ivj_ctx::StreamBufs& b) {
     if (b.h_in) (void)hipHostFree(b.h_in);
     if (b.d_in) (void)hipFree(b.d_in);
@@ -99,6 +100,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    while (!ctx->streams.empty()) stream_release(ctx->streams.back(), false);   // live streaming sessions: released and detached (their handles stay closable)
     for (ivj_index* ix : ctx->live) ix->ctx = nullptr;          // detached: they keep (and later free) their slabs
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->ov_buf) (void)hipFree(ctx->ov_buf);
@@ -387,10 +389,14 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     out->probe_idx = (int32_t*)host_result_alloc((size_t)total * 4);
     out->build_idx = (int32_t*)host_result_alloc((size_t)total * 4);
     if (!out->probe_idx || !out->build_idx) { ivj_pairs_free(out); return fail(IVJ_ENOMEM, "host malloc(pairs)"); }
-    HostPin pin_p(out->probe_idx, (size_t)total * 4), pin_b(out->build_idx, (size_t)total * 4);
-    hipError_t ce = hipMemcpyAsync(out->probe_idx, op.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (ce == hipSuccess) ce = hipMemcpyAsync(out->build_idx, ob.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+    hipError_t ce;
+    {
+        HostPin pin_p(out->probe_idx, (size_t)total * 4), pin_b(out->build_idx, (size_t)total * 4);     // unregistered before the buffers can be freed
+        ce = hipMemcpyAsync(out->probe_idx, op.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(out->build_idx, ob.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+        else (void)hipStreamSynchronize(ctx->stream);
+    }
     if (ce != hipSuccess) { ivj_pairs_free(out); return fail(IVJ_EHIP, std::string("D2H(pairs): ") + hipGetErrorString(ce)); }
     out->n_pairs = total;
     return IVJ_OK;
@@ -792,6 +798,7 @@ int ivj_stream_open(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, i
     DeviceGuard g(ctx->device);
     ivj_stream* st = new ivj_stream();
     st->ctx = ctx; st->opts = *opts; st->op = op; st->k = k; st->max_rows = max_batch_rows;
+    ctx->streams.push_back(st);
     auto bail = [&](int rc) { ivj_stream_close(st); return rc; };
     {
         DevSide db;
@@ -831,24 +838,29 @@ int ivj_stream_submit(ivj_stream* st, const ivj_side* batch, ivj_stream_result* 
     IVJ_TRY(check_side(batch, "batch"));
     if (batch->n > st->max_rows) return fail(IVJ_EINVAL, "batch has more rows than max_batch_rows");
     if (batch->row_id) return fail(IVJ_EINVAL, "stream batches report rows inside the batch: row_id must be NULL");
+    if (!st->ctx) return fail(IVJ_ESTATE, "the context of this streaming session was destroyed");
     return stream_turn(st, batch, done);
 }
 
 int ivj_stream_flush(ivj_stream* st, ivj_stream_result* done) {
     if (!st || !done) return fail(IVJ_EINVAL, "stream or done is NULL");
+    if (!st->ctx) return fail(IVJ_ESTATE, "the context of this streaming session was destroyed");
     return stream_turn(st, nullptr, done);
 }
 
-void ivj_stream_close(ivj_stream* st) {
-    if (!st) return;
-    DeviceGuard g(st->ctx->device);
+namespace {
+// device / pinned resources of a streaming session; the staging goes back to the context's cache when it is still there
+void stream_release(ivj_stream* st, bool keep_cache) {
+    ivj_ctx* ctx = st->ctx;
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
     if (st->s_h2d) (void)hipStreamSynchronize(st->s_h2d);
     if (st->s_d2h) (void)hipStreamSynchronize(st->s_d2h);
-    (void)hipStreamSynchronize(st->ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     for (int s = 0; s < 3; ++s) {
         ivj_stream::Slot& S = st->slot[s];
-        ivj_ctx::StreamBufs& cb = st->ctx->st_cache[s];                        // keep the (larger) staging for the next session
-        if (S.h_in && S.d_in && S.in_cap >= cb.in_cap) {
+        ivj_ctx::StreamBufs& cb = ctx->st_cache[s];                            // keep the (larger) staging for the next session
+        if (keep_cache && S.h_in && S.d_in && S.in_cap >= cb.in_cap) {
             free_stream_bufs(cb);
             cb.h_in = S.h_in; cb.d_in = S.d_in; cb.in_cap = S.in_cap; cb.d_out = S.d_out; cb.d_out_cap = S.d_out_cap; cb.h_out = S.h_out; cb.h_out_cap = S.h_out_cap;
         } else {
@@ -860,10 +872,21 @@ void ivj_stream_close(ivj_stream* st) {
         if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
         if (S.ev_join) (void)hipEventDestroy(S.ev_join);
         if (S.ev_d2h) (void)hipEventDestroy(S.ev_d2h);
+        S = ivj_stream::Slot();
     }
     if (st->s_h2d) (void)hipStreamDestroy(st->s_h2d);
     if (st->s_d2h) (void)hipStreamDestroy(st->s_d2h);
+    st->s_h2d = st->s_d2h = nullptr;
     if (st->ix) ivj_index_free(st->ix);
+    st->ix = nullptr;
+    ctx->streams.erase(std::remove(ctx->streams.begin(), ctx->streams.end(), st), ctx->streams.end());
+    st->ctx = nullptr;
+}
+}  // namespace
+
+void ivj_stream_close(ivj_stream* st) {
+    if (!st) return;
+    stream_release(st, true);          // no-op when ivj_ctx_destroy already detached the session
     delete st;
 }
 

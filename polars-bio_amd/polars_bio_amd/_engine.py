@@ -819,15 +819,16 @@ _default_lock = threading.Lock()
 
 def default_engine() -> Engine:
     """Process-wide engine (its native calls are serialised by Engine.lock; use one Engine per thread for
-    concurrent joins).  Device: the ``ivj.device`` option when it was set explicitly, else LOCAL_RANK (one
-    process per GPU under torch.distributed.run), else 0."""
+    concurrent joins).  One device: the ``ivj.device`` option when it was set explicitly, else LOCAL_RANK (one
+    process per GPU under torch.distributed.run), else 0.  Several devices (``ivj.devices`` = "0,1,..", or
+    ``ivj.num_gpus`` / ``datafusion.execution.target_partitions`` > 1 on a host with that many GPUs): a
+    ``multi.MultiEngine`` -- one context and one host thread per device, contigs dealt to the devices."""
     global _default_engine
     with _default_lock:
         if _default_engine is None:
-            from .context import get_option
-            opt = get_option("ivj.device")
-            dev = int(opt) if opt not in (None, "", "auto") else int(os.environ.get("LOCAL_RANK", "0"))
-            _default_engine = Engine(dev)
+            from .multi import MultiEngine, requested_devices
+            devs = requested_devices()
+            _default_engine = MultiEngine(devs) if len(devs) > 1 else Engine(devs[0])
         return _default_engine
 
 

@@ -21,6 +21,11 @@ class Context:
             "bio.interval_join_algorithm": "hip",
             # engine options of this implementation
             "ivj.device": "auto",   # "auto": LOCAL_RANK (one process per GPU) or 0; a number pins the device
+            # several GPUs in ONE process (multi.MultiEngine: one context + host thread per device, contigs dealt out):
+            # "ivj.devices" = explicit slots ("0,1"); else ivj.num_gpus, else datafusion.execution.target_partitions
+            # (the reference's parallelism knob, polars_bio/context.py:36) -- capped by the visible devices
+            "ivj.devices": "auto",
+            "ivj.num_gpus": "0",
             "ivj.low_memory_batch_rows": "8000000",
             # "host": result rows are gathered with Arrow take on the host from the index pairs;
             # "device": the key columns of both sides are materialised in HBM (ivj_overlap_rows)
@@ -33,7 +38,11 @@ class Context:
         elif isinstance(value, numbers.Number):
             value = str(value)
         with self._lock:
+            changed = self._opts.get(key) != value
             self._opts[key] = value
+        if changed and key in ("ivj.device", "ivj.devices", "ivj.num_gpus", "datafusion.execution.target_partitions"):
+            from ._engine import reset_default_engine      # the next call builds the engine(s) the new value asks for
+            reset_default_engine()
 
     def get_option(self, key):
         with self._lock:

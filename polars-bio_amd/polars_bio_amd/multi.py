@@ -1,0 +1,134 @@
+"""In-process multi-device driver behind the front door: one Engine (= one ivj_ctx) and one host thread per device.
+
+The reference's knob for parallelism is ``datafusion.execution.target_partitions`` -- probe-side partitions joined by
+DataFusion worker threads (/root/reference/polars_bio/context.py:36, src/scan.rs:233-277).  Here the unit of parallelism is
+a GPU: intervals on different contigs never interact (the reference builds one tree per contig, range_op.py:550), so the
+contigs are dealt to the devices by LPT on their row counts (``distributed.shard_sides``; fewer contigs than devices: the
+build side is replicated and the probe rows are split), every device joins its shard through the host entry points of the C
+ABI on its own thread (ctypes releases the GIL), and the results -- host arrays either way -- are put back together on the
+host: pairs are mapped to global rows and concatenated, per-probe results are stored at their rows.
+
+Selected by ``ivj.devices`` (explicit list, e.g. "0,1"; a device may be listed twice, which is how a 1-GPU box tests this)
+or ``ivj.num_gpus`` / ``datafusion.execution.target_partitions`` > 1 (the first n visible devices)."""
+from __future__ import annotations
+
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Sequence
+
+import numpy as np
+
+from . import distributed as D
+
+MIN_ROWS_TO_SHARD = 1 << 16        # below this a second device cannot repay the sharding
+
+
+class MultiEngine:
+    """The Engine host API (overlap / count_overlaps / nearest) over several devices; every other attribute is the first
+    engine's (merge, cluster, coverage, subtract, streaming sessions ... run on one device)."""
+
+    def __init__(self, devices: Sequence[int]):
+        from ._engine import Engine
+        if len(devices) < 2:
+            raise ValueError("MultiEngine needs at least two device slots")
+        self.devices = [int(d) for d in devices]
+        self.engines: List = [Engine(d) for d in self.devices]
+        self.lock = threading.RLock()
+        self._pool = ThreadPoolExecutor(max_workers=len(self.engines), thread_name_prefix="ivj-dev")
+        self.last_shards = None         # [(probe rows, build rows, mode)] of the last sharded call (tests, logging)
+
+    # everything that is not sharded runs on device slot 0
+    def __getattr__(self, name):
+        return getattr(self.engines[0], name)
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for e in self.engines:
+            e.close()
+
+    def _shards(self, probe, build, n_contigs):
+        world = len(self.engines)
+        sh = [D.shard_sides(probe, build, n_contigs, r, world) for r in range(world)]
+        self.last_shards = [(len(s[1]), len(s[3]), s[4]) for s in sh]
+        return sh
+
+    def _small(self, probe, build):
+        return len(probe[0]) + len(build[0]) < MIN_ROWS_TO_SHARD
+
+    def _run(self, fn, shards):
+        futs = [self._pool.submit(fn, e, s) for e, s in zip(self.engines, shards)]
+        return [f.result() for f in futs]
+
+    def overlap(self, probe, build, strict: bool, n_contigs: int, **kw):
+        if self._small(probe, build):
+            return self.engines[0].overlap(probe, build, strict, n_contigs, **kw)
+
+        def job(eng, s):
+            lp, pid, lb, bid, _ = s
+            if len(pid) == 0 or len(bid) == 0:
+                return np.empty(0, np.int32), np.empty(0, np.int32)
+            p, b = eng.overlap(lp, lb, strict, n_contigs, **kw)
+            return pid[p], bid[b]
+        parts = self._run(job, self._shards(probe, build, n_contigs))
+        return np.concatenate([p for p, _ in parts]), np.concatenate([b for _, b in parts])
+
+    def count_overlaps(self, probe, build, strict: bool, n_contigs: int, **kw):
+        if self._small(probe, build):
+            return self.engines[0].count_overlaps(probe, build, strict, n_contigs, **kw)
+
+        def job(eng, s):
+            lp, pid, lb, bid, _ = s
+            if len(pid) == 0:
+                return pid, np.empty(0, np.int64)
+            return pid, eng.count_overlaps(lp, lb, strict, n_contigs, **kw)
+        out = np.zeros(len(probe[0]), np.int64)      # rows no device owns (contig outside the dictionary) overlap nothing
+        for pid, c in self._run(job, self._shards(probe, build, n_contigs)):
+            out[pid] = c
+        return out
+
+    def nearest(self, probe, build, strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True, **kw):
+        if self._small(probe, build):
+            return self.engines[0].nearest(probe, build, strict, n_contigs, k, include_overlaps, **kw)
+        # rows no device owns: what one engine answers for a contig it has no rows for
+        one = (np.array([n_contigs + 1], np.int32), np.zeros(1, np.int32), np.ones(1, np.int32))
+        fi, fd, fn = self.engines[0].nearest(one, tuple(a[:0] for a in build), strict, n_contigs, k, include_overlaps, **kw)
+        n = len(probe[0])
+        idx = np.repeat(fi, n, axis=0); dist = np.repeat(fd, n, axis=0); nf = np.repeat(fn, n, axis=0)
+
+        def job(eng, s):
+            lp, pid, lb, bid, _ = s
+            if len(pid) == 0:
+                return None
+            i, d, f = eng.nearest(lp, lb, strict, n_contigs, k, include_overlaps, **kw)
+            gi = np.where(i >= 0, bid[np.where(i >= 0, i, 0)] if len(bid) else -1, -1).astype(np.int32)
+            return pid, gi, d, f
+        for r in self._run(job, self._shards(probe, build, n_contigs)):
+            if r is not None:
+                pid, gi, d, f = r
+                idx[pid] = gi; dist[pid] = d; nf[pid] = f
+        return idx, dist, nf
+
+
+def requested_devices():
+    """-> list of device slots the options ask for (length 1: single engine)."""
+    import os
+    from ._engine import device_count
+    from .context import get_option
+    spec = str(get_option("ivj.devices") or "auto").strip().lower()
+    if spec not in ("", "auto"):
+        return [int(x) for x in spec.split(",") if x.strip() != ""]
+    try:
+        n = int(get_option("ivj.num_gpus") or 0)
+    except ValueError:
+        n = 0
+    if n <= 0:
+        try:
+            n = int(get_option("datafusion.execution.target_partitions") or 1)
+        except ValueError:
+            n = 1
+    opt = get_option("ivj.device")
+    first = int(opt) if opt not in (None, "", "auto") else int(os.environ.get("LOCAL_RANK", "0"))
+    if n <= 1 or "WORLD_SIZE" in os.environ:          # one process per GPU under a launcher: never fan out inside a rank
+        return [first]
+    n = min(n, max(device_count(), 1))
+    return [first] if n <= 1 else list(range(n))

@@ -276,3 +276,23 @@ def test_engine_overlap_results_are_zero_copy_views():
     assert (view == keep).all()                                 # ... which stay alive as long as any view does
     o = np.argsort(np.concatenate([view[:0], eng.overlap(probe, build, True, 24)[0]]), kind="stable")
     assert len(o) == len(ep)
+
+
+@pytest.mark.gpu
+def test_stream_outlives_its_engine_without_touching_freed_memory():
+    """ivj_ctx_destroy releases and detaches the streaming sessions still open on the context: a later submit / flush is an
+    error (IVJ_ESTATE), close is a no-op on the device side -- never a use-after-free (an unconsumed lazy reader can be
+    overtaken by reset_default_engine() / Engine.close())."""
+    from polars_bio_amd import _engine, synth
+    eng = _engine.Engine(0)
+    build = synth.make_side(5000, 43, synth.BUILD_LEN, 4)
+    probe = synth.make_side(3000, 42, synth.PROBE_LEN, 4)
+    st = eng.probe_stream(build, True, 4, max_batch_rows=4096)
+    assert st.submit(probe) is None          # first batch in flight
+    eng.close()
+    with pytest.raises(_engine.EngineError, match="context of this streaming session was destroyed"):
+        st.submit(probe)
+    with pytest.raises(_engine.EngineError):
+        st.flush()
+    st.close()
+    st.close()
