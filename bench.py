@@ -78,6 +78,11 @@ def parse():
     ap.add_argument("--materialize", action="store_true",
                     help="overlap workloads: also gather the key columns of both sides for every pair in HBM "
                          "(ivj_materialize_dev, SURVEY.md 8f row 1) inside the step")
+    ap.add_argument("--exchange", choices=("auto", "lib", "torch"), default="auto",
+                    help="N>1 overlap: 'lib' = the communicator inside libivjoin_hip.so (RCCL, ivj_overlap_allgather_dev: the exchange "
+                         "overlaps the join), 'torch' = torch.distributed all-gatherv after the join; auto = lib when every rank has its "
+                         "own device, else torch over gloo (several ranks on one GPU: tests)")
+    ap.add_argument("--chunks", type=int, default=4, help="N>1, lib exchange: probe chunks per rank (join of chunk i overlaps the exchange of chunk i-1)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (RCCL init, sharding, all-gatherv) even with one rank")
     return ap.parse_args()
@@ -106,6 +111,44 @@ def gen_workload(name, scale):
     build = synth.make_side(n_b, 43, blen, nc)
     log(f"[bench] generated {name}: probe {n_p:,} build {n_b:,} contigs {nc} in {time.time() - t0:.1f}s")
     return probe, build, nc, op
+
+
+WORKLOADS_SHARDABLE = ("overlap_10M_1M_1contig", "overlap_100M_5M_24contig", "overlap_100M_5M_24contig_dense", "overlap_100M_5M_24contig_mid",
+                       "nearest_50M_2M_24contig", "count_200M_200k_24contig", "count_100M_5M_24contig")
+
+
+def gen_shard(name, scale, rank, world):
+    """N > 1: this rank's shard only (synth.make_shard: the same distribution drawn contig by contig from per-contig streams, so no
+    rank ever generates -- or filters -- the other ranks' rows).  -> (probe, probe ids, build, build ids, mode, nc, op, n_p, n_b)."""
+    from polars_bio_amd import synth
+    from polars_bio_amd import distributed as D
+    cfg = {
+        "overlap_10M_1M_1contig": (10_000_000, 1_000_000, 1, synth.BUILD_LEN, "overlap"),
+        "overlap_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "overlap"),
+        "overlap_100M_5M_24contig_dense": (100_000_000, 5_000_000, 24, synth.DENSE_BUILD_LEN, "overlap"),
+        "overlap_100M_5M_24contig_mid": (100_000_000, 5_000_000, 24, (1000, 9000), "overlap"),
+        "nearest_50M_2M_24contig": (50_000_000, 2_000_000, 24, synth.BUILD_LEN, "nearest"),
+        "count_200M_200k_24contig": (200_000_000, 200_000, 24, synth.BUILD_LEN, "count_overlaps"),
+        "count_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "count_overlaps"),
+    }[name]
+    n_p, n_b, nc, blen, op = cfg
+    n_p, n_b = max(1, int(n_p * scale)), max(1, int(n_b * scale))
+    t0 = time.time()
+    rp, rb = synth.contig_rows(n_p, nc), synth.contig_rows(n_b, nc)
+    if nc >= world:
+        owner = D.lpt_assign((rp + rb).astype(float), world)
+        mine = [c for c in range(nc) if owner[c] == rank]
+        pp = [(c, 0, int(rp[c])) for c in mine]
+        pb = [(c, 0, int(rb[c])) for c in mine]
+        mode = "contig"
+    else:   # fewer contigs than ranks (config 2): build side replicated, probe rows split
+        pp = [(c, int(rp[c]) * rank // world, int(rp[c]) * (rank + 1) // world) for c in range(nc)]
+        pb = [(c, 0, int(rb[c])) for c in range(nc)]
+        mode = "rows"
+    lp, lp_ids = synth.make_shard(n_p, 42, synth.PROBE_LEN, nc, pp, shuffle_seed=1000 + rank)
+    lb, lb_ids = synth.make_shard(n_b, 43, blen, nc, pb, shuffle_seed=2000 + (rank if mode == "contig" else 0))
+    log(f"[bench] rank {rank}: generated its shard of {name} ({mode}): probe {len(lp_ids):,} of {n_p:,}, build {len(lb_ids):,} of {n_b:,} in {time.time() - t0:.1f}s")
+    return lp, lp_ids, lb, lb_ids, mode, nc, op, n_p, n_b
 
 
 def algorithmic_bytes(op, n_p, n_b, n_out):
@@ -322,28 +365,75 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev                  # more ranks than devices (tests on a 1-GPU box): the ranks share devices
+    oversub = n_gpus > n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     multi = n_gpus > 1 or args.force_dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=n_gpus)
+        # control plane (barriers, the unique id, timing reductions) over gloo; the DATA goes over the library's own RCCL
+        # communicator (--exchange lib) or a torch.distributed nccl group (--exchange torch)
+        dist.init_process_group("gloo", rank=rank, world_size=n_gpus)
 
-    probe, build, nc, op = gen_workload(args.workload, args.scale)
-    n_p_total, n_b_total = len(probe[0]), len(build[0])
-    if multi:
-        lp, lp_ids, lb, lb_ids, mode = D.shard_sides(probe, build, nc, rank, n_gpus)
+    if multi and args.workload in WORKLOADS_SHARDABLE:
+        lp, lp_ids, lb, lb_ids, mode, nc, op, n_p_total, n_b_total = gen_shard(args.workload, args.scale, rank, n_gpus)
+        probe, build = lp, lb
     else:
-        lp, lp_ids, lb, lb_ids, mode = probe, None, build, None, "single"
+        probe, build, nc, op = gen_workload(args.workload, args.scale)
+        n_p_total, n_b_total = len(probe[0]), len(build[0])
+        if multi:
+            lp, lp_ids, lb, lb_ids, mode = D.shard_sides(probe, build, nc, rank, n_gpus)
+        else:
+            lp, lp_ids, lb, lb_ids, mode = probe, None, build, None, "single"
 
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
     d_probe = DeviceSide(up(lp[0]), up(lp[1]), up(lp[2]), up(lp_ids) if lp_ids is not None else None)
     d_build = DeviceSide(up(lb[0]), up(lb[1]), up(lb[2]), up(lb_ids) if lb_ids is not None else None)
-    join = DeviceJoin(local_rank)
+    join = DeviceJoin(dev_index)
     gather = multi and not args.no_gather and op == "overlap"
+
+    # ---- exchange transport of the N > 1 overlap
+    exchange, comm, xgroup = None, None, None
+    if gather:
+        from polars_bio_amd import _engine as E
+        want = args.exchange if args.exchange != "auto" else ("torch" if oversub else "lib")
+        if want == "lib":
+            ok = 1
+            try:
+                box = [E.comm_unique_id() if rank == 0 else None]
+            except Exception as e:
+                log(f"[bench] rank {rank}: ivj_comm_unique_id failed: {e!r}")
+                box, ok = [None], 0
+            dist.broadcast_object_list(box, src=0)
+            try:
+                if box[0] is None:
+                    raise RuntimeError("no unique id")
+                comm = E.Comm(join.engine, box[0], rank, n_gpus)
+            except Exception as e:
+                log(f"[bench] rank {rank}: ivj_comm_create failed: {e!r}")
+                ok = 0
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchange = "lib"
+            else:
+                comm = None
+                log("[bench] the library communicator is not available on every rank: falling back to torch.distributed for the exchange")
+        if exchange is None:
+            exchange = "torch-gloo" if oversub else "torch-nccl"
+            if not oversub:
+                try:
+                    xgroup = dist.new_group(backend="nccl", device_id=dev)
+                except TypeError:
+                    xgroup = dist.new_group(backend="nccl")
+        if rank == 0:
+            log(f"[bench] exchange transport: {exchange}" + (f", {args.chunks} chunks per rank" if exchange == "lib" else ""))
+    to_x = (lambda t: t.cpu()) if exchange == "torch-gloo" else (lambda t: t)
 
     state = {}
 
@@ -357,6 +447,23 @@ def main():
                 cols, local, fits = join.overlap_rows(d_probe, d_build, True, nc, state["rows"], partition_mode=args.partition_mode)
                 assert fits, "row buffers too small"
                 return local, (cols["probe_idx"], cols["build_idx"])
+            if exchange == "lib" and not state.get("no_gather"):
+                # shard join + all-gatherv inside the library: the exchange of chunk i - 1 overlaps the join of chunk i
+                opts = E.make_opts(True, nc, partition_mode=args.partition_mode)
+                ix = join.engine.index_build_dev(d_build.as_c(), opts, False)
+                try:
+                    if "gout" not in state:
+                        local = join.engine.overlap_count_dev(ix, d_probe.as_c(), opts) if d_probe.n and d_build.n else 0
+                        total = sum(comm.allgather_counts(local))
+                        cap = total + total // 50 + 1024
+                        state["gout"] = (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
+                    gp, gb = state["gout"]
+                    nt, nl, fits = comm.overlap_allgather_dev(ix, d_probe.as_c(), opts, args.chunks, gp.data_ptr(), gb.data_ptr(), int(gp.numel()))
+                    assert fits, "gathered result exceeds the preallocated buffers"
+                finally:
+                    ix.close()
+                state["gathered"] = nt
+                return nl, (gp[:nt], gb[:nt])
             p, b = join.overlap(d_probe, d_build, True, nc, out=state.get("out"), fused=not args.two_pass,
                                 partition_mode=args.partition_mode)
             if "out" not in state:
@@ -369,14 +476,14 @@ def main():
                 state["cols"] = join.materialize(d_probe, d_build, p, b, out=state["rows_sep"])
                 if not args.two_pass and "rows" not in state:
                     state["rows"] = dict(state["rows_sep"], probe_idx=state["out"][0], build_idx=state["out"][1])
-            if gather:
-                # the exchange is timed on its own as well (torch events on the current stream: the
-                # waits of the grouped isend/irecv order the stream behind RCCL's)
+            if gather and not state.get("no_gather"):
+                # torch.distributed exchange after the join, timed on its own as well
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-                (p, b), _ = D.all_gatherv([p, b])
+                (p, b), _ = D.all_gatherv([to_x(p), to_x(b)], group=xgroup)
                 ev[1].record()
                 state.setdefault("gather_events", []).append(ev)
+                state["gathered"] = int(p.shape[0])
             return local, (p, b)
         if op == "count_overlaps":
             return d_probe.n, join.count_overlaps(d_probe, d_build, True, nc, partition_mode=args.partition_mode)
@@ -418,19 +525,35 @@ def main():
     ktimes = join.engine.timings()
     join.engine.enable_timing(0)
 
-    t = torch.tensor([local_units], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([local_units], dtype=torch.int64)
+    tmax = torch.tensor([elapsed], dtype=torch.float64)
     if multi:
         dist.all_reduce(t)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_units = int(t.item())
     elapsed = float(tmax.item())
     if gather:
-        assert int(out[0].shape[0]) == total_units, "all-gatherv lost pairs"
+        assert int(state.get("gathered", -1)) == total_units, "all-gatherv lost pairs"
     ms_per_step = elapsed / args.steps * 1e3
     gather_ms = None
     if state.get("gather_events"):
         gather_ms = sum(a.elapsed_time(b) for a, b in state["gather_events"]) / len(state["gather_events"])
+    # N > 1: the same steps once more WITHOUT the exchange (what --no-gather would report), so that the line always carries
+    # the join-only rate next to the headline and the exchange's exposed share of the step
+    join_only_ms = None
+    if gather:
+        state["no_gather"] = True
+        kj = max(1, min(args.steps, 5))
+        step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(kj):
+            step()
+        barrier()
+        tj = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+        dist.all_reduce(tj, op=dist.ReduceOp.MAX)
+        join_only_ms = float(tj.item()) / kj * 1e3
+        state["no_gather"] = False
 
     # dominant kernel + roofline (per launch, this rank's shard)
     dom_name, dom = None, None
@@ -481,7 +604,7 @@ def main():
         for _ in range(k2):
             join.overlap(d_probe, d_build, True, nc, out=state.get("out"), fused=False, partition_mode=args.partition_mode)
         barrier()
-        tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
         if multi:
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
         two_pass_ms = float(tp.item()) / k2 * 1e3
@@ -552,16 +675,21 @@ def main():
             "config": {"workload": args.workload, "probe_rows": n_p_total, "build_rows": n_b_total, "contigs": nc,
                        "filter_op": "Strict", "units_per_step": total_units,
                        "parallelism": ("single GPU" if not multi else
-                                       f"{mode}-sharded x{n_gpus}, " + ("RCCL all-gatherv in timed region" if gather else "no gather")),
+                                       f"{mode}-sharded x{n_gpus}, " + ((f"all-gatherv in timed region ({exchange}" + (f", {args.chunks} chunks, exchange overlapping the join" if exchange == "lib" else "") + ")") if gather else "no gather")),
                        "step": ("index build (radix sort) + probe partition (" +
-                                ("equal-row-count index slices, 16-byte records" if any(k.startswith("slice_") for k in ktimes) else "256 genomic buckets") + ") + " +
-                                ("count + scan + fill" if (args.two_pass or not any(k.startswith(("overlap_fused", "overlap_flat", "slice_join_fused")) for k in ktimes)) else
+                                ("contig-aligned index slices, 12-byte records" if any(k.startswith("cs_") for k in ktimes) else
+                                 "equal-row-count index slices, 16-byte records" if any(k.startswith("slice_") for k in ktimes) else "256 genomic buckets") + ") + " +
+                                ("count + scan + fill" if (args.two_pass or not any(k.startswith(("overlap_fused", "overlap_flat", "slice_join_fused", "cs_join_fused")) for k in ktimes)) else
                                  "fused count/fill into the preallocated result buffers") +
                                 (" + key-column materialisation of every pair" if args.materialize else "") +
                                 ", inputs and outputs in HBM") if op == "overlap" else
                                "index build (radix sort) + probe kernel, inputs and outputs in HBM"},
-            "phases_ms": ({"join_rank0": round(ms_per_step - gather_ms, 4), "allgatherv_rank0": round(gather_ms, 4)}
-                          if gather_ms is not None else None),
+            "phases_ms": (None if join_only_ms is None else
+                          {"join": round(join_only_ms, 4), "allgatherv": round(max(ms_per_step - join_only_ms, 0.0), 4),
+                           "allgatherv_rank0_events": None if gather_ms is None else round(gather_ms, 4),
+                           "no_gather_value": total_units / (join_only_ms * 1e-3),
+                           "what": "join = the same steps without the exchange (max over ranks); allgatherv = step - join = the part of the exchange the join does not hide"}),
+            "exchange": exchange,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "two_pass_ms_per_step": None if two_pass_ms is None else round(two_pass_ms, 4),

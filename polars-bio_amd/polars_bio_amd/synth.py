@@ -59,3 +59,62 @@ def expected_pairs(n_probe: int, n_build: int, n_contigs: int = 24, build_len=BU
     p = lengths / lengths.sum()
     el = (PROBE_LEN[0] + PROBE_LEN[1]) / 2 + (build_len[0] + build_len[1]) / 2
     return float(((n_probe * p) * (n_build * p) * el / lengths).sum())
+
+
+# ---- the same distribution, generated shard by shard (bench.py at N > 1) ---------------------------------------------
+# make_side draws the whole side from ONE generator, so a rank that wants its contigs only would still have to draw all n
+# rows (100 M rows x N ranks of host work before the first kernel).  The sharded generator fixes the rows per contig
+# (largest remainder of n * len_c / sum len) and draws every contig in blocks of SHARD_BLOCK rows from its own stream
+# SeedSequence([seed, contig, block]): any rank can produce any row range of any contig, every rank agrees on the data, and
+# nothing outside the shard is ever drawn.  Global row id of row i of contig c = contig_offsets[c] + i.
+SHARD_BLOCK = 1 << 20
+
+
+def contig_rows(n: int, n_contigs: int = 24) -> np.ndarray:
+    """Rows per contig, proportional to the contig lengths (largest remainder), summing to n."""
+    lengths = CONTIG_LENGTHS[:n_contigs].astype(np.float64)
+    share = n * lengths / lengths.sum()
+    rows = np.floor(share).astype(np.int64)
+    rest = int(n - rows.sum())
+    if rest:
+        rows[np.argsort(-(share - rows), kind="stable")[:rest]] += 1
+    return rows
+
+
+def make_contig_rows(c: int, lo: int, hi: int, seed: int, len_range, n_contigs: int = 24):
+    """Rows lo .. hi-1 of contig c -> (start int32, end int32)."""
+    length = int(CONTIG_LENGTHS[c])
+    s_parts, e_parts = [], []
+    for k in range(lo // SHARD_BLOCK, (max(hi, lo + 1) - 1) // SHARD_BLOCK + 1):
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, c, k])))
+        L = rng.integers(len_range[0], len_range[1] + 1, size=SHARD_BLOCK, dtype=np.int64)
+        start = np.floor(rng.random(SHARD_BLOCK) * (length - L)).astype(np.int64)
+        a, b = max(lo, k * SHARD_BLOCK) - k * SHARD_BLOCK, min(hi, (k + 1) * SHARD_BLOCK) - k * SHARD_BLOCK
+        if b > a:
+            s_parts.append(start[a:b]); e_parts.append((start + L)[a:b])
+    if not s_parts:
+        return np.empty(0, np.int32), np.empty(0, np.int32)
+    return np.concatenate(s_parts).astype(np.int32), np.concatenate(e_parts).astype(np.int32)
+
+
+def make_shard(n: int, seed: int, len_range, n_contigs: int, pieces, shuffle_seed=None):
+    """pieces: [(contig, lo, hi)] row ranges -> ((contig, start, end) int32 arrays, global row ids int32).
+    shuffle_seed: permute the shard's rows (the N = 1 workload is unsorted with interleaved contigs; so is every shard)."""
+    rows = contig_rows(n, n_contigs)
+    offs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    cs, ss, es, ids = [], [], [], []
+    for c, lo, hi in pieces:
+        hi = min(hi, int(rows[c]))
+        if hi <= lo:
+            continue
+        s, e = make_contig_rows(c, lo, hi, seed, len_range, n_contigs)
+        cs.append(np.full(hi - lo, c, np.int32)); ss.append(s); es.append(e)
+        ids.append((offs[c] + np.arange(lo, hi, dtype=np.int64)).astype(np.int32))
+    if not cs:
+        z = np.empty(0, np.int32)
+        return (z, z, z), z
+    c, s, e, i = np.concatenate(cs), np.concatenate(ss), np.concatenate(es), np.concatenate(ids)
+    if shuffle_seed is not None:
+        p = np.random.Generator(np.random.PCG64(shuffle_seed)).permutation(len(c))
+        c, s, e, i = c[p], s[p], e[p], i[p]
+    return (c, s, e), i

@@ -226,6 +226,29 @@ def test_bench_gpus_2_self_spawn():
     assert j["n_gpus"] == 2 and j["value"] > 0 and "all-gatherv" in j["config"]["parallelism"]
 
 
+def test_bench_gpus_2_on_whatever_devices_there_are():
+    """`python bench.py --gpus 2` on THIS box: with two devices the ranks exchange through the library's RCCL communicator
+    (ivj_overlap_allgather_dev), on a 1-GPU box both ranks share GPU 0 and the exchange goes over gloo -- either way the N > 1
+    path of the bench (shard-only generation, contig sharding, all-gatherv inside the timed region, phases) runs and the
+    gathered total equals the sum of the shards."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.03", "--steps", "2", "--warmup", "1",
+                          "--no-pmc", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    j = json.loads(line[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "all-gatherv" in j["config"]["parallelism"]
+    assert j["exchange"] == ("lib" if _device_count() >= 2 else "torch-gloo")
+    ph = j["phases_ms"]
+    assert ph["join"] > 0 and ph["no_gather_value"] > 0
+    from polars_bio_amd import synth
+    exp = synth.expected_pairs(int(100_000_000 * 0.03), int(5_000_000 * 0.03), 24)
+    assert abs(j["config"]["units_per_step"] / exp - 1) < 0.05
+
+
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.01", "--steps", "1"],
