@@ -12,6 +12,8 @@ on the host by the row indices the engine returns.
 """
 from __future__ import annotations
 
+import os
+from concurrent.futures import ThreadPoolExecutor
 from typing import Tuple
 
 import numpy as np
@@ -26,6 +28,26 @@ try:
     import polars as pl
 except ImportError:
     pl = None
+
+# Host stages of the front door (key encoding, coordinate narrowing, row assembly) are memory-bound loops over 10^7-row columns:
+# numpy and pyarrow.compute release the GIL, so they are cut into row blocks / columns and run on a small thread pool.
+_POOL = ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1)), thread_name_prefix="ivj-host")
+_PAR_MIN_ROWS = 1 << 18          # below this a single thread is faster
+_BLOCK_ROWS = 1 << 20
+
+
+def _blocks(n: int):
+    k = max(1, min(_POOL._max_workers * 2, (n + _BLOCK_ROWS - 1) // _BLOCK_ROWS))
+    step = (n + k - 1) // k
+    return [(lo, min(n, lo + step)) for lo in range(0, n, step)]
+
+
+def _pmap(fn, items):
+    items = list(items)
+    if len(items) <= 1:
+        return [fn(x) for x in items]
+    return list(_POOL.map(fn, items))
+
 
 # "pyarrow.RecordBatchReader": the lazy result as an ArrowArrayStream (the streaming path; see _streaming.py)
 OUTPUT_TYPES = ("polars.LazyFrame", "polars.DataFrame", "pandas.DataFrame", "datafusion.DataFrame", "pyarrow.Table", "pyarrow.RecordBatchReader")
@@ -71,27 +93,79 @@ def _coord_to_i32(col: pa.ChunkedArray, name: str) -> np.ndarray:
     a = arr.to_numpy(zero_copy_only=False)                   # a view of the Arrow buffer for a null-free primitive array
     if a.dtype == np.int32:
         return a
-    if len(a):
-        # range check + narrowing in numpy: three streaming passes (min, max, astype) instead of Arrow's checked cast
-        lo, hi = int(a.min()), int(a.max())
-        if lo < -(1 << 31) or hi > (1 << 31) - 1:
-            bad = hi if hi > (1 << 31) - 1 else lo
-            raise ValueError(f"column '{name}' does not fit int32 coordinates (reference limit): Integer value {bad} not in range: "
-                             f"{-(1 << 31)} to {(1 << 31) - 1}")
-    return a.astype(np.int32)
+    out = np.empty(len(a), np.int32)
+    if len(a) == 0:
+        return out
+
+    def block(r):
+        # range check + narrowing of one row block: min, max and the narrowing copy while the block is in cache
+        lo, hi = r
+        v = a[lo:hi]
+        mn, mx = int(v.min()), int(v.max())
+        out[lo:hi] = v                                        # numpy's unchecked narrowing store (the check is the min / max)
+        return mn, mx
+    res = _pmap(block, _blocks(len(a)) if len(a) >= _PAR_MIN_ROWS else [(0, len(a))])
+    lo, hi = min(r[0] for r in res), max(r[1] for r in res)
+    if lo < -(1 << 31) or hi > (1 << 31) - 1:
+        bad = hi if hi > (1 << 31) - 1 else lo
+        raise ValueError(f"column '{name}' does not fit int32 coordinates (reference limit): Integer value {bad} not in range: "
+                         f"{-(1 << 31)} to {(1 << 31) - 1}")
+    return out
 
 
-def _dict_encode(col: pa.ChunkedArray):
-    """chrom column (string / large_string / string_view / dictionary of those, any chunking) -> (dictionary values,
-    int32-ish indices with nulls for null chroms), both plain Arrays."""
-    arr = col.combine_chunks() if isinstance(col, pa.ChunkedArray) else col
-    if isinstance(arr, pa.ChunkedArray):                     # zero chunks
-        arr = pa.array([], col.type)
-    if not pa.types.is_dictionary(arr.type):
-        if not (pa.types.is_string(arr.type) or pa.types.is_large_string(arr.type)):
-            arr = pc.cast(arr, pa.large_string())
-        arr = pc.dictionary_encode(arr)
-    return arr.dictionary, arr.indices
+def _encode_chrom(col: pa.ChunkedArray):
+    """chrom column (string / large_string / string_view / dictionary of those, any chunking) -> (dictionary: large_string
+    Array of the values that OCCUR, ids: int32 numpy array, -1 for a null chrom).
+
+    Dictionary-typed input (pandas categoricals, polars Categorical / Enum, Arrow dictionaries) is never hashed: its indices
+    are remapped through a table of the dictionary's size; entries no row refers to are dropped (a global string cache can
+    carry thousands of them).  String input is dictionary-encoded block by block on the thread pool (one hash pass over the
+    strings, pyarrow releases the GIL) and the small block dictionaries are unified."""
+    chunks = col.chunks if isinstance(col, pa.ChunkedArray) else [col]
+    n = sum(len(c) for c in chunks)
+    if n == 0:
+        return pa.array([], pa.large_string()), np.empty(0, np.int32)
+    pieces = []                                               # row blocks as zero-copy slices
+    for c in chunks:
+        for lo, hi in (_blocks(len(c)) if len(c) >= _PAR_MIN_ROWS else ([(0, len(c))] if len(c) else [])):
+            pieces.append(c.slice(lo, hi - lo))
+
+    def encode(piece):
+        if not pa.types.is_dictionary(piece.type):
+            if not (pa.types.is_string(piece.type) or pa.types.is_large_string(piece.type)):
+                piece = pc.cast(piece, pa.large_string())
+            piece = pc.dictionary_encode(piece)
+        d = pc.cast(piece.dictionary, pa.large_string())
+        idx = piece.indices
+        iv = idx.to_numpy(zero_copy_only=False)
+        if idx.null_count:
+            iv = np.where(pc.is_null(idx).to_numpy(zero_copy_only=False), -1, np.nan_to_num(iv, nan=0)).astype(np.int64)
+        else:
+            iv = iv.astype(np.int64, copy=False)
+        return d, iv
+    enc = _pmap(encode, pieces)
+    # unify the block dictionaries (tiny), keep the values that occur, remap every block's indices
+    all_d = pa.concat_arrays([d for d, _ in enc])
+    u = pc.drop_null(pc.unique(all_d))
+    u = u.combine_chunks() if isinstance(u, pa.ChunkedArray) else u
+    remaps = []
+    for d, iv in enc:
+        r = pc.fill_null(pc.index_in(d, value_set=u), -1).to_numpy(zero_copy_only=False).astype(np.int32)
+        remaps.append(np.concatenate([r, np.array([-1], np.int32)]))          # last slot: null chrom
+
+    def remap(k):
+        g = remaps[k][enc[k][1]]                                              # -1 indexes the null slot
+        return g
+    ids = _pmap(remap, range(len(enc)))
+    ids = ids[0] if len(ids) == 1 else np.concatenate(ids)
+    seen = np.bincount(ids[ids >= 0], minlength=len(u)) > 0 if len(u) else np.zeros(0, bool)
+    if not seen.all():                                                         # dictionary entries no row uses
+        keep = np.nonzero(seen)[0]
+        new = np.full(len(u) + 1, -1, np.int32)
+        new[keep] = np.arange(len(keep), dtype=np.int32)
+        ids = new[ids]
+        u = u.take(pa.array(keep))
+    return u, ids.astype(np.int32, copy=False)
 
 
 def _as_string(col: pa.ChunkedArray) -> pa.ChunkedArray:
@@ -114,29 +188,34 @@ def encode_keys(t1: pa.Table, cols1, t2: pa.Table, cols2, with_dictionary: bool 
         for c in cols:
             if c not in t.column_names:
                 raise ValueError(f"column '{c}' not found in {t.column_names}")
-    # every side is dictionary-encoded ONCE (one hash pass over its strings); the two small dictionaries are merged into the
-    # shared one and the per-row ids are a numpy gather through the remap table -- no copy of the string columns, no second
-    # hash pass (10 M rows: 0.5 s -> 0.15 s on the build container)
-    d1, d2 = _dict_encode(t1.column(cols1[0])), _dict_encode(t2.column(cols2[0]))
-    u = pc.unique(pa.concat_arrays([pc.cast(d1[0], pa.large_string()), pc.cast(d2[0], pa.large_string())]))
-    u = pc.drop_null(u)
+    # every side is dictionary-encoded ONCE (string input: one hash pass, in row blocks on the thread pool; dictionary-typed
+    # input: no hashing at all); the two small dictionaries are merged into the shared one and the per-row ids are a numpy
+    # gather through the remap table
+    (d1, i1), (d2, i2) = _encode_chrom(t1.column(cols1[0])), _encode_chrom(t2.column(cols2[0]))
+    u = pc.unique(pa.concat_arrays([d1, d2]))
+    u = u.combine_chunks() if isinstance(u, pa.ChunkedArray) else u
     n_contigs = len(u)
 
-    def ids(d):
-        dictionary, indices = d
-        if len(indices) == 0:
+    def ids(d, i):
+        if len(i) == 0:
             return np.empty(0, np.int32)
-        remap = pc.fill_null(pc.index_in(pc.cast(dictionary, pa.large_string()), value_set=u), -1).to_numpy(zero_copy_only=False).astype(np.int32)
+        remap = pc.index_in(d, value_set=u).to_numpy(zero_copy_only=False).astype(np.int32)
         remap = np.concatenate([remap, np.array([-1], np.int32)])           # slot for null chroms
-        idx = pc.fill_null(indices, len(remap) - 1)
-        idx = idx.to_numpy(zero_copy_only=False)
-        return remap[idx]
+        if len(i) < _PAR_MIN_ROWS:
+            return remap[i]
+        out = np.empty(len(i), np.int32)
 
-    ch1, ch2 = d1, d2
-    side1 = (ids(ch1), _coord_to_i32(t1.column(cols1[1]), cols1[1]), _coord_to_i32(t1.column(cols1[2]), cols1[2]))
-    side2 = (ids(ch2), _coord_to_i32(t2.column(cols2[1]), cols2[1]), _coord_to_i32(t2.column(cols2[2]), cols2[2]))
+        def block(r):
+            out[r[0]:r[1]] = remap[i[r[0]:r[1]]]
+        _pmap(block, _blocks(len(i)))
+        return out
+
+    (c1s, c1e), (c2s, c2e) = _pmap(lambda tc: (_coord_to_i32(tc[0].column(tc[1][1]), tc[1][1]), _coord_to_i32(tc[0].column(tc[1][2]), tc[1][2])),
+                                   [(t1, cols1), (t2, cols2)])
+    side1 = (ids(d1, i1), c1s, c1e)
+    side2 = (ids(d2, i2), c2s, c2e)
     if with_dictionary:
-        return side1, side2, n_contigs, (u.combine_chunks() if isinstance(u, pa.ChunkedArray) else u)
+        return side1, side2, n_contigs, u
     return side1, side2, n_contigs
 
 
@@ -161,16 +240,47 @@ def encode_frame(t: pa.Table, cols):
     return side, len(u), u
 
 
-def take_rows(t: pa.Table, idx: np.ndarray, nullable: bool = False) -> pa.Table:
-    """Gather rows; with nullable=True an index of -1 yields an all-null row."""
+def _chrom_from_ids(ids: np.ndarray, dictionary: pa.Array, typ: pa.DataType, null_mask=None) -> pa.Array:
+    """The chrom column of a result from per-row dictionary ids (-1 = null): a gather out of the (cache-resident) dictionary
+    instead of a string take out of the 10^7-row input column."""
+    mask = ids < 0
+    if null_mask is not None:
+        mask = mask | null_mask
+    any_null = bool(mask.any())
+    safe = np.where(mask, 0, ids) if any_null else ids
+    if pa.types.is_dictionary(typ):
+        d = pc.cast(dictionary, typ.value_type)
+        ind = pa.array(safe.astype(np.int32, copy=False), type=pa.int32(), mask=mask if any_null else None)
+        return pc.cast(pa.DictionaryArray.from_arrays(ind, d), typ)
+
+    def block(r):
+        lo, hi = r
+        ind = pa.array(safe[lo:hi].astype(np.int32, copy=False), type=pa.int32(), mask=mask[lo:hi] if any_null else None)
+        return pc.cast(pc.take(dictionary, ind), typ)
+    parts = _pmap(block, _blocks(len(ids)) if len(ids) >= _PAR_MIN_ROWS else [(0, len(ids))])
+    return parts[0] if len(parts) == 1 else pa.chunked_array(parts, type=typ)
+
+
+def take_rows(t: pa.Table, idx: np.ndarray, nullable: bool = False, chrom=None) -> pa.Table:
+    """Gather rows; with nullable=True an index of -1 yields an all-null row.  Columns are gathered in parallel on the thread
+    pool.  chrom = (column name, per-row dictionary ids of ``t``, dictionary): that column is rebuilt from the dictionary."""
     if nullable:
         mask = idx < 0
         arr = pa.array(np.where(mask, 0, idx), type=pa.int32(), mask=mask)
     else:
+        mask = None
         arr = pa.array(idx, type=pa.int32())
     if t.num_rows == 0 and nullable:
         return pa.table({n: pa.nulls(len(idx), t.schema.field(n).type) for n in t.column_names})
-    return t.take(arr)
+
+    def one(name):
+        if chrom is not None and name == chrom[0] and t.num_rows:
+            ids = chrom[1][np.where(mask, 0, idx)] if nullable else chrom[1][idx]
+            return _chrom_from_ids(ids, chrom[2], t.schema.field(name).type, mask)
+        return t.column(name).take(arr)
+    names = t.column_names
+    cols = _pmap(one, names) if len(idx) >= _PAR_MIN_ROWS else [one(n) for n in names]
+    return pa.Table.from_arrays(cols, names=names)
 
 
 def _device_takeable(col: pa.ChunkedArray) -> bool:

@@ -121,16 +121,21 @@ def _overlap_device_rows(t1, t2, cols1, cols2, suffixes, zero_based) -> pa.Table
 
 # ---- result assembly (shared by the eager and the streaming paths) ------------------------------------------------
 
-def _assemble_overlap(t1, t2, p_idx, b_idx, mode, distinct_output, suffixes) -> pa.Table:
-    """src/operation.rs:272-301: df1 columns + suffixes[0], df2 columns + suffixes[1]; "left": df1 columns only."""
+def _assemble_overlap(t1, t2, p_idx, b_idx, mode, distinct_output, suffixes, keys=None) -> pa.Table:
+    """src/operation.rs:272-301: df1 columns + suffixes[0], df2 columns + suffixes[1]; "left": df1 columns only.
+    keys = (chrom column of df1, its per-row dictionary ids, chrom column of df2, its ids, the shared dictionary) from the key
+    encoding: the two chrom columns of the result are then gathered out of the dictionary, not out of the input strings."""
+    k1 = (keys[0], keys[1], keys[4]) if keys is not None else None
+    k2 = (keys[2], keys[3], keys[4]) if keys is not None else None
     if mode == OverlapOutputMode.Left:
         if distinct_output:
             p_idx = np.unique(p_idx)
-        return A.take_rows(t1, p_idx)
-    return A.hconcat(A.with_suffix(A.take_rows(t1, p_idx), suffixes[0]), A.with_suffix(A.take_rows(t2, b_idx), suffixes[1]))
+        return A.take_rows(t1, p_idx, chrom=k1)
+    left, right = A._pmap(lambda a: A.take_rows(a[0], a[1], chrom=a[2]), [(t1, p_idx, k1), (t2, b_idx, k2)])
+    return A.hconcat(A.with_suffix(left, suffixes[0]), A.with_suffix(right, suffixes[1]))
 
 
-def _assemble_nearest(t1, t2, idx, dist, nf, suffixes, distance) -> pa.Table:
+def _assemble_nearest(t1, t2, idx, dist, nf, suffixes, distance, keys=None) -> pa.Table:
     """src/operation.rs:170-197: one output row per filled slot; rows without any candidate keep a single null slot."""
     n1 = t1.num_rows
     slots = np.maximum(nf, 1)
@@ -139,7 +144,9 @@ def _assemble_nearest(t1, t2, idx, dist, nf, suffixes, distance) -> pa.Table:
     within = np.arange(rep.shape[0], dtype=np.int64) - np.repeat(first, slots)
     b_sel = idx[rep, within] if n1 else np.empty(0, np.int32)
     d_sel = dist[rep, within] if n1 else np.empty(0, np.int64)
-    res = A.hconcat(A.with_suffix(A.take_rows(t1, rep), suffixes[0]), A.with_suffix(A.take_rows(t2, b_sel, nullable=True), suffixes[1]))
+    k1 = (keys[0], keys[1], keys[4]) if keys is not None else None
+    k2 = (keys[2], keys[3], keys[4]) if keys is not None else None
+    res = A.hconcat(A.with_suffix(A.take_rows(t1, rep, chrom=k1), suffixes[0]), A.with_suffix(A.take_rows(t2, b_sel, nullable=True, chrom=k2), suffixes[1]))
     if distance:
         res = res.append_column("distance", pa.array(d_sel, type=pa.int64(), mask=(b_sel < 0)))
     return res
@@ -227,8 +234,8 @@ def _prepare(df1, df2, cols1, cols2):
     cols1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
     cols2 = list(DEFAULT_INTERVAL_COLUMNS if cols2 is None else cols2)
     t1, t2 = A.to_arrow(df1), A.to_arrow(df2)
-    probe, build, n_contigs = A.encode_keys(t1, cols1, t2, cols2)
-    return t1, t2, probe, build, n_contigs
+    probe, build, n_contigs, dictionary = A.encode_keys(t1, cols1, t2, cols2, with_dictionary=True)
+    return t1, t2, probe, build, n_contigs, (cols1[0], probe[0], cols2[0], build[0], dictionary)
 
 
 def overlap(
@@ -268,7 +275,7 @@ def overlap(
         lazy = overlap_batches(df1, df2, suffixes, cols1, cols2, batch_rows=_low_memory_batch_rows(), limit=limit,
                                overlap_output=overlap_output, distinct_output=distinct_output, as_reader=True)
         return lazy if output_type == "pyarrow.RecordBatchReader" else A.from_arrow(lazy.read_all(), output_type, zero_based)
-    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    t1, t2, probe, build, n_contigs, keys = _prepare(df1, df2, cols1, cols2)
     if mode == OverlapOutputMode.Join and not low_memory and _materialize_on_device():
         return A.from_arrow(_overlap_device_rows(t1, t2, cols1, cols2, suffixes, zero_based), output_type, zero_based)
     if low_memory:
@@ -280,7 +287,7 @@ def overlap(
         b_idx = np.concatenate([b for _, b in parts]) if parts else np.empty(0, np.int32)
     else:
         p_idx, b_idx = default_engine().overlap(probe, build, strict=zero_based, n_contigs=n_contigs)
-    return A.from_arrow(_assemble_overlap(t1, t2, p_idx, b_idx, mode, distinct_output, suffixes), output_type, zero_based)
+    return A.from_arrow(_assemble_overlap(t1, t2, p_idx, b_idx, mode, distinct_output, suffixes, keys), output_type, zero_based)
 
 
 def nearest(
@@ -309,10 +316,10 @@ def nearest(
         lazy = nearest_batches(df1, df2, suffixes, cols1, cols2, k=k, overlap=overlap, distance=distance,
                                batch_rows=_low_memory_batch_rows(), limit=limit, as_reader=True)
         return lazy if output_type == "pyarrow.RecordBatchReader" else A.from_arrow(lazy.read_all(), output_type, zero_based)
-    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    t1, t2, probe, build, n_contigs, keys = _prepare(df1, df2, cols1, cols2)
     idx, dist, nf = default_engine().nearest(probe, build, strict=zero_based, n_contigs=n_contigs, k=int(k),
                                              include_overlaps=bool(overlap))
-    return A.from_arrow(_assemble_nearest(t1, t2, idx, dist, nf, suffixes, distance), output_type, zero_based)
+    return A.from_arrow(_assemble_nearest(t1, t2, idx, dist, nf, suffixes, distance, keys), output_type, zero_based)
 
 
 def count_overlaps(
@@ -339,7 +346,7 @@ def count_overlaps(
         lazy = count_overlaps_batches(df1, df2, suffixes, cols1, cols2, batch_rows=_low_memory_batch_rows(), limit=limit,
                                       naive_query=naive_query, as_reader=True)
         return lazy if output_type == "pyarrow.RecordBatchReader" else A.from_arrow(lazy.read_all(), output_type, zero_based)
-    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    t1, t2, probe, build, n_contigs, _keys = _prepare(df1, df2, cols1, cols2)
     counts = default_engine().count_overlaps(probe, build, strict=zero_based, n_contigs=n_contigs)
     c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
     return A.from_arrow(_assemble_count(t1, counts, naive_query, c1, suffixes), output_type, zero_based)
@@ -363,7 +370,7 @@ def coverage(
     Output = df1 columns + ``coverage`` (Int64), df1 row order kept (range_op_helpers.py:214-222, 317-318)."""
     _validate_overlap_input(cols1, cols2, on_cols, suffixes, output_type)
     zero_based = validate_coordinate_systems(df1, df2)
-    t1, t2, probe, build, n_contigs = _prepare(df1, df2, cols1, cols2)
+    t1, t2, probe, build, n_contigs, _keys = _prepare(df1, df2, cols1, cols2)
     cov = default_engine().coverage(probe, build, strict=zero_based, n_contigs=n_contigs)
     return A.from_arrow(t1.append_column("coverage", pa.array(cov, type=pa.int64())), output_type, zero_based)
 
@@ -489,7 +496,7 @@ def subtract(
     (range_op_helpers.py:140-158)."""
     _validate_overlap_input(cols1, cols2, None, ("_1", "_2"), output_type)
     zero_based = validate_coordinate_systems(df1, df2)
-    t1, t2, left, right, n_contigs = _prepare(df1, df2, cols1, cols2)
+    t1, t2, left, right, n_contigs, _keys = _prepare(df1, df2, cols1, cols2)
     c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
     row, s, e = default_engine().subtract(left, right, strict=zero_based, n_contigs=n_contigs)
     res = A.take_rows(t1, row)

@@ -448,3 +448,59 @@ def test_sort_scan_boundary_cases(engine, case):
         res = pb.coverage(_frame(case["df1"], case["zero_based"], case.get("dtype")), _frame(case["df2"], case["zero_based"], case.get("dtype")),
                           output_type="pandas.DataFrame")
         assert res["coverage"].tolist() == case["coverage"] and res["coverage"].dtype == np.int64
+
+
+# ---- key encoding: dictionary-typed chroms, unused entries, narrow index types, chunked and null chroms ----------------
+
+def test_encode_keys_dictionary_inputs_and_unused_entries():
+    """A dictionary-typed chrom column is remapped, never hashed; entries no row uses do not become contigs (a pandas
+    categorical or a polars string cache can carry thousands); an int8-indexed dictionary of 128 values works (the null
+    slot used to overflow the index type); chunked columns and null chroms keep their rows apart."""
+    from polars_bio_amd import _arrow as A
+    names = [f"c{i:03d}" for i in range(128)]
+    idx = pa.array(np.arange(128, dtype=np.int8).repeat(2), type=pa.int8())
+    d1 = pa.DictionaryArray.from_arrays(idx, pa.array(names))
+    t1 = pa.table({"chrom": d1, "start": np.arange(256, dtype=np.int64), "end": np.arange(256, dtype=np.int64) + 5})
+    t2 = pa.table({"chrom": pa.chunked_array([pa.array(["c005", None]), pa.array(["zz", "c127"])]), "start": pa.array([0, 1, 2, 3], pa.int32()),
+                   "end": pa.array([9, 9, 9, 9], pa.int32())})
+    (c1, s1, e1), (c2, s2, e2), nc, u = A.encode_keys(t1, ["chrom", "start", "end"], t2, ["chrom", "start", "end"], with_dictionary=True)
+    assert nc == 129 and len(u) == 129 and set(u.to_pylist()) == set(names) | {"zz"}
+    ul = u.to_pylist()
+    assert [ul[i] for i in c1] == [names[i // 2] for i in range(256)]
+    assert c2[1] == -1 and [ul[c2[0]], ul[c2[2]], ul[c2[3]]] == ["c005", "zz", "c127"]
+    assert s1.dtype == np.int32 and (s1 == np.arange(256)).all() and e2.dtype == np.int32
+    # a dictionary with many entries no row refers to: only the used ones become contigs
+    big = pa.DictionaryArray.from_arrays(pa.array([3, 3, 700], pa.int32()), pa.array([f"k{i}" for i in range(1000)]))
+    tb = pa.table({"chrom": big, "start": [1, 2, 3], "end": [4, 5, 6]})
+    (cb, _, _), (cb2, _, _), ncb, ub = A.encode_keys(tb, ["chrom", "start", "end"], tb, ["chrom", "start", "end"], with_dictionary=True)
+    assert ncb == 2 and sorted(ub.to_pylist()) == ["k3", "k700"] and (cb == cb2).all() and cb[0] == cb[1] != cb[2]
+    with pytest.raises(ValueError, match="does not fit int32"):
+        A.encode_keys(pa.table({"chrom": ["a"], "start": [1 << 40], "end": [5]}), ["chrom", "start", "end"], tb, ["chrom", "start", "end"])
+
+
+def test_overlap_with_categorical_and_large_parallel_inputs(engine):
+    """Frames above the parallel threshold (key encoding, narrowing and assembly in row blocks on the thread pool) with a
+    pandas categorical chrom on one side give the same rows as small sequential calls; the chrom columns of the result are
+    rebuilt from the shared dictionary and keep their input types."""
+    from polars_bio_amd import _arrow as A
+    rng = np.random.default_rng(4)
+    n1, n2 = (1 << 18) + 1000, 3000
+    ch = np.array(["chr1", "chr2", "chrX"], dtype=object)
+    df1 = pd.DataFrame({"chrom": pd.Categorical(ch[rng.integers(0, 3, n1)], categories=["chrU", "chr2", "chrX", "chr1"]),
+                        "start": rng.integers(0, 1_000_000, n1), "x": np.arange(n1)})
+    df1["end"] = df1["start"] + rng.integers(1, 50, n1)
+    df2 = pd.DataFrame({"chrom": ch[rng.integers(0, 3, n2)], "start": rng.integers(0, 1_000_000, n2), "y": np.arange(n2)})
+    df2["end"] = df2["start"] + rng.integers(1, 300, n2)
+    for d in (df1, df2):
+        d.attrs["coordinate_system_zero_based"] = True
+    res = pb.overlap(df1, df2, output_type="pandas.DataFrame")
+    assert len(res) > 1000
+    assert (res["chrom_1"].astype(str) == res["chrom_2"].astype(str)).all()
+    assert isinstance(res["chrom_1"].dtype, pd.CategoricalDtype) and res["chrom_2"].dtype == object
+    assert (res["start_1"] < res["end_2"]).all() and (res["start_2"] < res["end_1"]).all()
+    # row identity: x / y pick the same key values out of the inputs
+    assert (df1["start"].to_numpy()[res["x_1"]] == res["start_1"].to_numpy()).all()
+    assert (df2["end"].to_numpy()[res["y_2"]] == res["end_2"].to_numpy()).all()
+    assert (df1["chrom"].astype(str).to_numpy()[res["x_1"]] == res["chrom_1"].astype(str).to_numpy()).all()
+    cnt = pb.count_overlaps(df1, df2, output_type="pandas.DataFrame")
+    assert int(cnt["count"].sum()) == len(res)
