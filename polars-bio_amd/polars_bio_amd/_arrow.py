@@ -31,22 +31,28 @@ except ImportError:
 
 # Host stages of the front door (key encoding, coordinate narrowing, row assembly) are memory-bound loops over 10^7-row columns:
 # numpy and pyarrow.compute release the GIL, so they are cut into row blocks / columns and run on a small thread pool.
-_POOL = ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1)), thread_name_prefix="ivj-host")
+_NT = max(1, min(int(os.environ.get("IVJ_HOST_THREADS", "32")), os.cpu_count() or 1))
+# three levels (sides -> columns -> row blocks), one pool each: a task only ever waits for tasks of a DEEPER level, so a
+# bounded pool cannot deadlock on nested waits
+_POOLS = (ThreadPoolExecutor(max_workers=2, thread_name_prefix="ivj-host-side"),
+          ThreadPoolExecutor(max_workers=max(2, min(16, _NT)), thread_name_prefix="ivj-host-col"),
+          ThreadPoolExecutor(max_workers=_NT, thread_name_prefix="ivj-host-blk"))
+SIDES, COLUMNS, BLOCKS = 0, 1, 2
 _PAR_MIN_ROWS = 1 << 18          # below this a single thread is faster
 _BLOCK_ROWS = 1 << 20
 
 
 def _blocks(n: int):
-    k = max(1, min(_POOL._max_workers * 2, (n + _BLOCK_ROWS - 1) // _BLOCK_ROWS))
+    k = max(1, min(_NT * 2, (n + _BLOCK_ROWS - 1) // _BLOCK_ROWS))
     step = (n + k - 1) // k
     return [(lo, min(n, lo + step)) for lo in range(0, n, step)]
 
 
-def _pmap(fn, items):
+def _pmap(fn, items, level=BLOCKS):
     items = list(items)
     if len(items) <= 1:
         return [fn(x) for x in items]
-    return list(_POOL.map(fn, items))
+    return list(_POOLS[level].map(fn, items))
 
 
 # "pyarrow.RecordBatchReader": the lazy result as an ArrowArrayStream (the streaming path; see _streaming.py)
@@ -153,19 +159,27 @@ def _encode_chrom(col: pa.ChunkedArray):
         r = pc.fill_null(pc.index_in(d, value_set=u), -1).to_numpy(zero_copy_only=False).astype(np.int32)
         remaps.append(np.concatenate([r, np.array([-1], np.int32)]))          # last slot: null chrom
 
+    starts = np.concatenate([[0], np.cumsum([len(iv) for _, iv in enc])]).astype(np.int64)
+    ids = np.empty(int(starts[-1]), np.int32)
+    nu = len(u)
+
     def remap(k):
         g = remaps[k][enc[k][1]]                                              # -1 indexes the null slot
-        return g
-    ids = _pmap(remap, range(len(enc)))
-    ids = ids[0] if len(ids) == 1 else np.concatenate(ids)
-    seen = np.bincount(ids[ids >= 0], minlength=len(u)) > 0 if len(u) else np.zeros(0, bool)
+        ids[starts[k]:starts[k + 1]] = g
+        return np.bincount(g + 1, minlength=nu + 1)[1:] > 0                   # which dictionary values this block uses
+    seen = np.zeros(nu, bool)
+    for sk in _pmap(remap, range(len(enc))):
+        seen |= sk
     if not seen.all():                                                         # dictionary entries no row uses
         keep = np.nonzero(seen)[0]
-        new = np.full(len(u) + 1, -1, np.int32)
+        new = np.full(nu + 1, -1, np.int32)
         new[keep] = np.arange(len(keep), dtype=np.int32)
-        ids = new[ids]
+
+        def renumber(r):
+            ids[r[0]:r[1]] = new[ids[r[0]:r[1]]]
+        _pmap(renumber, _blocks(len(ids)) if len(ids) >= _PAR_MIN_ROWS else [(0, len(ids))])
         u = u.take(pa.array(keep))
-    return u, ids.astype(np.int32, copy=False)
+    return u, ids
 
 
 def _as_string(col: pa.ChunkedArray) -> pa.ChunkedArray:
@@ -211,7 +225,7 @@ def encode_keys(t1: pa.Table, cols1, t2: pa.Table, cols2, with_dictionary: bool 
         return out
 
     (c1s, c1e), (c2s, c2e) = _pmap(lambda tc: (_coord_to_i32(tc[0].column(tc[1][1]), tc[1][1]), _coord_to_i32(tc[0].column(tc[1][2]), tc[1][2])),
-                                   [(t1, cols1), (t2, cols2)])
+                                   [(t1, cols1), (t2, cols2)], SIDES)
     side1 = (ids(d1, i1), c1s, c1e)
     side2 = (ids(d2, i2), c2s, c2e)
     if with_dictionary:
@@ -279,7 +293,7 @@ def take_rows(t: pa.Table, idx: np.ndarray, nullable: bool = False, chrom=None) 
             return _chrom_from_ids(ids, chrom[2], t.schema.field(name).type, mask)
         return t.column(name).take(arr)
     names = t.column_names
-    cols = _pmap(one, names) if len(idx) >= _PAR_MIN_ROWS else [one(n) for n in names]
+    cols = _pmap(one, names, COLUMNS) if len(idx) >= _PAR_MIN_ROWS else [one(n) for n in names]
     return pa.Table.from_arrays(cols, names=names)
 
 

@@ -131,7 +131,7 @@ def _assemble_overlap(t1, t2, p_idx, b_idx, mode, distinct_output, suffixes, key
         if distinct_output:
             p_idx = np.unique(p_idx)
         return A.take_rows(t1, p_idx, chrom=k1)
-    left, right = A._pmap(lambda a: A.take_rows(a[0], a[1], chrom=a[2]), [(t1, p_idx, k1), (t2, b_idx, k2)])
+    left, right = A._pmap(lambda a: A.take_rows(a[0], a[1], chrom=a[2]), [(t1, p_idx, k1), (t2, b_idx, k2)], A.SIDES)
     return A.hconcat(A.with_suffix(left, suffixes[0]), A.with_suffix(right, suffixes[1]))
 
 

@@ -40,7 +40,7 @@ def main():
     for d in (d1, d2):
         d.attrs["coordinate_system_zero_based"] = True
     pb.overlap(t1.slice(0, 1000), t2, output_type="pyarrow.Table")            # engine start-up, library load
-    print(f"# host threads of the front door: {A._POOL._max_workers} (cpu_count {os.cpu_count()})")
+    print(f"# host threads of the front door: {A._NT} row-block workers (cpu_count {os.cpu_count()})")
     for mode in ("host", "device"):
         pb.set_option("ivj.materialize", mode)
         for label, a, bb, out in (("arrow(string chrom) -> arrow", t1, t2, "pyarrow.Table"), ("arrow(dictionary chrom) -> arrow", dict1, dict2, "pyarrow.Table"),
