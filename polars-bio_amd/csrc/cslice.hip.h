@@ -427,7 +427,9 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
             const int il = j * CS_THREADS + tid;
             if (il < tile_n && !(ablate & 256)) {
                 cs_rec v; v.x = l_rs[il]; v.y = l_re[il]; v.z = l_rr[il];
-                *reinterpret_cast<cs_rec*>(out + 3 * (int64_t)((uint32_t)il + delta[l_d[il]])) = v;
+                uint32_t oi = (uint32_t)il + delta[l_d[il]];
+                if (ablate & 2048) oi &= (1u << 22) - 1u;                      // profiling only: every store lands in the first 48 MB (address-translation probe)
+                *reinterpret_cast<cs_rec*>(out + 3 * (int64_t)oi) = v;
             }
         }
         // no barrier here: the next tile's barrier (A) separates this copy-out from the next placement

@@ -131,7 +131,7 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     else { if (P.part_items == 8) IVJ_CS_SCATTER(false, 8); else IVJ_CS_SCATTER(false, 4); }
 #undef IVJ_CS_SCATTER
     t_end(ctx);
-    if (ctx->sl_env_ablate & (256 | 1024)) { *n_pairs = 0; HIP_TRY(hipStreamSynchronize(ctx->stream)); return IVJ_OK; }   // profiling: the records are not usable
+    if (ctx->sl_env_ablate & (256 | 1024 | 2048)) { *n_pairs = 0; HIP_TRY(hipStreamSynchronize(ctx->stream)); return IVJ_OK; }   // profiling: the records are not usable
     HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
     CsJoinArgs A;
     A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta;

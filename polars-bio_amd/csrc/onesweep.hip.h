@@ -182,16 +182,28 @@ __global__ __launch_bounds__(OS_THREADS) void k_os_scatter(const int32_t* __rest
     unsigned short* my = wcnt + w * OS_RADIX;
     // wavefront w owns elements [w * 256, (w + 1) * 256) of the sub-tile: item j of lane l = w * 256 + j * 64 + l
     const int el0 = w * (OS_ITEMS * kWave) + lane;
+    // the next sub-tile's records are requested before this one is ranked: a pass walks ~5 sub-tiles per workgroup with seven
+    // barriers each and nothing else resident on the CU, so an exposed load is a stalled CU
+    int4 nxt[OS_ITEMS];
+    auto load_tile = [&](int64_t tb) {
+        const int tn = (int)((cend - tb) < (int64_t)OS_TILE ? (cend - tb) : (int64_t)OS_TILE);
+#pragma unroll
+        for (int j = 0; j < OS_ITEMS; ++j) {
+            const int il = el0 + j * kWave;
+            nxt[j] = il < tn ? os_load_record(FIRST, contig, start, end, row_id, src, tb + il, n_contigs) : make_int4(0, 0, 0, 0);
+        }
+    };
+    if (cbase < cend) load_tile(cbase);
     for (int64_t tbase = cbase; tbase < cend; tbase += OS_TILE) {
         const int tile_n = (int)((cend - tbase) < (int64_t)OS_TILE ? (cend - tbase) : (int64_t)OS_TILE);
         int4 r[OS_ITEMS];
         uint32_t d[OS_ITEMS], rank[OS_ITEMS];
 #pragma unroll
         for (int j = 0; j < OS_ITEMS; ++j) {
-            const int il = el0 + j * kWave;
-            r[j] = il < tile_n ? os_load_record(FIRST, contig, start, end, row_id, src, tbase + il, n_contigs) : make_int4(0, 0, 0, 0);
+            r[j] = nxt[j];
             d[j] = (uint32_t)((os_key(kg, (uint32_t)r[j].w, r[j].x) >> shift) & (OS_RADIX - 1));
         }
+        if (tbase + OS_TILE < cend) load_tile(tbase + OS_TILE);
         // stable rank inside (wavefront, digit): match-any ballots against the wavefront's private counter row
 #pragma unroll
         for (int j = 0; j < OS_ITEMS; ++j) {

@@ -182,10 +182,12 @@ __global__ void k_cov_meta(const int32_t* __restrict__ seg, const uint32_t* __re
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_contigs) return;
     const int a = seg[c], b = seg[c + 1];
-    int ca = 0, cb = 0, shift = 0;
+    // clusters of the contigs before this one: also the slot base of a contig WITHOUT rows, so that the slot bases stay
+    // monotonic (k_cov_records finds a slot's contig by a bound search over them) whatever ids the probe-only chroms have
+    int ca = a > 0 ? (int)cid1[a - 1] : 0, cb = ca, shift = 0;
     uint32_t ulo = 0, uhi = 0;
     if (b > a) {
-        ca = (int)cid1[a] - 1; cb = (int)cid1[b - 1];
+        cb = (int)cid1[b - 1];
         const unsigned long long lo = cov_ux(m_start[ca]), hi = cov_E<STRICT>(m_start, m_end, cb - 1);
         ulo = (uint32_t)lo; uhi = hi > 0xffffffffull ? 0xffffffffu : (uint32_t)hi;
         unsigned long long cap = 2ull * (unsigned long long)(cb - ca);
@@ -460,11 +462,12 @@ __global__ void k_sub_meta(const int32_t* __restrict__ seg, const uint32_t* __re
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_contigs) return;
     const int a = seg[c], b = seg[c + 1];
-    int ua = 0, ub = 0, shift = 0;
+    // union intervals of the contigs before this one (also for a contig without rows: monotonic slot bases, see k_cov_meta)
+    int ua = (int)newidx[a > 0 ? cid1[a - 1] : 0u], ub = ua, shift = 0;
     long long lo = 0;
     unsigned long long span = 0;
     if (b > a) {
-        ua = (int)newidx[cid1[a] - 1u]; ub = (int)newidx[cid1[b - 1]];
+        ub = (int)newidx[cid1[b - 1]];
         if (ub > ua) {
             lo = u_start[ua];
             span = (unsigned long long)(u_end[ub - 1] - lo);

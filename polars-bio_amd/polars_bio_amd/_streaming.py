@@ -97,6 +97,23 @@ def source_schema(df) -> Optional[pa.Schema]:
     if isinstance(df, str) and df.endswith(".parquet"):
         import pyarrow.parquet as pq
         return pq.read_schema(df)
+    if isinstance(df, str) and (df.endswith(".csv") or df.endswith(".bed")):
+        # the streaming reader infers the types from its first block: opening it yields the schema, nothing is joined
+        import pyarrow.csv as pcsv
+        if df.endswith(".bed"):
+            rd = pcsv.open_csv(df, read_options=pcsv.ReadOptions(column_names=["chrom", "start", "end"]), parse_options=pcsv.ParseOptions(delimiter="\t"))
+        else:
+            rd = pcsv.open_csv(df)
+        try:
+            return rd.schema
+        finally:
+            rd.close()
+    if A.pl is not None and isinstance(df, (A.pl.DataFrame, A.pl.LazyFrame)):
+        try:
+            frame = df if isinstance(df, A.pl.DataFrame) else df.limit(0).collect()
+            return frame.head(0).to_arrow().schema
+        except Exception:
+            return None
     if hasattr(df, "__arrow_c_schema__"):
         try:
             return pa.schema(df)

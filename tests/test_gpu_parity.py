@@ -941,3 +941,24 @@ def test_host_result_larger_than_available_memory_is_refused(eng, monkeypatch):
     monkeypatch.delenv("IVJ_HOST_MEM_AVAILABLE")
     p2, b2 = eng.overlap(probe, build, True, 1)
     assert (p2 == p).all() and (b2 == b).all()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_coverage_subtract_with_probe_only_contigs_interleaved(eng, strict):
+    """The shared dictionary holds chroms that only the probe side uses, with ids BETWEEN and ABOVE populated ones: the slot
+    bases of the coverage / subtract grids must stay monotonic (a contig without build rows continues from the previous
+    contig's clusters), otherwise slots of populated contigs resolve to an empty one."""
+    rng = np.random.default_rng(808)
+    nc = 9
+    populated = np.array([1, 4, 5, 8], np.int32)                     # 0, 2, 3, 6, 7 hold no build rows
+    b = random_side(rng, 6000, 1, 400_000, 300)
+    build = (populated[rng.integers(0, len(populated), 6000)], b[1], b[2])
+    probe = random_side(rng, 20000, nc + 1, 400_000, 900)
+    exp = O.np_coverage_fast(O.Side(*probe), O.Side(*build), strict)
+    for pm in (0, 1):
+        assert (eng.coverage(probe, build, strict, nc, partition_mode=pm) == exp).all(), pm
+    er, es, ee = O.np_subtract(O.Side(*probe), O.Side(*build), strict)
+    for pm in (0, 1):
+        gr, gs, ge = eng.subtract(probe, build, strict, nc, partition_mode=pm)
+        assert (gr == er).all() and (gs == es).all() and (ge == ee).all(), pm
+    assert (eng.count_overlaps(probe, build, strict, nc) == O.count_overlaps_fast(O.Index(O.Side(*build), nc), O.Side(*probe), strict)).all()

@@ -296,3 +296,13 @@ def test_stream_outlives_its_engine_without_touching_freed_memory():
         st.flush()
     st.close()
     st.close()
+
+
+def test_lazy_reader_schema_of_a_csv_source_without_rows(engine, tmp_path):
+    """A CSV / BED path reveals its schema when it is opened: the lazy result of an EMPTY df1 still has the documented columns
+    (it used to be built from the first result batch, i.e. after the index build and the first join -- and empty without rows)."""
+    p = tmp_path / "empty.csv"
+    p.write_text("contig,pos_start,pos_end\n")
+    rd = pb.overlap(str(p), _gold("overlap/targets.csv"), cols1=GOLD_COLS, cols2=GOLD_COLS, output_type="pyarrow.RecordBatchReader")
+    assert rd.schema.names == ["contig_1", "pos_start_1", "pos_end_1", "contig_2", "pos_start_2", "pos_end_2"]
+    assert rd.read_all().num_rows == 0
