@@ -436,7 +436,139 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
     }
 }
 
+// ---- partition, pass 2, STABLE variant (the deterministic count -> fill pair) ---------------------------------------------------
+// As k_slice_scatter: rank inside (wavefront, bucket) from match-any ballots against the wavefront's private counter row, prefix
+// over the wavefronts per bucket: the records of a bucket keep their input order, whatever the timing of the wavefronts.
+struct CsPartSLds { int cm, cell, spl, base, lstart, tot, wcnt, rs, re, rr, d, wsum, total; };
+__host__ __device__ inline CsPartSLds cs_part_s_lds(int nb, int ncells, int n_contigs) {
+    CsPartSLds L;
+    const int nbp = (nb + 2 + 1) & ~1;                          // counters per wavefront row, even
+    int o = 0;
+    L.cm = o; o += 16 * ((n_contigs + 3) & ~3);
+    L.spl = o; o += 8 * nb;
+    L.cell = o; o += 4 * ncells;
+    L.rs = (o + 15) & ~15; o = L.rs + 4 * CS_TILE;
+    L.re = o; o += 4 * CS_TILE;
+    L.rr = o; o += 4 * CS_TILE;
+    L.base = o; o += 4 * (nb + 2);
+    L.lstart = o; o += 4 * (nb + 2);
+    L.tot = o; o += 4 * (nb + 2);
+    L.wcnt = (o + 3) & ~3; o = L.wcnt + 2 * nbp * CS_WAVES;
+    L.d = (o + 3) & ~3; o = L.d + 2 * CS_TILE;
+    L.wsum = (o + 3) & ~3; o = L.wsum + 4 * CS_WAVES;
+    L.total = o;
+    return L;
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(CS_THREADS) void k_cs_scatter_stable(CsTab tab, CsGeom g, int nbits, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                                 const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
+                                                                 int chunk, int nchunks, const uint32_t* __restrict__ blk_off,
+                                                                 int32_t* __restrict__ out /* 3 int32 per record */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    const CsPartSLds L = cs_part_s_lds(g.nb, g.ncells, g.n_contigs);
+    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(cs_lds + L.spl);
+    int4* l_cm = reinterpret_cast<int4*>(cs_lds + L.cm);
+    uint32_t* l_cell = reinterpret_cast<uint32_t*>(cs_lds + L.cell);
+    int32_t* l_rs = reinterpret_cast<int32_t*>(cs_lds + L.rs);
+    int32_t* l_re = reinterpret_cast<int32_t*>(cs_lds + L.re);
+    int32_t* l_rr = reinterpret_cast<int32_t*>(cs_lds + L.rr);
+    uint32_t* base = reinterpret_cast<uint32_t*>(cs_lds + L.base);
+    uint32_t* lstart = reinterpret_cast<uint32_t*>(cs_lds + L.lstart);
+    uint32_t* tot = reinterpret_cast<uint32_t*>(cs_lds + L.tot);
+    unsigned short* wcnt = reinterpret_cast<unsigned short*>(cs_lds + L.wcnt);
+    unsigned short* l_d = reinterpret_cast<unsigned short*>(cs_lds + L.d);
+    uint32_t* wsum = reinterpret_cast<uint32_t*>(cs_lds + L.wsum);
+    const int nbp = (g.nb + 2 + 1) & ~1;
+    const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+    const int nbk = g.nb + 1;                                   // buckets incl. the "no candidate" one
+    cs_load_tab(tab, g, l_spl, l_cm, l_cell, CS_THREADS);
+    for (int k = tid; k < nbk; k += CS_THREADS) { base[k] = blk_off[(int64_t)k * nchunks + blockIdx.x]; tot[k] = 0; }
+    for (int k = tid; k < nbp * CS_WAVES / 2; k += CS_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
+    __syncthreads();
+    const int64_t cbase = (int64_t)blockIdx.x * chunk;
+    const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
+    const uint64_t lt = lanemask_lt();
+    unsigned short* my = wcnt + w * nbp;
+    // wavefront w owns the tile elements [w * 256, (w + 1) * 256): item j of lane l = w * 256 + j * 64 + l (input order)
+    const int el0 = w * (CS_ITEMS * kWave) + lane;
+    for (int64_t tbase = cbase; tbase < cend; tbase += CS_TILE) {
+        const int tile_n = (int)((cend - tbase) < (int64_t)CS_TILE ? (cend - tbase) : (int64_t)CS_TILE);
+        int32_t s[CS_ITEMS], e[CS_ITEMS], r[CS_ITEMS];
+        uint32_t d[CS_ITEMS], rank[CS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const int64_t i = tbase + el0 + j * kWave;
+            const bool valid = el0 + j * kWave < tile_n;
+            const int32_t c = valid ? __builtin_nontemporal_load(pc + i) : -1;
+            s[j] = valid ? __builtin_nontemporal_load(ps + i) : 0;
+            e[j] = valid ? __builtin_nontemporal_load(pe + i) : 0;
+            r[j] = valid ? (row_id ? __builtin_nontemporal_load(row_id + i) : (int32_t)i) : -1;
+            d[j] = !valid ? 0u : cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, c, e[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const bool valid = el0 + j * kWave < tile_n;
+            const uint64_t peers = wave_match_n(d[j], valid, nbits);
+            const uint32_t rk = (uint32_t)__popcll(peers & lt);
+            const uint32_t before = valid ? (uint32_t)my[d[j]] : 0u;
+            rank[j] = before + rk;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rk == 0) my[d[j]] = (unsigned short)(before + (uint32_t)__popcll(peers));
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();                                                        // (A) all wavefront rows counted
+        uint32_t x0 = 0, x1 = 0;
+        {
+            const int b0 = 2 * tid;
+            if (b0 < nbk) {
+                base[b0] += tot[b0];
+                if (b0 + 1 < nbk) base[b0 + 1] += tot[b0 + 1];
+                uint32_t* row32 = reinterpret_cast<uint32_t*>(wcnt) + tid;
+#pragma unroll
+                for (int k = 0; k < CS_WAVES; ++k) {
+                    const uint32_t v = row32[k * (nbp / 2)];
+                    row32[k * (nbp / 2)] = x0 | (x1 << 16);
+                    x0 += v & 0xffffu; x1 += v >> 16;
+                }
+                tot[b0] = x0;
+                if (b0 + 1 < nbk) tot[b0 + 1] = x1;
+            }
+        }
+        uint32_t tsum;
+        const uint32_t pre = sl_block_exclusive_sum(x0 + x1, wsum, &tsum);      // (B), (C)
+        if (2 * tid < nbk) { lstart[2 * tid] = pre; if (2 * tid + 1 < nbk) lstart[2 * tid + 1] = pre + x0; }
+        __syncthreads();                                                        // (D)
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            if (el0 + j * kWave < tile_n) {
+                const uint32_t pos = lstart[d[j]] + (uint32_t)my[d[j]] + rank[j];
+                l_rs[pos] = s[j]; l_re[pos] = e[j]; l_rr[pos] = r[j];
+                l_d[pos] = (unsigned short)d[j];
+            }
+        }
+        __syncthreads();                                                        // (E) tile sorted in LDS
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const int il = j * CS_THREADS + tid;
+            if (il < tile_n) {
+                const uint32_t dd = l_d[il];
+                cs_rec v; v.x = l_rs[il]; v.y = l_re[il]; v.z = l_rr[il];
+                *reinterpret_cast<cs_rec*>(out + 3 * (int64_t)(base[dd] + ((uint32_t)il - lstart[dd]))) = v;
+            }
+        }
+        for (int k = tid; k < nbp * CS_WAVES / 2; k += CS_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
+        __syncthreads();                                                        // (F) counters clear, staging free
+    }
+}
+
 // ---- the join ---------------------------------------------------------------------------------------------------------------------
+// FUSED: one pass, every tile reserves its output range with one atomic (tile order not reproducible).
+// COUNT / FILL: the deterministic pair -- COUNT writes the pairs of every (tile, wavefront) to its own slot, the host scans the
+// slots, FILL matches again and every wavefront emits at ITS scanned base: no atomics, no cross-wavefront hand-off, and (with the
+// stable partition) an output that is identical from run to run.
+enum { CS_FUSED = 0, CS_COUNT = 1, CS_FILL = 2 };
+
 struct CsJoinArgs {
     const int32_t* b_start;
     const int2* ep;
@@ -452,7 +584,8 @@ struct CsJoinArgs {
     int wcap;                         // staging entries per wavefront
     int ablate;                       // profiling only (IVJ_SLICE_ABLATE): 32 no copy-out
     long long capacity;
-    unsigned long long* state;        // [0] cursor, [1] overflow flag
+    unsigned long long* state;        // FUSED: [0] cursor, [1] overflow flag
+    long long* wslot;                 // COUNT: pairs per (tile, wavefront), written; FILL: their exclusive scan, read
     int32_t* out_probe;
     int32_t* out_build;
 };
@@ -473,7 +606,7 @@ __host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
     return L;
 }
 
-template <bool STRICT>
+template <bool STRICT, int MODE>
 __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
     const CsJoinLds L = cs_join_lds(A.R, A.wcap);
@@ -658,6 +791,84 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         }
     };
 
+    if constexpr (MODE != CS_FUSED) {
+        // deterministic pair: slot of (workgroup v, tile tix, wavefront wv); every wavefront works on its own
+        load_tile(q0);
+        const int ntile = (int)((q1 - q0 + CS_TILE - 1) / CS_TILE);
+        const int tiles_per_chunk = A.jchunk / CS_TILE;
+        for (int tix = 0; tix < ntile; ++tix) {
+            match_tile(q0 + (int64_t)tix * CS_TILE);
+            const long long slot = ((long long)v * tiles_per_chunk + tix) * CS_WAVES + wv;
+            int lsum = 0;
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) lsum += cnt[j];
+            const int linc = wave_incl_sum_dpp(lsum);
+            const int wtot = __builtin_amdgcn_readlane(linc, kWave - 1);
+            if constexpr (MODE == CS_COUNT) {
+                if (lane == 0) A.wslot[slot] = (long long)wtot;
+                continue;
+            }
+            if (wtot == 0) continue;                                           // uniform
+            const long long wbase = A.wslot[slot];
+            if (wtot <= A.wcap && !any_lng) {
+                int off = linc - lsum;
+#pragma unroll
+                for (int j = 0; j < CS_ITEMS; ++j) {
+                    qrw[j * kWave + lane] = qrow[j];
+                    uint32_t m = mask[j];
+                    const uint32_t ent = ((uint32_t)(j * kWave + lane) << 16) | (uint32_t)al[j];
+                    uint32_t* so = stw + off;
+                    while (m) {
+                        const int t = __builtin_ctz(m);
+                        m &= m - 1;
+                        so[0] = ent + (uint32_t)t;
+                        if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
+                        so += 2;
+                    }
+                    off += cnt[j];
+                }
+                __builtin_amdgcn_wave_barrier();
+                int32_t* op = A.out_probe + wbase;
+                int32_t* ob = A.out_build + wbase;
+#pragma unroll 4
+                for (int i = lane; i < wtot; i += kWave) {
+                    const uint32_t e = stw[i];
+                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                long long off = wbase + (linc - lsum);
+#pragma unroll
+                for (int j = 0; j < CS_ITEMS; ++j) {
+                    if (!lng[j]) {
+                        uint32_t m = mask[j];
+                        long long o = off;
+                        while (m) {
+                            const int t = __builtin_ctz(m);
+                            m &= m - 1;
+                            A.out_probe[o] = qrow[j]; A.out_build[o] = l_row[al[j] + t];
+                            ++o;
+                        }
+                    } else {
+                        long long o = off + cnt[j] - 1;
+                        for (int p = r0 + hi[j] - 1; o >= off; --p) {
+                            const int i = p - r0;
+                            int32_t ev = l_end[i < 0 ? 0 : i];
+                            if (i < 0) ev = A.ep[p].x;
+                            if (lt_op<STRICT>(qs[j], ev)) {
+                                int32_t rv = l_row[i < 0 ? 0 : i];
+                                if (i < 0) rv = A.b_row[p];
+                                A.out_probe[o] = qrow[j]; A.out_build[o] = rv; --o;
+                            }
+                        }
+                    }
+                    off += cnt[j];
+                }
+            }
+        }
+        return;
+    }
     // Barrier-free tile loop (protocol of slice.hip.h's fused mode): a wavefront's pairs of a tile are contiguous in the
     // tile's output range at the offset a returning LDS atomic on the tile's cursor gives it; the LAST wavefront to arrive
     // reserves the range with the one global atomic and publishes the base in LDS; the others look at it one iteration later.

@@ -85,6 +85,7 @@ struct ivj_ctx {
     int2* sl_map = nullptr;
     long long *sl_tile = nullptr, *sl_tpart = nullptr;
     bool ov_slice = false;             // the pending count -> fill hand-over went through the slice path
+    bool ov_cs = false;                //   ... through its contig-aligned form (cslice.hip.h)
     bool sl_plan_valid = false;
     int sl_items = 2;                  // probes per thread of the slice join (IVJ_SLICE_ITEMS = 2 | 4: tuning knob)
     int env_joint_bins = 0, env_count_nolds = 0, env_count_ablate = 0;     // IVJ_JOINT_BINS (1|2), IVJ_COUNT_NOLDS: tuning knobs of count_overlaps

@@ -82,7 +82,7 @@ int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* 
     P.jchunk = (int)jchunk;
     P.gmax = (int)(g.nb + (n + jchunk - 1) / jchunk);
     P.tiles_per_chunk = (int)(jchunk / CS_TILE);
-    P.ntiles = (int64_t)P.gmax * P.tiles_per_chunk;
+    P.ntiles = (int64_t)P.gmax * P.tiles_per_chunk * CS_WAVES;        // slots of the count -> fill pair: one per (tile, wavefront)
     // partition tiles of 8192 probes where the staging fits the LDS (IVJ_CS_PTILE=4096 pins the small tile: A/B runs)
     P.part_items = ((size_t)cs_part_lds(g.nb, g.ncells, g.n_contigs, 8).total <= 160 * 1024 && ctx->cs_env_ptile != 4096 && n >= (1ll << 20)) ? 8 : 4;
     P.part_lds = (size_t)cs_part_lds(g.nb, g.ncells, g.n_contigs, P.part_items).total;
@@ -91,19 +91,15 @@ int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* 
     if (fixed + 16 * 1024 > lds_cap || P.part_lds > lds_cap) return fail(IVJ_EINVAL, "slice geometry does not fit the LDS");
     wcap = (int)((lds_cap - fixed) / (4 * CS_WAVES)) & ~3;
     P.join_lds = (size_t)cs_join_lds(g.R, wcap).total;
+    P.stage = wcap;
     return IVJ_OK;
 }
 
-int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
-                     int64_t capacity, int64_t* n_pairs) {
+// probe side -> bucket-ordered 12-byte records + chunk table of the join.  stable: the deterministic pair (match-any ranking).
+int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const SlicePlan& P, bool stable) {
     const int64_t n = probe->n;
     const CsGeom& g = ix->cs_g;
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
-    SlicePlan P;
-    int wcap = 0;
-    IVJ_TRY(cs_plan(ctx, ix, n, opts, P, wcap));
-    IVJ_TRY(ensure_sl(ctx, n, P));
-    ctx->sl_plan_valid = false;
     IVJ_TRY(cs_ensure_tables(ctx, ix));
     const CsTab tab{ix->cs_spl, ix->cs_cm, ix->cs_cell};
     const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end) && (!probe->row_id || aligned16(probe->row_id));
@@ -113,7 +109,10 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
         IVJ_TRY(set_dyn_lds(&k_cs_hist<true>, 96 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_hist<false>, 96 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_scatter<true, 4>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter<false, 4>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_scatter<true, 8>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter<false, 8>, 160 * 1024));
-        IVJ_TRY(set_dyn_lds(&k_cs_join<true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_FUSED>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_FUSED>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_COUNT>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_COUNT>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_FILL>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_FILL>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_scatter_stable<true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter_stable<false>, 160 * 1024));
         ctx->cs_attr_set = true;
     }
     int32_t* rec = reinterpret_cast<int32_t*>(ctx->sl_rec);
@@ -123,6 +122,18 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     t_end(ctx);
     IVJ_TRY((lb_scan_u32<SumOp, true>(ctx, "cs_scan", ctx->sl_blk, (int64_t)hist, 0u)));
     LAUNCH(ctx, "cs_chunks", k_slice_chunks, 1, SL_THREADS, (const uint32_t*)ctx->sl_blk, P.nchunks, g.nb, n, P.jchunk, ctx->sl_bstart, ctx->sl_meta, ctx->sl_map);
+    if (stable) {
+        const size_t lds = (size_t)cs_part_s_lds(g.nb, g.ncells, g.n_contigs).total;
+        const int nbits = bits_for((uint32_t)g.nb);
+        t_begin(ctx, "cs_scatter_stable");
+        if (strict) hipLaunchKernelGGL((k_cs_scatter_stable<true>), dim3(P.nchunks), dim3(CS_THREADS), lds, ctx->stream, tab, g, nbits, probe->contig, probe->start, probe->end,
+                                       probe->row_id, n, P.chunk, P.nchunks, (const uint32_t*)ctx->sl_blk, rec);
+        else hipLaunchKernelGGL((k_cs_scatter_stable<false>), dim3(P.nchunks), dim3(CS_THREADS), lds, ctx->stream, tab, g, nbits, probe->contig, probe->start, probe->end,
+                                probe->row_id, n, P.chunk, P.nchunks, (const uint32_t*)ctx->sl_blk, rec);
+        t_end(ctx);
+        HIP_TRY(hipGetLastError());
+        return IVJ_OK;
+    }
     t_begin(ctx, "cs_scatter");
 #define IVJ_CS_SCATTER(S, I)                                                                                                            \
     hipLaunchKernelGGL((k_cs_scatter<S, I>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, \
@@ -131,19 +142,40 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     else { if (P.part_items == 8) IVJ_CS_SCATTER(false, 8); else IVJ_CS_SCATTER(false, 4); }
 #undef IVJ_CS_SCATTER
     t_end(ctx);
-    if (ctx->sl_env_ablate & (256 | 1024 | 2048)) { *n_pairs = 0; HIP_TRY(hipStreamSynchronize(ctx->stream)); return IVJ_OK; }   // profiling: the records are not usable
-    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+template <int MODE>
+int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const SlicePlan& P, long long capacity, int32_t* out_p, int32_t* out_b) {
+    const CsGeom& g = ix->cs_g;
     CsJoinArgs A;
     A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta;
-    A.rec = rec; A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
-    A.R = g.R; A.jchunk = P.jchunk; A.wcap = wcap; A.ablate = ctx->sl_env_ablate; A.capacity = (long long)capacity;
+    A.rec = reinterpret_cast<int32_t*>(ctx->sl_rec); A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
+    A.R = g.R; A.jchunk = P.jchunk; A.wcap = P.stage; A.ablate = ctx->sl_env_ablate; A.capacity = capacity;
     A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
+    A.wslot = ctx->sl_tile;
     A.out_probe = out_p; A.out_build = out_b;
     const unsigned grid = 8u * (unsigned)((P.gmax + 7) / 8);
-    t_begin(ctx, "cs_join_fused");
-    if (strict) hipLaunchKernelGGL((k_cs_join<true>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
-    else hipLaunchKernelGGL((k_cs_join<false>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
+    t_begin(ctx, MODE == CS_FUSED ? "cs_join_fused" : (MODE == CS_COUNT ? "cs_join_count" : "cs_join_fill"));
+    if (opts->filter_op == IVJ_FILTER_STRICT) hipLaunchKernelGGL((k_cs_join<true, MODE>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
+    else hipLaunchKernelGGL((k_cs_join<false, MODE>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
     t_end(ctx);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
+int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
+                     int64_t capacity, int64_t* n_pairs) {
+    SlicePlan P;
+    int wcap = 0;
+    IVJ_TRY(cs_plan(ctx, ix, probe->n, opts, P, wcap));
+    IVJ_TRY(ensure_sl(ctx, probe->n, P));
+    ctx->sl_plan_valid = false;
+    IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, false));
+    if (ctx->sl_env_ablate & (256 | 1024 | 2048)) { *n_pairs = 0; HIP_TRY(hipStreamSynchronize(ctx->stream)); return IVJ_OK; }   // profiling: the records are not usable
+    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
+    IVJ_TRY(cs_join_launch<CS_FUSED>(ctx, ix, opts, P, (long long)capacity, out_p, out_b));
     HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_meta + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
@@ -151,6 +183,30 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     if (ctx->h_total[1] != 0)
         return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");
     return IVJ_OK;
+}
+
+// the deterministic pair: stable partition + per-(tile, wavefront) counts + scan, then the fill at the scanned bases
+int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* n_pairs) {
+    SlicePlan P;
+    int wcap = 0;
+    IVJ_TRY(cs_plan(ctx, ix, probe->n, opts, P, wcap));
+    IVJ_TRY(ensure_sl(ctx, probe->n, P));
+    IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, true));
+    HIP_TRY(hipMemsetAsync(ctx->sl_tile, 0, (size_t)(P.ntiles + 2) * 8, ctx->stream));
+    IVJ_TRY(cs_join_launch<CS_COUNT>(ctx, ix, opts, P, 0, nullptr, nullptr));
+    device_scan<long long, SumOp, false>(ctx, "tile_scan", ctx->sl_tile, ctx->sl_tile, P.ntiles, 0ll, ctx->sl_tpart, ctx->sl_tile + P.ntiles);
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_tile + P.ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    ctx->sl_plan_valid = true;
+    ctx->sl_plan = P;
+    *n_pairs = *ctx->h_total;
+    return IVJ_OK;
+}
+
+int cs_overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int32_t* out_p, int32_t* out_b) {
+    if (!ctx->sl_plan_valid) return fail(IVJ_ESTATE, "slice fill without a matching count");
+    return cs_join_launch<CS_FILL>(ctx, ix, opts, ctx->sl_plan, 0, out_p, out_b);
 }
 
 }  // namespace

@@ -97,7 +97,9 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     SliceGeom sg;
     if (want_slices(ix, n, opts, sg, false)) {
         int64_t total = 0;
-        IVJ_TRY(slice_overlap_count(ctx, ix, probe, opts, sg, &total));
+        ctx->ov_cs = cs_wanted(ctx, ix, opts);
+        if (ctx->ov_cs) IVJ_TRY(cs_overlap_count(ctx, ix, probe, opts, &total));
+        else IVJ_TRY(slice_overlap_count(ctx, ix, probe, opts, sg, &total));
         ctx->ov_slice = true;
         ctx->ov_total = total;
         ctx->ov_n = n; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
@@ -141,7 +143,7 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     if (capacity < ctx->ov_total) return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->ov_total) + " pairs");
     if (ctx->ov_total == 0) return IVJ_OK;
     if (!out_p || !out_b) return fail(IVJ_EINVAL, "output buffers are NULL");
-    if (ctx->ov_slice) return slice_overlap_fill(ctx, ix, opts, out_p, out_b);
+    if (ctx->ov_slice) return ctx->ov_cs ? cs_overlap_fill(ctx, ix, opts, out_p, out_b) : slice_overlap_fill(ctx, ix, opts, out_p, out_b);
     const int64_t n = probe->n;
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;
     const int32_t* qs = ctx->ov_part ? ctx->pt_s : probe->start;
