@@ -41,7 +41,10 @@ bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, Sli
     if (opts->partition_mode != 0 && opts->partition_mode != 6) return false;
     if (opts->partition_mode == 0) {
         const int mode = ix->ctx ? ix->ctx->sl_env_auto : 1;
-        const bool on = mode == 2 || (mode == 1 && fused);
+        // round 3: the contig-aligned form (cslice.hip.h) also wins the deterministic count -> fill pair (config 3: 3.39 ms
+        // against 4.05 ms on 256 buckets); the round-2 slice kernels only ever paid for the fused pass
+        const bool cs = ix->cs_ok && !(ix->ctx && ix->ctx->cs_env_off) && opts->slice_rows == 0;
+        const bool on = mode == 2 || (mode == 1 && (fused || cs));
         // tools/policy_sweep.py (profiles/r02/policy_sweep.txt): against the 256-bucket window scan the slices only pay once the
         // sorted build side is far larger than the L2s (5 M rows: -5 % at 30 M probes, -6 % at 100 M; 1-2 M rows: +2..+60 %)
         if (!(on && n_probe >= (24ll << 20) && ix->n >= (4ll << 20))) return false;

@@ -115,6 +115,19 @@ def test_full_size_config3_overlap_100M_x_5M(eng):
         eng.d2h(hp, op)
         eng.d2h(hb, ob)
         _check_pair_properties(hp, hb, probe, build, counts, checksum, "two-pass slices")
+        #    ... EXACT (the oracle's pair list after a stable sort by probe row) and identical from run to run: stable partition,
+        #    per-(tile, wavefront) counts, scanned bases -- no atomics decide a position
+        ep, eb = O.overlap_fast(ix, ps, True, threads=cores)
+        o = np.argsort(hp, kind="stable")
+        assert (hp[o] == ep).all() and (hb[o] == eb).all()
+        del ep, eb, o
+        hp2, hb2 = np.empty(total, np.int32), np.empty(total, np.int32)
+        assert eng.overlap_count_dev(ixd, d.probe, o6) == total
+        eng.overlap_fill_dev(ixd, d.probe, o6, op, ob, total)
+        eng.d2h(hp2, op)
+        eng.d2h(hb2, ob)
+        assert (hp2 == hp).all() and (hb2 == hb).all(), "the deterministic pair differs between two runs"
+        del hp2, hb2
         # 3. the fused single pass (what bench.py times): auto mode (slice path), the 256-bucket window-scan path, explicit slices
         for pm in (0, 1, 6):
             o2 = _engine.make_opts(True, nc, partition_mode=pm)
