@@ -22,13 +22,15 @@ run_stage() {
     c3old) IVJ_CS=0 timeout 900 $B --steps 10 --warmup 2 $Q 2>$o.err | tee $o.json | cut -c1-400; grep -A16 "per-kernel" $o.err ;;
     c3two) timeout 900 $B --steps 10 --warmup 2 $Q --two-pass 2>$o.err | tee $o.json | cut -c1-400; grep -A16 "per-kernel" $o.err ;;
     c1) timeout 600 $B --workload overlap_1k_1k_1contig --steps 20 --warmup 3 --no-pmc --kernel-table 2>$o.err | tee $o.json | cut -c1-600; grep -A12 "per-kernel" $o.err ;;
-    c2) timeout 900 $B --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --no-pmc --kernel-table 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
-    c4) timeout 900 $B --workload nearest_50M_2M_24contig --steps 10 --warmup 2 --no-pmc --kernel-table 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
-    c5) timeout 900 $B --workload count_200M_200k_24contig --steps 10 --warmup 2 --no-pmc --kernel-table 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
+    c2) timeout 900 $B --workload overlap_10M_1M_1contig --steps 10 --warmup 2 --kernel-table 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
+    c4) timeout 900 $B --workload nearest_50M_2M_24contig --steps 10 --warmup 2 --kernel-table 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
+    c5) timeout 900 $B --workload count_200M_200k_24contig --steps 10 --warmup 2 --kernel-table 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
+    c3fd) echo "== bench config3 through the N > 1 code path on one rank (library communicator, world 1)"; timeout 900 $B --force-dist --steps 5 --warmup 2 $Q 2>$o.err | tee $o.json | cut -c1-900 ;;
+    frontend) timeout 600 python tools/frontend_e2e.py 2>&1 | tee $o.txt | tail -12 ;;
     c3dense) timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 $Q 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
     c3rows) timeout 900 $B --steps 10 --warmup 2 --materialize $Q 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
     sortscan) for w in coverage_100M_5M_24contig subtract_20M_5M_24contig merge_100M_24contig; do
-        timeout 900 $B --workload $w --steps 5 --warmup 2 --no-pmc --kernel-table 2>${o}_$w.err | tee ${o}_$w.json | cut -c1-400; grep -A12 "per-kernel" ${o}_$w.err | head -14; done ;;
+        timeout 900 $B --workload $w --steps 5 --warmup 2 --kernel-table 2>${o}_$w.err | tee ${o}_$w.json | cut -c1-400; grep -A12 "per-kernel" ${o}_$w.err | head -14; done ;;
     prof) echo "== rocprofv3 --kernel-trace --stats (config 3)";
       (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OLDPWD/${o}_dir" -o c3 --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras > "$OLDPWD/$o.out" 2> "$OLDPWD/$o.err");
       tail -2 $o.out | cut -c1-400; f=$(find ${o}_dir -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { cp "$f" $o.kernel_stats.csv; head -25 "$f"; } ;;
