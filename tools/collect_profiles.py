@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Copies the judged artefacts of one tools/gpu_r02.sh session (gpurun_out/<tag>_*) into profiles/r02/ under stable names
-and writes profiles/r02/MANIFEST.md (git commit the tree was built from, source hash stamped by bench.py, what each file is).
-usage: collect_profiles.py <tag> [<commit>]"""
+"""Copies the judged artefacts of one tools/gpu_r0N.sh session (gpurun_out/<tag>_*) into profiles/<round>/ under stable names
+and writes profiles/<round>/MANIFEST.md (git commit the tree was built from, source hash stamped by bench.py, what each file is).
+usage: collect_profiles.py <tag> [<commit>]      (IVJ_ROUND=r03 by default)"""
 import glob, json, os, re, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", "r02")
+ROUND = os.environ.get("IVJ_ROUND", "r03")
+SRC, DST = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", ROUND)
 NAMES = {
-    "c3": "bench_overlap_100M_5M", "c3two": "bench_overlap_100M_5M_two_pass", "c3m1": "bench_overlap_100M_5M_mode1_window_scan",
+    "c3": "bench_overlap_100M_5M", "c3two": "bench_overlap_100M_5M_two_pass", "c3old": "bench_overlap_100M_5M_round2_slice_kernels",
+    "c1": "bench_overlap_1k_1k", "c3fd": "bench_overlap_100M_5M_multi_rank_path_world1", "c3m1": "bench_overlap_100M_5M_mode1_window_scan",
     "c3m6": "bench_overlap_100M_5M_mode6_slices", "c2": "bench_overlap_10M_1M", "c4": "bench_nearest_50M_2M", "c5": "bench_count_200M_200k",
     "c3dense": "bench_overlap_100M_5M_dense", "c3rows": "bench_overlap_100M_5M_rows",
     "sortscan_coverage_100M_5M_24contig": "bench_coverage_100M_5M", "sortscan_subtract_20M_5M_24contig": "bench_subtract_20M_5M",
@@ -19,7 +21,7 @@ def main():
     tag = sys.argv[1]
     commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
     os.makedirs(DST, exist_ok=True)
-    lines = [f"# profiles/r02 -- artefacts of GPU session `{tag}`", "", f"Built from commit `{commit}` (+ the working tree at that time; "
+    lines = [f"# profiles/{ROUND} -- artefacts of GPU session `{tag}`", "", f"Built from commit `{commit}` (+ the working tree at that time; "
              "`source_sha16` in every bench line is the hash of the sources the run was made from).", "", "| file | what |", "|---|---|"]
     tables = []
     for stage, name in NAMES.items():
@@ -48,7 +50,9 @@ def main():
         lines.append("| `kernel_tables_hipevents.txt` | per-kernel HIP-event tables (`bench.py --kernel-table`, timing level 2) of the runs above |")
     for src, dst, what in ((f"{tag}_prof.kernel_stats.csv", "rocprofv3_kernel_stats_overlap_100M_5M.csv", "`rocprofv3 --kernel-trace --stats` of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras` (config 3)"),
                            (f"{tag}_fast.log", "pytest_gpu_fast.log", "`pytest -m gpu` without the full-size configs"),
-                           (f"{tag}_full.log", "pytest_gpu_full_size.log", "`pytest -m gpu -k 'full_size or two_rank or self_spawn'` (configs 3, 4, 5 at stated size; the 2-GPU tests skip on a 1-GPU box)")):
+                           (f"{tag}_full.log", "pytest_gpu_full_size.log", "`pytest -m gpu -k 'full_size or two_rank or self_spawn'` (configs 3, 4, 5 at stated size; the 2-GPU tests skip on a 1-GPU box)"),
+                           (f"{tag}_pmcsq.summary.json", "pmc_sq_lds_overlap_100M_5M.json", "`rocprofv3 --kernel-trace --pmc` SQ / LDS counter sets (three passes, `tools/gpu_r03.sh pmcsq`, per kernel, mean per launch) of config 3"),
+                           (f"{tag}_frontend.txt", "frontend_e2e.txt", "`tools/frontend_e2e.py`: pb.overlap end to end through the Python front door, per stage")):
         p = os.path.join(SRC, src)
         if os.path.exists(p):
             shutil.copyfile(p, os.path.join(DST, dst))

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Prints the BASELINE.md section-4 result tables (markdown) from the bench lines collected under profiles/r02/."""
+"""Prints the BASELINE.md section-4 result tables (markdown) from the bench lines collected under profiles/<round>/ (IVJ_ROUND, default r03)."""
 import json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-D = os.path.join(ROOT, "profiles", "r02")
+D = os.path.join(ROOT, "profiles", os.environ.get("IVJ_ROUND", "r03"))
 
 
 def load(name):
@@ -16,8 +16,10 @@ def sci(v):
 
 
 def main():
-    head = [("2 overlap 10M×1M, 1 contig", "bench_overlap_10M_1M"), ("3 overlap 100M×5M, 24 contigs (fused single pass, slice path)", "bench_overlap_100M_5M"),
-            ("3, deterministic count → fill pair (256-bucket path)", "bench_overlap_100M_5M_two_pass"),
+    head = [("1 overlap 1k×1k, 1 contig", "bench_overlap_1k_1k"), ("2 overlap 10M×1M, 1 contig", "bench_overlap_10M_1M"),
+            ("3 overlap 100M×5M, 24 contigs (fused single pass, contig-aligned slices)", "bench_overlap_100M_5M"),
+            ("3, deterministic count → fill pair", "bench_overlap_100M_5M_two_pass"),
+            ("3, fused, round-2 slice kernels (`IVJ_CS=0`)", "bench_overlap_100M_5M_round2_slice_kernels"),
             ("3, fused, 256-bucket window scan forced (`partition_mode` 1)", "bench_overlap_100M_5M_mode1_window_scan"),
             ("3 dense (build L 5k–40k)", "bench_overlap_100M_5M_dense"), ("4 nearest 50M×2M, 24 contigs", "bench_nearest_50M_2M"),
             ("5 count_overlaps 200M×200k", "bench_count_200M_200k")]
