@@ -34,6 +34,8 @@ constexpr int CS_TILE = CS_THREADS * CS_ITEMS;          // probes per tile of th
 constexpr int CS_WTILE = kWave * CS_ITEMS;              // probes of one wavefront per tile (its private slot range)
 constexpr int CS_MAX_CONTIGS = 256;
 constexpr int CS_WIN = 12;                              // rows below hi the branch-free window is guaranteed to cover
+constexpr int CS_POS_BIAS = 1 << 23;                    // staging entries carry (row - first row of the slice) + bias in 24 bits: rows below the slice too
+static_assert((long long)SL_MAX_BUCKETS * SL_MAX_ROWS <= CS_POS_BIAS, "an index of this path must fit a staging entry's row field");
 constexpr int CS_BIN_STRIDE_PAD = 2;                    // bins per slice in global memory: 2 R + 2 (u16)
 
 typedef int cs_rec __attribute__((ext_vector_type(3), aligned(4)));      // one probe record {start, end, row}: 12 bytes, 4-byte aligned
@@ -216,6 +218,51 @@ __device__ __forceinline__ uint32_t cs_bucket(const unsigned long long* __restri
     return pos <= (int)((uint32_t)m.w >> 16) ? (uint32_t)nb : (uint32_t)(pos - 1);
 }
 
+// ---- maxima of the ends over 16-row blocks, 16 blocks to a block (windows that run on below the branch-free one) ------------
+// A probe whose window is not settled by the CS_WIN rows below its hi-bound (the prefix max there is still above its start) has
+// to find every row further down that ends above its start.  With a tail of long intervals in the build side (genes among exons,
+// a contig-wide row) the prefix max stays high for hundreds to millions of rows, of which a handful match: a row-by-row walk is
+// what makes sorted-window joins fall off a cliff on such inputs.  hier level 0 = the ends in sorted order (a compact copy: one
+// 64-byte line = one block), level l >= 1, entry i = max end over the sorted rows [i << 4l, (i + 1) << 4l) (blocks may
+// straddle contigs, the walk stops at the contig's first row).  The walk enters a block only when its maximum is above the
+// probe's start, i.e. only blocks that hold a match, and reads a block with four 16-byte loads: a few dependent loads per match,
+// whatever the intervals look like.  (1 + 1/15) n values per index, every level padded to whole blocks.
+constexpr int CS_HIER_MAX = 8;                          // levels incl. level 0: 16^7 rows
+struct CsHier {
+    int nlev;                                           // highest level
+    int off[CS_HIER_MAX];                               // offset of level l in the hier array
+    int len[CS_HIER_MAX];
+};
+__host__ __device__ inline CsHier cs_hier_make(int64_t n) {
+    CsHier h;
+    h.nlev = 0;
+    int64_t o = 0, len = n;
+    for (int l = 0; l < CS_HIER_MAX; ++l) {
+        h.off[l] = (int)o; h.len[l] = 0;
+        if (l == 0 || len > 16) {
+            if (l > 0) len = (len + 15) / 16;
+            h.len[l] = (int)len; h.nlev = l;
+            o += (len + 15) & ~(int64_t)15;
+        } else len = 0;
+    }
+    return h;
+}
+inline size_t cs_hier_values(int64_t n) {
+    const CsHier h = cs_hier_make(n);
+    return (size_t)h.off[h.nlev] + (((size_t)h.len[h.nlev] + 15) & ~(size_t)15) + 16;
+}
+// level 0 from the ends (group 1, stride 2 in ep), level l + 1 from level l (group 16); pads of the last block = INT32_MIN
+__global__ void k_cs_hier(const int32_t* __restrict__ src, int stride, int group, int n_src, int32_t* __restrict__ dst, int n_dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((n_dst + 15) & ~15)) return;
+    int32_t m = INT32_MIN;
+    const int b = i * group;
+    for (int t = 0; t < group; ++t) {
+        if (b + t < n_src) { const int32_t v = src[(size_t)(b + t) * stride]; m = v > m ? v : m; }
+    }
+    dst[i] = m;
+}
+
 // ---- per-slice start bins, built once per index: one workgroup per slice ---------------------------------------------------
 // bins[j * (2 R + 2) + cl] = first slice-local row whose (start - min start) >> shift reaches cell cl (two cells per row);
 // bins[.. + ncell] = rows of the slice.
@@ -258,11 +305,11 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_bins(const int32_t* __restric
     __syncthreads();
     unsigned short* out = bins + (size_t)j * (size_t)(2 * R + CS_BIN_STRIDE_PAD);
     for (int i = tid; i <= ncell; i += CS_THREADS) out[i] = l_bin[i];
+    const int32_t cj = b_contig[r0];
+    const int seg_a = seg[cj];
     if (tid == 0) {
-        const int32_t c = b_contig[r0];
-        const int a = seg[c];
-        smeta[2 * j] = make_int4(l_start[0], bshift, ncell, r0 > a ? ep[r0 - 1].y : INT32_MIN);
-        smeta[2 * j + 1] = make_int4(a, c, rk, r0);
+        smeta[2 * j] = make_int4(l_start[0], bshift, ncell, r0 > seg_a ? ep[r0 - 1].y : INT32_MIN);
+        smeta[2 * j + 1] = make_int4(seg_a, cj, rk, r0);
     }
 }
 
@@ -575,6 +622,8 @@ struct CsJoinArgs {
     const int32_t* b_row;
     const unsigned short* bins;       // per-slice start bins (k_cs_bins)
     const int4* smeta;                // per-slice metadata (two int4)
+    const int32_t* hier;              // block maxima of the ends, levels 1 .. hl.nlev (k_cs_hier)
+    CsHier hl;
     const int32_t* rec;               // bucket-ordered probe records {start, end, row}
     const uint32_t* bstart;           // nb + 2 bucket starts
     const int32_t* meta;              // [0] = number of join workgroups
@@ -601,7 +650,7 @@ __host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
     L.bin = o; o += 2 * (2 * R + 8);
     L.qrow = (o + 15) & ~15; o = L.qrow + 4 * CS_TILE;
     L.stage = o; o += 4 * wcap * CS_WAVES;
-    L.ctl = (o + 15) & ~15; o = L.ctl + 64;
+    L.ctl = (o + 15) & ~15; o = L.ctl + 64 + 4 * CS_HIER_MAX;    // control blocks + the offsets of the hier levels
     L.total = o;
     return L;
 }
@@ -619,6 +668,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     uint32_t* l_stage = reinterpret_cast<uint32_t*>(cs_lds + L.stage);
     unsigned long long* lc = reinterpret_cast<unsigned long long*>(cs_lds + L.ctl);     // [2][2] {cursor, base}
     int* li = reinterpret_cast<int*>(lc + 4);                                           // [2][4] {arrived, done, ready, seq}
+    int* l_hoff = li + 8;                                                               // offsets of the hier levels
 
     // XCD-affine order: workgroup b runs on XCD b % 8 (observed); XCD x takes the contiguous eighth of the (bucket, chunk) list
     const int total_wg = A.meta[0];
@@ -668,6 +718,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         for (int i = tid; i < (ncell + 2) / 2; i += CS_THREADS) lb32[i] = gb32[i];
     }
     if (tid < 4) lc[tid] = 0;
+    if (tid < CS_HIER_MAX) l_hoff[tid] = A.hl.off[tid];
     if (tid < 8) li[tid] = (tid == 7) ? 1 : 0;                                 // block 1 serves tile 1 first (seq = li[1][3])
     __syncthreads();
 
@@ -693,8 +744,53 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     int al[CS_ITEMS], hi[CS_ITEMS];                                            // slice-local: first examined row, hi-bound
     uint32_t mask[CS_ITEMS];                                                   // bit t <=> row al + t matches
     int cnt[CS_ITEMS];
-    bool lng[CS_ITEMS];
     bool any_lng = false;
+
+    // Matches of a probe starting at qsv among the sorted rows BELOW slice-local row a0 (the rows the branch-free window does not
+    // cover; all of them start below the probe's end, so a row matches iff it ends above qsv), visited in descending position;
+    // f(p) gets the global sorted position.  Depth-first over the block maxima (k_cs_hier), right to left, one 16-entry block
+    // per step: the entries at or left of the cursor that are above qsv are rows to report (level 0) or the child to enter (the
+    // rightmost one); an exhausted block hands over to the entries left of its parent, and the prefix max of the row below the
+    // subtree just left says whether anything further down can still match.
+    auto ep_at = [&](int p) -> int2 {
+        const int i = p - r0;
+        if (i >= 0) return make_int2(l_end[i], l_pmx[i + 1]);
+        return A.ep[p];
+    };
+    auto walk_below = [&](int32_t qsv, int a0, auto&& f) {
+        int i = r0 + a0 - 1, lv = 0;
+        const int top = A.hl.nlev;
+        int chk = -1;                                                          // row whose prefix max is still to be looked at
+        while (i >= 0) {
+            if ((((i + 1) << (4 * lv)) - 1) < seg_a) return;                   // the entry lies below the contig
+            const int base = i & ~15;
+            const int4* bp = reinterpret_cast<const int4*>(A.hier + l_hoff[lv] + base);
+            const int4 w0 = bp[0], w1 = bp[1], w2 = bp[2], w3 = bp[3];
+            if (chk >= 0) {
+                if (!lt_op<STRICT>(qsv, ep_at(chk).y)) return;                 // nothing at or below row chk reaches the probe
+                chk = -1;
+            }
+            uint32_t m = cs_window_mask<STRICT>(qsv, w0, w1, w2, w3) & ((2u << (i & 15)) - 1u);
+            if (lv == 0) {
+                if (seg_a > base) m &= ~((1u << (seg_a - base)) - 1u);
+                while (m) { const int j = 31 - __builtin_clz(m); m ^= 1u << j; f(base + j); }
+            } else if (m) {
+                i = ((base + 31 - __builtin_clz(m)) << 4) + 15;               // the rightmost child above qsv, all of it
+                --lv;
+                continue;
+            }
+            // block exhausted: the entries left of its parent (of the first ancestor that has any)
+            int node = base;
+            do {
+                if (lv == top) return;
+                node >>= 4; ++lv;
+            } while ((node & 15) == 0);
+            const int b = node << (4 * lv);                                    // first row of the subtree just left
+            if (b <= seg_a) return;
+            chk = b - 1;
+            i = node - 1;
+        }
+    };
 
     auto match_tile = [&](int64_t tb) {
         int32_t qe[CS_ITEMS];
@@ -745,6 +841,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         // (l_pmx[0] = the row below the slice, INT32_MIN when the contig starts here) tells whether the window runs on: those
         // probes are redone exactly.
         unsigned long long lmask = 0;
+        uint32_t lngm = 0;
 #pragma unroll
         for (int jj = 0; jj < CS_ITEMS; jj += 2) {
             int4 w[2][4];
@@ -766,28 +863,71 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
                 const int j = jj + u;
                 uint32_t m = cs_window_mask<STRICT>(qs[j], w[u][0], w[u][1], w[u][2], w[u][3]);
                 m = __builtin_amdgcn_ubfe(m, 0u, (uint32_t)(hi[j] - al[j]));    // rows al .. hi - 1
-                lng[j] = valid[j] && lt_op<STRICT>(qs[j], pm[u]);
+                const bool lng = valid[j] && lt_op<STRICT>(qs[j], pm[u]);
                 mask[j] = valid[j] ? m : 0u;
                 cnt[j] = __popc(mask[j]);
-                lmask |= __ballot(lng[j]);
+                lmask |= __ballot(lng);
+                lngm |= lng ? (1u << j) : 0u;
             }
         }
         any_lng = lmask != 0;
-        if (any_lng) {
+        if (any_lng) {                                                         // uniform; rare: a window runs on below the examined rows
 #pragma unroll
             for (int j = 0; j < CS_ITEMS; ++j) {
-                if (lng[j]) {
+                if (lngm & (1u << j)) {
                     int c2 = 0;
-                    for (int p = r0 + hi[j] - 1; p >= seg_a; --p) {
-                        const int i = p - r0;
-                        int2 vv = make_int2(l_end[i < 0 ? 0 : i], l_pmx[i < 0 ? 1 : i + 1]);
-                        if (i < 0) vv = A.ep[p];
-                        if (!lt_op<STRICT>(qs[j], vv.y)) break;
-                        c2 += lt_op<STRICT>(qs[j], vv.x) ? 1 : 0;
-                    }
-                    cnt[j] = c2;
+                    walk_below(qs[j], al[j], [&](int) { ++c2; });
+                    cnt[j] += c2;
                 }
             }
+        }
+    };
+
+    // entries {wave-local probe slot << 24 | biased slice-local row} of item j into the wavefront's staging region at off
+    auto stage_item = [&](int j, int off) {
+        uint32_t m = mask[j];
+        const uint32_t slot = (uint32_t)(j * kWave + lane) << 24;
+        const int cw = cnt[j] - __popc(m);                                     // matches below the window
+        if (any_lng && cw > 0) {
+            uint32_t* sw = stw + off + cw - 1;
+            walk_below(qs[j], al[j], [&](int p) { *sw-- = slot | (uint32_t)(p - r0 + CS_POS_BIAS); });
+        }
+        const uint32_t ent = slot | (uint32_t)(al[j] + CS_POS_BIAS);
+        uint32_t* so = stw + off + cw;
+        while (m) {                                                            // two matches per trip: half the loop overhead
+            const int t = __builtin_ctz(m);
+            m &= m - 1;
+            so[0] = ent + (uint32_t)t;
+            if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
+            so += 2;
+        }
+    };
+    // the same pairs written from the lanes (wavefronts with more pairs than the staging region holds)
+    auto direct_item = [&](int j, long long off) {
+        uint32_t m = mask[j];
+        const int cw = cnt[j] - __popc(m);
+        if (any_lng && cw > 0) {
+            long long o = off + cw - 1;
+            walk_below(qs[j], al[j], [&](int p) { A.out_probe[o] = qrow[j]; A.out_build[o] = p >= r0 ? l_row[p - r0] : A.b_row[p]; --o; });
+        }
+        long long o = off + cw;
+        while (m) {
+            const int t = __builtin_ctz(m);
+            m &= m - 1;
+            A.out_probe[o] = qrow[j]; A.out_build[o] = l_row[al[j] + t];
+            ++o;
+        }
+    };
+    // staged entries -> pairs, coalesced over the wavefront
+    auto copy_out = [&](int32_t* op, int32_t* ob, int n_ent) {
+#pragma unroll 4
+        for (int i = lane; i < n_ent; i += kWave) {
+            const uint32_t e = stw[i];
+            const int pos = (int)(e & 0xffffffu) - CS_POS_BIAS;
+            int32_t br = l_row[pos < 0 ? 0 : pos];
+            if (__builtin_expect(pos < 0, 0)) br = A.b_row[r0 + pos];
+            __builtin_nontemporal_store(qrw[e >> 24], op + i);
+            __builtin_nontemporal_store(br, ob + i);
         }
     };
 
@@ -810,59 +950,22 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             }
             if (wtot == 0) continue;                                           // uniform
             const long long wbase = A.wslot[slot];
-            if (wtot <= A.wcap && !any_lng) {
+            if (wtot <= A.wcap) {
                 int off = linc - lsum;
 #pragma unroll
                 for (int j = 0; j < CS_ITEMS; ++j) {
                     qrw[j * kWave + lane] = qrow[j];
-                    uint32_t m = mask[j];
-                    const uint32_t ent = ((uint32_t)(j * kWave + lane) << 16) | (uint32_t)al[j];
-                    uint32_t* so = stw + off;
-                    while (m) {
-                        const int t = __builtin_ctz(m);
-                        m &= m - 1;
-                        so[0] = ent + (uint32_t)t;
-                        if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
-                        so += 2;
-                    }
+                    stage_item(j, off);
                     off += cnt[j];
                 }
                 __builtin_amdgcn_wave_barrier();
-                int32_t* op = A.out_probe + wbase;
-                int32_t* ob = A.out_build + wbase;
-#pragma unroll 4
-                for (int i = lane; i < wtot; i += kWave) {
-                    const uint32_t e = stw[i];
-                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
-                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
-                }
+                copy_out(A.out_probe + wbase, A.out_build + wbase, wtot);
                 __builtin_amdgcn_wave_barrier();
             } else {
                 long long off = wbase + (linc - lsum);
 #pragma unroll
                 for (int j = 0; j < CS_ITEMS; ++j) {
-                    if (!lng[j]) {
-                        uint32_t m = mask[j];
-                        long long o = off;
-                        while (m) {
-                            const int t = __builtin_ctz(m);
-                            m &= m - 1;
-                            A.out_probe[o] = qrow[j]; A.out_build[o] = l_row[al[j] + t];
-                            ++o;
-                        }
-                    } else {
-                        long long o = off + cnt[j] - 1;
-                        for (int p = r0 + hi[j] - 1; o >= off; --p) {
-                            const int i = p - r0;
-                            int32_t ev = l_end[i < 0 ? 0 : i];
-                            if (i < 0) ev = A.ep[p].x;
-                            if (lt_op<STRICT>(qs[j], ev)) {
-                                int32_t rv = l_row[i < 0 ? 0 : i];
-                                if (i < 0) rv = A.b_row[p];
-                                A.out_probe[o] = qrow[j]; A.out_build[o] = rv; --o;
-                            }
-                        }
-                    }
+                    direct_item(j, off);
                     off += cnt[j];
                 }
             }
@@ -886,14 +989,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
             const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
-                int32_t* op = A.out_probe + tb + pend_woff;
-                int32_t* ob = A.out_build + tb + pend_woff;
-#pragma unroll 4
-                for (int i = lane; i < pend_wtot; i += kWave) {
-                    const uint32_t e = stw[i];
-                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
-                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
-                }
+                copy_out(A.out_probe + tb + pend_woff, A.out_build + tb + pend_woff, pend_wtot);
             }
             if (lane == 0) {
                 if (atomicAdd(c + 1, 1) == CS_WAVES - 1) {                     // last wavefront out: recycle the block for tile tix + 1
@@ -927,55 +1023,25 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             }
         }
         woff = ((long long)__builtin_amdgcn_readfirstlane((int)(woff >> 32)) << 32) | (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(woff & 0xffffffffll));
-        if (wtot > 0 && wtot <= A.wcap && !any_lng) {
-            // usual case: entries {wave-local probe slot << 16 | slice-local row} into the wavefront's staging region
+        if (wtot > 0 && wtot <= A.wcap) {
+            // usual case: the wavefront's entries into its staging region, copied out one iteration later
             int off = linc - lsum;
 #pragma unroll
             for (int j = 0; j < CS_ITEMS; ++j) {
                 qrw[j * kWave + lane] = qrow[j];
-                uint32_t m = mask[j];
-                uint32_t ent = ((uint32_t)(j * kWave + lane) << 16) | (uint32_t)al[j];
-                uint32_t* so = stw + off;
-                while (m) {                                                    // two matches per trip: half the loop overhead
-                    const int t = __builtin_ctz(m);
-                    m &= m - 1;
-                    so[0] = ent + (uint32_t)t;
-                    if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
-                    so += 2;
-                }
+                stage_item(j, off);
                 off += cnt[j];
             }
             pend_wtot = wtot;
         } else if (wtot > 0) {
-            // dense wavefront or windows running on below the examined rows: wait for the base now, write from the lanes
+            // dense wavefront: wait for the base now, write from the lanes
             for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
             const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (tb >= 0) {
                 long long off = tb + woff + (linc - lsum);
 #pragma unroll
                 for (int j = 0; j < CS_ITEMS; ++j) {
-                    if (!lng[j]) {
-                        uint32_t m = mask[j];
-                        long long o = off;
-                        while (m) {
-                            const int t = __builtin_ctz(m);
-                            m &= m - 1;
-                            A.out_probe[o] = qrow[j]; A.out_build[o] = l_row[al[j] + t];
-                            ++o;
-                        }
-                    } else {
-                        long long o = off + cnt[j] - 1;                        // the f-th match from the top of the window owns slot end - 1 - f
-                        for (int p = r0 + hi[j] - 1; o >= off; --p) {
-                            const int i = p - r0;
-                            int32_t ev = l_end[i < 0 ? 0 : i];
-                            if (i < 0) ev = A.ep[p].x;
-                            if (lt_op<STRICT>(qs[j], ev)) {
-                                int32_t rv = l_row[i < 0 ? 0 : i];
-                                if (i < 0) rv = A.b_row[p];
-                                A.out_probe[o] = qrow[j]; A.out_build[o] = rv; --o;
-                            }
-                        }
-                    }
+                    direct_item(j, off);
                     off += cnt[j];
                 }
             }

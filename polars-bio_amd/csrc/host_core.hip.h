@@ -152,6 +152,7 @@ struct ivj_index {
     uint32_t* cs_cell = nullptr;
     unsigned short* cs_bins = nullptr;
     int4* cs_smeta = nullptr;
+    int32_t* cs_hier = nullptr;          // maxima of the ends over 16-row blocks, level by level (k_cs_hier)
     bool tables_built = false;   // the direct-address tables exist (built on first use)
     bool has_tables = true;    // false: built for merge / cluster only (with_end_order & 2)     // rec4 is filled on demand (join + materialisation path, flat path)
     char* slab = nullptr;      // single allocation holding every array above

@@ -7,7 +7,7 @@ namespace {
 int build_tables(ivj_ctx* ctx, ivj_index* ix);
 // contig-aligned slice path (host_cslice.hip.h): geometry and per-index arrays
 bool cs_geom(int64_t n, int nc, int want_rows, CsGeom& g);
-size_t cs_index_bytes(const CsGeom& g);
+size_t cs_index_bytes(const CsGeom& g, int64_t n);
 void cs_index_carve(ivj_index* ix, char* p);
 
 // The direct-address tables (bins / brec over the starts) are built on first use: the slice path of pb.overlap never needs
@@ -264,7 +264,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t spl_bytes = align_up((size_t)SL_MAX_BUCKETS * 8) + align_up((size_t)SL_TAB_CONTIGS * 16) +
                                  align_up((size_t)(4 * SL_MAX_BUCKETS + 2 * SL_TAB_CONTIGS) * 4);
         ix->cs_ok = n > 0 && cs_geom(n, opts->n_contigs, opts->slice_rows > 0 ? opts->slice_rows : ctx->sl_env_rows, ix->cs_g);
-        const size_t cs_bytes = ix->cs_ok ? cs_index_bytes(ix->cs_g) : 0;
+        const size_t cs_bytes = ix->cs_ok ? cs_index_bytes(ix->cs_g, n) : 0;
         const size_t need = cs_bytes + spl_bytes + flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 32) + 2 * align_up((size_t)ix->bins_len * 4) +
                             3 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {

@@ -267,3 +267,32 @@ def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.01", "--steps", "1"],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+def test_far_chain_down_a_7M_row_contig(eng):
+    """One contig of 7M build rows (the slice path's largest geometry) with a contig-wide row at its bottom and a thin tail of
+    long rows; the probes sit at the top: their matches lie millions of sorted rows below their slice, reached through the far-row
+    chain (cslice.hip.h::walk_below) from global memory.  Exact against the oracle: fused pass, count + fill pair, auto policy."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(91)
+    n, span = 7_000_000, 240_000_000
+    s = np.sort(rng.integers(1000, span, n)).astype(np.int32)
+    e = (s + rng.integers(1, 30, n)).astype(np.int32)
+    m = rng.random(n) < 4e-5
+    e[m] = np.minimum(s[m].astype(np.int64) + rng.integers(1_000_000, 200_000_000, int(m.sum())), span + 5).astype(np.int32)
+    s[0], e[0] = 0, span + 10
+    perm = rng.permutation(n)
+    build = (np.zeros(n, np.int32), s[perm], e[perm])
+    q = 300_000
+    qs = rng.integers(span - 3_000_000, span, q).astype(np.int32)
+    probe = (np.zeros(q, np.int32), qs, (qs + rng.integers(0, 200, q)).astype(np.int32))
+    ep, eb = O.overlap_fast(O.Index(O.Side(*build), 1), O.Side(*probe), True)
+    oe = np.lexsort((eb, ep))
+    for pm, fused in ((6, False), (6, True), (0, True)):
+        if fused:
+            from test_gpu_parity import _fused_overlap
+            p, b = _fused_overlap(eng, probe, build, True, 1, pm, len(ep))
+        else:
+            p, b = eng.overlap(probe, build, True, 1, partition_mode=pm)
+        o = np.lexsort((b, p))
+        assert len(p) == len(ep) and (p[o] == ep[oe]).all() and (b[o] == eb[oe]).all(), (pm, fused)

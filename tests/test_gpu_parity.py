@@ -978,3 +978,43 @@ def test_slice_count_fill_pair_is_deterministic(eng):
             assert (p1 == p2).all() and (b1 == b2).all(), (strict, sr)
             o = np.argsort(p1, kind="stable")
             assert len(p1) == len(ep) and (p1[o] == ep).all() and (b1[o] == eb).all(), (strict, sr)
+
+
+def _long_tail_build(rng, n, nc, span, frac_long, n_wide):
+    """Short rows with a tail of long ones (50k .. 500k positions) and a few contig-wide rows: the shape that makes a sorted
+    index's backward windows run on (prefix maxima stay above every later start)."""
+    c = rng.integers(0, nc, n).astype(np.int32)
+    s = rng.integers(0, span, n).astype(np.int32)
+    e = (s + rng.integers(1, 400, n)).astype(np.int32)
+    m = rng.random(n) < frac_long
+    e[m] = s[m] + rng.integers(50_000, 500_000, int(m.sum())).astype(np.int32)
+    w = rng.integers(0, n, n_wide)
+    s[w] = rng.integers(0, 1000, n_wide).astype(np.int32)
+    e[w] = span + 1000
+    return c, s, e
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_long_build_tail_on_the_slice_path(eng, strict):
+    """Slice path with a tail of long build rows: the probes whose window runs on below the branch-free one take the far-row
+    chain (cslice.hip.h::walk_below) in the fused pass, the count pass and the fill pass.  Exact against the oracle for tiny
+    slices (the chain crosses many slices, rows come from global memory) and the default geometry; the auto policy too."""
+    rng = np.random.default_rng(77)
+    nc, span = 3, 6_000_000
+    build = _long_tail_build(rng, 150_000, nc, span, 0.01, 4)
+    pc = rng.integers(0, nc + 1, 400_000).astype(np.int32)
+    ps = rng.integers(0, span, 400_000).astype(np.int32)
+    probe = (pc, ps, (ps + rng.integers(0, 300, 400_000)).astype(np.int32))
+    ep, eb = O.overlap_fast(O.Index(O.Side(*build), nc), O.Side(*probe), strict)
+    ec = O.count_overlaps_fast(O.Index(O.Side(*build), nc), O.Side(*probe), strict)
+    for sr in (64, 0):
+        hp, hb = _fused_overlap(eng, probe, build, strict, nc, 6, len(ep), slice_rows=sr)
+        p, b = _canon(hp, hb)
+        assert (p == ep).all() and (b == eb).all(), ("fused", sr)
+        p1, b1 = eng.overlap(probe, build, strict, nc, partition_mode=6, slice_rows=sr)      # count + fill
+        o = np.argsort(p1, kind="stable")
+        assert len(p1) == len(ep) and (p1[o] == ep).all() and (b1[o] == eb).all(), ("two-pass", sr)
+    hp, hb = _fused_overlap(eng, probe, build, strict, nc, 0, len(ep))
+    p, b = _canon(hp, hb)
+    assert (p == ep).all() and (b == eb).all(), "auto"
+    assert (eng.count_overlaps(probe, build, strict, nc) == ec).all()
