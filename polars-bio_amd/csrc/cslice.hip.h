@@ -63,40 +63,7 @@ __device__ __forceinline__ int wave_incl_sum_dpp(int v) {
     return v;
 }
 
-// gfx950 needs two wait states between a VALU write of an SGPR pair / VCC and a VALU that reads it as a carry or lane mask
-// (the compiler pads every v_cmp -> v_cndmask / v_addc pair with s_nop 1).  The two hot compare sequences of the join are
-// therefore written out with rotating SGPR pairs, every consumer three instructions behind its compare: no padding.
-//
-// Window mask: bit i <=> qs (<) e[i] for the sixteen ends e[0..15]; row 15 is shifted in first (m = m + m + carry).
-#define IVJ_CS_WINDOW_ASM(CMP)                                                                                                     \
-    asm("v_cmp_" CMP "_i32_e64 %1, %5, %21\n\tv_cmp_" CMP "_i32_e64 %2, %5, %20\n\tv_cmp_" CMP "_i32_e64 %3, %5, %19\n\t"     \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %18\n\t"                                       \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %17\n\t"                                       \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %16\n\t"                                       \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %15\n\t"                                       \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %14\n\t"                                       \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %13\n\t"                                       \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %12\n\t"                                       \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %11\n\t"                                       \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %10\n\t"                                       \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %9\n\t"                                        \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %8\n\t"                                        \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %7\n\t"                                        \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %6\n\t"                                        \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t"                                                                             \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"                                                                             \
-        "v_addc_co_u32_e64 %0, %4, %0, %0, %1"                                                                                  \
-        : "+v"(m), "=&s"(ta), "=&s"(tb), "=&s"(tc), "=&s"(td)                                                                   \
-        : "v"(qs), "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w), "v"(v2.x), "v"(v2.y),  \
-          "v"(v2.z), "v"(v2.w), "v"(v3.x), "v"(v3.y), "v"(v3.z), "v"(v3.w))
-template <bool STRICT>
-__device__ __forceinline__ uint32_t cs_window_mask(int32_t qs, const int4& v0, const int4& v1, const int4& v2, const int4& v3) {
-    uint32_t m = 0;
-    unsigned long long ta, tb, tc, td;
-    if (STRICT) IVJ_CS_WINDOW_ASM("lt");
-    else IVJ_CS_WINDOW_ASM("le");
-    return m;
-}
+// (the two-wait-state rule and the sixteen-end window mask, ends_mask16, live in index_view.hip.h)
 // h + number of the four starts below the probe's end (s (<) qe); *m4 = lanes whose fourth start is still below it
 #define IVJ_CS_COUNT4_ASM(CMP)                                                                                                     \
     asm("v_cmp_" CMP "_i32_e64 %1, %6, %10\n\tv_cmp_" CMP "_i32_e64 %2, %7, %10\n\tv_cmp_" CMP "_i32_e64 %3, %8, %10\n\t"      \
@@ -216,51 +183,6 @@ __device__ __forceinline__ uint32_t cs_bucket(const unsigned long long* __restri
     const int hi = (int)(lh >> 16);
     while (pos < hi && l_spl[pos] < key) ++pos;
     return pos <= (int)((uint32_t)m.w >> 16) ? (uint32_t)nb : (uint32_t)(pos - 1);
-}
-
-// ---- maxima of the ends over 16-row blocks, 16 blocks to a block (windows that run on below the branch-free one) ------------
-// A probe whose window is not settled by the CS_WIN rows below its hi-bound (the prefix max there is still above its start) has
-// to find every row further down that ends above its start.  With a tail of long intervals in the build side (genes among exons,
-// a contig-wide row) the prefix max stays high for hundreds to millions of rows, of which a handful match: a row-by-row walk is
-// what makes sorted-window joins fall off a cliff on such inputs.  hier level 0 = the ends in sorted order (a compact copy: one
-// 64-byte line = one block), level l >= 1, entry i = max end over the sorted rows [i << 4l, (i + 1) << 4l) (blocks may
-// straddle contigs, the walk stops at the contig's first row).  The walk enters a block only when its maximum is above the
-// probe's start, i.e. only blocks that hold a match, and reads a block with four 16-byte loads: a few dependent loads per match,
-// whatever the intervals look like.  (1 + 1/15) n values per index, every level padded to whole blocks.
-constexpr int CS_HIER_MAX = 8;                          // levels incl. level 0: 16^7 rows
-struct CsHier {
-    int nlev;                                           // highest level
-    int off[CS_HIER_MAX];                               // offset of level l in the hier array
-    int len[CS_HIER_MAX];
-};
-__host__ __device__ inline CsHier cs_hier_make(int64_t n) {
-    CsHier h;
-    h.nlev = 0;
-    int64_t o = 0, len = n;
-    for (int l = 0; l < CS_HIER_MAX; ++l) {
-        h.off[l] = (int)o; h.len[l] = 0;
-        if (l == 0 || len > 16) {
-            if (l > 0) len = (len + 15) / 16;
-            h.len[l] = (int)len; h.nlev = l;
-            o += (len + 15) & ~(int64_t)15;
-        } else len = 0;
-    }
-    return h;
-}
-inline size_t cs_hier_values(int64_t n) {
-    const CsHier h = cs_hier_make(n);
-    return (size_t)h.off[h.nlev] + (((size_t)h.len[h.nlev] + 15) & ~(size_t)15) + 16;
-}
-// level 0 from the ends (group 1, stride 2 in ep), level l + 1 from level l (group 16); pads of the last block = INT32_MIN
-__global__ void k_cs_hier(const int32_t* __restrict__ src, int stride, int group, int n_src, int32_t* __restrict__ dst, int n_dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ((n_dst + 15) & ~15)) return;
-    int32_t m = INT32_MIN;
-    const int b = i * group;
-    for (int t = 0; t < group; ++t) {
-        if (b + t < n_src) { const int32_t v = src[(size_t)(b + t) * stride]; m = v > m ? v : m; }
-    }
-    dst[i] = m;
 }
 
 // ---- per-slice start bins, built once per index: one workgroup per slice ---------------------------------------------------
@@ -622,8 +544,7 @@ struct CsJoinArgs {
     const int32_t* b_row;
     const unsigned short* bins;       // per-slice start bins (k_cs_bins)
     const int4* smeta;                // per-slice metadata (two int4)
-    const int32_t* hier;              // block maxima of the ends, levels 1 .. hl.nlev (k_cs_hier)
-    CsHier hl;
+    HierView hier;                    // the sorted ends and their block maxima (index_view.hip.h)
     const int32_t* rec;               // bucket-ordered probe records {start, end, row}
     const uint32_t* bstart;           // nb + 2 bucket starts
     const int32_t* meta;              // [0] = number of join workgroups
@@ -650,7 +571,7 @@ __host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
     L.bin = o; o += 2 * (2 * R + 8);
     L.qrow = (o + 15) & ~15; o = L.qrow + 4 * CS_TILE;
     L.stage = o; o += 4 * wcap * CS_WAVES;
-    L.ctl = (o + 15) & ~15; o = L.ctl + 64 + 4 * CS_HIER_MAX;    // control blocks + the offsets of the hier levels
+    L.ctl = (o + 15) & ~15; o = L.ctl + 64;
     L.total = o;
     return L;
 }
@@ -668,7 +589,6 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     uint32_t* l_stage = reinterpret_cast<uint32_t*>(cs_lds + L.stage);
     unsigned long long* lc = reinterpret_cast<unsigned long long*>(cs_lds + L.ctl);     // [2][2] {cursor, base}
     int* li = reinterpret_cast<int*>(lc + 4);                                           // [2][4] {arrived, done, ready, seq}
-    int* l_hoff = li + 8;                                                               // offsets of the hier levels
 
     // XCD-affine order: workgroup b runs on XCD b % 8 (observed); XCD x takes the contiguous eighth of the (bucket, chunk) list
     const int total_wg = A.meta[0];
@@ -718,7 +638,6 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         for (int i = tid; i < (ncell + 2) / 2; i += CS_THREADS) lb32[i] = gb32[i];
     }
     if (tid < 4) lc[tid] = 0;
-    if (tid < CS_HIER_MAX) l_hoff[tid] = A.hl.off[tid];
     if (tid < 8) li[tid] = (tid == 7) ? 1 : 0;                                 // block 1 serves tile 1 first (seq = li[1][3])
     __syncthreads();
 
@@ -748,49 +667,13 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
 
     // Matches of a probe starting at qsv among the sorted rows BELOW slice-local row a0 (the rows the branch-free window does not
     // cover; all of them start below the probe's end, so a row matches iff it ends above qsv), visited in descending position;
-    // f(p) gets the global sorted position.  Depth-first over the block maxima (k_cs_hier), right to left, one 16-entry block
-    // per step: the entries at or left of the cursor that are above qsv are rows to report (level 0) or the child to enter (the
-    // rightmost one); an exhausted block hands over to the entries left of its parent, and the prefix max of the row below the
-    // subtree just left says whether anything further down can still match.
+    // f(p) gets the global sorted position: hier_walk (index_view.hip.h), with the slice's rows read from LDS.
     auto ep_at = [&](int p) -> int2 {
         const int i = p - r0;
         if (i >= 0) return make_int2(l_end[i], l_pmx[i + 1]);
         return A.ep[p];
     };
-    auto walk_below = [&](int32_t qsv, int a0, auto&& f) {
-        int i = r0 + a0 - 1, lv = 0;
-        const int top = A.hl.nlev;
-        int chk = -1;                                                          // row whose prefix max is still to be looked at
-        while (i >= 0) {
-            if ((((i + 1) << (4 * lv)) - 1) < seg_a) return;                   // the entry lies below the contig
-            const int base = i & ~15;
-            const int4* bp = reinterpret_cast<const int4*>(A.hier + l_hoff[lv] + base);
-            const int4 w0 = bp[0], w1 = bp[1], w2 = bp[2], w3 = bp[3];
-            if (chk >= 0) {
-                if (!lt_op<STRICT>(qsv, ep_at(chk).y)) return;                 // nothing at or below row chk reaches the probe
-                chk = -1;
-            }
-            uint32_t m = cs_window_mask<STRICT>(qsv, w0, w1, w2, w3) & ((2u << (i & 15)) - 1u);
-            if (lv == 0) {
-                if (seg_a > base) m &= ~((1u << (seg_a - base)) - 1u);
-                while (m) { const int j = 31 - __builtin_clz(m); m ^= 1u << j; f(base + j); }
-            } else if (m) {
-                i = ((base + 31 - __builtin_clz(m)) << 4) + 15;               // the rightmost child above qsv, all of it
-                --lv;
-                continue;
-            }
-            // block exhausted: the entries left of its parent (of the first ancestor that has any)
-            int node = base;
-            do {
-                if (lv == top) return;
-                node >>= 4; ++lv;
-            } while ((node & 15) == 0);
-            const int b = node << (4 * lv);                                    // first row of the subtree just left
-            if (b <= seg_a) return;
-            chk = b - 1;
-            i = node - 1;
-        }
-    };
+    auto walk_below = [&](int32_t qsv, int a0, auto&& f) { hier_walk<STRICT>(A.hier, ep_at, seg_a, r0 + a0 - 1, qsv, f); };
 
     auto match_tile = [&](int64_t tb) {
         int32_t qe[CS_ITEMS];
@@ -861,7 +744,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int j = jj + u;
-                uint32_t m = cs_window_mask<STRICT>(qs[j], w[u][0], w[u][1], w[u][2], w[u][3]);
+                uint32_t m = ends_mask16<STRICT>(qs[j], w[u][0], w[u][1], w[u][2], w[u][3]);
                 m = __builtin_amdgcn_ubfe(m, 0u, (uint32_t)(hi[j] - al[j]));    // rows al .. hi - 1
                 const bool lng = valid[j] && lt_op<STRICT>(qs[j], pm[u]);
                 mask[j] = valid[j] ? m : 0u;
@@ -876,7 +759,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             for (int j = 0; j < CS_ITEMS; ++j) {
                 if (lngm & (1u << j)) {
                     int c2 = 0;
-                    walk_below(qs[j], al[j], [&](int) { ++c2; });
+                    walk_below(qs[j], al[j], [&](int) { ++c2; return true; });
                     cnt[j] += c2;
                 }
             }
@@ -890,7 +773,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         const int cw = cnt[j] - __popc(m);                                     // matches below the window
         if (any_lng && cw > 0) {
             uint32_t* sw = stw + off + cw - 1;
-            walk_below(qs[j], al[j], [&](int p) { *sw-- = slot | (uint32_t)(p - r0 + CS_POS_BIAS); });
+            walk_below(qs[j], al[j], [&](int p) { *sw-- = slot | (uint32_t)(p - r0 + CS_POS_BIAS); return true; });
         }
         const uint32_t ent = slot | (uint32_t)(al[j] + CS_POS_BIAS);
         uint32_t* so = stw + off + cw;
@@ -908,7 +791,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         const int cw = cnt[j] - __popc(m);
         if (any_lng && cw > 0) {
             long long o = off + cw - 1;
-            walk_below(qs[j], al[j], [&](int p) { A.out_probe[o] = qrow[j]; A.out_build[o] = p >= r0 ? l_row[p - r0] : A.b_row[p]; --o; });
+            walk_below(qs[j], al[j], [&](int p) { A.out_probe[o] = qrow[j]; A.out_build[o] = p >= r0 ? l_row[p - r0] : A.b_row[p]; --o; return true; });
         }
         long long o = off + cw;
         while (m) {

@@ -61,6 +61,7 @@ struct ivj_ctx {
     int32_t* ov_cnt = nullptr;
     long long* ov_tile = nullptr;   // ntiles + 1: tile bases, last = total
     long long* h_total = nullptr;   // pinned
+    char* bounce = nullptr;         // pinned bounce buffer of the host <-> HBM copies (HostXfer), allocated on first use
     // one released index slab kept for reuse (bench/streaming loops rebuild the index every call)
     char* ix_cache = nullptr;
     size_t ix_cache_cap = 0;
@@ -152,7 +153,8 @@ struct ivj_index {
     uint32_t* cs_cell = nullptr;
     unsigned short* cs_bins = nullptr;
     int4* cs_smeta = nullptr;
-    int32_t* cs_hier = nullptr;          // maxima of the ends over 16-row blocks, level by level (k_cs_hier)
+    int32_t* hier = nullptr;             // the sorted ends and their block maxima, level by level (k_hier_level); filled on first use
+    bool hier_built = false;
     bool tables_built = false;   // the direct-address tables exist (built on first use)
     bool has_tables = true;    // false: built for merge / cluster only (with_end_order & 2)     // rec4 is filled on demand (join + materialisation path, flat path)
     char* slab = nullptr;      // single allocation holding every array above
@@ -295,6 +297,11 @@ IndexView view_of(const ivj_index* ix) {
     v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec; v.cmeta_j = ix->cmeta_j; v.crec = ix->crec;
     v.bins = ix->bins; v.bins_e = ix->bins_e; v.rec4 = ix->rec4; v.tab2 = ix->tab2;
     // 16-byte bin records once the 4-byte tables + key arrays no longer fit the XCD L2s anyway
+    {
+        const HierShape h = hier_shape(ix->n > 0 ? ix->n : 1);
+        v.hier.v = ix->hier; v.hier.nlev = h.nlev;
+        for (int l = 0; l < HIER_MAX; ++l) v.hier.off[l] = h.off[l];
+    }
     v.use_rec = ix->table_mode == 1 ? 1 : (ix->table_mode == 2 ? 0 : (ix->n >= (1ll << 20) ? 1 : 0));
     return v;
 }

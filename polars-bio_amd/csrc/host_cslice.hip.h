@@ -29,8 +29,8 @@ bool cs_geom(int64_t n, int nc, int want_rows, CsGeom& g) {
 }
 
 // bytes of the per-index arrays of this path (part of the index slab)
-size_t cs_index_bytes(const CsGeom& g, int64_t n) {
-    return align_up(cs_hier_values(n) * 4) + align_up((size_t)(g.nb + 2) * 4) + align_up((size_t)g.nb * 8) + align_up((size_t)CS_MAX_CONTIGS * 16) + align_up((size_t)g.ncells * 4) +
+size_t cs_index_bytes(const CsGeom& g) {
+    return align_up((size_t)(g.nb + 2) * 4) + align_up((size_t)g.nb * 8) + align_up((size_t)CS_MAX_CONTIGS * 16) + align_up((size_t)g.ncells * 4) +
            align_up((size_t)g.nb * (size_t)(2 * g.R + CS_BIN_STRIDE_PAD) * 2) + align_up((size_t)g.nb * 32);
 }
 void cs_index_carve(ivj_index* ix, char* p) {
@@ -40,8 +40,7 @@ void cs_index_carve(ivj_index* ix, char* p) {
     ix->cs_cm = (int4*)p; p += align_up((size_t)CS_MAX_CONTIGS * 16);
     ix->cs_cell = (uint32_t*)p; p += align_up((size_t)g.ncells * 4);
     ix->cs_bins = (unsigned short*)p; p += align_up((size_t)g.nb * (size_t)(2 * g.R + CS_BIN_STRIDE_PAD) * 2);
-    ix->cs_smeta = (int4*)p; p += align_up((size_t)g.nb * 32);
-    ix->cs_hier = (int32_t*)p;
+    ix->cs_smeta = (int4*)p;
 }
 
 // The path serves the FUSED single pass wherever the slice path is wanted (host_slice.hip.h::want_slices) and the index has
@@ -63,17 +62,7 @@ int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix) {
                        (const int32_t*)ix->b_contig, (const int32_t*)ix->seg, g.R, ix->cs_bins, ix->cs_smeta);
     t_end(ctx);
     HIP_TRY(hipGetLastError());
-    // the ends in sorted order and their block maxima, level by level (cslice.hip.h: windows that run on below the branch-free one)
-    {
-        const CsHier h = cs_hier_make(ix->n);
-        for (int l = 0; l <= h.nlev; ++l) {
-            const int32_t* src = l == 0 ? reinterpret_cast<const int32_t*>(ix->ep) : ix->cs_hier + h.off[l - 1];
-            const int padded = (h.len[l] + 15) & ~15;
-            LAUNCH(ctx, "cs_hier", k_cs_hier, (unsigned)((padded + 255) / 256), 256, src, l == 0 ? 2 : 1, l == 0 ? 1 : 16, l == 0 ? (int)ix->n : h.len[l - 1],
-                   ix->cs_hier + h.off[l], h.len[l]);
-        }
-        HIP_TRY(hipGetLastError());
-    }
+    IVJ_TRY(ensure_hier(ctx, ix));
     ix->cs_built = true;
     return IVJ_OK;
 }
@@ -162,7 +151,7 @@ template <int MODE>
 int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const SlicePlan& P, long long capacity, int32_t* out_p, int32_t* out_b) {
     const CsGeom& g = ix->cs_g;
     CsJoinArgs A;
-    A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta; A.hier = ix->cs_hier; A.hl = cs_hier_make(ix->n);
+    A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta; A.hier = view_of(ix).hier;
     A.rec = reinterpret_cast<int32_t*>(ctx->sl_rec); A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
     A.R = g.R; A.jchunk = P.jchunk; A.wcap = P.stage; A.ablate = ctx->sl_env_ablate; A.capacity = capacity;
     A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);

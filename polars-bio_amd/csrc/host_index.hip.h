@@ -7,13 +7,29 @@ namespace {
 int build_tables(ivj_ctx* ctx, ivj_index* ix);
 // contig-aligned slice path (host_cslice.hip.h): geometry and per-index arrays
 bool cs_geom(int64_t n, int nc, int want_rows, CsGeom& g);
-size_t cs_index_bytes(const CsGeom& g, int64_t n);
+size_t cs_index_bytes(const CsGeom& g);
 void cs_index_carve(ivj_index* ix, char* p);
 
 // The direct-address tables (bins / brec over the starts) are built on first use: the slice path of pb.overlap never needs
 // them, the window-scan kernels, nearest, count_overlaps, coverage and subtract do.
+// the sorted ends and their block maxima, level by level (index_view.hip.h: windows that run on); filled on first use
+int ensure_hier(ivj_ctx* ctx, ivj_index* ix) {
+    if (ix->hier_built || ix->n <= 0) return IVJ_OK;
+    const HierShape h = hier_shape(ix->n);
+    for (int l = 0; l <= h.nlev; ++l) {
+        const int32_t* src = l == 0 ? reinterpret_cast<const int32_t*>(ix->ep) : ix->hier + h.off[l - 1];
+        const int64_t padded = (h.len[l] + 15) & ~(int64_t)15;
+        LAUNCH(ctx, "hier_level", k_hier_level, (unsigned)((padded + 255) / 256), 256, src, l == 0 ? 2 : 1, l == 0 ? 1 : 16, l == 0 ? ix->n : h.len[l - 1],
+               ix->hier + h.off[l], h.len[l]);
+    }
+    HIP_TRY(hipGetLastError());
+    ix->hier_built = true;
+    return IVJ_OK;
+}
+
 int need_tables(ivj_ctx* ctx, ivj_index* ix) {
     if (!ix->has_tables) return fail(IVJ_ESTATE, "this index was built for merge / cluster only (with_end_order & 2): it has no lookup tables");
+    IVJ_TRY(ensure_hier(ctx, ix));
     if (ix->tables_built) return IVJ_OK;
     return build_tables(ctx, ix);
 }
@@ -264,8 +280,9 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t spl_bytes = align_up((size_t)SL_MAX_BUCKETS * 8) + align_up((size_t)SL_TAB_CONTIGS * 16) +
                                  align_up((size_t)(4 * SL_MAX_BUCKETS + 2 * SL_TAB_CONTIGS) * 4);
         ix->cs_ok = n > 0 && cs_geom(n, opts->n_contigs, opts->slice_rows > 0 ? opts->slice_rows : ctx->sl_env_rows, ix->cs_g);
-        const size_t cs_bytes = ix->cs_ok ? cs_index_bytes(ix->cs_g, n) : 0;
-        const size_t need = cs_bytes + spl_bytes + flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 32) + 2 * align_up((size_t)ix->bins_len * 4) +
+        const size_t cs_bytes = ix->cs_ok ? cs_index_bytes(ix->cs_g) : 0;
+        const size_t hier_bytes = align_up(hier_shape((int64_t)nn).values * 4);
+        const size_t need = hier_bytes + cs_bytes + spl_bytes + flat_bytes + 6 * col + align_up(nn * 8) + align_up((nn + 1) * 32) + 2 * align_up((size_t)ix->bins_len * 4) +
                             3 * align_up((size_t)ix->bins_len * 16) + small + 256;
         if (ctx->ix_cache && ctx->ix_cache_cap >= need) {
             ix->slab = ctx->ix_cache; ix->slab_cap = ctx->ix_cache_cap;
@@ -304,7 +321,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->cmeta = (int4*)p; p += align_up((nc + 1) * 32);
         ix->cmeta_e = (int4*)p; p += align_up((nc + 1) * 32);
         ix->cmeta_j = (int4*)p; p += align_up((nc + 1) * 32);
-        if (ix->cs_ok) cs_index_carve(ix, p);
+        if (ix->cs_ok) { cs_index_carve(ix, p); p += cs_bytes; }
+        ix->hier = (int32_t*)p;
         // seg, flags and cmeta start zeroed: an empty index answers every probe with "no rows"
         hipError_t e = hipMemsetAsync(small_base, 0, small, ctx->stream);
         if (e != hipSuccess) return cleanup(fail(IVJ_EHIP, std::string("hipMemsetAsync(index meta): ") + hipGetErrorString(e)));

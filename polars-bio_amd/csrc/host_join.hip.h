@@ -379,15 +379,13 @@ int upload_side(ivj_ctx* ctx, const ivj_side* h, DevSide& d) {
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(side): ") + hipGetErrorString(e));
     int32_t* c = d.buf; int32_t* s = (int32_t*)((char*)d.buf + col); int32_t* en = (int32_t*)((char*)d.buf + 2 * col);
     // the caller's (Arrow / numpy) buffers are registered in place for the copy: the DMA engine reads them directly
-    // (tools/pcie_probe.py: ~3 ms per GB to register, 57 GB/s); small or unregistrable ranges go the pageable way
+    // (tools/pcie_probe.py: ~3 ms per GB to register, 57 GB/s); small or unregistrable ranges go through the bounce buffer
     const size_t nb = (size_t)h->n * 4;
-    {
-        HostPin pc(h->contig, nb), ps(h->start, nb), pe(h->end, nb);
-        HIP_TRY(hipMemcpyAsync(c, h->contig, nb, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(s, h->start, nb, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(en, h->end, nb, hipMemcpyHostToDevice, ctx->stream));
-        if (pc.ok || ps.ok || pe.ok) HIP_TRY(hipStreamSynchronize(ctx->stream));      // before the ranges are unregistered
-    }
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.h2d(c, h->contig, nb);
+    copy.h2d(s, h->start, nb);
+    copy.h2d(en, h->end, nb);
+    HIP_TRY(copy.finish());
     d.s.contig = c; d.s.start = s; d.s.end = en;
     return IVJ_OK;
 }

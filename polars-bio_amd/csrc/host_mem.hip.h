@@ -12,6 +12,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <thread>
 
 namespace {
@@ -105,16 +106,95 @@ void host_copy_parallel(void* dst, const void* src, size_t bytes) {
 struct HostPin {
     void* p = nullptr;
     bool ok = false;
-    HostPin(const void* ptr, size_t bytes) {
-        if (ptr && bytes >= ((size_t)1 << 20)) {
+    hipError_t code = hipSuccess;
+    HostPin(const void* ptr, size_t bytes, size_t min_bytes = (size_t)1 << 20) {
+        if (ptr && bytes >= min_bytes) {
             p = const_cast<void*>(ptr);
-            ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
+            code = hipHostRegister(p, bytes, hipHostRegisterDefault);
+            ok = code == hipSuccess;
             if (!ok) (void)hipGetLastError();
         }
     }
     ~HostPin() { if (ok) (void)hipHostUnregister(p); }
     HostPin(const HostPin&) = delete;
     HostPin& operator=(const HostPin&) = delete;
+};
+
+// Every copy between caller / library host memory and HBM goes through this object, never through the runtime's own handling
+// of pageable memory: left to itself the runtime pins a pageable range on the fly and keeps up to eight such pins per queue
+// cached BY ADDRESS -- a later copy whose host range starts where an earlier, since freed one did reuses the stale pin (an H2D
+// source is pinned read-only: "Memory access fault ... Write access to a read-only page" when malloc hands the same address to a
+// result buffer; pages that were unmapped in between: "Reason: Unknown").  Here a range of XFER_PIN_MIN bytes or more is
+// registered for the duration of the copy (hipHostRegister, ~3 ms / GB; a range the caller has registered already is used as it
+// is), anything smaller -- or not registrable -- is staged through the context's own pinned bounce buffer.
+// add copies, then finish(): when it returns every copy is complete and every range unregistered.
+constexpr size_t XFER_PIN_MIN = (size_t)256 << 10;
+constexpr size_t XFER_BOUNCE = (size_t)4 << 20;
+
+struct HostXfer {
+    hipStream_t stream;
+    char** bounce;                                         // the context's pinned bounce buffer (allocated on first use)
+    std::vector<HostPin*> pins;
+    struct Pend { void* dst; size_t off, bytes; };
+    std::vector<Pend> outs;                                // D2H copies parked in the bounce buffer
+    size_t used = 0;
+    hipError_t err = hipSuccess;
+    HostXfer(hipStream_t s, char** bounce_slot) : stream(s), bounce(bounce_slot) {}
+    HostXfer(const HostXfer&) = delete;
+    HostXfer& operator=(const HostXfer&) = delete;
+    ~HostXfer() { (void)finish(); }
+
+    bool direct(const void* host, size_t bytes) {          // true: the DMA engine may address the range itself
+        if (bytes < XFER_PIN_MIN) return false;
+        HostPin* p = new HostPin(host, bytes, XFER_PIN_MIN);
+        if (p->ok) { pins.push_back(p); return true; }
+        const bool already = p->code == hipErrorHostMemoryAlreadyRegistered;
+        delete p;
+        return already;
+    }
+    bool have_bounce() {
+        if (!*bounce && err == hipSuccess) err = hipHostMalloc((void**)bounce, XFER_BOUNCE, hipHostMallocDefault);
+        return *bounce != nullptr;
+    }
+    void drain() {                                         // completes what is parked in the bounce buffer
+        const hipError_t s = hipStreamSynchronize(stream);
+        if (err == hipSuccess) err = s;
+        if (err == hipSuccess) for (const Pend& o : outs) std::memcpy(o.dst, *bounce + o.off, o.bytes);
+        outs.clear();
+        used = 0;
+    }
+    void h2d(void* dst_dev, const void* src_host, size_t bytes) {
+        if (err != hipSuccess || bytes == 0) return;
+        if (direct(src_host, bytes)) { err = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream); return; }
+        if (!have_bounce()) return;
+        for (size_t o = 0; o < bytes && err == hipSuccess;) {
+            if (used == XFER_BOUNCE) drain();
+            const size_t n = std::min(bytes - o, XFER_BOUNCE - used);
+            std::memcpy(*bounce + used, (const char*)src_host + o, n);
+            err = hipMemcpyAsync((char*)dst_dev + o, *bounce + used, n, hipMemcpyHostToDevice, stream);
+            used += (n + 255) & ~(size_t)255; if (used > XFER_BOUNCE) used = XFER_BOUNCE;
+            o += n;
+        }
+    }
+    void d2h(void* dst_host, const void* src_dev, size_t bytes) {
+        if (err != hipSuccess || bytes == 0) return;
+        if (direct(dst_host, bytes)) { err = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, stream); return; }
+        if (!have_bounce()) return;
+        for (size_t o = 0; o < bytes && err == hipSuccess;) {
+            if (used == XFER_BOUNCE) drain();
+            const size_t n = std::min(bytes - o, XFER_BOUNCE - used);
+            err = hipMemcpyAsync(*bounce + used, (const char*)src_dev + o, n, hipMemcpyDeviceToHost, stream);
+            outs.push_back(Pend{(char*)dst_host + o, used, n});
+            used += (n + 255) & ~(size_t)255; if (used > XFER_BOUNCE) used = XFER_BOUNCE;
+            o += n;
+        }
+    }
+    hipError_t finish() {
+        if (used || !pins.empty() || !outs.empty()) drain();
+        for (HostPin* p : pins) delete p;
+        pins.clear();
+        return err;
+    }
 };
 
 }  // namespace

@@ -35,6 +35,13 @@ constexpr int PROBE_ITEMS_LAT = 2;   // nearest and the dense fill: shorter per-
 constexpr int PROBE_TILE = PROBE_THREADS * PROBE_ITEMS;
 constexpr int CM_LDS = 256;      // per-contig grid metadata is copied to LDS by the per-probe kernels up to this many contigs
 
+constexpr int HIER_MAX = 8;                             // levels of the block maxima incl. level 0: 16^7 rows
+struct HierView {
+    const int32_t* v;
+    int nlev;                                           // highest level
+    uint32_t off[HIER_MAX];                             // offset of level l in v
+};
+
 struct IndexView {
     const int32_t* b_start;
     const int2* ep;
@@ -60,6 +67,7 @@ struct IndexView {
     const int4* rec4;       // flat overlap path: {start, end, build row, prefix max} per sorted position
     const uint2* tab2;      //   tab2[slot] = {first position of start bin `slot`, first position whose prefix max reaches its lower edge}
     int32_t n_contigs;
+    HierView hier;          // the sorted ends and their block maxima: windows that run on (hier_walk)
 };
 
 __device__ __forceinline__ uint32_t flip(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
@@ -67,6 +75,126 @@ __device__ __forceinline__ int32_t unflip(uint32_t v) { return (int32_t)(v ^ 0x8
 
 template <bool STRICT>
 __device__ __forceinline__ bool lt_op(int32_t x, int32_t y) { return STRICT ? (x < y) : (x <= y); }
+
+// gfx950 needs two wait states between a VALU write of an SGPR pair / VCC and a VALU that reads it as a carry or lane mask
+// (the compiler pads every v_cmp -> v_cndmask / v_addc pair with s_nop 1).  The two hot compare sequences of the join are
+// therefore written out with rotating SGPR pairs, every consumer three instructions behind its compare: no padding.
+//
+// Mask of sixteen ends: bit i <=> qs (<) e[i] for the sixteen ends e[0..15]; row 15 is shifted in first (m = m + m + carry).
+#define IVJ_ENDS_MASK_ASM(CMP)                                                                                                     \
+    asm("v_cmp_" CMP "_i32_e64 %1, %5, %21\n\tv_cmp_" CMP "_i32_e64 %2, %5, %20\n\tv_cmp_" CMP "_i32_e64 %3, %5, %19\n\t"     \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %18\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %17\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %16\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %15\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %14\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %13\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %12\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %11\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %10\n\t"                                       \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %9\n\t"                                        \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\tv_cmp_" CMP "_i32_e64 %2, %5, %8\n\t"                                        \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\tv_cmp_" CMP "_i32_e64 %3, %5, %7\n\t"                                        \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\tv_cmp_" CMP "_i32_e64 %1, %5, %6\n\t"                                        \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t"                                                                             \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"                                                                             \
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1"                                                                                  \
+        : "+v"(m), "=&s"(ta), "=&s"(tb), "=&s"(tc), "=&s"(td)                                                                   \
+        : "v"(qs), "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w), "v"(v2.x), "v"(v2.y),  \
+          "v"(v2.z), "v"(v2.w), "v"(v3.x), "v"(v3.y), "v"(v3.z), "v"(v3.w))
+template <bool STRICT>
+__device__ __forceinline__ uint32_t ends_mask16(int32_t qs, const int4& v0, const int4& v1, const int4& v2, const int4& v3) {
+    uint32_t m = 0;
+    unsigned long long ta, tb, tc, td;
+    if (STRICT) IVJ_ENDS_MASK_ASM("lt");
+    else IVJ_ENDS_MASK_ASM("le");
+    return m;
+}
+
+// ---- the sorted ends and their block maxima ("hier"): windows that run on --------------------------------------------------------
+// A probe whose window is not settled by the few rows below its hi-bound (the prefix max there is still above its start) has to
+// find every row further down that ends above its start.  With a tail of long intervals in the build side (genes among exons, a
+// contig-wide row) the prefix max stays high for hundreds to millions of rows, of which a handful match: a row-by-row scan is what
+// makes sorted-window joins fall off a cliff on such inputs.  hier level 0 = the ends in sorted order (a compact copy: one
+// 64-byte line = one block of sixteen), level l >= 1, entry i = max end over the sorted rows [i << 4l, (i + 1) << 4l) (blocks
+// may straddle contigs, the walk stops at the contig's first row).  hier_walk enters a block only when its maximum is above the
+// probe's start, i.e. only blocks that hold a match, and reads a block with four 16-byte loads: a few dependent loads per match,
+// whatever the intervals look like.  (1 + 1/15) n values per index, every level padded to whole blocks.
+struct HierShape {
+    int nlev;
+    uint32_t off[HIER_MAX];
+    int64_t len[HIER_MAX];
+    size_t values;                                      // allocation, in values
+};
+inline HierShape hier_shape(int64_t n) {
+    HierShape h;
+    h.nlev = 0;
+    int64_t o = 0, len = n;
+    for (int l = 0; l < HIER_MAX; ++l) {
+        h.off[l] = (uint32_t)o; h.len[l] = 0;
+        if (l == 0 || len > 16) {
+            if (l > 0) len = (len + 15) / 16;
+            h.len[l] = len; h.nlev = l;
+            o += (len + 15) & ~(int64_t)15;
+        } else len = 0;
+    }
+    h.values = (size_t)o + 16;
+    return h;
+}
+// level 0 from the ends (group 1, stride 2 in ep), level l + 1 from level l (group 16); pads of the last block = INT32_MIN
+__global__ void k_hier_level(const int32_t* __restrict__ src, int stride, int group, int64_t n_src, int32_t* __restrict__ dst, int64_t n_dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((n_dst + 15) & ~(int64_t)15)) return;
+    int32_t m = INT32_MIN;
+    const int64_t b = i * group;
+    for (int t = 0; t < group; ++t) {
+        if (b + t < n_src) { const int32_t v = src[(size_t)(b + t) * stride]; m = v > m ? v : m; }
+    }
+    dst[i] = m;
+}
+
+// Rows at or below sorted position i (down to seg_a, the contig's first row) that end above qsv, in descending position; every
+// one of them must start below the probe's end (i < hi-bound).  ep_at(p) = {end, prefix max} of row p; f(p) returns false to stop.  Depth-first over the
+// block maxima, right to left, one 16-entry block per step: the entries at or left of the cursor that are above qsv are rows to
+// report (level 0) or the child to enter (the rightmost one); an exhausted block hands over to the entries left of its parent,
+// and the prefix max of the row below the subtree just left says whether anything further down can still match.
+template <bool STRICT, class EpAt, class F>
+__device__ __forceinline__ void hier_walk(const HierView& H, const EpAt& ep_at, int seg_a, int i, int32_t qsv, F&& f) {
+    int lv = 0;
+    int chk = -1;                                                              // row whose prefix max is still to be looked at
+    while (i >= 0) {
+        if ((((int64_t)(i + 1) << (4 * lv)) - 1) < (int64_t)seg_a) return;     // the entry lies below the contig
+        const int base = i & ~15;
+        uint32_t off = 0;
+#pragma unroll
+        for (int l = 1; l < HIER_MAX; ++l) off = lv == l ? H.off[l] : off;
+        const int4* bp = reinterpret_cast<const int4*>(H.v + (size_t)off + (size_t)base);
+        const int4 w0 = bp[0], w1 = bp[1], w2 = bp[2], w3 = bp[3];
+        if (chk >= 0) {
+            if (!lt_op<STRICT>(qsv, ep_at(chk).y)) return;                     // nothing at or below row chk reaches the probe
+            chk = -1;
+        }
+        uint32_t m = ends_mask16<STRICT>(qsv, w0, w1, w2, w3) & ((2u << (i & 15)) - 1u);
+        if (lv == 0) {
+            if (seg_a > base) m &= ~((1u << (seg_a - base)) - 1u);
+            while (m) { const int j = 31 - __builtin_clz(m); m ^= 1u << j; if (!f(base + j)) return; }
+        } else if (m) {
+            i = ((base + 31 - __builtin_clz(m)) << 4) + 15;                    // the rightmost child above qsv, all of it
+            --lv;
+            continue;
+        }
+        // block exhausted: the entries left of its parent (of the first ancestor that has any)
+        int node = base;
+        do {
+            if (lv == H.nlev) return;
+            node >>= 4; ++lv;
+        } while ((node & 15) == 0);
+        const int64_t b = (int64_t)node << (4 * lv);                           // first row of the subtree just left
+        if (b <= (int64_t)seg_a) return;
+        chk = (int)(b - 1);
+        i = node - 1;
+    }
+}
 
 // Workgroup b is observed to run on XCD b % 8.  Giving every XCD one CONTIGUOUS eighth of the (bucket-ordered) tiles
 // means its L2 only ever holds the index slices of its own buckets, instead of all eight L2s fetching every slice.

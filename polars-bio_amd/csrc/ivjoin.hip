@@ -109,6 +109,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     for (auto& cb : ctx->st_cache) free_stream_bufs(cb);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+    if (ctx->bounce) (void)hipHostFree(ctx->bounce);
     for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -389,14 +390,10 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     out->probe_idx = (int32_t*)host_result_alloc((size_t)total * 4);
     out->build_idx = (int32_t*)host_result_alloc((size_t)total * 4);
     if (!out->probe_idx || !out->build_idx) { ivj_pairs_free(out); return fail(IVJ_ENOMEM, "host malloc(pairs)"); }
-    hipError_t ce;
-    {
-        HostPin pin_p(out->probe_idx, (size_t)total * 4), pin_b(out->build_idx, (size_t)total * 4);     // unregistered before the buffers can be freed
-        ce = hipMemcpyAsync(out->probe_idx, op.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (ce == hipSuccess) ce = hipMemcpyAsync(out->build_idx, ob.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
-        else (void)hipStreamSynchronize(ctx->stream);
-    }
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.d2h(out->probe_idx, op.p, (size_t)total * 4);
+    copy.d2h(out->build_idx, ob.p, (size_t)total * 4);
+    const hipError_t ce = copy.finish();
     if (ce != hipSuccess) { ivj_pairs_free(out); return fail(IVJ_EHIP, std::string("D2H(pairs): ") + hipGetErrorString(ce)); }
     out->n_pairs = total;
     return IVJ_OK;
@@ -472,16 +469,17 @@ int ivj_merge(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_t 
     IVJ_TRY(cluster_core(ctx, h.ix, opts->filter_op == IVJ_FILTER_STRICT, (long long)min_dist, align_up((size_t)(side->n + 1) * 8), cl));
     long long* cnt = arena_take<long long>(ctx, side->n + 1);
     LAUNCH(ctx, "cluster_counts", k_cluster_counts, grid1d(cl.n, 256), 256, (const int32_t*)cl.m_first, cl.n, cnt);
-    out->contig = (int32_t*)std::malloc((size_t)cl.n * 4);
-    out->start = (int32_t*)std::malloc((size_t)cl.n * 4);
-    out->end = (int32_t*)std::malloc((size_t)cl.n * 4);
-    out->n_intervals = (int64_t*)std::malloc((size_t)cl.n * 8);
+    out->contig = (int32_t*)host_result_alloc((size_t)cl.n * 4);
+    out->start = (int32_t*)host_result_alloc((size_t)cl.n * 4);
+    out->end = (int32_t*)host_result_alloc((size_t)cl.n * 4);
+    out->n_intervals = (int64_t*)host_result_alloc((size_t)cl.n * 8);
     if (!out->contig || !out->start || !out->end || !out->n_intervals) { ivj_merged_free(out); return fail(IVJ_ENOMEM, "host malloc(merged)"); }
-    hipError_t e = hipMemcpyAsync(out->contig, cl.m_contig, (size_t)cl.n * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out->start, cl.m_start, (size_t)cl.n * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out->end, cl.m_end, (size_t)cl.n * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out->n_intervals, cnt, (size_t)cl.n * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.d2h(out->contig, cl.m_contig, (size_t)cl.n * 4);
+    copy.d2h(out->start, cl.m_start, (size_t)cl.n * 4);
+    copy.d2h(out->end, cl.m_end, (size_t)cl.n * 4);
+    copy.d2h(out->n_intervals, cnt, (size_t)cl.n * 8);
+    const hipError_t e = copy.finish();
     if (e != hipSuccess) { ivj_merged_free(out); return fail(IVJ_EHIP, std::string("D2H(merged): ") + hipGetErrorString(e)); }
     out->n = cl.n;
     return IVJ_OK;
@@ -510,10 +508,11 @@ int ivj_cluster(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_
     int32_t* d_e = (int32_t*)((char*)d_s + align_up(n * 4));
     int64_t ncl = 0;
     IVJ_TRY(ivj_cluster_dev(ctx, h.ix, opts, min_dist, d_c, d_s, d_e, &ncl));
-    HIP_TRY(hipMemcpyAsync(cluster, d_c, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(cluster_start, d_s, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(cluster_end, d_e, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.d2h(cluster, d_c, n * 8);
+    copy.d2h(cluster_start, d_s, n * 4);
+    copy.d2h(cluster_end, d_e, n * 4);
+    HIP_TRY(copy.finish());
     if (n_clusters) *n_clusters = ncl;
     return IVJ_OK;
 }
@@ -535,8 +534,9 @@ int ivj_coverage(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, con
     hipError_t e = hipMalloc(&out.p, (size_t)probe->n * 8);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(coverage): ") + hipGetErrorString(e));
     IVJ_TRY(coverage_core(ctx, h.ix, &dp.s, opts, (int64_t*)out.p));
-    HIP_TRY(hipMemcpyAsync(coverage, out.p, (size_t)probe->n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.d2h(coverage, out.p, (size_t)probe->n * 8);
+    HIP_TRY(copy.finish());
     return IVJ_OK;
 }
 
@@ -576,14 +576,15 @@ int ivj_subtract(ivj_ctx* ctx, const ivj_side* left, const ivj_side* right, cons
     int64_t total = 0;
     IVJ_TRY(subtract_core(ctx, h.ix, &dl.s, opts, -1, &d_row, &d_start, &d_end, &own, &total));
     if (total == 0) return IVJ_OK;
-    out->row = (int32_t*)std::malloc((size_t)total * 4);
-    out->start = (int32_t*)std::malloc((size_t)total * 4);
-    out->end = (int32_t*)std::malloc((size_t)total * 4);
+    out->row = (int32_t*)host_result_alloc((size_t)total * 4);
+    out->start = (int32_t*)host_result_alloc((size_t)total * 4);
+    out->end = (int32_t*)host_result_alloc((size_t)total * 4);
     if (!out->row || !out->start || !out->end) { ivj_pieces_free(out); return fail(IVJ_ENOMEM, "host malloc(pieces)"); }
-    hipError_t e = hipMemcpyAsync(out->row, d_row, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out->start, d_start, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out->end, d_end, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.d2h(out->row, d_row, (size_t)total * 4);
+    copy.d2h(out->start, d_start, (size_t)total * 4);
+    copy.d2h(out->end, d_end, (size_t)total * 4);
+    const hipError_t e = copy.finish();
     if (e != hipSuccess) { ivj_pieces_free(out); return fail(IVJ_EHIP, std::string("D2H(pieces): ") + hipGetErrorString(e)); }
     out->n = total;
     return IVJ_OK;
@@ -655,23 +656,21 @@ int ivj_take(ivj_ctx* ctx, const int32_t* idx, int64_t n, int32_t n_cols, const 
     if (e == hipSuccess) e = hipMalloc(&d_dst.p, max_dst);
     if (e == hipSuccess && any_valid) e = hipMalloc(&d_val.p, words * 8);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(take): ") + hipGetErrorString(e));
-    {
-        HostPin pin(idx, (size_t)n * 4);
-        HIP_TRY(hipMemcpyAsync(d_idx.p, idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.h2d(d_idx.p, idx, (size_t)n * 4);
     for (int c = 0; c < n_cols; ++c) {
         const size_t sb = (size_t)src_rows[c] * (size_t)elem_bytes[c], db = (size_t)n * (size_t)elem_bytes[c];
         uint64_t* val = validity ? validity[c] : nullptr;
         host_prefault(dst[c], db);
-        HostPin ps(src[c], sb), pd(dst[c], db);
-        if (sb) HIP_TRY(hipMemcpyAsync(d_src.p, src[c], sb, hipMemcpyHostToDevice, ctx->stream));
+        copy.h2d(d_src.p, src[c], sb);
+        HIP_TRY(copy.err);
         int rc = ivj_take_dev(ctx, d_src.p, elem_bytes[c], (const int32_t*)d_idx.p, n, d_dst.p, val ? (uint64_t*)d_val.p : nullptr);
         if (rc != IVJ_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(dst[c], d_dst.p, db, hipMemcpyDeviceToHost, ctx->stream));
-        if (val) HIP_TRY(hipMemcpyAsync(val, d_val.p, words * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));                          // before the ranges are unregistered / the buffers reused
+        copy.d2h(dst[c], d_dst.p, db);
+        if (val) copy.d2h(val, d_val.p, words * 8);
+        HIP_TRY(copy.finish());                                              // before the device buffers are reused
     }
+    HIP_TRY(copy.finish());
     return IVJ_OK;
 }
 
@@ -711,14 +710,14 @@ int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
     IVJ_TRY(overlap_fill(ctx, h.ix, &dp.s, opts, d.probe_idx, d.build_idx, total));
     IVJ_TRY(ivj_materialize_dev(ctx, &dp.s, &db.s, &d));
     int32_t** hcols[7] = {&out->probe_idx, &out->build_idx, &out->contig, &out->start_1, &out->end_1, &out->start_2, &out->end_2};
+    HostXfer copy(ctx->stream, &ctx->bounce);
     for (int k = 0; k < 7; ++k) {
-        *hcols[k] = (int32_t*)std::malloc((size_t)total * 4);
-        if (!*hcols[k]) { ivj_rows_free(out); return fail(IVJ_ENOMEM, "host malloc(rows)"); }
-        hipError_t ce = hipMemcpyAsync(*hcols[k], *dcols[k], (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (ce != hipSuccess) { ivj_rows_free(out); return fail(IVJ_EHIP, std::string("D2H(rows): ") + hipGetErrorString(ce)); }
+        *hcols[k] = (int32_t*)host_result_alloc((size_t)total * 4);
+        if (!*hcols[k]) { (void)copy.finish(); ivj_rows_free(out); return fail(IVJ_ENOMEM, "host malloc(rows)"); }
+        copy.d2h(*hcols[k], *dcols[k], (size_t)total * 4);
     }
-    hipError_t se = hipStreamSynchronize(ctx->stream);
-    if (se != hipSuccess) { ivj_rows_free(out); return fail(IVJ_EHIP, std::string("sync(rows): ") + hipGetErrorString(se)); }
+    const hipError_t se = copy.finish();
+    if (se != hipSuccess) { ivj_rows_free(out); return fail(IVJ_EHIP, std::string("D2H(rows): ") + hipGetErrorString(se)); }
     out->n_pairs = total;
     return IVJ_OK;
 }
@@ -748,8 +747,9 @@ int ivj_count_overlaps(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* buil
     hipError_t e = hipMalloc(&dc.p, (size_t)probe->n * 8);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(counts): ") + hipGetErrorString(e));
     IVJ_TRY(count_overlaps_dev(ctx, h.ix, &dp.s, opts, (int64_t*)dc.p));
-    HIP_TRY(hipMemcpyAsync(counts, dc.p, (size_t)probe->n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.d2h(counts, dc.p, (size_t)probe->n * 8);
+    HIP_TRY(copy.finish());
     return IVJ_OK;
 }
 
@@ -777,10 +777,11 @@ int ivj_nearest(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     if (e == hipSuccess) e = hipMalloc(&dn.p, (size_t)probe->n * 4);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(nearest): ") + hipGetErrorString(e));
     IVJ_TRY(nearest_dev(ctx, h.ix, &dp.s, opts, (int32_t*)di.p, (int64_t*)dd.p, (int32_t*)dn.p));
-    HIP_TRY(hipMemcpyAsync(idx, di.p, slots * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(dist, dd.p, slots * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(n_found, dn.p, (size_t)probe->n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.d2h(idx, di.p, slots * 4);
+    copy.d2h(dist, dd.p, slots * 8);
+    copy.d2h(n_found, dn.p, (size_t)probe->n * 4);
+    HIP_TRY(copy.finish());
     return IVJ_OK;
 }
 
@@ -913,16 +914,18 @@ int ivj_memcpy_h2d(ivj_ctx* ctx, void* dst_dev, const void* src_host, int64_t by
     if (!ctx || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
     if (bytes == 0) return IVJ_OK;
     DeviceGuard g(ctx->device);
-    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.h2d(dst_dev, src_host, (size_t)bytes);
+    HIP_TRY(copy.finish());
     return IVJ_OK;
 }
 int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes) {
     if (!ctx || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
     if (bytes == 0) return IVJ_OK;
     DeviceGuard g(ctx->device);
-    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HostXfer copy(ctx->stream, &ctx->bounce);
+    copy.d2h(dst_host, src_dev, (size_t)bytes);
+    HIP_TRY(copy.finish());
     return IVJ_OK;
 }
 

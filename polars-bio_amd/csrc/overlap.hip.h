@@ -18,45 +18,17 @@ __device__ __forceinline__ void probe_windows(const IndexView& ix, const int32_t
                                               int (&x)[PROBE_ITEMS], int (&cnt)[PROBE_ITEMS]) {
     int a[PROBE_ITEMS], b[PROBE_ITEMS];
     bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
-    const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
         uint32_t mask; int cn;
         const bool small = window_mask<STRICT>(ix, a[k], hi[k], s[k], mask, cn);
         x[k] = (int)mask;
-        // wavefront-cooperative exact count of every long window of this round (uniform loop);
-        // four windows per step so that four first-chunk reads are in flight together
-        unsigned long long todo = __ballot(!small);
-        while (todo) {
-            int src[4], ca[4], chi[4]; int32_t cqs[4]; int2 v0[4], v1[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                src[t] = todo ? __ffsll((long long)todo) - 1 : -1;
-                if (todo) todo &= todo - 1;
-                const int sl = src[t] < 0 ? 0 : src[t];
-                ca[t] = __shfl(a[k], sl, kWave); chi[t] = __shfl(hi[k], sl, kWave); cqs[t] = __shfl(s[k], sl, kWave);
-                if (src[t] < 0) { ca[t] = 0; chi[t] = 0; }
-                const int p = chi[t] - 1 - lane;
-                v0[t] = (p >= ca[t]) ? ix.ep[p] : make_int2(0, 0);
-                v1[t] = (p - kWave >= ca[t]) ? ix.ep[p - kWave] : make_int2(0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (src[t] < 0) continue;                      // uniform
-                int cc = 0;
-                int2 v = v0[t];
-                int step = 0;
-                for (int p0 = chi[t] - 1; p0 >= ca[t]; p0 -= kWave, ++step) {
-                    const int p = p0 - lane;
-                    if (step == 1) v = v1[t];
-                    else if (step > 1) v = (p >= ca[t]) ? ix.ep[p] : make_int2(0, 0);
-                    const bool pass = p >= ca[t] && lt_op<STRICT>(cqs[t], v.y);
-                    const bool match = pass && lt_op<STRICT>(cqs[t], v.x);
-                    cc += (int)__popcll(__ballot(match));
-                    if (__popcll(__ballot(pass)) < kWave) break;
-                }
-                if (lane == src[t]) { cn = cc; x[k] = cc; }
-            }
+        // a window longer than the mask: counted over the block maxima of the ends (hier_walk) -- dense windows cost a block read
+        // per sixteen rows, windows kept open by a few long rows (a contig-wide one) a few reads per match
+        if (!small) {
+            int cc = 0;
+            hier_walk<STRICT>(ix.hier, [&](int p) { return ix.ep[p]; }, a[k], hi[k] - 1, s[k], [&](int) { ++cc; return true; });
+            cn = cc; x[k] = cc;
         }
         if (!small) hi[k] |= (int)0x80000000;      // flag: x is a count, the emission rescans
         cnt[k] = cn;
@@ -99,8 +71,6 @@ __device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf&
                                                const int32_t (&x)[N], const int32_t (&cnt)[N],
                                                const int32_t (&row)[N], const int32_t (&qs)[N],
                                                long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const unsigned long long lt_lanes = (1ull << lane) - 1ull;
     for (long long w0 = 0; w0 < tot; w0 += STAGE) {
         const long long w1 = w0 + STAGE;
         long long off = loc0;                                  // tile-local offset of the current probe
@@ -121,31 +91,16 @@ __device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf&
                     ++o;
                 }
             }
-            unsigned long long todo = __ballot(in_win && hi[k] < 0);
-            while (todo) {
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int h = __shfl(hi[k], src, kWave) & 0x7fffffff;
-                const int c = __shfl(cnt[k], src, kWave);
-                const int32_t cqs = __shfl(qs[k], src, kWave);
-                const int32_t crow = __shfl(row[k], src, kWave);
-                const long long cend = ((long long)__shfl((int)(end >> 32), src, kWave) << 32) |
-                                       (unsigned long long)(unsigned int)__shfl((int)(end & 0xffffffffll), src, kWave);
-                int found = 0;
-                for (int p0 = h - 1; found < c && p0 >= 0 && cend - found > w0; p0 -= kWave) {
-                    const int p = p0 - lane;
-                    int2 v = make_int2(0, 0);
-                    int32_t br = 0;
-                    if (p >= 0) { v = ix.ep[p]; br = rowof(p); }
-                    const bool m = p >= 0 && lt_op<STRICT>(cqs, v.x);
-                    const unsigned long long mm = __ballot(m);
-                    if (m) {
-                        // rows below the window (or of the previous contig) rank past the c-th match
-                        const long long o = cend - 1 - found - (long long)__popcll(mm & lt_lanes);
-                        if (o >= w0 && o < w1 && o >= cend - c) { st_p[o - w0] = crow; st_b[o - w0] = br; }
-                    }
-                    found += (int)__popcll(mm);
-                }
+            if (in_win && hi[k] < 0) {
+                // long window: the same walk as the count, descending; the f-th match from the top owns slot end - 1 - f
+                // (the first cnt matches going down are the window's: the walk needs no lower bound, it stops there or below
+                // the staging window)
+                long long o = end - 1;
+                hier_walk<STRICT>(ix.hier, [&](int p) { return ix.ep[p]; }, 0, (hi[k] & 0x7fffffff) - 1, qs[k], [&](int p) {
+                    if (o < w1) { st_p[o - w0] = row[k]; st_b[o - w0] = rowof(p); }
+                    --o;
+                    return o >= off && o >= w0;
+                });
             }
             off = end;
         }

@@ -1018,3 +1018,16 @@ def test_long_build_tail_on_the_slice_path(eng, strict):
     p, b = _canon(hp, hb)
     assert (p == ep).all() and (b == eb).all(), "auto"
     assert (eng.count_overlaps(probe, build, strict, nc) == ec).all()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_long_build_tail_on_every_path(eng, strict):
+    """The same shape through every overlap / count / nearest path (probe order, 256 buckets, record tables, slices, fused
+    variants): windows longer than the 32-row mask are counted and emitted through the block maxima of the ends."""
+    rng = np.random.default_rng(78)
+    nc, span = 2, 3_000_000
+    build = _long_tail_build(rng, 30_000, nc, span, 0.02, 3)
+    pc = rng.integers(0, nc + 1, 50_000).astype(np.int32)
+    ps = rng.integers(0, span, 50_000).astype(np.int32)
+    probe = (pc, ps, (ps + rng.integers(0, 300, 50_000)).astype(np.int32))
+    _cmp_all(eng, probe, build, nc, strict, nearest_cfgs=((1, True), (2, True)))
