@@ -390,6 +390,33 @@ int ivj_dev_free(ivj_ctx* ctx, void* p);
 int ivj_memcpy_h2d(ivj_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
 int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
 
+/* ---- host-side helpers of the front door (no device work, no context; plain std::thread workers; threads <= 0: 32) ----------
+ * What the reference's executor does around the join in Rust -- the dictionary handling of the chrom key and the column gathers
+ * of the renaming SELECT (src/operation.rs:272-301), the int32 coordinate limit (docs/features/operations.md:36-37) -- as ONE
+ * pass over the rows each; the Python front door (polars_bio_amd/_arrow.py) calls them on the buffers of its Arrow columns. */
+
+/* Coordinate column of src_bytes-wide (1, 2, 4, 8) signed / unsigned integers -> int32, with the column's minimum and maximum
+ * (the caller refuses a column that leaves the int32 range; unsigned values beyond INT64_MAX are reported as INT64_MAX). */
+int ivj_host_narrow_i32(const void* src, int32_t src_bytes, int32_t is_unsigned, int64_t n, int32_t* dst, int64_t* out_min, int64_t* out_max,
+                        int32_t threads);
+
+/* Arrow string / large_string column (n + 1 offsets of offset_bytes = 4 / 8, the value bytes, optional validity bitmap read from
+ * bit validity_bit0) -> ids[n] (dictionary ids in first-occurrence order, -1 for a null) and dict_rows[*n_values] (one row that
+ * holds each value).  IVJ_ECAPACITY: more than dict_cap (or 4096) distinct values -- the caller falls back to its own encoder. */
+int ivj_host_encode_utf8(const void* offsets, int32_t offset_bytes, const uint8_t* data, const uint8_t* validity, int64_t validity_bit0, int64_t n,
+                         int32_t* ids, int64_t* dict_rows, int32_t dict_cap, int32_t* n_values, int32_t threads);
+
+/* Dictionary indices (idx_bytes = 1, 2, 4, 8, signed; negative = null) -> out[i] = remap[idx[i]] (-1 for a null), and seen[v] = 1
+ * for every dictionary entry some row refers to (seen: remap_len bytes, OR-ed into). */
+int ivj_host_remap_i32(const void* idx, int32_t idx_bytes, int64_t n, const int32_t* remap, int64_t remap_len, int32_t* out, uint8_t* seen,
+                       int32_t threads);
+
+/* dst[i] = src[idx[i]] for 4- or 8-byte values (0 for a negative index): the non-key columns of the joined rows. */
+int ivj_host_take(const void* src, int32_t elem_bytes, int64_t n_src, const int32_t* idx, int64_t n, void* dst, int32_t threads);
+
+/* int32 -> int64: key columns materialised in HBM back to the dtype of the caller's frame. */
+int ivj_host_widen_i32(const int32_t* src, int64_t n, int64_t* dst, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,12 +16,11 @@ void cs_index_carve(ivj_index* ix, char* p);
 int ensure_hier(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->hier_built || ix->n <= 0) return IVJ_OK;
     const HierShape h = hier_shape(ix->n);
-    for (int l = 0; l <= h.nlev; ++l) {
-        const int32_t* src = l == 0 ? reinterpret_cast<const int32_t*>(ix->ep) : ix->hier + h.off[l - 1];
-        const int64_t padded = (h.len[l] + 15) & ~(int64_t)15;
-        LAUNCH(ctx, "hier_level", k_hier_level, (unsigned)((padded + 255) / 256), 256, src, l == 0 ? 2 : 1, l == 0 ? 1 : 16, l == 0 ? ix->n : h.len[l - 1],
-               ix->hier + h.off[l], h.len[l]);
-    }
+    // blocks past the rows (the pads of levels 0 .. 2) are written by the same launch: one workgroup per 4096 padded rows
+    const int64_t wgs = (((ix->n + 15) & ~(int64_t)15) + HIER_WG_ROWS - 1) / HIER_WG_ROWS;
+    LAUNCH(ctx, "hier_low", k_hier_low, (unsigned)wgs, 256, (const int2*)ix->ep, ix->n, ix->hier, h.len[1], h.nlev >= 1 ? ix->hier + h.off[1] : nullptr,
+           h.len[2], h.nlev >= 2 ? ix->hier + h.off[2] : nullptr);
+    if (h.nlev >= 3) LAUNCH(ctx, "hier_high", k_hier_high, 1, 256, ix->hier, h);
     HIP_TRY(hipGetLastError());
     ix->hier_built = true;
     return IVJ_OK;

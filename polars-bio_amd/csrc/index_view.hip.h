@@ -141,16 +141,48 @@ inline HierShape hier_shape(int64_t n) {
     h.values = (size_t)o + 16;
     return h;
 }
-// level 0 from the ends (group 1, stride 2 in ep), level l + 1 from level l (group 16); pads of the last block = INT32_MIN
-__global__ void k_hier_level(const int32_t* __restrict__ src, int stride, int group, int64_t n_src, int32_t* __restrict__ dst, int64_t n_dst) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ((n_dst + 15) & ~(int64_t)15)) return;
+// Levels 0, 1 and 2 in one pass over ep: one workgroup per 4096 rows (256 threads x 16 rows; level 1 = the thread's maximum,
+// level 2 = the maximum of sixteen neighbouring threads); pads of the last blocks = INT32_MIN.
+constexpr int HIER_WG_ROWS = 4096;
+__global__ __launch_bounds__(256) void k_hier_low(const int2* __restrict__ ep, int64_t n, int32_t* __restrict__ l0, int64_t len1, int32_t* __restrict__ l1,
+                                                  int64_t len2, int32_t* __restrict__ l2) {
+    const int64_t row0 = (int64_t)blockIdx.x * HIER_WG_ROWS + (int64_t)threadIdx.x * 16;
     int32_t m = INT32_MIN;
-    const int64_t b = i * group;
-    for (int t = 0; t < group; ++t) {
-        if (b + t < n_src) { const int32_t v = src[(size_t)(b + t) * stride]; m = v > m ? v : m; }
+    int32_t e[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        e[t] = row0 + t < n ? ep[row0 + t].x : INT32_MIN;
+        m = e[t] > m ? e[t] : m;
     }
-    dst[i] = m;
+    const int64_t pad0 = (n + 15) & ~(int64_t)15;
+    if (row0 < pad0) {
+        int4* o = reinterpret_cast<int4*>(l0 + row0);
+        o[0] = make_int4(e[0], e[1], e[2], e[3]); o[1] = make_int4(e[4], e[5], e[6], e[7]);
+        o[2] = make_int4(e[8], e[9], e[10], e[11]); o[3] = make_int4(e[12], e[13], e[14], e[15]);
+    }
+    const int64_t i1 = row0 >> 4;
+    if (l1 && i1 < ((len1 + 15) & ~(int64_t)15)) l1[i1] = m;
+    int32_t m2 = m;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { const int32_t o = __shfl_xor(m2, d, kWave); m2 = o > m2 ? o : m2; }
+    const int64_t i2 = row0 >> 8;
+    if (l2 && (threadIdx.x & 15) == 0 && i2 < ((len2 + 15) & ~(int64_t)15)) l2[i2] = m2;
+}
+// Levels 3 and up from level 2: a few thousand values at most, one workgroup, level after level.
+__global__ __launch_bounds__(256) void k_hier_high(int32_t* __restrict__ v, HierShape h) {
+    for (int l = 3; l <= h.nlev; ++l) {
+        const int32_t* src = v + h.off[l - 1];
+        int32_t* dst = v + h.off[l];
+        const int64_t n_src = h.len[l - 1], padded = (h.len[l] + 15) & ~(int64_t)15;
+        for (int64_t i = threadIdx.x; i < padded; i += blockDim.x) {
+            int32_t m = INT32_MIN;
+            for (int t = 0; t < 16; ++t) {
+                if (i * 16 + t < n_src) { const int32_t x = src[i * 16 + t]; m = x > m ? x : m; }
+            }
+            dst[i] = m;
+        }
+        __syncthreads();
+    }
 }
 
 // Rows at or below sorted position i (down to seg_a, the contig's first row) that end above qsv, in descending position; every

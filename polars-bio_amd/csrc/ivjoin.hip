@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <type_traits>
 
 #include "probe.hip.h"
 #include "slice.hip.h"
@@ -930,3 +931,5 @@ int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t by
 }
 
 }  // extern "C"
+
+#include "host_frontdoor.hip.h"

@@ -20,6 +20,8 @@ import numpy as np
 import pyarrow as pa
 import pyarrow.compute as pc
 
+from . import _host as H
+
 try:
     import pandas as pd
 except ImportError:  # pragma: no cover
@@ -99,19 +101,9 @@ def _coord_to_i32(col: pa.ChunkedArray, name: str) -> np.ndarray:
     a = arr.to_numpy(zero_copy_only=False)                   # a view of the Arrow buffer for a null-free primitive array
     if a.dtype == np.int32:
         return a
-    out = np.empty(len(a), np.int32)
     if len(a) == 0:
-        return out
-
-    def block(r):
-        # range check + narrowing of one row block: min, max and the narrowing copy while the block is in cache
-        lo, hi = r
-        v = a[lo:hi]
-        mn, mx = int(v.min()), int(v.max())
-        out[lo:hi] = v                                        # numpy's unchecked narrowing store (the check is the min / max)
-        return mn, mx
-    res = _pmap(block, _blocks(len(a)) if len(a) >= _PAR_MIN_ROWS else [(0, len(a))])
-    lo, hi = min(r[0] for r in res), max(r[1] for r in res)
+        return np.empty(0, np.int32)
+    out, lo, hi = H.narrow_i32(a)                             # one threaded pass: narrowing copy + min / max (the range check)
     if lo < -(1 << 31) or hi > (1 << 31) - 1:
         bad = hi if hi > (1 << 31) - 1 else lo
         raise ValueError(f"column '{name}' does not fit int32 coordinates (reference limit): Integer value {bad} not in range: "
@@ -119,65 +111,73 @@ def _coord_to_i32(col: pa.ChunkedArray, name: str) -> np.ndarray:
     return out
 
 
-def _encode_chrom(col: pa.ChunkedArray):
-    """chrom column (string / large_string / string_view / dictionary of those, any chunking) -> (dictionary: large_string
-    Array of the values that OCCUR, ids: int32 numpy array, -1 for a null chrom).
+def _string_buffers(arr: pa.Array):
+    """(offsets incl. the array's offset, data bytes, validity bytes or None, first validity bit) of a string / large_string array."""
+    vbuf, obuf, dbuf = arr.buffers()
+    width = 8 if pa.types.is_large_string(arr.type) else 4
+    offs = np.frombuffer(obuf, dtype=np.dtype(f"i{width}"), count=len(arr) + 1, offset=arr.offset * width)
+    data = np.frombuffer(dbuf, dtype=np.uint8) if dbuf is not None else None
+    valid = np.frombuffer(vbuf, dtype=np.uint8) if (vbuf is not None and arr.null_count) else None
+    return offs, data, valid, arr.offset
 
-    Dictionary-typed input (pandas categoricals, polars Categorical / Enum, Arrow dictionaries) is never hashed: its indices
-    are remapped through a table of the dictionary's size; entries no row refers to are dropped (a global string cache can
-    carry thousands of them).  String input is dictionary-encoded block by block on the thread pool (one hash pass over the
-    strings, pyarrow releases the GIL) and the small block dictionaries are unified."""
-    chunks = col.chunks if isinstance(col, pa.ChunkedArray) else [col]
-    n = sum(len(c) for c in chunks)
-    if n == 0:
-        return pa.array([], pa.large_string()), np.empty(0, np.int32)
-    pieces = []                                               # row blocks as zero-copy slices
-    for c in chunks:
-        for lo, hi in (_blocks(len(c)) if len(c) >= _PAR_MIN_ROWS else ([(0, len(c))] if len(c) else [])):
-            pieces.append(c.slice(lo, hi - lo))
 
-    def encode(piece):
-        if not pa.types.is_dictionary(piece.type):
-            if not (pa.types.is_string(piece.type) or pa.types.is_large_string(piece.type)):
-                piece = pc.cast(piece, pa.large_string())
-            piece = pc.dictionary_encode(piece)
+def _encode_piece(piece: pa.Array, out: np.ndarray):
+    """One chunk of the chrom column -> (its dictionary values as a large_string array, index array to push through the
+    remap table, or None when ``out`` already holds the chunk's local ids)."""
+    if pa.types.is_dictionary(piece.type):
         d = pc.cast(piece.dictionary, pa.large_string())
         idx = piece.indices
         iv = idx.to_numpy(zero_copy_only=False)
-        if idx.null_count:
+        if idx.null_count:                                                    # rare: null chroms inside a dictionary column
             iv = np.where(pc.is_null(idx).to_numpy(zero_copy_only=False), -1, np.nan_to_num(iv, nan=0)).astype(np.int64)
-        else:
-            iv = iv.astype(np.int64, copy=False)
         return d, iv
-    enc = _pmap(encode, pieces)
-    # unify the block dictionaries (tiny), keep the values that occur, remap every block's indices
+    if not (pa.types.is_string(piece.type) or pa.types.is_large_string(piece.type)):
+        piece = pc.cast(piece, pa.large_string())                             # string_view, ...
+    offs, data, valid, bit0 = _string_buffers(piece)
+    rows = H.encode_utf8(offs, data, valid, bit0, len(piece), out)            # native: one threaded hash pass
+    if rows is None:                                                          # thousands of distinct values: pyarrow's encoder
+        enc = pc.dictionary_encode(piece)
+        iv = enc.indices.to_numpy(zero_copy_only=False)
+        if enc.indices.null_count:
+            iv = np.where(pc.is_null(enc.indices).to_numpy(zero_copy_only=False), -1, np.nan_to_num(iv, nan=0)).astype(np.int64)
+        return pc.cast(enc.dictionary, pa.large_string()), iv
+    return pc.cast(piece.take(pa.array(rows)), pa.large_string()), None
+
+
+def _encode_chrom(col: pa.ChunkedArray):
+    """chrom column (string / large_string / string_view / dictionary of those, any chunking) -> (dictionary: large_string
+    Array of the values that OCCUR, in first-occurrence order, ids: int32 numpy array, -1 for a null chrom).
+
+    String chunks are hashed once by the native encoder (ivj_host_encode_utf8, threaded); dictionary-typed input (pandas
+    categoricals, polars Categorical / Enum, Arrow dictionaries) is never hashed: its indices go through a remap table of the
+    dictionary's size (ivj_host_remap_i32) and entries no row refers to are dropped (a global string cache can carry thousands)."""
+    chunks = [c for c in (col.chunks if isinstance(col, pa.ChunkedArray) else [col]) if len(c)]
+    n = sum(len(c) for c in chunks)
+    if n == 0:
+        return pa.array([], pa.large_string()), np.empty(0, np.int32)
+    ids = np.empty(n, np.int32)
+    starts = np.concatenate([[0], np.cumsum([len(c) for c in chunks])]).astype(np.int64)
+    enc = [_encode_piece(c, ids[starts[k]:starts[k + 1]]) for k, c in enumerate(chunks)]
+    if len(enc) == 1 and enc[0][1] is None and enc[0][0].null_count == 0:
+        return enc[0][0], ids                                                 # one string chunk: the local ids are final
+    # unify the chunk dictionaries (tiny), remap every chunk's indices, keep the values that occur
     all_d = pa.concat_arrays([d for d, _ in enc])
     u = pc.drop_null(pc.unique(all_d))
     u = u.combine_chunks() if isinstance(u, pa.ChunkedArray) else u
-    remaps = []
-    for d, iv in enc:
-        r = pc.fill_null(pc.index_in(d, value_set=u), -1).to_numpy(zero_copy_only=False).astype(np.int32)
-        remaps.append(np.concatenate([r, np.array([-1], np.int32)]))          # last slot: null chrom
-
-    starts = np.concatenate([[0], np.cumsum([len(iv) for _, iv in enc])]).astype(np.int64)
-    ids = np.empty(int(starts[-1]), np.int32)
     nu = len(u)
-
-    def remap(k):
-        g = remaps[k][enc[k][1]]                                              # -1 indexes the null slot
-        ids[starts[k]:starts[k + 1]] = g
-        return np.bincount(g + 1, minlength=nu + 1)[1:] > 0                   # which dictionary values this block uses
-    seen = np.zeros(nu, bool)
-    for sk in _pmap(remap, range(len(enc))):
-        seen |= sk
-    if not seen.all():                                                         # dictionary entries no row uses
-        keep = np.nonzero(seen)[0]
-        new = np.full(nu + 1, -1, np.int32)
+    seen = np.zeros(max(nu, 1), np.uint8)
+    for k, (d, iv) in enumerate(enc):
+        table = pc.fill_null(pc.index_in(d, value_set=u), -1).to_numpy(zero_copy_only=False).astype(np.int32)
+        out = ids[starts[k]:starts[k + 1]]
+        sk = np.zeros(max(len(table), 1), np.uint8)
+        H.remap_i32(out if iv is None else iv, table, out, sk)
+        used = table[sk[:len(table)].astype(bool)]
+        seen[used[used >= 0]] = 1
+    if nu and not seen[:nu].all():                                            # dictionary entries no row uses
+        keep = np.nonzero(seen[:nu])[0]
+        new = np.full(nu, -1, np.int32)
         new[keep] = np.arange(len(keep), dtype=np.int32)
-
-        def renumber(r):
-            ids[r[0]:r[1]] = new[ids[r[0]:r[1]]]
-        _pmap(renumber, _blocks(len(ids)) if len(ids) >= _PAR_MIN_ROWS else [(0, len(ids))])
+        H.remap_i32(ids, new, ids)
         u = u.take(pa.array(keep))
     return u, ids
 
@@ -214,14 +214,10 @@ def encode_keys(t1: pa.Table, cols1, t2: pa.Table, cols2, with_dictionary: bool 
         if len(i) == 0:
             return np.empty(0, np.int32)
         remap = pc.index_in(d, value_set=u).to_numpy(zero_copy_only=False).astype(np.int32)
-        remap = np.concatenate([remap, np.array([-1], np.int32)])           # slot for null chroms
-        if len(i) < _PAR_MIN_ROWS:
-            return remap[i]
+        if (remap == np.arange(len(remap), dtype=np.int32)).all():            # this side's dictionary is a prefix of the shared one
+            return i
         out = np.empty(len(i), np.int32)
-
-        def block(r):
-            out[r[0]:r[1]] = remap[i[r[0]:r[1]]]
-        _pmap(block, _blocks(len(i)))
+        H.remap_i32(i, remap, out)
         return out
 
     (c1s, c1e), (c2s, c2e) = _pmap(lambda tc: (_coord_to_i32(tc[0].column(tc[1][1]), tc[1][1]), _coord_to_i32(tc[0].column(tc[1][2]), tc[1][2])),
@@ -257,6 +253,8 @@ def encode_frame(t: pa.Table, cols):
 def _chrom_from_ids(ids: np.ndarray, dictionary: pa.Array, typ: pa.DataType, null_mask=None) -> pa.Array:
     """The chrom column of a result from per-row dictionary ids (-1 = null): a gather out of the (cache-resident) dictionary
     instead of a string take out of the 10^7-row input column."""
+    if len(ids) == 0:
+        return pa.array([], type=typ)
     mask = ids < 0
     if null_mask is not None:
         mask = mask | null_mask
@@ -275,24 +273,59 @@ def _chrom_from_ids(ids: np.ndarray, dictionary: pa.Array, typ: pa.DataType, nul
     return parts[0] if len(parts) == 1 else pa.chunked_array(parts, type=typ)
 
 
+def _fixed_width_view(col):
+    """A null-free 4- or 8-byte column (integers, floats, dates / timestamps) as a numpy view of its ONE buffer, else None."""
+    t = col.type
+    if col.null_count or not (pa.types.is_integer(t) or pa.types.is_floating(t) or pa.types.is_temporal(t)) or t.bit_width not in (32, 64):
+        return None
+    a = col
+    if isinstance(a, pa.ChunkedArray):
+        if a.num_chunks != 1:
+            a = a.combine_chunks()
+            a = a.chunk(0) if isinstance(a, pa.ChunkedArray) and a.num_chunks == 1 else a
+            if isinstance(a, pa.ChunkedArray):
+                return None
+        else:
+            a = a.chunk(0)
+    width = t.bit_width // 8
+    return np.frombuffer(a.buffers()[1], dtype=np.dtype(f"u{width}"), count=len(a), offset=a.offset * width)
+
+
+def _validity_buffer(mask: np.ndarray):
+    return pa.py_buffer(np.packbits(~mask, bitorder="little"))
+
+
 def take_rows(t: pa.Table, idx: np.ndarray, nullable: bool = False, chrom=None) -> pa.Table:
-    """Gather rows; with nullable=True an index of -1 yields an all-null row.  Columns are gathered in parallel on the thread
-    pool.  chrom = (column name, per-row dictionary ids of ``t``, dictionary): that column is rebuilt from the dictionary."""
-    if nullable:
-        mask = idx < 0
-        arr = pa.array(np.where(mask, 0, idx), type=pa.int32(), mask=mask)
-    else:
-        mask = None
-        arr = pa.array(idx, type=pa.int32())
+    """Gather rows; with nullable=True an index of -1 yields an all-null row.  Fixed-width null-free columns go through the
+    native threaded gather (ivj_host_take), the rest through pyarrow's take, column by column on the thread pool.
+    chrom = (column name, per-row dictionary ids of ``t``, dictionary): that column is rebuilt from the dictionary."""
+    idx = np.ascontiguousarray(idx, np.int32)
+    mask = (idx < 0) if nullable else None
     if t.num_rows == 0 and nullable:
         return pa.table({n: pa.nulls(len(idx), t.schema.field(n).type) for n in t.column_names})
+    arr_box = []
+
+    def arrow_idx():
+        if not arr_box:
+            arr_box.append(pa.array(np.where(mask, 0, idx), type=pa.int32(), mask=mask) if nullable else pa.array(idx, type=pa.int32()))
+        return arr_box[0]
 
     def one(name):
         if chrom is not None and name == chrom[0] and t.num_rows:
-            ids = chrom[1][np.where(mask, 0, idx)] if nullable else chrom[1][idx]
+            ids = H.take(chrom[1], idx)                                        # (a negative index reads 0: masked below)
             return _chrom_from_ids(ids, chrom[2], t.schema.field(name).type, mask)
-        return t.column(name).take(arr)
+        col = t.column(name)
+        view = views.get(name)
+        if view is not None:
+            vals = H.take(view, idx)
+            vbuf = _validity_buffer(mask) if (nullable and mask.any()) else None
+            return pa.Array.from_buffers(col.type, len(idx), [vbuf, pa.py_buffer(vals)])
+        return col.take(arrow_idx())
     names = t.column_names
+    is_chrom = lambda n: chrom is not None and n == chrom[0] and t.num_rows
+    views = {n: _fixed_width_view(t.column(n)) for n in names if t.num_rows and not is_chrom(n)}
+    if any(views.get(n) is None for n in names if not is_chrom(n)):
+        arrow_idx()                                                            # built once, before the columns fan out
     cols = _pmap(one, names, COLUMNS) if len(idx) >= _PAR_MIN_ROWS else [one(n) for n in names]
     return pa.Table.from_arrays(cols, names=names)
 

@@ -1,0 +1,73 @@
+"""Host-side passes of the front door, in the native library (include/ivjoin.h, "host-side helpers"; csrc/host_frontdoor.hip.h).
+
+The reference runs these inside its Rust executor (DataFusion: dictionary handling of the join key, the column gathers of
+the renaming SELECT, /root/reference/src/operation.rs:272-301; the int32 coordinate limit, docs/features/operations.md:36-37).
+Each wrapper hands the buffers of numpy / Arrow arrays to ONE threaded pass; ctypes releases the interpreter lock for the call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from ._engine import _check, load_library
+
+THREADS = max(1, min(int(os.environ.get("IVJ_HOST_THREADS", "32")), os.cpu_count() or 1))
+MAX_DICT = 4096
+
+
+def _ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+def narrow_i32(a: np.ndarray) -> Tuple[np.ndarray, int, int]:
+    """Integer column -> (int32 copy, min, max) in one pass; the caller checks the range."""
+    L = load_library()
+    a = np.ascontiguousarray(a)
+    out = np.empty(len(a), np.int32)
+    mn, mx = C.c_int64(0), C.c_int64(0)
+    _check(L, L.ivj_host_narrow_i32(_ptr(a), a.dtype.itemsize, 1 if a.dtype.kind == "u" else 0, len(a), _ptr(out), C.byref(mn), C.byref(mx), THREADS),
+           "ivj_host_narrow_i32")
+    return out, mn.value, mx.value
+
+
+def encode_utf8(offsets: np.ndarray, data: Optional[np.ndarray], validity: Optional[np.ndarray], bit0: int, n: int, out: np.ndarray):
+    """String column buffers -> ids written to ``out`` (int32, n), returns the rows that hold the dictionary values in
+    first-occurrence order, or None when the column has more distinct values than the native encoder keeps."""
+    L = load_library()
+    rows = np.empty(MAX_DICT, np.int64)
+    nv = C.c_int32(0)
+    rc = L.ivj_host_encode_utf8(_ptr(offsets), offsets.dtype.itemsize, _ptr(data) if data is not None and len(data) else None,
+                                _ptr(validity) if validity is not None else None, int(bit0), int(n), _ptr(out), _ptr(rows), MAX_DICT,
+                                C.byref(nv), THREADS)
+    if rc == -4:                                             # IVJ_ECAPACITY
+        return None
+    _check(L, rc, "ivj_host_encode_utf8")
+    return rows[:nv.value].copy()
+
+
+def remap_i32(idx: np.ndarray, table: np.ndarray, out: np.ndarray, seen: Optional[np.ndarray] = None) -> None:
+    """out[i] = table[idx[i]] (-1 for a negative index); seen[v] |= 1 for every table slot used."""
+    L = load_library()
+    idx = np.ascontiguousarray(idx)
+    table = np.ascontiguousarray(table, np.int32)
+    if seen is None:
+        seen = np.zeros(max(len(table), 1), np.uint8)
+    _check(L, L.ivj_host_remap_i32(_ptr(idx), idx.dtype.itemsize, len(idx), _ptr(table), len(table), _ptr(out), _ptr(seen), THREADS), "ivj_host_remap_i32")
+
+
+def take(src: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """src[idx] for a contiguous 4- or 8-byte column (a negative index yields 0)."""
+    L = load_library()
+    out = np.empty(len(idx), src.dtype)
+    _check(L, L.ivj_host_take(_ptr(src), src.dtype.itemsize, len(src), _ptr(idx), len(idx), _ptr(out), THREADS), "ivj_host_take")
+    return out
+
+
+def widen_i64(src: np.ndarray) -> np.ndarray:
+    L = load_library()
+    out = np.empty(len(src), np.int64)
+    _check(L, L.ivj_host_widen_i32(_ptr(src), len(src), _ptr(out), THREADS), "ivj_host_widen_i32")
+    return out

@@ -27,8 +27,9 @@ class Context:
             "ivj.devices": "auto",
             "ivj.num_gpus": "0",
             "ivj.low_memory_batch_rows": "8000000",
-            # "host": result rows are gathered with Arrow take on the host from the index pairs;
-            # "device": the key columns of both sides are materialised in HBM (ivj_overlap_rows)
+            # joined rows of pb.overlap: the key columns of both sides always come back from HBM in pair order
+            # (ivj_overlap_rows); the other columns are gathered by the pair indices on the host ("host", native threaded
+            # gather) or through HBM ("device", ivj_take); "pairs": index pairs only, every column gathered on the host
             "ivj.materialize": "host",
         }
 

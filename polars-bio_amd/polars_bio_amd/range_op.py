@@ -75,47 +75,69 @@ def _low_memory_batch_rows() -> int:
         return 8_000_000
 
 
+def _key_columns_from_device(t1, t2, cols1, cols2) -> bool:
+    """The key columns of a joined result can come back from the device (int32 in pair order) when the frames' coordinate
+    columns are plain integers (any width: the engine computes in int32) and the engine offers ivj_overlap_rows;
+    ``ivj.materialize = pairs`` keeps the index-pair path (the result rows are then gathered on the host)."""
+    from .context import get_option
+    if str(get_option("ivj.materialize") or "host").lower() == "pairs":
+        return False
+    c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
+    c2 = list(DEFAULT_INTERVAL_COLUMNS if cols2 is None else cols2)
+    for t, c in ((t1, c1), (t2, c2)):
+        for name in c[1:]:
+            if not pa.types.is_integer(t.schema.field(name).type):
+                return False
+    return hasattr(default_engine(), "overlap_rows")
+
+
 def _materialize_on_device() -> bool:
     from .context import get_option
     return str(get_option("ivj.materialize") or "host").lower() == "device"
 
 
-def _overlap_device_rows(t1, t2, cols1, cols2, suffixes, zero_based) -> pa.Table:
-    """Join-mode overlap whose key columns are materialised in HBM (ivj_overlap_rows, SURVEY.md
-    section 8f row 1) and arrive through the Arrow C Data interface; only the non-key columns are
-    gathered on the host.  Same output contract as the host path (src/operation.rs:272-301)."""
+def _overlap_join_rows(t1, t2, probe, build, n_contigs, keys, cols1, cols2, suffixes, zero_based, others_on_device) -> pa.Table:
+    """Join-mode overlap whose key columns are materialised in HBM (ivj_overlap_rows) and arrive
+    through the Arrow C Data interface as int32 columns in pair order: the six key columns of the result are then sequential
+    passes (a widening back to the frame's dtype, a gather out of the chrom dictionary) instead of six random gathers out of the
+    10^7-row inputs; only the non-key columns are gathered by the pair indices -- on the host (native threaded gather) or,
+    with ``ivj.materialize = device``, in HBM (ivj_take).  Same output contract as the host path (src/operation.rs:272-301)."""
     c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
     c2 = list(DEFAULT_INTERVAL_COLUMNS if cols2 is None else cols2)
-    probe, build, n_contigs, dictionary = A.encode_keys(t1, c1, t2, c2, with_dictionary=True)
-    rows = default_engine().overlap_rows(probe, build, strict=zero_based, n_contigs=n_contigs, as_arrow=True)
-    p_idx, b_idx = rows.column("probe_idx"), rows.column("build_idx")
+    dictionary = keys[4]
+    eng = default_engine()
+    rows = eng.overlap_rows(probe, build, strict=zero_based, n_contigs=n_contigs, as_arrow=True)
+    col = lambda name: rows.column(name).to_numpy(zero_copy_only=False)     # views of the library's buffers (owned by `rows`)
+    p_idx, b_idx, contig = col("probe_idx"), col("build_idx"), col("contig")
     other1 = [n for n in t1.column_names if n not in c1]
     other2 = [n for n in t2.column_names if n not in c2]
-    # non-key columns: fixed-width null-free ones are gathered in HBM as well (ivj_take), the rest by the host take;
-    # key columns: placeholders that are replaced below
-    eng = default_engine()
-    pi = p_idx.to_numpy(zero_copy_only=False) if other1 else None
-    bi = b_idx.to_numpy(zero_copy_only=False) if other2 else None
-    left = A.take_rows_device(eng, t1.select(other1), pi) if other1 else None
-    right = A.take_rows_device(eng, t2.select(other2), bi) if other2 else None
+    take = (lambda t, idx: A.take_rows_device(eng, t, idx)) if others_on_device else (lambda t, idx: A.take_rows(t, idx))
 
-    def assemble(src, names_other, taken_other, cols, contig, start, end):
-        arrays = {}
+    def coord(values, typ):
+        if pa.types.is_int32(typ):
+            return pa.array(values, type=typ)
+        if pa.types.is_int64(typ):
+            return pa.Array.from_buffers(typ, len(values), [None, pa.py_buffer(A.H.widen_i64(values))])
+        return pc.cast(pa.array(values, type=pa.int32()), typ)
+
+    def side(args):
+        src, cols, others, idx, start, end = args
+        taken = take(src.select(others), idx) if others else None
+        arrays = []
         for name in src.column_names:
             typ = src.schema.field(name).type
             if name == cols[0]:
-                val = pc.take(dictionary, contig)
-                arrays[name] = pc.cast(val, typ) if not pa.types.is_dictionary(typ) else pc.cast(pc.dictionary_encode(pc.cast(val, typ.value_type)), typ)
+                arrays.append(A._chrom_from_ids(contig, dictionary, typ))
             elif name == cols[1]:
-                arrays[name] = pc.cast(start, typ)
+                arrays.append(coord(start, typ))
             elif name == cols[2]:
-                arrays[name] = pc.cast(end, typ)
+                arrays.append(coord(end, typ))
             else:
-                arrays[name] = taken_other.column(name)
-        return pa.table(arrays)
+                arrays.append(taken.column(name))
+        return pa.Table.from_arrays(arrays, names=src.column_names)
 
-    res1 = assemble(t1, other1, left, c1, rows.column("contig"), rows.column("start_1"), rows.column("end_1"))
-    res2 = assemble(t2, other2, right, c2, rows.column("contig"), rows.column("start_2"), rows.column("end_2"))
+    jobs = [(t1, c1, other1, p_idx, col("start_1"), col("end_1")), (t2, c2, other2, b_idx, col("start_2"), col("end_2"))]
+    res1, res2 = A._pmap(side, jobs, A.SIDES) if len(p_idx) >= A._PAR_MIN_ROWS else [side(j) for j in jobs]
     return A.hconcat(A.with_suffix(res1, suffixes[0]), A.with_suffix(res2, suffixes[1]))
 
 
@@ -276,8 +298,9 @@ def overlap(
                                overlap_output=overlap_output, distinct_output=distinct_output, as_reader=True)
         return lazy if output_type == "pyarrow.RecordBatchReader" else A.from_arrow(lazy.read_all(), output_type, zero_based)
     t1, t2, probe, build, n_contigs, keys = _prepare(df1, df2, cols1, cols2)
-    if mode == OverlapOutputMode.Join and not low_memory and _materialize_on_device():
-        return A.from_arrow(_overlap_device_rows(t1, t2, cols1, cols2, suffixes, zero_based), output_type, zero_based)
+    if mode == OverlapOutputMode.Join and not low_memory and _key_columns_from_device(t1, t2, cols1, cols2):
+        return A.from_arrow(_overlap_join_rows(t1, t2, probe, build, n_contigs, keys, cols1, cols2, suffixes, zero_based, _materialize_on_device()),
+                            output_type, zero_based)
     if low_memory:
         # bounded device footprint and result batches: the probe side streams through the GPU in
         # tiles against the resident build index (reference: low_memory caps the output batch size)

@@ -308,9 +308,22 @@ def test_device_materialised_key_columns_equal_host_take(engine):
     df2["gene"] = [f"g{i}" for i in range(n2)]
     for d in (df1, df2):
         d.attrs["coordinate_system_zero_based"] = True
-    host = pb.overlap(df1, df2, suffixes=("_x", "_y"), output_type="pandas.DataFrame")
-    gold_host = pb.overlap(_csv(f"{GOLDEN}/overlap/reads.csv"), _csv(f"{GOLDEN}/overlap/targets.csv"),
-                           cols1=COLS, cols2=COLS, output_type="pandas.DataFrame")
+    # "pairs": index pairs from the engine, every result column gathered on the host -- the reference frame for the two modes
+    # whose key columns come back from the device ("host": the default, other columns by the native host gather; "device":
+    # other columns through HBM)
+    pb.set_option("ivj.materialize", "pairs")
+    try:
+        host = pb.overlap(df1, df2, suffixes=("_x", "_y"), output_type="pandas.DataFrame")
+        gold_host = pb.overlap(_csv(f"{GOLDEN}/overlap/reads.csv"), _csv(f"{GOLDEN}/overlap/targets.csv"),
+                               cols1=COLS, cols2=COLS, output_type="pandas.DataFrame")
+    finally:
+        pb.set_option("ivj.materialize", "host")
+    default = pb.overlap(df1, df2, suffixes=("_x", "_y"), output_type="pandas.DataFrame")
+    assert list(default.columns) == list(host.columns) and len(default) == len(host)
+    assert default["start_x"].dtype == np.int64 and default["start_y"].dtype == np.int32
+    for col in host.columns:
+        assert (default.sort_values(["tag_x", "gene_y"]).reset_index(drop=True)[col].astype(str) ==
+                host.sort_values(["tag_x", "gene_y"]).reset_index(drop=True)[col].astype(str)).all(), col
     pb.set_option("ivj.materialize", "device")
     try:
         dev = pb.overlap(df1, df2, suffixes=("_x", "_y"), output_type="pandas.DataFrame")

@@ -14,16 +14,20 @@ from polars_bio_amd._engine import default_engine
 
 
 def stages(t1, t2):
+    """key encoding | engine incl. the key columns of the pairs (ivj_overlap_rows) | the rest of the row assembly"""
     c = ["chrom", "start", "end"]
     t = time.perf_counter()
     probe, build, nc, u = A.encode_keys(t1, c, t2, c, with_dictionary=True)
     t_enc = time.perf_counter() - t
+    keys = ("chrom", probe[0], "chrom", build[0], u)
+    eng = default_engine()
     t = time.perf_counter()
-    p, b = default_engine().overlap(probe, build, strict=True, n_contigs=nc)
+    rows = eng.overlap_rows(probe, build, strict=True, n_contigs=nc, as_arrow=True)
     t_eng = time.perf_counter() - t
+    del rows
     t = time.perf_counter()
-    res = R._assemble_overlap(t1, t2, p, b, R.OverlapOutputMode.Join, False, ("_1", "_2"), ("chrom", probe[0], "chrom", build[0], u))
-    t_asm = time.perf_counter() - t
+    res = R._overlap_join_rows(t1, t2, probe, build, nc, keys, c, c, ("_1", "_2"), True, False)
+    t_asm = time.perf_counter() - t - t_eng
     return t_enc, t_eng, t_asm, res.num_rows
 
 
@@ -41,7 +45,7 @@ def main():
         d.attrs["coordinate_system_zero_based"] = True
     pb.overlap(t1.slice(0, 1000), t2, output_type="pyarrow.Table")            # engine start-up, library load
     print(f"# host threads of the front door: {A._NT} row-block workers (cpu_count {os.cpu_count()})")
-    for mode in ("host", "device"):
+    for mode in ("host", "device", "pairs"):
         pb.set_option("ivj.materialize", mode)
         for label, a, bb, out in (("arrow(string chrom) -> arrow", t1, t2, "pyarrow.Table"), ("arrow(dictionary chrom) -> arrow", dict1, dict2, "pyarrow.Table"),
                                   ("pandas -> pandas", d1, d2, "pandas.DataFrame")):
@@ -59,7 +63,7 @@ def main():
         for _ in range(3):
             s = stages(a, bb)
             best = s if best is None or sum(s[:3]) < sum(best[:3]) else best
-        print(f"stages ({label}): key encoding {best[0]:.3f} s | engine (H2D + index + join + D2H) {best[1]:.3f} s | row assembly {best[2]:.3f} s   rows {best[3]:,}")
+        print(f"stages ({label}): key encoding {best[0]:.3f} s | engine (H2D + index + join + key columns + D2H) {best[1]:.3f} s | row assembly {best[2]:.3f} s   rows {best[3]:,}")
 
 
 if __name__ == "__main__":
