@@ -205,9 +205,10 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_general(IndexView ix,
     if (b > a) {
         const int hi = bound_hi<STRICT>(ix, a, b, qe);
         if (include_overlaps) {
+            // the first kk overlapping rows in (start, row) order, over the block maxima of the ends: a contig-wide row at the
+            // contig's start does not make this a scan of every row below the probe
             const int lo = bound_lo<STRICT>(ix, a, hi, qs);
-            for (int p = lo; p < hi && found < kk; ++p)
-                if (lt_op<STRICT>(qs, ix.ep[p].x)) { oi[found] = ix.b_row[p]; od[found] = 0; ++found; }
+            hier_walk_up<STRICT>(ix.hier, lo, hi, qs, [&](int p) { oi[found] = ix.b_row[p]; od[found] = 0; ++found; return found < kk; });
         }
         const int r_top = bound_r<STRICT>(ix, a, b, qs);
         int run_hi = r_top, run_lo = r_top, lp = r_top, rp = hi;

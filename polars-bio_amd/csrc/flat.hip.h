@@ -23,6 +23,7 @@ namespace ivj {
 constexpr int FLAT_THREADS = 256;
 constexpr int FLAT_ITEMS = 2;
 constexpr int FLAT_TILE = FLAT_THREADS * FLAT_ITEMS;   // probes per workgroup
+constexpr int FLAT_MAX_CAND = 1 << 15;                  // candidates of ONE probe the flat path accepts
 constexpr int FLAT_CH = 2048;                          // candidates per chunk (one 16-byte mark vector per thread)
 static_assert(FLAT_CH * 2 == FLAT_THREADS * 16, "one uint4 of marks per thread");
 static_assert(FLAT_TILE < 65535, "probe index + 1 must fit the 16-bit marks");
@@ -206,6 +207,10 @@ __global__ __launch_bounds__(FLAT_THREADS, 6) void k_overlap_flat(IndexView ix, 
 #pragma unroll
     for (int k = 0; k < FLAT_ITEMS; ++k) {
         flat_range<STRICT>(ix, c[k], s[k], e[k], i0 + k < n, lo[k], cn[k]);
+        // a candidate range this long is not a dense window, it is a window kept open by a few long rows (a contig-wide one):
+        // testing every row of it is the cliff hier_walk exists for -- the probe is dropped, the flag makes the host redo the
+        // call with the window kernels
+        if (cn[k] > FLAT_MAX_CAND) { cn[k] = 0; atomicOr(&state[2], 1ull); }
         tsum += cn[k];
     }
     long long T;

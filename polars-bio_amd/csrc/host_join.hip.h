@@ -191,33 +191,38 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     // dense results (the caller expects >= 16 pairs per probe; at ~8 the two kernels tie and the flat one still has
     // to fill its arrays and the end order): the flat kernel spreads every window over the whole
     // workgroup (1.8x the count + dense-fill pair on 37 pairs per probe); sparse ones keep the window-scan kernel
-    const bool flat = opts->partition_mode == 5 || (opts->partition_mode == 0 && capacity >= 16 * n && ix->n_contigs > 0);
+    bool flat = opts->partition_mode == 5 || (opts->partition_mode == 0 && capacity >= 16 * n && ix->n_contigs > 0);
     if (flat) IVJ_TRY(build_flat(ctx, ix));
     // dense tiles of the flat kernel get their match counts from the end order (two-rank formula) instead of a sweep
     const bool rank_counts = flat && capacity >= 16 * n;
     if (rank_counts) IVJ_TRY(build_end_table(ctx, ix));
-    const int64_t tiles = flat ? (n + FLAT_TILE - 1) / FLAT_TILE : (n + PROBE_TILE - 1) / PROBE_TILE;
-    unsigned long long* state = (unsigned long long*)ctx->ov_tile;   // [0] cursor, [1] overflow
+    unsigned long long* state = (unsigned long long*)ctx->ov_tile;   // [0] cursor, [1] overflow, [2] flat kernel: some candidate range was too long
     const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *ids = probe->row_id;
     if (part) {
         IVJ_TRY(partition_probes(ctx, ix, probe, opts));
         qc = ctx->pt_c; qs = ctx->pt_s; qe = ctx->pt_e; ids = ctx->pt_row;
     }
-    HIP_TRY(hipMemsetAsync(state, 0, 16, ctx->stream));
-    const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
-    IndexView v = view_of(ix);
-    if (flat) {
-        if (opts->filter_op == IVJ_FILTER_STRICT)
-            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<true>), 8 * ((tiles + 7) / 8), FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int64_t tiles = flat ? (n + FLAT_TILE - 1) / FLAT_TILE : (n + PROBE_TILE - 1) / PROBE_TILE;
+        HIP_TRY(hipMemsetAsync(state, 0, 24, ctx->stream));
+        const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+        IndexView v = view_of(ix);
+        if (flat) {
+            if (opts->filter_op == IVJ_FILTER_STRICT)
+                LAUNCH(ctx, "overlap_flat", (k_overlap_flat<true>), 8 * ((tiles + 7) / 8), FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
+            else
+                LAUNCH(ctx, "overlap_flat", (k_overlap_flat<false>), 8 * ((tiles + 7) / 8), FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
+        } else if (opts->filter_op == IVJ_FILTER_STRICT)
+            LAUNCH(ctx, "overlap_fused", (k_overlap_fused<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
         else
-            LAUNCH(ctx, "overlap_flat", (k_overlap_flat<false>), 8 * ((tiles + 7) / 8), FLAT_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b, (int)rank_counts);
-    } else if (opts->filter_op == IVJ_FILTER_STRICT)
-        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<true>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
-    else
-        LAUNCH(ctx, "overlap_fused", (k_overlap_fused<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
-    HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipGetLastError());
+            LAUNCH(ctx, "overlap_fused", (k_overlap_fused<false>), 8 * ((tiles + 7) / 8), PROBE_THREADS, v, qc, qs, qe, ids, n, vec, (long long)capacity, state, out_p, out_b);
+        HIP_TRY(hipMemcpyAsync(ctx->h_total, state, 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipGetLastError());
+        // the flat kernel met a probe whose candidate range is a long sparse window (flat.hip.h FLAT_MAX_CAND): the window kernels redo the call
+        if (flat && ctx->h_total[2] != 0) { flat = false; continue; }
+        break;
+    }
     *n_pairs = ctx->h_total[0];
     if (ctx->h_total[1] != 0)
         return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");

@@ -228,6 +228,34 @@ __device__ __forceinline__ void hier_walk(const HierView& H, const EpAt& ep_at, 
     }
 }
 
+// The same enumeration in ASCENDING position over the rows [lo, hi) (all of one contig): rows that end above qsv, smallest
+// (start, row) first -- the order nearest(k > 1) lists overlapping rows in.  Cursor = an entry none of whose rows has been looked
+// at; a block hands over to the entry right of its parent.  f(p) returns false to stop.
+template <bool STRICT, class F>
+__device__ __forceinline__ void hier_walk_up(const HierView& H, int lo, int hi, int32_t qsv, F&& f) {
+    int i = lo, lv = 0;
+    while (((int64_t)i << (4 * lv)) < (int64_t)hi) {
+        const int base = i & ~15;
+        uint32_t off = 0;
+#pragma unroll
+        for (int l = 1; l < HIER_MAX; ++l) off = lv == l ? H.off[l] : off;
+        const int4* bp = reinterpret_cast<const int4*>(H.v + (size_t)off + (size_t)base);
+        const int4 w0 = bp[0], w1 = bp[1], w2 = bp[2], w3 = bp[3];
+        uint32_t m = ends_mask16<STRICT>(qsv, w0, w1, w2, w3) & ~((1u << (i & 15)) - 1u);
+        if (lv == 0) {
+            if (hi - base < 16) m &= (1u << (hi - base)) - 1u;
+            while (m) { const int j = __builtin_ctz(m); m &= m - 1; if (!f(base + j)) return; }
+        } else if (m) {
+            i = (base + __builtin_ctz(m)) << 4;                                // the leftmost child above qsv, from its first entry
+            --lv;
+            continue;
+        }
+        if (lv == H.nlev) return;
+        i = (base >> 4) + 1; ++lv;
+        while ((i & 15) == 0 && lv < H.nlev) { i >>= 4; ++lv; }
+    }
+}
+
 // Workgroup b is observed to run on XCD b % 8.  Giving every XCD one CONTIGUOUS eighth of the (bucket-ordered) tiles
 // means its L2 only ever holds the index slices of its own buckets, instead of all eight L2s fetching every slice.
 // Launch 8 * ceil(ntiles / 8) workgroups; a tile index >= ntiles has nothing to do.  Speed only, never the result.

@@ -8,6 +8,8 @@ namespace ivj {
 
 // ---- shared bodies of the count / fill / fused kernels -------------------------------------------
 
+constexpr int COOP_MIN = 16;            // matches a 64-row cooperative step must find for the window to stay with the wavefront
+
 // For the PROBE_ITEMS probes of this thread: hi-bound through the table, then the window below hi
 // as a 32-row match mask (x = mask) or -- window longer than 32 rows -- an exact count made by
 // the whole wavefront (x = count, sign bit of hi set).  cnt = number of matches.
@@ -18,17 +20,55 @@ __device__ __forceinline__ void probe_windows(const IndexView& ix, const int32_t
                                               int (&x)[PROBE_ITEMS], int (&cnt)[PROBE_ITEMS]) {
     int a[PROBE_ITEMS], b[PROBE_ITEMS];
     bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
+    const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
     for (int k = 0; k < PROBE_ITEMS; ++k) {
         uint32_t mask; int cn;
         const bool small = window_mask<STRICT>(ix, a[k], hi[k], s[k], mask, cn);
         x[k] = (int)mask;
-        // a window longer than the mask: counted over the block maxima of the ends (hier_walk) -- dense windows cost a block read
-        // per sixteen rows, windows kept open by a few long rows (a contig-wide one) a few reads per match
+        // A window longer than the mask.  Dense windows (deeply nested / long build rows under many probes) are counted by the
+        // whole wavefront, 64 rows per step with one coalesced read -- as long as a step still finds COOP_MIN matches; a window
+        // that runs on with few matches (kept open by a handful of long rows, a contig-wide one) is handed to its lane, which
+        // finds the remaining matches over the block maxima of the ends (hier_walk): a few reads per match however far down
+        // they lie.  The emission (emit_tile_rows) replays exactly these decisions.
+        int cont = -1;                                         // this lane's window: first row the cooperative steps did not cover
+        unsigned long long todo = __ballot(!small);
+        while (todo) {
+            int src[4], ca[4], chi[4]; int32_t cqs[4]; int2 v0[4], v1[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                src[t] = todo ? __ffsll((long long)todo) - 1 : -1;
+                if (todo) todo &= todo - 1;
+                const int sl = src[t] < 0 ? 0 : src[t];
+                ca[t] = __shfl(a[k], sl, kWave); chi[t] = __shfl(hi[k], sl, kWave); cqs[t] = __shfl(s[k], sl, kWave);
+                if (src[t] < 0) { ca[t] = 0; chi[t] = 0; }
+                const int p = chi[t] - 1 - lane;
+                v0[t] = (p >= ca[t]) ? ix.ep[p] : make_int2(0, 0);
+                v1[t] = (p - kWave >= ca[t]) ? ix.ep[p - kWave] : make_int2(0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (src[t] < 0) continue;                      // uniform
+                int cc = 0, rest = -1;
+                int2 v = v0[t];
+                int step = 0;
+                for (int p0 = chi[t] - 1; p0 >= ca[t]; p0 -= kWave, ++step) {
+                    const int p = p0 - lane;
+                    if (step == 1) v = v1[t];
+                    else if (step > 1) v = (p >= ca[t]) ? ix.ep[p] : make_int2(0, 0);
+                    const bool pass = p >= ca[t] && lt_op<STRICT>(cqs[t], v.y);
+                    const bool match = pass && lt_op<STRICT>(cqs[t], v.x);
+                    const int nm = (int)__popcll(__ballot(match));
+                    cc += nm;
+                    if (__popcll(__ballot(pass)) < kWave) break;
+                    if (nm < COOP_MIN) { rest = p0 - kWave; break; }
+                }
+                if (lane == src[t]) { cn = cc; cont = rest; }
+            }
+        }
         if (!small) {
-            int cc = 0;
-            hier_walk<STRICT>(ix.hier, [&](int p) { return ix.ep[p]; }, a[k], hi[k] - 1, s[k], [&](int) { ++cc; return true; });
-            cn = cc; x[k] = cc;
+            if (cont >= a[k]) hier_walk<STRICT>(ix.hier, [&](int p) { return ix.ep[p]; }, a[k], cont, s[k], [&](int) { ++cn; return true; });
+            x[k] = cn;
         }
         if (!small) hi[k] |= (int)0x80000000;      // flag: x is a count, the emission rescans
         cnt[k] = cn;
@@ -71,6 +111,8 @@ __device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf&
                                                const int32_t (&x)[N], const int32_t (&cnt)[N],
                                                const int32_t (&row)[N], const int32_t (&qs)[N],
                                                long long loc0, long long tot, long long tbase, int32_t* st_p, int32_t* st_b) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned long long lt_lanes = (1ull << lane) - 1ull;
     for (long long w0 = 0; w0 < tot; w0 += STAGE) {
         const long long w1 = w0 + STAGE;
         long long off = loc0;                                  // tile-local offset of the current probe
@@ -91,16 +133,49 @@ __device__ __forceinline__ void emit_tile_rows(const IndexView& ix, const RowOf&
                     ++o;
                 }
             }
-            if (in_win && hi[k] < 0) {
-                // long window: the same walk as the count, descending; the f-th match from the top owns slot end - 1 - f
+            // long windows: the decisions of the count replayed (probe_windows): cooperative steps of 64 rows while a step finds
+            // COOP_MIN matches, the f-th match from the top of the window owns slot end - 1 - f (ballot + popcount of the lower
+            // lanes); what is left belongs to the lane's own walk over the block maxima
+            int cont = -1, done = 0;
+            unsigned long long todo = __ballot(in_win && hi[k] < 0);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int h = __shfl(hi[k], src, kWave) & 0x7fffffff;
+                const int c = __shfl(cnt[k], src, kWave);
+                const int32_t cqs = __shfl(qs[k], src, kWave);
+                const int32_t crow = __shfl(row[k], src, kWave);
+                const long long cend = ((long long)__shfl((int)(end >> 32), src, kWave) << 32) |
+                                       (unsigned long long)(unsigned int)__shfl((int)(end & 0xffffffffll), src, kWave);
+                int found = 0, rest = -1;
+                for (int p0 = h - 1; found < c && p0 >= 0 && cend - found > w0; p0 -= kWave) {
+                    const int p = p0 - lane;
+                    int2 v = make_int2(0, 0);
+                    int32_t br = 0;
+                    if (p >= 0) { v = ix.ep[p]; br = rowof(p); }
+                    const bool m = p >= 0 && lt_op<STRICT>(cqs, v.x);
+                    const unsigned long long mm = __ballot(m);
+                    if (m) {
+                        // rows below the window (or of the previous contig) rank past the c-th match
+                        const long long o = cend - 1 - found - (long long)__popcll(mm & lt_lanes);
+                        if (o >= w0 && o < w1 && o >= cend - c) { st_p[o - w0] = crow; st_b[o - w0] = br; }
+                    }
+                    const int nm = (int)__popcll(mm);
+                    found += nm;
+                    if (found < c && nm < COOP_MIN) { rest = p0 - kWave; break; }
+                }
+                if (lane == src) { cont = rest; done = found; }
+            }
+            if (cont >= 0) {
                 // (the first cnt matches going down are the window's: the walk needs no lower bound, it stops there or below
                 // the staging window)
-                long long o = end - 1;
-                hier_walk<STRICT>(ix.hier, [&](int p) { return ix.ep[p]; }, 0, (hi[k] & 0x7fffffff) - 1, qs[k], [&](int p) {
-                    if (o < w1) { st_p[o - w0] = row[k]; st_b[o - w0] = rowof(p); }
-                    --o;
-                    return o >= off && o >= w0;
-                });
+                long long o = end - 1 - done;
+                if (o >= off && o >= w0)
+                    hier_walk<STRICT>(ix.hier, [&](int p) { return ix.ep[p]; }, 0, cont, qs[k], [&](int p) {
+                        if (o < w1) { st_p[o - w0] = row[k]; st_b[o - w0] = rowof(p); }
+                        --o;
+                        return o >= off && o >= w0;
+                    });
             }
             off = end;
         }

@@ -26,8 +26,10 @@ def _canon(p, b):
     return p[o], b[o]
 
 
-def _fused_overlap(eng, probe, build, strict, n_contigs, partition_mode, total, slice_rows=0):
-    """ivj_overlap_fused_dev with device-resident columns; returns the raw (probe, build) pair arrays."""
+def _fused_overlap(eng, probe, build, strict, n_contigs, partition_mode, total, slice_rows=0, capacity=None):
+    """ivj_overlap_fused_dev with device-resident columns; returns the raw (probe, build) pair arrays.  capacity > total: the
+    caller's buffers are larger than the result (the auto policy reads >= 16 pairs per probe as a dense result)."""
+    cap = total if capacity is None else capacity
     ptrs, sides = [], []
     for side in (probe, build):
         n = len(side[0])
@@ -40,12 +42,13 @@ def _fused_overlap(eng, probe, build, strict, n_contigs, partition_mode, total, 
         sides.append(eng.dev_side(ps[0], ps[1], ps[2], n))
     opts = _engine.make_opts(strict, n_contigs, partition_mode=partition_mode, slice_rows=slice_rows)
     ix = eng.index_build_dev(sides[1], opts)
-    op, ob = eng.dev_alloc(max(4 * total, 16)), eng.dev_alloc(max(4 * total, 16))
-    n_pairs, fits = eng.overlap_fused_dev(ix, sides[0], opts, op, ob, total)
+    op, ob = eng.dev_alloc(max(4 * cap, 16)), eng.dev_alloc(max(4 * cap, 16))
+    n_pairs, fits = eng.overlap_fused_dev(ix, sides[0], opts, op, ob, cap)
     assert fits and n_pairs == total, (partition_mode, slice_rows, n_pairs, total)
-    hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
+    hp, hb = np.empty(cap, np.int32), np.empty(cap, np.int32)
     eng.d2h(hp, op)
     eng.d2h(hb, ob)
+    hp, hb = hp[:total], hb[:total]
     ix.close()
     for p in ptrs + [op, ob]:
         eng.dev_free(p)
@@ -1031,3 +1034,20 @@ def test_long_build_tail_on_every_path(eng, strict):
     ps = rng.integers(0, span, 50_000).astype(np.int32)
     probe = (pc, ps, (ps + rng.integers(0, 300, 50_000)).astype(np.int32))
     _cmp_all(eng, probe, build, nc, strict, nearest_cfgs=((1, True), (2, True)))
+
+
+def test_flat_kernel_hands_long_sparse_windows_to_the_window_kernels(eng):
+    """partition_mode 5 (and the auto policy for a dense-looking capacity) on a build side whose windows are kept open by a
+    contig-wide row: the flat kernel's candidate ranges would be the whole contig (flat.hip.h FLAT_MAX_CAND); it flags the call
+    and the host redoes it with the window kernels -- same pairs."""
+    rng = np.random.default_rng(79)
+    nc, span = 2, 30_000_000
+    build = _long_tail_build(rng, 160_000, nc, span, 0.001, 4)
+    pc = rng.integers(0, nc, 60_000).astype(np.int32)
+    ps = rng.integers(0, span, 60_000).astype(np.int32)
+    probe = (pc, ps, (ps + rng.integers(0, 300, 60_000)).astype(np.int32))
+    ep, eb = O.overlap_fast(O.Index(O.Side(*build), nc), O.Side(*probe), True)
+    for pm in (5, 0):
+        hp, hb = _fused_overlap(eng, probe, build, True, nc, pm, len(ep), capacity=max(len(ep), 16 * len(pc) + 1))
+        p, b = _canon(hp, hb)
+        assert (p == ep).all() and (b == eb).all(), pm
