@@ -283,7 +283,7 @@ def test_far_chain_down_a_7M_row_contig(eng):
     s[0], e[0] = 0, span + 10
     perm = rng.permutation(n)
     build = (np.zeros(n, np.int32), s[perm], e[perm])
-    q = 300_000
+    q = 60_000
     qs = rng.integers(span - 3_000_000, span, q).astype(np.int32)
     probe = (np.zeros(q, np.int32), qs, (qs + rng.integers(0, 200, q)).astype(np.int32))
     ep, eb = O.overlap_fast(O.Index(O.Side(*build), 1), O.Side(*probe), True)
