@@ -34,6 +34,7 @@ constexpr int CS_TILE = CS_THREADS * CS_ITEMS;          // probes per tile of th
 constexpr int CS_WTILE = kWave * CS_ITEMS;              // probes of one wavefront per tile (its private slot range)
 constexpr int CS_MAX_CONTIGS = 256;
 constexpr int CS_WIN = 12;                              // rows below hi the branch-free window is guaranteed to cover
+constexpr int CS_LIN = 16;                             // rows below the window a running-on probe checks one by one (LDS) before it takes the block maxima
 constexpr int CS_POS_BIAS = 1 << 23;                    // staging entries carry (row - first row of the slice) + bias in 24 bits: rows below the slice too
 static_assert((long long)SL_MAX_BUCKETS * SL_MAX_ROWS <= CS_POS_BIAS, "an index of this path must fit a staging entry's row field");
 constexpr int CS_BIN_STRIDE_PAD = 2;                    // bins per slice in global memory: 2 R + 2 (u16)
@@ -673,7 +674,17 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         if (i >= 0) return make_int2(l_end[i], l_pmx[i + 1]);
         return A.ep[p];
     };
-    auto walk_below = [&](int32_t qsv, int a0, auto&& f) { hier_walk<STRICT>(A.hier, ep_at, seg_a, r0 + a0 - 1, qsv, f); };
+    auto walk_below = [&](int32_t qsv, int a0, auto&& f) {
+        // a window usually runs on by a row or two: those come from the slice in LDS, row by row; only a window that is still
+        // open CS_LIN rows further down (or at the slice's first row) takes the block maxima in HBM
+        int i = a0 - 1;
+        const int stop = a0 - CS_LIN > 0 ? a0 - CS_LIN : 0;
+        for (; i >= stop; --i) {
+            if (!lt_op<STRICT>(qsv, l_pmx[i + 1])) return;
+            if (lt_op<STRICT>(qsv, l_end[i])) { if (!f(r0 + i)) return; }
+        }
+        if (r0 + i >= seg_a) hier_walk<STRICT>(A.hier, ep_at, seg_a, r0 + i, qsv, f);
+    };
 
     auto match_tile = [&](int64_t tb) {
         int32_t qe[CS_ITEMS];
@@ -766,14 +777,19 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         }
     };
 
-    // entries {wave-local probe slot << 24 | biased slice-local row} of item j into the wavefront's staging region at off
-    auto stage_item = [&](int j, int off) {
+    // entries {wave-local probe slot << 24 | biased slice-local row} of item j into the wavefront's staging region at off;
+    // returns whether one of them lies below the slice (its build row then comes from HBM at copy-out)
+    auto stage_item = [&](int j, int off) -> bool {
         uint32_t m = mask[j];
         const uint32_t slot = (uint32_t)(j * kWave + lane) << 24;
-        const int cw = cnt[j] - __popc(m);                                     // matches below the window
-        if (any_lng && cw > 0) {
-            uint32_t* sw = stw + off + cw - 1;
-            walk_below(qs[j], al[j], [&](int p) { *sw-- = slot | (uint32_t)(p - r0 + CS_POS_BIAS); return true; });
+        int cw = 0;
+        bool below = false;
+        if (any_lng) {                                                         // uniform
+            cw = cnt[j] - __popc(m);                                           // matches below the window
+            if (cw > 0) {
+                uint32_t* sw = stw + off + cw - 1;
+                walk_below(qs[j], al[j], [&](int p) { *sw-- = slot | (uint32_t)(p - r0 + CS_POS_BIAS); below = below || p < r0; return true; });
+            }
         }
         const uint32_t ent = slot | (uint32_t)(al[j] + CS_POS_BIAS);
         uint32_t* so = stw + off + cw;
@@ -784,14 +800,24 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
             so += 2;
         }
+        return below;
     };
     // the same pairs written from the lanes (wavefronts with more pairs than the staging region holds)
     auto direct_item = [&](int j, long long off) {
         uint32_t m = mask[j];
-        const int cw = cnt[j] - __popc(m);
-        if (any_lng && cw > 0) {
-            long long o = off + cw - 1;
-            walk_below(qs[j], al[j], [&](int p) { A.out_probe[o] = qrow[j]; A.out_build[o] = p >= r0 ? l_row[p - r0] : A.b_row[p]; --o; return true; });
+        int cw = 0;
+        if (any_lng) {
+            cw = cnt[j] - __popc(m);
+            if (cw > 0) {
+                long long o = off + cw - 1;
+                walk_below(qs[j], al[j], [&](int p) {
+                    int32_t br;
+                    if (p >= r0) br = l_row[p - r0];
+                    else br = A.b_row[p];
+                    A.out_probe[o] = qrow[j]; A.out_build[o] = br; --o;
+                    return true;
+                });
+            }
         }
         long long o = off + cw;
         while (m) {
@@ -801,14 +827,24 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             ++o;
         }
     };
-    // staged entries -> pairs, coalesced over the wavefront
-    auto copy_out = [&](int32_t* op, int32_t* ob, int n_ent) {
+    // staged entries -> pairs, coalesced over the wavefront.  below (uniform): some entry points below the slice -- the usual
+    // loop reads LDS only (a pointer select between LDS and HBM would make every read a flat load behind the stores' counter)
+    auto copy_out = [&](int32_t* op, int32_t* ob, int n_ent, bool below) {
+        if (!below) {
 #pragma unroll 4
+            for (int i = lane; i < n_ent; i += kWave) {
+                const uint32_t e = stw[i];
+                __builtin_nontemporal_store(qrw[e >> 24], op + i);
+                __builtin_nontemporal_store(l_row[(int)(e & 0xffffffu) - CS_POS_BIAS], ob + i);
+            }
+            return;
+        }
         for (int i = lane; i < n_ent; i += kWave) {
             const uint32_t e = stw[i];
             const int pos = (int)(e & 0xffffffu) - CS_POS_BIAS;
-            int32_t br = l_row[pos < 0 ? 0 : pos];
-            if (__builtin_expect(pos < 0, 0)) br = A.b_row[r0 + pos];
+            int32_t br = 0;
+            if (pos >= 0) br = l_row[pos];
+            if (pos < 0) br = __builtin_nontemporal_load(A.b_row + (r0 + pos));
             __builtin_nontemporal_store(qrw[e >> 24], op + i);
             __builtin_nontemporal_store(br, ob + i);
         }
@@ -835,14 +871,15 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             const long long wbase = A.wslot[slot];
             if (wtot <= A.wcap) {
                 int off = linc - lsum;
+                bool below = false;
 #pragma unroll
                 for (int j = 0; j < CS_ITEMS; ++j) {
                     qrw[j * kWave + lane] = qrow[j];
-                    stage_item(j, off);
+                    below = stage_item(j, off) || below;
                     off += cnt[j];
                 }
                 __builtin_amdgcn_wave_barrier();
-                copy_out(A.out_probe + wbase, A.out_build + wbase, wtot);
+                copy_out(A.out_probe + wbase, A.out_build + wbase, wtot, any_lng && __ballot(below) != 0);
                 __builtin_amdgcn_wave_barrier();
             } else {
                 long long off = wbase + (linc - lsum);
@@ -861,6 +898,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     load_tile(q0);
     const int ntile = (int)((q1 - q0 + CS_TILE - 1) / CS_TILE);
     int pend_wtot = -1;                                                        // this wavefront's staged pairs of the previous tile
+    bool pend_below = false;                                                   //   ... some of them below the slice
     long long pend_woff = 0;
     for (int tix = 0; tix <= ntile; ++tix) {
         if (tix < ntile) match_tile(q0 + (int64_t)tix * CS_TILE);
@@ -872,7 +910,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
             const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
-                copy_out(A.out_probe + tb + pend_woff, A.out_build + tb + pend_woff, pend_wtot);
+                copy_out(A.out_probe + tb + pend_woff, A.out_build + tb + pend_woff, pend_wtot, pend_below);
             }
             if (lane == 0) {
                 if (atomicAdd(c + 1, 1) == CS_WAVES - 1) {                     // last wavefront out: recycle the block for tile tix + 1
@@ -909,13 +947,15 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         if (wtot > 0 && wtot <= A.wcap) {
             // usual case: the wavefront's entries into its staging region, copied out one iteration later
             int off = linc - lsum;
+            bool below = false;
 #pragma unroll
             for (int j = 0; j < CS_ITEMS; ++j) {
                 qrw[j * kWave + lane] = qrow[j];
-                stage_item(j, off);
+                below = stage_item(j, off) || below;
                 off += cnt[j];
             }
             pend_wtot = wtot;
+            pend_below = any_lng && __ballot(below) != 0;
         } else if (wtot > 0) {
             // dense wavefront: wait for the base now, write from the lanes
             for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);

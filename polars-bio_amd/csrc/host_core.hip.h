@@ -45,6 +45,19 @@ struct SlicePlan {                     // slice path: launch geometry of one cal
     size_t part_lds = 0, join_lds = 0, join_lds_count = 0;
 };
 
+// pinned staging slots of the host <-> HBM copies (host_mem.hip.h: HostXfer)
+struct XferSlots {                                         // owned by the context, allocated on first use
+    char* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    void release() {
+        for (int k = 0; k < 2; ++k) {
+            if (buf[k]) (void)hipHostFree(buf[k]);
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+            buf[k] = nullptr; ev[k] = nullptr;
+        }
+    }
+};
+
 struct ivj_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -61,7 +74,7 @@ struct ivj_ctx {
     int32_t* ov_cnt = nullptr;
     long long* ov_tile = nullptr;   // ntiles + 1: tile bases, last = total
     long long* h_total = nullptr;   // pinned
-    char* bounce = nullptr;         // pinned bounce buffer of the host <-> HBM copies (HostXfer), allocated on first use
+    XferSlots xfer;                 // pinned staging slots of the host <-> HBM copies (HostXfer), allocated on first use
     // one released index slab kept for reuse (bench/streaming loops rebuild the index every call)
     char* ix_cache = nullptr;
     size_t ix_cache_cap = 0;

@@ -18,9 +18,8 @@ int ensure_hier(ivj_ctx* ctx, ivj_index* ix) {
     const HierShape h = hier_shape(ix->n);
     // blocks past the rows (the pads of levels 0 .. 2) are written by the same launch: one workgroup per 4096 padded rows
     const int64_t wgs = (((ix->n + 15) & ~(int64_t)15) + HIER_WG_ROWS - 1) / HIER_WG_ROWS;
-    LAUNCH(ctx, "hier_low", k_hier_low, (unsigned)wgs, 256, (const int2*)ix->ep, ix->n, ix->hier, h.len[1], h.nlev >= 1 ? ix->hier + h.off[1] : nullptr,
-           h.len[2], h.nlev >= 2 ? ix->hier + h.off[2] : nullptr);
-    if (h.nlev >= 3) LAUNCH(ctx, "hier_high", k_hier_high, 1, 256, ix->hier, h);
+    LAUNCH(ctx, "hier_low", k_hier_low, (unsigned)wgs, 256, (const int2*)ix->ep, ix->n, ix->hier, h);
+    if (h.nlev >= 3) LAUNCH(ctx, "hier_high", k_hier_high, 1, 256, ix->hier, h, wgs);
     HIP_TRY(hipGetLastError());
     ix->hier_built = true;
     return IVJ_OK;

@@ -383,10 +383,9 @@ int upload_side(ivj_ctx* ctx, const ivj_side* h, DevSide& d) {
     hipError_t e = hipMalloc((void**)&d.buf, 3 * col);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(side): ") + hipGetErrorString(e));
     int32_t* c = d.buf; int32_t* s = (int32_t*)((char*)d.buf + col); int32_t* en = (int32_t*)((char*)d.buf + 2 * col);
-    // the caller's (Arrow / numpy) buffers are registered in place for the copy: the DMA engine reads them directly
-    // (tools/pcie_probe.py: ~3 ms per GB to register, 57 GB/s); small or unregistrable ranges go through the bounce buffer
+    // through the context's pinned staging slots (HostXfer): chunk i is copied into a slot while chunk i - 1 is on the wire
     const size_t nb = (size_t)h->n * 4;
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.h2d(c, h->contig, nb);
     copy.h2d(s, h->start, nb);
     copy.h2d(en, h->end, nb);

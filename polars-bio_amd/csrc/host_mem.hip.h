@@ -102,97 +102,91 @@ void host_copy_parallel(void* dst, const void* src, size_t bytes) {
     for (auto& x : th) x.join();
 }
 
-// registers a host range for the lifetime of the object (failure is not an error: the copy then goes the pageable way)
-struct HostPin {
-    void* p = nullptr;
-    bool ok = false;
-    hipError_t code = hipSuccess;
-    HostPin(const void* ptr, size_t bytes, size_t min_bytes = (size_t)1 << 20) {
-        if (ptr && bytes >= min_bytes) {
-            p = const_cast<void*>(ptr);
-            code = hipHostRegister(p, bytes, hipHostRegisterDefault);
-            ok = code == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-        }
-    }
-    ~HostPin() { if (ok) (void)hipHostUnregister(p); }
-    HostPin(const HostPin&) = delete;
-    HostPin& operator=(const HostPin&) = delete;
-};
-
-// Every copy between caller / library host memory and HBM goes through this object, never through the runtime's own handling
-// of pageable memory: left to itself the runtime pins a pageable range on the fly and keeps up to eight such pins per queue
-// cached BY ADDRESS -- a later copy whose host range starts where an earlier, since freed one did reuses the stale pin (an H2D
-// source is pinned read-only: "Memory access fault ... Write access to a read-only page" when malloc hands the same address to a
-// result buffer; pages that were unmapped in between: "Reason: Unknown").  Here a range of XFER_PIN_MIN bytes or more is
-// registered for the duration of the copy (hipHostRegister, ~3 ms / GB; a range the caller has registered already is used as it
-// is), anything smaller -- or not registrable -- is staged through the context's own pinned bounce buffer.
-// add copies, then finish(): when it returns every copy is complete and every range unregistered.
-constexpr size_t XFER_PIN_MIN = (size_t)256 << 10;
-constexpr size_t XFER_BOUNCE = (size_t)4 << 20;
+// Every copy between caller / library host memory and HBM goes through this object and the context's own PINNED staging
+// slots -- never through a host pointer the runtime has to pin, and never through hipHostRegister.  Left to itself the runtime pins
+// a pageable range on the fly and keeps such pins cached BY ADDRESS (eight per queue, in one process-wide map); torch does the same
+// for its pageable copies.  A later copy -- or a later hipHostRegister, which then reports "already registered" -- whose range
+// overlaps an address a since-freed buffer used to occupy runs through the stale mapping: "Memory access fault ... Write access to a
+// read-only page" (the stale pin was an H2D source) or "Reason: Unknown" (the pages are gone), both seen in the GPU test suite once
+// torch and this library had shared a process for a few hundred calls.  So: two slots of XFER_SLOT bytes; an H2D chunk is copied
+// into a slot by a few host threads and sent from there, a D2H chunk lands in a slot and is copied out while the next chunk's DMA
+// runs; small copies share a slot.  The DMA moves ~57 GB/s, four copy threads ~95 GB/s (tools/pcie_probe.py): the pipeline stays
+// DMA-bound.  add copies, then finish(): when it returns every copy is complete.
+constexpr size_t XFER_SLOT = (size_t)16 << 20;
 
 struct HostXfer {
     hipStream_t stream;
-    char** bounce;                                         // the context's pinned bounce buffer (allocated on first use)
-    std::vector<HostPin*> pins;
+    XferSlots* slots;
     struct Pend { void* dst; size_t off, bytes; };
-    std::vector<Pend> outs;                                // D2H copies parked in the bounce buffer
+    std::vector<Pend> outs[2];                             // D2H chunks parked in a slot, not yet copied out
+    bool busy[2] = {false, false};                         // the slot has DMA in flight behind its event
+    int cur = 0;
     size_t used = 0;
     hipError_t err = hipSuccess;
-    HostXfer(hipStream_t s, char** bounce_slot) : stream(s), bounce(bounce_slot) {}
+    HostXfer(hipStream_t s, XferSlots* sl) : stream(s), slots(sl) {}
     HostXfer(const HostXfer&) = delete;
     HostXfer& operator=(const HostXfer&) = delete;
     ~HostXfer() { (void)finish(); }
 
-    bool direct(const void* host, size_t bytes) {          // true: the DMA engine may address the range itself
-        if (bytes < XFER_PIN_MIN) return false;
-        HostPin* p = new HostPin(host, bytes, XFER_PIN_MIN);
-        if (p->ok) { pins.push_back(p); return true; }
-        const bool already = p->code == hipErrorHostMemoryAlreadyRegistered;
-        delete p;
-        return already;
+    bool ready() {
+        for (int k = 0; k < 2 && err == hipSuccess; ++k) {
+            if (!slots->buf[k]) err = hipHostMalloc((void**)&slots->buf[k], XFER_SLOT, hipHostMallocDefault);
+            if (err == hipSuccess && !slots->ev[k]) err = hipEventCreateWithFlags(&slots->ev[k], hipEventDisableTiming);
+        }
+        return err == hipSuccess;
     }
-    bool have_bounce() {
-        if (!*bounce && err == hipSuccess) err = hipHostMalloc((void**)bounce, XFER_BOUNCE, hipHostMallocDefault);
-        return *bounce != nullptr;
+    void settle(int k) {                                   // slot k: its DMA is done, its D2H chunks are in the caller's memory
+        if (busy[k]) {
+            const hipError_t e = hipEventSynchronize(slots->ev[k]);
+            if (err == hipSuccess) err = e;
+            busy[k] = false;
+        }
+        if (err == hipSuccess) for (const Pend& o : outs[k]) host_copy_parallel(o.dst, slots->buf[k] + o.off, o.bytes);
+        outs[k].clear();
     }
-    void drain() {                                         // completes what is parked in the bounce buffer
-        const hipError_t s = hipStreamSynchronize(stream);
-        if (err == hipSuccess) err = s;
-        if (err == hipSuccess) for (const Pend& o : outs) std::memcpy(o.dst, *bounce + o.off, o.bytes);
-        outs.clear();
+    void rotate() {                                        // the current slot is full: mark it, take the other one
+        if (err == hipSuccess) err = hipEventRecord(slots->ev[cur], stream);
+        busy[cur] = true;
+        cur ^= 1;
+        settle(cur);
         used = 0;
     }
+    size_t reserve(size_t want, size_t& off) {             // a piece of the current slot (256-byte granules)
+        if (used >= XFER_SLOT) rotate();
+        off = used;
+        const size_t n = want < XFER_SLOT - used ? want : XFER_SLOT - used;
+        used += (n + 255) & ~(size_t)255;
+        return n;
+    }
     void h2d(void* dst_dev, const void* src_host, size_t bytes) {
-        if (err != hipSuccess || bytes == 0) return;
-        if (direct(src_host, bytes)) { err = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream); return; }
-        if (!have_bounce()) return;
+        if (err != hipSuccess || bytes == 0 || !ready()) return;
         for (size_t o = 0; o < bytes && err == hipSuccess;) {
-            if (used == XFER_BOUNCE) drain();
-            const size_t n = std::min(bytes - o, XFER_BOUNCE - used);
-            std::memcpy(*bounce + used, (const char*)src_host + o, n);
-            err = hipMemcpyAsync((char*)dst_dev + o, *bounce + used, n, hipMemcpyHostToDevice, stream);
-            used += (n + 255) & ~(size_t)255; if (used > XFER_BOUNCE) used = XFER_BOUNCE;
+            size_t off;
+            const size_t n = reserve(bytes - o, off);
+            host_copy_parallel(slots->buf[cur] + off, (const char*)src_host + o, n);
+            err = hipMemcpyAsync((char*)dst_dev + o, slots->buf[cur] + off, n, hipMemcpyHostToDevice, stream);
             o += n;
         }
     }
     void d2h(void* dst_host, const void* src_dev, size_t bytes) {
-        if (err != hipSuccess || bytes == 0) return;
-        if (direct(dst_host, bytes)) { err = hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, stream); return; }
-        if (!have_bounce()) return;
+        if (err != hipSuccess || bytes == 0 || !ready()) return;
         for (size_t o = 0; o < bytes && err == hipSuccess;) {
-            if (used == XFER_BOUNCE) drain();
-            const size_t n = std::min(bytes - o, XFER_BOUNCE - used);
-            err = hipMemcpyAsync(*bounce + used, (const char*)src_dev + o, n, hipMemcpyDeviceToHost, stream);
-            outs.push_back(Pend{(char*)dst_host + o, used, n});
-            used += (n + 255) & ~(size_t)255; if (used > XFER_BOUNCE) used = XFER_BOUNCE;
+            size_t off;
+            const size_t n = reserve(bytes - o, off);
+            err = hipMemcpyAsync(slots->buf[cur] + off, (const char*)src_dev + o, n, hipMemcpyDeviceToHost, stream);
+            outs[cur].push_back(Pend{(char*)dst_host + o, off, n});
             o += n;
         }
     }
     hipError_t finish() {
-        if (used || !pins.empty() || !outs.empty()) drain();
-        for (HostPin* p : pins) delete p;
-        pins.clear();
+        if (used || busy[0] || busy[1] || !outs[0].empty() || !outs[1].empty()) {
+            const hipError_t s = hipStreamSynchronize(stream);
+            if (err == hipSuccess) err = s;
+            busy[0] = busy[1] = false;
+            settle(cur ^ 1);                               // the older slot first (row order of a result does not depend on it, cache warmth does)
+            settle(cur);
+            used = 0;
+        }
         return err;
     }
 };

@@ -141,11 +141,12 @@ inline HierShape hier_shape(int64_t n) {
     h.values = (size_t)o + 16;
     return h;
 }
-// Levels 0, 1 and 2 in one pass over ep: one workgroup per 4096 rows (256 threads x 16 rows; level 1 = the thread's maximum,
-// level 2 = the maximum of sixteen neighbouring threads); pads of the last blocks = INT32_MIN.
+// Levels 0 .. 3 in one pass over ep: one workgroup per 4096 rows = ONE level-3 entry (256 threads x 16 rows; level 1 = the
+// thread's maximum, level 2 = the maximum of sixteen neighbouring threads, level 3 = the workgroup's); pads of the last blocks =
+// INT32_MIN.  The levels above (a thousand values at most) are a second, one-workgroup launch.
 constexpr int HIER_WG_ROWS = 4096;
-__global__ __launch_bounds__(256) void k_hier_low(const int2* __restrict__ ep, int64_t n, int32_t* __restrict__ l0, int64_t len1, int32_t* __restrict__ l1,
-                                                  int64_t len2, int32_t* __restrict__ l2) {
+__global__ __launch_bounds__(256) void k_hier_low(const int2* __restrict__ ep, int64_t n, int32_t* __restrict__ v, HierShape h) {
+    __shared__ int32_t s_w[256 / kWave];
     const int64_t row0 = (int64_t)blockIdx.x * HIER_WG_ROWS + (int64_t)threadIdx.x * 16;
     int32_t m = INT32_MIN;
     int32_t e[16];
@@ -156,30 +157,43 @@ __global__ __launch_bounds__(256) void k_hier_low(const int2* __restrict__ ep, i
     }
     const int64_t pad0 = (n + 15) & ~(int64_t)15;
     if (row0 < pad0) {
-        int4* o = reinterpret_cast<int4*>(l0 + row0);
+        int4* o = reinterpret_cast<int4*>(v + row0);
         o[0] = make_int4(e[0], e[1], e[2], e[3]); o[1] = make_int4(e[4], e[5], e[6], e[7]);
         o[2] = make_int4(e[8], e[9], e[10], e[11]); o[3] = make_int4(e[12], e[13], e[14], e[15]);
     }
     const int64_t i1 = row0 >> 4;
-    if (l1 && i1 < ((len1 + 15) & ~(int64_t)15)) l1[i1] = m;
+    if (h.nlev >= 1 && i1 < ((h.len[1] + 15) & ~(int64_t)15)) v[h.off[1] + i1] = m;
     int32_t m2 = m;
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) { const int32_t o = __shfl_xor(m2, d, kWave); m2 = o > m2 ? o : m2; }
     const int64_t i2 = row0 >> 8;
-    if (l2 && (threadIdx.x & 15) == 0 && i2 < ((len2 + 15) & ~(int64_t)15)) l2[i2] = m2;
+    if (h.nlev >= 2 && (threadIdx.x & 15) == 0 && i2 < ((h.len[2] + 15) & ~(int64_t)15)) v[h.off[2] + i2] = m2;
+    if (h.nlev < 3) return;                                                    // uniform
+    int32_t m3 = m2;
+#pragma unroll
+    for (int d = 16; d < kWave; d <<= 1) { const int32_t o = __shfl_xor(m3, d, kWave); m3 = o > m3 ? o : m3; }
+    if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = m3;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; ++w) m3 = s_w[w] > m3 ? s_w[w] : m3;
+        if ((int64_t)blockIdx.x < ((h.len[3] + 15) & ~(int64_t)15)) v[h.off[3] + blockIdx.x] = m3;
+    }
 }
-// Levels 3 and up from level 2: a few thousand values at most, one workgroup, level after level.
-__global__ __launch_bounds__(256) void k_hier_high(int32_t* __restrict__ v, HierShape h) {
-    for (int l = 3; l <= h.nlev; ++l) {
+// Levels 4 and up from level 3 (and the pads of level 3's last block): one workgroup, level after level.
+__global__ __launch_bounds__(256) void k_hier_high(int32_t* __restrict__ v, HierShape h, int64_t low_wgs) {
+    const int64_t pad3 = (h.len[3] + 15) & ~(int64_t)15;
+    for (int64_t i = low_wgs + threadIdx.x; i < pad3; i += blockDim.x) v[h.off[3] + i] = INT32_MIN;
+    __syncthreads();
+    for (int l = 4; l <= h.nlev; ++l) {
         const int32_t* src = v + h.off[l - 1];
         int32_t* dst = v + h.off[l];
         const int64_t n_src = h.len[l - 1], padded = (h.len[l] + 15) & ~(int64_t)15;
         for (int64_t i = threadIdx.x; i < padded; i += blockDim.x) {
-            int32_t m = INT32_MIN;
+            int32_t mx = INT32_MIN;
             for (int t = 0; t < 16; ++t) {
-                if (i * 16 + t < n_src) { const int32_t x = src[i * 16 + t]; m = x > m ? x : m; }
+                if (i * 16 + t < n_src) { const int32_t x = src[i * 16 + t]; mx = x > mx ? x : mx; }
             }
-            dst[i] = m;
+            dst[i] = mx;
         }
         __syncthreads();
     }

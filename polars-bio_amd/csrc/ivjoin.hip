@@ -110,7 +110,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     for (auto& cb : ctx->st_cache) free_stream_bufs(cb);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
-    if (ctx->bounce) (void)hipHostFree(ctx->bounce);
+    ctx->xfer.release();
     for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -391,7 +391,7 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     out->probe_idx = (int32_t*)host_result_alloc((size_t)total * 4);
     out->build_idx = (int32_t*)host_result_alloc((size_t)total * 4);
     if (!out->probe_idx || !out->build_idx) { ivj_pairs_free(out); return fail(IVJ_ENOMEM, "host malloc(pairs)"); }
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.d2h(out->probe_idx, op.p, (size_t)total * 4);
     copy.d2h(out->build_idx, ob.p, (size_t)total * 4);
     const hipError_t ce = copy.finish();
@@ -475,7 +475,7 @@ int ivj_merge(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_t 
     out->end = (int32_t*)host_result_alloc((size_t)cl.n * 4);
     out->n_intervals = (int64_t*)host_result_alloc((size_t)cl.n * 8);
     if (!out->contig || !out->start || !out->end || !out->n_intervals) { ivj_merged_free(out); return fail(IVJ_ENOMEM, "host malloc(merged)"); }
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.d2h(out->contig, cl.m_contig, (size_t)cl.n * 4);
     copy.d2h(out->start, cl.m_start, (size_t)cl.n * 4);
     copy.d2h(out->end, cl.m_end, (size_t)cl.n * 4);
@@ -509,7 +509,7 @@ int ivj_cluster(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_
     int32_t* d_e = (int32_t*)((char*)d_s + align_up(n * 4));
     int64_t ncl = 0;
     IVJ_TRY(ivj_cluster_dev(ctx, h.ix, opts, min_dist, d_c, d_s, d_e, &ncl));
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.d2h(cluster, d_c, n * 8);
     copy.d2h(cluster_start, d_s, n * 4);
     copy.d2h(cluster_end, d_e, n * 4);
@@ -535,7 +535,7 @@ int ivj_coverage(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, con
     hipError_t e = hipMalloc(&out.p, (size_t)probe->n * 8);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(coverage): ") + hipGetErrorString(e));
     IVJ_TRY(coverage_core(ctx, h.ix, &dp.s, opts, (int64_t*)out.p));
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.d2h(coverage, out.p, (size_t)probe->n * 8);
     HIP_TRY(copy.finish());
     return IVJ_OK;
@@ -581,7 +581,7 @@ int ivj_subtract(ivj_ctx* ctx, const ivj_side* left, const ivj_side* right, cons
     out->start = (int32_t*)host_result_alloc((size_t)total * 4);
     out->end = (int32_t*)host_result_alloc((size_t)total * 4);
     if (!out->row || !out->start || !out->end) { ivj_pieces_free(out); return fail(IVJ_ENOMEM, "host malloc(pieces)"); }
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.d2h(out->row, d_row, (size_t)total * 4);
     copy.d2h(out->start, d_start, (size_t)total * 4);
     copy.d2h(out->end, d_end, (size_t)total * 4);
@@ -657,7 +657,7 @@ int ivj_take(ivj_ctx* ctx, const int32_t* idx, int64_t n, int32_t n_cols, const 
     if (e == hipSuccess) e = hipMalloc(&d_dst.p, max_dst);
     if (e == hipSuccess && any_valid) e = hipMalloc(&d_val.p, words * 8);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(take): ") + hipGetErrorString(e));
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.h2d(d_idx.p, idx, (size_t)n * 4);
     for (int c = 0; c < n_cols; ++c) {
         const size_t sb = (size_t)src_rows[c] * (size_t)elem_bytes[c], db = (size_t)n * (size_t)elem_bytes[c];
@@ -711,7 +711,7 @@ int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
     IVJ_TRY(overlap_fill(ctx, h.ix, &dp.s, opts, d.probe_idx, d.build_idx, total));
     IVJ_TRY(ivj_materialize_dev(ctx, &dp.s, &db.s, &d));
     int32_t** hcols[7] = {&out->probe_idx, &out->build_idx, &out->contig, &out->start_1, &out->end_1, &out->start_2, &out->end_2};
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     for (int k = 0; k < 7; ++k) {
         *hcols[k] = (int32_t*)host_result_alloc((size_t)total * 4);
         if (!*hcols[k]) { (void)copy.finish(); ivj_rows_free(out); return fail(IVJ_ENOMEM, "host malloc(rows)"); }
@@ -748,7 +748,7 @@ int ivj_count_overlaps(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* buil
     hipError_t e = hipMalloc(&dc.p, (size_t)probe->n * 8);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(counts): ") + hipGetErrorString(e));
     IVJ_TRY(count_overlaps_dev(ctx, h.ix, &dp.s, opts, (int64_t*)dc.p));
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.d2h(counts, dc.p, (size_t)probe->n * 8);
     HIP_TRY(copy.finish());
     return IVJ_OK;
@@ -778,7 +778,7 @@ int ivj_nearest(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     if (e == hipSuccess) e = hipMalloc(&dn.p, (size_t)probe->n * 4);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc(nearest): ") + hipGetErrorString(e));
     IVJ_TRY(nearest_dev(ctx, h.ix, &dp.s, opts, (int32_t*)di.p, (int64_t*)dd.p, (int32_t*)dn.p));
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.d2h(idx, di.p, slots * 4);
     copy.d2h(dist, dd.p, slots * 8);
     copy.d2h(n_found, dn.p, (size_t)probe->n * 4);
@@ -915,7 +915,7 @@ int ivj_memcpy_h2d(ivj_ctx* ctx, void* dst_dev, const void* src_host, int64_t by
     if (!ctx || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
     if (bytes == 0) return IVJ_OK;
     DeviceGuard g(ctx->device);
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.h2d(dst_dev, src_host, (size_t)bytes);
     HIP_TRY(copy.finish());
     return IVJ_OK;
@@ -924,7 +924,7 @@ int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t by
     if (!ctx || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
     if (bytes == 0) return IVJ_OK;
     DeviceGuard g(ctx->device);
-    HostXfer copy(ctx->stream, &ctx->bounce);
+    HostXfer copy(ctx->stream, &ctx->xfer);
     copy.d2h(dst_host, src_dev, (size_t)bytes);
     HIP_TRY(copy.finish());
     return IVJ_OK;

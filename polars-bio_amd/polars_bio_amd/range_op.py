@@ -88,7 +88,9 @@ def _key_columns_from_device(t1, t2, cols1, cols2) -> bool:
         for name in c[1:]:
             if not pa.types.is_integer(t.schema.field(name).type):
                 return False
-    return hasattr(default_engine(), "overlap_rows")
+    eng = default_engine()
+    # several devices (multi.MultiEngine): the shards' results are merged as index pairs
+    return hasattr(eng, "overlap_rows") and not hasattr(eng, "last_shards")
 
 
 def _materialize_on_device() -> bool:
