@@ -235,8 +235,9 @@ int ivj_take_dev(ivj_ctx* ctx, const void* src_dev, int32_t elem_bytes, const in
  * frame: src/operation.rs:272-301 gathers every column of both sides for every pair).  idx (n int32, host) is uploaded
  * once; every column c -- src[c]: src_rows[c] values of elem_bytes[c] = 4 or 8 bytes, host -- is uploaded, gathered in
  * HBM and downloaded into the caller's dst[c] (n values); validity[c] (may be NULL; ceil(n / 64) words) receives the
- * Arrow validity bitmap of the negative-index slots.  The caller's buffers are registered in place for the copies and
- * dst is first-touched by a few threads (a D2H into untouched pages runs at 7 GB/s).  idx values must be < src_rows[c]. */
+ * Arrow validity bitmap of the negative-index slots.  The copies go through the context's pinned staging slots (never through
+ * hipHostRegister or a pageable hipMemcpy of the caller's pointers); dst is first-touched by a few threads.
+ * idx values must be < src_rows[c]. */
 int ivj_take(ivj_ctx* ctx, const int32_t* idx, int64_t n, int32_t n_cols, const void* const* src, const int64_t* src_rows,
              const int32_t* elem_bytes, void* const* dst, uint64_t* const* validity);
 

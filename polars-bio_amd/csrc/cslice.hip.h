@@ -34,7 +34,7 @@ constexpr int CS_TILE = CS_THREADS * CS_ITEMS;          // probes per tile of th
 constexpr int CS_WTILE = kWave * CS_ITEMS;              // probes of one wavefront per tile (its private slot range)
 constexpr int CS_MAX_CONTIGS = 256;
 constexpr int CS_WIN = 12;                              // rows below hi the branch-free window is guaranteed to cover
-constexpr int CS_LIN = 16;                             // rows below the window a running-on probe checks one by one (LDS) before it takes the block maxima
+constexpr int CS_LIN = 4;                              // rows below the window a running-on probe checks one by one (LDS) before it takes the block maxima
 constexpr int CS_POS_BIAS = 1 << 23;                    // staging entries carry (row - first row of the slice) + bias in 24 bits: rows below the slice too
 static_assert((long long)SL_MAX_BUCKETS * SL_MAX_ROWS <= CS_POS_BIAS, "an index of this path must fit a staging entry's row field");
 constexpr int CS_BIN_STRIDE_PAD = 2;                    // bins per slice in global memory: 2 R + 2 (u16)
@@ -192,7 +192,7 @@ __device__ __forceinline__ uint32_t cs_bucket(const unsigned long long* __restri
 __global__ __launch_bounds__(CS_THREADS) void k_cs_bins(const int32_t* __restrict__ bound, const int32_t* __restrict__ b_start,
                                                        const int2* __restrict__ ep, const int32_t* __restrict__ b_contig,
                                                        const int32_t* __restrict__ seg, int R, unsigned short* __restrict__ bins,
-                                                       int4* __restrict__ smeta) {
+                                                       int4* __restrict__ smeta, int32_t* __restrict__ far_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
     int32_t* l_start = reinterpret_cast<int32_t*>(cs_lds);                     // R
     unsigned short* l_bin = reinterpret_cast<unsigned short*>(l_start + R);    // 2 R + 2
@@ -234,6 +234,16 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_bins(const int32_t* __restric
         smeta[2 * j] = make_int4(l_start[0], bshift, ncell, r0 > seg_a ? ep[r0 - 1].y : INT32_MIN);
         smeta[2 * j + 1] = make_int4(seg_a, cj, rk, r0);
     }
+    // Rows a short probe landing right behind them could NOT settle inside the branch-free window: the prefix max CS_WIN rows back
+    // still reaches past the row's start.  Their share of the build side picks the join kernel (host: cs_far_share).
+    int far = 0;
+    for (int i = tid; i < rk; i += CS_THREADS) {
+        const int p = r0 + i - CS_WIN;
+        if (p >= seg_a && ep[p].y > l_start[i]) ++far;
+    }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) far += __shfl_xor(far, d, kWave);
+    if ((tid & (kWave - 1)) == 0 && far) atomicAdd(far_rows, far);
 }
 
 // ---- partition, pass 1: per-chunk bucket histogram -----------------------------------------------------------------------------
@@ -577,6 +587,391 @@ __host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
     return L;
 }
 
+// ---- the join kernel for build sides WITHOUT a tail of long rows (cs_far_share below CS_FAR_LIMIT: the synthetic configs, exons) ----
+// The same tiles, LDS layout and emission as k_cs_join below, but a probe whose window runs on below the branch-free one is
+// recounted row by row and its wavefront writes from the lanes -- no walk over the block maxima, no staging of rows below the
+// slice.  It is kept as a kernel of its own because the walk, inlined into the hot loops, costs the benign case 4 % of the join
+// (0.91 -> 0.95 ms) and the index 0.03 ms for the maxima; the host picks the kernel per index from ONE statistic of the build
+// side (host_cslice.hip.h::cs_far_share).  Exact on every input; slow (row-by-row) only where k_cs_join is the one chosen.
+template <bool STRICT, int MODE>
+__global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    const CsJoinLds L = cs_join_lds(A.R, A.wcap);
+    int32_t* l_end = reinterpret_cast<int32_t*>(cs_lds + L.end);
+    int32_t* l_pmx = reinterpret_cast<int32_t*>(cs_lds + L.pmx);
+    int32_t* l_start = reinterpret_cast<int32_t*>(cs_lds + L.start);
+    int32_t* l_row = reinterpret_cast<int32_t*>(cs_lds + L.row);
+    unsigned short* l_bin = reinterpret_cast<unsigned short*>(cs_lds + L.bin);
+    int32_t* l_qrow = reinterpret_cast<int32_t*>(cs_lds + L.qrow);
+    uint32_t* l_stage = reinterpret_cast<uint32_t*>(cs_lds + L.stage);
+    unsigned long long* lc = reinterpret_cast<unsigned long long*>(cs_lds + L.ctl);     // [2][2] {cursor, base}
+    int* li = reinterpret_cast<int*>(lc + 4);                                           // [2][4] {arrived, done, ready, seq}
+
+    // XCD-affine order: workgroup b runs on XCD b % 8 (observed); XCD x takes the contiguous eighth of the (bucket, chunk) list
+    const int total_wg = A.meta[0];
+    const int per = (total_wg + 7) / 8;
+    const int wslot = (int)(blockIdx.x >> 3);
+    const int v = (int)(blockIdx.x & 7) * per + wslot;
+    if (wslot >= per || v >= total_wg) return;                                 // uniform
+    const int2 bc = A.wg_map[v];
+    const int k = bc.x;
+    const int64_t q0 = (int64_t)A.bstart[k] + (int64_t)bc.y * A.jchunk;
+    const int64_t qend = (int64_t)A.bstart[k + 1];
+    const int64_t q1 = q0 + A.jchunk < qend ? q0 + A.jchunk : qend;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+
+    const int4 sm0 = A.smeta[2 * k], sm1 = A.smeta[2 * k + 1];
+    const int32_t smin = sm0.x;
+    const int bshift = sm0.y, ncell = sm0.z;
+    const int seg_a = sm1.x, rk = sm1.z, r0 = sm1.w;
+    // slice k = sorted rows [r0, r0 + rk): ends / prefix maxima / starts / build rows / bins -> LDS
+    typedef int v4u __attribute__((ext_vector_type(4), aligned(4)));             // 16-byte global loads at any 4-byte aligned row
+    for (int i = tid * 4; i < rk; i += CS_THREADS * 4) {
+        if (i + 4 <= rk) {
+            const v4u s4 = *reinterpret_cast<const v4u*>(A.b_start + r0 + i);
+            const v4u r4 = *reinterpret_cast<const v4u*>(A.b_row + r0 + i);
+            const v4u e01 = *reinterpret_cast<const v4u*>(reinterpret_cast<const int32_t*>(A.ep + r0 + i));
+            const v4u e23 = *reinterpret_cast<const v4u*>(reinterpret_cast<const int32_t*>(A.ep + r0 + i + 2));
+            *reinterpret_cast<int4*>(l_start + i) = make_int4(s4.x, s4.y, s4.z, s4.w);
+            *reinterpret_cast<int4*>(l_row + i) = make_int4(r4.x, r4.y, r4.z, r4.w);
+            *reinterpret_cast<int4*>(l_end + i) = make_int4(e01.x, e01.z, e23.x, e23.z);
+            l_pmx[i + 1] = e01.y; l_pmx[i + 2] = e01.w; l_pmx[i + 3] = e23.y; l_pmx[i + 4] = e23.w;
+        } else {
+            for (int j = i; j < rk; ++j) {
+                l_start[j] = A.b_start[r0 + j]; l_row[j] = A.b_row[r0 + j];
+                const int2 e = A.ep[r0 + j];
+                l_end[j] = e.x; l_pmx[j + 1] = e.y;
+            }
+        }
+    }
+    if (tid < 4) l_start[rk + tid] = INT32_MAX;
+    if (tid < 16) l_end[rk + tid] = INT32_MIN;
+    if (tid == 0) l_pmx[0] = sm0.w;
+    {
+        const unsigned short* gb = A.bins + (size_t)k * (size_t)(2 * A.R + CS_BIN_STRIDE_PAD);
+        // 2 R + 2 entries per slice: the stride is even, so pairs of bins are 4-byte aligned
+        const uint32_t* gb32 = reinterpret_cast<const uint32_t*>(gb);
+        uint32_t* lb32 = reinterpret_cast<uint32_t*>(l_bin);
+        for (int i = tid; i < (ncell + 2) / 2; i += CS_THREADS) lb32[i] = gb32[i];
+    }
+    if (tid < 4) lc[tid] = 0;
+    if (tid < 8) li[tid] = (tid == 7) ? 1 : 0;                                 // block 1 serves tile 1 first (seq = li[1][3])
+    __syncthreads();
+
+    uint32_t* stw = l_stage + wv * A.wcap;                                     // this wavefront's staging entries
+    int32_t* qrw = l_qrow + wv * CS_WTILE;                                     // this wavefront's probe rows of the tile
+    auto ld = [](const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto stv = [](int* p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+
+    // records of the tile: wavefront wv owns the contiguous probes [wv * 256, (wv + 1) * 256), item j of lane l = wv * 256 + j * 64 + l
+    cs_rec nxt[CS_ITEMS];
+    auto load_tile = [&](int64_t tb) {
+        const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
+        const int32_t* tp = A.rec + 3 * tb;                                    // uniform
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const int il = wv * CS_WTILE + j * kWave + lane;
+            if (il < rem) nxt[j] = __builtin_nontemporal_load(reinterpret_cast<const cs_rec*>(tp + 3 * il));
+            else { nxt[j].x = 0; nxt[j].y = 0; nxt[j].z = -1; }
+        }
+    };
+    // per-probe state of the tile whose matches are known but not yet emitted
+    int32_t qs[CS_ITEMS], qrow[CS_ITEMS];
+    int al[CS_ITEMS], hi[CS_ITEMS];                                            // slice-local: first examined row, hi-bound
+    uint32_t mask[CS_ITEMS];                                                   // bit t <=> row al + t matches
+    int cnt[CS_ITEMS];
+    bool lng[CS_ITEMS];
+    bool any_lng = false;
+
+    auto match_tile = [&](int64_t tb) {
+        int32_t qe[CS_ITEMS];
+        bool valid[CS_ITEMS];
+        const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            qs[j] = nxt[j].x; qe[j] = nxt[j].y; qrow[j] = nxt[j].z;
+            valid[j] = wv * CS_WTILE + j * kWave + lane < rem;
+        }
+        if (tb + CS_TILE < q1) load_tile(tb + CS_TILE);                        // next tile's records in flight
+        // hi-bound: bin of the end, then the (at most four) rows of the bin that start below it.  Rows before the bin's first
+        // row start below the bin's lower edge <= end; rows of later bins start above the end: no range checks needed.
+        int first[CS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            uint32_t cl = ((uint32_t)qe[j] - (uint32_t)smin) >> bshift;
+            cl = cl < (uint32_t)(ncell - 1) ? cl : (uint32_t)(ncell - 1);
+            first[j] = l_bin[cl];
+        }
+        int32_t s4[CS_ITEMS][4];
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const int32_t* sp = l_start + first[j];
+            s4[j][0] = sp[0]; s4[j][1] = sp[1]; s4[j][2] = sp[2]; s4[j][3] = sp[3];
+        }
+        unsigned long long more = 0;
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            unsigned long long m4;
+            hi[j] = cs_count4<STRICT>(first[j], s4[j][0], s4[j][1], s4[j][2], s4[j][3], qe[j], &m4);
+            more |= m4;
+        }
+        if (__builtin_expect(more != 0, 0)) {                                  // uniform: some probe may have more than four rows of its bin below its end
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                if (valid[j] && hi[j] == first[j] + 4) {
+                    uint32_t cl = ((uint32_t)qe[j] - (uint32_t)smin) >> bshift;
+                    cl = cl < (uint32_t)(ncell - 1) ? cl : (uint32_t)(ncell - 1);
+                    int lo = hi[j], hh = l_bin[cl + 1];                        // first row of [hi, rend) that does not start below the end
+                    while (lo < hh) { const int mid = (lo + hh) >> 1; if (lt_op<STRICT>(l_start[mid], qe[j])) lo = mid + 1; else hh = mid; }
+                    hi[j] = lo;
+                }
+            }
+        }
+        // window below hi, branch-free: sixteen ends from the 16-byte aligned row at or below hi - CS_WIN (never below row 0);
+        // bit t <=> row al + t, rows at or above hi are cut off.  One prefix-max read of the row below the examined ones
+        // (l_pmx[0] = the row below the slice, INT32_MIN when the contig starts here) tells whether the window runs on: those
+        // probes are redone exactly.
+        unsigned long long lmask = 0;
+#pragma unroll
+        for (int jj = 0; jj < CS_ITEMS; jj += 2) {
+            int4 w[2][4];
+            int32_t pm[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = jj + u;
+                const int h = hi[j] < rk ? hi[j] : rk;
+                hi[j] = h;
+                int a0 = (h - CS_WIN) & ~3;
+                a0 = a0 > 0 ? a0 : 0;
+                al[j] = a0;
+                const int4* p4 = reinterpret_cast<const int4*>(l_end + a0);
+                w[u][0] = p4[0]; w[u][1] = p4[1]; w[u][2] = p4[2]; w[u][3] = p4[3];
+                pm[u] = l_pmx[a0];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = jj + u;
+                uint32_t m = ends_mask16<STRICT>(qs[j], w[u][0], w[u][1], w[u][2], w[u][3]);
+                m = __builtin_amdgcn_ubfe(m, 0u, (uint32_t)(hi[j] - al[j]));    // rows al .. hi - 1
+                lng[j] = valid[j] && lt_op<STRICT>(qs[j], pm[u]);
+                mask[j] = valid[j] ? m : 0u;
+                cnt[j] = __popc(mask[j]);
+                lmask |= __ballot(lng[j]);
+            }
+        }
+        any_lng = lmask != 0;
+        if (any_lng) {
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                if (lng[j]) {
+                    int c2 = 0;
+                    for (int p = r0 + hi[j] - 1; p >= seg_a; --p) {
+                        const int i = p - r0;
+                        int2 vv = make_int2(l_end[i < 0 ? 0 : i], l_pmx[i < 0 ? 1 : i + 1]);
+                        if (i < 0) vv = A.ep[p];
+                        if (!lt_op<STRICT>(qs[j], vv.y)) break;
+                        c2 += lt_op<STRICT>(qs[j], vv.x) ? 1 : 0;
+                    }
+                    cnt[j] = c2;
+                }
+            }
+        }
+    };
+
+    if constexpr (MODE != CS_FUSED) {
+        // deterministic pair: slot of (workgroup v, tile tix, wavefront wv); every wavefront works on its own
+        load_tile(q0);
+        const int ntile = (int)((q1 - q0 + CS_TILE - 1) / CS_TILE);
+        const int tiles_per_chunk = A.jchunk / CS_TILE;
+        for (int tix = 0; tix < ntile; ++tix) {
+            match_tile(q0 + (int64_t)tix * CS_TILE);
+            const long long slot = ((long long)v * tiles_per_chunk + tix) * CS_WAVES + wv;
+            int lsum = 0;
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) lsum += cnt[j];
+            const int linc = wave_incl_sum_dpp(lsum);
+            const int wtot = __builtin_amdgcn_readlane(linc, kWave - 1);
+            if constexpr (MODE == CS_COUNT) {
+                if (lane == 0) A.wslot[slot] = (long long)wtot;
+                continue;
+            }
+            if (wtot == 0) continue;                                           // uniform
+            const long long wbase = A.wslot[slot];
+            if (wtot <= A.wcap && !any_lng) {
+                int off = linc - lsum;
+#pragma unroll
+                for (int j = 0; j < CS_ITEMS; ++j) {
+                    qrw[j * kWave + lane] = qrow[j];
+                    uint32_t m = mask[j];
+                    const uint32_t ent = ((uint32_t)(j * kWave + lane) << 16) | (uint32_t)al[j];
+                    uint32_t* so = stw + off;
+                    while (m) {
+                        const int t = __builtin_ctz(m);
+                        m &= m - 1;
+                        so[0] = ent + (uint32_t)t;
+                        if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
+                        so += 2;
+                    }
+                    off += cnt[j];
+                }
+                __builtin_amdgcn_wave_barrier();
+                int32_t* op = A.out_probe + wbase;
+                int32_t* ob = A.out_build + wbase;
+#pragma unroll 4
+                for (int i = lane; i < wtot; i += kWave) {
+                    const uint32_t e = stw[i];
+                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                long long off = wbase + (linc - lsum);
+#pragma unroll
+                for (int j = 0; j < CS_ITEMS; ++j) {
+                    if (!lng[j]) {
+                        uint32_t m = mask[j];
+                        long long o = off;
+                        while (m) {
+                            const int t = __builtin_ctz(m);
+                            m &= m - 1;
+                            A.out_probe[o] = qrow[j]; A.out_build[o] = l_row[al[j] + t];
+                            ++o;
+                        }
+                    } else {
+                        long long o = off + cnt[j] - 1;
+                        for (int p = r0 + hi[j] - 1; o >= off; --p) {
+                            const int i = p - r0;
+                            int32_t ev = l_end[i < 0 ? 0 : i];
+                            if (i < 0) ev = A.ep[p].x;
+                            if (lt_op<STRICT>(qs[j], ev)) {
+                                int32_t rv = l_row[i < 0 ? 0 : i];
+                                if (i < 0) rv = A.b_row[p];
+                                A.out_probe[o] = qrow[j]; A.out_build[o] = rv; --o;
+                            }
+                        }
+                    }
+                    off += cnt[j];
+                }
+            }
+        }
+        return;
+    }
+    // Barrier-free tile loop (protocol of slice.hip.h's fused mode): a wavefront's pairs of a tile are contiguous in the
+    // tile's output range at the offset a returning LDS atomic on the tile's cursor gives it; the LAST wavefront to arrive
+    // reserves the range with the one global atomic and publishes the base in LDS; the others look at it one iteration later.
+    load_tile(q0);
+    const int ntile = (int)((q1 - q0 + CS_TILE - 1) / CS_TILE);
+    int pend_wtot = -1;                                                        // this wavefront's staged pairs of the previous tile
+    long long pend_woff = 0;
+    for (int tix = 0; tix <= ntile; ++tix) {
+        if (tix < ntile) match_tile(q0 + (int64_t)tix * CS_TILE);
+        if (tix > 0) {
+            // finish tile tix - 1: its base was requested one iteration ago
+            __builtin_amdgcn_wave_barrier();
+            int* c = li + ((tix - 1) & 1) * 4;
+            unsigned long long* c64 = lc + ((tix - 1) & 1) * 2;
+            for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
+            const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
+                int32_t* op = A.out_probe + tb + pend_woff;
+                int32_t* ob = A.out_build + tb + pend_woff;
+#pragma unroll 4
+                for (int i = lane; i < pend_wtot; i += kWave) {
+                    const uint32_t e = stw[i];
+                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                }
+            }
+            if (lane == 0) {
+                if (atomicAdd(c + 1, 1) == CS_WAVES - 1) {                     // last wavefront out: recycle the block for tile tix + 1
+                    __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    stv(c + 0, 0); stv(c + 1, 0); stv(c + 2, 0);
+                    stv(c + 3, tix + 1);
+                }
+            }
+        }
+        if (tix == ntile) break;
+        int* c = li + (tix & 1) * 4;
+        unsigned long long* c64 = lc + (tix & 1) * 2;
+        for (int spin = 0; ld(c + 3) != tix && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // the block is ours (recycled after tile tix - 2)
+        int lsum = 0;
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) lsum += cnt[j];
+        const int linc = wave_incl_sum_dpp(lsum);
+        const int wtot = __builtin_amdgcn_readlane(linc, kWave - 1);
+        long long woff = 0;
+        if (lane == 0) {
+            woff = (long long)atomicAdd(c64, (unsigned long long)wtot);
+            if (atomicAdd(c + 0, 1) == CS_WAVES - 1) {                         // last wavefront in: the tile's total is complete
+                const long long total = (long long)__hip_atomic_load(c64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                long long base = 0;
+                if (total > 0) {
+                    base = (long long)atomicAdd(&A.state[0], (unsigned long long)total);
+                    if (base + total > A.capacity) { atomicExch(&A.state[1], 1ull); base = -1; }
+                }
+                __hip_atomic_store(c64 + 1, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                stv(c + 2, 1);
+            }
+        }
+        woff = ((long long)__builtin_amdgcn_readfirstlane((int)(woff >> 32)) << 32) | (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(woff & 0xffffffffll));
+        if (wtot > 0 && wtot <= A.wcap && !any_lng) {
+            // usual case: entries {wave-local probe slot << 16 | slice-local row} into the wavefront's staging region
+            int off = linc - lsum;
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                qrw[j * kWave + lane] = qrow[j];
+                uint32_t m = mask[j];
+                uint32_t ent = ((uint32_t)(j * kWave + lane) << 16) | (uint32_t)al[j];
+                uint32_t* so = stw + off;
+                while (m) {                                                    // two matches per trip: half the loop overhead
+                    const int t = __builtin_ctz(m);
+                    m &= m - 1;
+                    so[0] = ent + (uint32_t)t;
+                    if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
+                    so += 2;
+                }
+                off += cnt[j];
+            }
+            pend_wtot = wtot;
+        } else if (wtot > 0) {
+            // dense wavefront or windows running on below the examined rows: wait for the base now, write from the lanes
+            for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
+            const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tb >= 0) {
+                long long off = tb + woff + (linc - lsum);
+#pragma unroll
+                for (int j = 0; j < CS_ITEMS; ++j) {
+                    if (!lng[j]) {
+                        uint32_t m = mask[j];
+                        long long o = off;
+                        while (m) {
+                            const int t = __builtin_ctz(m);
+                            m &= m - 1;
+                            A.out_probe[o] = qrow[j]; A.out_build[o] = l_row[al[j] + t];
+                            ++o;
+                        }
+                    } else {
+                        long long o = off + cnt[j] - 1;                        // the f-th match from the top of the window owns slot end - 1 - f
+                        for (int p = r0 + hi[j] - 1; o >= off; --p) {
+                            const int i = p - r0;
+                            int32_t ev = l_end[i < 0 ? 0 : i];
+                            if (i < 0) ev = A.ep[p].x;
+                            if (lt_op<STRICT>(qs[j], ev)) {
+                                int32_t rv = l_row[i < 0 ? 0 : i];
+                                if (i < 0) rv = A.b_row[p];
+                                A.out_probe[o] = qrow[j]; A.out_build[o] = rv; --o;
+                            }
+                        }
+                    }
+                    off += cnt[j];
+                }
+            }
+            pend_wtot = 0;
+        } else pend_wtot = 0;
+        pend_woff = woff;
+    }
+}
+
 template <bool STRICT, int MODE>
 __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
@@ -831,11 +1226,14 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     // loop reads LDS only (a pointer select between LDS and HBM would make every read a flat load behind the stores' counter)
     auto copy_out = [&](int32_t* op, int32_t* ob, int n_ent, bool below) {
         if (!below) {
+            // (the bias comes off the LDS address once, outside the loop: every entry of this loop is >= the bias)
+            typedef __attribute__((address_space(3))) const int32_t lds_ci32;
+            lds_ci32* rowb = (lds_ci32*)(uintptr_t)((uint32_t)(uintptr_t)(lds_ci32*)l_row - 4u * (uint32_t)CS_POS_BIAS);
 #pragma unroll 4
             for (int i = lane; i < n_ent; i += kWave) {
                 const uint32_t e = stw[i];
                 __builtin_nontemporal_store(qrw[e >> 24], op + i);
-                __builtin_nontemporal_store(l_row[(int)(e & 0xffffffu) - CS_POS_BIAS], ob + i);
+                __builtin_nontemporal_store((int32_t)rowb[e & 0xffffffu], ob + i);
             }
             return;
         }

@@ -106,6 +106,7 @@ struct ivj_ctx {
     int sl_env_rows = 0, sl_env_chunk = 0, sl_env_notab = 0, sl_env_nobins = 0, sl_env_ablate = 0, sl_env_auto = 1, sl_env_stable = 0, sl_env_sthreads = 1024;   // IVJ_SLICE_ROWS / IVJ_SLICE_CHUNK: tuning knobs used when the opts fields are 0
     SlicePlan sl_plan;
     bool cs_attr_set = false;          // contig-aligned slice path (cslice.hip.h): LDS attributes set once
+    int cs_env_walk = -1;           // IVJ_CS_WALK: -1 auto, 0 / 1 force the join kernel of the contig-aligned slices
     int cs_env_off = 0;                // IVJ_CS=0: keep the round-2 slice kernels (A/B runs)
     int cs_env_ptile = 0;              // IVJ_CS_PTILE=4096: partition tiles of 4096 probes even where 8192 fit
     // timing
@@ -160,6 +161,8 @@ struct ivj_index {
     // contig-aligned slice path (cslice.hip.h): geometry fixed at build time, arrays in the slab, filled on first use
     CsGeom cs_g{0, 0, 0, 0, 0};
     bool cs_ok = false, cs_built = false;
+    bool cs_walk = false;                // k_cs_join (windows that run on walk the block maxima) instead of k_cs_join_plain
+    int64_t cs_far = 0;                  // rows whose window would overflow the branch-free one (k_cs_bins)
     int32_t* cs_bound = nullptr;
     unsigned long long* cs_spl = nullptr;
     int4* cs_cm = nullptr;

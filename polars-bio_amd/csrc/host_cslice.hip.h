@@ -52,6 +52,8 @@ bool cs_wanted(const ivj_ctx* ctx, const ivj_index* ix, const ivj_opts* opts) {
     return true;
 }
 
+constexpr double CS_FAR_LIMIT = 5e-4;
+
 int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->cs_built) return IVJ_OK;
     const CsGeom& g = ix->cs_g;
@@ -59,10 +61,23 @@ int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix) {
     const size_t lds = (size_t)4 * g.R + (size_t)2 * (2 * g.R + 8);
     t_begin(ctx, "cs_bins");
     hipLaunchKernelGGL(k_cs_bins, dim3(g.nb), dim3(CS_THREADS), lds, ctx->stream, (const int32_t*)ix->cs_bound, (const int32_t*)ix->b_start, (const int2*)ix->ep,
-                       (const int32_t*)ix->b_contig, (const int32_t*)ix->seg, g.R, ix->cs_bins, ix->cs_smeta);
+                       (const int32_t*)ix->b_contig, (const int32_t*)ix->seg, g.R, ix->cs_bins, ix->cs_smeta, ix->flags + 1);
     t_end(ctx);
     HIP_TRY(hipGetLastError());
-    IVJ_TRY(ensure_hier(ctx, ix));
+    // Which join kernel serves this index: the share of the build rows whose prefix max, CS_WIN rows back, still reaches past
+    // their start (k_cs_bins counts them) = the share of positions where a short probe's window would NOT settle inside the
+    // branch-free one.  Above CS_FAR_LIMIT (a tail of long rows: genes among exons, a contig-wide row) windows that run on are the
+    // rule and k_cs_join walks them over the block maxima; below it (the synthetic configs: 2e-4) they are the rare exception
+    // and k_cs_join_plain recounts them row by row -- without the walk in its hot loops and without the maxima being built.
+    // One 4-byte copy + stream synchronisation per index.  IVJ_CS_WALK = 0 / 1 forces the choice (tests, A/B runs).
+    {
+        HIP_TRY(hipMemcpyAsync(ctx->h_total + 5, ix->flags + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ix->cs_far = *reinterpret_cast<const int32_t*>(ctx->h_total + 5);
+        const double share = ix->n > 0 ? (double)ix->cs_far / (double)ix->n : 0.0;
+        ix->cs_walk = ctx->cs_env_walk >= 0 ? ctx->cs_env_walk != 0 : share > CS_FAR_LIMIT;
+    }
+    if (ix->cs_walk) IVJ_TRY(ensure_hier(ctx, ix));
     ix->cs_built = true;
     return IVJ_OK;
 }
@@ -113,6 +128,9 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_FUSED>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_FUSED>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_COUNT>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_COUNT>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_FILL>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_FILL>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_join_plain<true, CS_FUSED>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join_plain<false, CS_FUSED>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_join_plain<true, CS_COUNT>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join_plain<false, CS_COUNT>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_join_plain<true, CS_FILL>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join_plain<false, CS_FILL>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_scatter_stable<true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter_stable<false>, 160 * 1024));
         ctx->cs_attr_set = true;
     }
@@ -159,8 +177,14 @@ int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     A.out_probe = out_p; A.out_build = out_b;
     const unsigned grid = 8u * (unsigned)((P.gmax + 7) / 8);
     t_begin(ctx, MODE == CS_FUSED ? "cs_join_fused" : (MODE == CS_COUNT ? "cs_join_count" : "cs_join_fill"));
-    if (opts->filter_op == IVJ_FILTER_STRICT) hipLaunchKernelGGL((k_cs_join<true, MODE>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
-    else hipLaunchKernelGGL((k_cs_join<false, MODE>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    if (ix->cs_walk) {                                     // a tail of long build rows: windows that run on walk the block maxima
+        if (strict) hipLaunchKernelGGL((k_cs_join<true, MODE>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
+        else hipLaunchKernelGGL((k_cs_join<false, MODE>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
+    } else {
+        if (strict) hipLaunchKernelGGL((k_cs_join_plain<true, MODE>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
+        else hipLaunchKernelGGL((k_cs_join_plain<false, MODE>), dim3(grid), dim3(CS_THREADS), P.join_lds, ctx->stream, A);
+    }
     t_end(ctx);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;

@@ -1051,3 +1051,29 @@ def test_flat_kernel_hands_long_sparse_windows_to_the_window_kernels(eng):
         hp, hb = _fused_overlap(eng, probe, build, True, nc, pm, len(ep), capacity=max(len(ep), 16 * len(pc) + 1))
         p, b = _canon(hp, hb)
         assert (p == ep).all() and (b == eb).all(), pm
+
+
+@pytest.mark.parametrize("walk", ["0", "1"])
+def test_both_slice_join_kernels_on_both_kinds_of_build_side(walk, monkeypatch):
+    """The slice path has two join kernels and picks one per index from the build side's share of far-reaching rows
+    (host_cslice.hip.h::cs_ensure_tables): k_cs_join_plain (windows that run on are recounted row by row) and k_cs_join (they
+    walk the block maxima of the ends).  IVJ_CS_WALK forces either kernel onto either kind of input: both are exact on both."""
+    monkeypatch.setenv("IVJ_CS_WALK", walk)
+    e = _engine.Engine(0)
+    try:
+        rng = np.random.default_rng(80)
+        probe = synth.make_side(300_000, 42, synth.PROBE_LEN, 24)
+        benign = synth.make_side(60_000, 43, synth.BUILD_LEN, 24)
+        tail = _long_tail_build(rng, 60_000, 24, 40_000_000, 0.01, 6)
+        for build in (benign, tail):
+            for strict in (True, False):
+                ep, eb = O.overlap_fast(O.Index(O.Side(*build), 24), O.Side(*probe), strict)
+                for sr in (64, 0):
+                    hp, hb = _fused_overlap(e, probe, build, strict, 24, 6, len(ep), slice_rows=sr)
+                    p, b = _canon(hp, hb)
+                    assert (p == ep).all() and (b == eb).all(), ("fused", strict, sr)
+                p1, b1 = e.overlap(probe, build, strict, 24, partition_mode=6)
+                o = np.argsort(p1, kind="stable")
+                assert len(p1) == len(ep) and (p1[o] == ep).all() and (b1[o] == eb).all(), ("two-pass", strict)
+    finally:
+        e.close()
