@@ -128,20 +128,22 @@ def encode_build(t2: pa.Table, cols2):
     for c in cols2:
         if c not in t2.column_names:
             raise ValueError(f"column '{c}' not found in {t2.column_names}")
-    ch = A._as_string(t2.column(cols2[0]))
-    u = pc.drop_null(pc.unique(ch))
-    u = u.combine_chunks() if isinstance(u, pa.ChunkedArray) else u
-    ids = _ids(ch, u)
+    u, ids = A._encode_chrom(t2.column(cols2[0]))
     side = (ids, A._coord_to_i32(t2.column(cols2[1]), cols2[1]), A._coord_to_i32(t2.column(cols2[2]), cols2[2]))
     return side, len(u), u
 
 
 def _ids(ch, u) -> np.ndarray:
+    """chrom column -> ids in the dictionary ``u`` (-1: null, or a value that is not in it).  The column is dictionary-encoded once
+    by the native host pass (one threaded hash pass for strings, none for dictionary-typed input: _arrow._encode_chrom) and its
+    few distinct values are looked up in ``u``; the rows then go through a remap table."""
     if len(ch) == 0:
         return np.empty(0, np.int32)
-    idx = pc.fill_null(pc.index_in(ch, value_set=u), -1)
-    idx = idx.combine_chunks() if isinstance(idx, pa.ChunkedArray) else idx
-    return idx.to_numpy(zero_copy_only=False).astype(np.int32, copy=False)
+    d, local = A._encode_chrom(ch if isinstance(ch, pa.ChunkedArray) else pa.chunked_array([ch]))
+    table = pc.fill_null(pc.index_in(d, value_set=u), -1).to_numpy(zero_copy_only=False).astype(np.int32)
+    out = np.empty(len(local), np.int32)
+    A.H.remap_i32(local, table, out)
+    return out
 
 
 def encode_probe_batch(rb: pa.RecordBatch, cols1, dictionary):
@@ -149,7 +151,7 @@ def encode_probe_batch(rb: pa.RecordBatch, cols1, dictionary):
         if c not in rb.schema.names:
             raise ValueError(f"column '{c}' not found in {rb.schema.names}")
     t = pa.Table.from_batches([rb])
-    ids = _ids(A._as_string(t.column(cols1[0])), dictionary)
+    ids = _ids(t.column(cols1[0]), dictionary)
     return ids, A._coord_to_i32(t.column(cols1[1]), cols1[1]), A._coord_to_i32(t.column(cols1[2]), cols1[2])
 
 
