@@ -407,6 +407,12 @@ int ivj_host_narrow_i32(const void* src, int32_t src_bytes, int32_t is_unsigned,
 int ivj_host_encode_utf8(const void* offsets, int32_t offset_bytes, const uint8_t* data, const uint8_t* validity, int64_t validity_bit0, int64_t n,
                          int32_t* ids, int64_t* dict_rows, int32_t dict_cap, int32_t* n_values, int32_t threads);
 
+/* Column of 64-bit keys -> ids[n] in first-occurrence order and dict_rows[*n_values] (one row that holds each key).  The front
+ * door runs it over the object POINTERS of a pandas object-dtype column: rows that share a string object (the CSV parser interns
+ * them per column) get one dictionary entry without the string being looked at, and only the few distinct objects are converted.
+ * IVJ_ECAPACITY: more than dict_cap (or 4096) distinct keys -- the caller falls back to the ordinary conversion. */
+int ivj_host_encode_keys64(const uint64_t* keys, int64_t n, int32_t* ids, int64_t* dict_rows, int32_t dict_cap, int32_t* n_values, int32_t threads);
+
 /* Dictionary indices (idx_bytes = 1, 2, 4, 8, signed; negative = null) -> out[i] = remap[idx[i]] (-1 for a null), and seen[v] = 1
  * for every dictionary entry some row refers to (seen: remap_len bytes, OR-ed into). */
 int ivj_host_remap_i32(const void* idx, int32_t idx_bytes, int64_t n, const int32_t* remap, int64_t remap_len, int32_t* out, uint8_t* seen,

@@ -7,6 +7,7 @@
 // over the rows on plain std::thread workers: no device work, no context.
 //   ivj_host_narrow_i32   coordinate column (8 / 4 / 2 / 1-byte integers) -> int32 + its min / max   (the reference's int32 limit)
 //   ivj_host_encode_utf8  Arrow string column (offsets + bytes) -> dictionary ids in first-occurrence order + one row per value
+//   ivj_host_encode_keys64 column of 64-bit keys (the object pointers of a pandas object column) -> ids + one row per distinct key
 //   ivj_host_remap_i32    dictionary indices -> ids of the shared dictionary through a small table, + which entries occur
 //   ivj_host_take         fixed-width gather dst[i] = src[idx[i]] (the non-key columns of the joined rows)
 //   ivj_host_widen_i32    int32 -> int64 (key columns materialised on the device back to the frame's dtype)
@@ -153,6 +154,33 @@ int fd_encode(const Off* off, const unsigned char* data, const uint8_t* validity
     return rc;
 }
 
+// dictionary over 64-bit keys (PyObject pointers of an object column): open addressing per worker, merged in worker order
+struct FdKeyDict {
+    std::vector<int32_t> slot;
+    std::vector<unsigned long long> keys;
+    std::vector<int64_t> rows;
+    bool overflow = false;
+    unsigned long long last = 0;
+    int32_t last_id = -1;
+    FdKeyDict() : slot(FD_SLOTS, -1) {}
+    inline int32_t id_of(unsigned long long k, int64_t row) {
+        if (last_id >= 0 && k == last) return last_id;
+        unsigned long long h = k * 0x9e3779b97f4a7c15ull;
+        h ^= h >> 29;
+        for (unsigned s = (unsigned)h & (FD_SLOTS - 1);; s = (s + 1) & (FD_SLOTS - 1)) {
+            const int32_t v = slot[s];
+            if (v < 0) {
+                if ((int)keys.size() >= FD_MAX_VALUES) { overflow = true; return 0; }
+                slot[s] = (int32_t)keys.size();
+                keys.push_back(k); rows.push_back(row);
+                last = k; last_id = slot[s];
+                return last_id;
+            }
+            if (keys[v] == k) { last = k; last_id = v; return v; }
+        }
+    }
+};
+
 template <class I>
 void fd_remap_range(const I* idx, int64_t lo, int64_t hi, const int32_t* remap, int64_t remap_len, int32_t* out, uint8_t* seen, bool& bad) {
     for (int64_t i = lo; i < hi; ++i) {
@@ -218,6 +246,40 @@ int ivj_host_encode_utf8(const void* offsets, int32_t offset_bytes, const uint8_
                                      : fd_encode((const int64_t*)offsets, d, validity, validity_bit0, n, ids, dict_rows, dict_cap, n_values, threads);
     if (rc == IVJ_ECAPACITY) return fail(IVJ_ECAPACITY, "encode: more distinct values than the native encoder holds");
     return rc;
+}
+
+int ivj_host_encode_keys64(const uint64_t* keys, int64_t n, int32_t* ids, int64_t* dict_rows, int32_t dict_cap, int32_t* n_values, int32_t threads) {
+    if (n < 0 || !n_values || (n > 0 && (!keys || !ids || !dict_rows))) return fail(IVJ_EINVAL, "encode keys: bad argument");
+    *n_values = 0;
+    if (n == 0) return IVJ_OK;
+    const int t = fd_threads(n, threads, 1 << 16);
+    std::vector<FdKeyDict> enc(t);
+    fd_parallel(n, t, [&](int k, int64_t lo, int64_t hi) {
+        FdKeyDict& e = enc[k];
+        for (int64_t i = lo; i < hi && !e.overflow; ++i) ids[i] = e.id_of((unsigned long long)keys[i], i);
+    });
+    bool overflow = false;
+    for (int k = 0; k < t; ++k) overflow |= enc[k].overflow;
+    FdKeyDict glob;
+    std::vector<std::vector<int32_t>> remap(t);
+    for (int k = 0; k < t && !overflow; ++k) {
+        remap[k].resize(enc[k].keys.size());
+        for (size_t v = 0; v < enc[k].keys.size() && !overflow; ++v) {
+            remap[k][v] = glob.id_of(enc[k].keys[v], enc[k].rows[v]);
+            overflow |= glob.overflow;
+        }
+    }
+    if (overflow || (int64_t)glob.keys.size() > (int64_t)dict_cap) return fail(IVJ_ECAPACITY, "encode keys: more distinct values than the native encoder holds");
+    bool identity = true;
+    for (int k = 0; k < t; ++k) for (size_t v = 0; v < remap[k].size(); ++v) identity &= remap[k][v] == (int32_t)v;
+    if (!identity)
+        fd_parallel(n, t, [&](int k, int64_t lo, int64_t hi) {
+            const int32_t* r = remap[k].data();
+            for (int64_t i = lo; i < hi; ++i) ids[i] = r[ids[i]];
+        });
+    for (size_t v = 0; v < glob.keys.size(); ++v) dict_rows[v] = glob.rows[v];
+    *n_values = (int32_t)glob.keys.size();
+    return IVJ_OK;
 }
 
 int ivj_host_remap_i32(const void* idx, int32_t idx_bytes, int64_t n, const int32_t* remap, int64_t remap_len, int32_t* out, uint8_t* seen,

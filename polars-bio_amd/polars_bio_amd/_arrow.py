@@ -68,7 +68,7 @@ def to_arrow(df) -> pa.Table:
     if isinstance(df, pa.RecordBatch):
         return pa.Table.from_batches([df])
     if pd is not None and isinstance(df, pd.DataFrame):
-        return pa.Table.from_pandas(df, preserve_index=False)
+        return _from_pandas(df)
     if pl is not None and isinstance(df, pl.LazyFrame):
         return df.collect().to_arrow()
     if pl is not None and isinstance(df, pl.DataFrame):
@@ -88,6 +88,76 @@ def to_arrow(df) -> pa.Table:
     if hasattr(df, "__arrow_c_stream__"):
         return pa.table(df)
     raise TypeError(f"unsupported input type {type(df)!r}")
+
+
+# A pandas object-dtype column of strings whose rows share their string objects (read_csv interns them per column; so does
+# anything built by indexing an array of names) is dictionary-encoded by object IDENTITY: one native pass over the pointers, only the
+# few distinct objects are converted.  Such columns travel as dictionary<int32, large_string> -- a type pandas' own conversion never
+# produces (categoricals arrive as dictionary<int8.., string>) -- and from_arrow turns that type back into an object column by
+# indexing the distinct Python strings: neither direction builds one string per row.
+_OBJECT_DICT = pa.dictionary(pa.int32(), pa.large_string())
+_OBJECT_MIN_ROWS = 1 << 16
+
+
+def _object_column(series) -> "pa.Array | None":
+    values = series.to_numpy()
+    if values.dtype != object or len(values) < _OBJECT_MIN_ROWS:
+        return None
+    values = np.ascontiguousarray(values)
+    ids = np.empty(len(values), np.int32)
+    rows = H.encode_object_pointers(values, ids)
+    if rows is None:
+        return None
+    try:
+        distinct = pa.array(values[rows], from_pandas=True)
+    except (pa.ArrowInvalid, pa.ArrowTypeError):
+        return None
+    if not (pa.types.is_string(distinct.type) or pa.types.is_large_string(distinct.type)):
+        return None                                            # numbers, mixed objects, all nulls: the ordinary conversion decides
+    return pa.DictionaryArray.from_arrays(pa.array(ids, type=pa.int32()), distinct.cast(pa.large_string()))
+
+
+def _from_pandas(df) -> pa.Table:
+    obj = {}
+    for name in df.columns:
+        col = df[name]
+        if getattr(col, "dtype", None) == object and isinstance(name, str):
+            arr = _object_column(col)
+            if arr is not None:
+                obj[name] = arr
+    if not obj:
+        return pa.Table.from_pandas(df, preserve_index=False)
+    rest = [n for n in df.columns if n not in obj]
+    base = pa.Table.from_pandas(df[rest], preserve_index=False) if rest else None
+    cols = [obj[n] if n in obj else base.column(n) for n in df.columns]
+    return pa.Table.from_arrays(cols, names=[str(n) for n in df.columns])
+
+
+def _to_pandas(t: pa.Table):
+    marked = [i for i, f in enumerate(t.schema) if f.type == _OBJECT_DICT]
+    if not marked:
+        return t.to_pandas()
+    rest = t.drop_columns([t.schema.field(i).name for i in marked]) if len(marked) < t.num_columns else None
+    out = rest.to_pandas() if rest is not None else pd.DataFrame(index=pd.RangeIndex(t.num_rows))
+    data = {}
+    for i in marked:
+        col = t.column(i).combine_chunks()
+        col = col.chunk(0) if isinstance(col, pa.ChunkedArray) and col.num_chunks == 1 else col
+        if isinstance(col, pa.ChunkedArray):                   # zero rows
+            data[t.schema.field(i).name] = np.empty(0, object)
+            continue
+        objs = np.empty(len(col.dictionary) + 1, object)
+        objs[:len(col.dictionary)] = col.dictionary.to_pylist()
+        objs[len(col.dictionary)] = None
+        idx = col.indices.to_numpy(zero_copy_only=False)
+        if col.indices.null_count:
+            idx = np.where(pc.is_null(col.indices).to_numpy(zero_copy_only=False), len(col.dictionary), np.nan_to_num(idx, nan=0)).astype(np.int64)
+        data[t.schema.field(i).name] = objs[idx]
+    # the reference's column order: rebuild the frame column by column (no copy of the numeric blocks)
+    frame = {}
+    for f in t.schema:
+        frame[f.name] = data[f.name] if f.name in data else out[f.name]
+    return pd.DataFrame(frame, copy=False)
 
 
 def _coord_to_i32(col: pa.ChunkedArray, name: str) -> np.ndarray:
@@ -388,7 +458,7 @@ def from_arrow(t: pa.Table, output_type: str, zero_based: bool):
     if output_type == "pandas.DataFrame":
         if pd is None:
             raise ImportError("pandas is not installed. Install pandas or use `polars-bio[pandas]`.")
-        return set_coordinate_system(t.to_pandas(), zero_based)
+        return set_coordinate_system(_to_pandas(t), zero_based)
     if output_type in ("polars.DataFrame", "polars.LazyFrame"):
         if pl is None:
             # the reference's default output kind needs polars; without it the Arrow table itself is handed back

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
     "ivj_comm_unique_id", "ivj_comm_create", "ivj_comm_create_local", "ivj_comm_destroy", "ivj_comm_info",
     "ivj_allgather_counts", "ivj_allgatherv_dev", "ivj_overlap_allgather_dev",
-    "ivj_host_narrow_i32", "ivj_host_encode_utf8", "ivj_host_remap_i32", "ivj_host_take", "ivj_host_widen_i32",
+    "ivj_host_narrow_i32", "ivj_host_encode_utf8", "ivj_host_encode_keys64", "ivj_host_remap_i32", "ivj_host_take", "ivj_host_widen_i32",
 ]
 
 STREAM_OVERLAP, STREAM_COUNT, STREAM_NEAREST = 0, 1, 2
@@ -182,6 +182,7 @@ def load_library() -> C.CDLL:
         L.ivj_overlap_allgather_dev.argtypes = [vp, vp, P, O, C.c_int, vp, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.ivj_host_narrow_i32.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
         L.ivj_host_encode_utf8.argtypes = [vp, C.c_int32, vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
+        L.ivj_host_encode_keys64.argtypes = [vp, C.c_int64, vp, vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
         L.ivj_host_remap_i32.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32]
         L.ivj_host_take.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, vp, C.c_int32]
         L.ivj_host_widen_i32.argtypes = [vp, C.c_int64, vp, C.c_int32]

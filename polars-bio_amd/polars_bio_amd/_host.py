@@ -48,6 +48,20 @@ def encode_utf8(offsets: np.ndarray, data: Optional[np.ndarray], validity: Optio
     return rows[:nv.value].copy()
 
 
+def encode_object_pointers(col: np.ndarray, out: np.ndarray):
+    """Object-dtype numpy column -> ids (written to ``out``) by object IDENTITY; returns the rows holding the distinct objects in
+    first-occurrence order, or None when there are more of them than the native encoder keeps."""
+    L = load_library()
+    assert col.dtype == object and col.flags.c_contiguous
+    rows = np.empty(MAX_DICT, np.int64)
+    nv = C.c_int32(0)
+    rc = L.ivj_host_encode_keys64(C.c_void_p(col.ctypes.data), len(col), _ptr(out), _ptr(rows), MAX_DICT, C.byref(nv), THREADS)
+    if rc == -4:
+        return None
+    _check(L, rc, "ivj_host_encode_keys64")
+    return rows[:nv.value].copy()
+
+
 def remap_i32(idx: np.ndarray, table: np.ndarray, out: np.ndarray, seen: Optional[np.ndarray] = None) -> None:
     """out[i] = table[idx[i]] (-1 for a negative index); seen[v] |= 1 for every table slot used."""
     L = load_library()

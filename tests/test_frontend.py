@@ -517,3 +517,45 @@ def test_overlap_with_categorical_and_large_parallel_inputs(engine):
     assert (df1["chrom"].astype(str).to_numpy()[res["x_1"]] == res["chrom_1"].astype(str).to_numpy()).all()
     cnt = pb.count_overlaps(df1, df2, output_type="pandas.DataFrame")
     assert int(cnt["count"].sum()) == len(res)
+
+
+def test_pandas_object_columns_by_object_identity_equal_the_ordinary_conversion(engine, monkeypatch):
+    """pandas object-dtype string columns whose rows share their string objects enter as dictionary<int32, large_string> built
+    from the object POINTERS (_arrow._from_pandas) and leave as object columns indexed out of the distinct strings
+    (_arrow._to_pandas): same frames, same dtypes as the ordinary per-row conversion -- nulls (None and NaN), a second object
+    column with too many distinct values (falls back), a categorical column (stays categorical) and the golden tables included."""
+    from polars_bio_amd import _arrow as A
+    rng = np.random.default_rng(9)
+    n1, n2 = 3000, 500
+    names = np.array(["chr1", "chr2", "chrX", "chrUn_KI270302v1"], dtype=object)
+    c1 = names[rng.integers(0, 4, n1)]
+    c1[::97] = None
+    c1[5] = np.nan
+    df1 = pd.DataFrame({"chrom": c1, "start": rng.integers(0, 50_000, n1)})
+    df1["end"] = df1["start"] + rng.integers(1, 400, n1)
+    df1["label"] = np.array([f"r{i}" for i in range(n1)], dtype=object)            # every row its own string object
+    df1["kind"] = pd.Categorical(rng.choice(["a", "b"], n1))
+    df2 = pd.DataFrame({"chrom": names[rng.integers(0, 3, n2)], "start": rng.integers(0, 50_000, n2)})
+    df2["end"] = df2["start"] + rng.integers(1, 3000, n2)
+    df2["strand"] = np.array(["+", "-"], dtype=object)[rng.integers(0, 2, n2)]
+    for d in (df1, df2):
+        d.attrs["coordinate_system_zero_based"] = True
+
+    def run():
+        return (pb.overlap(df1, df2, output_type="pandas.DataFrame"), pb.nearest(df1, df2, output_type="pandas.DataFrame"),
+                pb.count_overlaps(df1, df2, output_type="pandas.DataFrame"),
+                pb.overlap(_csv(f"{GOLDEN}/overlap/reads.csv"), _csv(f"{GOLDEN}/overlap/targets.csv"), cols1=COLS, cols2=COLS, output_type="pandas.DataFrame"))
+    monkeypatch.setattr(A, "_OBJECT_MIN_ROWS", 1 << 40)
+    plain = run()
+    monkeypatch.setattr(A, "_OBJECT_MIN_ROWS", 1)
+    t1 = A.to_arrow(df1)
+    assert t1.schema.field("chrom").type == A._OBJECT_DICT and t1.schema.field("label").type != A._OBJECT_DICT or A.H.MAX_DICT >= n1
+    fast = run()
+    for a, b in zip(fast, plain):
+        assert list(a.columns) == list(b.columns) and [str(x) for x in a.dtypes] == [str(x) for x in b.dtypes]
+        key = list(a.columns)
+        sa = a.astype(str).sort_values(key).reset_index(drop=True)
+        sb = b.astype(str).sort_values(key).reset_index(drop=True)
+        pd.testing.assert_frame_equal(sa, sb)
+    assert fast[0]["chrom_1"].dtype == object and isinstance(fast[0]["chrom_1"].iloc[0], str)
+    pd.testing.assert_frame_equal(_sorted(fast[3]), _sorted(pd.read_csv(f"{GOLDEN}/expected_overlap.csv")))
