@@ -206,7 +206,7 @@ void fd_take_range(const T* src, int64_t n_src, const int32_t* idx, int64_t lo, 
 
 extern "C" {
 
-int ivj_host_narrow_i32(const void* src, int32_t src_bytes, int32_t is_unsigned, int64_t n, int32_t* dst, int64_t* out_min, int64_t* out_max,
+static int ivj_host_narrow_i32_impl(const void* src, int32_t src_bytes, int32_t is_unsigned, int64_t n, int32_t* dst, int64_t* out_min, int64_t* out_max,
                         int32_t threads) {
     if (n < 0 || (n > 0 && (!src || !dst)) || !out_min || !out_max) return fail(IVJ_EINVAL, "narrow: bad argument");
     if (src_bytes != 1 && src_bytes != 2 && src_bytes != 4 && src_bytes != 8) return fail(IVJ_EINVAL, "narrow: src_bytes must be 1, 2, 4 or 8");
@@ -234,7 +234,7 @@ int ivj_host_narrow_i32(const void* src, int32_t src_bytes, int32_t is_unsigned,
     return IVJ_OK;
 }
 
-int ivj_host_encode_utf8(const void* offsets, int32_t offset_bytes, const uint8_t* data, const uint8_t* validity, int64_t validity_bit0, int64_t n,
+static int ivj_host_encode_utf8_impl(const void* offsets, int32_t offset_bytes, const uint8_t* data, const uint8_t* validity, int64_t validity_bit0, int64_t n,
                          int32_t* ids, int64_t* dict_rows, int32_t dict_cap, int32_t* n_values, int32_t threads) {
     if (n < 0 || !n_values || (n > 0 && (!offsets || !ids || !dict_rows))) return fail(IVJ_EINVAL, "encode: bad argument");
     if (offset_bytes != 4 && offset_bytes != 8) return fail(IVJ_EINVAL, "encode: offset_bytes must be 4 or 8");
@@ -248,7 +248,7 @@ int ivj_host_encode_utf8(const void* offsets, int32_t offset_bytes, const uint8_
     return rc;
 }
 
-int ivj_host_encode_keys64(const uint64_t* keys, int64_t n, int32_t* ids, int64_t* dict_rows, int32_t dict_cap, int32_t* n_values, int32_t threads) {
+static int ivj_host_encode_keys64_impl(const uint64_t* keys, int64_t n, int32_t* ids, int64_t* dict_rows, int32_t dict_cap, int32_t* n_values, int32_t threads) {
     if (n < 0 || !n_values || (n > 0 && (!keys || !ids || !dict_rows))) return fail(IVJ_EINVAL, "encode keys: bad argument");
     *n_values = 0;
     if (n == 0) return IVJ_OK;
@@ -282,7 +282,7 @@ int ivj_host_encode_keys64(const uint64_t* keys, int64_t n, int32_t* ids, int64_
     return IVJ_OK;
 }
 
-int ivj_host_remap_i32(const void* idx, int32_t idx_bytes, int64_t n, const int32_t* remap, int64_t remap_len, int32_t* out, uint8_t* seen,
+static int ivj_host_remap_i32_impl(const void* idx, int32_t idx_bytes, int64_t n, const int32_t* remap, int64_t remap_len, int32_t* out, uint8_t* seen,
                        int32_t threads) {
     if (n < 0 || remap_len < 0 || (n > 0 && (!idx || !out)) || (remap_len > 0 && (!remap || !seen))) return fail(IVJ_EINVAL, "remap: bad argument");
     if (idx_bytes != 1 && idx_bytes != 2 && idx_bytes != 4 && idx_bytes != 8) return fail(IVJ_EINVAL, "remap: idx_bytes must be 1, 2, 4 or 8");
@@ -307,7 +307,7 @@ int ivj_host_remap_i32(const void* idx, int32_t idx_bytes, int64_t n, const int3
     return IVJ_OK;
 }
 
-int ivj_host_take(const void* src, int32_t elem_bytes, int64_t n_src, const int32_t* idx, int64_t n, void* dst, int32_t threads) {
+static int ivj_host_take_impl(const void* src, int32_t elem_bytes, int64_t n_src, const int32_t* idx, int64_t n, void* dst, int32_t threads) {
     if (n < 0 || n_src < 0 || (n > 0 && (!idx || !dst)) || (n_src > 0 && !src)) return fail(IVJ_EINVAL, "host take: bad argument");
     if (elem_bytes != 4 && elem_bytes != 8) return fail(IVJ_EINVAL, "host take: elem_bytes must be 4 or 8");
     if (n == 0) return IVJ_OK;
@@ -319,12 +319,42 @@ int ivj_host_take(const void* src, int32_t elem_bytes, int64_t n_src, const int3
     return IVJ_OK;
 }
 
-int ivj_host_widen_i32(const int32_t* src, int64_t n, int64_t* dst, int32_t threads) {
+static int ivj_host_widen_i32_impl(const int32_t* src, int64_t n, int64_t* dst, int32_t threads) {
     if (n < 0 || (n > 0 && (!src || !dst))) return fail(IVJ_EINVAL, "widen: bad argument");
     if (n == 0) return IVJ_OK;
     const int t = fd_threads(n, threads, 1 << 17);
     fd_parallel(n, t, [&](int, int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) dst[i] = (int64_t)src[i]; });
     return IVJ_OK;
 }
+
+
+// no C++ exception may cross the C ABI (std::thread / std::vector can throw under resource exhaustion)
+#define IVJ_HOST_GUARD(call)                                                                        \
+    try { return call; }                                                                            \
+    catch (const std::bad_alloc&) { return fail(IVJ_ENOMEM, "host helper: out of memory"); }        \
+    catch (const std::exception& e) { return fail(IVJ_EINVAL, std::string("host helper: ") + e.what()); }
+
+int ivj_host_narrow_i32(const void* src, int32_t src_bytes, int32_t is_unsigned, int64_t n, int32_t* dst, int64_t* out_min, int64_t* out_max,
+                        int32_t threads) {
+    IVJ_HOST_GUARD(ivj_host_narrow_i32_impl(src, src_bytes, is_unsigned, n, dst, out_min, out_max, threads))
+}
+int ivj_host_encode_utf8(const void* offsets, int32_t offset_bytes, const uint8_t* data, const uint8_t* validity, int64_t validity_bit0, int64_t n,
+                         int32_t* ids, int64_t* dict_rows, int32_t dict_cap, int32_t* n_values, int32_t threads) {
+    IVJ_HOST_GUARD(ivj_host_encode_utf8_impl(offsets, offset_bytes, data, validity, validity_bit0, n, ids, dict_rows, dict_cap, n_values, threads))
+}
+int ivj_host_encode_keys64(const uint64_t* keys, int64_t n, int32_t* ids, int64_t* dict_rows, int32_t dict_cap, int32_t* n_values, int32_t threads) {
+    IVJ_HOST_GUARD(ivj_host_encode_keys64_impl(keys, n, ids, dict_rows, dict_cap, n_values, threads))
+}
+int ivj_host_remap_i32(const void* idx, int32_t idx_bytes, int64_t n, const int32_t* remap, int64_t remap_len, int32_t* out, uint8_t* seen,
+                       int32_t threads) {
+    IVJ_HOST_GUARD(ivj_host_remap_i32_impl(idx, idx_bytes, n, remap, remap_len, out, seen, threads))
+}
+int ivj_host_take(const void* src, int32_t elem_bytes, int64_t n_src, const int32_t* idx, int64_t n, void* dst, int32_t threads) {
+    IVJ_HOST_GUARD(ivj_host_take_impl(src, elem_bytes, n_src, idx, n, dst, threads))
+}
+int ivj_host_widen_i32(const int32_t* src, int64_t n, int64_t* dst, int32_t threads) {
+    IVJ_HOST_GUARD(ivj_host_widen_i32_impl(src, n, dst, threads))
+}
+#undef IVJ_HOST_GUARD
 
 }  // extern "C"
