@@ -38,7 +38,7 @@ void release_rows_array(ArrowArray* a) {
 }
 }  // namespace
 
-int ivj_side_from_arrow(const void* array, const void* schema, ivj_side* out) {
+int ivj_side_from_arrow(const void* array, const void* schema, ivj_side* out) try {
     if (!array || !schema || !out) return fail(IVJ_EINVAL, "import: NULL argument");
     const auto* arr = static_cast<const ArrowArray*>(array);
     const auto* sch = static_cast<const ArrowSchema*>(schema);
@@ -67,9 +67,9 @@ int ivj_side_from_arrow(const void* array, const void* schema, ivj_side* out) {
     out->n = arr->length;
     out->row_id = nullptr;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_rows_export_arrow(ivj_rows* rows, void* out_array, void* out_schema) {
+int ivj_rows_export_arrow(ivj_rows* rows, void* out_array, void* out_schema) try {
     if (!rows || !out_array || !out_schema) return fail(IVJ_EINVAL, "export: NULL argument");
     auto* arr = static_cast<ArrowArray*>(out_array);
     auto* sch = static_cast<ArrowSchema*>(out_schema);
@@ -95,4 +95,4 @@ int ivj_rows_export_arrow(ivj_rows* rows, void* out_array, void* out_schema) {
     *sch = ArrowSchema{"+s", "", nullptr, 0, kRowCols, sh->ptrs, nullptr, release_rows_schema, sh};
     *arr = ArrowArray{n, 0, 0, 1, kRowCols, ah->pbuf, ah->ptrs, nullptr, release_rows_array, ah};
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH

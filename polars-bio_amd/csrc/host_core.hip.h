@@ -15,6 +15,13 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
             return fail(IVJ_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
     } while (0)
 
+// Every int-returning entry point of the C ABI is a function-try-block ending in this: no C++ exception (std::bad_alloc of a
+// std::vector / std::string, std::system_error of a std::thread) may cross the boundary into a C, Rust or ctypes caller.
+#define IVJ_ABI_CATCH                                                                                     \
+    catch (const std::bad_alloc&) { return fail(IVJ_ENOMEM, "host allocation failed (std::bad_alloc)"); }   \
+    catch (const std::exception& e) { return fail(IVJ_ESTATE, std::string("internal error: ") + e.what()); } \
+    catch (...) { return fail(IVJ_ESTATE, "internal error: unknown exception"); }
+
 #define IVJ_TRY(expr)                 \
     do {                              \
         int _r = (expr);              \

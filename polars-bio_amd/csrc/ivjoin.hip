@@ -46,16 +46,16 @@ const char* ivj_last_error(void) { return g_err.c_str(); }
 const char* ivj_version(void) { return "ivjoin-hip 0.1 (gfx950)"; }
 int64_t ivj_host_mem_available(void) { return (int64_t)host_mem_available(); }
 
-int ivj_device_count(int* n) {
+int ivj_device_count(int* n) try {
     if (!n) return fail(IVJ_EINVAL, "n is NULL");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
     if (e != hipSuccess) { *n = 0; return fail(IVJ_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
     *n = c;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_ctx_create(int device, ivj_ctx** out) {
+int ivj_ctx_create(int device, ivj_ctx** out) try {
     if (!out) return fail(IVJ_EINVAL, "out is NULL");
     int cnt = 0;
     IVJ_TRY(ivj_device_count(&cnt));
@@ -85,7 +85,7 @@ int ivj_ctx_create(int device, ivj_ctx** out) {
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(IVJ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
     *out = ctx;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 namespace {
 void stream_release(ivj_stream* st, bool keep_cache);
@@ -117,39 +117,39 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     delete ctx;
 }
 
-int ivj_ctx_set_stream(ivj_ctx* ctx, void* hip_stream) {
+int ivj_ctx_set_stream(ivj_ctx* ctx, void* hip_stream) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = (hip_stream == (void*)-1) ? ctx->own_stream : (hipStream_t)hip_stream;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_ctx_sync(ivj_ctx* ctx) {
+int ivj_ctx_sync(ivj_ctx* ctx) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 namespace ivj { __global__ void k_profile_mark() {} }
 
-int ivj_ctx_profile_mark(ivj_ctx* ctx) {
+int ivj_ctx_profile_mark(ivj_ctx* ctx) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     DeviceGuard g(ctx->device);
     hipLaunchKernelGGL(ivj::k_profile_mark, dim3(1), dim3(1), 0, ctx->stream);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_ctx_enable_timing(ivj_ctx* ctx, int on) {
+int ivj_ctx_enable_timing(ivj_ctx* ctx, int on) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
     ctx->recs.clear();
     ctx->pool_used = 0;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_ctx_get_timings(ivj_ctx* ctx, ivj_timing* out, int cap, int* n) {
+int ivj_ctx_get_timings(ivj_ctx* ctx, ivj_timing* out, int cap, int* n) try {
     if (!ctx || !n) return fail(IVJ_EINVAL, "ctx or n is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<ivj_timing> agg;
@@ -170,17 +170,17 @@ int ivj_ctx_get_timings(ivj_ctx* ctx, ivj_timing* out, int cap, int* n) {
     ctx->recs.clear();
     ctx->pool_used = 0;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 // ---------------------------------------------------------------- device-resident API
 
-int ivj_index_build_dev(ivj_ctx* ctx, const ivj_side* build_dev, const ivj_opts* opts, int with_end_order, ivj_index** out) {
+int ivj_index_build_dev(ivj_ctx* ctx, const ivj_side* build_dev, const ivj_opts* opts, int with_end_order, ivj_index** out) try {
     if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(build_dev, "build"));
     DeviceGuard g(ctx->device);
     return index_build(ctx, build_dev, opts, with_end_order, out);
-}
+} IVJ_ABI_CATCH
 
 void ivj_index_free(ivj_index* ix) {
     if (!ix) return;
@@ -204,36 +204,36 @@ void ivj_index_free(ivj_index* ix) {
     delete ix;
 }
 
-int ivj_overlap_count_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* n_pairs) {
+int ivj_overlap_count_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* n_pairs) try {
     if (!ctx || !ix || !n_pairs) return fail(IVJ_EINVAL, "ctx, index or n_pairs is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
     DeviceGuard g(ctx->device);
     return overlap_count(ctx, ix, probe_dev, opts, n_pairs);
-}
+} IVJ_ABI_CATCH
 
 int ivj_overlap_fill_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts,
-                         int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity) {
+                         int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity) try {
     if (!ctx || !ix) return fail(IVJ_EINVAL, "ctx or index is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
     DeviceGuard g(ctx->device);
     return overlap_fill(ctx, ix, probe_dev, opts, probe_idx_dev, build_idx_dev, capacity);
-}
+} IVJ_ABI_CATCH
 
 int ivj_overlap_fused_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts,
-                          int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_pairs) {
+                          int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_pairs) try {
     if (!ctx || !ix || !n_pairs) return fail(IVJ_EINVAL, "ctx, index or n_pairs is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
     if (capacity < 0 || (capacity > 0 && (!probe_idx_dev || !build_idx_dev))) return fail(IVJ_EINVAL, "bad output buffers");
     DeviceGuard g(ctx->device);
     return overlap_fused(ctx, ix, probe_dev, opts, probe_idx_dev, build_idx_dev, capacity, n_pairs);
-}
+} IVJ_ABI_CATCH
 
 // ---- multi-GPU: communicator, all-gatherv, sharded overlap with the exchange overlapping the join (host_comm.hip.h) ----
 
-int ivj_comm_unique_id(void* id_out) {
+int ivj_comm_unique_id(void* id_out) try {
     if (!id_out) return fail(IVJ_EINVAL, "id_out is NULL");
     const RcclApi* api = rccl_api();
     if (!api) return fail(IVJ_EHIP, g_rccl.error);
@@ -241,9 +241,9 @@ int ivj_comm_unique_id(void* id_out) {
     RCCL_TRY(api, api->GetUniqueId(&id));
     std::memcpy(id_out, &id, sizeof(id));
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_comm_create(ivj_ctx* ctx, const void* unique_id, int rank, int world, ivj_comm** out) {
+int ivj_comm_create(ivj_ctx* ctx, const void* unique_id, int rank, int world, ivj_comm** out) try {
     if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
     if (world < 1 || rank < 0 || rank >= world) return fail(IVJ_EINVAL, "rank / world out of range");
     if (world > 1 && !unique_id) return fail(IVJ_EINVAL, "unique_id is NULL");
@@ -262,9 +262,9 @@ int ivj_comm_create(ivj_ctx* ctx, const void* unique_id, int rank, int world, iv
     if (rc != IVJ_OK) { ivj_comm_destroy(c); return rc; }
     *out = c;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_comm_create_local(ivj_ctx* const* ctxs, int n, ivj_comm** out) {
+int ivj_comm_create_local(ivj_ctx* const* ctxs, int n, ivj_comm** out) try {
     if (!ctxs || !out || n < 1) return fail(IVJ_EINVAL, "ctxs / out is NULL or n < 1");
     std::vector<RcclComm> comms((size_t)n, nullptr);
     if (n > 1) {
@@ -286,7 +286,7 @@ int ivj_comm_create_local(ivj_ctx* const* ctxs, int n, ivj_comm** out) {
         out[i] = c;
     }
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 void ivj_comm_destroy(ivj_comm* c) {
     if (!c) return;
@@ -301,30 +301,30 @@ void ivj_comm_destroy(ivj_comm* c) {
     delete c;
 }
 
-int ivj_comm_info(const ivj_comm* c, int* rank, int* world) {
+int ivj_comm_info(const ivj_comm* c, int* rank, int* world) try {
     if (!c) return fail(IVJ_EINVAL, "comm is NULL");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_allgather_counts(ivj_comm* c, int64_t n_local, int64_t* counts) {
+int ivj_allgather_counts(ivj_comm* c, int64_t n_local, int64_t* counts) try {
     if (!c || !counts || n_local < 0) return fail(IVJ_EINVAL, "comm / counts is NULL or n_local < 0");
     DeviceGuard g(c->ctx->device);
     return comm_allgather_counts(c, n_local, counts);
-}
+} IVJ_ABI_CATCH
 
-int ivj_allgatherv_dev(ivj_comm* c, const void* const* send_cols, void* const* recv_cols, int n_cols, int elem_bytes, const int64_t* counts) {
+int ivj_allgatherv_dev(ivj_comm* c, const void* const* send_cols, void* const* recv_cols, int n_cols, int elem_bytes, const int64_t* counts) try {
     if (!c || !send_cols || !recv_cols || !counts || n_cols < 1 || elem_bytes < 1) return fail(IVJ_EINVAL, "bad all-gatherv arguments");
     DeviceGuard g(c->ctx->device);
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));                   // the payload is whatever the context's stream produced
     IVJ_TRY(comm_exchange(c, send_cols, recv_cols, n_cols, elem_bytes, counts, 0));
     HIP_TRY(hipStreamSynchronize(c->xstream));
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 int ivj_overlap_allgather_dev(ivj_comm* c, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int n_chunks,
-                              int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_total, int64_t* n_local) {
+                              int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_total, int64_t* n_local) try {
     if (!c || !ix || !n_total) return fail(IVJ_EINVAL, "comm, index or n_total is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
@@ -332,10 +332,10 @@ int ivj_overlap_allgather_dev(ivj_comm* c, ivj_index* ix, const ivj_side* probe_
     if (capacity < 0 || (capacity > 0 && (!probe_idx_dev || !build_idx_dev))) return fail(IVJ_EINVAL, "bad output buffers");
     DeviceGuard g(c->ctx->device);
     return overlap_allgather(c, ix, probe_dev, opts, n_chunks, probe_idx_dev, build_idx_dev, capacity, n_total, n_local);
-}
+} IVJ_ABI_CATCH
 
 int ivj_overlap_fused_rows_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, const ivj_rows* rows_dev,
-                               int64_t* n_pairs) {
+                               int64_t* n_pairs) try {
     if (!ctx || !ix || !rows_dev || !n_pairs) return fail(IVJ_EINVAL, "ctx, index, rows or n_pairs is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
@@ -343,19 +343,19 @@ int ivj_overlap_fused_rows_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* prob
     if (opts->partition_mode == 5) return fail(IVJ_EINVAL, "partition_mode 5 is not available for the rows path");
     DeviceGuard g(ctx->device);
     return overlap_fused_rows(ctx, ix, probe_dev, opts, rows_dev, n_pairs);
-}
+} IVJ_ABI_CATCH
 
-int ivj_count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* counts_dev) {
+int ivj_count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* counts_dev) try {
     if (!ctx || !ix) return fail(IVJ_EINVAL, "ctx or index is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
     if (probe_dev->n > 0 && !counts_dev) return fail(IVJ_EINVAL, "counts is NULL");
     DeviceGuard g(ctx->device);
     return count_overlaps_dev(ctx, ix, probe_dev, opts, counts_dev);
-}
+} IVJ_ABI_CATCH
 
 int ivj_nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int32_t* idx_dev,
-                    int64_t* dist_dev, int32_t* n_found_dev) {
+                    int64_t* dist_dev, int32_t* n_found_dev) try {
     if (!ctx || !ix) return fail(IVJ_EINVAL, "ctx or index is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
@@ -363,11 +363,11 @@ int ivj_nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, cons
     if (opts->nearest_k > 1024) return fail(IVJ_EINVAL, "nearest_k > 1024");
     DeviceGuard g(ctx->device);
     return nearest_dev(ctx, ix, probe_dev, opts, idx_dev, dist_dev, n_found_dev);
-}
+} IVJ_ABI_CATCH
 
 // ---------------------------------------------------------------- host-buffer API
 
-int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, ivj_pairs* out) {
+int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, ivj_pairs* out) try {
     if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
     out->n_pairs = 0; out->probe_idx = nullptr; out->build_idx = nullptr;
     IVJ_TRY(check_opts(opts));
@@ -399,12 +399,12 @@ int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     if (ce != hipSuccess) { ivj_pairs_free(out); return fail(IVJ_EHIP, std::string("D2H(pairs): ") + hipGetErrorString(ce)); }
     out->n_pairs = total;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 // ---------------------------------------------------------------- merge / cluster / coverage
 
 int ivj_cluster_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min_dist, int64_t* cluster_dev, int32_t* cluster_start_dev,
-                    int32_t* cluster_end_dev, int64_t* n_clusters) {
+                    int32_t* cluster_end_dev, int64_t* n_clusters) try {
     if (!ctx || !ix || !n_clusters) return fail(IVJ_EINVAL, "ctx, index or n_clusters is NULL");
     IVJ_TRY(check_opts(opts));
     if (min_dist < 0) return fail(IVJ_EINVAL, "min_dist < 0");
@@ -418,10 +418,10 @@ int ivj_cluster_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t m
            (const int32_t*)cl.m_end, ix->n, (long long*)cluster_dev, cluster_start_dev, cluster_end_dev);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 int ivj_merge_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min_dist, int64_t capacity, int32_t* contig_dev, int32_t* start_dev,
-                  int32_t* end_dev, int64_t* n_intervals_dev, int64_t* n_merged) {
+                  int32_t* end_dev, int64_t* n_intervals_dev, int64_t* n_merged) try {
     if (!ctx || !ix || !n_merged) return fail(IVJ_EINVAL, "ctx, index or n_merged is NULL");
     IVJ_TRY(check_opts(opts));
     if (min_dist < 0 || capacity < 0) return fail(IVJ_EINVAL, "min_dist or capacity < 0");
@@ -438,16 +438,16 @@ int ivj_merge_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int64_t min
     LAUNCH(ctx, "cluster_counts", k_cluster_counts, grid1d(cl.n, 256), 256, (const int32_t*)cl.m_first, cl.n, (long long*)n_intervals_dev);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_coverage_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* coverage_dev) {
+int ivj_coverage_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t* coverage_dev) try {
     if (!ctx || !ix) return fail(IVJ_EINVAL, "ctx or index is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
     if (probe_dev->n > 0 && !coverage_dev) return fail(IVJ_EINVAL, "coverage is NULL");
     DeviceGuard g(ctx->device);
     return coverage_core(ctx, ix, probe_dev, opts, coverage_dev);
-}
+} IVJ_ABI_CATCH
 
 void ivj_merged_free(ivj_merged* m) {
     if (!m) return;
@@ -455,7 +455,7 @@ void ivj_merged_free(ivj_merged* m) {
     m->contig = m->start = m->end = nullptr; m->n_intervals = nullptr; m->n = 0;
 }
 
-int ivj_merge(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_t min_dist, ivj_merged* out) {
+int ivj_merge(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_t min_dist, ivj_merged* out) try {
     if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
     std::memset(out, 0, sizeof(*out));
     IVJ_TRY(check_opts(opts));
@@ -485,10 +485,10 @@ int ivj_merge(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_t 
     if (e != hipSuccess) { ivj_merged_free(out); return fail(IVJ_EHIP, std::string("D2H(merged): ") + hipGetErrorString(e)); }
     out->n = cl.n;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 int ivj_cluster(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_t min_dist, int64_t* cluster, int32_t* cluster_start,
-                int32_t* cluster_end, int64_t* n_clusters) {
+                int32_t* cluster_end, int64_t* n_clusters) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(side, "frame"));
@@ -517,9 +517,9 @@ int ivj_cluster(ivj_ctx* ctx, const ivj_side* side, const ivj_opts* opts, int64_
     HIP_TRY(copy.finish());
     if (n_clusters) *n_clusters = ncl;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_coverage(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int64_t* coverage) {
+int ivj_coverage(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int64_t* coverage) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe, "probe"));
@@ -540,19 +540,19 @@ int ivj_coverage(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, con
     copy.d2h(coverage, out.p, (size_t)probe->n * 8);
     HIP_TRY(copy.finish());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 // ---------------------------------------------------------------- subtract / complement
 
 int ivj_subtract_dev(ivj_ctx* ctx, ivj_index* right_ix, const ivj_side* left_dev, const ivj_opts* opts, int64_t capacity, int32_t* row_dev,
-                     int32_t* start_dev, int32_t* end_dev, int64_t* n_pieces) {
+                     int32_t* start_dev, int32_t* end_dev, int64_t* n_pieces) try {
     if (!ctx || !right_ix || !n_pieces) return fail(IVJ_EINVAL, "ctx, index or n_pieces is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(left_dev, "left"));
     if (capacity < 0) return fail(IVJ_EINVAL, "capacity < 0");
     DeviceGuard g(ctx->device);
     return subtract_core(ctx, right_ix, left_dev, opts, capacity, &row_dev, &start_dev, &end_dev, nullptr, n_pieces);
-}
+} IVJ_ABI_CATCH
 
 void ivj_pieces_free(ivj_pieces* p) {
     if (!p) return;
@@ -560,7 +560,7 @@ void ivj_pieces_free(ivj_pieces* p) {
     p->row = p->start = p->end = nullptr; p->n = 0;
 }
 
-int ivj_subtract(ivj_ctx* ctx, const ivj_side* left, const ivj_side* right, const ivj_opts* opts, ivj_pieces* out) {
+int ivj_subtract(ivj_ctx* ctx, const ivj_side* left, const ivj_side* right, const ivj_opts* opts, ivj_pieces* out) try {
     if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
     std::memset(out, 0, sizeof(*out));
     IVJ_TRY(check_opts(opts));
@@ -590,15 +590,15 @@ int ivj_subtract(ivj_ctx* ctx, const ivj_side* left, const ivj_side* right, cons
     if (e != hipSuccess) { ivj_pieces_free(out); return fail(IVJ_EHIP, std::string("D2H(pieces): ") + hipGetErrorString(e)); }
     out->n = total;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_complement(ivj_ctx* ctx, const ivj_side* frame, const ivj_side* view, const ivj_opts* opts, ivj_pieces* out) {
+int ivj_complement(ivj_ctx* ctx, const ivj_side* frame, const ivj_side* view, const ivj_opts* opts, ivj_pieces* out) try {
     return ivj_subtract(ctx, view, frame, opts, out);      // the gaps of `frame` inside every view interval
-}
+} IVJ_ABI_CATCH
 
 // ---------------------------------------------------------------- row materialisation
 
-int ivj_materialize_dev(ivj_ctx* ctx, const ivj_side* probe_dev, const ivj_side* build_dev, const ivj_rows* rows) {
+int ivj_materialize_dev(ivj_ctx* ctx, const ivj_side* probe_dev, const ivj_side* build_dev, const ivj_rows* rows) try {
     if (!ctx || !rows) return fail(IVJ_EINVAL, "ctx or rows is NULL");
     IVJ_TRY(check_side(probe_dev, "probe"));
     IVJ_TRY(check_side(build_dev, "build"));
@@ -615,10 +615,10 @@ int ivj_materialize_dev(ivj_ctx* ctx, const ivj_side* probe_dev, const ivj_side*
            rows->start_1, rows->end_1, rows->start_2, rows->end_2);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 int ivj_take_dev(ivj_ctx* ctx, const void* src_dev, int32_t elem_bytes, const int32_t* idx_dev, int64_t n, void* dst_dev,
-                 uint64_t* validity_dev) {
+                 uint64_t* validity_dev) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     if (elem_bytes != 4 && elem_bytes != 8) return fail(IVJ_EINVAL, "elem_bytes must be 4 or 8");
     if (n < 0) return fail(IVJ_EINVAL, "n < 0");
@@ -633,10 +633,10 @@ int ivj_take_dev(ivj_ctx* ctx, const void* src_dev, int32_t elem_bytes, const in
                (unsigned long long*)dst_dev, (unsigned long long*)validity_dev);
     HIP_TRY(hipGetLastError());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 int ivj_take(ivj_ctx* ctx, const int32_t* idx, int64_t n, int32_t n_cols, const void* const* src, const int64_t* src_rows,
-             const int32_t* elem_bytes, void* const* dst, uint64_t* const* validity) {
+             const int32_t* elem_bytes, void* const* dst, uint64_t* const* validity) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     if (n < 0 || n_cols < 0) return fail(IVJ_EINVAL, "take: negative size");
     if (n == 0 || n_cols == 0) return IVJ_OK;
@@ -674,7 +674,7 @@ int ivj_take(ivj_ctx* ctx, const int32_t* idx, int64_t n, int32_t n_cols, const 
     }
     HIP_TRY(copy.finish());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 void ivj_rows_free(ivj_rows* r) {
     if (!r) return;
@@ -683,7 +683,7 @@ void ivj_rows_free(ivj_rows* r) {
     r->n_pairs = 0;
 }
 
-int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, ivj_rows* out) {
+int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, ivj_rows* out) try {
     if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
     std::memset(out, 0, sizeof(*out));
     IVJ_TRY(check_opts(opts));
@@ -722,7 +722,7 @@ int ivj_overlap_rows(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
     if (se != hipSuccess) { ivj_rows_free(out); return fail(IVJ_EHIP, std::string("D2H(rows): ") + hipGetErrorString(se)); }
     out->n_pairs = total;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 #include "arrow_cdata.hip.h"
 
@@ -732,7 +732,7 @@ void ivj_pairs_free(ivj_pairs* p) {
     p->probe_idx = nullptr; p->build_idx = nullptr; p->n_pairs = 0;
 }
 
-int ivj_count_overlaps(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int64_t* counts) {
+int ivj_count_overlaps(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int64_t* counts) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe, "probe"));
@@ -753,10 +753,10 @@ int ivj_count_overlaps(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* buil
     copy.d2h(counts, dc.p, (size_t)probe->n * 8);
     HIP_TRY(copy.finish());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 int ivj_nearest(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, const ivj_opts* opts, int32_t* idx, int64_t* dist,
-                int32_t* n_found) {
+                int32_t* n_found) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe, "probe"));
@@ -785,11 +785,11 @@ int ivj_nearest(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build, cons
     copy.d2h(n_found, dn.p, (size_t)probe->n * 4);
     HIP_TRY(copy.finish());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 // ---------------------------------------------------------------- streaming probe session
 
-int ivj_stream_open(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int op, int64_t max_batch_rows, ivj_stream** out) {
+int ivj_stream_open(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int op, int64_t max_batch_rows, ivj_stream** out) try {
     if (!ctx || !out) return fail(IVJ_EINVAL, "ctx or out is NULL");
     *out = nullptr;
     IVJ_TRY(check_opts(opts));
@@ -834,22 +834,22 @@ int ivj_stream_open(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, i
     if (e != hipSuccess) return bail(fail(IVJ_ENOMEM, std::string("stream slots: ") + hipGetErrorString(e)));
     *out = st;
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
-int ivj_stream_submit(ivj_stream* st, const ivj_side* batch, ivj_stream_result* done) {
+int ivj_stream_submit(ivj_stream* st, const ivj_side* batch, ivj_stream_result* done) try {
     if (!st || !done) return fail(IVJ_EINVAL, "stream or done is NULL");
     IVJ_TRY(check_side(batch, "batch"));
     if (batch->n > st->max_rows) return fail(IVJ_EINVAL, "batch has more rows than max_batch_rows");
     if (batch->row_id) return fail(IVJ_EINVAL, "stream batches report rows inside the batch: row_id must be NULL");
     if (!st->ctx) return fail(IVJ_ESTATE, "the context of this streaming session was destroyed");
     return stream_turn(st, batch, done);
-}
+} IVJ_ABI_CATCH
 
-int ivj_stream_flush(ivj_stream* st, ivj_stream_result* done) {
+int ivj_stream_flush(ivj_stream* st, ivj_stream_result* done) try {
     if (!st || !done) return fail(IVJ_EINVAL, "stream or done is NULL");
     if (!st->ctx) return fail(IVJ_ESTATE, "the context of this streaming session was destroyed");
     return stream_turn(st, nullptr, done);
-}
+} IVJ_ABI_CATCH
 
 namespace {
 // device / pinned resources of a streaming session; the staging goes back to the context's cache when it is still there
@@ -895,7 +895,7 @@ void ivj_stream_close(ivj_stream* st) {
 
 // ---------------------------------------------------------------- memory helpers
 
-int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out) {
+int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out) try {
     if (!ctx || !out || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
     DeviceGuard g(ctx->device);
     *out = nullptr;
@@ -903,16 +903,16 @@ int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out) {
     hipError_t e = hipMalloc(out, (size_t)bytes);
     if (e != hipSuccess) return fail(IVJ_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
     return IVJ_OK;
-}
-int ivj_dev_free(ivj_ctx* ctx, void* p) {
+} IVJ_ABI_CATCH
+int ivj_dev_free(ivj_ctx* ctx, void* p) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     if (!p) return IVJ_OK;
     DeviceGuard g(ctx->device);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(p));
     return IVJ_OK;
-}
-int ivj_memcpy_h2d(ivj_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes) {
+} IVJ_ABI_CATCH
+int ivj_memcpy_h2d(ivj_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes) try {
     if (!ctx || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
     if (bytes == 0) return IVJ_OK;
     DeviceGuard g(ctx->device);
@@ -920,8 +920,8 @@ int ivj_memcpy_h2d(ivj_ctx* ctx, void* dst_dev, const void* src_host, int64_t by
     copy.h2d(dst_dev, src_host, (size_t)bytes);
     HIP_TRY(copy.finish());
     return IVJ_OK;
-}
-int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes) {
+} IVJ_ABI_CATCH
+int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes) try {
     if (!ctx || bytes < 0) return fail(IVJ_EINVAL, "bad argument");
     if (bytes == 0) return IVJ_OK;
     DeviceGuard g(ctx->device);
@@ -929,7 +929,7 @@ int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t by
     copy.d2h(dst_host, src_dev, (size_t)bytes);
     HIP_TRY(copy.finish());
     return IVJ_OK;
-}
+} IVJ_ABI_CATCH
 
 }  // extern "C"
 
