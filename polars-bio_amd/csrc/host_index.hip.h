@@ -27,7 +27,6 @@ int ensure_hier(ivj_ctx* ctx, ivj_index* ix) {
 
 int need_tables(ivj_ctx* ctx, ivj_index* ix) {
     if (!ix->has_tables) return fail(IVJ_ESTATE, "this index was built for merge / cluster only (with_end_order & 2): it has no lookup tables");
-    IVJ_TRY(ensure_hier(ctx, ix));
     if (ix->tables_built) return IVJ_OK;
     return build_tables(ctx, ix);
 }

@@ -107,6 +107,7 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         return IVJ_OK;
     }
     IVJ_TRY(need_tables(ctx, ix));
+    IVJ_TRY(ensure_hier(ctx, ix));                     // windows longer than the mask walk the block maxima
     const bool part = want_partition(ix, n, opts);
     IVJ_TRY(ensure_ov(ctx, n, part ? 1 : 0));
     ctx->ov_part = part;
@@ -186,6 +187,7 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         }
     }
     IVJ_TRY(need_tables(ctx, ix));
+    IVJ_TRY(ensure_hier(ctx, ix));                     // windows longer than the mask walk the block maxima
     const bool part = want_partition(ix, n, opts);
     IVJ_TRY(ensure_ov(ctx, n, part ? 1 : 0));
     // dense results (the caller expects >= 16 pairs per probe; at ~8 the two kernels tie and the flat one still has
@@ -245,6 +247,7 @@ int unpermute(ivj_ctx* ctx, int64_t n, const UnpermuteCols& cols) {
 // fused join + key-column materialisation (k_overlap_fused_rows); same partitioning as overlap_fused
 int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const ivj_rows* rows, int64_t* n_pairs) {
     IVJ_TRY(need_tables(ctx, ix));
+    IVJ_TRY(ensure_hier(ctx, ix));                     // windows longer than the mask walk the block maxima
     const int64_t n = probe->n;
     const int64_t capacity = rows->n_pairs;
     ctx->ov_n = -1;
@@ -330,7 +333,7 @@ int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_op
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
     const bool k1 = k == 1 && opts->include_overlaps;
     if (k1) IVJ_TRY(build_argmax(ctx, ix));
-    else IVJ_TRY(build_end_order(ctx, ix));
+    else { IVJ_TRY(build_end_order(ctx, ix)); IVJ_TRY(ensure_hier(ctx, ix)); }     // nearest_general lists overlapping rows with hier_walk_up
     // large probe sides: bucket them by genomic position first (every gather of the kernel then stays in the
     // XCD L2s); the kernels write each result to the probe's original row
     const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *qrow = nullptr;
