@@ -20,7 +20,7 @@ import pyarrow as pa
 import pyarrow.compute as pc
 
 from . import _arrow as A
-from ._engine import default_engine
+from ._engine import EngineError, default_engine
 from ._metadata import validate_coordinate_system_single, validate_coordinate_systems
 from .constants import DEFAULT_INTERVAL_COLUMNS
 
@@ -301,8 +301,13 @@ def overlap(
         return lazy if output_type == "pyarrow.RecordBatchReader" else A.from_arrow(lazy.read_all(), output_type, zero_based)
     t1, t2, probe, build, n_contigs, keys = _prepare(df1, df2, cols1, cols2)
     if mode == OverlapOutputMode.Join and not low_memory and _key_columns_from_device(t1, t2, cols1, cols2):
-        return A.from_arrow(_overlap_join_rows(t1, t2, probe, build, n_contigs, keys, cols1, cols2, suffixes, zero_based, _materialize_on_device()),
-                            output_type, zero_based)
+        try:
+            return A.from_arrow(_overlap_join_rows(t1, t2, probe, build, n_contigs, keys, cols1, cols2, suffixes, zero_based, _materialize_on_device()),
+                                output_type, zero_based)
+        except EngineError as e:
+            # seven int32 columns per pair did not fit the host (28 bytes per pair; the index pairs below need 8): keep going
+            if "does not fit the available host memory" not in str(e):
+                raise
     if low_memory:
         # bounded device footprint and result batches: the probe side streams through the GPU in
         # tiles against the resident build index (reference: low_memory caps the output batch size)

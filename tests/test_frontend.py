@@ -559,3 +559,23 @@ def test_pandas_object_columns_by_object_identity_equal_the_ordinary_conversion(
         pd.testing.assert_frame_equal(sa, sb)
     assert fast[0]["chrom_1"].dtype == object and isinstance(fast[0]["chrom_1"].iloc[0], str)
     pd.testing.assert_frame_equal(_sorted(fast[3]), _sorted(pd.read_csv(f"{GOLDEN}/expected_overlap.csv")))
+
+
+def test_join_falls_back_to_index_pairs_when_the_key_columns_do_not_fit_the_host(monkeypatch):
+    """ivj_overlap_rows brings seven int32 columns per pair to the host (28 bytes per pair, gated on MemAvailable); when that does
+    not fit but the index pairs (8 bytes per pair) do, pb.overlap must still answer -- through the pair path."""
+    from polars_bio_amd import _engine
+    calls = []
+
+    class Tight(OracleEngine):
+        def overlap_rows(self, *a, **k):
+            calls.append("rows")
+            raise _engine.EngineError("ivj_overlap_rows failed (-3): the result (9 rows x 7 columns) does not fit the available host memory")
+
+        def overlap(self, *a, **k):
+            calls.append("pairs")
+            return super().overlap(*a, **k)
+    monkeypatch.setattr(range_op, "default_engine", lambda: Tight())
+    res = pb.overlap(_csv(f"{GOLDEN}/overlap/reads.csv"), _csv(f"{GOLDEN}/overlap/targets.csv"), cols1=COLS, cols2=COLS, output_type="pandas.DataFrame")
+    assert calls == ["rows", "pairs"]
+    pd.testing.assert_frame_equal(_sorted(res), _sorted(pd.read_csv(f"{GOLDEN}/expected_overlap.csv")))
