@@ -162,15 +162,22 @@ def _assemble_overlap(t1, t2, p_idx, b_idx, mode, distinct_output, suffixes, key
 def _assemble_nearest(t1, t2, idx, dist, nf, suffixes, distance, keys=None) -> pa.Table:
     """src/operation.rs:170-197: one output row per filled slot; rows without any candidate keep a single null slot."""
     n1 = t1.num_rows
-    slots = np.maximum(nf, 1)
-    rep = np.repeat(np.arange(n1, dtype=np.int32), slots)
-    first = np.cumsum(slots) - slots
-    within = np.arange(rep.shape[0], dtype=np.int64) - np.repeat(first, slots)
-    b_sel = idx[rep, within] if n1 else np.empty(0, np.int32)
-    d_sel = dist[rep, within] if n1 else np.empty(0, np.int64)
     k1 = (keys[0], keys[1], keys[4]) if keys is not None else None
     k2 = (keys[2], keys[3], keys[4]) if keys is not None else None
-    res = A.hconcat(A.with_suffix(A.take_rows(t1, rep, chrom=k1), suffixes[0]), A.with_suffix(A.take_rows(t2, b_sel, nullable=True, chrom=k2), suffixes[1]))
+    if idx.ndim == 2 and idx.shape[1] == 1:
+        # k = 1: exactly one slot per df1 row -- the left side IS df1 (no gather, no copy), the right side one gather
+        left = t1
+        b_sel = np.ascontiguousarray(idx.reshape(-1))
+        d_sel = np.ascontiguousarray(dist.reshape(-1))
+    else:
+        slots = np.maximum(nf, 1)
+        rep = np.repeat(np.arange(n1, dtype=np.int32), slots)
+        first = np.cumsum(slots) - slots
+        within = np.arange(rep.shape[0], dtype=np.int64) - np.repeat(first, slots)
+        b_sel = idx[rep, within] if n1 else np.empty(0, np.int32)
+        d_sel = dist[rep, within] if n1 else np.empty(0, np.int64)
+        left = A.take_rows(t1, rep, chrom=k1)
+    res = A.hconcat(A.with_suffix(left, suffixes[0]), A.with_suffix(A.take_rows(t2, b_sel, nullable=True, chrom=k2), suffixes[1]))
     if distance:
         res = res.append_column("distance", pa.array(d_sel, type=pa.int64(), mask=(b_sel < 0)))
     return res

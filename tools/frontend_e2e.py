@@ -58,6 +58,18 @@ def main():
             print(f"materialize={mode:6s} {label:34s} {best:7.3f} s   rows {len(r):,}", flush=True)
             del r
     pb.set_option("ivj.materialize", "host")
+    # the two per-row operations through the same front door (one result row per df1 row)
+    for op, fn in (("nearest", lambda a, b, out: pb.nearest(a, b, output_type=out)), ("count_overlaps", lambda a, b, out: pb.count_overlaps(a, b, output_type=out))):
+        for label, a, bb, out in (("arrow(string chrom) -> arrow", t1, t2, "pyarrow.Table"), ("arrow(dictionary chrom) -> arrow", dict1, dict2, "pyarrow.Table"),
+                                  ("pandas -> pandas", d1, d2, "pandas.DataFrame")):
+            best = None
+            for _ in range(3):
+                t = time.perf_counter()
+                r = fn(a, bb, out)
+                dt = time.perf_counter() - t
+                best = dt if best is None else min(best, dt)
+            print(f"{op:15s}    {label:34s} {best:7.3f} s   rows {len(r):,}", flush=True)
+            del r
     for label, a, bb in (("string chrom", t1, t2), ("dictionary chrom", dict1, dict2)):
         best = None
         for _ in range(3):
