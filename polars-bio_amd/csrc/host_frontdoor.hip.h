@@ -23,20 +23,16 @@ int fd_threads(int64_t n, int want, int64_t min_rows_per_thread) {
     return t < 1 ? 1 : t;
 }
 
-// runs fn(thread, lo, hi) over [0, n) cut into `t` contiguous ranges (multiples of 64 rows)
+// runs fn(part, lo, hi) over [0, n) cut into `t` contiguous ranges (multiples of 64 rows) on the host worker pool
 template <class F>
 void fd_parallel(int64_t n, int t, F&& fn) {
     if (t <= 1) { fn(0, (int64_t)0, n); return; }
     const int64_t per = ((n + t - 1) / t + 63) / 64 * 64;
-    std::vector<std::thread> th;
-    th.reserve(t - 1);
-    for (int k = 1; k < t; ++k) {
+    const int parts = (int)((n + per - 1) / per);
+    host_parallel(parts, [&fn, per, n](int k) {
         const int64_t lo = (int64_t)k * per, hi = lo + per < n ? lo + per : n;
-        if (lo >= hi) break;
-        th.emplace_back([&fn, k, lo, hi] { fn(k, lo, hi); });
-    }
-    fn(0, (int64_t)0, per < n ? per : n);
-    for (auto& x : th) x.join();
+        if (lo < hi) fn(k, lo, hi);
+    });
 }
 
 template <class T>

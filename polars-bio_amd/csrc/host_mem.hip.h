@@ -13,6 +13,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 namespace {
@@ -43,6 +47,105 @@ size_t host_mem_available() {
     return (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz : 0;
 }
 
+// ---- host worker pool ---------------------------------------------------------------------------------------------------------------
+// The host passes of this library (staging copies of HostXfer, first touch of result buffers, the front door's per-row passes) are
+// short: 0.1 - 3 ms of work cut into a few dozen parts, hundreds of times per call.  Spawning std::threads for each (~25 us apiece,
+// one after the other) cost config 3's host path ~13 ms of 65 and pb.overlap ~8 ms of 40.  host_parallel(parts, f) runs f(0 ..
+// parts - 1) on a process-wide pool of workers that sleep on a condition variable between jobs; the caller takes parts too.  One job
+// at a time: a second caller that finds the pool busy (the front door calls in from several Python threads) runs its parts on
+// threads of its own, as before.  A forked child starts with a fresh pool (the parent's workers do not exist in it).
+struct HostPool {
+    std::mutex run;                                        // one job at a time
+    std::mutex m;                                          // guards everything below
+    std::condition_variable cv_job, cv_done;
+    int n_workers = 0;
+    const std::function<void(int)>* job = nullptr;
+    unsigned long long gen = 0;
+    int parts = 0;
+    std::atomic<int> next{0};
+    int pending = 0;                                       // parts not yet finished
+    int active = 0;                                        // workers that picked this job up and have not let go of it yet
+    static constexpr int MAX_WORKERS = 63;
+
+    // grab parts until none is left; `worker`: the caller of execute() is not counted in `active`
+    void work(const std::function<void(int)>& f, int n, bool worker) {
+        int done = 0;
+        for (int i = next.fetch_add(1, std::memory_order_relaxed); i < n; i = next.fetch_add(1, std::memory_order_relaxed)) { f(i); ++done; }
+        std::lock_guard<std::mutex> g(m);
+        pending -= done;
+        if (worker) --active;
+        if (pending == 0 && active == 0) cv_done.notify_all();
+    }
+    void worker_main() {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f;
+            int n;
+            {
+                std::unique_lock<std::mutex> g(m);
+                cv_job.wait(g, [&] { return gen != seen; });
+                seen = gen; f = job; n = parts;
+                if (f) ++active;                           // execute() does not return (and `f` stays alive) until we let go
+            }
+            if (f) work(*f, n, true);
+        }
+    }
+    void ensure_workers(int want) {                        // called with `run` held
+        if (want > MAX_WORKERS) want = MAX_WORKERS;
+        while (n_workers < want) {
+            std::thread([this] { worker_main(); }).detach();   // process-lifetime workers: never joined (no static-destructor order games)
+            ++n_workers;
+        }
+    }
+    void execute(int n, const std::function<void(int)>& f) {
+        ensure_workers(n - 1);
+        {
+            std::lock_guard<std::mutex> g(m);
+            job = &f; parts = n; pending = n; next.store(0, std::memory_order_relaxed); ++gen;
+        }
+        cv_job.notify_all();
+        work(f, n, false);
+        std::unique_lock<std::mutex> g(m);
+        cv_done.wait(g, [&] { return pending == 0 && active == 0; });
+        job = nullptr;                                     // a worker that wakes up late finds no job
+    }
+};
+
+inline HostPool*& host_pool_slot() { static HostPool* p = nullptr; return p; }
+inline void host_pool_after_fork() { host_pool_slot() = nullptr; }      // the child must not touch the parent's pool (its threads are gone)
+inline HostPool* host_pool() {
+    static std::mutex init;
+    std::lock_guard<std::mutex> g(init);
+    HostPool*& p = host_pool_slot();
+    if (!p) {
+        static bool hooked = false;
+        if (!hooked) { (void)pthread_atfork(nullptr, nullptr, host_pool_after_fork); hooked = true; }
+        p = new HostPool();                                // leaked on purpose: lives as long as the process
+    }
+    return p;
+}
+
+// f(0 .. parts - 1), in parallel; returns when all have run
+inline void host_parallel(int parts, const std::function<void(int)>& f) {
+    if (parts <= 1) { if (parts == 1) f(0); return; }
+    static thread_local bool inside = false;               // a part that calls host_parallel itself must not touch the pool's lock again
+    if (!inside) {
+        HostPool* pool = host_pool();
+        std::unique_lock<std::mutex> busy(pool->run, std::try_to_lock);
+        if (busy.owns_lock()) {
+            inside = true;
+            try { pool->execute(parts, f); } catch (...) { inside = false; throw; }
+            inside = false;
+            return;
+        }
+    }
+    std::vector<std::thread> th;                           // pool busy with another caller's job: threads of our own
+    th.reserve(parts - 1);
+    for (int k = 1; k < parts; ++k) th.emplace_back([&f, k] { f(k); });
+    f(0);
+    for (auto& x : th) x.join();
+}
+
 // A result that cannot fit the host is refused with an error instead of being first-touched into the OOM killer (an
 // all-against-all join of 400 k x 600 k rows is 1.7e10 pairs = 139 GB: that took two GPU boxes down in round 2).
 bool host_result_fits(size_t bytes) {
@@ -60,15 +163,13 @@ void* host_result_alloc(size_t bytes) {
     if (bytes >= huge) (void)madvise(p, sz, MADV_HUGEPAGE);
     if (bytes >= ((size_t)8 << 20)) {
         unsigned hw = std::thread::hardware_concurrency();
-        const unsigned nt = hw >= 16 ? 16u : (hw ? hw : 1u);
-        std::vector<std::thread> th;
+        const int nt = hw >= 16 ? 16 : (hw ? (int)hw : 1);
         const size_t per = (sz / nt + 4095) / 4096 * 4096;
-        for (unsigned t = 0; t < nt; ++t) {
+        host_parallel(nt, [p, per, sz](int t) {
             const size_t lo = (size_t)t * per, hi = lo + per < sz ? lo + per : sz;
-            if (lo >= hi) break;
-            th.emplace_back([p, lo, hi] { volatile char* c = (volatile char*)p; for (size_t o = lo; o < hi; o += 4096) c[o] = 0; });
-        }
-        for (auto& x : th) x.join();
+            volatile char* c = (volatile char*)p;
+            for (size_t o = lo; o < hi; o += 4096) c[o] = 0;
+        });
     }
     return p;
 }
@@ -77,29 +178,26 @@ void* host_result_alloc(size_t bytes) {
 void host_prefault(void* p, size_t bytes) {
     if (!p || bytes < ((size_t)8 << 20)) return;
     unsigned hw = std::thread::hardware_concurrency();
-    const unsigned nt = hw >= 16 ? 16u : (hw ? hw : 1u);
-    std::vector<std::thread> th;
+    const int nt = hw >= 16 ? 16 : (hw ? (int)hw : 1);
     const size_t per = (bytes / nt + 4095) / 4096 * 4096;
-    for (unsigned t = 0; t < nt; ++t) {
+    host_parallel(nt, [p, per, bytes](int t) {
         const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
-        if (lo >= hi) break;
-        th.emplace_back([p, lo, hi] { volatile char* c = (volatile char*)p; for (size_t o = lo; o < hi; o += 4096) c[o] = c[o]; c[hi - 1] = c[hi - 1]; });
-    }
-    for (auto& x : th) x.join();
+        if (lo >= hi) return;
+        volatile char* c = (volatile char*)p;
+        for (size_t o = lo; o < hi; o += 4096) c[o] = c[o];
+        c[hi - 1] = c[hi - 1];
+    });
 }
 
 // copy into a pinned staging slot with a few threads (one thread moves ~31 GB/s, four ~95 GB/s: tools/pcie_probe.py)
 void host_copy_parallel(void* dst, const void* src, size_t bytes) {
     if (bytes < ((size_t)8 << 20)) { std::memcpy(dst, src, bytes); return; }
-    constexpr unsigned nt = 4;
-    std::thread th[nt - 1];
+    constexpr int nt = 4;
     const size_t per = (bytes / nt + 4095) / 4096 * 4096;
-    for (unsigned t = 1; t < nt; ++t) {
+    host_parallel(nt, [=](int t) {
         const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
-        th[t - 1] = std::thread([=] { if (lo < hi) std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
-    }
-    std::memcpy(dst, src, per < bytes ? per : bytes);
-    for (auto& x : th) x.join();
+        if (lo < hi) std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo);
+    });
 }
 
 // Every copy between caller / library host memory and HBM goes through this object and the context's own PINNED staging

@@ -147,3 +147,34 @@ def test_take_rows_native_and_pyarrow_columns_agree_with_arrow_take():
 def test_widen_i64():
     a = np.array([-(1 << 31), -1, 0, (1 << 31) - 1] * 70_000, np.int32)
     assert (H.widen_i64(a) == a.astype(np.int64)).all()
+
+
+def test_host_worker_pool_under_concurrent_callers_and_after_fork():
+    """The native passes share one process-wide worker pool (csrc/host_mem.hip.h: host_parallel): a caller that finds it busy runs on
+    threads of its own, a forked child starts a fresh pool.  Six Python threads hammer two passes; a forked child runs one."""
+    import os
+    import threading
+    rng = np.random.default_rng(0)
+    a = rng.integers(-2 ** 31, 2 ** 31 - 1, 1_500_003, dtype=np.int64)
+    src = rng.integers(0, 2 ** 60, 500_003, dtype=np.int64)
+    idx = rng.integers(0, len(src), 1_000_001).astype(np.int32)
+    exp_n, exp_t = a.astype(np.int32), src[idx]
+    errs = []
+
+    def worker(k):
+        for it in range(15):
+            out, mn, mx = H.narrow_i32(a)
+            if not (out == exp_n).all() or mn != a.min() or mx != a.max():
+                errs.append(("narrow", k, it))
+            if not (H.take(src, idx) == exp_t).all():
+                errs.append(("take", k, it))
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs[:3]
+    pid = os.fork()
+    if pid == 0:
+        ok = (H.narrow_i32(a)[0] == exp_n).all()
+        os._exit(0 if ok else 3)
+    _, st = os.waitpid(pid, 0)
+    assert os.WEXITSTATUS(st) == 0
