@@ -103,7 +103,9 @@ struct HostPool {
             std::lock_guard<std::mutex> g(m);
             job = &f; parts = n; pending = n; next.store(0, std::memory_order_relaxed); ++gen;
         }
-        cv_job.notify_all();
+        // wake as many workers as there are parts besides the caller's (not all 63: a four-part staging copy must not pay for a
+        // stampede on `m`); a worker that stays asleep picks up whatever job is current when it is next woken
+        for (int k = 0; k < n - 1 && k < n_workers; ++k) cv_job.notify_one();
         work(f, n, false);
         std::unique_lock<std::mutex> g(m);
         cv_done.wait(g, [&] { return pending == 0 && active == 0; });

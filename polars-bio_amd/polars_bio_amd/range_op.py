@@ -168,7 +168,7 @@ def _assemble_nearest(t1, t2, idx, dist, nf, suffixes, distance, keys=None) -> p
         # k = 1: exactly one slot per df1 row -- the left side IS df1 (no gather, no copy), the right side one gather
         left = t1
         b_sel = np.ascontiguousarray(idx.reshape(-1))
-        d_sel = np.ascontiguousarray(dist.reshape(-1))
+        d_sel = np.array(dist.reshape(-1), copy=True)          # becomes a result column: must not alias a streaming session's recycled slot
     else:
         slots = np.maximum(nf, 1)
         rep = np.repeat(np.arange(n1, dtype=np.int32), slots)
