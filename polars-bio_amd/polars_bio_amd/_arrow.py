@@ -14,7 +14,6 @@ from __future__ import annotations
 
 import os
 from concurrent.futures import ThreadPoolExecutor
-from typing import Tuple
 
 import numpy as np
 import pyarrow as pa
