@@ -575,11 +575,17 @@ def main():
             traffic, traffic_detail = pmc_traffic(args, dom_name)
             log(f"[bench] PMC traffic passes: {time.perf_counter() - t_p:.1f}s -> {traffic}")
     if dom is not None and dom["launches"] > 0:
+        # per LAUNCH: a kernel that runs several times per step (the N > 1 path joins its shard chunk by chunk) processes
+        # 1 / launches_per_step of the step's units each time, so bytes per launch = step bytes / launches per step
+        # (equivalently: step bytes / the kernel's time per step) -- never step bytes over ONE launch's duration
         avg_ms = dom["ms"] / dom["launches"]
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        launches_per_step = dom["launches"] / args.steps
+        bytes_per_launch = alg_bytes / launches_per_step
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
-                    "kernel_avg_ms": round(avg_ms, 4), "algorithmic_bytes": int(alg_bytes),
+                    "kernel_avg_ms": round(avg_ms, 4), "launches_per_step": round(launches_per_step, 3),
+                    "algorithmic_bytes": int(alg_bytes), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in ktimes.items()}}
 

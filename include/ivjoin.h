@@ -55,6 +55,7 @@ extern "C" {
 #define IVJ_ENOMEM       -3   /* device or host allocation failed */
 #define IVJ_ECAPACITY    -4   /* caller-provided output capacity too small */
 #define IVJ_ESTATE       -5   /* fill called without a matching count; index lacks what the call needs */
+#define IVJ_EPEER        -6   /* multi-rank call: ANOTHER rank failed; this rank's part is complete, the result is not */
 
 /* FilterOp of the reference (src/option.rs:95-100) */
 #define IVJ_FILTER_WEAK   0   /* 1-based closed:    a.start <= b.end && b.start <= a.end */
@@ -366,7 +367,11 @@ int ivj_comm_unique_id(void* id_out);
 int ivj_comm_create(ivj_ctx* ctx, const void* unique_id, int rank, int world, ivj_comm** out);
 /* one process, one context per device: ncclCommInitAll; out[i] = communicator of ctxs[i] (rank i).  Calls on the n
  * communicators that belong together (ivj_allgather_counts, ivj_allgatherv_dev, ivj_overlap_allgather_dev) must then
- * come from n host threads, one per rank. */
+ * come from n host threads, one per rank.  Contexts that SHARE a device (RCCL wants one device per rank), or
+ * IVJ_COMM_LOOPBACK=1, get the library's in-process transport instead of RCCL: a host-memory rendezvous + device copies
+ * issued by the receiving rank, same calls, same order, same blocking behaviour (a rank that never arrives makes its
+ * peers fail with IVJ_EHIP after IVJ_COMM_LOOPBACK_TIMEOUT seconds, default 120, instead of waiting forever) -- a 1-GPU
+ * box runs the multi-rank protocol with it. */
 int ivj_comm_create_local(ivj_ctx* const* ctxs, int n, ivj_comm** out);
 void ivj_comm_destroy(ivj_comm* comm);
 int ivj_comm_info(const ivj_comm* comm, int* rank, int* world);
@@ -381,7 +386,18 @@ int ivj_allgatherv_dev(ivj_comm* comm, const void* const* send_cols, void* const
  * probe rows are cut into n_chunks contiguous chunks (the same number on every rank, 1 .. 64); while chunk i is joined
  * (fused single pass) a helper thread exchanges chunk i - 1 straight into the caller's columns.  Every rank ends up with
  * all *n_total pairs (layout: chunk after chunk, inside a chunk rank after rank; the pairs of one probe row contiguous);
- * *n_local = this rank's share.  IVJ_ECAPACITY when capacity < *n_total (nothing is written past it). */
+ * *n_local = this rank's share.
+ * Failure contract (no rank is left waiting in a collective, whatever happens on another one):
+ *   - every rank takes part in the count all-gather of EVERY chunk.  A rank whose own work fails (join, allocation) marks
+ *     the failed chunk and all later ones as failed instead of joining them and returns its own error code after the last
+ *     chunk; every other rank completes its chunks and returns IVJ_EPEER (the failed rank's pairs from that chunk on are
+ *     missing from the columns, *n_total counts what was exchanged);
+ *   - IVJ_ECAPACITY on EVERY rank when the pairs outgrow the capacity of ANY rank: the decision is taken from the gathered
+ *     counts, so all ranks stop moving pairs at the same chunk (nothing is written past a capacity), the remaining chunks
+ *     are still joined and counted, and *n_total = the capacity the call needs -- one regrow step is enough;
+ *   - an error of the collective itself (RCCL, the exchange stream) is returned as IVJ_EHIP; nothing can be promised to
+ *     the peers then.
+ * IVJ_FAULT_ALLGATHER="<rank>:<chunk>" in the environment makes that chunk's join on that rank fail (test knob). */
 int ivj_overlap_allgather_dev(ivj_comm* comm, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int n_chunks,
                               int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_total, int64_t* n_local);
 

@@ -12,6 +12,7 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -72,12 +73,42 @@ const RcclApi* rccl_api() {
 
 }  // namespace
 
+namespace {
+// In-process transport for the ranks of ONE process (ivj_comm_create_local): a rendezvous in host memory + device copies
+// issued by the RECEIVING rank.  It carries the same protocol as the RCCL transport (same calls in the same order, the same
+// blocking behaviour: a rank that skips a collective leaves its peers waiting -- here until LOOP_TIMEOUT_S, then IVJ_EHIP),
+// and it is what lets two ranks share one device, which RCCL refuses: a 1-GPU box runs the world-2 protocol of the sharded
+// overlap with it.  Chosen by ivj_comm_create_local when two contexts share a device or IVJ_COMM_LOOPBACK=1 is set.
+struct LoopGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int world = 0, arrived = 0, refs = 0;
+    uint64_t gen = 0;
+    std::vector<int64_t> vals;                        // world * 2
+    std::vector<const void*> send;                    // world * LOOP_MAX_COLS
+    std::vector<int64_t> cnt;                         // world
+    static constexpr int MAX_COLS = 8;
+    // -> false on timeout
+    bool barrier(int timeout_s) {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = gen;
+        if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); return true; }
+        if (cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return gen != g; })) return true;
+        --arrived;                                   // give up: the barrier stays consistent for whoever comes later
+        return false;
+    }
+};
+int loop_timeout_s() { const char* ev = std::getenv("IVJ_COMM_LOOPBACK_TIMEOUT"); const int t = ev ? std::atoi(ev) : 0; return t > 0 ? t : 120; }
+}  // namespace
+
 struct ivj_comm {
-    ivj_ctx* ctx = nullptr;
+    ivj_ctx* ctx = nullptr;              // nullptr once the context was destroyed under the communicator (calls then fail with IVJ_ESTATE)
+    int device = 0;
     int rank = 0, world = 1;
     RcclComm comm = nullptr;             // nullptr for a single-rank communicator (nothing to exchange, RCCL never touched)
+    LoopGroup* loop = nullptr;           // in-process transport instead of RCCL (shared by the communicators of one create_local call)
     hipStream_t xstream = nullptr;       // the exchange runs on its own stream so that it overlaps the join
-    long long* d_counts = nullptr;       // world + 1 int64 in HBM
+    long long* d_counts = nullptr;       // 2 * (world + 1) int64 in HBM: gathered values (<= 2 per rank), then this rank's send slots
     long long* h_counts = nullptr;       // pinned mirror
     int32_t* stage[2] = {nullptr, nullptr};   // result staging of the sharded overlap (2 x {probe rows | build rows}), kept between calls
     int64_t stage_cap = 0;               //   pairs per staging buffer
@@ -87,24 +118,20 @@ struct ivj_comm {
 
 namespace {
 
-int comm_finish_create(ivj_comm* c) {
-    DeviceGuard g(c->ctx->device);
-    HIP_TRY(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void**)&c->d_counts, (size_t)(c->world + 1) * 8));
-    HIP_TRY(hipHostMalloc((void**)&c->h_counts, (size_t)(c->world + 1) * 8, hipHostMallocDefault));
-    return IVJ_OK;
+// the context goes away under a live communicator: the device resources that live on the context's device stay with the
+// communicator (ivj_comm_destroy releases them), only the way back to the context is cut
+void comm_detach(ivj_comm* c) {
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+    c->ctx = nullptr;
 }
 
-// counts[r] = n of rank r (all ranks), on the exchange stream; synchronises that stream
-int comm_allgather_counts(ivj_comm* c, int64_t n_local, int64_t* counts) {
-    if (c->world == 1) { counts[0] = n_local; return IVJ_OK; }
-    const RcclApi* api = rccl_api();
-    c->h_counts[c->world] = (long long)n_local;
-    HIP_TRY(hipMemcpyAsync(c->d_counts + c->world, c->h_counts + c->world, 8, hipMemcpyHostToDevice, c->xstream));
-    RCCL_TRY(api, api->AllGather(c->d_counts + c->world, c->d_counts, 1, RCCL_INT64, c->comm, c->xstream));
-    HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)c->world * 8, hipMemcpyDeviceToHost, c->xstream));
-    HIP_TRY(hipStreamSynchronize(c->xstream));
-    for (int r = 0; r < c->world; ++r) counts[r] = (int64_t)c->h_counts[r];
+int comm_finish_create(ivj_comm* c) {
+    c->device = c->ctx->device;
+    c->ctx->comms.push_back(c);
+    DeviceGuard g(c->device);
+    HIP_TRY(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&c->d_counts, (size_t)(c->world + 1) * 16));
+    HIP_TRY(hipHostMalloc((void**)&c->h_counts, (size_t)(c->world + 1) * 16, hipHostMallocDefault));
     return IVJ_OK;
 }
 
@@ -118,6 +145,22 @@ int comm_exchange(ivj_comm* c, const void* const* send, void* const* recv, int n
         if (n_local > 0)
             HIP_TRY(hipMemcpyAsync((char*)recv[k] + (size_t)(dst_off + off[c->rank]) * elem_bytes, send[k], (size_t)n_local * elem_bytes, hipMemcpyDeviceToDevice, c->xstream));
     if (c->world == 1) return IVJ_OK;
+    if (c->loop) {
+        LoopGroup* L = c->loop;
+        if (n_cols > LoopGroup::MAX_COLS) return fail(IVJ_EINVAL, "loopback transport: too many columns");
+        { std::lock_guard<std::mutex> lk(L->mu); for (int k = 0; k < n_cols; ++k) L->send[(size_t)c->rank * LoopGroup::MAX_COLS + k] = send[k]; }
+        if (!L->barrier(loop_timeout_s())) return fail(IVJ_EHIP, "loopback transport: a rank did not reach the exchange (timeout)");
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < n_cols && e == hipSuccess; ++k)
+            for (int peer = 0; peer < c->world && e == hipSuccess; ++peer)
+                if (peer != c->rank && counts[peer] > 0)
+                    e = hipMemcpyAsync((char*)recv[k] + (size_t)(dst_off + off[peer]) * elem_bytes, L->send[(size_t)peer * LoopGroup::MAX_COLS + k],
+                                       (size_t)counts[peer] * elem_bytes, hipMemcpyDefault, c->xstream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->xstream);
+        if (!L->barrier(loop_timeout_s())) return fail(IVJ_EHIP, "loopback transport: a rank did not finish the exchange (timeout)");   // the peers' send buffers are free again
+        if (e != hipSuccess) return fail(IVJ_EHIP, std::string("loopback transport copy: ") + hipGetErrorString(e));
+        return IVJ_OK;
+    }
     const RcclApi* api = rccl_api();
     RCCL_TRY(api, api->GroupStart());
     for (int k = 0; k < n_cols; ++k) {
@@ -138,55 +181,110 @@ __global__ void k_iota(int32_t* __restrict__ out, int64_t n) {
     if (i < n) out[i] = (int32_t)i;
 }
 
+// (values[0 .. nv) of every rank) -> all[r * nv + v], on the exchange stream; synchronises that stream.  nv <= 2.
+int comm_allgather_i64(ivj_comm* c, const int64_t* vals, int nv, int64_t* all) {
+    if (c->world == 1) { for (int v = 0; v < nv; ++v) all[v] = vals[v]; return IVJ_OK; }
+    if (c->loop) {
+        LoopGroup* L = c->loop;
+        { std::lock_guard<std::mutex> lk(L->mu); for (int v = 0; v < nv; ++v) L->vals[(size_t)c->rank * 2 + v] = vals[v]; }
+        if (!L->barrier(loop_timeout_s())) return fail(IVJ_EHIP, "loopback transport: a rank did not reach the count all-gather (timeout)");
+        { std::lock_guard<std::mutex> lk(L->mu); for (int r = 0; r < c->world; ++r) for (int v = 0; v < nv; ++v) all[(size_t)r * nv + v] = L->vals[(size_t)r * 2 + v]; }
+        if (!L->barrier(loop_timeout_s())) return fail(IVJ_EHIP, "loopback transport: a rank did not leave the count all-gather (timeout)");
+        return IVJ_OK;
+    }
+    const RcclApi* api = rccl_api();
+    long long* h_send = c->h_counts + (size_t)c->world * 2;
+    long long* d_send = c->d_counts + (size_t)c->world * 2;
+    for (int v = 0; v < nv; ++v) h_send[v] = (long long)vals[v];
+    HIP_TRY(hipMemcpyAsync(d_send, h_send, (size_t)nv * 8, hipMemcpyHostToDevice, c->xstream));
+    RCCL_TRY(api, api->AllGather(d_send, c->d_counts, (size_t)nv, RCCL_INT64, c->comm, c->xstream));
+    HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)c->world * nv * 8, hipMemcpyDeviceToHost, c->xstream));
+    HIP_TRY(hipStreamSynchronize(c->xstream));
+    for (int i = 0; i < c->world * nv; ++i) all[i] = (int64_t)c->h_counts[i];
+    return IVJ_OK;
+}
+
+// counts[r] = n of rank r (all ranks), on the exchange stream; synchronises that stream
+int comm_allgather_counts(ivj_comm* c, int64_t n_local, int64_t* counts) { return comm_allgather_i64(c, &n_local, 1, counts); }
+
+// IVJ_FAULT_ALLGATHER="<rank>:<chunk>" (test knob): the join of that chunk on that rank reports a failure instead of running.
+bool fault_injected(int rank, int chunk) {
+    const char* ev = std::getenv("IVJ_FAULT_ALLGATHER");
+    if (!ev || !*ev) return false;
+    int r = -1, ch = -1;
+    if (std::sscanf(ev, "%d:%d", &r, &ch) != 2) return false;
+    return r == rank && ch == chunk;
+}
+
 // Sharded pb.overlap whose exchange overlaps the join.  This rank's probe rows are cut into n_chunks contiguous chunks (the
 // same number on every rank); chunk i is joined (fused single pass) into a staging buffer while a helper thread exchanges
-// chunk i - 1: ncclAllGather of the chunk's per-rank counts, then the grouped send / receive batch straight into the caller's
-// result columns.  Result layout: chunk after chunk, inside a chunk rank after rank (the reference leaves the row order of
-// pb.overlap unspecified; the pairs of one probe row stay contiguous).  Every rank ends up with every pair.
+// chunk i - 1: ncclAllGather of the chunk's per-rank {pair count | failure mark, room left in the caller's columns}, then the
+// grouped send / receive batch straight into the caller's result columns.  Result layout: chunk after chunk, inside a chunk
+// rank after rank (the reference leaves the row order of pb.overlap unspecified; the pairs of one probe row stay contiguous).
+// Every rank ends up with every pair.
+//
+// Failure protocol -- no rank is ever left waiting in a collective:
+//   * EVERY rank issues the count all-gather of EVERY chunk, whatever happened to it before.  A rank whose join failed
+//     submits the failed chunk and all later ones with the mark -1 (it does not join them) and returns its own error at the end;
+//     the other ranks read the mark as "0 pairs from that rank", finish, and return IVJ_EPEER.
+//   * the decision to move a chunk's pairs is taken from the GATHERED values only (pairs of the chunk against the smallest
+//     room any rank has left), so all ranks take it alike: once one rank's columns are too small, no rank sends or receives
+//     any more, the remaining chunks are still counted, and every rank returns IVJ_ECAPACITY with *n_total = the capacity
+//     the call needs.
+//   * only an error of the collective itself (RCCL / the exchange stream) ends this rank's participation: the fabric is
+//     gone then and nothing can be promised to the peers.
 int overlap_allgather(ivj_comm* c, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int n_chunks, int32_t* out_p, int32_t* out_b,
                       int64_t capacity, int64_t* n_total, int64_t* n_local_out) {
     ivj_ctx* ctx = c->ctx;
     const int64_t n = probe->n;
     *n_total = 0;
     if (n_local_out) *n_local_out = 0;
+    int rc = IVJ_OK;                                   // first failure of this rank's own work (joins, allocations)
+    std::string main_err;
+    auto note = [&](int r) { if (r != IVJ_OK && rc == IVJ_OK) { rc = r; main_err = g_err; } };
     const int32_t* row_id = probe->row_id;
     if (!row_id && n > 0 && n_chunks > 1) {
         if (c->iota_n < n) {
-            if (c->iota) HIP_TRY(hipFree(c->iota));
+            if (c->iota) (void)hipFree(c->iota);
             c->iota = nullptr; c->iota_n = 0;
-            HIP_TRY(hipMalloc((void**)&c->iota, (size_t)n * 4));
-            hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, c->iota, n);
-            HIP_TRY(hipGetLastError());
-            c->iota_n = n;
+            if (hipMalloc((void**)&c->iota, (size_t)n * 4) != hipSuccess) note(fail(IVJ_ENOMEM, "row ids of the chunks: hipMalloc failed"));
+            else {
+                hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, c->iota, n);
+                if (hipGetLastError() != hipSuccess) note(fail(IVJ_EHIP, "k_iota launch failed"));
+                else c->iota_n = n;
+            }
         }
         row_id = c->iota;
     }
     auto ensure_stage = [&](int64_t cap) -> int {
         if (cap <= c->stage_cap) return IVJ_OK;
-        for (auto& b : c->stage) { if (b) HIP_TRY(hipFree(b)); b = nullptr; }
+        for (auto& b : c->stage) { if (b) (void)hipFree(b); b = nullptr; }
         c->stage_cap = 0;
-        for (auto& b : c->stage) HIP_TRY(hipMalloc((void**)&b, (size_t)cap * 8));
+        for (auto& b : c->stage)
+            if (hipMalloc((void**)&b, (size_t)cap * 8) != hipSuccess) return fail(IVJ_ENOMEM, "staging of the sharded overlap: hipMalloc of " + std::to_string(cap * 8) + " bytes failed");
         c->stage_cap = cap;
         return IVJ_OK;
     };
-    {
+    if (rc == IVJ_OK) {
         int64_t guess = capacity / ((int64_t)c->world * n_chunks);
         guess += guess / 2 + (1 << 16);
-        IVJ_TRY(ensure_stage(guess < capacity + 1 ? guess : capacity + 1));
+        note(ensure_stage(guess < capacity + 1 ? guess : capacity + 1));
     }
     // exchange thread: one job per chunk, in order
-    struct Job { int chunk; int64_t n; int buf; };
+    struct Job { int chunk; int64_t n; int buf; };      // n = pairs of the chunk on this rank, -1: this rank has failed
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Job> q;
     bool done[2] = {true, true};                      // staging buffer free again
-    int x_rc = IVJ_OK;
+    int x_rc = IVJ_OK;                                // error of the collectives themselves
     std::string x_err;
+    bool overflow = false, peer_failed = false;
+    int failed_peer = -1, failed_chunk = -1;
     int64_t dst_off = 0, local_sum = 0;
     bool stop = false;
     std::thread xt([&] {
         (void)hipSetDevice(ctx->device);
-        std::vector<int64_t> counts((size_t)c->world);
+        std::vector<int64_t> all((size_t)c->world * 2), counts((size_t)c->world);
         for (;;) {
             Job j;
             {
@@ -195,50 +293,63 @@ int overlap_allgather(ivj_comm* c, ivj_index* ix, const ivj_side* probe, const i
                 if (q.empty()) return;
                 j = q.front(); q.pop_front();
             }
-            int rc = x_rc;
-            if (rc == IVJ_OK) rc = comm_allgather_counts(c, j.n, counts.data());        // every rank takes part in every chunk's collectives
-            if (rc == IVJ_OK) {
-                int64_t tot = 0;
-                for (int r = 0; r < c->world; ++r) tot += counts[r];
-                if (dst_off + tot > capacity) { rc = fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(dst_off + tot) + " pairs after chunk " + std::to_string(j.chunk)); dst_off += tot; }
-                else {
-                    const void* send[2] = {c->stage[j.buf], c->stage[j.buf] + c->stage_cap};
-                    void* recv[2] = {out_p, out_b};
-                    rc = comm_exchange(c, send, recv, 2, 4, counts.data(), dst_off);
-                    if (rc == IVJ_OK && hipStreamSynchronize(c->xstream) != hipSuccess) rc = fail(IVJ_EHIP, "exchange stream synchronize failed");
+            int xr = IVJ_OK;
+            if (x_rc == IVJ_OK) {
+                const int64_t mine[2] = {j.n, capacity - dst_off};
+                xr = comm_allgather_i64(c, mine, 2, all.data());             // every rank, every chunk
+                if (xr == IVJ_OK) {
+                    int64_t tot = 0, room = capacity - dst_off;
+                    for (int r = 0; r < c->world; ++r) {
+                        const int64_t nr = all[(size_t)r * 2];
+                        if (nr < 0 && r != c->rank && !peer_failed) { peer_failed = true; failed_peer = r; failed_chunk = j.chunk; }
+                        counts[r] = nr < 0 ? 0 : nr;
+                        tot += counts[r];
+                        if (all[(size_t)r * 2 + 1] < room) room = all[(size_t)r * 2 + 1];
+                    }
+                    if (tot > room) overflow = true;                         // sticky, and the same on every rank
+                    if (!overflow) {
+                        const void* send[2] = {c->stage[j.buf], c->stage[j.buf] + c->stage_cap};
+                        void* recv[2] = {out_p, out_b};
+                        xr = comm_exchange(c, send, recv, 2, 4, counts.data(), dst_off);
+                        if (xr == IVJ_OK && hipStreamSynchronize(c->xstream) != hipSuccess) xr = fail(IVJ_EHIP, "exchange stream synchronize failed");
+                    }
                     dst_off += tot;
                 }
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                if (rc != IVJ_OK && x_rc == IVJ_OK) { x_rc = rc; x_err = g_err; }
+                if (xr != IVJ_OK && x_rc == IVJ_OK) { x_rc = xr; x_err = g_err; }
                 done[j.buf] = true;
             }
             cv.notify_all();
         }
     });
-    int rc = IVJ_OK;
-    for (int i = 0; i < n_chunks && rc == IVJ_OK; ++i) {
+    struct Joiner {                                    // the helper is joined on every way out of this frame (also an exception's)
+        std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& stop;
+        ~Joiner() { if (t.joinable()) { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); t.join(); } }
+    } joiner{xt, mu, cv, stop};
+    for (int i = 0; i < n_chunks; ++i) {
         const int64_t lo = n * i / n_chunks, hi = n * (i + 1) / n_chunks;
         const int buf = i & 1;
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done[buf]; }); }
         int64_t got = 0;
-        if (hi > lo && ix->n > 0) {
+        if (rc == IVJ_OK && fault_injected(c->rank, i)) note(fail(IVJ_EHIP, "injected fault (IVJ_FAULT_ALLGATHER) in chunk " + std::to_string(i)));
+        if (rc == IVJ_OK && hi > lo && ix->n > 0) {
             ivj_side sub{probe->contig + lo, probe->start + lo, probe->end + lo, hi - lo, row_id ? row_id + lo : nullptr};
-            rc = overlap_fused(ctx, ix, &sub, opts, c->stage[buf], c->stage[buf] + c->stage_cap, c->stage_cap, &got);
-            if (rc == IVJ_ECAPACITY) {
+            int r = overlap_fused(ctx, ix, &sub, opts, c->stage[buf], c->stage[buf] + c->stage_cap, c->stage_cap, &got);
+            if (r == IVJ_ECAPACITY) {
                 // the chunk's pairs did not fit the staging: drain the exchange, grow both buffers, redo the chunk
                 { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done[0] && done[1]; }); }
-                rc = ensure_stage(got + got / 8 + 1024);
-                if (rc == IVJ_OK) rc = overlap_fused(ctx, ix, &sub, opts, c->stage[buf], c->stage[buf] + c->stage_cap, c->stage_cap, &got);
+                r = ensure_stage(got + got / 8 + 1024);
+                if (r == IVJ_OK) r = overlap_fused(ctx, ix, &sub, opts, c->stage[buf], c->stage[buf] + c->stage_cap, c->stage_cap, &got);
             }
+            note(r);
         }
-        if (rc != IVJ_OK) got = 0;                                   // keep the collective sequence of the other ranks alive
-        local_sum += got;
+        if (rc != IVJ_OK) got = -1;                                  // failure mark: this and every later chunk still reach the collective
+        else local_sum += got;
         { std::lock_guard<std::mutex> lk(mu); done[buf] = false; q.push_back(Job{i, got, buf}); }
         cv.notify_all();
     }
-    const std::string main_err = g_err;
     { std::lock_guard<std::mutex> lk(mu); stop = true; }
     cv.notify_all();
     xt.join();
@@ -246,6 +357,8 @@ int overlap_allgather(ivj_comm* c, ivj_index* ix, const ivj_side* probe, const i
     if (n_local_out) *n_local_out = local_sum;
     if (rc != IVJ_OK) { g_err = main_err; return rc; }
     if (x_rc != IVJ_OK) { g_err = x_err; return x_rc; }
+    if (peer_failed) return fail(IVJ_EPEER, "rank " + std::to_string(failed_peer) + " failed in chunk " + std::to_string(failed_chunk) + " of the sharded overlap; its pairs from there on are missing");
+    if (overflow) return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(dst_off) + " pairs (on some rank): nothing was exchanged past the first chunk that did not fit");
     return IVJ_OK;
 }
 

@@ -127,6 +127,8 @@ struct ivj_ctx {
     std::vector<ivj_index*> live;
     // streaming sessions opened on this context that are still alive: ivj_ctx_destroy releases and detaches them
     std::vector<struct ivj_stream*> streams;
+    // communicators created on this context that are still alive: ivj_ctx_destroy detaches them (their handles stay destroyable)
+    std::vector<struct ivj_comm*> comms;
 };
 
 struct ivj_index {

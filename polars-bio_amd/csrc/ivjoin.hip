@@ -104,6 +104,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     while (!ctx->streams.empty()) stream_release(ctx->streams.back(), false);   // live streaming sessions: released and detached (their handles stay closable)
     for (ivj_index* ix : ctx->live) ix->ctx = nullptr;          // detached: they keep (and later free) their slabs
+    for (ivj_comm* cm : ctx->comms) comm_detach(cm);            // detached: no call runs on them any more, ivj_comm_destroy still releases them
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->ov_buf) (void)hipFree(ctx->ov_buf);
     if (ctx->sl_buf) (void)hipFree(ctx->sl_buf);
@@ -267,22 +268,46 @@ int ivj_comm_create(ivj_ctx* ctx, const void* unique_id, int rank, int world, iv
 int ivj_comm_create_local(ivj_ctx* const* ctxs, int n, ivj_comm** out) try {
     if (!ctxs || !out || n < 1) return fail(IVJ_EINVAL, "ctxs / out is NULL or n < 1");
     std::vector<RcclComm> comms((size_t)n, nullptr);
+    LoopGroup* loop = nullptr;
     if (n > 1) {
-        const RcclApi* api = rccl_api();
-        if (!api) return fail(IVJ_EHIP, g_rccl.error);
         std::vector<int> devs((size_t)n);
+        bool shared = false;
         for (int i = 0; i < n; ++i) {
             if (!ctxs[i]) return fail(IVJ_EINVAL, "a context is NULL");
             devs[i] = ctxs[i]->device;
-            for (int j = 0; j < i; ++j) if (devs[j] == devs[i]) return fail(IVJ_EINVAL, "RCCL needs one device per rank: two contexts share device " + std::to_string(devs[i]));
+            for (int j = 0; j < i; ++j) if (devs[j] == devs[i]) shared = true;
         }
-        RCCL_TRY(api, api->CommInitAll(comms.data(), n, devs.data()));
+        const char* ev = std::getenv("IVJ_COMM_LOOPBACK");
+        if (shared || (ev && std::atoi(ev) != 0)) {
+            // RCCL needs one device per rank; ranks that share a device (a 1-GPU box running the world-n protocol), or a host
+            // that asks for it, get the in-process transport
+            loop = new LoopGroup();
+            loop->world = n; loop->refs = n;
+            loop->vals.assign((size_t)n * 2, 0);
+            loop->send.assign((size_t)n * LoopGroup::MAX_COLS, nullptr);
+            loop->cnt.assign((size_t)n, 0);
+        } else {
+            const RcclApi* api = rccl_api();
+            if (!api) return fail(IVJ_EHIP, g_rccl.error);
+            RCCL_TRY(api, api->CommInitAll(comms.data(), n, devs.data()));
+        }
     }
     for (int i = 0; i < n; ++i) {
         ivj_comm* c = new ivj_comm();
-        c->ctx = ctxs[i]; c->rank = i; c->world = n; c->comm = comms[i];
+        c->ctx = ctxs[i]; c->rank = i; c->world = n; c->comm = comms[i]; c->loop = loop;
         const int rc = comm_finish_create(c);
-        if (rc != IVJ_OK) { ivj_comm_destroy(c); for (int j = 0; j < i; ++j) { ivj_comm_destroy(out[j]); out[j] = nullptr; } return rc; }
+        if (rc != IVJ_OK) {
+            const std::string why = g_err;
+            ivj_comm_destroy(c);
+            for (int j = 0; j < i; ++j) { ivj_comm_destroy(out[j]); out[j] = nullptr; }
+            if (loop && n - 1 - i > 0) {                 // the communicators never made: drop their references too
+                bool last;
+                { std::lock_guard<std::mutex> lk(loop->mu); loop->refs -= n - 1 - i; last = loop->refs == 0; }
+                if (last) delete loop;
+            }
+            g_err = why;
+            return rc;
+        }
         out[i] = c;
     }
     return IVJ_OK;
@@ -290,9 +315,15 @@ int ivj_comm_create_local(ivj_ctx* const* ctxs, int n, ivj_comm** out) try {
 
 void ivj_comm_destroy(ivj_comm* c) {
     if (!c) return;
-    DeviceGuard g(c->ctx ? c->ctx->device : 0);
+    DeviceGuard g(c->device);
+    if (c->ctx) { auto& v = c->ctx->comms; v.erase(std::remove(v.begin(), v.end(), c), v.end()); }
     if (c->xstream) { (void)hipStreamSynchronize(c->xstream); }
     if (c->comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
+    if (c->loop) {
+        bool last;
+        { std::lock_guard<std::mutex> lk(c->loop->mu); last = --c->loop->refs == 0; }
+        if (last) delete c->loop;
+    }
     for (auto& b : c->stage) if (b) (void)hipFree(b);
     if (c->iota) (void)hipFree(c->iota);
     if (c->d_counts) (void)hipFree(c->d_counts);
@@ -310,12 +341,14 @@ int ivj_comm_info(const ivj_comm* c, int* rank, int* world) try {
 
 int ivj_allgather_counts(ivj_comm* c, int64_t n_local, int64_t* counts) try {
     if (!c || !counts || n_local < 0) return fail(IVJ_EINVAL, "comm / counts is NULL or n_local < 0");
+    if (!c->ctx) return fail(IVJ_ESTATE, "the communicator's context was destroyed");
     DeviceGuard g(c->ctx->device);
     return comm_allgather_counts(c, n_local, counts);
 } IVJ_ABI_CATCH
 
 int ivj_allgatherv_dev(ivj_comm* c, const void* const* send_cols, void* const* recv_cols, int n_cols, int elem_bytes, const int64_t* counts) try {
     if (!c || !send_cols || !recv_cols || !counts || n_cols < 1 || elem_bytes < 1) return fail(IVJ_EINVAL, "bad all-gatherv arguments");
+    if (!c->ctx) return fail(IVJ_ESTATE, "the communicator's context was destroyed");
     DeviceGuard g(c->ctx->device);
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));                   // the payload is whatever the context's stream produced
     IVJ_TRY(comm_exchange(c, send_cols, recv_cols, n_cols, elem_bytes, counts, 0));
@@ -326,6 +359,7 @@ int ivj_allgatherv_dev(ivj_comm* c, const void* const* send_cols, void* const* r
 int ivj_overlap_allgather_dev(ivj_comm* c, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int n_chunks,
                               int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_total, int64_t* n_local) try {
     if (!c || !ix || !n_total) return fail(IVJ_EINVAL, "comm, index or n_total is NULL");
+    if (!c->ctx) return fail(IVJ_ESTATE, "the communicator's context was destroyed");
     IVJ_TRY(check_opts(opts));
     IVJ_TRY(check_side(probe_dev, "probe"));
     if (n_chunks < 1 || n_chunks > 64) return fail(IVJ_EINVAL, "n_chunks must be in 1 .. 64");

@@ -44,8 +44,16 @@ STREAM_OVERLAP, STREAM_COUNT, STREAM_NEAREST = 0, 1, 2
 ROW_COLUMNS = ("probe_idx", "build_idx", "contig", "start_1", "end_1", "start_2", "end_2")
 
 
+IVJ_ECAPACITY, IVJ_ESTATE, IVJ_EPEER = -4, -5, -6
+
+
 class EngineError(RuntimeError):
-    """HIP / engine failure (the reference surfaces these as PanicException)."""
+    """HIP / engine failure (the reference surfaces these as PanicException).  ``code`` = the IVJ_E* status."""
+    code = 0
+
+
+class PeerError(EngineError):
+    """A multi-rank call completed on this rank but ANOTHER rank failed (IVJ_EPEER): the gathered result is incomplete."""
 
 
 class _Side(C.Structure):
@@ -193,7 +201,9 @@ def load_library() -> C.CDLL:
 def _check(L, rc: int, what: str):
     if rc != 0:
         msg = L.ivj_last_error()
-        raise EngineError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        err = (PeerError if rc == IVJ_EPEER else EngineError)(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        err.code = rc
+        raise err
 
 
 def device_count() -> int:

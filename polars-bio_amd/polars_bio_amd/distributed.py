@@ -68,11 +68,20 @@ def shard_sides(probe, build, n_contigs: int, rank: int, world: int):
     return (pc[pi], ps[pi], pe[pi]), pi, (bc[bi], bs[bi], be[bi]), bi, mode
 
 
-def all_gatherv(tensors, group=None):
+class PeerFailure(RuntimeError):
+    """Another rank's join failed: this rank's share is complete, the gathered result is not (the C ABI's IVJ_EPEER)."""
+
+
+def all_gatherv(tensors, group=None, local_error=None, device=None):
     """All-gatherv of equally-typed 1-D tensors (one list entry per payload, e.g. probe_idx and
     build_idx).  Every rank ends up with, for each payload, the concatenation over ranks in rank
     order.  One all_gather of the lengths, then ONE grouped batch of isend/irecv (RCCL:
     ncclGroupStart/End around ncclSend/ncclRecv -> every pair of GPUs uses its own xGMI link).
+
+    Failure protocol (the one of ivj_overlap_allgather_dev, include/ivjoin.h): a rank whose join failed still calls
+    this -- ``tensors=None, local_error=<its exception>, device=<where the collectives run>`` -- so the length
+    all_gather is never short of a rank; it carries -1 for that rank, NO rank posts a send or a receive, the failed
+    rank re-raises its own error and every other rank raises ``PeerFailure``.  ``join_then_gatherv`` wraps that.
 
     Returns (list of gathered tensors, counts per rank as a python list)."""
     import torch
@@ -80,12 +89,18 @@ def all_gatherv(tensors, group=None):
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    n_local = int(tensors[0].shape[0])
-    dev = tensors[0].device
+    failed = local_error is not None or tensors is None
+    n_local = -1 if failed else int(tensors[0].shape[0])
+    dev = torch.device(device) if failed and device is not None else (tensors[0].device if not failed else torch.device("cpu"))
     cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
     cnts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(cnts, cnt, group=group)
     counts = [int(x) for x in cnts.tolist()]
+    bad = [r for r, c in enumerate(counts) if c < 0]
+    if bad:
+        if failed:
+            raise local_error if local_error is not None else RuntimeError("all_gatherv: this rank brought no tensors")
+        raise PeerFailure(f"rank(s) {bad} failed before the exchange; nothing was gathered")
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     outs = [torch.empty(int(offs[-1]), dtype=t.dtype, device=dev) for t in tensors]
     ops = []
@@ -102,6 +117,17 @@ def all_gatherv(tensors, group=None):
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return outs, counts
+
+
+def join_then_gatherv(join_fn, group=None, device="cpu"):
+    """``join_fn() -> [tensors]`` (this rank's shard joined) followed by the all-gatherv, such that a join that raises on
+    one rank strands nobody: that rank takes part in the length exchange with a failure mark and re-raises, the others
+    raise ``PeerFailure``.  ``device``: where the collectives of this group run ("cpu" for gloo, the rank's GPU for RCCL)."""
+    try:
+        tensors, err = join_fn(), None
+    except Exception as e:                      # noqa: BLE001 -- whatever the join raised travels to the caller below
+        tensors, err = None, e
+    return all_gatherv(tensors, group=group, local_error=err, device=device)
 
 
 def gather_per_probe(values, row_ids, n_total: int, fill=0, group=None):

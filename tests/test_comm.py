@@ -102,11 +102,147 @@ def test_world1_allgatherv_copies_the_local_columns():
     eng.close()
 
 
-def test_create_local_refuses_two_ranks_on_one_device():
-    e0, e1 = _engine.Engine(0), _engine.Engine(0)
-    with pytest.raises(_engine.EngineError, match="one device per rank"):
-        _engine.Comm.create_local([e0, e1])
-    e0.close(); e1.close()
+def test_world1_fault_injection_returns_the_injected_error(monkeypatch):
+    """IVJ_FAULT_ALLGATHER fails chunk 1 of 3 on rank 0: the call comes back (no chunk is skipped on the way to the
+    collectives) with the join's own error, and the communicator serves the next call."""
+    eng = _engine.Engine(0)
+    rng = np.random.default_rng(11)
+    probe = random_side(rng, 30000, 4, 300000, 300)
+    build = random_side(rng, 10000, 3, 300000, 300)
+    total = len(O.overlap_fast(O.Index(O.Side(*build), 3), O.Side(*probe), True)[0])
+    comm = _engine.Comm(eng, None, 0, 1)
+    d = _Dev(eng, probe, build)
+    try:
+        opts = _engine.make_opts(True, 3)
+        ix = eng.index_build_dev(d.build, opts)
+        op, ob = d.alloc(4 * total), d.alloc(4 * total)
+        monkeypatch.setenv("IVJ_FAULT_ALLGATHER", "0:1")
+        with pytest.raises(_engine.EngineError, match="injected fault") as ei:
+            comm.overlap_allgather_dev(ix, d.probe, opts, 3, op, ob, total)
+        assert ei.value.code == -2 and not isinstance(ei.value, _engine.PeerError)
+        monkeypatch.delenv("IVJ_FAULT_ALLGATHER")
+        nt, nl, fits = comm.overlap_allgather_dev(ix, d.probe, opts, 3, op, ob, total)
+        assert fits and nt == nl == total
+        ix.close()
+    finally:
+        d.close()
+    comm.close()
+    eng.close()
+
+
+def _loopback_pair():
+    """Two contexts on device 0 + the library's in-process transport: the world-2 protocol on a 1-GPU box."""
+    engines = [_engine.Engine(0), _engine.Engine(0)]
+    return engines, _engine.Comm.create_local(engines)
+
+
+def _run_ranks(target, argsets, timeout=240):
+    th = [threading.Thread(target=target, args=a, daemon=True) for a in argsets]
+    for t in th: t.start()
+    for t in th: t.join(timeout)
+    assert not any(t.is_alive() for t in th), "a rank hangs in a collective"
+
+
+def _loop_inputs(seed=9, nc=6):
+    rng = np.random.default_rng(seed)
+    probe = random_side(rng, 200000, nc, 2_000_000, 400)
+    build = random_side(rng, 60000, nc, 2_000_000, 400)
+    ep, eb = _canon(*O.overlap_fast(O.Index(O.Side(*build), nc), O.Side(*probe), True))
+    return probe, build, nc, ep, eb
+
+
+def test_two_ranks_on_one_device_over_the_loopback_transport():
+    """ivj_comm_create_local with two contexts on ONE device: the in-process transport carries the same calls RCCL would
+    (count all-gather + exchange of every chunk); every rank ends up with every pair."""
+    probe, build, nc, ep, eb = _loop_inputs()
+    engines, comms = _loopback_pair()
+    out = {}
+    _run_ranks(_shard_job, [(engines[r], comms[r], probe, build, nc, r, 2, len(ep), 4, out) for r in range(2)])
+    assert sorted(out) == [0, 1]
+    for r in range(2):
+        nt, nl, fits, hp, hb = out[r]
+        assert fits and nt == len(ep)
+        gp, gb = _canon(hp, hb)
+        assert (gp == ep).all() and (gb == eb).all(), r
+    assert out[0][1] + out[1][1] == len(ep) and min(out[0][1], out[1][1]) > 0
+    assert comms[0].allgather_counts is not None
+    for c in comms: c.close()
+    for e in engines: e.close()
+
+
+def _shard_job_catching(eng, comm, probe, build, nc, rank, world, cap, chunks, out):
+    try:
+        _shard_job(eng, comm, probe, build, nc, rank, world, cap, chunks, out)
+    except _engine.EngineError as e:
+        out[rank] = e
+
+
+def test_loopback_world2_failed_join_on_one_rank_strands_nobody(monkeypatch):
+    """Rank 0's join of chunk 1 (of 4) fails: rank 0 still reaches the count all-gather of chunks 1, 2, 3 with a failure
+    mark, rank 1 completes all four and returns IVJ_EPEER -- nobody hangs (the header's contract, include/ivjoin.h)."""
+    probe, build, nc, ep, eb = _loop_inputs(seed=10)
+    engines, comms = _loopback_pair()
+    monkeypatch.setenv("IVJ_FAULT_ALLGATHER", "0:1")
+    monkeypatch.setenv("IVJ_COMM_LOOPBACK_TIMEOUT", "30")
+    out = {}
+    _run_ranks(_shard_job_catching, [(engines[r], comms[r], probe, build, nc, r, 2, len(ep), 4, out) for r in range(2)])
+    assert isinstance(out[0], _engine.EngineError) and out[0].code == -2 and "injected fault" in str(out[0])
+    assert isinstance(out[1], _engine.PeerError) and out[1].code == -6 and "rank 0 failed in chunk 1" in str(out[1])
+    # and the communicators are in step afterwards
+    monkeypatch.delenv("IVJ_FAULT_ALLGATHER")
+    out = {}
+    _run_ranks(_shard_job, [(engines[r], comms[r], probe, build, nc, r, 2, len(ep), 4, out) for r in range(2)])
+    for r in range(2):
+        assert out[r][2] and out[r][0] == len(ep)
+        gp, gb = _canon(out[r][3], out[r][4])
+        assert (gp == ep).all() and (gb == eb).all()
+    for c in comms: c.close()
+    for e in engines: e.close()
+
+
+def _cap_job(eng, comm, probe, build, nc, rank, cap, total, out):
+    (lp, pid, lb, bid, _mode) = D.shard_sides(probe, build, nc, rank, 2)
+    d = _Dev(eng, lp, lb, pid)
+    try:
+        bptr = d.alloc(4 * len(bid)); eng.h2d(bptr, bid)
+        opts = _engine.make_opts(True, nc)
+        ix = eng.index_build_dev(eng.dev_side(d.build.contig, d.build.start, d.build.end, len(bid), bptr), opts)
+        op, ob = d.alloc(4 * total + 64), d.alloc(4 * total + 64)
+        guard = np.full(16, -7, np.int32)
+        eng.h2d(op + 4 * cap, guard)
+        out[rank] = comm.overlap_allgather_dev(ix, d.probe, opts, 4, op, ob, cap)
+        back = np.empty(16, np.int32)
+        eng.d2h(back, op + 4 * cap)
+        assert (back == -7).all(), "written past the capacity"
+        ix.close()
+    finally:
+        d.close()
+
+
+def test_loopback_world2_capacity_too_small_on_one_rank_reports_the_full_need():
+    """Rank 1's columns are too small: BOTH ranks stop moving pairs at the same chunk (decided from the gathered values),
+    both keep counting, both return IVJ_ECAPACITY with *n_total = the total the call needs."""
+    probe, build, nc, ep, eb = _loop_inputs(seed=12)
+    total = len(ep)
+    engines, comms = _loopback_pair()
+    out = {}
+    _run_ranks(_cap_job, [(engines[0], comms[0], probe, build, nc, 0, total, total, out),
+                          (engines[1], comms[1], probe, build, nc, 1, total // 2, total, out)])
+    for r in range(2):
+        nt, nl, fits = out[r]
+        assert not fits and nt == total, (r, out[r])
+    assert out[0][1] + out[1][1] == total
+    for c in comms: c.close()
+    for e in engines: e.close()
+
+
+def test_context_destroyed_under_a_live_communicator():
+    eng = _engine.Engine(0)
+    comm = _engine.Comm(eng, None, 0, 1)
+    eng.close()
+    with pytest.raises(_engine.EngineError, match="context was destroyed"):
+        comm.allgather_counts(3)
+    comm.close()                                             # still releases its own resources
 
 
 def _shard_job(eng, comm, probe, build, nc, rank, world, total, chunks, out):

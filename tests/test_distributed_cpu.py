@@ -147,3 +147,42 @@ def test_two_rank_gloo_per_probe_results_in_probe_order(tmp_path, n_contigs):
         assert (gn[owned] == en[owned]).all() and (en[~owned] == 0).all()
         assert (gi[owned] == ei[owned]).all() and (gd[owned] == ed[owned]).all()
         assert (gi == ei).all() and (gd == ed).all()           # rows nobody owns read -1 like the single-process result
+
+
+def _worker_fault(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from datetime import timedelta
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
+
+    def join():
+        if rank == 0:
+            raise ValueError("injected join failure on rank 0")
+        return [torch.arange(10, dtype=torch.int32), torch.arange(10, dtype=torch.int32)]
+    try:
+        D.join_then_gatherv(join)
+        outcome = "ok"
+    except D.PeerFailure as e:
+        outcome = "peer:" + str(e)
+    except ValueError as e:
+        outcome = "own:" + str(e)
+    # the group is still usable: nobody is parked in a half-posted exchange
+    (a,), counts = D.join_then_gatherv(lambda: [torch.full((rank + 1,), rank, dtype=torch.int32)])
+    with open(os.path.join(out_dir, f"o{rank}.txt"), "w") as f:
+        f.write(outcome + "|" + ",".join(map(str, a.tolist())) + "|" + ",".join(map(str, counts)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_join_failure_strands_nobody(tmp_path):
+    """Fault injection on the torch.distributed host: rank 0's join raises; rank 0 re-raises its own error, rank 1 gets
+    PeerFailure, neither hangs in the exchange, and the next collective on the same group works."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_fault, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    o0 = (tmp_path / "o0.txt").read_text().split("|")
+    o1 = (tmp_path / "o1.txt").read_text().split("|")
+    assert o0[0] == "own:injected join failure on rank 0"
+    assert o1[0].startswith("peer:rank(s) [0] failed")
+    assert o0[1] == o1[1] == "0,1,1" and o0[2] == o1[2] == "1,2"

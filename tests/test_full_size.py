@@ -257,6 +257,14 @@ def test_bench_gpus_2_on_whatever_devices_there_are():
     assert j["exchange"] == ("lib" if _device_count() >= 2 else "torch-gloo")
     ph = j["phases_ms"]
     assert ph["join"] > 0 and ph["no_gather_value"] > 0
+    # the roofline of a kernel that runs several times per step (the chunked join) is priced per LAUNCH on a launch's share of
+    # the bytes: frac x (kernel time per step) and pipeline_frac x (step time) are the same bytes, and frac cannot pass 1
+    rf = j["roofline"]
+    k_ms = rf["kernels_ms_per_step"][rf["kernel"]]
+    step_bytes_a, step_bytes_b = rf["frac"] * k_ms, rf["pipeline_frac"] * j["ms_per_step"]
+    assert 0 < rf["frac"] <= 1.0 and k_ms <= j["ms_per_step"] * 1.001
+    assert abs(step_bytes_a - step_bytes_b) <= 0.05 * step_bytes_b + 1e-4, rf
+    assert abs(rf["algorithmic_bytes_per_launch"] * rf["launches_per_step"] / rf["algorithmic_bytes"] - 1) < 0.01
     from polars_bio_amd import synth
     exp = synth.expected_pairs(int(100_000_000 * 0.03), int(5_000_000 * 0.03), 24)
     assert abs(j["config"]["units_per_step"] / exp - 1) < 0.05
