@@ -861,6 +861,8 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
     // reserves the range with the one global atomic and publishes the base in LDS; the others look at it one iteration later.
     load_tile(q0);
     const int ntile = (int)((q1 - q0 + CS_TILE - 1) / CS_TILE);
+    const int spin_bound = (A.ablate & SL_ABLATE_TILE_FAULT) ? SL_SPIN_BOUND_TEST : SL_SPIN_BOUND;
+    const bool tile_fault = (A.ablate & SL_ABLATE_TILE_FAULT) && v == 0;
     int pend_wtot = -1;                                                        // this wavefront's staged pairs of the previous tile
     long long pend_woff = 0;
     for (int tix = 0; tix <= ntile; ++tix) {
@@ -870,8 +872,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
             __builtin_amdgcn_wave_barrier();
             int* c = li + ((tix - 1) & 1) * 4;
             unsigned long long* c64 = lc + ((tix - 1) & 1) * 2;
-            for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
-            const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool timed_out = false;
+            IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
+            long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (timed_out) tb = -1;
             if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
                 int32_t* op = A.out_probe + tb + pend_woff;
                 int32_t* ob = A.out_build + tb + pend_woff;
@@ -893,7 +897,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
         if (tix == ntile) break;
         int* c = li + (tix & 1) * 4;
         unsigned long long* c64 = lc + (tix & 1) * 2;
-        for (int spin = 0; ld(c + 3) != tix && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // the block is ours (recycled after tile tix - 2)
+        IVJ_TILE_WAIT(ld(c + 3) != tix, spin_bound, A.state, lane, return);       // the block is ours (recycled after tile tix - 2)
         int lsum = 0;
 #pragma unroll
         for (int j = 0; j < CS_ITEMS; ++j) lsum += cnt[j];
@@ -907,10 +911,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
                 long long base = 0;
                 if (total > 0) {
                     base = (long long)atomicAdd(&A.state[0], (unsigned long long)total);
-                    if (base + total > A.capacity) { atomicExch(&A.state[1], 1ull); base = -1; }
+                    if (base + total > A.capacity) { atomicOr(&A.state[1], 1ull); base = -1; }
                 }
                 __hip_atomic_store(c64 + 1, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                stv(c + 2, 1);
+                if (!(tile_fault && tix == 0)) stv(c + 2, 1);
             }
         }
         woff = ((long long)__builtin_amdgcn_readfirstlane((int)(woff >> 32)) << 32) | (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(woff & 0xffffffffll));
@@ -935,8 +939,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
             pend_wtot = wtot;
         } else if (wtot > 0) {
             // dense wavefront or windows running on below the examined rows: wait for the base now, write from the lanes
-            for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
-            const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool timed_out = false;
+            IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
+            long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (timed_out) tb = -1;
             if (tb >= 0) {
                 long long off = tb + woff + (linc - lsum);
 #pragma unroll
@@ -1295,6 +1301,8 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     // reserves the range with the one global atomic and publishes the base in LDS; the others look at it one iteration later.
     load_tile(q0);
     const int ntile = (int)((q1 - q0 + CS_TILE - 1) / CS_TILE);
+    const int spin_bound = (A.ablate & SL_ABLATE_TILE_FAULT) ? SL_SPIN_BOUND_TEST : SL_SPIN_BOUND;
+    const bool tile_fault = (A.ablate & SL_ABLATE_TILE_FAULT) && v == 0;
     int pend_wtot = -1;                                                        // this wavefront's staged pairs of the previous tile
     bool pend_below = false;                                                   //   ... some of them below the slice
     long long pend_woff = 0;
@@ -1305,8 +1313,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             __builtin_amdgcn_wave_barrier();
             int* c = li + ((tix - 1) & 1) * 4;
             unsigned long long* c64 = lc + ((tix - 1) & 1) * 2;
-            for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
-            const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool timed_out = false;
+            IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
+            long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (timed_out) tb = -1;
             if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
                 copy_out(A.out_probe + tb + pend_woff, A.out_build + tb + pend_woff, pend_wtot, pend_below);
             }
@@ -1321,7 +1331,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         if (tix == ntile) break;
         int* c = li + (tix & 1) * 4;
         unsigned long long* c64 = lc + (tix & 1) * 2;
-        for (int spin = 0; ld(c + 3) != tix && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // the block is ours (recycled after tile tix - 2)
+        IVJ_TILE_WAIT(ld(c + 3) != tix, spin_bound, A.state, lane, return);       // the block is ours (recycled after tile tix - 2)
         int lsum = 0;
 #pragma unroll
         for (int j = 0; j < CS_ITEMS; ++j) lsum += cnt[j];
@@ -1335,10 +1345,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
                 long long base = 0;
                 if (total > 0) {
                     base = (long long)atomicAdd(&A.state[0], (unsigned long long)total);
-                    if (base + total > A.capacity) { atomicExch(&A.state[1], 1ull); base = -1; }
+                    if (base + total > A.capacity) { atomicOr(&A.state[1], 1ull); base = -1; }
                 }
                 __hip_atomic_store(c64 + 1, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                stv(c + 2, 1);
+                if (!(tile_fault && tix == 0)) stv(c + 2, 1);
             }
         }
         woff = ((long long)__builtin_amdgcn_readfirstlane((int)(woff >> 32)) << 32) | (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(woff & 0xffffffffll));
@@ -1356,8 +1366,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             pend_below = any_lng && __ballot(below) != 0;
         } else if (wtot > 0) {
             // dense wavefront: wait for the base now, write from the lanes
-            for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
-            const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool timed_out = false;
+            IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
+            long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (timed_out) tb = -1;
             if (tb >= 0) {
                 long long off = tb + woff + (linc - lsum);
 #pragma unroll

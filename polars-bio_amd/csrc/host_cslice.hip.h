@@ -205,6 +205,8 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
     *n_pairs = ctx->h_total[0];
+    if (ctx->h_total[1] & 2)          // a bounded wait of the fused tile protocol ran out: the pairs cannot be trusted
+        return fail(IVJ_EHIP, "tile protocol timeout in the fused slice join: a workgroup waited for a tile base that never came; the result was discarded");
     if (ctx->h_total[1] != 0)
         return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->h_total[0]) + " pairs");
     return IVJ_OK;

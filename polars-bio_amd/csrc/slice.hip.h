@@ -560,6 +560,22 @@ __device__ __forceinline__ int32_t slice_row(const int32_t* l_row, const int32_t
     return v;
 }
 
+// The bounded waits of the fused tile protocol.  A protocol bug must neither hang the box nor pass unseen: a wait that runs out
+// raises bit 1 of the call's state word (bit 0: the capacity was exceeded) and the host reports IVJ_EHIP "tile protocol timeout"
+// instead of pairs that may be wrong.  IVJ_SLICE_ABLATE bit 4096 (test knob): workgroup 0 never publishes the base of its first
+// tile and the bound drops to SL_SPIN_BOUND_TEST, so the failure path runs in milliseconds.
+constexpr int SL_SPIN_BOUND = 1 << 24;
+constexpr int SL_SPIN_BOUND_TEST = 1 << 8;
+constexpr int SL_ABLATE_TILE_FAULT = 4096;
+#define IVJ_TILE_WAIT(STILL_WAITING, BOUND, STATE, LANE, ON_TIMEOUT)                                                            \
+    {                                                                                                                           \
+        int spin_ = 0;                                                                                                          \
+        for (; (STILL_WAITING) && spin_ < (BOUND); ++spin_) __builtin_amdgcn_s_sleep(1);                                        \
+        if (__builtin_expect(spin_ >= (BOUND), 0)) {                                                                            \
+            if (STILL_WAITING) { if ((LANE) == 0) atomicOr((STATE) + 1, 2ull); ON_TIMEOUT; }                                    \
+        }                                                                                                                       \
+    }
+
 struct SliceJoinArgs {
     // the build index as this kernel needs it (a slim copy: the full IndexView costs ~50 SGPRs of kernel arguments)
     const int32_t* b_start;
@@ -856,6 +872,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
         auto stv = [](int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
         load_tile(q0);
         const int ntile = (int)((q1 - q0 + TILE - 1) / TILE);
+        const int spin_bound = (A.ablate & SL_ABLATE_TILE_FAULT) ? SL_SPIN_BOUND_TEST : SL_SPIN_BOUND;
+        const bool tile_fault = (A.ablate & SL_ABLATE_TILE_FAULT) && v == 0;
         int pend_wtot = -1;                                                    // this wavefront's staged pairs of the previous tile
         long long pend_woff = 0;
         for (int tix = 0; tix <= ntile; ++tix) {
@@ -864,8 +882,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                 // finish tile tix - 1: its base was requested one iteration ago
                 int* c = li + ((tix - 1) & 1) * 4;
                 unsigned long long* c64 = lc + ((tix - 1) & 1) * 2;
-                for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
-                const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                bool timed_out = false;
+                IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
+                long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (timed_out) tb = -1;
                 if (tb >= 0 && pend_wtot > 0 && pend_wtot <= wcap && !(A.ablate & 32)) {
                     for (int i = lane; i < pend_wtot; i += kWave) {
                         const int2 pr = stw[i];
@@ -884,7 +904,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             if (tix == ntile) break;
             int* c = li + (tix & 1) * 4;
             unsigned long long* c64 = lc + (tix & 1) * 2;
-            for (int spin = 0; ld(c + 3) != tix && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // the block is ours (recycled after tile tix - 2)
+            IVJ_TILE_WAIT(ld(c + 3) != tix, spin_bound, A.state, lane, return);   // the block is ours (recycled after tile tix - 2)
             int lsum = 0;
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) lsum += cnt[j];
@@ -898,10 +918,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                     long long base = 0;
                     if (total > 0) {
                         base = (long long)atomicAdd(&A.state[0], (unsigned long long)total);
-                        if (base + total > A.capacity) { atomicExch(&A.state[1], 1ull); base = -1; }
+                        if (base + total > A.capacity) { atomicOr(&A.state[1], 1ull); base = -1; }
                     }
                     __hip_atomic_store(c64 + 1, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    stv(c + 2, 1);
+                    if (!(tile_fault && tix == 0)) stv(c + 2, 1);
                 }
             }
             woff = ((long long)__shfl((int)(woff >> 32), 0, kWave) << 32) | (unsigned long long)(unsigned int)__shfl((int)(woff & 0xffffffffll), 0, kWave);
@@ -932,8 +952,10 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
                 }
             } else if (wtot > wcap) {
                 // dense wavefront: its pairs do not fit the staging region -- wait for the base now and write them from the lanes
-                for (int spin = 0; ld(c + 2) == 0 && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);   // bounded: a bug must not hang the box
-                const long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                bool timed_out = false;
+                IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
+                long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (timed_out) tb = -1;
                 if (tb >= 0) {
                     long long off = tb + woff + (linc - lsum);
 #pragma unroll

@@ -1077,3 +1077,31 @@ def test_both_slice_join_kernels_on_both_kinds_of_build_side(walk, monkeypatch):
                 assert len(p1) == len(ep) and (p1[o] == ep).all() and (b1[o] == eb).all(), ("two-pass", strict)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("cs", ["1", "0"])
+def test_fused_tile_protocol_timeout_fails_loudly(cs, monkeypatch):
+    """The barrier-free tile loop of the fused slice joins waits on LDS words with a bound.  IVJ_SLICE_ABLATE bit 4096 makes
+    workgroup 0 never publish the base of its first tile (and shortens the bound): the call must come back with IVJ_EHIP
+    "tile protocol timeout" -- not with rc 0 and pairs that may be wrong.  Both slice paths (cslice.hip.h / slice.hip.h)."""
+    probe = synth.make_side(300_000, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(60_000, 43, synth.BUILD_LEN, 24)
+    total = len(O.overlap_fast(O.Index(O.Side(*build), 24), O.Side(*probe), True)[0])
+    monkeypatch.setenv("IVJ_CS", cs)
+    monkeypatch.setenv("IVJ_SLICE_ABLATE", "4096")
+    e = _engine.Engine(0)
+    try:
+        with pytest.raises(_engine.EngineError, match="tile protocol timeout") as ei:
+            _fused_overlap(e, probe, build, True, 24, 6, total)
+        assert ei.value.code == -2
+    finally:
+        e.close()
+    monkeypatch.delenv("IVJ_SLICE_ABLATE")
+    e = _engine.Engine(0)                       # the same call without the knob is exact
+    try:
+        hp, hb = _fused_overlap(e, probe, build, True, 24, 6, total)
+        ep, eb = O.overlap_fast(O.Index(O.Side(*build), 24), O.Side(*probe), True)
+        p, b = _canon(hp, hb)
+        assert (p == ep).all() and (b == eb).all()
+    finally:
+        e.close()
