@@ -159,6 +159,16 @@ def _to_pandas(t: pa.Table):
     return pd.DataFrame(frame, copy=False)
 
 
+def _decode_object_dict(t: pa.Table) -> pa.Table:
+    """The internal marker type of pandas object-string columns never leaves through a non-pandas output: such columns become
+    plain large_string again (what the reference's ``pl.from_pandas`` makes of an object column: String, not Categorical), and a
+    None / NaN row -- a null DICTIONARY VALUE behind a valid index -- becomes a null the column's null_count sees."""
+    marked = [i for i, f in enumerate(t.schema) if f.type == _OBJECT_DICT]
+    for i in marked:
+        t = t.set_column(i, t.schema.field(i).name, pc.cast(t.column(i), pa.large_string()))
+    return t
+
+
 def _coord_to_i32(col: pa.ChunkedArray, name: str) -> np.ndarray:
     if col.null_count:
         raise ValueError(f"column '{name}' contains nulls; interval coordinates must be non-null")
@@ -452,6 +462,8 @@ def from_arrow(t: pa.Table, output_type: str, zero_based: bool):
     """Arrow result -> the requested output kind, coordinate-system metadata attached
     (reference: range_op_helpers.py:36-53 ``_set_result_metadata``)."""
     from ._metadata import set_coordinate_system
+    if output_type != "pandas.DataFrame":
+        t = _decode_object_dict(t)
     if output_type == "pyarrow.Table":
         return set_coordinate_system(t, zero_based)
     if output_type == "pandas.DataFrame":

@@ -217,8 +217,9 @@ def _lazy_reader(df1, df2, zero_based, batches, assemble_empty):
     else:
         t2 = A.to_arrow(df2) if not isinstance(df2, pa.Table) else df2
         schema = assemble_empty(sch1.empty_table(), t2.slice(0, 0)).schema
-    schema = set_coordinate_system(schema.empty_table(), zero_based).schema
-    return S.range_reader(schema, batches)
+    # the marker type of pandas object-string columns (_arrow._OBJECT_DICT) never leaves through an Arrow stream
+    schema = set_coordinate_system(A._decode_object_dict(schema.empty_table()), zero_based).schema
+    return S.range_reader(schema, (A._decode_object_dict(b) for b in batches))
 
 
 def overlap_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, batch_rows: int = 8_000_000, limit=None,

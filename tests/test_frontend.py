@@ -579,3 +579,43 @@ def test_join_falls_back_to_index_pairs_when_the_key_columns_do_not_fit_the_host
     res = pb.overlap(_csv(f"{GOLDEN}/overlap/reads.csv"), _csv(f"{GOLDEN}/overlap/targets.csv"), cols1=COLS, cols2=COLS, output_type="pandas.DataFrame")
     assert calls == ["rows", "pairs"]
     pd.testing.assert_frame_equal(_sorted(res), _sorted(pd.read_csv(f"{GOLDEN}/expected_overlap.csv")))
+
+
+def test_pandas_object_columns_leave_as_plain_strings_through_non_pandas_outputs(engine, monkeypatch):
+    """The pointer-identity encoding of pandas object-string columns is internal: through pyarrow.Table / the lazy reader (and
+    polars, where installed) such columns come out as large_string -- what the reference's pl.from_pandas makes of an object
+    column (String, not Categorical) -- and a None / NaN row is a NULL the column's null_count sees."""
+    from polars_bio_amd import _arrow as A
+    monkeypatch.setattr(A, "_OBJECT_MIN_ROWS", 1)
+    rng = np.random.default_rng(3)
+    n1, n2 = 2000, 300
+    names = np.array(["chr1", "chr2", "chrX"], dtype=object)
+    c1 = names[rng.integers(0, 3, n1)]
+    c1[::50] = None
+    c1[7] = np.nan
+    tag = np.array(["a", "b"], dtype=object)[rng.integers(0, 2, n1)]
+    tag[3::40] = None
+    df1 = pd.DataFrame({"chrom": c1, "start": rng.integers(0, 50_000, n1), "tag": tag})
+    df1["end"] = df1["start"] + rng.integers(1, 400, n1)
+    df2 = pd.DataFrame({"chrom": names[rng.integers(0, 3, n2)], "start": rng.integers(0, 50_000, n2)})
+    df2["end"] = df2["start"] + rng.integers(1, 3000, n2)
+    for d in (df1, df2):
+        d.attrs["coordinate_system_zero_based"] = True
+    assert A.to_arrow(df1).schema.field("chrom").type == A._OBJECT_DICT          # the encoding is in use on the way in
+    t = pb.count_overlaps(df1, df2, output_type="pyarrow.Table")
+    assert t.schema.field("chrom").type == pa.large_string() and t.schema.field("tag").type == pa.large_string()
+    assert t.column("chrom").null_count == int(df1["chrom"].isna().sum()) > 0
+    assert t.column("tag").null_count == int(df1["tag"].isna().sum()) > 0
+    assert t.column("chrom").to_pylist() == [None if (x is None or x != x) else x for x in c1]
+    j = pb.overlap(df1, df2, output_type="pyarrow.Table")
+    for name in ("chrom_1", "tag_1", "chrom_2"):
+        assert j.schema.field(name).type == pa.large_string(), name
+    ref = pb.overlap(df1, df2, output_type="pandas.DataFrame")
+    assert sorted(zip(j.column("start_1").to_pylist(), j.column("start_2").to_pylist(), j.column("chrom_1").to_pylist())) == \
+        sorted(zip(ref["start_1"], ref["start_2"], ref["chrom_1"]))
+    rd = pb.overlap(df1, df2, output_type="pyarrow.RecordBatchReader")
+    assert all(f.type != A._OBJECT_DICT for f in rd.schema)
+    got = rd.read_all()
+    assert got.schema.field("chrom_1").type in (pa.large_string(), pa.string()) and got.num_rows == j.num_rows
+    n = pb.nearest(df1, df2, output_type="pyarrow.Table")
+    assert n.schema.field("chrom_1").type == pa.large_string() and n.schema.field("chrom_2").type == pa.large_string()

@@ -49,13 +49,13 @@ run_stage() {
     counters) (cd /tmp && rocprofv3 -L 2>/dev/null | grep -o "TCC_EA[A-Za-z0-9_]*\|TCC_REQ[A-Za-z0-9_]*\|TCC_READ[A-Za-z0-9_]*\|TCC_BUBBLE[A-Za-z0-9_]*" | sort -u | tr '\n' ' ') | tee $o.txt; echo ;;
     pmctcc*) echo "== PMC: L2 -> fabric read requests by size (workload ${WL:-count_200M_200k_24contig})";
       i=0; dirs="";
-      for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_REQ_sum TCC_READ_sum TCC_HIT_sum TCC_MISS_sum"; do
+      for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum" "TCC_REQ_sum TCC_READ_sum TCC_HIT_sum TCC_MISS_sum"; do
         i=$((i+1));
         (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $set -d "$OLDPWD/${o}_$i" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --workload ${WL:-count_200M_200k_24contig} --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extras > "$OLDPWD/${o}_$i.out" 2> "$OLDPWD/${o}_$i.err");
         tail -1 ${o}_$i.err | cut -c1-160; dirs="$dirs ${o}_$i";
       done;
       python tools/pmc_summary.py $dirs > $o.summary.json 2> $o.summary.err; tail -3 $o.summary.err;
-      python -c "import json,sys; d=json.load(open('$o.summary.json')); [print(k[:64], {n: round(v[n]['sum']/max(v[n]['rows'],1)) for n in v}) for k,v in d.items() if any(t in k for t in ('count_overlaps','nearest_k1','k_cs_join','k_cs_scatter'))]" ;;
+      python -c "import json,sys; d=json.load(open('$o.summary.json')); [print(k[:64], {n: round(v[n]['sum']/max(v[n]['rows'],1)) for n in v}) for k,v in d.items() if any(t in k for t in ('count_overlaps','nearest_k1','k_cs_join','k_cs_scatter','k_cs_hist','k_unpermute','k_part_scatter','k_overlap_fused'))]" ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     *) echo "unknown stage $stage" ;;
   esac
@@ -63,7 +63,7 @@ run_stage() {
 for stage in "$@"; do
   case "$stage" in
     env=*:*) kv=${stage#env=}; st=${kv#*:}; kv=${kv%%:*}; sfx=_${kv//[^A-Za-z0-9]/_};
-             ( IFS=,; for a in $kv; do export "$a"; done; echo "== [$kv] $st"; run_stage "$st" "$sfx" ) ;;
+             ( IFS=,; for a in $kv; do export "$a"; done; unset IFS; echo "== [$kv] $st"; run_stage "$st" "$sfx" ) ;;
     *) run_stage "$stage" "" ;;
   esac
 done
