@@ -401,6 +401,50 @@ int ivj_allgatherv_dev(ivj_comm* comm, const void* const* send_cols, void* const
 int ivj_overlap_allgather_dev(ivj_comm* comm, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int n_chunks,
                               int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_total, int64_t* n_local);
 
+/* ---- the one-call Arrow entry: two ArrowArrayStreams in, a stream of joined record batches out -------------------------- *
+ * This is the shape of the reference's own FFI: range_operation_frame / range_operation_lazy take df1 and df2 as Arrow C
+ * streams with a STRING chrom and start / end of any integer width and answer with a lazy frame of joined rows
+ * (/root/reference/src/lib.rs:79-145, 154-214; the renaming SELECT over the joined batches: src/operation.rs:272-301,
+ * 170-197).  A host binds ONE call per operation and re-implements nothing: both streams are drained (and released), chrom
+ * (utf8 / large_utf8 / a dictionary of those, per batch) is encoded with one dictionary over both sides, start / end
+ * (int8 .. int64, signed or unsigned) are narrowed to int32 with the reference's range check
+ * (docs/features/operations.md:36-37; nulls in a coordinate column and values beyond int32 are IVJ_EINVAL with the column's
+ * name), the join runs on the device through the host entry points above, and `out_stream` -- a caller-allocated
+ * `struct ArrowArrayStream` (https://arrow.apache.org/docs/format/CStreamInterface.html) -- yields the result in batches of
+ * batch_rows rows (<= 0: 1 Mi) that are assembled WHEN PULLED: every column of df1 named <name><suffix1>, then every
+ * column of df2 named <name><suffix2>, gathered by the pair indices (fixed-width primitives of 1 .. 32 bytes, bool,
+ * utf8 / large_utf8 / binary / large_binary; dictionary-encoded columns are delivered decoded to their value type; any
+ * other column type is refused by name).  cols1 / cols2: {chrom, start, end} column names, NULL = those defaults.
+ * opts->n_contigs is ignored (the dictionary is made inside).  limit >= 0 bounds the result rows (src/lib.rs:80-88, 125-130).
+ * The stream pointers are `struct ArrowArrayStream*` (void* here so that this header needs no Arrow declarations). */
+int ivj_overlap_arrow_stream(ivj_ctx* ctx, void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2,
+                             const ivj_opts* opts, const char* suffix1 /* NULL: "_1" */, const char* suffix2 /* NULL: "_2" */,
+                             int64_t batch_rows, int64_t limit, void* out_stream);
+/* df1 columns (<name><suffix1>, NULL: no suffix) + count: int64, df1 row order (range_op.py:418-511, src/operation.rs:306-350) */
+int ivj_count_overlaps_arrow_stream(ivj_ctx* ctx, void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2,
+                                    const ivj_opts* opts, const char* suffix1, int64_t batch_rows, int64_t limit, void* out_stream);
+/* per df1 row its opts->nearest_k nearest df2 rows (one result row each; a df1 row without any keeps one row with null df2
+ * columns), + distance: int64 when with_distance (src/operation.rs:100-200) */
+int ivj_nearest_arrow_stream(ivj_ctx* ctx, void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2,
+                             const ivj_opts* opts, const char* suffix1, const char* suffix2, int32_t with_distance, int64_t batch_rows,
+                             int64_t limit, void* out_stream);
+
+/* The two host halves of that call on their own (no device, no context): */
+/* ... the key columns the join sees: both streams drained (and released), chrom encoded, coordinates narrowed */
+typedef struct {
+    int64_t n1, n2;
+    int32_t *contig1, *start1, *end1;      /* n1 values each */
+    int32_t *contig2, *start2, *end2;      /* n2 values each */
+    int32_t n_contigs;
+    int64_t* name_offsets;                 /* n_contigs + 1: name v of the shared dictionary = name_bytes[name_offsets[v] .. name_offsets[v + 1]) */
+    char* name_bytes;
+} ivj_arrow_keys;
+int ivj_arrow_encode_keys(void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2, ivj_arrow_keys* out);
+void ivj_arrow_keys_free(ivj_arrow_keys* keys);
+/* ... the row assembly: rows idx[0 .. n) (negative or out of range: a null row) of the drained stream as a new stream */
+int ivj_arrow_take_stream(void* in_stream, const int64_t* idx, int64_t n, int64_t batch_rows, void* out_stream);
+
+
 /* ---- device memory helpers for callers without a HIP binding ------------ */
 int ivj_dev_alloc(ivj_ctx* ctx, int64_t bytes, void** out);
 int ivj_dev_free(ivj_ctx* ctx, void* p);

@@ -968,3 +968,4 @@ int ivj_memcpy_d2h(ivj_ctx* ctx, void* dst_host, const void* src_dev, int64_t by
 }  // extern "C"
 
 #include "host_frontdoor.hip.h"
+#include "host_arrow_stream.hip.h"

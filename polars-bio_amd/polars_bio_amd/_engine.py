@@ -36,6 +36,8 @@ ABI_SYMBOLS = [
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
     "ivj_comm_unique_id", "ivj_comm_create", "ivj_comm_create_local", "ivj_comm_destroy", "ivj_comm_info",
     "ivj_allgather_counts", "ivj_allgatherv_dev", "ivj_overlap_allgather_dev",
+    "ivj_overlap_arrow_stream", "ivj_count_overlaps_arrow_stream", "ivj_nearest_arrow_stream", "ivj_arrow_encode_keys", "ivj_arrow_keys_free",
+    "ivj_arrow_take_stream",
     "ivj_host_narrow_i32", "ivj_host_encode_utf8", "ivj_host_encode_keys64", "ivj_host_remap_i32", "ivj_host_take", "ivj_host_widen_i32",
 ]
 
@@ -59,6 +61,18 @@ class PeerError(EngineError):
 class _Side(C.Structure):
     _fields_ = [("contig", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p), ("n", C.c_int64),
                 ("row_id", C.c_void_p)]
+
+
+class _ArrowStream(C.Structure):
+    """struct ArrowArrayStream (Arrow C stream interface): five pointers."""
+    _fields_ = [("get_schema", C.c_void_p), ("get_next", C.c_void_p), ("get_last_error", C.c_void_p), ("release", C.c_void_p),
+                ("private_data", C.c_void_p)]
+
+
+class _ArrowKeys(C.Structure):
+    _fields_ = [("n1", C.c_int64), ("n2", C.c_int64), ("contig1", C.c_void_p), ("start1", C.c_void_p), ("end1", C.c_void_p),
+                ("contig2", C.c_void_p), ("start2", C.c_void_p), ("end2", C.c_void_p), ("n_contigs", C.c_int32),
+                ("name_offsets", C.c_void_p), ("name_bytes", C.c_void_p)]
 
 
 class _Opts(C.Structure):
@@ -194,6 +208,14 @@ def load_library() -> C.CDLL:
         L.ivj_host_remap_i32.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32]
         L.ivj_host_take.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, vp, C.c_int32]
         L.ivj_host_widen_i32.argtypes = [vp, C.c_int64, vp, C.c_int32]
+        names3 = C.POINTER(C.c_char_p)
+        L.ivj_overlap_arrow_stream.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, vp]
+        L.ivj_count_overlaps_arrow_stream.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_int64, C.c_int64, vp]
+        L.ivj_nearest_arrow_stream.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, vp]
+        L.ivj_arrow_encode_keys.argtypes = [vp, vp, names3, names3, C.POINTER(_ArrowKeys)]
+        L.ivj_arrow_keys_free.argtypes = [C.POINTER(_ArrowKeys)]
+        L.ivj_arrow_keys_free.restype = None
+        L.ivj_arrow_take_stream.argtypes = [vp, vp, C.c_int64, C.c_int64, vp]
         _lib = L
         return L
 
@@ -828,6 +850,93 @@ class Comm:
             return nt.value, nl.value, False
         _check(self.L, rc, "ivj_overlap_allgather_dev")
         return nt.value, nl.value, True
+
+
+# ---- the one-call Arrow entry (include/ivjoin.h: ivj_*_arrow_stream): what a C / Rust host binds, driven from Python -------------
+def _export_stream(src):
+    """Anything Arrow-streamable (pyarrow.Table / RecordBatchReader / an object with __arrow_c_stream__) -> a filled
+    struct ArrowArrayStream (the library drains and releases it)."""
+    import pyarrow as pa
+    if isinstance(src, pa.Table):
+        src = src.to_reader()
+    elif not isinstance(src, pa.RecordBatchReader):
+        src = pa.RecordBatchReader.from_stream(src)
+    s = _ArrowStream()
+    src._export_to_c(C.addressof(s))
+    return s
+
+
+def _import_stream(s: _ArrowStream):
+    import pyarrow as pa
+    return pa.RecordBatchReader._import_from_c(C.addressof(s))
+
+
+def _names3(cols):
+    if cols is None:
+        return None
+    return (C.c_char_p * 3)(*[str(c).encode() for c in cols])
+
+
+def arrow_encode_keys(df1, df2, cols1=None, cols2=None):
+    """ivj_arrow_encode_keys: -> ((contig, start, end) of df1, of df2, dictionary names); host only."""
+    L = load_library()
+    s1, s2 = _export_stream(df1), _export_stream(df2)
+    k = _ArrowKeys()
+    _check(L, L.ivj_arrow_encode_keys(C.addressof(s1), C.addressof(s2), _names3(cols1), _names3(cols2), C.byref(k)), "ivj_arrow_encode_keys")
+    try:
+        col = lambda p, n: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(n,)).copy() if n else np.empty(0, np.int32)
+        side1 = (col(k.contig1, k.n1), col(k.start1, k.n1), col(k.end1, k.n1))
+        side2 = (col(k.contig2, k.n2), col(k.start2, k.n2), col(k.end2, k.n2))
+        offs = np.ctypeslib.as_array(C.cast(k.name_offsets, C.POINTER(C.c_int64)), shape=(k.n_contigs + 1,))
+        raw = C.string_at(k.name_bytes, int(offs[-1]))
+        names = [raw[offs[i]:offs[i + 1]].decode() for i in range(k.n_contigs)]
+        return side1, side2, names
+    finally:
+        L.ivj_arrow_keys_free(C.byref(k))
+
+
+def arrow_take_stream(src, idx, batch_rows: int = 0):
+    """ivj_arrow_take_stream: rows idx (negative: a null row) of an Arrow stream as a new pyarrow.RecordBatchReader; host only."""
+    L = load_library()
+    s, out = _export_stream(src), _ArrowStream()
+    idx = np.ascontiguousarray(idx, np.int64)
+    _check(L, L.ivj_arrow_take_stream(C.addressof(s), C.c_void_p(idx.ctypes.data), len(idx), int(batch_rows), C.addressof(out)), "ivj_arrow_take_stream")
+    return _import_stream(out)
+
+
+def _arrow_stream_call(engine, op: str, df1, df2, cols1, cols2, strict: bool, suffixes, k: int = 1, include_overlaps: bool = True,
+                       distance: bool = True, batch_rows: int = 0, limit=None):
+    L = load_library()
+    s1, s2, out = _export_stream(df1), _export_stream(df2), _ArrowStream()
+    opts = make_opts(strict, 0, k, include_overlaps)
+    lim = -1 if limit is None else int(limit)
+    sfx = [None if x is None else str(x).encode() for x in suffixes]
+    with engine.lock:
+        if op == "overlap":
+            rc = L.ivj_overlap_arrow_stream(engine.h, C.addressof(s1), C.addressof(s2), _names3(cols1), _names3(cols2), C.byref(opts), sfx[0], sfx[1],
+                                            int(batch_rows), lim, C.addressof(out))
+        elif op == "count_overlaps":
+            rc = L.ivj_count_overlaps_arrow_stream(engine.h, C.addressof(s1), C.addressof(s2), _names3(cols1), _names3(cols2), C.byref(opts), sfx[0],
+                                                   int(batch_rows), lim, C.addressof(out))
+        else:
+            rc = L.ivj_nearest_arrow_stream(engine.h, C.addressof(s1), C.addressof(s2), _names3(cols1), _names3(cols2), C.byref(opts), sfx[0], sfx[1],
+                                            1 if distance else 0, int(batch_rows), lim, C.addressof(out))
+    _check(L, rc, f"ivj_{op}_arrow_stream")
+    return _import_stream(out)
+
+
+def overlap_arrow_stream(engine, df1, df2, strict: bool, cols1=None, cols2=None, suffixes=("_1", "_2"), batch_rows: int = 0, limit=None):
+    """ivj_overlap_arrow_stream -> pyarrow.RecordBatchReader of the joined rows (every column of both sides, suffixed)."""
+    return _arrow_stream_call(engine, "overlap", df1, df2, cols1, cols2, strict, suffixes, batch_rows=batch_rows, limit=limit)
+
+
+def count_overlaps_arrow_stream(engine, df1, df2, strict: bool, cols1=None, cols2=None, suffix="", batch_rows: int = 0, limit=None):
+    return _arrow_stream_call(engine, "count_overlaps", df1, df2, cols1, cols2, strict, (suffix, None), batch_rows=batch_rows, limit=limit)
+
+
+def nearest_arrow_stream(engine, df1, df2, strict: bool, cols1=None, cols2=None, suffixes=("_1", "_2"), k: int = 1, include_overlaps: bool = True,
+                         distance: bool = True, batch_rows: int = 0, limit=None):
+    return _arrow_stream_call(engine, "nearest", df1, df2, cols1, cols2, strict, suffixes, k, include_overlaps, distance, batch_rows, limit)
 
 
 _default_engine: Optional[Engine] = None

@@ -1,0 +1,192 @@
+"""The one-call Arrow entry of the C ABI (include/ivjoin.h: ivj_overlap_arrow_stream / ivj_count_overlaps_arrow_stream /
+ivj_nearest_arrow_stream) -- the shape the reference's FFI has: two ArrowArrayStreams with a string chrom and start / end of any
+integer width in, joined record batches out (/root/reference/src/lib.rs:79-145, 154-214; src/operation.rs:272-301).
+
+CPU: the two host halves on their own -- ivj_arrow_encode_keys (stream drain, chrom dictionary over both sides, int32 narrowing
+with the reference's range check) against the Python front door's encoder, ivj_arrow_take_stream (the row assembly: every column
+kind, multi-batch inputs, null rows) against pyarrow's take.  GPU: the whole call against pb.overlap / nearest / count_overlaps and
+the reference's golden tables."""
+import os
+
+import numpy as np
+import pandas as pd
+import pyarrow as pa
+import pytest
+
+import polars_bio_amd as pb
+from polars_bio_amd import _arrow as A
+from polars_bio_amd import _engine as E
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+COLS = ["contig", "pos_start", "pos_end"]
+
+
+def _frames(rng, n1=5000, n2=700, nulls=True):
+    names = np.array(["chr1", "chr2", "chrX", "chrUn_KI270302v1_a_long_name"], dtype=object)
+    c1 = names[rng.integers(0, 4, n1)]
+    if nulls:
+        c1[::97] = None
+    s1 = rng.integers(0, 60_000, n1)
+    t1 = pa.table({"chrom": pa.array(c1, pa.large_string()), "start": pa.array(s1, pa.int64()), "end": pa.array(s1 + rng.integers(1, 400, n1), pa.int64()),
+                   "score": pa.array(rng.normal(size=n1), pa.float64()), "flag": pa.array(rng.integers(0, 2, n1).astype(bool)),
+                   "name": pa.array([None if i % 53 == 0 else f"read{i % 311}" for i in range(n1)], pa.string()),
+                   "small": pa.array(rng.integers(-100, 100, n1), pa.int8()),
+                   "cat": pa.array(np.array(["a", "bb", "ccc"], dtype=object)[rng.integers(0, 3, n1)]).dictionary_encode()})
+    s2 = rng.integers(0, 60_000, n2)
+    t2 = pa.table({"chrom": pa.array(names[rng.integers(0, 3, n2)], pa.string()).dictionary_encode(), "start": pa.array(s2, pa.uint32()),
+                   "end": pa.array(s2 + rng.integers(1, 3000, n2), pa.uint32()), "gene": pa.array([f"g{i}" for i in range(n2)], pa.large_string()),
+                   "when": pa.array(rng.integers(0, 10**9, n2), pa.timestamp("us"))})
+    return t1, t2
+
+
+def _rechunk(t, sizes):
+    out, lo = [], 0
+    for k in sizes:
+        out.append(t.slice(lo, k)); lo += k
+    out.append(t.slice(lo))
+    return pa.concat_tables([x for x in out if x.num_rows])          # keeps the slices as separate chunks = separate batches
+
+
+def test_encode_keys_matches_the_front_door_encoder():
+    rng = np.random.default_rng(1)
+    t1, t2 = _frames(rng)
+    t1c, t2c = _rechunk(t1, [1000, 7, 2000]), _rechunk(t2, [100, 300])
+    side1, side2, names = E.arrow_encode_keys(t1c, t2c)
+    (e1, e2, nc, u) = A.encode_keys(t1, ["chrom", "start", "end"], t2, ["chrom", "start", "end"], with_dictionary=True)
+    assert len(names) == nc
+    # the numbering of the dictionaries may differ: compare through the names
+    ref_names = np.array(u.to_pylist() + [None], dtype=object)
+    got_names = np.array(names + [None], dtype=object)
+    for got, ref in ((side1, e1), (side2, e2)):
+        assert (got_names[got[0]] == ref_names[ref[0]]).all()
+        assert (got[1] == ref[1]).all() and (got[2] == ref[2]).all()
+    assert (side1[0][::97] == -1).all()                               # null chrom: id -1, matches nothing
+
+
+def test_encode_keys_errors_name_the_column():
+    t = pa.table({"chrom": ["chr1"], "start": pa.array([5], pa.int64()), "end": pa.array([1 << 40], pa.int64())})
+    with pytest.raises(E.EngineError, match=r"df1: column 'end' does not fit int32 coordinates.*1099511627776 not in range"):
+        E.arrow_encode_keys(t, t)
+    with pytest.raises(E.EngineError, match="df2: column 'pos' not found"):
+        E.arrow_encode_keys(t.slice(0, 0), t, cols2=["chrom", "pos", "end"])
+    tn = pa.table({"chrom": ["chr1", "chr1"], "start": pa.array([5, None], pa.int32()), "end": pa.array([6, 7], pa.int32())})
+    with pytest.raises(E.EngineError, match="column 'start' contains nulls"):
+        E.arrow_encode_keys(tn, tn)
+    tf = pa.table({"chrom": [1.5], "start": pa.array([5], pa.int32()), "end": pa.array([6], pa.int32())})
+    with pytest.raises(E.EngineError, match="column 'chrom' must be utf8"):
+        E.arrow_encode_keys(tf, tf)
+    ts = pa.table({"chrom": ["c"], "start": pa.array([5.0]), "end": pa.array([6], pa.int32())})
+    with pytest.raises(E.EngineError, match="column 'start' must be an integer type"):
+        E.arrow_encode_keys(ts, ts)
+
+
+def test_encode_keys_many_distinct_names_and_empty_sides():
+    n = 30000
+    t = pa.table({"chrom": [f"scaffold_{i % 9000}" for i in range(n)], "start": pa.array(np.arange(n), pa.int16() if False else pa.int32()),
+                  "end": pa.array(np.arange(n) + 5, pa.int32())})
+    s1, s2, names = E.arrow_encode_keys(t, t.slice(0, 0))
+    assert len(names) == 9000 and len(s2[0]) == 0
+    assert [names[i] for i in s1[0][:5]] == [f"scaffold_{i}" for i in range(5)]
+    assert (np.array(names, dtype=object)[s1[0]] == np.array(t.column("chrom").to_pylist(), dtype=object)).all()
+
+
+@pytest.mark.parametrize("batch_rows", [0, 333])
+def test_take_stream_equals_pyarrow_take(batch_rows):
+    rng = np.random.default_rng(2)
+    t1, _ = _frames(rng, n1=4000)
+    tc = _rechunk(t1, [1, 999, 1500])
+    idx = rng.integers(-1, 4000, 9000)
+    idx[:10] = [3999, 0, -1, 1000, 999, 1, 2500, 2499, -5, 4000]           # batch edges, nulls, out of range
+    got = E.arrow_take_stream(tc, idx, batch_rows).read_all()
+    assert got.num_rows == len(idx)
+    safe = np.where((idx < 0) | (idx >= 4000), 0, idx)
+    mask = (idx < 0) | (idx >= 4000)
+    for name in t1.column_names:
+        ref = t1.column(name).combine_chunks().take(pa.array(safe, mask=mask))
+        col = got.column(name)
+        if pa.types.is_dictionary(t1.schema.field(name).type):
+            assert col.type == pa.string()                               # dictionaries are delivered decoded
+            ref = ref.cast(pa.string())
+        else:
+            assert col.type == t1.schema.field(name).type, name
+        assert col.null_count == ref.null_count, name
+        assert col.to_pylist() == ref.to_pylist(), name
+    if batch_rows:
+        assert max(len(b) for b in got.to_batches()) <= batch_rows
+
+
+def test_take_stream_refuses_nested_columns_by_name():
+    t = pa.table({"a": [1, 2], "nest": [[1], [2, 3]]})
+    with pytest.raises(E.EngineError, match=r"column 'nest' has Arrow format '\+l'"):
+        E.arrow_take_stream(t, [0])
+
+
+def _canon(df, key):
+    return df.sort_values(key).reset_index(drop=True)
+
+
+@pytest.mark.gpu
+def test_overlap_arrow_stream_matches_the_golden_table_and_the_front_door():
+    """BASELINE config 1's call shape (two small frames, string chrom) through ONE C call, and a multi-batch / many-column case."""
+    eng = E.Engine(0)
+    try:
+        import pyarrow.csv as pcsv
+        r, t = pcsv.read_csv(f"{GOLDEN}/overlap/reads.csv"), pcsv.read_csv(f"{GOLDEN}/overlap/targets.csv")
+        got = E.overlap_arrow_stream(eng, r, t, strict=False, cols1=COLS, cols2=COLS).read_all().to_pandas()
+        exp = pd.read_csv(f"{GOLDEN}/expected_overlap.csv")
+        key = list(exp.columns)
+        assert list(got.columns) == key
+        pd.testing.assert_frame_equal(_canon(got, key), _canon(exp, key), check_dtype=False)
+        rng = np.random.default_rng(5)
+        t1, t2 = _frames(rng)
+        t1c, t2c = _rechunk(t1, [1000, 7, 2000]), _rechunk(t2, [100, 300])
+        rd = E.overlap_arrow_stream(eng, t1c, t2c, strict=True, batch_rows=4096)
+        res = rd.read_all()
+        d1, d2 = t1.to_pandas(), t2.to_pandas()
+        for d in (d1, d2):
+            d.attrs["coordinate_system_zero_based"] = True
+        ref = pb.overlap(d1, d2, output_type="pandas.DataFrame")
+        assert res.num_rows == len(ref) > 1000 and max(len(b) for b in res.to_batches()) <= 4096
+        assert res.column_names == [f"{c}_1" for c in t1.column_names] + [f"{c}_2" for c in t2.column_names]
+        assert res.schema.field("start_1").type == pa.int64() and res.schema.field("start_2").type == pa.uint32()
+        assert res.schema.field("chrom_2").type == pa.string() and res.schema.field("when_2").type == pa.timestamp("us")
+        g = res.to_pandas()
+        key = ["start_1", "end_1", "start_2", "end_2", "gene_2", "score_1"]
+        ga, rb = _canon(g, key), _canon(ref, key)
+        for c in ("chrom_1", "name_1", "gene_2", "chrom_2", "cat_1"):
+            assert ga[c].astype(object).where(ga[c].notna(), None).tolist() == rb[c].astype(object).where(rb[c].notna(), None).tolist(), c
+        for c in ("start_1", "end_1", "start_2", "end_2", "small_1", "flag_1"):
+            assert (ga[c].to_numpy() == rb[c].to_numpy()).all(), c
+        lim = E.overlap_arrow_stream(eng, t1c, t2c, strict=True, limit=17).read_all()
+        assert lim.num_rows == 17
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_count_and_nearest_arrow_streams_match_the_golden_tables():
+    eng = E.Engine(0)
+    try:
+        import pyarrow.csv as pcsv
+        r, t = pcsv.read_csv(f"{GOLDEN}/count_overlaps/reads.csv"), pcsv.read_csv(f"{GOLDEN}/count_overlaps/targets.csv")
+        got = E.count_overlaps_arrow_stream(eng, t, r, strict=False, cols1=COLS, cols2=COLS).read_all().to_pandas()
+        exp = pd.read_csv(f"{GOLDEN}/expected_count_overlaps.csv")
+        key = list(exp.columns)
+        pd.testing.assert_frame_equal(_canon(got[key], key), _canon(exp, key), check_dtype=False)
+        r, t = pcsv.read_csv(f"{GOLDEN}/nearest/targets.csv"), pcsv.read_csv(f"{GOLDEN}/nearest/reads.csv")
+        exp = pd.read_csv(f"{GOLDEN}/expected_nearest.csv")
+        got = E.nearest_arrow_stream(eng, r, t, strict=False, cols1=COLS, cols2=COLS).read_all().to_pandas()
+        key = list(exp.columns)
+        assert list(got.columns) == key
+        pd.testing.assert_frame_equal(_canon(got, key), _canon(exp, key), check_dtype=False)
+        # a df1 row whose chrom df2 does not know keeps one row with null df2 columns and a null distance; k = 2
+        t1 = pa.table({"chrom": ["chr1", "chrZ"], "start": [100, 5], "end": [110, 9]})
+        t2 = pa.table({"chrom": ["chr1", "chr1", "chr1"], "start": [10, 200, 400], "end": [20, 210, 410], "g": ["a", "b", "c"]})
+        n2 = E.nearest_arrow_stream(eng, t1, t2, strict=True, k=2).read_all()
+        assert n2.num_rows == 3
+        rows = sorted(zip(n2.column("chrom_1").to_pylist(), n2.column("g_2").to_pylist(), n2.column("distance").to_pylist()), key=str)
+        assert rows == sorted([("chr1", "a", 80), ("chr1", "b", 90), ("chrZ", None, None)], key=str)
+        nod = E.nearest_arrow_stream(eng, t1, t2, strict=True, distance=False).read_all()
+        assert "distance" not in nod.column_names
+    finally:
+        eng.close()
