@@ -68,10 +68,10 @@ def to_arrow(df) -> pa.Table:
         return pa.Table.from_batches([df])
     if pd is not None and isinstance(df, pd.DataFrame):
         return _from_pandas(df)
-    if pl is not None and isinstance(df, pl.LazyFrame):
-        return df.collect().to_arrow()
     if pl is not None and isinstance(df, pl.DataFrame):
         return df.to_arrow()
+    if (pl is not None and isinstance(df, pl.LazyFrame)) or (hasattr(df, "collect_batches") and hasattr(df, "collect_schema")):
+        return df.collect().to_arrow()          # LazyFrames are collected when a whole table is asked for (range_op_helpers.py:186-190)
     if isinstance(df, str):
         if df.endswith(".parquet"):
             import pyarrow.parquet as pq

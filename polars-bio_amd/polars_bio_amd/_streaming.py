@@ -69,9 +69,12 @@ def _source(df, batch_rows):
         return [df]
     if A.pd is not None and isinstance(df, A.pd.DataFrame):
         return pa.Table.from_pandas(df, preserve_index=False).to_batches(max_chunksize=batch_rows)
-    if A.pl is not None and isinstance(df, (A.pl.DataFrame, A.pl.LazyFrame)):
-        t = df.collect().to_arrow() if isinstance(df, A.pl.LazyFrame) else df.to_arrow()
-        return t.to_batches(max_chunksize=batch_rows)
+    if A.pl is not None and isinstance(df, A.pl.DataFrame):
+        return df.to_arrow().to_batches(max_chunksize=batch_rows)
+    from . import _polars_lazy as PL
+    if PL.is_lazyframe_like(df):
+        # a LazyFrame probe side is streamed, never collected (reference: _prepare_lazy_stream_input, range_op_io.py:185-283)
+        return PL.lazy_batches(df, batch_rows)
     if isinstance(df, str):
         if df.endswith(".parquet"):
             import pyarrow.parquet as pq
@@ -108,12 +111,14 @@ def source_schema(df) -> Optional[pa.Schema]:
             return rd.schema
         finally:
             rd.close()
-    if A.pl is not None and isinstance(df, (A.pl.DataFrame, A.pl.LazyFrame)):
+    if A.pl is not None and isinstance(df, A.pl.DataFrame):
         try:
-            frame = df if isinstance(df, A.pl.DataFrame) else df.limit(0).collect()
-            return frame.head(0).to_arrow().schema
+            return df.head(0).to_arrow().schema
         except Exception:
             return None
+    from . import _polars_lazy as PL
+    if PL.is_lazyframe_like(df):
+        return PL.lazy_schema(df)
     if hasattr(df, "__arrow_c_schema__"):
         try:
             return pa.schema(df)

@@ -192,9 +192,10 @@ def _assemble_count(t1, counts, naive_query, cols1, suffixes) -> pa.Table:
 
 # ---- streaming / lazy front end ----------------------------------------------------
 
-def _stream(op, df1, df2, cols1, cols2, assemble, batch_rows, limit, k=1, include_overlaps=True):
+def _stream(op, df1, df2, cols1, cols2, assemble, batch_rows, limit, k=1, include_overlaps=True, zero_based=None):
     from . import _streaming as S
-    zero_based = validate_coordinate_systems(df1, df2)
+    if zero_based is None:
+        zero_based = validate_coordinate_systems(df1, df2)
     cols1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
     cols2 = list(DEFAULT_INTERVAL_COLUMNS if cols2 is None else cols2)
     rows = int(batch_rows) if batch_rows else _low_memory_batch_rows()
@@ -223,7 +224,7 @@ def _lazy_reader(df1, df2, zero_based, batches, assemble_empty):
 
 
 def overlap_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, batch_rows: int = 8_000_000, limit=None,
-                    overlap_output: str = "join", distinct_output: bool = False, as_reader: bool = False):
+                    overlap_output: str = "join", distinct_output: bool = False, as_reader: bool = False, _zero_based=None):
     """Streaming form of ``overlap``: df2 is indexed once on the device, df1 is CONSUMED batch by batch -- an Arrow C stream
     producer (``__arrow_c_stream__`` / ``pyarrow.RecordBatchReader``), a Parquet / CSV / BED path, or an in-memory frame --
     and one pyarrow.Table of joined rows is yielded per probe batch (H2D, join and D2H of consecutive batches overlap).
@@ -232,7 +233,7 @@ def overlap_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, bat
     (/root/reference/polars_bio/range_op_io.py:100-174) and ``range_operation_lazy`` (src/lib.rs:154-214)."""
     mode = _parse_overlap_output_mode(overlap_output)
     asm = lambda bt, t2, res: _assemble_overlap(bt, t2, res["probe_idx"], res["build_idx"], mode, distinct_output, suffixes)
-    zero_based, gen = _stream("overlap", df1, df2, cols1, cols2, asm, batch_rows, limit)
+    zero_based, gen = _stream("overlap", df1, df2, cols1, cols2, asm, batch_rows, limit, zero_based=_zero_based)
     if as_reader:
         e = np.empty(0, np.int32)
         return _lazy_reader(df1, df2, zero_based, gen, lambda a, b: _assemble_overlap(a, b, e, e, mode, distinct_output, suffixes))
@@ -240,26 +241,48 @@ def overlap_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, bat
 
 
 def count_overlaps_batches(df1, df2, suffixes=("", "_"), cols1=None, cols2=None, batch_rows: int = 8_000_000, limit=None,
-                           naive_query: bool = True, as_reader: bool = False):
+                           naive_query: bool = True, as_reader: bool = False, _zero_based=None):
     """Streaming form of ``count_overlaps`` (see ``overlap_batches``): df1 rows + ``count`` per probe batch, df1 order kept."""
     c1 = list(DEFAULT_INTERVAL_COLUMNS if cols1 is None else cols1)
     asm = lambda bt, t2, res: _assemble_count(bt, res["counts"], naive_query, c1, suffixes)
-    zero_based, gen = _stream("count_overlaps", df1, df2, cols1, cols2, asm, batch_rows, limit)
+    zero_based, gen = _stream("count_overlaps", df1, df2, cols1, cols2, asm, batch_rows, limit, zero_based=_zero_based)
     if as_reader:
         return _lazy_reader(df1, df2, zero_based, gen, lambda a, b: _assemble_count(a, np.empty(0, np.int64), naive_query, c1, suffixes))
     return gen
 
 
 def nearest_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, k: int = 1, overlap: bool = True, distance: bool = True,
-                    batch_rows: int = 8_000_000, limit=None, as_reader: bool = False):
+                    batch_rows: int = 8_000_000, limit=None, as_reader: bool = False, _zero_based=None):
     """Streaming form of ``nearest`` (see ``overlap_batches``)."""
     asm = lambda bt, t2, res: _assemble_nearest(bt, t2, res["build_idx"], res["dist"], res["n_found"], suffixes, distance)
-    zero_based, gen = _stream("nearest", df1, df2, cols1, cols2, asm, batch_rows, limit, k=int(k), include_overlaps=bool(overlap))
+    zero_based, gen = _stream("nearest", df1, df2, cols1, cols2, asm, batch_rows, limit, k=int(k), include_overlaps=bool(overlap), zero_based=_zero_based)
     if as_reader:
         kk = int(k)
         return _lazy_reader(df1, df2, zero_based, gen, lambda a, b: _assemble_nearest(a, b, np.empty((0, kk), np.int32), np.empty((0, kk), np.int64),
                                                                                      np.empty(0, np.int32), suffixes, distance))
     return gen
+
+
+def _polars_lazy_result(df1, df2, zero_based, limit, batches_fn, **kw):
+    """``output_type="polars.LazyFrame"`` (the reference's default) with polars installed: a ``register_io_source`` LazyFrame
+    over the streaming session -- nothing is read or joined until polars pulls, every collect() runs a fresh stream, a LazyFrame
+    df1 is streamed through the device batch by batch instead of being collected (reference: range_lazy_scan /
+    _prepare_lazy_stream_input, polars_bio/range_op_io.py:31-174, 185-283).  None: df1 reveals its schema only with its first
+    batch (a bare Arrow C stream): the caller keeps the eager path."""
+    from . import _polars_lazy as PL
+    from . import _streaming as S
+    from ._metadata import set_coordinate_system
+    if A.pl is None or S.source_schema(df1) is None:
+        return None
+    t2 = df2 if isinstance(df2, pa.Table) else A.to_arrow(df2)      # the build side is read ONCE, whatever the number of collects
+    probe = batches_fn(df1, t2, as_reader=True, limit=0, _zero_based=zero_based, **kw)      # schema only: assembles an empty result
+    schema = probe.schema
+    probe.close()
+
+    def make(n_rows):
+        lim = limit if n_rows is None else (n_rows if limit is None else min(limit, n_rows))
+        return (A._decode_object_dict(b) for b in batches_fn(df1, t2, limit=lim, _zero_based=zero_based, **kw))
+    return set_coordinate_system(PL.range_lazy_scan(make, schema), zero_based)
 
 
 def _prepare(df1, df2, cols1, cols2):
@@ -303,6 +326,11 @@ def overlap(
     zero_based = validate_coordinate_systems(df1, df2)
     mode = _parse_overlap_output_mode(overlap_output)
     logger.info("Optimizing into IntervalJoinExec using %s algorithm (executed by the HIP engine)", algorithm)
+    if output_type == "polars.LazyFrame":
+        lf = _polars_lazy_result(df1, df2, zero_based, limit, overlap_batches, suffixes=suffixes, cols1=cols1, cols2=cols2,
+                                 batch_rows=_low_memory_batch_rows(), overlap_output=overlap_output, distinct_output=distinct_output)
+        if lf is not None:
+            return lf
     if output_type == "pyarrow.RecordBatchReader" or limit is not None:
         lazy = overlap_batches(df1, df2, suffixes, cols1, cols2, batch_rows=_low_memory_batch_rows(), limit=limit,
                                overlap_output=overlap_output, distinct_output=distinct_output, as_reader=True)
@@ -350,6 +378,11 @@ def nearest(
     distance (unpinned in the reference; tests/test_native.py:133-140 drops such rows)."""
     _validate_overlap_input(cols1, cols2, on_cols, suffixes, output_type)
     zero_based = validate_coordinate_systems(df1, df2)
+    if output_type == "polars.LazyFrame":
+        lf = _polars_lazy_result(df1, df2, zero_based, limit, nearest_batches, suffixes=suffixes, cols1=cols1, cols2=cols2, k=k, overlap=overlap,
+                                 distance=distance, batch_rows=_low_memory_batch_rows())
+        if lf is not None:
+            return lf
     if output_type == "pyarrow.RecordBatchReader" or limit is not None:
         lazy = nearest_batches(df1, df2, suffixes, cols1, cols2, k=k, overlap=overlap, distance=distance,
                                batch_rows=_low_memory_batch_rows(), limit=limit, as_reader=True)
@@ -380,6 +413,11 @@ def count_overlaps(
     (key columns + suffixes[0]) is honoured."""
     _validate_overlap_input(cols1, cols2, on_cols, suffixes, output_type)
     zero_based = validate_coordinate_systems(df1, df2)
+    if output_type == "polars.LazyFrame":
+        lf = _polars_lazy_result(df1, df2, zero_based, limit, count_overlaps_batches, suffixes=suffixes, cols1=cols1, cols2=cols2,
+                                 batch_rows=_low_memory_batch_rows(), naive_query=naive_query)
+        if lf is not None:
+            return lf
     if output_type == "pyarrow.RecordBatchReader" or limit is not None:
         lazy = count_overlaps_batches(df1, df2, suffixes, cols1, cols2, batch_rows=_low_memory_batch_rows(), limit=limit,
                                       naive_query=naive_query, as_reader=True)
