@@ -481,6 +481,16 @@ int ivj_host_remap_i32(const void* idx, int32_t idx_bytes, int64_t n, const int3
 /* dst[i] = src[idx[i]] for 4- or 8-byte values (0 for a negative index): the non-key columns of the joined rows. */
 int ivj_host_take(const void* src, int32_t elem_bytes, int64_t n_src, const int32_t* idx, int64_t n, void* dst, int32_t threads);
 
+/* Contig sharding of one side for `world` ranks ("host buckets both sides by contig id"; the reference's
+ * partitioner cuts by row count, src/scan.rs:233-277): owner[c] = rank of contig c (n_contigs entries), a row whose contig lies
+ * outside [0, n_contigs) belongs to no rank.  One counting pass fills counts[world]; with output columns (arrays of `world`
+ * pointers, each sized from a first counts-only call with all four NULL; any of the four may be NULL) one placing pass writes
+ * every rank's rows -- contig / start / end and the GLOBAL row (what ivj_side.row_id carries) -- in input order. */
+int ivj_host_shard(const int32_t* contig, const int32_t* start, const int32_t* end, int64_t n, const int32_t* owner, int32_t n_contigs, int32_t world,
+                   int64_t* counts, int32_t* const* out_contig, int32_t* const* out_start, int32_t* const* out_end, int32_t* const* out_row, int32_t threads);
+/* rows per contig (the weights of the LPT contig -> rank assignment): hist[n_contigs] */
+int ivj_host_contig_hist(const int32_t* contig, int64_t n, int32_t n_contigs, int64_t* hist, int32_t threads);
+
 /* int32 -> int64: key columns materialised in HBM back to the dtype of the caller's frame. */
 int ivj_host_widen_i32(const int32_t* src, int64_t n, int64_t* dst, int32_t threads);
 

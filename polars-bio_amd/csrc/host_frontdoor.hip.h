@@ -324,6 +324,67 @@ static int ivj_host_widen_i32_impl(const int32_t* src, int64_t n, int64_t* dst, 
 }
 
 
+// Contig sharding of one side for `world` ranks: ONE counting pass and ONE placing pass over the rows, both threaded, input
+// order kept inside every rank's share.  owner[c] = rank of contig c; a row whose contig lies outside [0, n_contigs) belongs to
+// no rank.  counts_only: fill counts[world] and stop (the caller sizes the outputs from it).
+static int ivj_host_shard_impl(const int32_t* contig, const int32_t* start, const int32_t* end, int64_t n, const int32_t* owner, int32_t n_contigs,
+                               int32_t world, int64_t* counts, int32_t* const* out_contig, int32_t* const* out_start, int32_t* const* out_end,
+                               int32_t* const* out_row, int32_t threads) {
+    if (n < 0 || world < 1 || n_contigs < 0 || !counts || (n > 0 && !contig) || (n_contigs > 0 && !owner)) return fail(IVJ_EINVAL, "shard: bad argument");
+    for (int32_t c = 0; c < n_contigs; ++c) if (owner[c] < 0 || owner[c] >= world) return fail(IVJ_EINVAL, "shard: an owner lies outside [0, world)");
+    const bool place = out_contig || out_start || out_end || out_row;
+    if (place && n > 0 && (!start || !end)) return fail(IVJ_EINVAL, "shard: start / end is NULL");
+    const int t = fd_threads(n, threads, 1 << 16);
+    std::vector<int64_t> cnt((size_t)t * (size_t)world, 0);
+    fd_parallel(n, t, [&](int k, int64_t lo, int64_t hi) {
+        int64_t* c = cnt.data() + (size_t)k * (size_t)world;
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint32_t cc = (uint32_t)contig[i];
+            if (cc < (uint32_t)n_contigs) ++c[owner[cc]];
+        }
+    });
+    // exclusive prefix over the parts, per rank: part k of rank r writes from base[k][r]
+    for (int32_t r = 0; r < world; ++r) {
+        int64_t run = 0;
+        for (int k = 0; k < t; ++k) { const int64_t v = cnt[(size_t)k * world + r]; cnt[(size_t)k * world + r] = run; run += v; }
+        counts[r] = run;
+    }
+    if (!place) return IVJ_OK;
+    for (int32_t r = 0; r < world; ++r)
+        if (counts[r] > 0 && ((out_contig && !out_contig[r]) || (out_start && !out_start[r]) || (out_end && !out_end[r]) || (out_row && !out_row[r])))
+            return fail(IVJ_EINVAL, "shard: an output column of a rank with rows is NULL");
+    fd_parallel(n, t, [&](int k, int64_t lo, int64_t hi) {
+        std::vector<int64_t> pos(cnt.begin() + (size_t)k * world, cnt.begin() + (size_t)(k + 1) * world);
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint32_t cc = (uint32_t)contig[i];
+            if (cc >= (uint32_t)n_contigs) continue;
+            const int32_t r = owner[cc];
+            const int64_t o = pos[(size_t)r]++;
+            if (out_contig) out_contig[r][o] = (int32_t)cc;
+            if (out_start) out_start[r][o] = start[i];
+            if (out_end) out_end[r][o] = end[i];
+            if (out_row) out_row[r][o] = (int32_t)i;
+        }
+    });
+    return IVJ_OK;
+}
+
+// rows per contig of one side (the LPT weights of the contig -> rank assignment): hist[c] for c in [0, n_contigs)
+static int ivj_host_contig_hist_impl(const int32_t* contig, int64_t n, int32_t n_contigs, int64_t* hist, int32_t threads) {
+    if (n < 0 || n_contigs < 0 || (n > 0 && !contig) || (n_contigs > 0 && !hist)) return fail(IVJ_EINVAL, "contig hist: bad argument");
+    for (int32_t c = 0; c < n_contigs; ++c) hist[c] = 0;
+    if (n == 0 || n_contigs == 0) return IVJ_OK;
+    const int t = fd_threads(n, threads, 1 << 17);
+    std::vector<int64_t> part((size_t)t * (size_t)n_contigs, 0);
+    fd_parallel(n, t, [&](int k, int64_t lo, int64_t hi) {
+        int64_t* h = part.data() + (size_t)k * (size_t)n_contigs;
+        for (int64_t i = lo; i < hi; ++i) { const uint32_t cc = (uint32_t)contig[i]; if (cc < (uint32_t)n_contigs) ++h[cc]; }
+    });
+    for (int k = 0; k < t; ++k) for (int32_t c = 0; c < n_contigs; ++c) hist[c] += part[(size_t)k * n_contigs + c];
+    return IVJ_OK;
+}
+
+
 // no C++ exception may cross the C ABI (std::thread / std::vector can throw under resource exhaustion)
 #define IVJ_HOST_GUARD(call)                                                                        \
     try { return call; }                                                                            \
@@ -350,6 +411,13 @@ int ivj_host_take(const void* src, int32_t elem_bytes, int64_t n_src, const int3
 }
 int ivj_host_widen_i32(const int32_t* src, int64_t n, int64_t* dst, int32_t threads) {
     IVJ_HOST_GUARD(ivj_host_widen_i32_impl(src, n, dst, threads))
+}
+int ivj_host_shard(const int32_t* contig, const int32_t* start, const int32_t* end, int64_t n, const int32_t* owner, int32_t n_contigs, int32_t world,
+                   int64_t* counts, int32_t* const* out_contig, int32_t* const* out_start, int32_t* const* out_end, int32_t* const* out_row, int32_t threads) {
+    IVJ_HOST_GUARD(ivj_host_shard_impl(contig, start, end, n, owner, n_contigs, world, counts, out_contig, out_start, out_end, out_row, threads))
+}
+int ivj_host_contig_hist(const int32_t* contig, int64_t n, int32_t n_contigs, int64_t* hist, int32_t threads) {
+    IVJ_HOST_GUARD(ivj_host_contig_hist_impl(contig, n, n_contigs, hist, threads))
 }
 #undef IVJ_HOST_GUARD
 

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -65,13 +66,23 @@ struct HostPool {
     std::atomic<int> next{0};
     int pending = 0;                                       // parts not yet finished
     int active = 0;                                        // workers that picked this job up and have not let go of it yet
+    std::exception_ptr error;                              // the first exception a part threw (rethrown by execute() on the caller's thread)
     static constexpr int MAX_WORKERS = 63;
 
-    // grab parts until none is left; `worker`: the caller of execute() is not counted in `active`
+    // grab parts until none is left; `worker`: the caller of execute() is not counted in `active`.  A part that throws (std::bad_alloc
+    // out of a std::vector growing inside a front-door pass) must neither terminate the process from a detached worker nor leave
+    // `pending` unsettled: the exception is parked, the part counts as done, and the parts still unclaimed are skipped.
     void work(const std::function<void(int)>& f, int n, bool worker) {
         int done = 0;
-        for (int i = next.fetch_add(1, std::memory_order_relaxed); i < n; i = next.fetch_add(1, std::memory_order_relaxed)) { f(i); ++done; }
+        std::exception_ptr mine;
+        for (int i = next.fetch_add(1, std::memory_order_relaxed); i < n; i = next.fetch_add(1, std::memory_order_relaxed)) {
+            if (!mine) {
+                try { f(i); } catch (...) { mine = std::current_exception(); }
+            }
+            ++done;
+        }
         std::lock_guard<std::mutex> g(m);
+        if (mine && !error) error = mine;
         pending -= done;
         if (worker) --active;
         if (pending == 0 && active == 0) cv_done.notify_all();
@@ -107,17 +118,24 @@ struct HostPool {
         // stampede on `m`); a worker that stays asleep picks up whatever job is current when it is next woken
         for (int k = 0; k < n - 1 && k < n_workers; ++k) cv_job.notify_one();
         work(f, n, false);
-        std::unique_lock<std::mutex> g(m);
-        cv_done.wait(g, [&] { return pending == 0 && active == 0; });
-        job = nullptr;                                     // a worker that wakes up late finds no job
+        std::exception_ptr err;
+        {
+            std::unique_lock<std::mutex> g(m);
+            cv_done.wait(g, [&] { return pending == 0 && active == 0; });
+            job = nullptr;                                 // a worker that wakes up late finds no job
+            err = error; error = nullptr;
+        }
+        if (err) std::rethrow_exception(err);              // on the caller's thread, where IVJ_HOST_GUARD / IVJ_ABI_CATCH turn it into a status
     }
 };
 
 inline HostPool*& host_pool_slot() { static HostPool* p = nullptr; return p; }
-inline void host_pool_after_fork() { host_pool_slot() = nullptr; }      // the child must not touch the parent's pool (its threads are gone)
+inline std::mutex*& host_pool_init_mutex() { static std::mutex* m = new std::mutex(); return m; }
+// the child must not touch the parent's pool (its threads are gone) NOR the init mutex, which another thread of the parent may have
+// held at the fork: the child gets a fresh one (both old objects are leaked, a few bytes per fork)
+inline void host_pool_after_fork() { host_pool_slot() = nullptr; host_pool_init_mutex() = new std::mutex(); }
 inline HostPool* host_pool() {
-    static std::mutex init;
-    std::lock_guard<std::mutex> g(init);
+    std::lock_guard<std::mutex> g(*host_pool_init_mutex());
     HostPool*& p = host_pool_slot();
     if (!p) {
         static bool hooked = false;
@@ -143,9 +161,13 @@ inline void host_parallel(int parts, const std::function<void(int)>& f) {
     }
     std::vector<std::thread> th;                           // pool busy with another caller's job: threads of our own
     th.reserve(parts - 1);
-    for (int k = 1; k < parts; ++k) th.emplace_back([&f, k] { f(k); });
-    f(0);
+    std::mutex em;
+    std::exception_ptr err;                                // an exception inside a std::thread body would be std::terminate
+    auto guarded = [&](int k) { try { f(k); } catch (...) { std::lock_guard<std::mutex> g(em); if (!err) err = std::current_exception(); } };
+    for (int k = 1; k < parts; ++k) th.emplace_back([&guarded, k] { guarded(k); });
+    guarded(0);
     for (auto& x : th) x.join();
+    if (err) std::rethrow_exception(err);
 }
 
 // A result that cannot fit the host is refused with an error instead of being first-touched into the OOM killer (an

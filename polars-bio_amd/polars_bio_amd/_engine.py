@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "ivj_allgather_counts", "ivj_allgatherv_dev", "ivj_overlap_allgather_dev",
     "ivj_overlap_arrow_stream", "ivj_count_overlaps_arrow_stream", "ivj_nearest_arrow_stream", "ivj_arrow_encode_keys", "ivj_arrow_keys_free",
     "ivj_arrow_take_stream",
+    "ivj_host_shard", "ivj_host_contig_hist",
     "ivj_host_narrow_i32", "ivj_host_encode_utf8", "ivj_host_encode_keys64", "ivj_host_remap_i32", "ivj_host_take", "ivj_host_widen_i32",
 ]
 
@@ -208,6 +209,8 @@ def load_library() -> C.CDLL:
         L.ivj_host_remap_i32.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32]
         L.ivj_host_take.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, vp, C.c_int32]
         L.ivj_host_widen_i32.argtypes = [vp, C.c_int64, vp, C.c_int32]
+        L.ivj_host_shard.argtypes = [vp, vp, vp, C.c_int64, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_int32]
+        L.ivj_host_contig_hist.argtypes = [vp, C.c_int64, C.c_int32, vp, C.c_int32]
         names3 = C.POINTER(C.c_char_p)
         L.ivj_overlap_arrow_stream.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, vp]
         L.ivj_count_overlaps_arrow_stream.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_int64, C.c_int64, vp]
@@ -947,7 +950,7 @@ def default_engine() -> Engine:
     """Process-wide engine (its native calls are serialised by Engine.lock; use one Engine per thread for
     concurrent joins).  One device: the ``ivj.device`` option when it was set explicitly, else LOCAL_RANK (one
     process per GPU under torch.distributed.run), else 0.  Several devices (``ivj.devices`` = "0,1,..", or
-    ``ivj.num_gpus`` / ``datafusion.execution.target_partitions`` > 1 on a host with that many GPUs): a
+    ``ivj.num_gpus`` > 1 on a host with that many GPUs): a
     ``multi.MultiEngine`` -- one context and one host thread per device, contigs dealt to the devices."""
     global _default_engine
     with _default_lock:
@@ -959,9 +962,9 @@ def default_engine() -> Engine:
 
 
 def reset_default_engine():
-    """Drop the process-wide engine (the next call creates a new one, e.g. after ``ivj.device`` changed)."""
+    """Drop the process-wide engine (the next call creates a new one, e.g. after ``ivj.device`` changed).  The old engine is
+    NOT closed here: another thread or an unconsumed lazy reader may still be running on it -- its context goes when the last
+    reference does (Engine.__del__)."""
     global _default_engine
     with _default_lock:
-        if _default_engine is not None:
-            _default_engine.close()
         _default_engine = None

@@ -85,3 +85,28 @@ def widen_i64(src: np.ndarray) -> np.ndarray:
     out = np.empty(len(src), np.int64)
     _check(L, L.ivj_host_widen_i32(_ptr(src), len(src), _ptr(out), THREADS), "ivj_host_widen_i32")
     return out
+
+
+def contig_hist(contig: np.ndarray, n_contigs: int) -> np.ndarray:
+    """Rows per contig (ids outside [0, n_contigs) are not counted): one threaded pass."""
+    L = load_library()
+    contig = np.ascontiguousarray(contig, np.int32)
+    out = np.zeros(max(int(n_contigs), 0), np.int64)
+    _check(L, L.ivj_host_contig_hist(_ptr(contig), len(contig), int(n_contigs), _ptr(out), THREADS), "ivj_host_contig_hist")
+    return out
+
+
+def shard_by_owner(side, owner: np.ndarray, world: int):
+    """(contig, start, end) int32 columns + owner[contig] -> per rank ((contig, start, end), global rows): one counting and one
+    placing pass over the rows for ALL ranks (ivj_host_shard), input order kept inside a rank."""
+    L = load_library()
+    c, s, e = (np.ascontiguousarray(a, np.int32) for a in side)
+    owner = np.ascontiguousarray(owner, np.int32)
+    n, nc = len(c), len(owner)
+    counts = np.zeros(world, np.int64)
+    _check(L, L.ivj_host_shard(_ptr(c), _ptr(s), _ptr(e), n, _ptr(owner), nc, int(world), _ptr(counts), None, None, None, None, THREADS), "ivj_host_shard")
+    outs = [[np.empty(int(counts[r]), np.int32) for r in range(world)] for _ in range(4)]
+    arrs = [(C.c_void_p * world)(*[a.ctypes.data for a in col]) for col in outs]
+    _check(L, L.ivj_host_shard(_ptr(c), _ptr(s), _ptr(e), n, _ptr(owner), nc, int(world), _ptr(counts), arrs[0], arrs[1], arrs[2], arrs[3], THREADS),
+           "ivj_host_shard")
+    return [((outs[0][r], outs[1][r], outs[2][r]), outs[3][r]) for r in range(world)]

@@ -22,8 +22,9 @@ class Context:
             # engine options of this implementation
             "ivj.device": "auto",   # "auto": LOCAL_RANK (one process per GPU) or 0; a number pins the device
             # several GPUs in ONE process (multi.MultiEngine: one context + host thread per device, contigs dealt out):
-            # "ivj.devices" = explicit slots ("0,1"); else ivj.num_gpus, else datafusion.execution.target_partitions
-            # (the reference's parallelism knob, polars_bio/context.py:36) -- capped by the visible devices
+            # "ivj.devices" = explicit slots ("0,1"); else ivj.num_gpus devices counted from ivj.device, capped by the visible
+            # devices.  datafusion.execution.target_partitions (the reference's parallelism knob, polars_bio/context.py:36) is
+            # stored for call compatibility only: raising it must not change which GPUs a process touches
             "ivj.devices": "auto",
             "ivj.num_gpus": "0",
             "ivj.low_memory_batch_rows": "8000000",
@@ -41,7 +42,7 @@ class Context:
         with self._lock:
             changed = self._opts.get(key) != value
             self._opts[key] = value
-        if changed and key in ("ivj.device", "ivj.devices", "ivj.num_gpus", "datafusion.execution.target_partitions"):
+        if changed and key in ("ivj.device", "ivj.devices", "ivj.num_gpus"):
             from ._engine import reset_default_engine      # the next call builds the engine(s) the new value asks for
             reset_default_engine()
 

@@ -68,6 +68,26 @@ def shard_sides(probe, build, n_contigs: int, rank: int, world: int):
     return (pc[pi], ps[pi], pe[pi]), pi, (bc[bi], bs[bi], be[bi]), bi, mode
 
 
+def shard_all(probe, build, n_contigs: int, world: int):
+    """All ranks' shards at once -> [(probe_local, probe_row_id, build_local, build_row_id, mode)] * world, the same shards
+    ``shard_sides`` cuts rank by rank -- through the native host passes (``ivj_host_contig_hist`` for the LPT weights,
+    ``ivj_host_shard``: one counting + one placing pass over the rows for ALL ranks, threaded, no interpreter lock held) instead of
+    ``world`` rounds of bincount + boolean masks + fancy-index gathers over the full columns."""
+    from . import _host as H
+    pc, bc = probe[0], build[0]
+    if n_contigs >= world:
+        w = (H.contig_hist(pc, n_contigs) + H.contig_hist(bc, n_contigs)).astype(np.float64)
+        owner = np.asarray(lpt_assign(w, world), dtype=np.int32)
+        ps, bs = H.shard_by_owner(probe, owner, world), H.shard_by_owner(build, owner, world)
+        return [(ps[r][0], ps[r][1], bs[r][0], bs[r][1], "contig") for r in range(world)]
+    out = []
+    bi = np.arange(len(bc), dtype=np.int32)
+    for r in range(world):                                     # fewer contigs than ranks: views of the probe rows, the build side shared
+        lo, hi = len(pc) * r // world, len(pc) * (r + 1) // world
+        out.append(((probe[0][lo:hi], probe[1][lo:hi], probe[2][lo:hi]), np.arange(lo, hi, dtype=np.int32), tuple(build), bi, "rows"))
+    return out
+
+
 class PeerFailure(RuntimeError):
     """Another rank's join failed: this rank's share is complete, the gathered result is not (the C ABI's IVJ_EPEER)."""
 

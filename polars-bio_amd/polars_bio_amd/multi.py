@@ -9,7 +9,8 @@ ABI on its own thread (ctypes releases the GIL), and the results -- host arrays 
 host: pairs are mapped to global rows and concatenated, per-probe results are stored at their rows.
 
 Selected by ``ivj.devices`` (explicit list, e.g. "0,1"; a device may be listed twice, which is how a 1-GPU box tests this)
-or ``ivj.num_gpus`` / ``datafusion.execution.target_partitions`` > 1 (the first n visible devices)."""
+or ``ivj.num_gpus`` > 1 (that many devices counted from ``ivj.device``).  ``datafusion.execution.target_partitions`` is stored
+for call compatibility and does not select devices."""
 from __future__ import annotations
 
 import threading
@@ -46,9 +47,15 @@ class MultiEngine:
         for e in self.engines:
             e.close()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _shards(self, probe, build, n_contigs):
         world = len(self.engines)
-        sh = [D.shard_sides(probe, build, n_contigs, r, world) for r in range(world)]
+        sh = D.shard_all(probe, build, n_contigs, world)       # one native threaded pass per side for all devices
         self.last_shards = [(len(s[1]), len(s[3]), s[4]) for s in sh]
         return sh
 
@@ -110,7 +117,12 @@ class MultiEngine:
 
 
 def requested_devices():
-    """-> list of device slots the options ask for (length 1: single engine)."""
+    """-> list of device slots the options ask for (length 1: single engine).
+
+    Several devices only on an EXPLICIT request: ``ivj.devices`` (the slots, e.g. "0,1") or ``ivj.num_gpus`` = n (n slots
+    counted from ``ivj.device``, wrapping at the number of visible devices).  The reference's parallelism knob
+    ``datafusion.execution.target_partitions`` (polars_bio/context.py:36) is accepted and stored but does NOT fan the join out
+    over GPUs: its docs recommend raising it routinely, which must not silently change the devices a process touches."""
     import os
     from ._engine import device_count
     from .context import get_option
@@ -121,14 +133,10 @@ def requested_devices():
         n = int(get_option("ivj.num_gpus") or 0)
     except ValueError:
         n = 0
-    if n <= 0:
-        try:
-            n = int(get_option("datafusion.execution.target_partitions") or 1)
-        except ValueError:
-            n = 1
     opt = get_option("ivj.device")
     first = int(opt) if opt not in (None, "", "auto") else int(os.environ.get("LOCAL_RANK", "0"))
     if n <= 1 or "WORLD_SIZE" in os.environ:          # one process per GPU under a launcher: never fan out inside a rank
         return [first]
-    n = min(n, max(device_count(), 1))
-    return [first] if n <= 1 else list(range(n))
+    have = max(device_count(), 1)
+    n = min(n, have)
+    return [first] if n <= 1 else [(first + i) % have for i in range(n)]

@@ -20,10 +20,15 @@ def test_requested_devices_follow_the_options(monkeypatch):
     old = {k: pb.get_option(k) for k in ("ivj.devices", "ivj.num_gpus", "datafusion.execution.target_partitions", "ivj.device")}
     try:
         assert multi.requested_devices() == [0]
-        pb.set_option("datafusion.execution.target_partitions", 8)           # the reference's knob, capped by the devices
-        assert multi.requested_devices() == [0, 1, 2, 3]
+        pb.set_option("datafusion.execution.target_partitions", 8)           # the reference's knob: stored, but it selects no GPUs
+        assert multi.requested_devices() == [0]
         pb.set_option("ivj.num_gpus", 2)
         assert multi.requested_devices() == [0, 1]
+        pb.set_option("ivj.num_gpus", 16)                                     # capped by the visible devices
+        assert multi.requested_devices() == [0, 1, 2, 3]
+        pb.set_option("ivj.device", 3); pb.set_option("ivj.num_gpus", 2)     # ivj.device is the first slot
+        assert multi.requested_devices() == [3, 0]
+        pb.set_option("ivj.device", "auto")
         pb.set_option("ivj.devices", "3,1")
         assert multi.requested_devices() == [3, 1]
         pb.set_option("ivj.devices", "auto"); pb.set_option("ivj.num_gpus", 0); pb.set_option("datafusion.execution.target_partitions", 1)
@@ -35,6 +40,25 @@ def test_requested_devices_follow_the_options(monkeypatch):
     finally:
         for k, v in old.items():
             pb.set_option(k, v)
+
+
+@pytest.mark.parametrize("nc,world", [(24, 2), (24, 8), (5, 3), (1, 4)])
+def test_native_sharding_equals_the_numpy_restatement(nc, world):
+    """distributed.shard_all (ivj_host_contig_hist + ivj_host_shard: one threaded pass per side for all ranks) cuts exactly the
+    shards distributed.shard_sides cuts rank by rank, rows outside the dictionary included (they belong to no rank)."""
+    from polars_bio_amd import distributed as D
+    rng = np.random.default_rng(nc * 10 + world)
+    probe = random_side(rng, 300_000, nc + 1, 800000, 300)
+    build = random_side(rng, 50_000, nc, 800000, 300)
+    probe[0][:11] = -1
+    got = D.shard_all(probe, build, nc, world)
+    assert len(got) == world
+    for r in range(world):
+        lp, pid, lb, bid, mode = D.shard_sides(probe, build, nc, r, world)
+        gp, gpid, gb, gbid, gmode = got[r]
+        assert gmode == mode and (gpid == pid).all() and (gbid == bid).all()
+        for a, b in zip(gp + gb, lp + lb):
+            assert a.dtype == np.int32 and (a == b).all()
 
 
 @pytest.mark.gpu
