@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gatherv (reported in config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows of the all-core CPU-baseline sample (the 1-thread sample is a tenth of it)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="bound the all-core CPU-baseline runs to the first N probe rows (0: the identical input, every row; the 1-thread runs always take 2 M rows)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip two_pass_ms_per_step / host_path_s")
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps: timed steps only
@@ -167,48 +167,50 @@ def algorithmic_bytes(op, n_p, n_b, n_out):
 
 
 def cpu_baseline(op, probe, build, nc, sample_rows):
-    """The oracle's CPU port on the host cores, bounded sample: first `sample_rows` probe rows (a tenth of that
-    for the 1-thread runs) against the FULL build side.  overlap: ONE pass per probe row (orc_overlap_baseline:
-    matches appended to recycled per-thread batches, like a streaming executor), both index forms (bound search
-    over the sorted arrays; implicit augmented interval tree = the stand-in for the reference's COITrees), probe
-    rows as given and sorted per thread share (sort inside the timed call); 1 thread and all cores; best of 3.
-    `value` = best all-core rate, with the (1-thread) index build charged in proportion to the sample."""
+    """The oracle's CPU port on the host cores.  All-core runs: the IDENTICAL input (every probe row, SURVEY.md section 8d;
+    ``--cpu-sample N`` > 0 bounds them to the first N rows), index built with all cores and charged in full, probe columns
+    placed so that every thread reads pages it touched first (oracle.placed: NUMA), and the cores the best run kept busy
+    (process CPU time / wall time) printed next to the thread count.  1-thread runs: a bounded sample (2 M rows), probe only.
+    overlap: ONE pass per probe row (orc_overlap_baseline: matches appended to recycled per-thread batches, like a streaming
+    executor), both index forms (bound search over the sorted arrays; implicit augmented interval tree = the stand-in for the
+    reference's COITrees), probe rows as given and sorted per thread share (sort inside the timed call); best of 2 (1 thread: 3)."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     n_total = len(probe[0])
-    n = min(sample_rows, n_total)
-    n1 = max(1, min(n, sample_rows // 10))
+    n = n_total if sample_rows <= 0 else min(sample_rows, n_total)
+    n1 = max(1, min(n, 2_000_000))
     bs = O.Side(*build)
     t0 = time.perf_counter()
-    ix = O.Index(bs, nc)
+    ix = O.Index(bs, nc)                          # parallel LSD sort + per-contig passes (oracle/ivj_oracle.c)
     t_index = time.perf_counter() - t0
-    ps_all = O.Side(probe[0][:n], probe[1][:n], probe[2][:n])
+    ps_all = O.placed(O.Side(probe[0][:n], probe[1][:n], probe[2][:n]), cores)
     ps_one = O.Side(probe[0][:n1], probe[1][:n1], probe[2][:n1])
 
     def best_of(fn, reps=3):
-        best, units = None, 0
+        best, units, busy = None, 0, 0.0
         for _ in range(reps):
-            t = time.perf_counter()
+            t, c = time.perf_counter(), time.process_time()
             units = fn()
-            dt = time.perf_counter() - t
-            best = dt if best is None else min(best, dt)
-        return best, units
+            dt, dc = time.perf_counter() - t, time.process_time() - c
+            if best is None or dt < best:
+                best, busy = dt, dc / dt if dt > 0 else 0.0
+        return best, units, busy
 
     runs = {}
     if op == "overlap":
         for label, side, thr in (("all_cores", ps_all, cores), ("one_thread", ps_one, 1)):
             for tree in (False, True):
                 for srt in (False, True):
-                    dt, units = best_of(lambda: O.overlap_baseline(ix, side, True, thr, tree, srt)[0])
+                    dt, units, busy = best_of(lambda: O.overlap_baseline(ix, side, True, thr, tree, srt)[0], 2 if thr > 1 else 3)
                     runs[f"{label}/{'tree' if tree else 'bsearch'}/{'sorted' if srt else 'unsorted'}"] = {
-                        "probe_s": round(dt, 4), "units": units, "rate": units / dt}
+                        "probe_s": round(dt, 4), "units": units, "rate": units / dt, "busy_cores": round(busy, 1)}
         unit = "overlap-pairs/s"
     else:
         fn_all = (lambda s, t: (O.count_overlaps_fast(ix, s, True, threads=t), s.n)[1]) if op == "count_overlaps" else \
                  (lambda s, t: (O.nearest_fast(ix, s, True, 1, True, threads=t), s.n)[1])
         for label, side, thr in (("all_cores", ps_all, cores), ("one_thread", ps_one, 1)):
-            dt, units = best_of(lambda: fn_all(side, thr))
-            runs[f"{label}/bsearch/unsorted"] = {"probe_s": round(dt, 4), "units": units, "rate": units / dt}
+            dt, units, busy = best_of(lambda: fn_all(side, thr), 2 if thr > 1 else 3)
+            runs[f"{label}/bsearch/unsorted"] = {"probe_s": round(dt, 4), "units": units, "rate": units / dt, "busy_cores": round(busy, 1)}
         unit = "probe-rows/s"
     # the reference's published 1-thread figure (7.6e7 pairs/s) is for 31 pairs per probe row; config 3 has 2.  The same port on
     # a sample of THAT density (same probe rows, build side with 5-40 kb intervals: ~37 pairs per probe row) shows what the
@@ -221,7 +223,7 @@ def cpu_baseline(op, probe, build, nc, sample_rows):
             dbuild = synth.make_side(len(build[0]), 43, synth.DENSE_BUILD_LEN, nc)
             dix = O.Index(O.Side(*dbuild), nc)
             dside = O.Side(probe[0][:nd], probe[1][:nd], probe[2][:nd])
-            dt, units = best_of(lambda: O.overlap_baseline(dix, dside, True, 1, False, True)[0], reps=2)
+            dt, units, _ = best_of(lambda: O.overlap_baseline(dix, dside, True, 1, False, True)[0], reps=2)
             dense = {"value": units / dt, "pairs_per_probe_row": round(units / nd, 1), "probe_rows": nd,
                      "what": "1 thread, bound search, sorted probes, build side of the same size with 5-40 kb intervals"}
             del dix, dbuild
@@ -231,10 +233,11 @@ def cpu_baseline(op, probe, build, nc, sample_rows):
     best_one = max((k for k in runs if k.startswith("one_thread")), key=lambda k: runs[k]["rate"])
     ra, r1 = runs[best_all], runs[best_one]
     value = ra["units"] / (ra["probe_s"] + t_index * n / n_total)
-    return {"value": value, "unit": unit, "cores": cores, "kind": "port",
-            "sample": f"first {n:,} probe rows (1-thread runs: {n1:,}) x full build ({len(build[0]):,} rows); best of 3; "
-                      f"all-core best = {best_all} {ra['probe_s']:.3f}s for {ra['units']:,} units; index build (1 thread) "
-                      f"{t_index:.2f}s charged x{n / n_total:.2f}",
+    return {"value": value, "unit": unit, "cores": cores, "busy_cores": ra["busy_cores"], "kind": "port",
+            "sample": (f"the identical input: all {n:,} probe rows" if n == n_total else f"first {n:,} of {n_total:,} probe rows") +
+                      f" x full build ({len(build[0]):,} rows), {cores} threads, best of 2 (1-thread runs: first {n1:,} probe rows, best of 3); "
+                      f"all-core best = {best_all} {ra['probe_s']:.3f}s for {ra['units']:,} units, {ra['busy_cores']} cores busy on average; "
+                      f"index build (all cores) {t_index:.2f}s charged x{n / n_total:.2f}",
             "one_thread": {"value": r1["rate"], "variant": best_one, "note": "probe only (index build excluded), 1 thread; "
                            "compare with the reference's published 7.6e7 pairs/s @ 1 thread on other hardware/data (BASELINE.md)",
                            "at_reference_density": dense},

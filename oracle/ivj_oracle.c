@@ -123,22 +123,51 @@ struct orc_index {
     int32_t* tmax;        /* implicit interval tree: max end in the subtree whose root is this position */
 };
 
-/* LSD radix sort of 64-bit keys with a 32-bit payload, 16-bit digits. */
+/* LSD radix sort of 64-bit keys with a 32-bit payload, 16-bit digits.  Large inputs: every pass is cut into one contiguous
+ * chunk per thread (per-thread digit histograms -> offsets by (digit, thread) -> stable scatter), so that the all-core CPU
+ * baseline of bench.py is not charged a single-threaded index build. */
 static void radix_sort_u64(uint64_t* keys, int32_t* vals, int64_t n, int key_bits) {
     if (n <= 1) return;
     uint64_t* k2 = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
     int32_t* v2 = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
-    int64_t* cnt = (int64_t*)malloc(sizeof(int64_t) * 65537);
     uint64_t* src = keys; uint64_t* dst = k2; int32_t* vs = vals; int32_t* vd = v2;
+    int nt = 1;
+#ifdef _OPENMP
+    /* (inside a parallel region -- the per-thread sorts of orc_overlap_baseline -- a nested team would have one thread) */
+    if (n >= (1 << 20) && !omp_in_parallel()) { nt = omp_get_max_threads(); if (nt > 64) nt = 64; if (nt < 1) nt = 1; }
+#endif
+    int64_t* cnt = (int64_t*)malloc(sizeof(int64_t) * 65536 * (size_t)nt);
     for (int shift = 0; shift < key_bits; shift += 16) {
-        memset(cnt, 0, sizeof(int64_t) * 65537);
-        for (int64_t i = 0; i < n; ++i) cnt[((src[i] >> shift) & 0xFFFF) + 1]++;
-        for (int d = 0; d < 65536; ++d) cnt[d + 1] += cnt[d];
-        for (int64_t i = 0; i < n; ++i) {
-            int64_t p = cnt[(src[i] >> shift) & 0xFFFF]++;
-            dst[p] = src[i]; vd[p] = vs[i];
+        memset(cnt, 0, sizeof(int64_t) * 65536 * (size_t)nt);
+#pragma omp parallel num_threads(nt)
+        {
+#ifdef _OPENMP
+            const int t = omp_get_thread_num();
+#else
+            const int t = 0;
+#endif
+            const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            int64_t* c = cnt + (size_t)t * 65536;
+            for (int64_t i = lo; i < hi; ++i) c[(src[i] >> shift) & 0xFFFF]++;
         }
-        uint64_t* t = src; src = dst; dst = t;
+        int64_t run = 0;
+        for (int d = 0; d < 65536; ++d)
+            for (int t = 0; t < nt; ++t) { int64_t* c = cnt + (size_t)t * 65536 + d; const int64_t v = *c; *c = run; run += v; }
+#pragma omp parallel num_threads(nt)
+        {
+#ifdef _OPENMP
+            const int t = omp_get_thread_num();
+#else
+            const int t = 0;
+#endif
+            const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            int64_t* c = cnt + (size_t)t * 65536;
+            for (int64_t i = lo; i < hi; ++i) {
+                const int64_t p = c[(src[i] >> shift) & 0xFFFF]++;
+                dst[p] = src[i]; vd[p] = vs[i];
+            }
+        }
+        uint64_t* tk = src; src = dst; dst = tk;
         int32_t* tv = vs; vs = vd; vd = tv;
     }
     if (src != keys) { memcpy(keys, src, sizeof(uint64_t) * (size_t)n); memcpy(vals, vs, sizeof(int32_t) * (size_t)n); }
@@ -208,13 +237,16 @@ orc_index* orc_index_build(const orc_side* build, int n_contigs) {
     uint64_t* keys = (uint64_t*)malloc(8 * nn);
     /* build rows whose contig id is outside [0, n_contigs) can never match:
      * they are parked in a trailing pseudo-segment by giving them the id n_contigs */
+    int inverted = 0;
+#pragma omp parallel for schedule(static) reduction(| : inverted) if (n >= (1 << 20))
     for (int64_t j = 0; j < n; ++j) {
         int32_t c = build->contig[j];
         if (c < 0 || c >= n_contigs) c = n_contigs;
         keys[j] = compose(c, build->start[j]);
         ix->s_row[j] = (int32_t)j;
-        if (build->start[j] > build->end[j]) ix->has_inverted = 1;
+        if (build->start[j] > build->end[j]) inverted |= 1;
     }
+    ix->has_inverted = inverted;
     radix_sort_u64(keys, ix->s_row, n, 64);
     int64_t n_valid = n;
     for (int64_t p = 0; p < n; ++p) {
@@ -223,11 +255,13 @@ orc_index* orc_index_build(const orc_side* build, int n_contigs) {
         ix->seg[c + 1]++;
     }
     for (int c = 0; c < n_contigs; ++c) ix->seg[c + 1] += ix->seg[c];
+#pragma omp parallel for schedule(static) if (n_valid >= (1 << 20))
     for (int64_t p = 0; p < n_valid; ++p) {
         int32_t r = ix->s_row[p];
         ix->s_start[p] = build->start[r];
         ix->s_end[p] = build->end[r];
     }
+#pragma omp parallel for schedule(dynamic, 1) if (n_valid >= (1 << 20))
     for (int c = 0; c < n_contigs; ++c) {
         int32_t m = INT32_MIN;
         for (int64_t p = ix->seg[c]; p < ix->seg[c + 1]; ++p) {
@@ -236,14 +270,17 @@ orc_index* orc_index_build(const orc_side* build, int n_contigs) {
         }
     }
     /* ends sorted by (contig, end, position in start order) */
+#pragma omp parallel for schedule(static) if (n_valid >= (1 << 20))
     for (int64_t p = 0; p < n_valid; ++p) {
         keys[p] = compose(build->contig[ix->s_row[p]], ix->s_end[p]);
         ix->e_pos[p] = (int32_t)p;
     }
     radix_sort_u64(keys, ix->e_pos, n_valid, 64);
+#pragma omp parallel for schedule(static) if (n_valid >= (1 << 20))
     for (int64_t p = 0; p < n_valid; ++p) ix->e_end[p] = ix->s_end[ix->e_pos[p]];
     free(keys);
     ix->tmax = (int32_t*)malloc(4 * nn);
+#pragma omp parallel for schedule(dynamic, 1) if (n_valid >= (1 << 20))
     for (int c = 0; c < n_contigs; ++c) tree_build(ix, ix->seg[c], ix->seg[c + 1]);
     return ix;
 }
@@ -529,4 +566,28 @@ int64_t orc_overlap_baseline(const orc_index* ix, const orc_side* probe, int str
     }
     if (checksum) *checksum = csum;
     return total;
+}
+
+
+/* Copy of one probe column whose pages are first touched by the thread that will read them in orc_overlap_baseline (the same
+ * static shares np * t / nt): on a multi-socket host the all-core baseline then reads local memory instead of the one NUMA node
+ * a single-threaded generator left the column on.  Not part of any timed region. */
+void orc_place_i32(const int32_t* src, int32_t* dst, int64_t n, int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    int nt = omp_get_max_threads();
+#else
+    int nt = 1;
+#endif
+    (void)threads;
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        if (hi > lo) memcpy(dst + lo, src + lo, sizeof(int32_t) * (size_t)(hi - lo));
+    }
 }

@@ -79,6 +79,8 @@ def lib() -> C.CDLL:
         L.orc_overlap_baseline.argtypes = [C.c_void_p, P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
         L.orc_nearest_fast.restype = None
         L.orc_nearest_fast.argtypes = [C.c_void_p, P, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_place_i32.restype = None
+        L.orc_place_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         _LIB = L
     return _LIB
 
@@ -180,6 +182,17 @@ def overlap_baseline(ix: Index, probe: Side, strict: bool, threads: int, use_tre
     cs = C.c_int64(0)
     n = lib().orc_overlap_baseline(ix.h, probe.ref(), int(strict), int(threads), int(use_tree), int(sort_chunks), C.byref(cs))
     return int(n), int(cs.value)
+
+
+def placed(side: "Side", threads: int = 0) -> "Side":
+    """Copy of a side whose pages are first touched by the threads that read them in overlap_baseline (orc_place_i32): NUMA
+    placement for the all-core CPU baseline of bench.py; never inside a timed region."""
+    cols = []
+    for a in (side.contig, side.start, side.end):
+        d = np.empty(len(a), np.int32)
+        lib().orc_place_i32(a.ctypes.data, d.ctypes.data, len(a), int(threads))
+        cols.append(d)
+    return Side(*cols)
 
 
 def nearest_fast(ix: Index, probe: Side, strict: bool, k: int = 1, include_overlaps: bool = True,
