@@ -307,6 +307,8 @@ struct AsOutCol {
     int col;
     std::string name;
     AsType type;
+    bool from_ids = false;                                 // the chrom KEY column: rebuilt from the side's dictionary ids (AsResult::chrom_ids) and the
+                                                           // few names of the shared dictionary instead of a string gather out of the 10^7-row input column
 };
 
 struct AsResult {
@@ -316,6 +318,8 @@ struct AsResult {
     std::vector<int32_t> own_idx[2];
     const int32_t* idx[2] = {nullptr, nullptr};            // nullptr: identity (row r of the side)
     ivj_pairs pairs{0, nullptr, nullptr};                  // overlap: the library-owned pair buffers idx[] point into
+    std::vector<int32_t> chrom_ids[2];                     // per row of the side: id in `names` (-1: null chrom)
+    std::vector<std::string> names;                        // the shared chrom dictionary
     std::vector<int64_t> extra;
     std::vector<uint8_t> extra_null;                       // 1 = null (distance of a probe row without a neighbour)
     std::string extra_name;
@@ -401,6 +405,58 @@ inline bool as_resolve(const AsTable& t, const AsType& ty, int col, int b, int32
     va = s.d;
     if (s.d->null_count != 0 && s.d->buffers[0] && !as_bit((const uint8_t*)s.d->buffers[0], vi)) return false;
     return true;
+}
+
+// the chrom key column of output rows [lo, lo + n): names[ids[row]] -- offsets from the name lengths, bytes from the dictionary
+int as_chrom_col(const AsResult& R, const AsOutCol& oc, int64_t lo, int64_t n, int threads, ArrowArray* out) {
+    const std::vector<int32_t>& ids = R.chrom_ids[oc.side];
+    const int32_t* idx = R.idx[oc.side];
+    const int ob = oc.type.kind == AS_STR32 ? 4 : 8;
+    auto* own = new AsBufOwner();
+    std::unique_ptr<AsBufOwner> guard(own);
+    uint8_t* valid = (uint8_t*)std::calloc((size_t)((n + 7) / 8) + 1, 1);
+    int32_t* id = (int32_t*)std::malloc(n ? (size_t)n * 4 : 4);
+    if (!valid || !id) { std::free(valid); std::free(id); return fail(IVJ_ENOMEM, "result batch: out of memory"); }
+    own->bufs[0] = valid;
+    std::unique_ptr<int32_t, void (*)(void*)> idg(id, std::free);
+    std::vector<int64_t> nlen(R.names.size());
+    for (size_t v = 0; v < R.names.size(); ++v) nlen[v] = (int64_t)R.names[v].size();
+    const int tn = fd_threads(n, threads, 1 << 15);
+    std::vector<int64_t> part((size_t)tn + 1, 0), nulls((size_t)tn, 0);
+    const int64_t n_src = (int64_t)ids.size();
+    fd_parallel(n, tn, [&](int k, int64_t a, int64_t b) {
+        int64_t bytes = 0, nn = 0;
+        for (int64_t i = a; i < b; ++i) {
+            const int64_t r = idx ? (int64_t)idx[lo + i] : lo + i;
+            const int32_t v = (r >= 0 && r < n_src) ? ids[(size_t)r] : -1;
+            id[i] = v;
+            if (v >= 0) { bytes += nlen[(size_t)v]; valid[i >> 3] |= (uint8_t)(1u << (i & 7)); } else ++nn;
+        }
+        part[(size_t)k + 1] = bytes; nulls[(size_t)k] = nn;
+    });
+    for (int k = 0; k < tn; ++k) part[(size_t)k + 1] += part[(size_t)k];
+    const int64_t total = part[(size_t)tn];
+    if (ob == 4 && total > (int64_t)INT32_MAX) return fail(IVJ_EINVAL, "result batch: the values of utf8 column '" + oc.name + "' pass 2 GiB in one batch; lower batch_rows");
+    void* offs = std::malloc((size_t)(n + 1) * (size_t)ob);
+    char* bytes = (char*)std::malloc(total ? (size_t)total : 1);
+    if (!offs || !bytes) { std::free(offs); std::free(bytes); return fail(IVJ_ENOMEM, "result batch: out of memory"); }
+    own->bufs[1] = offs; own->bufs[2] = bytes;
+    fd_parallel(n, tn, [&](int k, int64_t a, int64_t b) {
+        int64_t o = part[(size_t)k];
+        for (int64_t i = a; i < b; ++i) {
+            if (ob == 4) ((int32_t*)offs)[i] = (int32_t)o; else ((int64_t*)offs)[i] = o;
+            const int32_t v = id[i];
+            if (v >= 0) { std::memcpy(bytes + o, R.names[(size_t)v].data(), (size_t)nlen[(size_t)v]); o += nlen[(size_t)v]; }
+        }
+    });
+    if (ob == 4) ((int32_t*)offs)[n] = (int32_t)total; else ((int64_t*)offs)[n] = total;
+    int64_t nn = 0;
+    for (int64_t x : nulls) nn += x;
+    for (int k = 0; k < 3; ++k) own->ptrs[k] = own->bufs[k];
+    if (nn == 0) own->ptrs[0] = nullptr;
+    *out = ArrowArray{n, nn, 0, 3, 0, own->ptrs, nullptr, nullptr, as_release_col, own};
+    guard.release();
+    return IVJ_OK;
 }
 
 int as_gather_col(const AsTable& t, const AsOutCol& oc, const AsLoc& L, int64_t n, int threads, ArrowArray* out) {
@@ -540,7 +596,7 @@ int as_stream_get_next(ArrowArrayStream* s, ArrowArray* out) {
         const int64_t lo = R->cursor, hi = lo + R->batch_rows < R->n_rows ? lo + R->batch_rows : R->n_rows, n = hi - lo;
         AsLoc L[2];
         bool used[2] = {false, false};
-        for (const AsOutCol& c : R->cols) if (c.side < 2) used[c.side] = true;
+        for (const AsOutCol& c : R->cols) if (c.side < 2 && !c.from_ids) used[c.side] = true;
         for (int sd = 0; sd < 2; ++sd) if (used[sd]) as_locate(*R->t[sd], R->idx[sd], lo, hi, L[sd], R->threads);
         auto* o = new AsBatchOwner();
         std::unique_ptr<AsBatchOwner> guard(o);
@@ -548,7 +604,9 @@ int as_stream_get_next(ArrowArrayStream* s, ArrowArray* out) {
         for (ArrowArray& c : o->child) c.release = nullptr;
         for (size_t c = 0; c < R->cols.size(); ++c) {
             const AsOutCol& oc = R->cols[c];
-            const int rc = oc.side == 2 ? as_extra_col(*R, lo, n, &o->child[c]) : as_gather_col(*R->t[oc.side], oc, L[oc.side], n, R->threads, &o->child[c]);
+            const int rc = oc.side == 2 ? as_extra_col(*R, lo, n, &o->child[c])
+                           : (oc.from_ids ? as_chrom_col(*R, oc, lo, n, R->threads, &o->child[c])
+                                          : as_gather_col(*R->t[oc.side], oc, L[oc.side], n, R->threads, &o->child[c]));
             if (rc != IVJ_OK) {
                 R->last_error = g_err;
                 for (ArrowArray& d : o->child) if (d.release) d.release(&d);
@@ -673,7 +731,9 @@ struct AsCall {
     AsKeys K;
     ivj_opts opts;
     ivj_side probe, build;
+    int chrom_col[2] = {-1, -1};
 };
+void as_keys_to_result(AsCall& C);
 int as_open(ivj_ctx* ctx, void* df1, void* df2, const char* const* cols1, const char* const* cols2, const ivj_opts* opts, void* out, AsCall& C) {
     IVJ_TRY(as_check_common(ctx, opts, static_cast<ArrowArrayStream*>(out)));
     if (!df1 || !df2) return fail(IVJ_EINVAL, "an input stream is NULL");
@@ -687,7 +747,18 @@ int as_open(ivj_ctx* ctx, void* df1, void* df2, const char* const* cols1, const 
     C.opts.n_contigs = (int32_t)C.K.dict.names.size();      // the dictionary is made here: the caller's value is not looked at
     C.probe = ivj_side{C.K.c1.data(), C.K.s1.data(), C.K.e1.data(), C.R->t[0]->n, nullptr};
     C.build = ivj_side{C.K.c2.data(), C.K.s2.data(), C.K.e2.data(), C.R->t[1]->n, nullptr};
+    static const char* const dflt[3] = {"chrom", "start", "end"};
+    C.chrom_col[0] = C.R->t[0]->find((cols1 ? cols1 : dflt)[0]);
+    C.chrom_col[1] = C.R->t[1]->find((cols2 ? cols2 : dflt)[0]);
     return IVJ_OK;
+}
+// after the join (the key vectors are no longer needed as inputs): the chrom key columns of the result come from the ids
+void as_keys_to_result(AsCall& C) {
+    AsResult& R = *C.R;
+    R.chrom_ids[0] = std::move(C.K.c1); R.chrom_ids[1] = std::move(C.K.c2);
+    R.names = std::move(C.K.dict.names);
+    for (AsOutCol& oc : R.cols)
+        if (oc.side < 2 && oc.col == C.chrom_col[oc.side]) oc.from_ids = true;
 }
 }  // namespace
 
@@ -701,6 +772,7 @@ int ivj_overlap_arrow_stream(ivj_ctx* ctx, void* df1_stream, void* df2_stream, c
     C.R->idx[0] = C.R->pairs.probe_idx; C.R->idx[1] = C.R->pairs.build_idx;
     C.R->n_rows = (limit >= 0 && limit < C.R->pairs.n_pairs) ? limit : C.R->pairs.n_pairs;
     if (batch_rows > 0) C.R->batch_rows = batch_rows;
+    as_keys_to_result(C);
     as_publish(C.R.release(), static_cast<ArrowArrayStream*>(out_stream));
     return IVJ_OK;
 } IVJ_ABI_CATCH
@@ -715,6 +787,7 @@ int ivj_count_overlaps_arrow_stream(ivj_ctx* ctx, void* df1_stream, void* df2_st
     C.R->cols.push_back(AsOutCol{2, 0, "count", AsType()});
     C.R->n_rows = (limit >= 0 && limit < C.probe.n) ? limit : C.probe.n;
     if (batch_rows > 0) C.R->batch_rows = batch_rows;
+    as_keys_to_result(C);
     as_publish(C.R.release(), static_cast<ArrowArrayStream*>(out_stream));
     return IVJ_OK;
 } IVJ_ABI_CATCH
@@ -750,6 +823,7 @@ int ivj_nearest_arrow_stream(ivj_ctx* ctx, void* df1_stream, void* df2_stream, c
     const int64_t rows = (int64_t)R.own_idx[0].size();
     R.n_rows = (limit >= 0 && limit < rows) ? limit : rows;
     if (batch_rows > 0) R.batch_rows = batch_rows;
+    as_keys_to_result(C);
     as_publish(C.R.release(), static_cast<ArrowArrayStream*>(out_stream));
     return IVJ_OK;
 } IVJ_ABI_CATCH

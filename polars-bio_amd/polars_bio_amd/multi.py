@@ -75,7 +75,8 @@ class MultiEngine:
             if len(pid) == 0 or len(bid) == 0:
                 return np.empty(0, np.int32), np.empty(0, np.int32)
             p, b = eng.overlap(lp, lb, strict, n_contigs, **kw)
-            return pid[p], bid[b]
+            from . import _host as H
+            return H.take(pid, p), H.take(bid, b)              # local rows -> global rows: the native threaded gather
         parts = self._run(job, self._shards(probe, build, n_contigs))
         return np.concatenate([p for p, _ in parts]), np.concatenate([b for _, b in parts])
 
