@@ -94,6 +94,9 @@ typedef struct {
                                   1 records, 2 plain 4-byte bins */
     int32_t slice_rows;        /* slice path: build rows per slice, 0 = auto (rows / 1024, rounded up to 64, <= 5120) */
     int32_t slice_chunk;       /* slice path: probes per join workgroup, 0 = auto (multiple of 4096) */
+    int32_t deterministic;     /* overlap count -> fill pair on the slice path: 1 = the output is identical from run to run (stable
+                                  partition, +0.5 ms per 100 M probes); 0 = same pairs, the order of the probe rows inside a
+                                  bucket tile may differ between runs (the reference leaves the row order unspecified) */
 } ivj_opts;
 
 /* Result of overlap on the host path: library-owned host buffers. */

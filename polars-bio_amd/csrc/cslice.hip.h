@@ -549,6 +549,27 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter_stable(CsTab tab, CsG
 // stable partition) an output that is identical from run to run.
 enum { CS_FUSED = 0, CS_COUNT = 1, CS_FILL = 2 };
 
+// What COUNT knows about a probe and k_cs_fill needs to emit its pairs without matching again: one word per probe record.
+//   bits 0 .. 12   first examined row of the slice (al; at most SL_MAX_ROWS - 1) -- or, flagged by k_cs_join_plain, the hi-bound
+//   bits 13 .. 28  match mask of the sixteen-row window (bit t <=> row al + t)
+//   bit 31         the window runs on below the examined rows: k_cs_fill redoes that part (plain: recounts from hi; walk: walks
+//                  the block maxima below al) -- rare by construction of the two kernels' domains
+constexpr uint32_t CS_CACHE_FLAG = 0x80000000u;
+static_assert(SL_MAX_ROWS <= (1 << 13), "a slice-local row must fit 13 bits of the cache word");
+__device__ __forceinline__ uint32_t cs_cache_word(int al, uint32_t mask, bool flagged) {
+    return (uint32_t)al | (mask << 13) | (flagged ? CS_CACHE_FLAG : 0u);
+}
+// the word travels with the probe's row: k_cs_fill then reads 8 bytes per probe instead of the 12-byte record + the word
+typedef unsigned int cs_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cs_cache_store(uint2* p, uint32_t word, int32_t qrow) {
+    cs_u2 v; v.x = word; v.y = (uint32_t)qrow;
+    __builtin_nontemporal_store(v, reinterpret_cast<cs_u2*>(p));
+}
+__device__ __forceinline__ uint2 cs_cache_load(const uint2* p) {
+    const cs_u2 v = __builtin_nontemporal_load(reinterpret_cast<const cs_u2*>(p));
+    return make_uint2(v.x, v.y);
+}
+
 struct CsJoinArgs {
     const int32_t* b_start;
     const int2* ep;
@@ -567,6 +588,7 @@ struct CsJoinArgs {
     long long capacity;
     unsigned long long* state;        // FUSED: [0] cursor, [1] overflow flag
     long long* wslot;                 // COUNT: pairs per (tile, wavefront), written; FILL: their exclusive scan, read
+    uint2* cache;                     // COUNT -> k_cs_fill: {cs_cache_word, probe row} per probe record, bucket order
     int32_t* out_probe;
     int32_t* out_build;
 };
@@ -793,6 +815,15 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
             const int wtot = __builtin_amdgcn_readlane(linc, kWave - 1);
             if constexpr (MODE == CS_COUNT) {
                 if (lane == 0) A.wslot[slot] = (long long)wtot;
+                if (A.cache) {                                                 // uniform: the matches go to k_cs_fill instead of being redone there
+                    const int64_t tb = q0 + (int64_t)tix * CS_TILE;
+                    const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
+#pragma unroll
+                    for (int j = 0; j < CS_ITEMS; ++j) {
+                        const int il = wv * CS_WTILE + j * kWave + lane;
+                        if (il < rem) cs_cache_store(A.cache + tb + il, lng[j] ? cs_cache_word(hi[j], 0u, true) : cs_cache_word(al[j], mask[j], false), qrow[j]);
+                    }
+                }
                 continue;
             }
             if (wtot == 0) continue;                                           // uniform
@@ -1269,6 +1300,15 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             const int wtot = __builtin_amdgcn_readlane(linc, kWave - 1);
             if constexpr (MODE == CS_COUNT) {
                 if (lane == 0) A.wslot[slot] = (long long)wtot;
+                if (A.cache) {
+                    const int64_t tb = q0 + (int64_t)tix * CS_TILE;
+                    const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
+#pragma unroll
+                    for (int j = 0; j < CS_ITEMS; ++j) {
+                        const int il = wv * CS_WTILE + j * kWave + lane;
+                        if (il < rem) cs_cache_store(A.cache + tb + il, cs_cache_word(al[j], mask[j], cnt[j] != __popc(mask[j])), qrow[j]);
+                    }
+                }
                 continue;
             }
             if (wtot == 0) continue;                                           // uniform
@@ -1381,6 +1421,242 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             pend_wtot = 0;
         } else pend_wtot = 0;
         pend_woff = woff;
+    }
+}
+
+
+// ---- FILL from the cache: the second pass of the count -> fill pair without a second matching pass ---------------------------------
+// COUNT left {word, probe row} per probe record (cs_cache_word) and one scanned slot per (tile, wavefront).  This kernel streams
+// those 8 bytes per probe (not the 12-byte records), turns mask bits into pairs and writes them at the wavefront's base: no bins, no
+// starts, no ends, no window compare -- the slice's build ROWS are the only index data in LDS (4 bytes per row), so two workgroups
+// share a CU.  Same workgroup -> (bucket, chunk) map, same tiles, same wavefront shares as COUNT (the slots must line up).
+// Flagged words (a window running on below the examined rows) redo exactly what COUNT did for them, reading the ends and prefix
+// maxima from HBM: WALK = false recounts row by row from the hi-bound (k_cs_join_plain's rule), WALK = true walks the block maxima
+// below al (k_cs_join's rule).
+struct CsFillLds { int row, qrow, stage, total; };
+__host__ __device__ inline CsFillLds cs_fill_lds(int R, int wcap) {
+    CsFillLds L;
+    int o = 0;
+    L.row = o; o += 4 * R;
+    L.qrow = (o + 15) & ~15; o = L.qrow + 4 * CS_TILE;
+    L.stage = o; o += 4 * wcap * CS_WAVES;
+    L.total = o;
+    return L;
+}
+
+template <bool STRICT, bool WALK, bool TWO>
+__global__ __launch_bounds__(CS_THREADS, TWO ? 8 : 4) void k_cs_fill(CsJoinArgs A) {      // (second bound: wavefronts per SIMD -- 8 = two workgroups per CU)
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    const CsFillLds L = cs_fill_lds(A.R, A.wcap);
+    int32_t* l_row = reinterpret_cast<int32_t*>(cs_lds + L.row);
+    int32_t* l_qrow = reinterpret_cast<int32_t*>(cs_lds + L.qrow);
+    uint32_t* l_stage = reinterpret_cast<uint32_t*>(cs_lds + L.stage);
+
+    const int total_wg = A.meta[0];
+    const int per = (total_wg + 7) / 8;
+    const int wslot = (int)(blockIdx.x >> 3);
+    const int v = (int)(blockIdx.x & 7) * per + wslot;
+    if (wslot >= per || v >= total_wg) return;                                 // uniform
+    const int2 bc = A.wg_map[v];
+    const int k = bc.x;
+    const int64_t q0 = (int64_t)A.bstart[k] + (int64_t)bc.y * A.jchunk;
+    const int64_t qend = (int64_t)A.bstart[k + 1];
+    const int64_t q1 = q0 + A.jchunk < qend ? q0 + A.jchunk : qend;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    const int4 sm1 = A.smeta[2 * k + 1];
+    const int seg_a = sm1.x, rk = sm1.z, r0 = sm1.w;
+    for (int i = tid; i < rk; i += CS_THREADS) l_row[i] = A.b_row[r0 + i];
+    __syncthreads();
+
+    uint32_t* stw = l_stage + wv * A.wcap;
+    int32_t* qrw = l_qrow + wv * CS_WTILE;
+    auto ep_at = [&](int p) -> int2 { return A.ep[p]; };
+    // k_cs_join's walk over the rows below slice-local row a0, every row read from HBM
+    auto walk_below = [&](int32_t qsv, int a0, auto&& f) {
+        int i = a0 - 1;
+        const int stop = a0 - CS_LIN > 0 ? a0 - CS_LIN : 0;
+        for (; i >= stop; --i) {
+            const int2 e = A.ep[r0 + i];
+            if (!lt_op<STRICT>(qsv, e.y)) return;
+            if (lt_op<STRICT>(qsv, e.x)) { if (!f(r0 + i)) return; }
+        }
+        if (r0 + i >= seg_a) hier_walk<STRICT>(A.hier, ep_at, seg_a, r0 + i, qsv, f);
+    };
+
+    const int ntile = (int)((q1 - q0 + CS_TILE - 1) / CS_TILE);
+    const int tiles_per_chunk = A.jchunk / CS_TILE;
+    // records and words of the next tile are requested before the current one is emitted
+    int32_t n_row[CS_ITEMS];
+    uint32_t n_w[CS_ITEMS];
+    auto load_tile = [&](int64_t tb) {
+        const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            const int il = wv * CS_WTILE + j * kWave + lane;
+            n_row[j] = -1; n_w[j] = 0u;
+            if (il < rem) {
+                const uint2 c = cs_cache_load(A.cache + tb + il);
+                n_w[j] = c.x; n_row[j] = (int32_t)c.y;
+            }
+        }
+    };
+    if (!TWO && ntile > 0) load_tile(q0);
+    for (int tix = 0; tix < ntile; ++tix) {
+        int32_t qs[CS_ITEMS], qrow[CS_ITEMS];
+        uint32_t w[CS_ITEMS];
+        const int64_t tb0 = q0 + (int64_t)tix * CS_TILE;
+        if (TWO) load_tile(tb0);                                               // two workgroups per CU: the other one covers the latency, no prefetch registers
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            qrow[j] = n_row[j]; w[j] = n_w[j];
+            qs[j] = 0;
+            // (rare) the probe's start is only needed to redo a running-on window: fetched here, not prefetched
+            if (w[j] & CS_CACHE_FLAG) qs[j] = A.rec[3 * (tb0 + wv * CS_WTILE + j * kWave + lane)];
+        }
+        if (!TWO && tix + 1 < ntile) load_tile(q0 + (int64_t)(tix + 1) * CS_TILE);
+        int al[CS_ITEMS], cnt[CS_ITEMS];
+        uint32_t mask[CS_ITEMS];
+        uint32_t flg = 0;
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) {
+            al[j] = (int)(w[j] & 0x1fffu);
+            mask[j] = (w[j] >> 13) & 0xffffu;
+            cnt[j] = __popc(mask[j]);
+            flg |= (w[j] & CS_CACHE_FLAG) ? (1u << j) : 0u;
+        }
+        const bool any_flag = __ballot(flg != 0) != 0;                         // uniform
+        if (any_flag) {
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                if (flg & (1u << j)) {
+                    int c2 = 0;
+                    if constexpr (WALK) { walk_below(qs[j], al[j], [&](int) { ++c2; return true; }); cnt[j] += c2; }
+                    else {
+                        for (int p = r0 + al[j] - 1; p >= seg_a; --p) {        // al = the hi-bound here: every row below it, as COUNT walked them
+                            const int2 e = A.ep[p];
+                            if (!lt_op<STRICT>(qs[j], e.y)) break;
+                            c2 += lt_op<STRICT>(qs[j], e.x) ? 1 : 0;
+                        }
+                        cnt[j] = c2;
+                    }
+                }
+            }
+        }
+        int lsum = 0;
+#pragma unroll
+        for (int j = 0; j < CS_ITEMS; ++j) lsum += cnt[j];
+        const int linc = wave_incl_sum_dpp(lsum);
+        const int wtot = __builtin_amdgcn_readlane(linc, kWave - 1);
+        if (wtot == 0) continue;                                               // uniform
+        const long long slot = ((long long)v * tiles_per_chunk + tix) * CS_WAVES + wv;
+        const long long wbase = A.wslot[slot];
+        if (wtot <= A.wcap && (WALK || !any_flag)) {
+            int off = linc - lsum;
+            if constexpr (!WALK) {
+                // the usual case: entries {wave-local probe slot << 16 | slice-local row}, resolved at copy-out
+#pragma unroll
+                for (int j = 0; j < CS_ITEMS; ++j) {
+                    qrw[j * kWave + lane] = qrow[j];
+                    uint32_t m = mask[j];
+                    const uint32_t ent = ((uint32_t)(j * kWave + lane) << 16) | (uint32_t)al[j];
+                    uint32_t* so = stw + off;
+                    while (m) {
+                        const int t = __builtin_ctz(m);
+                        m &= m - 1;
+                        so[0] = ent + (uint32_t)t;
+                        if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
+                        so += 2;
+                    }
+                    off += cnt[j];
+                }
+                __builtin_amdgcn_wave_barrier();
+                int32_t* op = A.out_probe + wbase;
+                int32_t* ob = A.out_build + wbase;
+#pragma unroll 4
+                for (int i = lane; i < wtot; i += kWave) {
+                    const uint32_t e = stw[i];
+                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // k_cs_join's entries {wave-local probe slot << 24 | (row - first row of the slice) + bias}: rows below the slice
+                // (reached by the walk) are staged too and take their build row from HBM at copy-out
+                bool below = false;
+#pragma unroll
+                for (int j = 0; j < CS_ITEMS; ++j) {
+                    qrw[j * kWave + lane] = qrow[j];
+                    uint32_t m = mask[j];
+                    const uint32_t pslot = (uint32_t)(j * kWave + lane) << 24;
+                    int cw = 0;
+                    if (any_flag && ((flg >> j) & 1u)) {
+                        cw = cnt[j] - __popc(m);
+                        if (cw > 0) {
+                            uint32_t* sw = stw + off + cw - 1;
+                            walk_below(qs[j], al[j], [&](int p) { *sw-- = pslot | (uint32_t)(p - r0 + CS_POS_BIAS); below = below || p < r0; return true; });
+                        }
+                    }
+                    const uint32_t ent = pslot | (uint32_t)(al[j] + CS_POS_BIAS);
+                    uint32_t* so = stw + off + cw;
+                    while (m) {
+                        const int t = __builtin_ctz(m);
+                        m &= m - 1;
+                        so[0] = ent + (uint32_t)t;
+                        if (m) { so[1] = ent + (uint32_t)__builtin_ctz(m); m &= m - 1; }
+                        so += 2;
+                    }
+                    off += cnt[j];
+                }
+                const bool any_below = any_flag && __ballot(below) != 0;
+                __builtin_amdgcn_wave_barrier();
+                int32_t* op = A.out_probe + wbase;
+                int32_t* ob = A.out_build + wbase;
+                for (int i = lane; i < wtot; i += kWave) {
+                    const uint32_t e = stw[i];
+                    const int pos = (int)(e & 0xffffffu) - CS_POS_BIAS;
+                    int32_t br = 0;
+                    if (!any_below || pos >= 0) br = l_row[pos];
+                    if (any_below && pos < 0) br = __builtin_nontemporal_load(A.b_row + (r0 + pos));
+                    __builtin_nontemporal_store(qrw[e >> 24], op + i);
+                    __builtin_nontemporal_store(br, ob + i);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            // a wavefront with more pairs than its staging holds, or with a window that ran on: written from the lanes
+            long long off = wbase + (linc - lsum);
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                const bool f = (flg >> j) & 1u;
+                if (WALK || !f) {
+                    int cw = 0;
+                    if (WALK && f) {
+                        cw = cnt[j] - __popc(mask[j]);
+                        long long o = off + cw - 1;                            // matches below the window first in the range, in ascending position
+                        walk_below(qs[j], al[j], [&](int p) {
+                            A.out_probe[o] = qrow[j]; A.out_build[o] = p >= r0 ? l_row[p - r0] : A.b_row[p]; --o;
+                            return true;
+                        });
+                    }
+                    uint32_t m = mask[j];
+                    long long o = off + cw;
+                    while (m) {
+                        const int t = __builtin_ctz(m);
+                        m &= m - 1;
+                        A.out_probe[o] = qrow[j]; A.out_build[o] = l_row[al[j] + t];
+                        ++o;
+                    }
+                } else {
+                    long long o = off + cnt[j] - 1;                            // the f-th match from the top owns slot end - 1 - f
+                    for (int p = r0 + al[j] - 1; o >= off; --p) {
+                        if (lt_op<STRICT>(qs[j], A.ep[p].x)) {
+                            A.out_probe[o] = qrow[j]; A.out_build[o] = p >= r0 ? l_row[p - r0] : A.b_row[p]; --o;
+                        }
+                    }
+                }
+                off += cnt[j];
+            }
+        }
     }
 }
 

@@ -101,6 +101,7 @@ struct ivj_ctx {
     char* sl_buf = nullptr;
     size_t sl_cap = 0;
     int4* sl_rec = nullptr;
+    uint2* sl_cache = nullptr;
     uint32_t *sl_blk = nullptr, *sl_part = nullptr, *sl_bstart = nullptr;
     int32_t* sl_meta = nullptr;
     int2* sl_map = nullptr;
@@ -116,6 +117,8 @@ struct ivj_ctx {
     int cs_env_walk = -1;           // IVJ_CS_WALK: -1 auto, 0 / 1 force the join kernel of the contig-aligned slices
     int cs_env_off = 0;                // IVJ_CS=0: keep the round-2 slice kernels (A/B runs)
     int cs_env_ptile = 0;              // IVJ_CS_PTILE=4096: partition tiles of 4096 probes even where 8192 fit
+    int cs_env_fill_two = 0;           // IVJ_CS_FILL_TWO=1: k_cs_fill with two workgroups per CU and no prefetch (A/B runs: 0.68-0.72 against 0.63-0.69 ms)
+    int cs_env_nocache = 0;            // IVJ_CS_NOCACHE=1: the FILL pass matches again instead of reading COUNT's words (A/B runs)
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel
     bool t_open = false;

@@ -132,6 +132,9 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         IVJ_TRY(set_dyn_lds(&k_cs_join_plain<true, CS_COUNT>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join_plain<false, CS_COUNT>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join_plain<true, CS_FILL>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join_plain<false, CS_FILL>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_scatter_stable<true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter_stable<false>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_fill<true, false, false>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_fill<false, false, false>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_fill<true, false, true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_fill<false, false, true>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds(&k_cs_fill<true, true, false>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_fill<false, true, false>, 160 * 1024));
         ctx->cs_attr_set = true;
     }
     int32_t* rec = reinterpret_cast<int32_t*>(ctx->sl_rec);
@@ -174,6 +177,7 @@ int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     A.R = g.R; A.jchunk = P.jchunk; A.wcap = P.stage; A.ablate = ctx->sl_env_ablate; A.capacity = capacity;
     A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
     A.wslot = ctx->sl_tile;
+    A.cache = (MODE == CS_FUSED || ctx->cs_env_nocache) ? nullptr : ctx->sl_cache;
     A.out_probe = out_p; A.out_build = out_b;
     const unsigned grid = 8u * (unsigned)((P.gmax + 7) / 8);
     t_begin(ctx, MODE == CS_FUSED ? "cs_join_fused" : (MODE == CS_COUNT ? "cs_join_count" : "cs_join_fill"));
@@ -218,7 +222,9 @@ int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     int wcap = 0;
     IVJ_TRY(cs_plan(ctx, ix, probe->n, opts, P, wcap));
     IVJ_TRY(ensure_sl(ctx, probe->n, P));
-    IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, true));
+    // the stable partition (match-any ranking: 1.39 against 0.88 ms for config 3) only where the caller asks for an output that
+    // is identical from run to run (opts->deterministic, IVJ_SLICE_STABLE=1); the pair is exact either way
+    IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, opts->deterministic != 0 || ctx->sl_env_stable != 0));
     HIP_TRY(hipMemsetAsync(ctx->sl_tile, 0, (size_t)(P.ntiles + 2) * 8, ctx->stream));
     IVJ_TRY(cs_join_launch<CS_COUNT>(ctx, ix, opts, P, 0, nullptr, nullptr));
     device_scan<long long, SumOp, false>(ctx, "tile_scan", ctx->sl_tile, ctx->sl_tile, P.ntiles, 0ll, ctx->sl_tpart, ctx->sl_tile + P.ntiles);
@@ -231,9 +237,49 @@ int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     return IVJ_OK;
 }
 
+// FILL from the words COUNT left per probe record (k_cs_fill): no second matching pass; two workgroups per CU where the build
+// rows of a slice + the tile's probe rows + the staging fit 80 KB.  IVJ_CS_NOCACHE=1 keeps the round-3 form (match again).
+int cs_fill_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const SlicePlan& P, int32_t* out_p, int32_t* out_b) {
+    const CsGeom& g = ix->cs_g;
+    CsJoinArgs A;
+    A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta; A.hier = view_of(ix).hier;
+    A.rec = reinterpret_cast<int32_t*>(ctx->sl_rec); A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
+    A.R = g.R; A.jchunk = P.jchunk; A.ablate = ctx->sl_env_ablate; A.capacity = 0;
+    A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
+    A.wslot = ctx->sl_tile; A.cache = ctx->sl_cache;
+    A.out_probe = out_p; A.out_build = out_b;
+    const size_t fixed = (size_t)cs_fill_lds(g.R, 0).total;
+    const size_t half = 80 * 1024, full = 160 * 1024;
+    // staging entries per wavefront: a wavefront-tile of 256 probes emits ~2 pairs per probe on the benchmark shapes.  One
+    // workgroup per CU with the whole LDS as staging and the next tile's words prefetched is the default; IVJ_CS_FILL_TWO=1 runs
+    // two workgroups per CU without the prefetch (measured slower: the kernel is bound by its 1.6 GB of pair stores)
+    const bool two = !ix->cs_walk && ctx->cs_env_fill_two != 0 && fixed + 4 * CS_WAVES * 384 <= half;
+    int wcap = (int)(((two ? half : full) - fixed) / (4 * CS_WAVES)) & ~3;
+    if (wcap > 4096) wcap = 4096;
+    A.wcap = wcap;
+    const size_t lds = (size_t)cs_fill_lds(g.R, wcap).total;
+    const unsigned grid = 8u * (unsigned)((P.gmax + 7) / 8);
+    const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
+    t_begin(ctx, "cs_fill_cached");
+    if (ix->cs_walk) {
+        if (strict) hipLaunchKernelGGL((k_cs_fill<true, true, false>), dim3(grid), dim3(CS_THREADS), lds, ctx->stream, A);
+        else hipLaunchKernelGGL((k_cs_fill<false, true, false>), dim3(grid), dim3(CS_THREADS), lds, ctx->stream, A);
+    } else if (two) {
+        if (strict) hipLaunchKernelGGL((k_cs_fill<true, false, true>), dim3(grid), dim3(CS_THREADS), lds, ctx->stream, A);
+        else hipLaunchKernelGGL((k_cs_fill<false, false, true>), dim3(grid), dim3(CS_THREADS), lds, ctx->stream, A);
+    } else {
+        if (strict) hipLaunchKernelGGL((k_cs_fill<true, false, false>), dim3(grid), dim3(CS_THREADS), lds, ctx->stream, A);
+        else hipLaunchKernelGGL((k_cs_fill<false, false, false>), dim3(grid), dim3(CS_THREADS), lds, ctx->stream, A);
+    }
+    t_end(ctx);
+    HIP_TRY(hipGetLastError());
+    return IVJ_OK;
+}
+
 int cs_overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, int32_t* out_p, int32_t* out_b) {
     if (!ctx->sl_plan_valid) return fail(IVJ_ESTATE, "slice fill without a matching count");
-    return cs_join_launch<CS_FILL>(ctx, ix, opts, ctx->sl_plan, 0, out_p, out_b);
+    if (ctx->cs_env_nocache) return cs_join_launch<CS_FILL>(ctx, ix, opts, ctx->sl_plan, 0, out_p, out_b);
+    return cs_fill_launch(ctx, ix, opts, ctx->sl_plan, out_p, out_b);
 }
 
 }  // namespace

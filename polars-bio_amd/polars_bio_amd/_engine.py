@@ -78,7 +78,8 @@ class _ArrowKeys(C.Structure):
 
 class _Opts(C.Structure):
     _fields_ = [("filter_op", C.c_int32), ("n_contigs", C.c_int32), ("nearest_k", C.c_int32),
-                ("include_overlaps", C.c_int32), ("partition_mode", C.c_int32), ("table_mode", C.c_int32), ("slice_rows", C.c_int32), ("slice_chunk", C.c_int32)]
+                ("include_overlaps", C.c_int32), ("partition_mode", C.c_int32), ("table_mode", C.c_int32), ("slice_rows", C.c_int32), ("slice_chunk", C.c_int32),
+                ("deterministic", C.c_int32)]
 
 
 class _Pairs(C.Structure):
@@ -264,8 +265,9 @@ def side_from_arrow(batch) -> Tuple[_Side, tuple]:
 
 
 def make_opts(strict: bool, n_contigs: int, k: int = 1, include_overlaps: bool = True, partition_mode: int = 0,
-              table_mode: int = 0, slice_rows: int = 0, slice_chunk: int = 0) -> _Opts:
+              table_mode: int = 0, slice_rows: int = 0, slice_chunk: int = 0, deterministic: bool = False) -> _Opts:
     o = _Opts()
+    o.deterministic = 1 if deterministic else 0
     o.slice_rows = int(slice_rows)
     o.slice_chunk = int(slice_chunk)
     o.table_mode = int(table_mode)
@@ -446,12 +448,14 @@ class Engine:
 
     # ---- host-buffer entry points (numpy in, numpy out) --------------------
     def overlap(self, probe, build, strict: bool, n_contigs: int, partition_mode: int = 0, table_mode: int = 0, slice_rows: int = 0,
-                slice_chunk: int = 0):
+                slice_chunk: int = 0, deterministic: bool = False):
         """probe/build: (contig_id, start, end) int32 arrays -> (probe_idx, build_idx).
-        partition_mode: 0 auto, 1 256 buckets + window scan, 2 never (pairs then come in probe-row order), 6 index slices in LDS."""
+        partition_mode: 0 auto, 1 256 buckets + window scan, 2 never (pairs then come in probe-row order), 6 index slices in LDS.
+        deterministic: the slice path's output is identical from run to run (stable partition; ivj_opts.deterministic)."""
         ps, keep_p = _host_side(*probe)
         bs, keep_b = _host_side(*build)
-        o = make_opts(strict, n_contigs, partition_mode=partition_mode, table_mode=table_mode, slice_rows=slice_rows, slice_chunk=slice_chunk)
+        o = make_opts(strict, n_contigs, partition_mode=partition_mode, table_mode=table_mode, slice_rows=slice_rows, slice_chunk=slice_chunk,
+                      deterministic=deterministic)
         out = _Pairs()
         _check(self.L, self.L.ivj_overlap(self.h, C.byref(ps), C.byref(bs), C.byref(o), C.byref(out)), "ivj_overlap")
         del keep_p, keep_b

@@ -968,19 +968,22 @@ def test_coverage_subtract_with_probe_only_contigs_interleaved(eng, strict):
 
 
 def test_slice_count_fill_pair_is_deterministic(eng):
-    """partition_mode 6 through ivj_overlap = the deterministic pair of the contig-aligned slice path (stable partition,
-    per-(tile, wavefront) counts, scan, fill at the scanned bases): exact against the oracle and bit-identical between runs,
-    for several slice geometries and both predicates."""
+    """partition_mode 6 through ivj_overlap = the count -> fill pair of the contig-aligned slice path (per-(tile, wavefront)
+    counts, scan, fill at the scanned bases from the words COUNT cached per probe): exact against the oracle for several slice
+    geometries and both predicates; with opts.deterministic (stable partition) bit-identical between runs as well."""
     probe = synth.make_side(700_000, 42, synth.PROBE_LEN, 24)
     build = synth.make_side(120_000, 43, synth.BUILD_LEN, 24)
     for strict in (True, False):
         ep, eb = O.overlap_fast(O.Index(O.Side(*build), 24), O.Side(*probe), strict)
         for sr in (0, 256):
-            p1, b1 = eng.overlap(probe, build, strict, 24, partition_mode=6, slice_rows=sr)
-            p2, b2 = eng.overlap(probe, build, strict, 24, partition_mode=6, slice_rows=sr)
+            p1, b1 = eng.overlap(probe, build, strict, 24, partition_mode=6, slice_rows=sr, deterministic=True)
+            p2, b2 = eng.overlap(probe, build, strict, 24, partition_mode=6, slice_rows=sr, deterministic=True)
             assert (p1 == p2).all() and (b1 == b2).all(), (strict, sr)
             o = np.argsort(p1, kind="stable")
             assert len(p1) == len(ep) and (p1[o] == ep).all() and (b1[o] == eb).all(), (strict, sr)
+            p3, b3 = eng.overlap(probe, build, strict, 24, partition_mode=6, slice_rows=sr)       # default: unordered partition
+            o = np.argsort(p3, kind="stable")
+            assert len(p3) == len(ep) and (p3[o] == ep).all() and (b3[o] == eb).all(), (strict, sr, "unordered")
 
 
 def _long_tail_build(rng, n, nc, span, frac_long, n_wide):
