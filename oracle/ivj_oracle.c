@@ -139,13 +139,9 @@ static void radix_sort_u64(uint64_t* keys, int32_t* vals, int64_t n, int key_bit
     int64_t* cnt = (int64_t*)malloc(sizeof(int64_t) * 65536 * (size_t)nt);
     for (int shift = 0; shift < key_bits; shift += 16) {
         memset(cnt, 0, sizeof(int64_t) * 65536 * (size_t)nt);
-#pragma omp parallel num_threads(nt)
-        {
-#ifdef _OPENMP
-            const int t = omp_get_thread_num();
-#else
-            const int t = 0;
-#endif
+        /* (a loop over the nt chunks, not "one chunk per thread of the team": the runtime may hand out fewer threads than asked for) */
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; ++t) {
             const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
             int64_t* c = cnt + (size_t)t * 65536;
             for (int64_t i = lo; i < hi; ++i) c[(src[i] >> shift) & 0xFFFF]++;
@@ -153,13 +149,8 @@ static void radix_sort_u64(uint64_t* keys, int32_t* vals, int64_t n, int key_bit
         int64_t run = 0;
         for (int d = 0; d < 65536; ++d)
             for (int t = 0; t < nt; ++t) { int64_t* c = cnt + (size_t)t * 65536 + d; const int64_t v = *c; *c = run; run += v; }
-#pragma omp parallel num_threads(nt)
-        {
-#ifdef _OPENMP
-            const int t = omp_get_thread_num();
-#else
-            const int t = 0;
-#endif
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; ++t) {
             const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
             int64_t* c = cnt + (size_t)t * 65536;
             for (int64_t i = lo; i < hi; ++i) {

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_scatter(IndexView ix, con
     IVJ_PART_EXCHANGE(s, os);
     IVJ_PART_EXCHANGE(e, oe);
     IVJ_PART_EXCHANGE(c, oc);
-    IVJ_PART_EXCHANGE(r, orow);
+    IVJ_PART_EXCHANGE(r, orow);                      // (k_unpermute places every result by this column: it is not optional)
 #undef IVJ_PART_EXCHANGE
 }
 
