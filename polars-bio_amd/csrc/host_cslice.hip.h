@@ -7,10 +7,15 @@ namespace {
 // Geometry for an index of n rows over nc contigs; false when the path does not apply (the callers keep slice.hip.h /
 // the 256-bucket kernels).  Known on the host without looking at the data: the bucket SLOTS are an upper bound on the
 // slices (sum over contigs of ceil(n_c / R) <= n / R + min(nc, n)).
+// Rows per slice, auto: n / 1024 but not below CS_MIN_ROWS -- a 1 M-row index in 1024-row slices runs config 2's join at 0.35 ms,
+// in 3072-row slices at 0.23 ms (fewer, longer workgroups; profiles/r04/policy_sweep.txt); IVJ_CS_MIN_ROWS overrides (sweeps).
+constexpr int CS_MIN_ROWS = 3072;
 bool cs_geom(int64_t n, int nc, int want_rows, CsGeom& g) {
     if (n <= 0 || nc < 1 || nc > CS_MAX_CONTIGS) return false;
     const int64_t extra = (nc < n ? nc : n) + 1;
-    int64_t R = want_rows > 0 ? want_rows : (n + 1023) / 1024;
+    int64_t min_rows = CS_MIN_ROWS;
+    if (const char* ev = std::getenv("IVJ_CS_MIN_ROWS")) { const int v = std::atoi(ev); if (v > 0) min_rows = v; }
+    int64_t R = want_rows > 0 ? want_rows : std::max<int64_t>((n + 1023) / 1024, min_rows);
     R = (R + 63) / 64 * 64;
     if (n / R + extra > SL_MAX_BUCKETS) {
         if (extra + 8 >= SL_MAX_BUCKETS) return false;

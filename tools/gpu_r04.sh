@@ -27,6 +27,7 @@ run_stage() {
     c5) timeout 900 $B --workload count_200M_200k_24contig --steps 10 --warmup 2 --kernel-table 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
     c3fd) echo "== bench config3 through the N > 1 code path on one rank (library communicator, world 1)"; timeout 900 $B --force-dist --steps 5 --warmup 2 $Q 2>$o.err | tee $o.json | cut -c1-900 ;;
     frontend) timeout 600 python tools/frontend_e2e.py 2>&1 | tee $o.txt | tail -12 ;;
+    sweep) timeout 1200 python tools/policy_sweep.py ${GRID:-4e6x256e3x24 4e6x1e6x24 10e6x256e3x1 10e6x1e6x1 10e6x1e6x24 10e6x2e6x24 30e6x1e6x24 30e6x2e6x24 30e6x5e6x24 100e6x5e6x24} 2>&1 | tee $o.txt | tail -14 ;;
     shard) timeout 900 python tools/shard_probe.py 2>&1 | tee $o.txt | tail -12 ;;
     c3dense) timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 $Q 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;
     c3rows) timeout 900 $B --steps 10 --warmup 2 --materialize $Q 2>$o.err | tee $o.json | cut -c1-600; grep -A16 "per-kernel" $o.err ;;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Calibrates the automatic choice between the 256-bucket window-scan path (partition_mode 1) and the slice path
 (partition_mode 6) of the fused overlap pass: times ivj_overlap_fused_dev for a grid of (probe rows, build rows, contigs)
-on synthetic data of synth.make_side's shape.  Output: one line per grid point, ms per call for both modes."""
+on synthetic data of synth.make_side's shape.  Output: one line per grid point, ms per STEP (index build + per-index tables +
+partition + fused join, as bench.py times a step) for both modes and for the automatic choice."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "polars-bio_amd")):
@@ -32,19 +33,22 @@ def main():
         op, ob = eng.dev_alloc(4 * tot + 64), eng.dev_alloc(4 * tot + 64)
         ptrs += [op, ob]
         res = {}
+        ix.close()
         for pm in (1, 6, 0):
+            # a step as bench.py times it: index build + (per-index tables) + partition + fused join
             o = _engine.make_opts(True, nc, partition_mode=pm)
-            eng.overlap_fused_dev(ix, sides[0], o, op, ob, tot)
-            eng.sync()
-            t0 = time.perf_counter()
-            for _ in range(5):
+            for rep in range(7):
+                if rep == 2:
+                    eng.sync()
+                    t0 = time.perf_counter()
+                ix = eng.index_build_dev(sides[1], o)
                 n, fits = eng.overlap_fused_dev(ix, sides[0], o, op, ob, tot)
+                ix.close()
             eng.sync()
             res[pm] = (time.perf_counter() - t0) / 5 * 1e3
             assert fits and n == tot
         print(f"{np_:>11,d} x {nb:>10,d} x {nc:2d}  pairs {tot:>12,d}  mode1 {res[1]:7.3f} ms  mode6 {res[6]:7.3f} ms  auto {res[0]:7.3f} ms"
               f"  -> {'slices' if res[6] < res[1] else 'window scan'}", flush=True)
-        ix.close()
         for p in ptrs:
             eng.dev_free(p)
     eng.close()
