@@ -89,7 +89,8 @@ def test_full_size_config3_overlap_100M_x_5M(eng):
     try:
         op, ob = d.alloc(4 * total), d.alloc(4 * total)
         hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
-        # 1. the deterministic two-pass path (auto mode): EXACT pair list after a stable sort by probe row
+        # 1. the count -> fill pair (auto mode: unordered partition, FILL from COUNT's cached words): EXACT pair list after a stable
+        #    sort by probe row
         opts = _engine.make_opts(True, nc)
         ixd = eng.index_build_dev(d.build, opts)
         assert eng.overlap_count_dev(ixd, d.probe, opts) == total
@@ -108,8 +109,8 @@ def test_full_size_config3_overlap_100M_x_5M(eng):
         eng.d2h(got, cp)
         assert (got == counts).all()
         del got
-        # 2. the slice path's deterministic pair (partition_mode 6: stable scatter, count pass, fill pass)
-        o6 = _engine.make_opts(True, nc, partition_mode=6)
+        # 2. the slice path's DETERMINISTIC pair (partition_mode 6 + opts.deterministic: stable scatter, count pass, fill pass)
+        o6 = _engine.make_opts(True, nc, partition_mode=6, deterministic=True)
         assert eng.overlap_count_dev(ixd, d.probe, o6) == total
         eng.overlap_fill_dev(ixd, d.probe, o6, op, ob, total)
         eng.d2h(hp, op)
