@@ -5,7 +5,7 @@ import sys
 
 d = json.load(open(sys.argv[1]))
 for k, v in d.items():
-    if not any(t in k for t in ("slice", "overlap", "part_", "k_cs_", "k_os_", "k_ix_")):
+    if not any(t in k for t in ("slice", "overlap", "part_", "k_cs_", "k_os_", "k_ix_", "nearest", "unpermute")):
         continue
     g = lambda n: v.get(n, {}).get("sum", 0.0) / max(v.get(n, {}).get("rows", 1), 1)
     wc = g("SQ_WAVE_CYCLES") or 1
