@@ -8,7 +8,8 @@ Metric (BASELINE.json): emitted overlap-pairs/s (+ achieved HBM GB/s) of pb.over
 when the timed region starts, results left in HBM.
 
 A "step" is one full pass of the hot path over the batch: device radix sort of the build side
-(index build) -> count pass -> tile scan -> fill pass.  N > 1 (launched by
+(index build) -> probe partition (contig-aligned index slices) -> fused count / fill into the
+preallocated result columns (`--two-pass`: count pass -> slot scan -> fill pass).  N > 1 (launched by
 torch.distributed.run, one rank per GPU): the SAME 100M x 5M job is contig-sharded over the
 ranks (LPT), every rank joins its contigs, and the result batches are exchanged with an RCCL
 all-gatherv inside the timed region ("scaling": "strong": total work is fixed as N grows).
@@ -18,12 +19,14 @@ torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous); under an externa
 as given and `n_gpus` must equal --gpus.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      -- dominant kernel: algorithmic bytes / live HIP-event kernel time vs 8 TB/s; `traffic` = HBM
-                   bytes per launch of that kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) that
+  roofline      -- dominant kernel: algorithmic bytes PER LAUNCH / live HIP-event time of a launch vs 8 TB/s (a kernel
+                   that runs several times per step processes that fraction of the step's bytes each time); `traffic` =
+                   HBM bytes per launch of that kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) that
                    this run makes over itself (N=1; null when rocprofv3 is unavailable or --no-pmc)
-  cpu_baseline  -- the oracle's CPU port timed on the host cores (N=1 only) on a bounded sample of the same
-                   workload: 1 thread and all cores, best of 3, one pass per probe row.
-and, for overlap: `two_pass_ms_per_step` (the deterministic count -> scan -> fill pair, cold-capacity path) and
+  cpu_baseline  -- the oracle's CPU port timed on the host cores (N=1 only): all cores on the IDENTICAL input (index built
+                   with all cores, busy cores reported), 1 thread on a 2 M-row sample; one pass per probe row.
+and, for overlap: `two_pass_ms_per_step` (the count -> scan -> fill pair a call of unknown capacity runs, i.e. what
+ivj_overlap and the front door's pb.overlap take) and
 `host_path_s` (numpy columns in pageable host memory -> pb.overlap's C entry point -> numpy pairs, PCIe inclusive);
 for all three operations `stream_path_s` (the same columns through the streaming session, batch by batch).
 """
