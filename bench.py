@@ -169,6 +169,15 @@ def algorithmic_bytes(op, n_p, n_b, n_out):
     return 8 * n_p + 8 * n_b + 12 * n_p + contig      # nearest k=1
 
 
+def cgroup_cpu_quota():
+    """CPU quota of this process's cgroup in cores (cgroup v2 cpu.max = "<quota> <period>" | "max <period>"), None if unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        return None
+
+
 def cpu_baseline(op, probe, build, nc, sample_rows):
     """The oracle's CPU port on the host cores.  All-core runs: the IDENTICAL input (every probe row, SURVEY.md section 8d;
     ``--cpu-sample N`` > 0 bounds them to the first N rows), index built with all cores and charged in full, probe columns
@@ -178,11 +187,15 @@ def cpu_baseline(op, probe, build, nc, sample_rows):
     executor), both index forms (bound search over the sorted arrays; implicit augmented interval tree = the stand-in for the
     reference's COITrees), probe rows as given and sorted per thread share (sort inside the timed call); best of 2 (1 thread: 3)."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cpu_count = os.cpu_count() or 1
+    quota = cgroup_cpu_quota()
+    # threads = the cores this process may actually keep busy: a container's CPU quota (cgroup cpu.max) caps them below cpu_count
+    cores = cpu_count if quota is None else max(1, min(cpu_count, int(quota + 0.999)))
     n_total = len(probe[0])
     n = n_total if sample_rows <= 0 else min(sample_rows, n_total)
     n1 = max(1, min(n, 2_000_000))
     bs = O.Side(*build)
+    O.set_threads(cores)
     t0 = time.perf_counter()
     ix = O.Index(bs, nc)                          # parallel LSD sort + per-contig passes (oracle/ivj_oracle.c)
     t_index = time.perf_counter() - t0
@@ -236,9 +249,9 @@ def cpu_baseline(op, probe, build, nc, sample_rows):
     best_one = max((k for k in runs if k.startswith("one_thread")), key=lambda k: runs[k]["rate"])
     ra, r1 = runs[best_all], runs[best_one]
     value = ra["units"] / (ra["probe_s"] + t_index * n / n_total)
-    return {"value": value, "unit": unit, "cores": cores, "busy_cores": ra["busy_cores"], "kind": "port",
+    return {"value": value, "unit": unit, "cores": cores, "busy_cores": ra["busy_cores"], "cpu_count": cpu_count, "cgroup_quota_cores": quota, "kind": "port",
             "sample": (f"the identical input: all {n:,} probe rows" if n == n_total else f"first {n:,} of {n_total:,} probe rows") +
-                      f" x full build ({len(build[0]):,} rows), {cores} threads, best of 2 (1-thread runs: first {n1:,} probe rows, best of 3); "
+                      f" x full build ({len(build[0]):,} rows), {cores} threads" + (f" (cpu_count {cpu_count}, cgroup quota {quota:g} cores)" if quota is not None else "") + f", best of 2 (1-thread runs: first {n1:,} probe rows, best of 3); "
                       f"all-core best = {best_all} {ra['probe_s']:.3f}s for {ra['units']:,} units, {ra['busy_cores']} cores busy on average; "
                       f"index build (all cores) {t_index:.2f}s charged x{n / n_total:.2f}",
             "one_thread": {"value": r1["rate"], "variant": best_one, "note": "probe only (index build excluded), 1 thread; "

@@ -582,3 +582,13 @@ void orc_place_i32(const int32_t* src, int32_t* dst, int64_t n, int threads) {
         if (hi > lo) memcpy(dst + lo, src + lo, sizeof(int32_t) * (size_t)(hi - lo));
     }
 }
+
+
+/* threads of the parallel regions that take their count from the runtime (the index build): a host that knows its CPU quota sets it */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

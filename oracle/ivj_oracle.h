@@ -97,6 +97,8 @@ int64_t orc_overlap_tree(const orc_index* ix, const orc_side* probe, int strict,
 int64_t orc_overlap_baseline(const orc_index* ix, const orc_side* probe, int strict, int threads, int use_tree,
                              int sort_chunks, int64_t* checksum);
 
+void orc_set_threads(int n);
+
 /* copy of a probe column first-touched by the threads that read it in orc_overlap_baseline (NUMA placement; never timed) */
 void orc_place_i32(const int32_t* src, int32_t* dst, int64_t n, int threads);
 

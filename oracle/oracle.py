@@ -79,6 +79,8 @@ def lib() -> C.CDLL:
         L.orc_overlap_baseline.argtypes = [C.c_void_p, P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
         L.orc_nearest_fast.restype = None
         L.orc_nearest_fast.argtypes = [C.c_void_p, P, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_set_threads.restype = None
+        L.orc_set_threads.argtypes = [C.c_int]
         L.orc_place_i32.restype = None
         L.orc_place_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         _LIB = L
@@ -182,6 +184,11 @@ def overlap_baseline(ix: Index, probe: Side, strict: bool, threads: int, use_tre
     cs = C.c_int64(0)
     n = lib().orc_overlap_baseline(ix.h, probe.ref(), int(strict), int(threads), int(use_tree), int(sort_chunks), C.byref(cs))
     return int(n), int(cs.value)
+
+
+def set_threads(n: int) -> None:
+    """Threads of the index build's parallel passes (the other entry points take ``threads`` themselves)."""
+    lib().orc_set_threads(int(n))
 
 
 def placed(side: "Side", threads: int = 0) -> "Side":

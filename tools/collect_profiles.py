@@ -5,7 +5,7 @@ usage: collect_profiles.py <tag> [<commit>]      (IVJ_ROUND=r03 by default)"""
 import glob, json, os, re, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("IVJ_ROUND", "r03")
+ROUND = os.environ.get("IVJ_ROUND", "r04")
 SRC, DST = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", ROUND)
 NAMES = {
     "c3": "bench_overlap_100M_5M", "c3two": "bench_overlap_100M_5M_two_pass", "c3old": "bench_overlap_100M_5M_round2_slice_kernels",
@@ -51,7 +51,12 @@ def main():
     for src, dst, what in ((f"{tag}_prof.kernel_stats.csv", "rocprofv3_kernel_stats_overlap_100M_5M.csv", "`rocprofv3 --kernel-trace --stats` of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras` (config 3)"),
                            (f"{tag}_fast.log", "pytest_gpu_fast.log", "`pytest -m gpu` without the full-size configs"),
                            (f"{tag}_full.log", "pytest_gpu_full_size.log", "`pytest -m gpu -k 'full_size or two_rank or self_spawn'` (configs 3, 4, 5 at stated size; the 2-GPU tests skip on a 1-GPU box)"),
-                           (f"{tag}_pmcsq.summary.json", "pmc_sq_lds_overlap_100M_5M.json", "`rocprofv3 --kernel-trace --pmc` SQ / LDS counter sets (three passes, `tools/gpu_r03.sh pmcsq`, per kernel, mean per launch) of config 3"),
+                           (f"{tag}_pmcsq.summary.json", "pmc_sq_lds_overlap_100M_5M.json", "`rocprofv3 --kernel-trace --pmc` SQ / LDS counter sets (three passes, `tools/gpu_r04.sh pmcsq`, per kernel, mean per launch) of config 3"),
+                           (f"{tag}_pmctcc_WL_overlap_100M_5M_24contig.summary.json", "pmc_tcc_overlap_100M_5M.json", "`rocprofv3 --kernel-trace --pmc` L2 <-> fabric request counters by size (TCC_EA0_RDREQ / _32B / _64B / _128B, WRREQ / _64B, DRAM, TCC hit / miss; `tools/gpu_r04.sh pmctcc`), config 3, per kernel, mean per launch"),
+                           (f"{tag}_pmctcc_WL_nearest_50M_2M_24contig.summary.json", "pmc_tcc_nearest_50M_2M.json", "the same request-size passes for config 4"),
+                           (f"{tag}_pmctcc.summary.json", "pmc_tcc_count_200M_200k.json", "the same request-size passes for config 5 (the evidence behind its 14.6 GB of `traffic`: 101.6 M fabric reads, ALL of them 128-byte requests)"),
+                           (f"{tag}_shard.txt", "shard_probe.txt", "`tools/shard_probe.py`: host sharding behind MultiEngine at 100 M x 5 M rows (native one-pass form against the per-rank numpy form), MultiEngine.overlap on two slots of one GPU, the one-call Arrow entry against pb.overlap"),
+                           (f"{tag}_sweep.txt", "policy_sweep.txt", "`tools/policy_sweep.py`: whole steps (index build + tables + partition + fused join), 256-bucket window scan (mode 1) against contig-aligned slices (mode 6) and the automatic choice, over a grid of sizes"),
                            (f"{tag}_frontend.txt", "frontend_e2e.txt", "`tools/frontend_e2e.py`: pb.overlap end to end through the Python front door, per stage")):
         p = os.path.join(SRC, src)
         if os.path.exists(p):

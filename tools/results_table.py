@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Prints the BASELINE.md section-4 result tables (markdown) from the bench lines collected under profiles/<round>/ (IVJ_ROUND, default r03)."""
+"""Prints the BASELINE.md section-4 result tables (markdown) from the bench lines collected under profiles/<round>/ (IVJ_ROUND, default r04)."""
 import json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-D = os.path.join(ROOT, "profiles", os.environ.get("IVJ_ROUND", "r03"))
+D = os.path.join(ROOT, "profiles", os.environ.get("IVJ_ROUND", "r04"))
 
 
 def load(name):
@@ -18,7 +18,8 @@ def sci(v):
 def main():
     head = [("1 overlap 1k×1k, 1 contig", "bench_overlap_1k_1k"), ("2 overlap 10M×1M, 1 contig", "bench_overlap_10M_1M"),
             ("3 overlap 100M×5M, 24 contigs (fused single pass, contig-aligned slices)", "bench_overlap_100M_5M"),
-            ("3, deterministic count → fill pair", "bench_overlap_100M_5M_two_pass"),
+            ("3, count → fill pair (what `ivj_overlap` / the front door run: capacity unknown)", "bench_overlap_100M_5M_two_pass"),
+            ("3 through the N > 1 code path on one rank (4 chunks, library communicator of world 1)", "bench_overlap_100M_5M_multi_rank_path_world1"),
             ("3, fused, round-2 slice kernels (`IVJ_CS=0`)", "bench_overlap_100M_5M_round2_slice_kernels"),
             ("3, fused, 256-bucket window scan forced (`partition_mode` 1)", "bench_overlap_100M_5M_mode1_window_scan"),
             ("3 dense (build L 5k–40k)", "bench_overlap_100M_5M_dense"), ("4 nearest 50M×2M, 24 contigs", "bench_nearest_50M_2M"),
