@@ -190,3 +190,86 @@ def test_count_and_nearest_arrow_streams_match_the_golden_tables():
         assert "distance" not in nod.column_names
     finally:
         eng.close()
+
+
+def test_take_stream_column_kinds_offsets_and_per_batch_dictionaries():
+    """Sliced batches (array offsets != 0), decimals / fixed-size binary / dates / times / durations / binary / large_binary /
+    bool with nulls, and a dictionary column whose batches carry DIFFERENT dictionaries: the row assembly equals pyarrow's take."""
+    import datetime as dt
+    import decimal
+    n = 700
+    rng = np.random.default_rng(8)
+    base = pa.table({
+        "i16": pa.array(rng.integers(-30000, 30000, n), pa.int16()),
+        "u64": pa.array(rng.integers(0, 2**62, n, dtype=np.int64).astype(np.uint64), pa.uint64()),
+        "f32": pa.array(rng.normal(size=n).astype(np.float32)),
+        "dec": pa.array([decimal.Decimal(int(x)) / 100 for x in rng.integers(-10**6, 10**6, n)], pa.decimal128(12, 2)),
+        "fsb": pa.array([bytes(rng.integers(0, 256, 5).astype(np.uint8)) for _ in range(n)], pa.binary(5)),
+        "d32": pa.array([dt.date(2000, 1, 1) + dt.timedelta(days=int(x)) for x in rng.integers(0, 9000, n)], pa.date32()),
+        "t64": pa.array(rng.integers(0, 86_400_000_000, n), pa.time64("us")),
+        "dur": pa.array(rng.integers(0, 10**9, n), pa.duration("ms")),
+        "bin": pa.array([None if i % 11 == 0 else bytes([i % 256]) * (i % 7) for i in range(n)], pa.binary()),
+        "lbin": pa.array([bytes([i % 256]) * (i % 5) for i in range(n)], pa.large_binary()),
+        "flag": pa.array([None if i % 13 == 0 else bool(i % 3) for i in range(n)], pa.bool_()),
+    })
+    # a dictionary column with a different dictionary per batch
+    parts = []
+    for k, (lo, hi) in enumerate(((0, 200), (200, 450), (450, n))):
+        vals = [f"v{k}_{i % (3 + k)}" if i % 17 else None for i in range(lo, hi)]
+        parts.append(pa.array(vals).dictionary_encode())
+    batches = []
+    for k, (lo, hi) in enumerate(((0, 200), (200, 450), (450, n))):
+        sl = base.slice(lo, hi - lo)
+        rb = sl.combine_chunks().to_batches()[0]
+        batches.append(pa.RecordBatch.from_arrays(list(rb.columns) + [parts[k]], names=rb.schema.names + ["cat"]))
+    # array offsets != 0: every batch is itself a slice of a longer one
+    batches = [b.slice(3, b.num_rows - 5) for b in batches]
+    schema = batches[0].schema
+    reader = pa.RecordBatchReader.from_batches(schema, batches)
+    whole = pa.Table.from_batches([b.cast(schema) if b.schema == schema else b for b in batches])
+    m = whole.num_rows
+    idx = rng.integers(-1, m, 1500)
+    got = E.arrow_take_stream(reader, idx, 400).read_all()
+    mask = idx < 0
+    safe = np.where(mask, 0, idx)
+    for name in whole.column_names:
+        col = whole.column(name)
+        if pa.types.is_dictionary(col.type):
+            col = col.cast(pa.string())
+        ref = col.combine_chunks().take(pa.array(safe, mask=mask))
+        assert got.column(name).type == col.type, name
+        assert got.column(name).to_pylist() == ref.to_pylist(), name
+
+
+def test_streams_with_no_rows_and_no_batches():
+    empty = pa.table({"chrom": pa.array([], pa.string()), "start": pa.array([], pa.int64()), "end": pa.array([], pa.int64())})
+    t = pa.table({"chrom": ["chr1", "chr2"], "start": [1, 5], "end": [3, 9]})
+    s1, s2, names = E.arrow_encode_keys(empty, t)
+    assert len(s1[0]) == 0 and names == ["chr1", "chr2"] and s2[0].tolist() == [0, 1]
+    s1, s2, names = E.arrow_encode_keys(pa.RecordBatchReader.from_batches(t.schema, []), empty)      # a stream without a single batch
+    assert len(s1[0]) == 0 and len(s2[0]) == 0 and names == []
+    out = E.arrow_take_stream(empty, np.array([-1, 0, 5], np.int64)).read_all()
+    assert out.num_rows == 3 and out.column("chrom").null_count == 3 and out.column("start").null_count == 3
+    assert E.arrow_take_stream(t, np.empty(0, np.int64)).read_all().num_rows == 0
+
+
+@pytest.mark.gpu
+def test_arrow_stream_entries_on_empty_and_unsupported_inputs():
+    eng = E.Engine(0)
+    try:
+        empty = pa.table({"chrom": pa.array([], pa.string()), "start": pa.array([], pa.int32()), "end": pa.array([], pa.int32())})
+        t = pa.table({"chrom": ["chr1", "chr1"], "start": pa.array([1, 5], pa.int32()), "end": pa.array([3, 9], pa.int32()), "w": [0.5, 1.5]})
+        for a, b, rows in ((empty, t, 0), (t, empty, 0), (empty, empty, 0)):
+            res = E.overlap_arrow_stream(eng, a, b, True).read_all()
+            assert res.num_rows == rows and res.column_names == [f"{c}_1" for c in a.column_names] + [f"{c}_2" for c in b.column_names]
+        c = E.count_overlaps_arrow_stream(eng, t, empty, True).read_all()
+        assert c.column("count").to_pylist() == [0, 0] and c.column("w").to_pylist() == [0.5, 1.5]
+        nn = E.nearest_arrow_stream(eng, t, empty, True).read_all()
+        assert nn.num_rows == 2 and nn.column("chrom_2").null_count == 2 and nn.column("distance").null_count == 2
+        nested = t.append_column("lst", pa.array([[1], [2, 3]]))
+        with pytest.raises(E.EngineError, match="df2: column 'lst' has Arrow format"):
+            E.overlap_arrow_stream(eng, t, nested, True)
+        # ... while the key encoder does not care about payload columns it never assembles
+        assert E.arrow_encode_keys(t, nested)[2] == ["chr1"]
+    finally:
+        eng.close()
