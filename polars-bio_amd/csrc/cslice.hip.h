@@ -322,10 +322,17 @@ __host__ __device__ inline CsPartLds cs_part_lds(int nb, int ncells, int n_conti
 
 // PITEMS probes per thread: tiles of 4096 (4) or 8192 (8) probes.  The record stores are what the scatter pays for (0.50 ms
 // of 1.04 for config 3: ~25 M bucket runs of 48 bytes each); a tile twice as large makes every run twice as long.
-template <bool STRICT, int PITEMS>
+// SAMPLED (round 4): no histogram pass in front.  The buckets own REGIONS of the record buffer sized from a 1 / 64 sample of the probe
+// side (+ 25 % + a constant, k_cs_regions); a tile reserves the place of each of its bucket runs with one returning atomic on the
+// bucket's cursor (blk_off = region starts, rcur = cursors), the join reads [region start, region start + cursor).  A run that does
+// not fit its region raises bit 2 of the state word and is written over the region's start (in bounds: a region holds at least a
+// tile): the host discards the call's result and redoes it with the exact, histogram-first partition.  Probes without a candidate
+// row (bucket g.nb) are not stored at all.
+template <bool STRICT, int PITEMS, bool SAMPLED>
 __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
                                                           const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
                                                           int chunk, int nchunks, bool vec_ok, const uint32_t* __restrict__ blk_off,
+                                                          uint32_t* __restrict__ rcur, unsigned long long* __restrict__ state,
                                                           int32_t* __restrict__ out /* 3 int32 per record */, int ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
     constexpr int TILE = CS_THREADS * PITEMS;
@@ -345,7 +352,8 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
     const int tid = threadIdx.x;
     const int nbk = g.nb + 1;
     cs_load_tab(tab, g, l_spl, l_cm, l_cell, CS_THREADS);
-    for (int k = tid; k < nbk + 1; k += CS_THREADS) { base[k] = k < nbk ? blk_off[(int64_t)k * nchunks + blockIdx.x] : 0u; cnt[k] = 0; }
+    // exact: base[b] = running global offset of bucket b for this chunk; SAMPLED: base[b] = start of bucket b's region (b <= g.nb)
+    for (int k = tid; k < nbk + 1; k += CS_THREADS) { base[k] = SAMPLED ? blk_off[k < nbk ? k : nbk - 1] : (k < nbk ? blk_off[(int64_t)k * nchunks + blockIdx.x] : 0u); cnt[k] = 0; }
     __syncthreads();
     const int64_t cbase = (int64_t)blockIdx.x * chunk;
     const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
@@ -399,7 +407,19 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
 #pragma unroll
         for (int q = 0; q < OWN; ++q) {
             const int b = OWN * tid + q;
-            if (b < nbk) { lstart[b] = (uint32_t)pre; delta[b] = base[b] - (uint32_t)pre; base[b] += (uint32_t)x[q]; }
+            if (b < nbk) {
+                lstart[b] = (uint32_t)pre;
+                if constexpr (SAMPLED) {
+                    uint32_t at = base[b];                                      // region start (an overflowing run lands here, in bounds)
+                    if (x[q] > 0 && b < g.nb) {
+                        const uint32_t cap = base[b + 1] - base[b];
+                        const uint32_t got = atomicAdd(&rcur[b], (uint32_t)x[q]);
+                        if (got + (uint32_t)x[q] <= cap) at += got;
+                        else atomicOr(state + 1, 4ull);
+                    }
+                    delta[b] = at - (uint32_t)pre;
+                } else { delta[b] = base[b] - (uint32_t)pre; base[b] += (uint32_t)x[q]; }
+            }
             pre += x[q];
         }
         __syncthreads();                                                        // (C)
@@ -415,7 +435,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
 #pragma unroll
         for (int j = 0; j < PITEMS; ++j) {
             const int il = j * CS_THREADS + tid;
-            if (il < tile_n && !(ablate & 256)) {
+            if (il < tile_n && !(ablate & 256) && !(SAMPLED && l_d[il] == (unsigned short)g.nb)) {
                 cs_rec v; v.x = l_rs[il]; v.y = l_re[il]; v.z = l_rr[il];
                 uint32_t oi = (uint32_t)il + delta[l_d[il]];
                 if (ablate & 2048) oi &= (1u << 22) - 1u;                      // profiling only: every store lands in the first 48 MB (address-translation probe)
@@ -423,6 +443,98 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
             }
         }
         // no barrier here: the next tile's barrier (A) separates this copy-out from the next placement
+    }
+}
+
+// ---- SAMPLED partition: region sizes from 1 / 64 of the probe side ---------------------------------------------------------------
+// Sample = groups of CS_SGROUP consecutive probes (one 32-byte sector per column) every CS_SGROUP * CS_SRATE probes; gh[b] += sampled
+// probes of bucket b.  A few hundred workgroups, the bucket table in LDS as in k_cs_hist.
+constexpr int CS_SGROUP = 8, CS_SRATE = 64;
+template <bool STRICT>
+__global__ __launch_bounds__(CS_THREADS) void k_cs_sample_hist(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ pe,
+                                                              int64_t n, uint32_t* __restrict__ gh) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    int4* l_cm = reinterpret_cast<int4*>(cs_lds);
+    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(l_cm + CS_MAX_CONTIGS);
+    uint32_t* l_cell = reinterpret_cast<uint32_t*>(l_spl + g.nb);
+    uint32_t* h = l_cell + g.ncells;
+    cs_load_tab(tab, g, l_spl, l_cm, l_cell, CS_THREADS);
+    for (int k = threadIdx.x; k <= g.nb; k += CS_THREADS) h[k] = 0;
+    __syncthreads();
+    const int64_t n_groups = (n + (int64_t)CS_SGROUP * CS_SRATE - 1) / ((int64_t)CS_SGROUP * CS_SRATE);
+    for (int64_t t = (int64_t)blockIdx.x * CS_THREADS + threadIdx.x; t < n_groups * CS_SGROUP; t += (int64_t)gridDim.x * CS_THREADS) {
+        const int64_t i = (t / CS_SGROUP) * ((int64_t)CS_SGROUP * CS_SRATE) + (t % CS_SGROUP);
+        if (i < n) atomicAdd(&h[cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, pc[i], pe[i])], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= g.nb; k += CS_THREADS) if (h[k]) atomicAdd(&gh[k], h[k]);
+}
+
+// Regions of the record buffer: cap_b = 1.25 x (sampled count x CS_SRATE) + slack, starts aligned to 32 records (three 128-byte lines);
+// rstart[nb] = records reserved in total (bucket nb, "no candidate row", owns no region).  slack >= one partition tile, so that a run
+// which does not fit can be parked at its region's start without leaving it.  Clears the cursors.  One workgroup.
+__global__ __launch_bounds__(CS_THREADS) void k_cs_regions(const uint32_t* __restrict__ gh, int nb, uint32_t slack, uint32_t* __restrict__ rstart,
+                                                          uint32_t* __restrict__ rcur) {
+    __shared__ __attribute__((aligned(16))) int wsum[CS_WAVES];
+    constexpr int OWN = (SL_MAX_BUCKETS + 1 + CS_THREADS - 1) / CS_THREADS;
+    uint32_t cap[OWN];
+    long long mine = 0;
+#pragma unroll
+    for (int q = 0; q < OWN; ++q) {
+        const int b = OWN * threadIdx.x + q;
+        cap[q] = 0;
+        if (b < nb) {
+            const unsigned long long est = (unsigned long long)gh[b] * CS_SRATE;
+            unsigned long long c = est + est / 4 + slack;
+            c = (c + 31ull) & ~31ull;
+            cap[q] = (uint32_t)c;
+        }
+        mine += cap[q];
+    }
+    long long total;
+    long long pre = sl_block_exclusive_sum_i32<CS_WAVES>((int)mine, wsum, &total);      // (capacities sum below 2^31 records: checked on the host)
+#pragma unroll
+    for (int q = 0; q < OWN; ++q) {
+        const int b = OWN * threadIdx.x + q;
+        if (b < nb) { rstart[b] = (uint32_t)pre; rcur[b] = 0u; }
+        pre += cap[q];
+    }
+    if (threadIdx.x == 0) { rstart[nb] = (uint32_t)total; rcur[nb] = 0u; }
+}
+
+// chunk table of the join from the regions and their final cursors (k_slice_chunks' counterpart): bstart / bend per bucket, the
+// workgroup -> (bucket, chunk) map, meta[0] = number of join workgroups.  One workgroup.
+__global__ __launch_bounds__(SL_THREADS) void k_cs_chunks_sampled(const uint32_t* __restrict__ rstart, const uint32_t* __restrict__ rcur, int nb,
+                                                                 int jchunk, uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend,
+                                                                 int32_t* __restrict__ meta, int2* __restrict__ wg_map) {
+    __shared__ int l_cpre[SL_MAX_BUCKETS + 2];
+    __shared__ int wsum[SL_WAVES];
+    int cnt2[2];
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int b = 2 * threadIdx.x + k;
+        cnt2[k] = 0;
+        if (b <= nb) {
+            const uint32_t s = rstart[b];
+            uint32_t c = 0;
+            if (b < nb) { const uint32_t cap = rstart[b + 1] - s; c = rcur[b] < cap ? rcur[b] : cap; }
+            bstart[b] = s; bend[b] = s + c;
+            if (b == nb) { bstart[nb + 1] = s; bend[nb + 1] = s; }
+            if (b < nb) cnt2[k] = (int)((c + (uint32_t)jchunk - 1u) / (uint32_t)jchunk);
+        }
+        v += cnt2[k];
+    }
+    int total;
+    const int pre = sl_block_exclusive_sum(v, wsum, &total);
+    if (2 * threadIdx.x <= nb) l_cpre[2 * threadIdx.x] = pre;
+    if (2 * threadIdx.x + 1 <= nb) l_cpre[2 * threadIdx.x + 1] = pre + cnt2[0];
+    if (threadIdx.x == 0) { meta[0] = total; l_cpre[nb + 1] = total; }
+    __syncthreads();
+    for (int w = threadIdx.x; w < total; w += SL_THREADS) {
+        int lo = 0, hi = nb;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (l_cpre[m + 1] <= w) lo = m + 1; else hi = m; }
+        wg_map[w] = make_int2(lo, w - l_cpre[lo]);
     }
 }
 
@@ -589,6 +701,7 @@ struct CsJoinArgs {
     HierView hier;                    // the sorted ends and their block maxima (index_view.hip.h)
     const int32_t* rec;               // bucket-ordered probe records {start, end, row}
     const uint32_t* bstart;           // nb + 2 bucket starts
+    const uint32_t* bend;             // SAMPLED partition: end of every bucket's records inside its region (nullptr: bstart[k + 1])
     const int32_t* meta;              // [0] = number of join workgroups
     const int2* wg_map;               // workgroup -> (bucket, chunk inside the bucket)
     int R;
@@ -648,7 +761,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
     const int2 bc = A.wg_map[v];
     const int k = bc.x;
     const int64_t q0 = (int64_t)A.bstart[k] + (int64_t)bc.y * A.jchunk;
-    const int64_t qend = (int64_t)A.bstart[k + 1];
+    const int64_t qend = A.bend ? (int64_t)A.bend[k] : (int64_t)A.bstart[k + 1];
     const int64_t q1 = q0 + A.jchunk < qend ? q0 + A.jchunk : qend;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
 
@@ -1042,7 +1155,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     const int2 bc = A.wg_map[v];
     const int k = bc.x;
     const int64_t q0 = (int64_t)A.bstart[k] + (int64_t)bc.y * A.jchunk;
-    const int64_t qend = (int64_t)A.bstart[k + 1];
+    const int64_t qend = A.bend ? (int64_t)A.bend[k] : (int64_t)A.bstart[k + 1];
     const int64_t q1 = q0 + A.jchunk < qend ? q0 + A.jchunk : qend;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
 
@@ -1470,7 +1583,7 @@ __global__ __launch_bounds__(CS_THREADS, TWO ? 8 : 4) void k_cs_fill(CsJoinArgs 
     const int2 bc = A.wg_map[v];
     const int k = bc.x;
     const int64_t q0 = (int64_t)A.bstart[k] + (int64_t)bc.y * A.jchunk;
-    const int64_t qend = (int64_t)A.bstart[k + 1];
+    const int64_t qend = A.bend ? (int64_t)A.bend[k] : (int64_t)A.bstart[k + 1];
     const int64_t q1 = q0 + A.jchunk < qend ? q0 + A.jchunk : qend;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
     const int4 sm1 = A.smeta[2 * k + 1];

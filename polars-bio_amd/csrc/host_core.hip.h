@@ -102,6 +102,8 @@ struct ivj_ctx {
     size_t sl_cap = 0;
     int4* sl_rec = nullptr;
     uint2* sl_cache = nullptr;
+    uint32_t *sl_gh = nullptr, *sl_rstart = nullptr, *sl_rcur = nullptr, *sl_bend = nullptr;   // sampled partition (cslice.hip.h)
+    bool sl_sampled = false;           // the last contig-aligned partition was the sampled one (the join reads sl_bend)
     uint32_t *sl_blk = nullptr, *sl_part = nullptr, *sl_bstart = nullptr;
     int32_t* sl_meta = nullptr;
     int2* sl_map = nullptr;
@@ -113,11 +115,16 @@ struct ivj_ctx {
     int env_joint_bins = 0, env_count_nolds = 0, env_count_ablate = 0;     // IVJ_JOINT_BINS (1|2), IVJ_COUNT_NOLDS: tuning knobs of count_overlaps
     int sl_env_rows = 0, sl_env_chunk = 0, sl_env_notab = 0, sl_env_nobins = 0, sl_env_ablate = 0, sl_env_auto = 1, sl_env_stable = 0, sl_env_sthreads = 1024;   // IVJ_SLICE_ROWS / IVJ_SLICE_CHUNK: tuning knobs used when the opts fields are 0
     SlicePlan sl_plan;
+    bool cs_sattr_set = false;         // ... and those of the sampled partition
     bool cs_attr_set = false;          // contig-aligned slice path (cslice.hip.h): LDS attributes set once
     int cs_env_walk = -1;           // IVJ_CS_WALK: -1 auto, 0 / 1 force the join kernel of the contig-aligned slices
     int cs_env_off = 0;                // IVJ_CS=0: keep the round-2 slice kernels (A/B runs)
     int cs_env_ptile = 0;              // IVJ_CS_PTILE=4096: partition tiles of 4096 probes even where 8192 fit
     int cs_env_fill_two = 0;           // IVJ_CS_FILL_TWO=1: k_cs_fill with two workgroups per CU and no prefetch (A/B runs: 0.68-0.72 against 0.63-0.69 ms)
+    int cs_env_sampled = 1;            // IVJ_CS_SAMPLED=0: always the histogram-first partition (A/B runs)
+    int cs_env_slack = 0;              // IVJ_CS_SLACK: records of slack per bucket region (tests force the overflow path with a tiny one)
+    int64_t cs_sampled_overflows = 0;  // calls redone because a sampled region overflowed (ivj_debug_counter)
+    bool cs_force_exact = false;       // set while a call whose sampled regions overflowed is redone
     int cs_env_nocache = 0;            // IVJ_CS_NOCACHE=1: the FILL pass matches again instead of reading COUNT's words (A/B runs)
     // timing
     int timing = 0;          // 0 off, 1 probe kernels only, 2 every kernel

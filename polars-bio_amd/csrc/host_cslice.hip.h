@@ -87,6 +87,19 @@ int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix) {
     return IVJ_OK;
 }
 
+// Sampled partition (no histogram pass): the unordered scatter only, and only where the record capacity stays a 32-bit count.
+// slack per region: >= one partition tile (an overflowing run is parked at its region's start), + n / (16 nb).
+bool cs_sampled_wanted(const ivj_ctx* ctx, int64_t n, bool stable) {
+    return !stable && ctx->cs_env_sampled != 0 && !ctx->cs_force_exact && n >= (1ll << 16) && n <= (1ll << 30);
+}
+uint32_t cs_region_slack(const ivj_ctx* ctx, const CsGeom& g, int64_t n) {
+    if (ctx->cs_env_slack > 0) return (uint32_t)((ctx->cs_env_slack + 31) & ~31);        // (tests: below a tile, overflowing runs may leave the region -- only with regions that overflow anyway)
+    return (uint32_t)((2 * CS_TILE + n / (16 * (int64_t)(g.nb > 0 ? g.nb : 1)) + 31) & ~31ll);
+}
+int64_t cs_record_capacity(const ivj_ctx* ctx, const CsGeom& g, int64_t n) {
+    return n + n / 4 + n / 32 + (int64_t)(cs_region_slack(ctx, g, n) + 64) * (g.nb + 2) + 2 * CS_TILE;
+}
+
 int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* opts, SlicePlan& P, int& wcap) {
     const CsGeom& g = ix->cs_g;
     P.g.nb = g.nb; P.g.R = g.R; P.g.ncells = g.ncells; P.g.cps = g.cps;
@@ -128,8 +141,8 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     const size_t hist = (size_t)(g.nb + 1) * (size_t)P.nchunks;
     if (!ctx->cs_attr_set) {
         IVJ_TRY(set_dyn_lds(&k_cs_hist<true>, 96 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_hist<false>, 96 * 1024));
-        IVJ_TRY(set_dyn_lds(&k_cs_scatter<true, 4>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter<false, 4>, 160 * 1024));
-        IVJ_TRY(set_dyn_lds(&k_cs_scatter<true, 8>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter<false, 8>, 160 * 1024));
+        IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 4, false>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 4, false>), 160 * 1024));
+        IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, false>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 8, false>), 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_FUSED>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_FUSED>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_COUNT>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_COUNT>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_FILL>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_FILL>, 160 * 1024));
@@ -143,6 +156,37 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         ctx->cs_attr_set = true;
     }
     int32_t* rec = reinterpret_cast<int32_t*>(ctx->sl_rec);
+    ctx->sl_sampled = cs_sampled_wanted(ctx, n, stable);
+    if (ctx->sl_sampled) {
+        // region sizes from a 1 / 64 sample of the probe side, one returning atomic per (tile, bucket) run in the scatter, no histogram pass
+        if (!ctx->cs_sattr_set) {
+            IVJ_TRY(set_dyn_lds(&k_cs_sample_hist<true>, 96 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_sample_hist<false>, 96 * 1024));
+            IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 4, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 4, true>), 160 * 1024));
+            IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 8, true>), 160 * 1024));
+            ctx->cs_sattr_set = true;
+        }
+        HIP_TRY(hipMemsetAsync(ctx->sl_gh, 0, (size_t)(g.nb + 2) * 4, ctx->stream));
+        const int64_t n_samp = (n + CS_SRATE - 1) / CS_SRATE;
+        const unsigned sgrid = (unsigned)std::min<int64_t>(256, (n_samp + CS_THREADS - 1) / CS_THREADS);
+        t_begin(ctx, "cs_sample");
+        if (strict) hipLaunchKernelGGL((k_cs_sample_hist<true>), dim3(sgrid), dim3(CS_THREADS), hist_lds, ctx->stream, tab, g, probe->contig, probe->end, n, ctx->sl_gh);
+        else hipLaunchKernelGGL((k_cs_sample_hist<false>), dim3(sgrid), dim3(CS_THREADS), hist_lds, ctx->stream, tab, g, probe->contig, probe->end, n, ctx->sl_gh);
+        t_end(ctx);
+        LAUNCH(ctx, "cs_regions", k_cs_regions, 1, CS_THREADS, (const uint32_t*)ctx->sl_gh, g.nb, cs_region_slack(ctx, g, n), ctx->sl_rstart, ctx->sl_rcur);
+        unsigned long long* state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
+        t_begin(ctx, "cs_scatter");
+#define IVJ_CS_SCATTER_S(S, I)                                                                                                          \
+    hipLaunchKernelGGL((k_cs_scatter<S, I, true>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, \
+                       probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_rstart, ctx->sl_rcur, state, rec, ctx->sl_env_ablate)
+        if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER_S(true, 8); else IVJ_CS_SCATTER_S(true, 4); }
+        else { if (P.part_items == 8) IVJ_CS_SCATTER_S(false, 8); else IVJ_CS_SCATTER_S(false, 4); }
+#undef IVJ_CS_SCATTER_S
+        t_end(ctx);
+        LAUNCH(ctx, "cs_chunks", k_cs_chunks_sampled, 1, SL_THREADS, (const uint32_t*)ctx->sl_rstart, (const uint32_t*)ctx->sl_rcur, g.nb, P.jchunk, ctx->sl_bstart,
+               ctx->sl_bend, ctx->sl_meta, ctx->sl_map);
+        HIP_TRY(hipGetLastError());
+        return IVJ_OK;
+    }
     t_begin(ctx, "cs_hist");
     if (strict) hipLaunchKernelGGL((k_cs_hist<true>), dim3(P.nchunks), dim3(CS_THREADS), hist_lds, ctx->stream, tab, g, probe->contig, probe->end, n, P.chunk, P.nchunks, vec, ctx->sl_blk);
     else hipLaunchKernelGGL((k_cs_hist<false>), dim3(P.nchunks), dim3(CS_THREADS), hist_lds, ctx->stream, tab, g, probe->contig, probe->end, n, P.chunk, P.nchunks, vec, ctx->sl_blk);
@@ -163,8 +207,8 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     }
     t_begin(ctx, "cs_scatter");
 #define IVJ_CS_SCATTER(S, I)                                                                                                            \
-    hipLaunchKernelGGL((k_cs_scatter<S, I>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, \
-                       probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, rec, ctx->sl_env_ablate)
+    hipLaunchKernelGGL((k_cs_scatter<S, I, false>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, \
+                       probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, (uint32_t*)nullptr, (unsigned long long*)nullptr, rec, ctx->sl_env_ablate)
     if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER(true, 8); else IVJ_CS_SCATTER(true, 4); }
     else { if (P.part_items == 8) IVJ_CS_SCATTER(false, 8); else IVJ_CS_SCATTER(false, 4); }
 #undef IVJ_CS_SCATTER
@@ -178,7 +222,7 @@ int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     const CsGeom& g = ix->cs_g;
     CsJoinArgs A;
     A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta; A.hier = view_of(ix).hier;
-    A.rec = reinterpret_cast<int32_t*>(ctx->sl_rec); A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
+    A.rec = reinterpret_cast<int32_t*>(ctx->sl_rec); A.bstart = ctx->sl_bstart; A.bend = ctx->sl_sampled ? ctx->sl_bend : nullptr; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
     A.R = g.R; A.jchunk = P.jchunk; A.wcap = P.stage; A.ablate = ctx->sl_env_ablate; A.capacity = capacity;
     A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
     A.wslot = ctx->sl_tile;
@@ -199,20 +243,32 @@ int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     return IVJ_OK;
 }
 
+// A sampled partition whose regions overflowed (state bit 4) left records out: the whole call is redone with the histogram-first
+// partition.  The flag lives in the context only for the duration of that second attempt.
+struct CsExactScope {
+    ivj_ctx* ctx;
+    explicit CsExactScope(ivj_ctx* c) : ctx(c) { ctx->cs_force_exact = true; ++ctx->cs_sampled_overflows; }
+    ~CsExactScope() { ctx->cs_force_exact = false; }
+};
+
 int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
                      int64_t capacity, int64_t* n_pairs) {
     SlicePlan P;
     int wcap = 0;
     IVJ_TRY(cs_plan(ctx, ix, probe->n, opts, P, wcap));
-    IVJ_TRY(ensure_sl(ctx, probe->n, P));
+    IVJ_TRY(ensure_sl(ctx, probe->n, P, cs_sampled_wanted(ctx, probe->n, false) ? cs_record_capacity(ctx, ix->cs_g, probe->n) : 0));
     ctx->sl_plan_valid = false;
+    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));                // {pairs, flags}: the sampled scatter may set bit 4
     IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, false));
     if (ctx->sl_env_ablate & (256 | 1024 | 2048)) { *n_pairs = 0; HIP_TRY(hipStreamSynchronize(ctx->stream)); return IVJ_OK; }   // profiling: the records are not usable
-    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
     IVJ_TRY(cs_join_launch<CS_FUSED>(ctx, ix, opts, P, (long long)capacity, out_p, out_b));
     HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_meta + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
+    if ((ctx->h_total[1] & 4) && ctx->sl_sampled) {
+        CsExactScope redo(ctx);
+        return cs_overlap_fused(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
+    }
     *n_pairs = ctx->h_total[0];
     if (ctx->h_total[1] & 2)          // a bounded wait of the fused tile protocol ran out: the pairs cannot be trusted
         return fail(IVJ_EHIP, "tile protocol timeout in the fused slice join: a workgroup waited for a tile base that never came; the result was discarded");
@@ -226,16 +282,24 @@ int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     SlicePlan P;
     int wcap = 0;
     IVJ_TRY(cs_plan(ctx, ix, probe->n, opts, P, wcap));
-    IVJ_TRY(ensure_sl(ctx, probe->n, P));
     // the stable partition (match-any ranking: 1.39 against 0.88 ms for config 3) only where the caller asks for an output that
     // is identical from run to run (opts->deterministic, IVJ_SLICE_STABLE=1); the pair is exact either way
-    IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, opts->deterministic != 0 || ctx->sl_env_stable != 0));
+    const bool stable = opts->deterministic != 0 || ctx->sl_env_stable != 0;
+    IVJ_TRY(ensure_sl(ctx, probe->n, P, cs_sampled_wanted(ctx, probe->n, stable) ? cs_record_capacity(ctx, ix->cs_g, probe->n) : 0));
+    ctx->sl_plan_valid = false;
+    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
+    IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, stable));
     HIP_TRY(hipMemsetAsync(ctx->sl_tile, 0, (size_t)(P.ntiles + 2) * 8, ctx->stream));
     IVJ_TRY(cs_join_launch<CS_COUNT>(ctx, ix, opts, P, 0, nullptr, nullptr));
     device_scan<long long, SumOp, false>(ctx, "tile_scan", ctx->sl_tile, ctx->sl_tile, P.ntiles, 0ll, ctx->sl_tpart, ctx->sl_tile + P.ntiles);
     HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_tile + P.ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_total + 1, ctx->sl_meta + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
+    if ((ctx->h_total[1] & 4) && ctx->sl_sampled) {
+        CsExactScope redo(ctx);
+        return cs_overlap_count(ctx, ix, probe, opts, n_pairs);
+    }
     ctx->sl_plan_valid = true;
     ctx->sl_plan = P;
     *n_pairs = *ctx->h_total;
@@ -248,7 +312,7 @@ int cs_fill_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     const CsGeom& g = ix->cs_g;
     CsJoinArgs A;
     A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta; A.hier = view_of(ix).hier;
-    A.rec = reinterpret_cast<int32_t*>(ctx->sl_rec); A.bstart = ctx->sl_bstart; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
+    A.rec = reinterpret_cast<int32_t*>(ctx->sl_rec); A.bstart = ctx->sl_bstart; A.bend = ctx->sl_sampled ? ctx->sl_bend : nullptr; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
     A.R = g.R; A.jchunk = P.jchunk; A.ablate = ctx->sl_env_ablate; A.capacity = 0;
     A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
     A.wslot = ctx->sl_tile; A.cache = ctx->sl_cache;

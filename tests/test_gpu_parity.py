@@ -1108,3 +1108,67 @@ def test_fused_tile_protocol_timeout_fails_loudly(cs, monkeypatch):
         assert (p == ep).all() and (b == eb).all()
     finally:
         e.close()
+
+
+def _periodic_adversary(n_probe, n_build, n_contigs=24):
+    """A probe side that defeats the 1 / 64 sample of the sampled partition: the sample reads the first 8 rows of every 512, and
+    exactly those rows sit on contig 0 while every other row sits on contig 1 -- the sample sees an empty contig 1."""
+    probe = synth.make_side(n_probe, 77, synth.PROBE_LEN, n_contigs)
+    build = synth.make_side(n_build, 78, synth.BUILD_LEN, n_contigs)
+    c = np.where(np.arange(n_probe) % 512 < 8, 0, 1).astype(np.int32)
+    probe = (c, probe[1], probe[2])
+    bc = (np.arange(n_build) % 2).astype(np.int32)           # build rows on both contigs
+    build = (bc, build[1], build[2])
+    return probe, build
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_sampled_partition_matches_and_falls_back(strict, monkeypatch):
+    """The contig-aligned slice path sizes its bucket regions from a sample (no histogram pass).  (a) the sampled partition is the
+    one that runs by default and its pairs are exact; (b) a probe side the sample misjudges overflows a region, the call is redone
+    with the histogram-first partition (both kernels appear in the timings) and is still exact; (c) IVJ_CS_SAMPLED=0 never samples."""
+    monkeypatch.setenv("IVJ_CS", "1")
+    probe = synth.make_side(400_000, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(80_000, 43, synth.BUILD_LEN, 24)
+    adv_probe, adv_build = _periodic_adversary(400_000, 80_000)
+    for (pr, bu), expect_redo in (((probe, build), False), ((adv_probe, adv_build), True)):
+        ep, eb = O.overlap_fast(O.Index(O.Side(*bu), 24), O.Side(*pr), strict)
+        e = _engine.Engine(0)
+        try:
+            e.enable_timing(2)
+            hp, hb = _fused_overlap(e, pr, bu, strict, 24, 6, len(ep))
+            t = e.timings()
+            assert "cs_sample" in t, sorted(t)
+            assert ("cs_hist" in t) == expect_redo, sorted(t)
+            p, b = _canon(hp, hb)
+            assert (p == ep).all() and (b == eb).all()
+        finally:
+            e.close()
+    monkeypatch.setenv("IVJ_CS_SAMPLED", "0")
+    e = _engine.Engine(0)
+    try:
+        e.enable_timing(2)
+        ep, eb = O.overlap_fast(O.Index(O.Side(*build), 24), O.Side(*probe), strict)
+        hp, hb = _fused_overlap(e, probe, build, strict, 24, 6, len(ep))
+        t = e.timings()
+        assert "cs_hist" in t and "cs_sample" not in t, sorted(t)
+        p, b = _canon(hp, hb)
+        assert (p == ep).all() and (b == eb).all()
+    finally:
+        e.close()
+
+
+def test_sampled_partition_count_fill_pair(monkeypatch):
+    """The two-pass protocol (ivj_overlap_count_dev / ivj_overlap_fill_dev) over sampled regions, and over the redo after an
+    overflowing region: same pairs as the oracle."""
+    monkeypatch.setenv("IVJ_CS", "1")
+    for pr, bu in ((synth.make_side(300_000, 5, synth.PROBE_LEN, 24), synth.make_side(70_000, 6, synth.BUILD_LEN, 24)),
+                   _periodic_adversary(300_000, 70_000)):
+        ep, eb = O.overlap_fast(O.Index(O.Side(*bu), 24), O.Side(*pr), True)
+        e = _engine.Engine(0)
+        try:
+            hp, hb = e.overlap(pr, bu, True, 24, partition_mode=6)          # ivj_overlap: count, allocate, fill
+            p, b = _canon(np.asarray(hp), np.asarray(hb))
+            assert (p == ep).all() and (b == eb).all()
+        finally:
+            e.close()
