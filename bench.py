@@ -86,6 +86,8 @@ def parse():
                          "overlaps the join), 'torch' = torch.distributed all-gatherv after the join; auto = lib when every rank has its "
                          "own device, else torch over gloo (several ranks on one GPU: tests)")
     ap.add_argument("--chunks", type=int, default=4, help="N>1, lib exchange: probe chunks per rank (join of chunk i overlaps the exchange of chunk i-1)")
+    ap.add_argument("--canary-timeout", type=float, default=180.0,
+                    help="N>1, lib exchange: seconds the 4-KB canary exchange may take before the run falls back to torch.distributed")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (RCCL init, sharding, all-gatherv) even with one rank")
     return ap.parse_args()
@@ -366,6 +368,40 @@ def respawn_under_torchrun(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+
+def _comm_canary(comm, rank, world, dev, timeout_s):
+    """True when every rank's 1024 int32 arrive at this rank through the library communicator within `timeout_s` seconds."""
+    import threading
+    out = {}
+
+    def run():
+        try:
+            counts = comm.allgather_counts(1024)
+            if counts != [1024] * world:
+                raise RuntimeError(f"count all-gather returned {counts}")
+            send = torch.full((1024,), rank, dtype=torch.int32, device=dev)
+            recv = torch.full((1024 * world,), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+            comm.allgatherv_dev([send.data_ptr()], [recv.data_ptr()], 4, counts)
+            torch.cuda.synchronize(dev)
+            want = torch.arange(world, dtype=torch.int32, device=dev).repeat_interleave(1024)
+            if not bool((recv == want).all()):
+                raise RuntimeError("canary payload differs")
+            out["ok"] = True
+        except Exception as e:                      # noqa: BLE001 -- reported, then the caller falls back
+            out["err"] = repr(e)
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        log(f"[bench] rank {rank}: the library communicator's canary exchange did not finish in {timeout_s:.0f} s")
+        return False
+    if "err" in out:
+        log(f"[bench] rank {rank}: the library communicator's canary exchange failed: {out['err']}")
+        return False
+    return True
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -436,6 +472,10 @@ def main():
             except Exception as e:
                 log(f"[bench] rank {rank}: ivj_comm_create failed: {e!r}")
                 ok = 0
+            if ok:
+                # canary: one small count all-gather + all-gatherv over the new communicator, on a helper thread with a deadline.  A
+                # transport that cannot move 4 KB between the devices of this node (or hangs doing so) must not take the timed run with it.
+                ok = 1 if _comm_canary(comm, rank, n_gpus, dev, args.canary_timeout) else 0
             flag = torch.tensor([ok])
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:

@@ -48,8 +48,10 @@ bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, Sli
         // tools/policy_sweep.py.  Round-2 slice kernels (profiles/r02/policy_sweep.txt): against the 256-bucket window scan they only pay
         // once the sorted build side is far larger than the L2s (5 M rows: -5 % at 30 M probes, -6 % at 100 M; 1-2 M rows: +2..+60 %).
         // The contig-aligned form with slices of >= 3072 rows (round 4, profiles/r04/policy_sweep.txt) wins the whole step wherever
-        // bucketing pays at all: 4 M x 256 k rows -13 %, 10 M x 1 M (config 2) -18 %, 30 M x 1 M -25 %, 100 M x 5 M -31 %.
-        if (cs) { if (!(on && n_probe >= (4ll << 20) && ix->n >= (256ll << 10))) return false; }
+        // bucketing pays at all: 4 M x 256 k rows -13 %, 10 M x 1 M (config 2) -18 %, 30 M x 1 M -25 %, 100 M x 5 M -31 %; with the
+        // sampled partition also on the shards of an 8-rank run and their chunks (2 M x 625 k x 3 contigs -16 %, 3 M x 625 k -12 %,
+        // 12.5 M x 625 k -27 %; 1 M probes: a tie).
+        if (cs) { if (!(on && n_probe >= (3ll << 19) && ix->n >= (256ll << 10))) return false; }
         else if (!(on && n_probe >= (24ll << 20) && ix->n >= (4ll << 20))) return false;
     }
     return slice_geom(ix, opts, g);
