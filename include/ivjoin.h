@@ -90,8 +90,10 @@ typedef struct {
                                   results); 6 LDS-resident index slices: one stable partition into <= 1536 slices of equal
                                   row count + join on the slice held in LDS (overlap count / fill / fused; falls back to 1
                                   when the build side exceeds 1536 x 5120 rows or for the other operations) */
-    int32_t table_mode;        /* direct-address table form: 0 auto (16-byte records for build sides >= 2^20 rows),
-                                  1 records, 2 plain 4-byte bins */
+    int32_t table_mode;        /* direct-address table form: 0 auto (16-byte records for build sides >= 2^20 rows; nearest k = 1 over
+                                  128-byte LINES -- one fetch per probe, probes in input order -- for build sides >= 2^17 rows once
+                                  the probe side is >= 8 x the build side), 1 records, 2 plain 4-byte bins, 3 records + the nearest
+                                  lines whatever the sizes (256 bytes of index per build row; other operations: as 1) */
     int32_t slice_rows;        /* slice path: build rows per slice, 0 = auto (rows / 1024, rounded up to 64, <= 5120) */
     int32_t slice_chunk;       /* slice path: probes per join workgroup, 0 = auto (multiple of 4096) */
     int32_t deterministic;     /* overlap count -> fill pair on the slice path: 1 = the output is identical from run to run (stable

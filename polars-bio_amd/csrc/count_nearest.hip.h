@@ -119,6 +119,47 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
 
 // ------------------------------------------------------------------ nearest
 
+__device__ __forceinline__ int4 sel3(int m0, const int4& a, int m1, const int4& b, int m2, const int4& c) {
+    return make_int4((a.x & m0) | (b.x & m1) | (c.x & m2), (a.y & m0) | (b.y & m1) | (c.y & m2), (a.z & m0) | (b.z & m1) | (c.z & m2),
+                     (a.w & m0) | (b.w & m1) | (c.w & m2));
+}
+
+// bound_lo for a probe that is known to overlap a row below hi: the first position whose prefix max satisfies "q.start (<) pmax" lies a few
+// rows below hi, so gallop down from hi (2, 8, 32, ... rows) to a position that fails and search the rows above it: ~ 5 dependent
+// reads instead of log2(rows of the contig) -- what a probe pays when the index is not L2-resident.
+template <bool STRICT>
+__device__ __forceinline__ int bound_lo_near(const IndexView& ix, int a, int hi, int32_t qs) {
+    int lo = a, step = 2;
+    for (;;) {
+        const int p = hi - step;
+        if (p <= a) break;
+        if (!lt_op<STRICT>(qs, ix.ep[p].y)) { lo = p + 1; break; }
+        step <<= 2;
+    }
+    return bound_lo<STRICT>(ix, lo, hi, qs);
+}
+
+// The answer of one probe from the record of its hi-bound (R = nrec[2 hi], Q = nrec[2 hi + 1]); [a, b) = the contig's segment, b > a.
+template <bool STRICT>
+__device__ __forceinline__ void nearest_k1_resolve(const IndexView& ix, int a, int b, int hi, int32_t s, int32_t e, const int4& R, const int4& Q,
+                                                   int32_t& idx, long long& dist, int32_t& found) {
+    const bool have_l = hi > a, have_r = hi < b;
+    if (have_l && lt_op<STRICT>(s, R.x)) {
+        // some row below hi overlaps.  The overlapping row with the smallest (start,row) is the first position whose
+        // prefix max satisfies "q.start (<) pmax", i.e. the first row of the earliest prefix-max level above q.start:
+        // level m (R), m-1 (Q) come with their build rows; a probe below level m-2 as well takes the bound search
+        if (!(Q.z >= 0 && lt_op<STRICT>(s, Q.y))) idx = R.y;
+        else if (!lt_op<STRICT>(s, Q.w)) idx = Q.z;
+        else idx = ix.b_row[bound_lo_near<STRICT>(ix, a, hi, s)];
+        dist = 0; found = 1;
+    } else {
+        const long long dl = (long long)s - (long long)R.x;
+        const long long dr = have_r ? gap_dist(s, e, R.z, R.w) : 0;
+        if (have_l && (!have_r || dl <= dr)) { idx = R.y; dist = dl; found = 1; }
+        else if (have_r) { idx = Q.x; dist = dr; found = 1; }
+    }
+}
+
 // k = 1, include_overlaps = 1 (the default pb.nearest).  An overlapping row wins with distance 0
 // (the one with the smallest (start,row): tests/_expected.py:130-172 tie-break); otherwise the
 // closer of the row with the largest end before the probe (ties: smallest (start,row)) and the
@@ -158,26 +199,185 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
     for (int k = 0; k < N; ++k) {
         if (i0 + k >= n) continue;
         int32_t idx = -1; long long dist = -1; int32_t found = 0;
-        if (b[k] > a[k]) {
-            const bool have_l = hi[k] > a[k], have_r = hi[k] < b[k];
-            if (have_l && lt_op<STRICT>(s[k], R[k].x)) {
-                // some row below hi overlaps.  The overlapping row with the smallest (start,row) is the first position whose
-                // prefix max satisfies "q.start (<) pmax", i.e. the first row of the earliest prefix-max level above q.start:
-                // level m (R), m-1 (Q) come with their build rows; a probe below level m-2 as well takes the bound search
-                if (!(Q[k].z >= 0 && lt_op<STRICT>(s[k], Q[k].y))) idx = R[k].y;
-                else if (!lt_op<STRICT>(s[k], Q[k].w)) idx = Q[k].z;
-                else idx = ix.b_row[bound_lo<STRICT>(ix, a[k], hi[k], s[k])];
-                dist = 0; found = 1;
-            } else {
-                const long long dl = (long long)s[k] - (long long)R[k].x;
-                const long long dr = have_r ? gap_dist(s[k], e[k], R[k].z, R[k].w) : 0;
-                if (have_l && (!have_r || dl <= dr)) { idx = R[k].y; dist = dl; found = 1; }
-                else if (have_r) { idx = Q[k].x; dist = dr; found = 1; }
-            }
-        }
+        if (b[k] > a[k]) nearest_k1_resolve<STRICT>(ix, a[k], b[k], hi[k], s[k], e[k], R[k], Q[k], idx, dist, found);
         const int64_t o = out_row ? (int64_t)out_row[i0 + k] : i0 + k;
         if ((ablate & 4) && idx != 123456789) continue;
         out_idx[o] = idx; out_dist[o] = dist; out_n[o] = found;
+    }
+}
+
+// k = 1 over the nearest LINES (index_build.hip.h, k_nearest_lines): probes in INPUT order, no bucketing, no inverse permutation.  One
+// 128-byte line per probe -- the start-table record of the bin its end falls into AND the records of the three positions hi can take
+// there -- fetched with seven independent 16-byte loads; only a bin with a third row below the probe's end, or a probe outside its
+// contig's table, takes the second (dependent) gather from nrec.  Per-contig metadata in LDS (n_contigs <= CM_LDS).
+template <bool STRICT, int N>
+__global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_lines(IndexView ix, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                                    const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
+                                                                    int32_t* __restrict__ out_idx, long long* __restrict__ out_dist,
+                                                                    int32_t* __restrict__ out_n, unsigned long long* __restrict__ rest) {
+    __shared__ int4 l_cm[2 * CM_LDS];
+    for (int i = threadIdx.x; i < 2 * ix.n_contigs; i += PROBE_THREADS) l_cm[i] = ix.cmeta[i];
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
+    if (i0 >= n) return;
+    int32_t c[N], s[N], e[N];
+    load_items_nt(pc, i0, n, vec_ok, -1, c);
+    load_items_nt(ps, i0, n, vec_ok, 0, s);
+    load_items_nt(pe, i0, n, vec_ok, 0, e);
+    int a[N], b[N], hi[N], shift[N];
+    unsigned long long tu[N];
+    uint32_t ulo[N];
+    bool inb[N];
+    int4 W0[N], W1[N], W2[N], W3[N], W4[N], W5[N], W6[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        W0[k] = W1[k] = W2[k] = W3[k] = W4[k] = W5[k] = W6[k] = make_int4(0, 0, 0, 0);
+        const bool ok = i0 + k < n && (uint32_t)c[k] < (uint32_t)ix.n_contigs;
+        int4 m0 = make_int4(0, 0, 0, 0), m1 = make_int4(0, 0, 0, 0);
+        if (ok) { m0 = l_cm[2 * c[k]]; m1 = l_cm[2 * c[k] + 1]; }
+        a[k] = m0.x; b[k] = m0.y; ulo[k] = (uint32_t)m0.z; shift[k] = m1.x;
+        tu[k] = (unsigned long long)flip(e[k]) + (STRICT ? 0ull : 1ull);
+        inb[k] = false; hi[k] = a[k];
+        if (b[k] <= a[k] || tu[k] <= (unsigned long long)ulo[k]) hi[k] = a[k];
+        else if (tu[k] > (unsigned long long)(uint32_t)m0.w) hi[k] = b[k];
+        else {
+            inb[k] = true;
+            const int4* line = ix.nline + 8 * (int64_t)((uint32_t)m1.y + (((uint32_t)tu[k] - ulo[k]) >> m1.x));
+            W0[k] = line[0]; W1[k] = line[1]; W2[k] = line[2]; W3[k] = line[3]; W4[k] = line[4]; W5[k] = line[5]; W6[k] = line[6];
+        }
+    }
+    int4 R[N], Q[N];
+    bool far[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        R[k] = make_int4(0, -1, 0, 0); Q[k] = make_int4(-1, 0, -1, (int)0x80000000);
+        far[k] = i0 + k < n && b[k] > a[k];                                   // the record comes from nrec (outside the table / crowded bin)
+        if (inb[k]) {
+        // rank inside the bin from the start-table record (index_view.hip.h, lb_tab4): six inline key offsets, or three keys of a wide bin
+        const int4 rec = W0[k];
+        const int p0 = rec.x & 0x7fffffff;
+        int lo;
+        if (shift[k] <= 16) {
+            const uint32_t toff = ((uint32_t)tu[k] - ulo[k]) & ((1u << shift[k]) - 1u);
+            const uint32_t w1 = (uint32_t)rec.y, w2 = (uint32_t)rec.z, w3 = (uint32_t)rec.w;
+            const int cnt = ((w1 & 0xffffu) < toff ? 1 : 0) + ((w1 >> 16) < toff ? 1 : 0) + ((w2 & 0xffffu) < toff ? 1 : 0) +
+                            ((w2 >> 16) < toff ? 1 : 0) + ((w3 & 0xffffu) < toff ? 1 : 0) + ((w3 >> 16) < toff ? 1 : 0);
+            lo = p0 + cnt;
+        } else {
+            const bool n0 = (unsigned long long)flip(rec.y) < tu[k];
+            const bool n1 = n0 && (unsigned long long)flip(rec.z) < tu[k];
+            const bool n2 = n1 && (unsigned long long)flip(rec.w) < tu[k];
+            lo = p0 + (n0 ? 1 : 0) + (n1 ? 1 : 0) + (n2 ? 1 : 0);
+        }
+        hi[k] = lo;
+        const int d = lo - p0;                                                  // (a crowded bin, full && more, has d = 6 or 3: left to the list)
+        if (d <= 2) {
+            far[k] = false;
+            // (masks, not selects: the compiler turns a three-way select over loaded registers into an indexed read of a stack copy)
+            const int k0 = -(int)(d == 0), k1 = -(int)(d == 1), k2 = -(int)(d == 2);
+            R[k] = sel3(k0, W1[k], k1, W3[k], k2, W5[k]);
+            Q[k] = sel3(k0, W2[k], k1, W4[k], k2, W6[k]);
+        }
+        }
+    }
+    // The lanes this line cannot settle -- hi outside the line (a third row of the bin below the probe's end, a probe outside its
+    // contig's table) or an overlap whose first row lies below the two prefix-max levels the record carries -- are NOT finished here:
+    // a few per cent of the lanes, but some in nearly every wavefront, and each would put one or more dependent fabric round trips into
+    // the wavefront's lifetime (measured: 1.9 instead of 1.0 ms for config 4).  They are marked in a bit mask per (wavefront, item) and
+    // k_nearest_k1_rest finishes them with the two-gather form.
+    int32_t idx[N], found[N];
+    long long dist[N];
+    bool slow[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        idx[k] = -1; dist[k] = -1; found[k] = 0;
+        slow[k] = far[k];
+        if (i0 + k < n && b[k] > a[k] && !far[k]) {
+            const bool have_l = hi[k] > a[k], have_r = hi[k] < b[k];
+            if (have_l && lt_op<STRICT>(s[k], R[k].x)) {
+                if (!(Q[k].z >= 0 && lt_op<STRICT>(s[k], Q[k].y))) idx[k] = R[k].y;
+                else if (!lt_op<STRICT>(s[k], Q[k].w)) idx[k] = Q[k].z;
+                else slow[k] = true;
+                dist[k] = 0; found[k] = 1;
+            } else {
+                const long long dl = (long long)s[k] - (long long)R[k].x;
+                const long long dr = have_r ? gap_dist(s[k], e[k], R[k].z, R[k].w) : 0;
+                if (have_l && (!have_r || dl <= dr)) { idx[k] = R[k].y; dist[k] = dl; found[k] = 1; }
+                else if (have_r) { idx[k] = Q[k].x; dist[k] = dr; found[k] = 1; }
+            }
+        }
+    }
+    // rest[N * wavefront + k], bit l <=> item k of lane l is left over (a single list cursor would serialise 390 k same-address atomics)
+    {
+        const int lane = threadIdx.x & (kWave - 1);
+        const int64_t wf = ((int64_t)blockIdx.x * PROBE_THREADS + threadIdx.x) / kWave;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const unsigned long long m = __ballot(slow[k]);
+            if (lane == 0) rest[N * wf + k] = m;
+        }
+    }
+    if (N == 2 && i0 + 2 <= n && ((reinterpret_cast<uintptr_t>(out_idx) | reinterpret_cast<uintptr_t>(out_n)) & 7u) == 0 &&
+        (reinterpret_cast<uintptr_t>(out_dist) & 15u) == 0) {
+        typedef long long v2ll __attribute__((ext_vector_type(2)));
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        v2i vi; vi.x = idx[0]; vi.y = idx[N - 1];
+        v2i vf; vf.x = found[0]; vf.y = found[N - 1];
+        v2ll vd; vd.x = dist[0]; vd.y = dist[N - 1];
+        __builtin_nontemporal_store(vi, reinterpret_cast<v2i*>(out_idx + i0));
+        __builtin_nontemporal_store(vd, reinterpret_cast<v2ll*>(out_dist + i0));
+        __builtin_nontemporal_store(vf, reinterpret_cast<v2i*>(out_n + i0));
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (i0 + k < n) { out_idx[i0 + k] = idx[k]; out_dist[i0 + k] = dist[k]; out_n[i0 + k] = found[k]; }
+    }
+}
+
+// The probes k_nearest_k1_lines left over, finished with the two-gather form: start table, nrec, and the bound search where the record's
+// two levels do not reach.  Nearly every wavefront of the lines kernel leaves a few, so they are COMPACTED first: a workgroup reads
+// REST_WORDS mask words (REST_WORDS x 64 probes), lists the marked probes in LDS (exclusive scan of the popcounts) and works through the
+// list with full wavefronts -- left in place, ~ 3 % of the lanes kept every wavefront alive for the longest dependent chain (0.81 ms).
+constexpr int REST_WORDS = 128;
+template <bool STRICT, int N>
+__global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_rest(IndexView ix, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                                   const int32_t* __restrict__ pe, int64_t n, int64_t n_words,
+                                                                   const unsigned long long* __restrict__ rest, int32_t* __restrict__ out_idx,
+                                                                   long long* __restrict__ out_dist, int32_t* __restrict__ out_n) {
+    __shared__ int32_t l_list[REST_WORDS * 64];
+    __shared__ int l_wsum[PROBE_THREADS / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    const int64_t w = (int64_t)blockIdx.x * REST_WORDS + tid;
+    unsigned long long m = (tid < REST_WORDS && w < n_words) ? rest[w] : 0ull;
+    const int cnt = __popcll(m);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) { const int t = __shfl_up(inc, d, kWave); if (lane >= d) inc += t; }
+    if (lane == kWave - 1) l_wsum[wv] = inc;
+    __syncthreads();
+    int pre = inc - cnt, total = 0;
+#pragma unroll
+    for (int i = 0; i < PROBE_THREADS / kWave; ++i) { const int x = l_wsum[i]; if (i < wv) pre += x; total += x; }
+    // word w = N * wavefront + item; bit l = lane l of that wavefront; the lines kernel's probe of (wavefront, lane, item) = (64 wavefront + l) N + item
+    const int64_t pbase = (w / N) * (int64_t)(kWave * N) + (w % N);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        l_list[pre++] = (int32_t)(pbase + (int64_t)l * N);
+    }
+    __syncthreads();
+    for (int q = tid; q < total; q += PROBE_THREADS) {
+        const int64_t i = l_list[q];
+        int32_t c[1] = {pc[i]}, s = ps[i], e[1] = {pe[i]};
+        bool valid[1] = {true};
+        int a[1], b[1], hi[1];
+        bound_hi_tab4<STRICT>(ix, c, valid, e, a, b, hi);
+        int32_t idx = -1; long long dist = -1; int32_t found = 0;
+        if (b[0] > a[0]) {
+            const int4 R = ix.nrec[2 * (int64_t)hi[0]], Q = ix.nrec[2 * (int64_t)hi[0] + 1];
+            nearest_k1_resolve<STRICT>(ix, a[0], b[0], hi[0], s, e[0], R, Q, idx, dist, found);
+        }
+        out_idx[i] = idx; out_dist[i] = dist; out_n[i] = found;
     }
 }
 

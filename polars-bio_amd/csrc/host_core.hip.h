@@ -83,6 +83,9 @@ struct ivj_ctx {
     long long* h_total = nullptr;   // pinned
     XferSlots xfer;                 // pinned staging slots of the host <-> HBM copies (HostXfer), allocated on first use
     // one released index slab kept for reuse (bench/streaming loops rebuild the index every call)
+    char* nl_cache = nullptr;          // the nearest-line table of the last index freed on this context (reused like ix_cache)
+    size_t nl_cache_cap = 0;
+    int env_nearest_lines = -1;        // IVJ_NEAREST_LINES: 0 never, 1 wherever the kernel applies, unset: by size
     char* ix_cache = nullptr;
     size_t ix_cache_cap = 0;
     int64_t ov_total = 0;
@@ -171,6 +174,9 @@ struct ivj_index {
     int64_t bins_len = 0;
     bool has_end_order = false, has_end_table = false;
     bool has_argmax = false;
+    int4* nline = nullptr;             // nearest lines (build_lines): own allocation, 128 bytes per table slot, on first use
+    size_t nline_cap = 0;
+    bool has_lines = false;
     bool has_flat = false;
     bool has_rec4 = false;
     unsigned long long* spl = nullptr;   // slice path: composite key of the first row of every slice
@@ -311,7 +317,7 @@ int check_opts(const ivj_opts* o) {
     if (!o) return fail(IVJ_EINVAL, "opts is NULL");
     if (o->filter_op != IVJ_FILTER_WEAK && o->filter_op != IVJ_FILTER_STRICT) return fail(IVJ_EINVAL, "filter_op must be 0 (Weak) or 1 (Strict)");
     if (o->n_contigs < 0) return fail(IVJ_EINVAL, "n_contigs < 0");
-    if (o->table_mode < 0 || o->table_mode > 2) return fail(IVJ_EINVAL, "table_mode must be 0 (auto), 1 (records) or 2 (bins)");
+    if (o->table_mode < 0 || o->table_mode > 3) return fail(IVJ_EINVAL, "table_mode must be 0 (auto), 1 (records), 2 (bins) or 3 (records + nearest lines)");
     if (o->partition_mode < 0 || o->partition_mode > 6 || o->partition_mode == 3 || o->partition_mode == 4)
         return fail(IVJ_EINVAL, "partition_mode must be 0 (auto), 1 (256-way buckets), 2 (never), 5 (flat, fused path only) or 6 (LDS-resident index slices)");
     if (o->slice_rows < 0 || o->slice_chunk < 0) return fail(IVJ_EINVAL, "slice_rows / slice_chunk must be >= 0");
@@ -329,7 +335,7 @@ IndexView view_of(const ivj_index* ix) {
     IndexView v;
     v.b_start = ix->b_start; v.ep = ix->ep; v.b_row = ix->b_row; v.seg = ix->seg;
     v.e_end = ix->e_end; v.e_pos = ix->e_pos; v.flags = ix->flags; v.n_contigs = ix->n_contigs;
-    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec; v.cmeta_j = ix->cmeta_j; v.crec = ix->crec;
+    v.cmeta = ix->cmeta; v.brec = ix->brec; v.cmeta_e = ix->cmeta_e; v.brec_e = ix->brec_e; v.pargmax = ix->pargmax; v.nrec = ix->nrec; v.nline = ix->nline; v.cmeta_j = ix->cmeta_j; v.crec = ix->crec;
     v.bins = ix->bins; v.bins_e = ix->bins_e; v.rec4 = ix->rec4; v.tab2 = ix->tab2;
     // 16-byte bin records once the 4-byte tables + key arrays no longer fit the XCD L2s anyway
     {
@@ -337,7 +343,7 @@ IndexView view_of(const ivj_index* ix) {
         v.hier.v = ix->hier; v.hier.nlev = h.nlev;
         for (int l = 0; l < HIER_MAX; ++l) v.hier.off[l] = h.off[l];
     }
-    v.use_rec = ix->table_mode == 1 ? 1 : (ix->table_mode == 2 ? 0 : (ix->n >= (1ll << 20) ? 1 : 0));
+    v.use_rec = (ix->table_mode == 1 || ix->table_mode == 3) ? 1 : (ix->table_mode == 2 ? 0 : (ix->n >= (1ll << 20) ? 1 : 0));
     return v;
 }
 

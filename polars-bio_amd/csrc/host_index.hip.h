@@ -197,6 +197,30 @@ int build_argmax(ivj_ctx* ctx, ivj_index* ix) {
     return IVJ_OK;
 }
 
+// nearest lines (k_nearest_lines): 128 bytes per table slot in an allocation of its own (kept by the context between indexes like
+// the index slab), on first use by nearest_dev
+int build_lines(ivj_ctx* ctx, ivj_index* ix) {
+    if (ix->has_lines) return IVJ_OK;
+    IVJ_TRY(need_tables(ctx, ix));
+    IVJ_TRY(build_argmax(ctx, ix));
+    const size_t need = (size_t)ix->bins_len * 128;
+    if (ix->nline_cap < need) {
+        if (ix->nline) { (void)hipFree(ix->nline); ix->nline = nullptr; ix->nline_cap = 0; }
+        if (ctx->nl_cache && ctx->nl_cache_cap >= need) {
+            ix->nline = reinterpret_cast<int4*>(ctx->nl_cache); ix->nline_cap = ctx->nl_cache_cap;
+            ctx->nl_cache = nullptr; ctx->nl_cache_cap = 0;
+        } else {
+            hipError_t e = hipMalloc((void**)&ix->nline, need);
+            if (e != hipSuccess) { ix->nline = nullptr; return fail(IVJ_ENOMEM, std::string("hipMalloc(nearest lines): ") + hipGetErrorString(e)); }
+            ix->nline_cap = need;
+        }
+    }
+    LAUNCH(ctx, "nearest_lines", k_nearest_lines, grid1d(ix->bins_len * 8, 256), 256, (const int4*)ix->brec, (const int4*)ix->nrec, ix->bins_len, ix->n, ix->nline);
+    HIP_TRY(hipGetLastError());
+    ix->has_lines = true;
+    return IVJ_OK;
+}
+
 // rec4[p] = {start, end, build row, prefix max}: built on demand for the join + materialisation path
 int build_rec4(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->has_rec4 || ix->n == 0) return IVJ_OK;

@@ -337,6 +337,31 @@ int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_op
     // large probe sides: bucket them by genomic position first (every gather of the kernel then stays in the
     // XCD L2s); the kernels write each result to the probe's original row
     const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end, *qrow = nullptr;
+    // k = 1 over the nearest LINES: one 128-byte line fetch per probe, probes in input order (round 4; tools/micro/gather_probe.hip: a line
+    // from beyond the L2 costs ~ 20 ps per probe whatever the table size, the bucketed two-gather form 36 ps with its partition and inverse
+    // permutation).  The table costs 256 bytes per build row to write: auto takes it for an index beyond the L2s (>= 128 k rows) once it
+    // exists or the probe side is >= 8 x the build side; partition_mode 1 / 2 keep their meaning (bucketed / plain two-gather kernel).
+    if (k1 && ix->n > 0 && ix->n_contigs <= CM_LDS && ctx->env_nearest_lines != 0 &&
+        (ctx->env_nearest_lines > 0 || ix->table_mode == 3 ||
+         (opts->partition_mode == 0 && ix->table_mode == 0 && ix->n >= (128ll << 10) && (ix->has_lines || n >= 8 * ix->n))) &&
+        (size_t)ix->bins_len * 128 <= ((size_t)16 << 30) && n <= 0x7fffffffll) {
+        IVJ_TRY(build_lines(ctx, ix));
+        IndexView v = view_of(ix);
+        constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT;
+        const int64_t tiles = (n + NT - 1) / NT;
+        const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
+        // the probes a line cannot settle: one bit each in scratch, finished by the two-gather kernel over the same thread <-> probe mapping
+        const int64_t nwf = tiles * (PROBE_THREADS / kWave);
+        IVJ_TRY(arena_reserve(ctx, align_up((size_t)nwf * PROBE_ITEMS_LAT * 8) + 4096));
+        unsigned long long* rest = arena_take<unsigned long long>(ctx, nwf * PROBE_ITEMS_LAT);
+        if (strict) LAUNCH(ctx, "nearest_k1_lines", (k_nearest_k1_lines<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, idx, (long long*)dist, nf, rest);
+        else LAUNCH(ctx, "nearest_k1_lines", (k_nearest_k1_lines<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, idx, (long long*)dist, nf, rest);
+        const int64_t n_words = nwf * PROBE_ITEMS_LAT, rgrid = (n_words + REST_WORDS - 1) / REST_WORDS;
+        if (strict) LAUNCH(ctx, "nearest_k1_rest", (k_nearest_k1_rest<true, PROBE_ITEMS_LAT>), rgrid, PROBE_THREADS, v, qc, qs, qe, n, n_words, (const unsigned long long*)rest, idx, (long long*)dist, nf);
+        else LAUNCH(ctx, "nearest_k1_rest", (k_nearest_k1_rest<false, PROBE_ITEMS_LAT>), rgrid, PROBE_THREADS, v, qc, qs, qe, n, n_words, (const unsigned long long*)rest, idx, (long long*)dist, nf);
+        HIP_TRY(hipGetLastError());
+        return IVJ_OK;
+    }
     if (want_partition(ix, n, opts) && ix->n > 0) {
         ivj_side plain = *probe;
         plain.row_id = nullptr;

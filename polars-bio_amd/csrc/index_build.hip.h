@@ -111,6 +111,28 @@ __global__ void k_nearest_records(const int32_t* __restrict__ b_start, const int
     nrec[2 * p + 1] = q;
 }
 
+// Nearest lines: table slot i -> one 128-byte line {brec[i], nrec of positions p0, p0 + 1, p0 + 2 (two words each), one spare word}, p0 =
+// the slot's first position.  A probe whose end falls into the slot has hi in {p0 .. p0 + rows of the bin}: with two bins per build row
+// 98.6 % of the bins hold at most two rows, so ONE line fetch answers the probe (gather_probe: a line fetched from beyond the L2 costs
+// ~20 ps per probe whatever its width up to 128 bytes and whatever the table size; two dependent gathers cost 38 ps).  Eight threads per
+// slot, 16 bytes each: coalesced writes, near-sequential reads of nrec.
+__global__ void k_nearest_lines(const int4* __restrict__ brec, const int4* __restrict__ nrec, int64_t slots, int64_t n, int4* __restrict__ nline) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t slot = t >> 3;
+    const int w = (int)(t & 7);
+    if (slot >= slots) return;
+    const int4 br = brec[slot];
+    int4 v = make_int4(0, 0, 0, 0);
+    if (w == 0) v = br;
+    else if (w < 7) {
+        int64_t p = (int64_t)(br.x & 0x7fffffff) + ((w - 1) >> 1);
+        p = p < n ? p : n;
+        v = nrec[2 * p + ((w - 1) & 1)];
+    }
+    __builtin_nontemporal_store(v.x, &nline[t].x); __builtin_nontemporal_store(v.y, &nline[t].y);
+    __builtin_nontemporal_store(v.z, &nline[t].z); __builtin_nontemporal_store(v.w, &nline[t].w);
+}
+
 // Per-contig metadata of the direct-address table: bin width 2^shift chosen so that the contig has
 // at most 2 n_c bins (about one build row per bin for evenly spread rows); its slice of the table
 // starts at tb = 2 a + 2 c.

@@ -62,6 +62,7 @@ struct IndexView {
     const int32_t* pargmax; // position of the first row that attains ep[p].y (prefix max) -- nearest only
     const int4* cmeta_j;    // count_overlaps: ONE bin grid per contig shared by the start- and the end-sorted order
     const int4* crec;       //   crec[slot] = {first start position | more << 31, first end position | more << 31, 2 x 16-bit start offsets, 2 x 16-bit end offsets}
+    const int4* nline;      // nearest, k = 1: ONE 128-byte line per start-table slot = {brec, nrec of the slot's first three positions} (k_nearest_lines)
     const int4* nrec;       // nearest: nrec[2p] = {pmax[p-1], row of its argmax, start[p], end[p]}, nrec[2p+1] = {row of p, v1, row1, v2}
                             // (left / right candidate of hi = p; the two prefix-max levels below the current one)
     const int4* rec4;       // flat overlap path: {start, end, build row, prefix max} per sorted position

@@ -84,6 +84,7 @@ int ivj_ctx_create(int device, ivj_ctx** out) try {
     if (const char* ev = std::getenv("IVJ_CS_WALK")) ctx->cs_env_walk = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("IVJ_JOINT_BINS")) ctx->env_joint_bins = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_ABLATE")) ctx->env_count_ablate = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_NEAREST_LINES")) ctx->env_nearest_lines = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_NOLDS")) ctx->env_count_nolds = std::atoi(ev);
     e = hipHostMalloc((void**)&ctx->h_total, 64, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(IVJ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
@@ -115,6 +116,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     if (ctx->lb_buf) (void)hipFree(ctx->lb_buf);
     for (auto& cb : ctx->st_cache) free_stream_bufs(cb);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
+    if (ctx->nl_cache) (void)hipFree(ctx->nl_cache);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     ctx->xfer.release();
     for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);
@@ -194,6 +196,16 @@ void ivj_index_free(ivj_index* ix) {
         if (ctx->ov_ix == ix) { ctx->ov_ix = nullptr; ctx->ov_n = -1; }
         for (size_t k = 0; k < ctx->live.size(); ++k)
             if (ctx->live[k] == ix) { ctx->live[k] = ctx->live.back(); ctx->live.pop_back(); break; }
+    }
+    if (ix->nline) {
+        if (ctx && ix->nline_cap > ctx->nl_cache_cap) {
+            char* old = ctx->nl_cache;
+            ctx->nl_cache = reinterpret_cast<char*>(ix->nline); ctx->nl_cache_cap = ix->nline_cap;
+            if (old) { DeviceGuard g(ctx->device); (void)hipFree(old); }
+        } else {
+            DeviceGuard g(ix->device);
+            (void)hipFree(ix->nline);
+        }
     }
     if (ix->slab) {
         if (ctx && ix->slab_cap > ctx->ix_cache_cap) {

@@ -81,7 +81,7 @@ def _cmp_all(eng, probe, build, n_contigs, strict, brute=False, nearest_cfgs=((1
         assert (eng.count_overlaps(probe, build, strict, n_contigs, table_mode=tm, partition_mode=pm) == ec).all(), (tm, pm)
     for k, inc in nearest_cfgs:
         ei, ed, en = (O.nearest_brute(ps, bs, strict, k, inc) if brute else O.nearest_fast(ix, ps, strict, k, inc))
-        for tm, pm in ((2, 2), (1, 2), (1, 1)):         # bins / records, probe order / bucketed probes
+        for tm, pm in ((2, 2), (1, 2), (1, 1), (3, 0)):         # bins / records, probe order / bucketed probes; nearest lines (k = 1)
             i, d, n = eng.nearest(probe, build, strict, n_contigs, k, inc, table_mode=tm, partition_mode=pm)
             assert (n == en).all(), (k, inc, tm, pm)
             assert (d == ed).all(), (k, inc, tm, pm)
@@ -1172,3 +1172,35 @@ def test_sampled_partition_count_fill_pair(monkeypatch):
             assert (p == ep).all() and (b == eb).all()
         finally:
             e.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_nearest_lines_edge_shapes(strict):
+    """nearest (k = 1) over the 128-byte lines (table_mode 3): the timings name the kernel, and the shapes its line cannot answer
+    alone are exact -- bins wider than 2^16 (three rows over 2^28 coordinates: keys instead of offsets in the record), crowded
+    bins (hundreds of equal starts: gallop + bound search, record from nrec), probes outside the table's range and on contigs
+    without rows, a single build row, ragged sizes around the tile."""
+    rng = np.random.default_rng(31)
+    cases = []
+    wide_b = (np.zeros(3, np.int32), np.array([5, 1 << 27, (1 << 28) - 9], np.int32), np.array([900, (1 << 27) + 40, (1 << 28) - 2], np.int32))
+    ps = rng.integers(0, 1 << 28, 4000).astype(np.int32)
+    cases.append(((np.zeros(4000, np.int32), ps, (ps + rng.integers(1, 2000, 4000)).astype(np.int32)), wide_b, 1))
+    c, s, e = random_side(rng, 6000, 3, 50000, 300)
+    s[:700] = 1234; e[:700] = 1300; c[:700] = 1                              # one crowded bin
+    s[700:1100] = 1235; e[700:1100] = 1240; c[700:1100] = 1
+    pc, ps_, pe = random_side(rng, 5001, 5, 60000, 200)                         # contigs 3, 4: no build rows
+    ps_[:50] = -500; pe[:50] = -400                                            # before every table
+    cases.append(((pc, ps_, pe), (c, s, e), 3))
+    one = (np.zeros(1, np.int32), np.array([1000], np.int32), np.array([1010], np.int32))
+    cases.append((random_side(rng, 513, 1, 3000, 50), one, 1))
+    cases.append((random_side(rng, 1, 2, 3000, 50), random_side(rng, 1025, 2, 3000, 50), 2))
+    e_ = _engine.Engine(0)
+    try:
+        e_.enable_timing(2)
+        for probe, build, nc in cases:
+            ei, ed, en = O.nearest_fast(O.Index(O.Side(*build), nc), O.Side(*probe), strict, 1, True)
+            i, d, n = e_.nearest(probe, build, strict, nc, 1, True, table_mode=3)
+            assert "nearest_k1_lines" in e_.timings(), sorted(e_.timings())
+            assert (n == en).all() and (d == ed).all() and (i == ei).all()
+    finally:
+        e_.close()
