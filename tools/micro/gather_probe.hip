@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     std::printf("# %lld probes; one random record gather per probe (+ 8 B read, 12 B written per probe); ms per launch | ps per probe\n", (long long)n);
     std::printf("%10s %8s %12s %12s %12s %14s\n", "table", "record", "1 gather", "ps/probe", "2 dependent", "ps/probe");
-    const size_t sizes[] = {(size_t)2 << 20, (size_t)8 << 20, (size_t)32 << 20, (size_t)64 << 20, (size_t)128 << 20, (size_t)256 << 20, (size_t)512 << 20, (size_t)1 << 30};
+    const size_t sizes[] = {(size_t)2 << 20, (size_t)3 << 20, (size_t)4 << 20, (size_t)6 << 20, (size_t)8 << 20, (size_t)32 << 20, (size_t)64 << 20, (size_t)128 << 20, (size_t)256 << 20, (size_t)512 << 20, (size_t)1 << 30};
     for (size_t sz : sizes) {
         for (int words : {1, 2, 4, 8}) {
             const uint32_t nrec = (uint32_t)(sz / (16 * (size_t)words));
