@@ -1204,3 +1204,42 @@ def test_nearest_lines_edge_shapes(strict):
             assert (n == en).all() and (d == ed).all() and (i == ei).all()
     finally:
         e_.close()
+
+
+@pytest.mark.parametrize("shape", ["hotspot", "sorted", "one_bucket", "ragged"])
+def test_sampled_partition_on_skewed_and_sorted_probes(shape, monkeypatch):
+    """Probe sides the 1 / 64 sample has to get right or recover from: 90 % of the probes on 1 % of the coordinates, probes sorted by
+    (contig, start) (a tile's 8192 probes are then ONE run of one bucket), every probe in one slice, and sizes that end inside a sample
+    group / a partition tile.  Exact pairs against the oracle whichever partition ends up running."""
+    monkeypatch.setenv("IVJ_CS", "1")
+    rng = np.random.default_rng(91)
+    nb = 90_000
+    build = synth.make_side(nb, 7, synth.BUILD_LEN, 24)
+    if shape == "hotspot":
+        c, s, e = synth.make_side(260_000, 8, synth.PROBE_LEN, 24)
+        hot = rng.random(len(c)) < 0.9
+        c = np.where(hot, 3, c).astype(np.int32)
+        s = np.where(hot, 50_000_000 + rng.integers(0, 1_900_000, len(c)), s).astype(np.int32)
+        e = np.where(hot, s + rng.integers(100, 150, len(c)), e).astype(np.int32)
+        probe = (c, s, e)
+    elif shape == "sorted":
+        c, s, e = synth.make_side(300_000, 9, synth.PROBE_LEN, 24)
+        o = np.lexsort((s, c))
+        probe = (c[o], s[o], e[o])
+    elif shape == "one_bucket":
+        n = 150_000
+        s = (10_000_000 + rng.integers(0, 200_000, n)).astype(np.int32)
+        probe = (np.full(n, 5, np.int32), s, (s + 120).astype(np.int32))
+    else:
+        probe = synth.make_side(65_536 + 8 * 64 * 3 + 5, 10, synth.PROBE_LEN, 24)
+    ep, eb = O.overlap_fast(O.Index(O.Side(*build), 24), O.Side(*probe), True)
+    e_ = _engine.Engine(0)
+    try:
+        hp, hb = _fused_overlap(e_, probe, build, True, 24, 6, len(ep))
+        p, b = _canon(hp, hb)
+        assert (p == ep).all() and (b == eb).all()
+        hp, hb = e_.overlap(probe, build, True, 24, partition_mode=6)                 # count -> fill over the same partition
+        p, b = _canon(np.asarray(hp), np.asarray(hb))
+        assert (p == ep).all() and (b == eb).all()
+    finally:
+        e_.close()
