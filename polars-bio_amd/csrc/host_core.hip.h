@@ -295,9 +295,34 @@ int lb_scan_u32(ivj_ctx* ctx, const char* name, uint32_t* data, int64_t n, uint3
     return IVJ_OK;
 }
 
-// device-wide scan: three launches (reduce, partials, apply)
+// look-back status words + ticket of one single-launch scan (zeroed); nullptr when they cannot be had
+char* lb_status(ivj_ctx* ctx, int64_t tiles) {
+    const size_t need = align_up((size_t)tiles * 8) + align_up(16);
+    if (need > ctx->lb_cap) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+        if (ctx->lb_buf) (void)hipFree(ctx->lb_buf);
+        ctx->lb_buf = nullptr; ctx->lb_cap = 0;
+        const size_t want = align_up(need + need / 2, 1 << 16);
+        if (hipMalloc((void**)&ctx->lb_buf, want) != hipSuccess) { ctx->lb_buf = nullptr; return nullptr; }
+        ctx->lb_cap = want;
+    }
+    if (hipMemsetAsync(ctx->lb_buf, 0, need, ctx->stream) != hipSuccess) return nullptr;
+    return ctx->lb_buf;
+}
+
+// device-wide scan.  Sums of uint32 / int64 (every use but the max scans of the tables): ONE launch, decoupled look-back (round 4);
+// anything else, or no status buffer: three launches (reduce, partials, apply).
 template <class T, class Op, bool INCLUSIVE>
 void device_scan(ivj_ctx* ctx, const char* name, const T* in, T* out, int64_t n, T identity, T* partials, T* total_out) {
+    if constexpr (std::is_same<Op, SumOp>::value && (std::is_same<T, uint32_t>::value || std::is_same<T, long long>::value)) {
+        if (n > 0 && identity == (T)0) {
+            const int64_t lt = (n + LB_TILE - 1) / LB_TILE;
+            if (char* st = lb_status(ctx, lt)) {
+                LAUNCH(ctx, name, (k_scan_lb_sum<T, INCLUSIVE>), lt, OS_THREADS, in, out, n, (uint32_t*)(st + align_up((size_t)lt * 8)), (unsigned long long*)st, total_out);
+                return;
+            }
+        }
+    }
     const int64_t tiles = scan_num_tiles(n);
     LAUNCH(ctx, name, (k_scan_reduce<T, Op>), tiles, SCAN_THREADS, in, n, identity, partials);
     LAUNCH(ctx, name, (k_scan_partials<T, Op>), 1, SCAN_THREADS, partials, tiles, identity, total_out);

@@ -427,6 +427,63 @@ __global__ __launch_bounds__(OS_THREADS) void k_scan_lb_u32(uint32_t* __restrict
     }
 }
 
+// ---- single-launch sum scan (look-back), uint32 / int64, in -> out (may alias), optional grand total -----------------------------
+// What the count -> fill pair, the sort-scan family and the cluster ids used three launches for (reduce, partials, apply: the input
+// read twice).  Status word = flag << 62 | running sum (sums below 2^62); tiles handed out by ticket, as above.
+template <class T, bool INCLUSIVE>
+__global__ __launch_bounds__(OS_THREADS) void k_scan_lb_sum(const T* __restrict__ in, T* __restrict__ out, int64_t n, uint32_t* __restrict__ ticket,
+                                                           unsigned long long* __restrict__ status64, T* __restrict__ total_out) {
+    __shared__ unsigned long long wtot[OS_WAVES];
+    __shared__ unsigned long long s_carry;
+    __shared__ int l_tile;
+    const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+    if (tid == 0) l_tile = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tile = l_tile;
+    const int64_t i0 = (int64_t)tile * LB_TILE + (int64_t)tid * LB_ITEMS;
+    unsigned long long v[LB_ITEMS];
+#pragma unroll
+    for (int j = 0; j < LB_ITEMS; ++j) v[j] = i0 + j < n ? (unsigned long long)in[i0 + j] : 0ull;
+    unsigned long long run = 0;
+#pragma unroll
+    for (int j = 0; j < LB_ITEMS; ++j) { const unsigned long long x = v[j]; if (!INCLUSIVE) v[j] = run; run += x; if (INCLUSIVE) v[j] = run; }
+    unsigned long long inc = run;
+#pragma unroll
+    for (int dd = 1; dd < kWave; dd <<= 1) {
+        const unsigned long long o = __shfl_up(inc, dd, kWave);
+        if (lane >= dd) inc += o;
+    }
+    if (lane == kWave - 1) wtot[w] = inc;
+    __syncthreads();
+    unsigned long long wpre = 0, ttot = 0;
+#pragma unroll
+    for (int k = 0; k < OS_WAVES; ++k) { const unsigned long long x = wtot[k]; if (k < w) wpre += x; ttot += x; }
+    unsigned long long excl = __shfl_up(inc, 1, kWave);
+    if (lane == 0) excl = 0;
+    excl += wpre;
+    if (tid == 0) {
+        constexpr unsigned long long VAL = (1ull << 62) - 1ull;
+        unsigned long long carry = 0;
+        if (tile == 0) os_st64(status64, (2ull << 62) | (ttot & VAL));
+        else {
+            os_st64(status64 + tile, (1ull << 62) | (ttot & VAL));
+            for (int t = tile - 1; t >= 0; --t) {
+                unsigned long long x = os_ld64(status64 + t);
+                while ((x >> 62) == 0) { __builtin_amdgcn_s_sleep(2); x = os_ld64(status64 + t); }
+                carry += x & VAL;
+                if ((x >> 62) == 2ull) break;
+            }
+            os_st64(status64 + tile, (2ull << 62) | ((carry + ttot) & VAL));
+        }
+        s_carry = carry;
+        if (total_out && (int64_t)(tile + 1) * LB_TILE >= n) *total_out = (T)(carry + ttot);
+    }
+    __syncthreads();
+    const unsigned long long before = s_carry + excl;
+#pragma unroll
+    for (int j = 0; j < LB_ITEMS; ++j) if (i0 + j < n) out[i0 + j] = (T)(before + v[j]);
+}
+
 // ---- end order: the same sort over (contig, end) with the position as the record's row --------------------------------------
 __global__ void k_end_column(const int2* __restrict__ ep, int64_t n, int32_t* __restrict__ ends) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
