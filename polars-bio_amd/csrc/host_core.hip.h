@@ -316,9 +316,11 @@ template <class T, class Op, bool INCLUSIVE>
 void device_scan(ivj_ctx* ctx, const char* name, const T* in, T* out, int64_t n, T identity, T* partials, T* total_out) {
     if constexpr (std::is_same<Op, SumOp>::value && (std::is_same<T, uint32_t>::value || std::is_same<T, long long>::value)) {
         if (n > 0 && identity == (T)0) {
-            const int64_t lt = (n + LB_TILE - 1) / LB_TILE;
+            const bool big = n >= (4ll << 20);
+            const int64_t tile = (int64_t)OS_THREADS * (big ? 32 : LB_ITEMS), lt = (n + tile - 1) / tile;
             if (char* st = lb_status(ctx, lt)) {
-                LAUNCH(ctx, name, (k_scan_lb_sum<T, INCLUSIVE>), lt, OS_THREADS, in, out, n, (uint32_t*)(st + align_up((size_t)lt * 8)), (unsigned long long*)st, total_out);
+                if (big) LAUNCH(ctx, name, (k_scan_lb_sum<T, INCLUSIVE, 32>), lt, OS_THREADS, in, out, n, (uint32_t*)(st + align_up((size_t)lt * 8)), (unsigned long long*)st, total_out);
+                else LAUNCH(ctx, name, (k_scan_lb_sum<T, INCLUSIVE, LB_ITEMS>), lt, OS_THREADS, in, out, n, (uint32_t*)(st + align_up((size_t)lt * 8)), (unsigned long long*)st, total_out);
                 return;
             }
         }
