@@ -1,7 +1,7 @@
 // scan.hip.h -- device-wide prefix scans for gfx950 (wave64), three launches:
 // tile reduce -> scan of tile partials (one workgroup) -> tile apply.
-// Since round 4 only the fallback of host_core.hip.h::device_scan: sums of uint32 / int64 (output tile bases, cluster ids, merged
-// lengths, subtract offsets) take the single-launch look-back scan k_scan_lb_sum of onesweep.hip.h, like the sort and the partition tables.
+// Used for: output tile bases (i64 sum), cluster ids and merged lengths of the sort-scan family; the sort and the
+// partition tables use the single-launch look-back scans of onesweep.hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
