@@ -49,6 +49,9 @@ def main():
             f.write("\n".join(tables))
         lines.append("| `kernel_tables_hipevents.txt` | per-kernel HIP-event tables (`bench.py --kernel-table`, timing level 2) of the runs above |")
     for src, dst, what in ((f"{tag}_prof.kernel_stats.csv", "rocprofv3_kernel_stats_overlap_100M_5M.csv", "`rocprofv3 --kernel-trace --stats` of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras` (config 3)"),
+                           (f"{tag}_profw_WL_overlap_10M_1M_1contig.kernel_stats.csv", "rocprofv3_kernel_stats_overlap_10M_1M.csv", "the same for config 2 (`--workload overlap_10M_1M_1contig`)"),
+                           (f"{tag}_profw_WL_nearest_50M_2M_24contig.kernel_stats.csv", "rocprofv3_kernel_stats_nearest_50M_2M.csv", "the same for config 4 (`--workload nearest_50M_2M_24contig`)"),
+                           (f"{tag}_profw_WL_count_200M_200k_24contig.kernel_stats.csv", "rocprofv3_kernel_stats_count_200M_200k.csv", "the same for config 5 (`--workload count_200M_200k_24contig`)"),
                            (f"{tag}_fast.log", "pytest_gpu_fast.log", "`pytest -m gpu` without the full-size configs"),
                            (f"{tag}_full.log", "pytest_gpu_full_size.log", "`pytest -m gpu -k 'full_size or two_rank or self_spawn'` (configs 3, 4, 5 at stated size; the 2-GPU tests skip on a 1-GPU box)"),
                            (f"{tag}_pmcsq.summary.json", "pmc_sq_lds_overlap_100M_5M.json", "`rocprofv3 --kernel-trace --pmc` SQ / LDS counter sets (three passes, `tools/gpu_r04.sh pmcsq`, per kernel, mean per launch) of config 3"),
