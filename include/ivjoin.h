@@ -82,9 +82,10 @@ typedef struct {
     int32_t n_contigs;         /* size of the shared chrom dictionary */
     int32_t nearest_k;         /* RangeOptions.nearest_k, >= 1 (default 1) */
     int32_t include_overlaps;  /* RangeOptions.include_overlaps (default 1) */
-    int32_t partition_mode;    /* how the probe side is ordered before the join kernels run.  0 auto: the fused overlap pass takes the
-                                  slice path (6) from 24 M probe rows against 4 M build rows on (tools/policy_sweep.py), large
-                                  inputs below that and the per-probe kernels the 256-bucket path (1), small ones none (2); 1 256 genomic buckets + window-scan kernels (deterministic); 2 never (probe order);
+    int32_t partition_mode;    /* how the probe side is ordered before the join kernels run.  0 auto: overlap (the fused pass and the
+                                  count -> fill pair) takes the contig-aligned slice path (6) from 1.5 M probe rows against 256 k
+                                  build rows on (dictionaries of <= 256 contigs; tools/policy_sweep.py), large inputs outside
+                                  that and the per-probe kernels the 256-bucket path (1), small ones none (2); 1 256 genomic buckets + window-scan kernels (deterministic); 2 never (probe order);
                                   5 flat (256 buckets + load-balanced candidate test, ivj_overlap_fused_dev only; with 0 the
                                   fused entry point picks it by itself when capacity >= 16 pairs per probe row, i.e. for dense
                                   results); 6 LDS-resident index slices: one stable partition into <= 1536 slices of equal
@@ -97,7 +98,7 @@ typedef struct {
     int32_t slice_rows;        /* slice path: build rows per slice, 0 = auto (rows / 1024, rounded up to 64, <= 5120) */
     int32_t slice_chunk;       /* slice path: probes per join workgroup, 0 = auto (multiple of 4096) */
     int32_t deterministic;     /* overlap count -> fill pair on the slice path: 1 = the output is identical from run to run (stable
-                                  partition, +0.5 ms per 100 M probes); 0 = same pairs, the order of the probe rows inside a
+                                  partition behind a histogram pass, +0.7 ms per 100 M probes); 0 = same pairs, the order of the probe rows inside a
                                   bucket tile may differ between runs (the reference leaves the row order unspecified) */
 } ivj_opts;
 
