@@ -450,7 +450,9 @@ def main():
     d_probe = DeviceSide(up(lp[0]), up(lp[1]), up(lp[2]), up(lp_ids) if lp_ids is not None else None)
     d_build = DeviceSide(up(lb[0]), up(lb[1]), up(lb[2]), up(lb_ids) if lb_ids is not None else None)
     join = DeviceJoin(dev_index)
-    gather = multi and not args.no_gather and op == "overlap"
+    # N > 1: the exchange is part of the timed step for pb.overlap (all-gatherv of the pairs) AND for the per-probe operations
+    # (count_overlaps / nearest: fixed-width results scattered back to global probe order on every rank)
+    gather = multi and not args.no_gather and op in ("overlap", "count_overlaps", "nearest")
 
     # ---- exchange transport of the N > 1 overlap
     exchange, comm, xgroup = None, None, None
@@ -544,6 +546,37 @@ def main():
                 state.setdefault("gather_events", []).append(ev)
                 state["gathered"] = int(p.shape[0])
             return local, (p, b)
+        if op in ("count_overlaps", "nearest") and gather and not state.get("no_gather"):
+            fills = [0] if op == "count_overlaps" else [-1, -1, 0]
+            if exchange == "lib":
+                # shard kernel + per-probe exchange inside the library (ivj_count_overlaps_allgather_dev / ivj_nearest_allgather_dev)
+                opts = E.make_opts(True, nc, partition_mode=args.partition_mode)
+                ix = join.engine.index_build_dev(d_build.as_c(), opts, op == "count_overlaps")
+                try:
+                    if "pp" not in state:
+                        state["pp"] = ((torch.empty(n_p_total, dtype=torch.int64, device=dev),) if op == "count_overlaps" else
+                                       (torch.empty(n_p_total, dtype=torch.int32, device=dev), torch.empty(n_p_total, dtype=torch.int64, device=dev),
+                                        torch.empty(n_p_total, dtype=torch.int32, device=dev)))
+                    pp = state["pp"]
+                    if op == "count_overlaps":
+                        comm.count_overlaps_allgather_dev(ix, d_probe.as_c(), opts, n_p_total, pp[0].data_ptr())
+                    else:
+                        comm.nearest_allgather_dev(ix, d_probe.as_c(), opts, n_p_total, pp[0].data_ptr(), pp[1].data_ptr(), pp[2].data_ptr())
+                finally:
+                    ix.close()
+                state["gathered"] = n_p_total
+                return d_probe.n, pp
+            res = join.count_overlaps(d_probe, d_build, True, nc, partition_mode=args.partition_mode) if op == "count_overlaps" else \
+                join.nearest(d_probe, d_build, True, nc, partition_mode=args.partition_mode)
+            vals = [res] if op == "count_overlaps" else [res[0].reshape(-1), res[1].reshape(-1), res[2]]
+            ids = d_probe.row_id if d_probe.row_id is not None else torch.arange(d_probe.n, dtype=torch.int32, device=dev)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            full = D.gather_per_probe([to_x(v) for v in vals], to_x(ids), n_p_total, fill=fills, group=xgroup)
+            ev[1].record()
+            state.setdefault("gather_events", []).append(ev)
+            state["gathered"] = n_p_total
+            return d_probe.n, full
         if op == "count_overlaps":
             return d_probe.n, join.count_overlaps(d_probe, d_build, True, nc, partition_mode=args.partition_mode)
         if op == "coverage":
@@ -591,8 +624,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_units = int(t.item())
     elapsed = float(tmax.item())
-    if gather:
+    if gather and op == "overlap":
         assert int(state.get("gathered", -1)) == total_units, "all-gatherv lost pairs"
+    if gather and op != "overlap":
+        assert int(state.get("gathered", -1)) == n_p_total, "the per-probe exchange did not run"
     ms_per_step = elapsed / args.steps * 1e3
     gather_ms = None
     if state.get("gather_events"):
@@ -740,7 +775,8 @@ def main():
             "config": {"workload": args.workload, "probe_rows": n_p_total, "build_rows": n_b_total, "contigs": nc,
                        "filter_op": "Strict", "units_per_step": total_units,
                        "parallelism": ("single GPU" if not multi else
-                                       f"{mode}-sharded x{n_gpus}, " + ((f"all-gatherv in timed region ({exchange}" + (f", {args.chunks} chunks, exchange overlapping the join" if exchange == "lib" else "") + ")") if gather else "no gather")),
+                                       f"{mode}-sharded x{n_gpus}, " + ((f"all-gatherv in timed region ({exchange}" + (f", {args.chunks} chunks, exchange overlapping the join" if exchange == "lib" and op == "overlap" else "") +
+                                                                   (", per-probe results scattered to global probe order on every rank" if op != "overlap" else "") + ")") if gather else "no gather")),
                        "step": ("index build (radix sort) + probe partition (" +
                                 ("contig-aligned index slices, 12-byte records" if any(k.startswith("cs_") for k in ktimes) else
                                  "equal-row-count index slices, 16-byte records" if any(k.startswith("slice_") for k in ktimes) else "256 genomic buckets") + ") + " +

@@ -407,6 +407,23 @@ int ivj_allgatherv_dev(ivj_comm* comm, const void* const* send_cols, void* const
 int ivj_overlap_allgather_dev(ivj_comm* comm, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int n_chunks,
                               int32_t* probe_idx_dev, int32_t* build_idx_dev, int64_t capacity, int64_t* n_total, int64_t* n_local);
 
+/* pb.count_overlaps / pb.nearest of this rank's shard + the exchange of the PER-PROBE results ("the gather is
+ * of fixed-width per-probe results scattered back to original probe order (carry probe row id)"; replaces the single-process
+ * providers behind src/operation.rs:331-340 and :146-158 for a multi-GPU host).  probe_dev->row_id = the GLOBAL probe rows of the
+ * shard (required when world > 1; NULL at world 1 means 0 .. n-1), n_total = probe rows of the whole job (the same on every rank).
+ * Every rank ends up with the full-length columns in global probe order: counts_dev[n_total] (int64), or idx_dev[n_total * k] /
+ * dist_dev[n_total * k] / n_found_dev[n_total] with k = opts->nearest_k.  Rows no rank reports keep count 0 / build row -1, distance -1,
+ * n_found 0.  On the wire: {row int32, count int32} (8 bytes per probe; counts are bounded by the build rows) and
+ * {row int32, k x int32, k x int64, int32}: ONE count all-gather + ONE grouped send / receive batch, then a scatter kernel.
+ * Failure contract: every rank reaches the count all-gather whatever happened to its own shard; a rank whose work failed returns its
+ * own error, every other rank IVJ_EPEER, and nothing is sent or received (decided from the gathered values, so nobody waits in a
+ * collective); ranks that disagree on n_total, or report more rows than n_total, get IVJ_EINVAL on every rank.
+ * IVJ_FAULT_ALLGATHER="<rank>:0" makes that rank's shard fail (test knob). */
+int ivj_count_overlaps_allgather_dev(ivj_comm* comm, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t n_total,
+                                     int64_t* counts_dev);
+int ivj_nearest_allgather_dev(ivj_comm* comm, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t n_total,
+                              int32_t* idx_dev, int64_t* dist_dev, int32_t* n_found_dev);
+
 /* ---- the one-call Arrow entry: two ArrowArrayStreams in, a stream of joined record batches out -------------------------- *
  * This is the shape of the reference's own FFI: range_operation_frame / range_operation_lazy take df1 and df2 as Arrow C
  * streams with a STRING chrom and start / end of any integer width and answer with a lazy frame of joined rows

@@ -219,7 +219,16 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_lines(IndexView ix
     for (int i = threadIdx.x; i < 2 * ix.n_contigs; i += PROBE_THREADS) l_cm[i] = ix.cmeta[i];
     __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * (PROBE_THREADS * N) + (int64_t)threadIdx.x * N;
-    if (i0 >= n) return;
+    if (i0 >= n) {
+        // a wavefront that lies wholly beyond the probes still owns N mask words: k_nearest_k1_rest reads every word of the last
+        // tile, and the scratch they live in is not cleared (lane 0 holds the wavefront's smallest row)
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            const int64_t wf0 = ((int64_t)blockIdx.x * PROBE_THREADS + threadIdx.x) / kWave;
+#pragma unroll
+            for (int k = 0; k < N; ++k) rest[N * wf0 + k] = 0ull;
+        }
+        return;
+    }
     int32_t c[N], s[N], e[N];
     load_items_nt(pc, i0, n, vec_ok, -1, c);
     load_items_nt(ps, i0, n, vec_ok, 0, s);
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_rest(IndexView ix,
     __syncthreads();
     for (int q = tid; q < total; q += PROBE_THREADS) {
         const int64_t i = l_list[q];
+        if (i >= n) continue;                                                  // (defensive: the lines kernel never marks a row beyond n)
         int32_t c[1] = {pc[i]}, s = ps[i], e[1] = {pe[i]};
         bool valid[1] = {true};
         int a[1], b[1], hi[1];

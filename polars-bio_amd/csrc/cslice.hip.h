@@ -404,20 +404,18 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
         }
         long long tsum;
         int pre = (int)sl_block_exclusive_sum_i32<CS_WAVES>(xs, wsum + (tix & 1) * CS_WAVES, &tsum);      // (B)
+        // SAMPLED, split-phase (round 5): the returning atomic that reserves a run's place in its bucket's region is only ISSUED here;
+        // its answer is needed for the copy-out deltas alone, so the placement into LDS runs while it is in flight (the round-4 form
+        // waited for it -- twice in a row for a thread's two buckets, ~ 3 us of an 18-us tile -- before barrier (C))
+        uint32_t got[OWN];
 #pragma unroll
         for (int q = 0; q < OWN; ++q) {
             const int b = OWN * tid + q;
+            got[q] = 0u;
             if (b < nbk) {
                 lstart[b] = (uint32_t)pre;
                 if constexpr (SAMPLED) {
-                    uint32_t at = base[b];                                      // region start (an overflowing run lands here, in bounds)
-                    if (x[q] > 0 && b < g.nb) {
-                        const uint32_t cap = base[b + 1] - base[b];
-                        const uint32_t got = atomicAdd(&rcur[b], (uint32_t)x[q]);
-                        if (got + (uint32_t)x[q] <= cap) at += got;
-                        else atomicOr(state + 1, 4ull);
-                    }
-                    delta[b] = at - (uint32_t)pre;
+                    if (x[q] > 0 && b < g.nb) got[q] = atomicAdd(&rcur[b], (uint32_t)x[q]);
                 } else { delta[b] = base[b] - (uint32_t)pre; base[b] += (uint32_t)x[q]; }
             }
             pre += x[q];
@@ -429,6 +427,22 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
                 const uint32_t pos = lstart[d[j]] + rank[j];
                 l_rs[pos] = s[j]; l_re[pos] = e[j]; l_rr[pos] = r[j];
                 l_d[pos] = (unsigned short)d[j];
+            }
+        }
+        if constexpr (SAMPLED) {
+#pragma unroll
+            for (int q = OWN - 1; q >= 0; --q) {
+                const int b = OWN * tid + q;
+                pre -= x[q];
+                if (b < nbk) {
+                    uint32_t at = base[b];                                      // region start (an overflowing run lands here, in bounds)
+                    if (x[q] > 0 && b < g.nb) {
+                        const uint32_t cap = base[b + 1] - at;
+                        if (got[q] + (uint32_t)x[q] <= cap) at += got[q];
+                        else atomicOr(state + 1, 4ull);
+                    }
+                    delta[b] = at - (uint32_t)pre;
+                }
             }
         }
         __syncthreads();                                                        // (D) tile sorted in LDS
@@ -716,6 +730,15 @@ struct CsJoinArgs {
     int32_t* out_build;
 };
 
+// Copy-out of a wavefront's staged pairs (round 5): the output range starts at an arbitrary element of the two result columns, so a
+// plain `for (i = lane; ...)` makes EVERY 256-byte store instruction straddle five 64-byte lines (round-4 counters: 32.1 M write
+// requests for 24.8 M lines of pairs).  The loop starts at lane - (misalignment in elements) instead: the first trip writes the
+// partial head line(s), every later one four whole lines.  IVJ_SLICE_ABLATE bit 8192 keeps the unaligned form (A/B runs).
+constexpr int CS_ABLATE_UNALIGNED = 8192;
+__device__ __forceinline__ int cs_copy_align(const int32_t* op, int ablate) {
+    return (ablate & CS_ABLATE_UNALIGNED) ? 0 : (int)((reinterpret_cast<uintptr_t>(op) >> 2) & 15u);
+}
+
 struct CsJoinLds { int end, pmx, start, row, bin, qrow, stage, ctl, total; };
 __host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
     CsJoinLds L;
@@ -971,11 +994,14 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 int32_t* op = A.out_probe + wbase;
                 int32_t* ob = A.out_build + wbase;
+                const int ca = cs_copy_align(op, A.ablate);
 #pragma unroll 4
-                for (int i = lane; i < wtot; i += kWave) {
-                    const uint32_t e = stw[i];
-                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
-                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                for (int i = lane - ca; i < wtot; i += kWave) {
+                    if ((unsigned)i < (unsigned)wtot) {
+                        const uint32_t e = stw[i];
+                        __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                        __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             } else {
@@ -1033,11 +1059,14 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
             if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
                 int32_t* op = A.out_probe + tb + pend_woff;
                 int32_t* ob = A.out_build + tb + pend_woff;
+                const int ca = cs_copy_align(op, A.ablate);
 #pragma unroll 4
-                for (int i = lane; i < pend_wtot; i += kWave) {
-                    const uint32_t e = stw[i];
-                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
-                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                for (int i = lane - ca; i < pend_wtot; i += kWave) {
+                    if ((unsigned)i < (unsigned)pend_wtot) {
+                        const uint32_t e = stw[i];
+                        __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                        __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                    }
                 }
             }
             if (lane == 0) {
@@ -1389,11 +1418,14 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             // (the bias comes off the LDS address once, outside the loop: every entry of this loop is >= the bias)
             typedef __attribute__((address_space(3))) const int32_t lds_ci32;
             lds_ci32* rowb = (lds_ci32*)(uintptr_t)((uint32_t)(uintptr_t)(lds_ci32*)l_row - 4u * (uint32_t)CS_POS_BIAS);
+            const int ca = cs_copy_align(op, A.ablate);
 #pragma unroll 4
-            for (int i = lane; i < n_ent; i += kWave) {
-                const uint32_t e = stw[i];
-                __builtin_nontemporal_store(qrw[e >> 24], op + i);
-                __builtin_nontemporal_store((int32_t)rowb[e & 0xffffffu], ob + i);
+            for (int i = lane - ca; i < n_ent; i += kWave) {
+                if ((unsigned)i < (unsigned)n_ent) {
+                    const uint32_t e = stw[i];
+                    __builtin_nontemporal_store(qrw[e >> 24], op + i);
+                    __builtin_nontemporal_store((int32_t)rowb[e & 0xffffffu], ob + i);
+                }
             }
             return;
         }
@@ -1695,11 +1727,14 @@ __global__ __launch_bounds__(CS_THREADS, TWO ? 8 : 4) void k_cs_fill(CsJoinArgs 
                 __builtin_amdgcn_wave_barrier();
                 int32_t* op = A.out_probe + wbase;
                 int32_t* ob = A.out_build + wbase;
+                const int ca = cs_copy_align(op, A.ablate);
 #pragma unroll 4
-                for (int i = lane; i < wtot; i += kWave) {
-                    const uint32_t e = stw[i];
-                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
-                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                for (int i = lane - ca; i < wtot; i += kWave) {
+                    if ((unsigned)i < (unsigned)wtot) {
+                        const uint32_t e = stw[i];
+                        __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                        __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             } else {

@@ -114,6 +114,8 @@ struct ivj_comm {
     int64_t stage_cap = 0;               //   pairs per staging buffer
     int32_t* iota = nullptr;             // 0 .. iota_n - 1: row ids of a probe side that brings none (its chunks need absolute rows)
     int64_t iota_n = 0;
+    char* pp_buf = nullptr;              // scratch of the per-probe exchange (count_overlaps / nearest): local results, send and receive columns
+    size_t pp_cap = 0;
 };
 
 namespace {
@@ -137,13 +139,15 @@ int comm_finish_create(ivj_comm* c) {
 
 // For every column: recv[k] + dst_off + (exclusive prefix of counts)[r] <- rank r's send[k][0 .. counts[r]) ; elem_bytes per element.
 // One grouped batch of sends / receives on the exchange stream (own slice: device copy).  Does NOT synchronise.
-int comm_exchange(ivj_comm* c, const void* const* send, void* const* recv, int n_cols, int elem_bytes, const int64_t* counts, int64_t dst_off) {
+int comm_exchange_v(ivj_comm* c, const void* const* send, void* const* recv, int n_cols, const int* elem_bytes_v, const int64_t* counts, int64_t dst_off) {
     std::vector<int64_t> off((size_t)c->world + 1, 0);
     for (int r = 0; r < c->world; ++r) off[r + 1] = off[r] + counts[r];
     const int64_t n_local = counts[c->rank];
-    for (int k = 0; k < n_cols; ++k)
+    for (int k = 0; k < n_cols; ++k) {
+        const int elem_bytes = elem_bytes_v[k];
         if (n_local > 0)
             HIP_TRY(hipMemcpyAsync((char*)recv[k] + (size_t)(dst_off + off[c->rank]) * elem_bytes, send[k], (size_t)n_local * elem_bytes, hipMemcpyDeviceToDevice, c->xstream));
+    }
     if (c->world == 1) return IVJ_OK;
     if (c->loop) {
         LoopGroup* L = c->loop;
@@ -154,8 +158,8 @@ int comm_exchange(ivj_comm* c, const void* const* send, void* const* recv, int n
         for (int k = 0; k < n_cols && e == hipSuccess; ++k)
             for (int peer = 0; peer < c->world && e == hipSuccess; ++peer)
                 if (peer != c->rank && counts[peer] > 0)
-                    e = hipMemcpyAsync((char*)recv[k] + (size_t)(dst_off + off[peer]) * elem_bytes, L->send[(size_t)peer * LoopGroup::MAX_COLS + k],
-                                       (size_t)counts[peer] * elem_bytes, hipMemcpyDefault, c->xstream);
+                    e = hipMemcpyAsync((char*)recv[k] + (size_t)(dst_off + off[peer]) * elem_bytes_v[k], L->send[(size_t)peer * LoopGroup::MAX_COLS + k],
+                                       (size_t)counts[peer] * elem_bytes_v[k], hipMemcpyDefault, c->xstream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->xstream);
         if (!L->barrier(loop_timeout_s())) return fail(IVJ_EHIP, "loopback transport: a rank did not finish the exchange (timeout)");   // the peers' send buffers are free again
         if (e != hipSuccess) return fail(IVJ_EHIP, std::string("loopback transport copy: ") + hipGetErrorString(e));
@@ -164,6 +168,7 @@ int comm_exchange(ivj_comm* c, const void* const* send, void* const* recv, int n
     const RcclApi* api = rccl_api();
     RCCL_TRY(api, api->GroupStart());
     for (int k = 0; k < n_cols; ++k) {
+        const int elem_bytes = elem_bytes_v[k];
         for (int peer = 0; peer < c->world; ++peer) {
             if (peer == c->rank) continue;
             if (n_local > 0) RCCL_TRY(api, api->Send(send[k], (size_t)n_local * elem_bytes, RCCL_INT8, peer, c->comm, c->xstream));
@@ -173,6 +178,12 @@ int comm_exchange(ivj_comm* c, const void* const* send, void* const* recv, int n
     }
     RCCL_TRY(api, api->GroupEnd());
     return IVJ_OK;
+}
+int comm_exchange(ivj_comm* c, const void* const* send, void* const* recv, int n_cols, int elem_bytes, const int64_t* counts, int64_t dst_off) {
+    if (n_cols > LoopGroup::MAX_COLS) return fail(IVJ_EINVAL, "all-gatherv: too many columns");
+    int w[LoopGroup::MAX_COLS];
+    for (int k = 0; k < n_cols; ++k) w[k] = elem_bytes;
+    return comm_exchange_v(c, send, recv, n_cols, w, counts, dst_off);
 }
 
 
@@ -359,6 +370,175 @@ int overlap_allgather(ivj_comm* c, ivj_index* ix, const ivj_side* probe, const i
     if (x_rc != IVJ_OK) { g_err = x_err; return x_rc; }
     if (peer_failed) return fail(IVJ_EPEER, "rank " + std::to_string(failed_peer) + " failed in chunk " + std::to_string(failed_chunk) + " of the sharded overlap; its pairs from there on are missing");
     if (overflow) return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(dst_off) + " pairs (on some rank): nothing was exchanged past the first chunk that did not fit");
+    return IVJ_OK;
+}
+
+// ---- count_overlaps / nearest of a shard + the exchange of the PER-PROBE results ---------------------------------
+// Every probe row lives on exactly one rank (contig sharding; global row in ivj_side.row_id), its result has a fixed width, and every
+// rank wants the full-length columns in the ORIGINAL probe order: local results -> packed send columns {global row, value ...} ->
+// count all-gather + ONE grouped send / receive batch -> a scatter kernel that stores every received value at its row.
+//   count_overlaps: {row int32, count int32} on the wire (a count is bounded by the build rows, < 2^31), widened to int64 by the scatter
+//   nearest:        {row int32, k build rows int32, k distances int64, n_found int32}
+// Rows no rank reports keep the defaults (count 0; build row -1, distance -1, n_found 0).
+__global__ void k_pp_pack_count(const int32_t* __restrict__ row_id, const long long* __restrict__ cnt, int64_t n, int32_t* __restrict__ o_row, int32_t* __restrict__ o_cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    o_row[i] = row_id ? row_id[i] : (int32_t)i;
+    o_cnt[i] = (int32_t)cnt[i];
+}
+__global__ void k_pp_rows(const int32_t* __restrict__ row_id, int64_t n, int32_t* __restrict__ o_row) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o_row[i] = row_id ? row_id[i] : (int32_t)i;
+}
+__global__ void k_pp_scatter_count(const int32_t* __restrict__ row, const int32_t* __restrict__ cnt, int64_t n, int64_t n_out, long long* __restrict__ out,
+                                   unsigned int* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = row[i];
+    if ((uint64_t)(int64_t)r >= (uint64_t)n_out) { atomicOr(bad, 1u); return; }
+    out[r] = (long long)cnt[i];
+}
+__global__ void k_pp_scatter_nearest(const int32_t* __restrict__ row, const int32_t* __restrict__ idx, const long long* __restrict__ dist,
+                                     const int32_t* __restrict__ nf, int64_t n, int k, int64_t n_out, int32_t* __restrict__ o_idx,
+                                     long long* __restrict__ o_dist, int32_t* __restrict__ o_nf, unsigned int* __restrict__ bad) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * k) return;
+    const int64_t i = t / k;
+    const int j = (int)(t - i * k);
+    const int32_t r = row[i];
+    if ((uint64_t)(int64_t)r >= (uint64_t)n_out) { atomicOr(bad, 1u); return; }
+    o_idx[(int64_t)r * k + j] = idx[t];
+    o_dist[(int64_t)r * k + j] = dist[t];
+    if (j == 0) o_nf[r] = nf[i];
+}
+__global__ void k_pp_fill_i32(int32_t* __restrict__ p, int64_t n, int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int pp_ensure(ivj_comm* c, size_t bytes) {
+    if (bytes <= c->pp_cap) return IVJ_OK;
+    if (c->pp_buf) (void)hipFree(c->pp_buf);
+    c->pp_buf = nullptr; c->pp_cap = 0;
+    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    if (hipMalloc((void**)&c->pp_buf, want) != hipSuccess) return fail(IVJ_ENOMEM, "scratch of the per-probe exchange: hipMalloc of " + std::to_string(want) + " bytes failed");
+    c->pp_cap = want;
+    return IVJ_OK;
+}
+
+// op: IVJ_STREAM_COUNT or IVJ_STREAM_NEAREST.  Failure protocol as overlap_allgather: every rank reaches the ONE count all-gather with
+// {rows it reports | -1 = its own work failed, the n_total it was given}; whether anything is moved is decided from the gathered values
+// alone (a failed rank: nobody sends or receives, the failed rank returns its own error, the others IVJ_EPEER; n_total differing between
+// the ranks or fewer output rows than reported rows: IVJ_EINVAL on every rank), so no rank is ever left waiting in a collective.
+int per_probe_allgather(ivj_comm* c, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int op, int64_t n_total,
+                        int64_t* counts_out, int32_t* idx_out, int64_t* dist_out, int32_t* nf_out) {
+    ivj_ctx* ctx = c->ctx;
+    const int64_t n = probe->n;
+    const int k = op == IVJ_STREAM_NEAREST ? (opts->nearest_k < 1 ? 1 : opts->nearest_k) : 1;
+    int rc = IVJ_OK;
+    std::string main_err;
+    auto note = [&](int r) { if (r != IVJ_OK && rc == IVJ_OK) { rc = r; main_err = g_err; } };
+    if (c->world > 1 && n > 0 && !probe->row_id) note(fail(IVJ_EINVAL, "a shard of a multi-rank call needs the global probe rows in probe.row_id"));
+    if (n > n_total) note(fail(IVJ_EINVAL, "the shard has more probe rows than n_total"));
+    if (rc == IVJ_OK && fault_injected(c->rank, 0)) note(fail(IVJ_EHIP, "injected fault (IVJ_FAULT_ALLGATHER) in the per-probe exchange"));
+    // scratch layout: [bad flag | local results | send columns | receive columns (n_total rows)]
+    const size_t a_row = align_up((size_t)std::max<int64_t>(n, 1) * 4), a_row_t = align_up((size_t)std::max<int64_t>(n_total, 1) * 4);
+    size_t local_b, send_b, recv_b;
+    if (op == IVJ_STREAM_COUNT) { local_b = align_up((size_t)std::max<int64_t>(n, 1) * 8); send_b = 2 * a_row; recv_b = 2 * a_row_t; }
+    else {
+        local_b = 0;                                                            // nearest_dev writes straight into the send columns
+        send_b = a_row + align_up((size_t)std::max<int64_t>(n, 1) * k * 4) + align_up((size_t)std::max<int64_t>(n, 1) * k * 8) + a_row;
+        recv_b = a_row_t + align_up((size_t)std::max<int64_t>(n_total, 1) * k * 4) + align_up((size_t)std::max<int64_t>(n_total, 1) * k * 8) + a_row_t;
+    }
+    if (rc == IVJ_OK) note(pp_ensure(c, 256 + local_b + send_b + recv_b));
+    char* base = c->pp_buf;
+    unsigned int* d_bad = reinterpret_cast<unsigned int*>(base);
+    char* p_local = base ? base + 256 : nullptr;
+    char* p_send = p_local ? p_local + local_b : nullptr;
+    char* p_recv = p_send ? p_send + send_b : nullptr;
+    const void* send[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* recv[4] = {nullptr, nullptr, nullptr, nullptr};
+    int widths[4] = {4, 4, 8, 4};
+    int n_cols = 2;
+    if (rc == IVJ_OK) {
+        if (op == IVJ_STREAM_COUNT) {
+            int32_t* s_row = (int32_t*)p_send; int32_t* s_cnt = (int32_t*)(p_send + a_row);
+            send[0] = s_row; send[1] = s_cnt; recv[0] = p_recv; recv[1] = p_recv + a_row_t;
+            widths[0] = 4; widths[1] = 4; n_cols = 2;
+            if (n > 0) {
+                note(count_overlaps_dev(ctx, ix, probe, opts, (int64_t*)p_local));
+                if (rc == IVJ_OK) {
+                    hipLaunchKernelGGL(k_pp_pack_count, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, probe->row_id, (const long long*)p_local, n, s_row, s_cnt);
+                    if (hipGetLastError() != hipSuccess) note(fail(IVJ_EHIP, "k_pp_pack_count launch failed"));
+                }
+            }
+        } else {
+            char* q = p_send;
+            int32_t* s_row = (int32_t*)q; q += a_row;
+            int32_t* s_idx = (int32_t*)q; q += align_up((size_t)std::max<int64_t>(n, 1) * k * 4);
+            int64_t* s_dist = (int64_t*)q; q += align_up((size_t)std::max<int64_t>(n, 1) * k * 8);
+            int32_t* s_nf = (int32_t*)q;
+            char* r = p_recv;
+            recv[0] = r; r += a_row_t;
+            recv[1] = r; r += align_up((size_t)std::max<int64_t>(n_total, 1) * k * 4);
+            recv[2] = r; r += align_up((size_t)std::max<int64_t>(n_total, 1) * k * 8);
+            recv[3] = r;
+            send[0] = s_row; send[1] = s_idx; send[2] = s_dist; send[3] = s_nf;
+            widths[0] = 4; widths[1] = 4 * k; widths[2] = 8 * k; widths[3] = 4; n_cols = 4;
+            if (n > 0) {
+                note(nearest_dev(ctx, ix, probe, opts, s_idx, s_dist, s_nf));
+                if (rc == IVJ_OK) {
+                    hipLaunchKernelGGL(k_pp_rows, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, probe->row_id, n, s_row);
+                    if (hipGetLastError() != hipSuccess) note(fail(IVJ_EHIP, "k_pp_rows launch failed"));
+                }
+            }
+        }
+        if (rc == IVJ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) note(fail(IVJ_EHIP, "the shard's per-probe kernel failed"));
+    }
+    // every rank, whatever happened to it so far
+    std::vector<int64_t> all((size_t)c->world * 2), counts((size_t)c->world);
+    const int64_t mine[2] = {rc == IVJ_OK ? n : -1, n_total};
+    IVJ_TRY(comm_allgather_i64(c, mine, 2, all.data()));
+    int failed_peer = -1;
+    bool mismatch = false;
+    int64_t tot = 0;
+    for (int r = 0; r < c->world; ++r) {
+        const int64_t nr = all[(size_t)r * 2];
+        if (nr < 0 && failed_peer < 0) failed_peer = r;
+        if (all[(size_t)r * 2 + 1] != n_total) mismatch = true;
+        counts[r] = nr < 0 ? 0 : nr;
+        tot += counts[r];
+    }
+    if (rc != IVJ_OK) { g_err = main_err; return rc; }
+    if (failed_peer >= 0) return fail(IVJ_EPEER, "rank " + std::to_string(failed_peer) + " failed in the per-probe exchange; nothing was exchanged");
+    if (mismatch) return fail(IVJ_EINVAL, "the ranks of a per-probe exchange disagree on n_total");
+    if (tot > n_total) return fail(IVJ_EINVAL, "the ranks report " + std::to_string(tot) + " probe rows for n_total = " + std::to_string(n_total));
+    // defaults + exchange + scatter, all on the exchange stream (after whatever the context's stream still holds for the caller's columns)
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 4, c->xstream));
+    if (n_total > 0) {
+        if (op == IVJ_STREAM_COUNT) HIP_TRY(hipMemsetAsync(counts_out, 0, (size_t)n_total * 8, c->xstream));
+        else {
+            HIP_TRY(hipMemsetAsync(idx_out, 0xff, (size_t)n_total * k * 4, c->xstream));       // -1
+            HIP_TRY(hipMemsetAsync(dist_out, 0xff, (size_t)n_total * k * 8, c->xstream));      // -1
+            HIP_TRY(hipMemsetAsync(nf_out, 0, (size_t)n_total * 4, c->xstream));
+        }
+    }
+    IVJ_TRY(comm_exchange_v(c, send, recv, n_cols, widths, counts.data(), 0));
+    if (tot > 0) {
+        if (op == IVJ_STREAM_COUNT)
+            hipLaunchKernelGGL(k_pp_scatter_count, dim3(grid1d(tot, 256)), dim3(256), 0, c->xstream, (const int32_t*)recv[0], (const int32_t*)recv[1], tot, n_total,
+                               (long long*)counts_out, d_bad);
+        else
+            hipLaunchKernelGGL(k_pp_scatter_nearest, dim3(grid1d(tot * k, 256)), dim3(256), 0, c->xstream, (const int32_t*)recv[0], (const int32_t*)recv[1],
+                               (const long long*)recv[2], (const int32_t*)recv[3], tot, k, n_total, idx_out, (long long*)dist_out, nf_out, d_bad);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned int h_bad = 0;
+    HIP_TRY(hipMemcpyAsync(c->h_counts, d_bad, 4, hipMemcpyDeviceToHost, c->xstream));
+    HIP_TRY(hipStreamSynchronize(c->xstream));
+    h_bad = *reinterpret_cast<const unsigned int*>(c->h_counts);
+    if (h_bad) return fail(IVJ_EINVAL, "a probe row id of the per-probe exchange lies outside [0, n_total)");
     return IVJ_OK;
 }
 

@@ -96,6 +96,9 @@ struct ivj_ctx {
     uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
     bool part_attr_set = false;
     bool os_attr_set = false;
+    bool ix3_attr_set = false;         // index build, round 5 (ixsort3.hip.h): LDS attributes set once
+    int env_ix_v3 = -1;                // IVJ_IX_V3: -1 by size, 0 never (the round-2 LSD sort), 1 wherever it applies
+    int64_t ix3_fallbacks = 0;         // builds the balanced pass handed back to the LSD sort (a bucket above V3_CAP rows, keys beyond 32 bits)
     // slice path (host_slice.hip.h): bucket-ordered probe records, histogram, chunk table, tile totals
     // staging of the last closed streaming session, kept for the next one (pinned allocations cost ~70 ms per GB)
     struct StreamBufs { int32_t* h_in = nullptr; int32_t* d_in = nullptr; size_t in_cap = 0; char* d_out = nullptr; size_t d_out_cap = 0;

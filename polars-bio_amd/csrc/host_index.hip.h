@@ -258,6 +258,68 @@ int index_sort_v2(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     return IVJ_OK;
 }
 
+// round-5 build (ixsort3.hip.h): per-contig extremes -> ONE balanced bucket pass over HBM -> LDS sort per bucket that writes the
+// index arrays.  *done = false hands the build to index_sort_v2 -- more contig keys than the LDS tables hold, linear keys beyond
+// 32 bits, or a bucket above V3_CAP rows (clustered build sides): known from 8 bytes read back after the bucket pass, so exactness
+// never rests on the balance.  Auto: 128 k .. 7 M rows (below, the launches are the cost either way; above, 2048 buckets of V3_CAP
+// rows cannot hold the rows); IVJ_IX_V3 = 0 / 1 forces the choice (A/B runs, tests).
+bool ix3_wanted(const ivj_ctx* ctx, int64_t n, int nc) {
+    if (nc + 1 > V3_MAX_KEYS || n <= 0 || n > (int64_t)V3_CAP * V3_BUCKETS) return false;
+    if (ctx->env_ix_v3 >= 0) return ctx->env_ix_v3 != 0;
+    return n >= (128ll << 10) && n <= (7ll << 20);
+}
+int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_opts* opts, bool* done) {
+    *done = false;
+    const int64_t n = build->n;
+    const int nc = opts->n_contigs;
+    const int64_t tiles = (n + OS_TILE - 1) / OS_TILE;
+    int64_t chunk = ((n + 255) / 256 + OS_TILE - 1) / OS_TILE * OS_TILE;       // one workgroup per CU, whole sub-tiles (as os_sort_plan)
+    if (chunk < OS_TILE) chunk = OS_TILE;
+    const int nchunks = (int)((n + chunk - 1) / chunk);
+    const int64_t hist_len = (int64_t)V3_BUCKETS * nchunks;
+    const int64_t hs_tiles = (hist_len + LB_TILE - 1) / LB_TILE;
+    const size_t z_meta = align_up(sizeof(V3Meta)), z_st = align_up((size_t)V3_BUCKETS * 8), z_hs = align_up((size_t)hs_tiles * 8), z_tick = align_up(16);
+    const size_t zero_bytes = z_meta + z_st + z_hs + z_tick;
+    OsSort S;                                                                   // (the arena must also hold the fallback's scratch: reserve the larger of the two once)
+    const size_t v2_bytes = os_sort_plan(S, n, nc);
+    IVJ_TRY(arena_reserve(ctx, std::max(v2_bytes, zero_bytes + align_up((size_t)hist_len * 4) + align_up((size_t)n * 16)) + 4096));
+    char* z = arena_take<char>(ctx, zero_bytes);
+    uint32_t* hist = arena_take<uint32_t>(ctx, (size_t)hist_len);
+    int4* recs = arena_take<int4>(ctx, (size_t)n);
+    V3Meta* meta = (V3Meta*)z;
+    unsigned long long* st_local = (unsigned long long*)(z + z_meta);
+    unsigned long long* st_scan = (unsigned long long*)(z + z_meta + z_st);
+    uint32_t* tick_scan = (uint32_t*)(z + z_meta + z_st + z_hs);
+    HIP_TRY(hipMemsetAsync(z, 0, zero_bytes, ctx->stream));
+    const size_t pass_lds = (size_t)v3_pass_lds().total, local_lds = (size_t)v3_local_lds().total;
+    if (!ctx->ix3_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)local_lds));
+        ctx->ix3_attr_set = true;
+    }
+    const unsigned sgrid = (unsigned)(tiles < 512 ? tiles : 512);
+    LAUNCH(ctx, "ix3_stats", k_v3_stats, sgrid, OS_THREADS, build->start, build->end, build->contig, n, nc, meta);
+    LAUNCH(ctx, "ix3_hist", k_v3_hist, nchunks, OS_THREADS, build->contig, build->start, n, nc, (const V3Meta*)meta, (int)chunk, nchunks, hist);
+    LAUNCH(ctx, "ix_scan", (k_scan_lb_u32<SumOp, true>), hs_tiles, OS_THREADS, hist, hist_len, 0u, tick_scan, st_scan);
+    t_begin(ctx, "ix3_pass");
+    hipLaunchKernelGGL(k_v3_scatter, dim3((unsigned)nchunks), dim3(OS_THREADS), pass_lds, ctx->stream, build->contig, build->start, build->end, build->row_id,
+                       recs, n, nc, meta, (int)chunk, nchunks, (const uint32_t*)hist);
+    t_end(ctx);
+    HIP_TRY(hipGetLastError());
+    // {bad, max_bucket}: adjacent in V3Meta
+    HIP_TRY(hipMemcpyAsync(ctx->h_total + 6, &meta->bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint32_t* hv = reinterpret_cast<const uint32_t*>(ctx->h_total + 6);
+    if (hv[0] != 0u || hv[1] > (uint32_t)V3_CAP) { ++ctx->ix3_fallbacks; return IVJ_OK; }
+    t_begin(ctx, "ix3_local");
+    hipLaunchKernelGGL(k_v3_local, dim3(V3_BUCKETS), dim3(OS_THREADS), local_lds, ctx->stream, (const int4*)recs, (const uint32_t*)hist, nchunks, n, nc, meta, st_local,
+                       ix->b_start, ix->ep, ix->b_row, ix->b_contig, ix->seg, ix->flags);
+    t_end(ctx);
+    HIP_TRY(hipGetLastError());
+    *done = true;
+    return IVJ_OK;
+}
+
 // direct-address table over the starts (lazily, on the sorted index): per-contig geometry, head marks, look-back max-scan,
 // 16-byte bin records
 int build_tables(ivj_ctx* ctx, ivj_index* ix) {
@@ -350,7 +412,10 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
     }
     if (n > 0) {
         ix->has_tables = !(with_end_order & 2);
-        int r = index_sort_v2(ctx, ix, build, opts);
+        int r = IVJ_OK;
+        bool sorted = false;
+        if (ix3_wanted(ctx, n, opts->n_contigs)) { r = index_sort_v3(ctx, ix, build, opts, &sorted); if (r != IVJ_OK) return cleanup(r); }
+        if (!sorted) r = index_sort_v2(ctx, ix, build, opts);
         if (r != IVJ_OK) return cleanup(r);
         // 7. the flat overlap path's arrays (lot / tab2 / rec4) are filled on first use: build_flat
         if (opts->partition_mode == 5) { r = build_flat(ctx, ix); if (r != IVJ_OK) return cleanup(r); }

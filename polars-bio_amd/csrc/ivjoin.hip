@@ -24,6 +24,7 @@
 #include "slice.hip.h"
 #include "cslice.hip.h"
 #include "onesweep.hip.h"
+#include "ixsort3.hip.h"
 #include "scan.hip.h"
 
 using namespace ivj;
@@ -86,6 +87,7 @@ int ivj_ctx_create(int device, ivj_ctx** out) try {
     if (const char* ev = std::getenv("IVJ_COUNT_ABLATE")) ctx->env_count_ablate = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_NEAREST_LINES")) ctx->env_nearest_lines = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_NOLDS")) ctx->env_count_nolds = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_IX_V3")) ctx->env_ix_v3 = std::atoi(ev) != 0 ? 1 : 0;
     e = hipHostMalloc((void**)&ctx->h_total, 64, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(IVJ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
     *out = ctx;
@@ -342,6 +344,7 @@ void ivj_comm_destroy(ivj_comm* c) {
     }
     for (auto& b : c->stage) if (b) (void)hipFree(b);
     if (c->iota) (void)hipFree(c->iota);
+    if (c->pp_buf) (void)hipFree(c->pp_buf);
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
@@ -382,6 +385,29 @@ int ivj_overlap_allgather_dev(ivj_comm* c, ivj_index* ix, const ivj_side* probe_
     if (capacity < 0 || (capacity > 0 && (!probe_idx_dev || !build_idx_dev))) return fail(IVJ_EINVAL, "bad output buffers");
     DeviceGuard g(c->ctx->device);
     return overlap_allgather(c, ix, probe_dev, opts, n_chunks, probe_idx_dev, build_idx_dev, capacity, n_total, n_local);
+} IVJ_ABI_CATCH
+
+int ivj_count_overlaps_allgather_dev(ivj_comm* c, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t n_total,
+                                     int64_t* counts_dev) try {
+    if (!c || !ix) return fail(IVJ_EINVAL, "comm or index is NULL");
+    if (!c->ctx) return fail(IVJ_ESTATE, "the communicator's context was destroyed");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    if (n_total < 0 || (n_total > 0 && !counts_dev)) return fail(IVJ_EINVAL, "n_total < 0 or counts is NULL");
+    DeviceGuard g(c->ctx->device);
+    return per_probe_allgather(c, ix, probe_dev, opts, IVJ_STREAM_COUNT, n_total, counts_dev, nullptr, nullptr, nullptr);
+} IVJ_ABI_CATCH
+
+int ivj_nearest_allgather_dev(ivj_comm* c, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, int64_t n_total,
+                              int32_t* idx_dev, int64_t* dist_dev, int32_t* n_found_dev) try {
+    if (!c || !ix) return fail(IVJ_EINVAL, "comm or index is NULL");
+    if (!c->ctx) return fail(IVJ_ESTATE, "the communicator's context was destroyed");
+    IVJ_TRY(check_opts(opts));
+    IVJ_TRY(check_side(probe_dev, "probe"));
+    if (opts->nearest_k > 1024) return fail(IVJ_EINVAL, "nearest_k > 1024");
+    if (n_total < 0 || (n_total > 0 && (!idx_dev || !dist_dev || !n_found_dev))) return fail(IVJ_EINVAL, "n_total < 0 or nearest output buffers are NULL");
+    DeviceGuard g(c->ctx->device);
+    return per_probe_allgather(c, ix, probe_dev, opts, IVJ_STREAM_NEAREST, n_total, nullptr, idx_dev, dist_dev, n_found_dev);
 } IVJ_ABI_CATCH
 
 int ivj_overlap_fused_rows_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe_dev, const ivj_opts* opts, const ivj_rows* rows_dev,

@@ -1,0 +1,498 @@
+// ixsort3.hip.h -- index build, round 5: ONE balanced most-significant pass + an LDS-resident sort per bucket that writes the index.
+//
+// The round-2 build (onesweep.hip.h) is three least-significant 11-bit passes over 16-byte records, each a histogram, a look-back scan
+// and a scatter, then k_ix_final: 14 launches and ~0.45 ms for 5 M rows -- a fifth of a config-3 step, all of it latency (every pass
+// walks ~5 sub-tiles per workgroup behind seven barriers).  Here the records cross HBM ONCE between the caller's columns and the index:
+//
+//   k_v3_stats    per-contig min / max of the starts (LDS-privatised), inverted-row flag; the LAST workgroup to finish derives the key
+//                 geometry: the contigs' start ranges laid end to end give a DENSE linear key lin = base[c] + (start - min_c) < span,
+//                 and bucket(lin) = (lin * M) >> 32 with M = floor(2^43 / span) cuts [0, span) into 2048 equal ranges -- for rows
+//                 spread evenly over their contigs every bucket holds n / 2048 rows, whatever the contig lengths (a bit field of the
+//                 (contig, start) key would leave a human genome's 24 contigs in 739 of 2048 buckets)
+//   k_v3_hist     per-(bucket, chunk) histogram
+//   k_scan_lb_u32 its exclusive scan (onesweep.hip.h)
+//   k_v3_scatter  stable scatter of the 16-byte records {start, end, row, contig} into their buckets (the pass kernel of the round-2
+//                 sort with the bucket function above); workgroup 0 also reports the largest bucket
+//   -- 8 bytes to the host: a bucket above V3_CAP rows (clustered build sides) or a span beyond 32 bits hands the build to the
+//      round-2 sort, so exactness never rests on the balance --
+//   k_v3_local    one workgroup per bucket: rows -> LDS, stable LSD radix sort of (bucket-local key, slot) pairs inside LDS (2-3 passes
+//                 of <= 8 bits for ~21 key bits), then the index arrays straight from LDS in sorted order: b_start / (end, prefix max) /
+//                 b_row / b_contig, the prefix max carried across buckets by a decoupled look-back over (contig, end) composites
+//                 (k_ix_final's protocol; buckets are handed out by ticket, so every predecessor is running), segment offsets.
+//
+// Five launches.  Order and content of the index are exactly the round-2 build's: rows sorted by (contig, start) with equal keys in
+// input order (both passes are stable), rows outside the dictionary parked last under contig id n_contigs.
+#pragma once
+#include "onesweep.hip.h"
+
+namespace ivj {
+
+constexpr int V3_BUCKETS = OS_RADIX;                   // 2048: the pass kernel's digit count
+constexpr int V3_ITEMS = 4;
+constexpr int V3_CAP = OS_THREADS * V3_ITEMS;          // rows of one bucket the local kernel holds in LDS
+constexpr int V3_MAX_KEYS = 256;                       // contig keys 0 .. n_contigs (the last one: rows outside the dictionary)
+constexpr int V3_LBITS = 8;                            // digit bits of a local pass, at most
+constexpr int V3_LRADIX = 1 << V3_LBITS;
+
+struct V3Meta {                                        // device-resident, zero-initialised before every build
+    uint32_t inverted;                                 // some row of the dictionary has start > end
+    uint32_t done;                                     // workgroups of k_v3_stats that have published their extremes
+    uint32_t bad;                                      // the linear keys do not fit 32 bits: the host takes the round-2 sort
+    uint32_t max_bucket;                               // rows of the largest bucket (k_v3_scatter)
+    uint32_t ticket;                                   // bucket tickets of k_v3_local
+    uint32_t wbits;                                    // bits of a bucket-local key
+    uint32_t pad[2];
+    unsigned long long M;                              // bucket(lin) = (lin * M) >> 32
+    unsigned long long span;                           // sum of the contigs' start ranges
+    uint32_t cmax[V3_MAX_KEYS];                        // per contig key: max of flip(start)         (both grow from 0:
+    uint32_t cimn[V3_MAX_KEYS];                        //                 max of ~flip(start)          a key has rows iff cmax | cimn != 0)
+    uint32_t base[V3_MAX_KEYS];                        // linear key of the contig's smallest start
+};
+
+__device__ __forceinline__ uint32_t v3_bucket(uint32_t lin, unsigned long long M) { return (uint32_t)(((unsigned long long)lin * M) >> 32); }
+
+__device__ __forceinline__ void v3_load_tables(const V3Meta* __restrict__ meta, int nk, uint32_t* l_base, uint32_t* l_cmin) {
+    for (int k = threadIdx.x; k < nk; k += OS_THREADS) { l_base[k] = meta->base[k]; l_cmin[k] = ~meta->cimn[k]; }
+}
+
+// ---- statistics + key geometry ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OS_THREADS) void k_v3_stats(const int32_t* __restrict__ start, const int32_t* __restrict__ end,
+                                                        const int32_t* __restrict__ contig, int64_t n, int32_t n_contigs, V3Meta* __restrict__ meta) {
+    __shared__ uint32_t l_mx[V3_MAX_KEYS], l_imn[V3_MAX_KEYS];
+    __shared__ unsigned long long l_ws[OS_WAVES];
+    __shared__ uint32_t l_inv;
+    __shared__ int l_last;
+    const int tid = threadIdx.x, nk = n_contigs + 1;
+    for (int k = tid; k < V3_MAX_KEYS; k += OS_THREADS) { l_mx[k] = 0u; l_imn[k] = 0u; }
+    if (tid == 0) l_inv = 0u;
+    __syncthreads();
+    uint32_t inv = 0;
+    for (int64_t i = (int64_t)blockIdx.x * OS_THREADS + tid; i < n; i += (int64_t)gridDim.x * OS_THREADS) {
+        const int32_t s = start[i], c0 = contig[i];
+        const int c = (uint32_t)c0 < (uint32_t)n_contigs ? c0 : n_contigs;
+        const uint32_t u = flip(s);
+        // (an atomic only when it can change the value: after the first few rows of a contig nearly none is issued)
+        if (u > l_mx[c]) atomicMax(&l_mx[c], u);
+        if (~u > l_imn[c]) atomicMax(&l_imn[c], ~u);
+        if (s > end[i] && c < n_contigs) inv = 1u;
+    }
+    if (inv) l_inv = 1u;
+    __syncthreads();
+    for (int k = tid; k < nk; k += OS_THREADS) {
+        const uint32_t a = l_mx[k], b = l_imn[k];
+        if (a > os_ld(&meta->cmax[k])) atomicMax(&meta->cmax[k], a);
+        if (b > os_ld(&meta->cimn[k])) atomicMax(&meta->cimn[k], b);
+    }
+    if (tid == 0 && l_inv && !os_ld(&meta->inverted)) atomicOr(&meta->inverted, 1u);
+    // the last workgroup to get here sees every workgroup's extremes (device-scope fence before the counter) and lays the contigs out
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) l_last = atomicAdd(&meta->done, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!l_last) return;
+    __threadfence();
+    unsigned long long sp = 0;
+    if (tid < nk) {
+        const uint32_t cmx = os_ld(&meta->cmax[tid]), cim = os_ld(&meta->cimn[tid]);
+        if ((cmx | cim) != 0u) sp = (unsigned long long)(cmx - ~cim) + 1ull;
+    }
+    unsigned long long total;
+    const unsigned long long pre = sl_block_exclusive_sum<unsigned long long>(sp, l_ws, &total);
+    if (tid < nk) meta->base[tid] = (uint32_t)pre;                              // (meaningless when bad: nobody reads it then)
+    if (tid == 0) {
+        const bool bad = total == 0ull || total > 0xffffffffull;
+        meta->bad = bad ? 1u : 0u;
+        meta->span = total;
+        const unsigned long long M = bad ? 1ull : (1ull << 43) / total;
+        meta->M = M;
+        const unsigned long long wmax = (1ull << 32) / M;                       // bucket-local keys lie in [0, 2^32 / M]
+        meta->wbits = (uint32_t)os_bits_for(wmax > 0xffffffffull ? 0xffffffffu : (uint32_t)wmax);
+    }
+}
+
+// ---- per-(bucket, chunk) histogram (bucket-major: hist[b * nchunks + g]) ------------------------------------------------------------
+__global__ __launch_bounds__(OS_THREADS) void k_v3_hist(const int32_t* __restrict__ contig, const int32_t* __restrict__ start, int64_t n,
+                                                       int32_t n_contigs, const V3Meta* __restrict__ meta, int chunk, int nchunks,
+                                                       uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[V3_BUCKETS];
+    __shared__ uint32_t l_base[V3_MAX_KEYS], l_cmin[V3_MAX_KEYS];
+    if (meta->bad) return;                                                      // uniform
+    const unsigned long long M = meta->M;
+    v3_load_tables(meta, n_contigs + 1, l_base, l_cmin);
+    for (int k = threadIdx.x; k < V3_BUCKETS; k += OS_THREADS) h[k] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * chunk;
+    const int64_t end = base + chunk < n ? base + chunk : n;
+    for (int64_t i = base + threadIdx.x; i < end; i += OS_THREADS) {
+        const int32_t c0 = contig[i];
+        const int c = (uint32_t)c0 < (uint32_t)n_contigs ? c0 : n_contigs;
+        const uint32_t lin = l_base[c] + (flip(start[i]) - l_cmin[c]);
+        atomicAdd(&h[v3_bucket(lin, M)], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < V3_BUCKETS; k += OS_THREADS) hist[(int64_t)k * nchunks + blockIdx.x] = h[k];
+}
+
+// ---- the one pass over HBM: stable scatter into the buckets (k_os_scatter<true> with the bucket function above) ---------------------
+struct V3PassLds { OsPassLds P; int tbase, tcmin, total; };
+__host__ __device__ inline V3PassLds v3_pass_lds() {
+    V3PassLds L;
+    L.P = os_pass_lds();
+    int o = (L.P.total + 15) & ~15;
+    L.tbase = o; o += 4 * V3_MAX_KEYS;
+    L.tcmin = o; o += 4 * V3_MAX_KEYS;
+    L.total = o;
+    return L;
+}
+
+__global__ __launch_bounds__(OS_THREADS) void k_v3_scatter(const int32_t* __restrict__ contig, const int32_t* __restrict__ start,
+                                                          const int32_t* __restrict__ end, const int32_t* __restrict__ row_id,
+                                                          int4* __restrict__ dst, int64_t n, int32_t n_contigs, V3Meta* __restrict__ meta,
+                                                          int chunk, int nchunks, const uint32_t* __restrict__ off /* exclusive scan of the histogram */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char os_lds[];
+    const V3PassLds LL = v3_pass_lds();
+    const OsPassLds& L = LL.P;
+    int4* l_rec = reinterpret_cast<int4*>(os_lds + L.rec);
+    unsigned short* wcnt = reinterpret_cast<unsigned short*>(os_lds + L.wcnt);
+    unsigned short* l_d = reinterpret_cast<unsigned short*>(os_lds + L.d);
+    uint32_t* base = reinterpret_cast<uint32_t*>(os_lds + L.base);
+    uint32_t* lstart = reinterpret_cast<uint32_t*>(os_lds + L.lstart);
+    uint32_t* wsum = reinterpret_cast<uint32_t*>(os_lds + L.wsum);
+    uint32_t* l_base = reinterpret_cast<uint32_t*>(os_lds + LL.tbase);
+    uint32_t* l_cmin = reinterpret_cast<uint32_t*>(os_lds + LL.tcmin);
+    if (meta->bad) return;                                                      // uniform
+    const unsigned long long M = meta->M;
+    const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+    v3_load_tables(meta, n_contigs + 1, l_base, l_cmin);
+    for (int k = tid; k < OS_RADIX; k += OS_THREADS) base[k] = off[(int64_t)k * nchunks + blockIdx.x];
+    for (int k = tid; k < OS_RADIX * OS_WAVES / 2; k += OS_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
+    if (blockIdx.x == 0) {
+        // rows of the largest bucket: bucket b = [off[b * nchunks], off[(b + 1) * nchunks]) (the histogram is bucket-major)
+        uint32_t mx = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int b = 2 * tid + q;
+            const uint32_t a = off[(int64_t)b * nchunks];
+            const uint32_t z = b + 1 < V3_BUCKETS ? off[(int64_t)(b + 1) * nchunks] : (uint32_t)n;
+            mx = z - a > mx ? z - a : mx;
+        }
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(mx, d, kWave); mx = o > mx ? o : mx; }
+        if (lane == 0) wsum[w] = mx;
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 1; k < OS_WAVES; ++k) mx = wsum[k] > mx ? wsum[k] : mx;
+            meta->max_bucket = mx;
+        }
+    }
+    __syncthreads();
+    const int64_t cbase = (int64_t)blockIdx.x * chunk;
+    const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
+    const uint64_t lt = lanemask_lt();
+    unsigned short* my = wcnt + w * OS_RADIX;
+    const int el0 = w * (OS_ITEMS * kWave) + lane;
+    int4 nxt[OS_ITEMS];
+    auto load_tile = [&](int64_t tb) {
+        const int tn = (int)((cend - tb) < (int64_t)OS_TILE ? (cend - tb) : (int64_t)OS_TILE);
+#pragma unroll
+        for (int j = 0; j < OS_ITEMS; ++j) {
+            const int il = el0 + j * kWave;
+            nxt[j] = il < tn ? os_load_record(true, contig, start, end, row_id, nullptr, tb + il, n_contigs) : make_int4(0, 0, 0, 0);
+        }
+    };
+    if (cbase < cend) load_tile(cbase);
+    for (int64_t tbase = cbase; tbase < cend; tbase += OS_TILE) {
+        const int tile_n = (int)((cend - tbase) < (int64_t)OS_TILE ? (cend - tbase) : (int64_t)OS_TILE);
+        int4 r[OS_ITEMS];
+        uint32_t d[OS_ITEMS], rank[OS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < OS_ITEMS; ++j) {
+            r[j] = nxt[j];
+            d[j] = v3_bucket(l_base[r[j].w] + (flip(r[j].x) - l_cmin[r[j].w]), M);
+        }
+        if (tbase + OS_TILE < cend) load_tile(tbase + OS_TILE);
+#pragma unroll
+        for (int j = 0; j < OS_ITEMS; ++j) {
+            const bool valid = el0 + j * kWave < tile_n;
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < OS_BITS; ++b) {
+                const bool bit = (d[j] >> b) & 1u;
+                const uint64_t m = __ballot(valid && bit);
+                peers &= bit ? m : ~m;
+            }
+            const uint32_t rk = (uint32_t)__popcll(peers & lt);
+            const uint32_t before = valid ? (uint32_t)my[d[j]] : 0u;
+            rank[j] = before + rk;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rk == 0) my[d[j]] = (unsigned short)(before + (uint32_t)__popcll(peers));
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        uint32_t x0 = 0, x1 = 0;
+        {
+            uint32_t* row32 = reinterpret_cast<uint32_t*>(wcnt) + tid;
+#pragma unroll
+            for (int k = 0; k < OS_WAVES; ++k) {
+                const uint32_t v = row32[k * (OS_RADIX / 2)];
+                row32[k * (OS_RADIX / 2)] = x0 | (x1 << 16);
+                x0 += v & 0xffffu; x1 += v >> 16;
+            }
+        }
+        uint32_t tsum;
+        const uint32_t pre = sl_block_exclusive_sum(x0 + x1, wsum, &tsum);
+        lstart[2 * tid] = pre;
+        lstart[2 * tid + 1] = pre + x0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < OS_ITEMS; ++j) {
+            if (el0 + j * kWave < tile_n) {
+                const uint32_t pos = lstart[d[j]] + (uint32_t)my[d[j]] + rank[j];
+                l_rec[pos] = r[j];
+                l_d[pos] = (unsigned short)d[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < OS_ITEMS; ++j) {
+            const int il = j * OS_THREADS + tid;
+            if (il < tile_n) {
+                const uint32_t dd = l_d[il];
+                const int4 rr = l_rec[il];
+                dst[base[dd] + ((uint32_t)il - lstart[dd])] = rr;
+            }
+        }
+        for (int k = tid; k < OS_RADIX * OS_WAVES / 2; k += OS_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
+        __syncthreads();
+        base[2 * tid] += x0;
+        base[2 * tid + 1] += x1;
+        __syncthreads();
+    }
+}
+
+// ---- one workgroup per bucket: LDS sort + index arrays ------------------------------------------------------------------------------
+struct V3LocalLds { int rec, ka, kb, ia, ib, wcnt, dstart, tbase, tcmin, wsum, total; };
+__host__ __device__ inline V3LocalLds v3_local_lds() {
+    V3LocalLds L;
+    int o = 0;
+    L.rec = o; o += 16 * V3_CAP;
+    L.ka = o; o += 4 * V3_CAP;                         // (after the sort: the prefix maxima per sorted position)
+    L.kb = o; o += 4 * V3_CAP;
+    L.ia = o; o += 2 * V3_CAP;
+    L.ib = o; o += 2 * V3_CAP;
+    L.wcnt = o; o += 2 * V3_LRADIX * OS_WAVES;
+    L.dstart = o; o += 4 * V3_LRADIX;
+    L.tbase = o; o += 4 * V3_MAX_KEYS;
+    L.tcmin = o; o += 4 * V3_MAX_KEYS;
+    L.wsum = (o + 15) & ~15; o = L.wsum + 8 * OS_WAVES;
+    L.total = o;
+    return L;
+}
+
+__global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict__ rec, const uint32_t* __restrict__ off, int nchunks, int64_t n,
+                                                        int32_t n_contigs, V3Meta* __restrict__ meta, unsigned long long* __restrict__ status64,
+                                                        int32_t* __restrict__ b_start, int2* __restrict__ ep, int32_t* __restrict__ b_row,
+                                                        int32_t* __restrict__ b_contig, int32_t* __restrict__ seg, int32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char os_lds[];
+    const V3LocalLds L = v3_local_lds();
+    int4* l_rec = reinterpret_cast<int4*>(os_lds + L.rec);
+    uint32_t* l_k[2] = {reinterpret_cast<uint32_t*>(os_lds + L.ka), reinterpret_cast<uint32_t*>(os_lds + L.kb)};
+    unsigned short* l_i[2] = {reinterpret_cast<unsigned short*>(os_lds + L.ia), reinterpret_cast<unsigned short*>(os_lds + L.ib)};
+    unsigned short* wcnt = reinterpret_cast<unsigned short*>(os_lds + L.wcnt);
+    uint32_t* dstart = reinterpret_cast<uint32_t*>(os_lds + L.dstart);
+    uint32_t* l_base = reinterpret_cast<uint32_t*>(os_lds + L.tbase);
+    uint32_t* l_cmin = reinterpret_cast<uint32_t*>(os_lds + L.tcmin);
+    unsigned long long* wmax = reinterpret_cast<unsigned long long*>(os_lds + L.wsum);
+    uint32_t* wsum = reinterpret_cast<uint32_t*>(wmax);
+    uint32_t* l_pm = l_k[0];
+    __shared__ int l_tile;
+    __shared__ uint32_t l_lo;
+    __shared__ unsigned long long s_carry;
+    const int tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
+    if (tid == 0) {
+        const int t = (int)atomicAdd(&meta->ticket, 1u);
+        l_tile = t;
+        const unsigned long long M = meta->M;
+        l_lo = (uint32_t)((((unsigned long long)t << 32) + M - 1ull) / M);      // smallest linear key of bucket t
+    }
+    v3_load_tables(meta, n_contigs + 1, l_base, l_cmin);
+    for (int k = tid; k < V3_LRADIX * OS_WAVES / 2; k += OS_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
+    __syncthreads();
+    const int tile = l_tile;
+    const uint32_t lo = l_lo;
+    const uint32_t b0 = off[(int64_t)tile * nchunks];
+    const uint32_t b1 = tile + 1 < V3_BUCKETS ? off[(int64_t)(tile + 1) * nchunks] : (uint32_t)n;
+    const int nb = (int)(b1 - b0);                                              // <= V3_CAP: checked by the host before this launch
+    const int wbits = (int)meta->wbits;
+    const int P = (wbits + V3_LBITS - 1) / V3_LBITS;                            // >= 1
+    const int bits = (wbits + P - 1) / P;
+    const uint32_t dmask = (1u << bits) - 1u;
+    const int ndig = 1 << bits;
+
+    // rows of the bucket -> LDS (slot p = input order inside the bucket); wavefront w owns the slots [w * 256, (w + 1) * 256)
+    uint32_t kv[V3_ITEMS], iv[V3_ITEMS];
+#pragma unroll
+    for (int j = 0; j < V3_ITEMS; ++j) {
+        const int p = w * (V3_ITEMS * kWave) + j * kWave + lane;
+        kv[j] = 0u; iv[j] = (uint32_t)p;
+        if (p < nb) {
+            const int4 r = rec[(int64_t)b0 + p];
+            l_rec[p] = r;
+            kv[j] = l_base[r.w] + (flip(r.x) - l_cmin[r.w]) - lo;
+        }
+    }
+    const uint64_t lt = lanemask_lt();
+    unsigned short* my = wcnt + w * V3_LRADIX;
+    const int npass = nb > 0 ? P : 0;                                           // (uniform) an empty bucket only takes part in the look-back
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = pass * bits;
+        uint32_t* kd = l_k[pass & 1];
+        unsigned short* id = l_i[pass & 1];
+        if (pass > 0) {
+            const uint32_t* ks = l_k[(pass - 1) & 1];
+            const unsigned short* is = l_i[(pass - 1) & 1];
+#pragma unroll
+            for (int j = 0; j < V3_ITEMS; ++j) {
+                const int p = w * (V3_ITEMS * kWave) + j * kWave + lane;
+                if (p < nb) { kv[j] = ks[p]; iv[j] = is[p]; }
+            }
+        }
+        uint32_t dg[V3_ITEMS], rank[V3_ITEMS];
+#pragma unroll
+        for (int j = 0; j < V3_ITEMS; ++j) {
+            const int p = w * (V3_ITEMS * kWave) + j * kWave + lane;
+            const bool valid = p < nb;
+            dg[j] = (kv[j] >> shift) & dmask;
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < V3_LBITS; ++b) {
+                if (b < bits) {                                                 // uniform
+                    const bool bit = (dg[j] >> b) & 1u;
+                    const uint64_t m = __ballot(valid && bit);
+                    peers &= bit ? m : ~m;
+                }
+            }
+            const uint32_t rk = (uint32_t)__popcll(peers & lt);
+            const uint32_t before = valid ? (uint32_t)my[dg[j]] : 0u;
+            rank[j] = before + rk;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rk == 0) my[dg[j]] = (unsigned short)(before + (uint32_t)__popcll(peers));
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // thread t < ndig owns digit t: exclusive prefix over the wavefronts, then over the digits
+        uint32_t tot = 0;
+        if (tid < ndig) {
+#pragma unroll
+            for (int k = 0; k < OS_WAVES; ++k) {
+                const uint32_t v = wcnt[k * V3_LRADIX + tid];
+                wcnt[k * V3_LRADIX + tid] = (unsigned short)tot;
+                tot += v;
+            }
+        }
+        uint32_t tsum;
+        const uint32_t pre = sl_block_exclusive_sum<uint32_t>(tot, wsum, &tsum);
+        if (tid < ndig) dstart[tid] = pre;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < V3_ITEMS; ++j) {
+            const int p = w * (V3_ITEMS * kWave) + j * kWave + lane;
+            if (p < nb) {
+                const uint32_t dpos = dstart[dg[j]] + (uint32_t)my[dg[j]] + rank[j];
+                kd[dpos] = kv[j];
+                id[dpos] = (unsigned short)iv[j];
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < V3_LRADIX * OS_WAVES / 2; k += OS_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
+        __syncthreads();
+    }
+    const unsigned short* iF = l_i[(P - 1) & 1];                                 // slot of the row at sorted position q
+
+    // prefix max of (contig, end) in sorted order: thread t holds the positions 4 t .. 4 t + 3
+    unsigned long long comp[V3_ITEMS];
+    int32_t cc[V3_ITEMS];
+    unsigned long long run = 0;
+#pragma unroll
+    for (int k = 0; k < V3_ITEMS; ++k) {
+        const int q = V3_ITEMS * tid + k;
+        unsigned long long c = 0ull;
+        cc[k] = 0;
+        if (q < nb) {
+            const int4 r = l_rec[iF[q]];
+            c = ((unsigned long long)(uint32_t)r.w << 32) | (unsigned long long)flip(r.y);
+            cc[k] = r.w;
+        }
+        run = c > run ? c : run;
+        comp[k] = run;
+    }
+    int32_t prev_c = -1;
+    if (tid > 0 && V3_ITEMS * tid < nb) prev_c = l_rec[iF[V3_ITEMS * tid - 1]].w;
+    unsigned long long inc = run;
+#pragma unroll
+    for (int dd = 1; dd < kWave; dd <<= 1) {
+        const unsigned long long o = __shfl_up(inc, dd, kWave);
+        if (lane >= dd) inc = o > inc ? o : inc;
+    }
+    __syncthreads();                                                            // (wsum / wmax: the last pass's scan has been read by everyone)
+    if (lane == kWave - 1) wmax[w] = inc;
+    __syncthreads();
+    unsigned long long wpre = 0, tmax = 0;
+#pragma unroll
+    for (int k = 0; k < OS_WAVES; ++k) { const unsigned long long x = wmax[k]; if (k < w) wpre = x > wpre ? x : wpre; tmax = x > tmax ? x : tmax; }
+    unsigned long long excl = __shfl_up(inc, 1, kWave);
+    if (lane == 0) excl = 0;
+    excl = wpre > excl ? wpre : excl;
+    if (tid == 0) {
+        const unsigned long long VAL = (1ull << 62) - 1ull;
+        unsigned long long carry = 0;
+        if (tile == 0) os_st64(status64, (2ull << 62) | tmax);
+        else {
+            os_st64(status64 + tile, (1ull << 62) | tmax);
+            for (int t = tile - 1; t >= 0; --t) {
+                unsigned long long v = os_ld64(status64 + t);
+                while ((v >> 62) == 0) { __builtin_amdgcn_s_sleep(2); v = os_ld64(status64 + t); }
+                const unsigned long long x = v & VAL;
+                carry = x > carry ? x : carry;
+                if ((v >> 62) == 2ull) break;
+            }
+            os_st64(status64 + tile, (2ull << 62) | (carry > tmax ? carry : tmax));
+        }
+        s_carry = carry;
+        if (tile == 0) flags[0] = (int32_t)meta->inverted;
+    }
+    __syncthreads();
+    const unsigned long long before = s_carry > excl ? s_carry : excl;
+    // the row before this bucket's first one carries the largest contig key so far: the high word of the carried composite
+    if (tid == 0) prev_c = b0 == 0u ? -1 : (int32_t)(s_carry >> 32);
+#pragma unroll
+    for (int k = 0; k < V3_ITEMS; ++k) {
+        const int q = V3_ITEMS * tid + k;
+        if (q < nb) {
+            const unsigned long long pm = before > comp[k] ? before : comp[k];
+            l_pm[q] = (uint32_t)pm;
+            // segment offsets: seg[key] = first position whose contig key is >= key (keys 0 .. n_contigs; n_contigs + 1 = n)
+            const int64_t p = (int64_t)b0 + q;
+            for (int32_t kk = prev_c + 1; kk <= cc[k]; ++kk) seg[kk] = (int32_t)p;
+            prev_c = cc[k];
+            if (p == n - 1) for (int32_t kk = cc[k] + 1; kk <= n_contigs + 1; ++kk) seg[kk] = (int32_t)n;
+        }
+    }
+    __syncthreads();
+    // index arrays, coalesced: position q = j * 1024 + tid
+#pragma unroll
+    for (int j = 0; j < V3_ITEMS; ++j) {
+        const int q = j * OS_THREADS + tid;
+        if (q < nb) {
+            const int4 r = l_rec[iF[q]];
+            const int64_t g = (int64_t)b0 + q;
+            b_start[g] = r.x;
+            ep[g] = make_int2(r.y, unflip(l_pm[q]));
+            b_row[g] = r.z;
+            b_contig[g] = r.w;
+        }
+    }
+}
+
+}  // namespace ivj

@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "ivj_dev_alloc", "ivj_dev_free", "ivj_memcpy_h2d", "ivj_memcpy_d2h",
     "ivj_comm_unique_id", "ivj_comm_create", "ivj_comm_create_local", "ivj_comm_destroy", "ivj_comm_info",
     "ivj_allgather_counts", "ivj_allgatherv_dev", "ivj_overlap_allgather_dev",
+    "ivj_count_overlaps_allgather_dev", "ivj_nearest_allgather_dev",
     "ivj_overlap_arrow_stream", "ivj_count_overlaps_arrow_stream", "ivj_nearest_arrow_stream", "ivj_arrow_encode_keys", "ivj_arrow_keys_free",
     "ivj_arrow_take_stream",
     "ivj_host_shard", "ivj_host_contig_hist",
@@ -204,6 +205,8 @@ def load_library() -> C.CDLL:
         L.ivj_allgather_counts.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64)]
         L.ivj_allgatherv_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_int64)]
         L.ivj_overlap_allgather_dev.argtypes = [vp, vp, P, O, C.c_int, vp, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.ivj_count_overlaps_allgather_dev.argtypes = [vp, vp, P, O, C.c_int64, vp]
+        L.ivj_nearest_allgather_dev.argtypes = [vp, vp, P, O, C.c_int64, vp, vp, vp]
         L.ivj_host_narrow_i32.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
         L.ivj_host_encode_utf8.argtypes = [vp, C.c_int32, vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
         L.ivj_host_encode_keys64.argtypes = [vp, C.c_int64, vp, vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
@@ -857,6 +860,20 @@ class Comm:
             return nt.value, nl.value, False
         _check(self.L, rc, "ivj_overlap_allgather_dev")
         return nt.value, nl.value, True
+
+    def count_overlaps_allgather_dev(self, ix: "DeviceIndex", probe: _Side, opts: _Opts, n_total: int, counts_ptr: int):
+        """count_overlaps of this rank's shard (probe.row_id = global rows) + the exchange of the per-probe results: the int64
+        column counts_ptr[n_total] holds every probe row's count, in global probe order, on every rank."""
+        with self.engine.lock:
+            _check(self.L, self.L.ivj_count_overlaps_allgather_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), int(n_total), C.c_void_p(counts_ptr)),
+                   "ivj_count_overlaps_allgather_dev")
+
+    def nearest_allgather_dev(self, ix: "DeviceIndex", probe: _Side, opts: _Opts, n_total: int, idx_ptr: int, dist_ptr: int, nf_ptr: int):
+        """nearest of this rank's shard + the exchange: idx_ptr[n_total * k] (int32), dist_ptr[n_total * k] (int64),
+        nf_ptr[n_total] (int32) in global probe order on every rank."""
+        with self.engine.lock:
+            _check(self.L, self.L.ivj_nearest_allgather_dev(self.h, ix.handle, C.byref(probe), C.byref(opts), int(n_total), C.c_void_p(idx_ptr),
+                                                            C.c_void_p(dist_ptr), C.c_void_p(nf_ptr)), "ivj_nearest_allgather_dev")
 
 
 # ---- the one-call Arrow entry (include/ivjoin.h: ivj_*_arrow_stream): what a C / Rust host binds, driven from Python -------------

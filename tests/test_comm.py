@@ -299,3 +299,119 @@ def test_two_processes_over_the_library_communicator(tmp_path):
     a, b = np.load(tmp_path / "out0.npz"), np.load(tmp_path / "out1.npz")
     assert int(a["ok"]) == 1 and int(b["ok"]) == 1
     assert (a["p"] == b["p"]).all() and (a["b"] == b["b"]).all()
+
+
+# ---- per-probe exchange (round 5): count_overlaps / nearest of the shards, every rank gets the full-length columns in probe order ----
+def _local_group(world):
+    """`world` contexts on device 0 over the library's in-process transport."""
+    engines = [_engine.Engine(0) for _ in range(world)]
+    return engines, (_engine.Comm.create_local(engines) if world > 1 else [_engine.Comm(engines[0], None, 0, 1)])
+
+
+def _pp_job(eng, comm, probe, build, nc, rank, world, op, k, out):
+    try:
+        (lp, pid, lb, bid, _mode) = D.shard_sides(probe, build, nc, rank, world)
+        d = _Dev(eng, lp, lb, pid)
+        try:
+            bptr = d.alloc(4 * len(bid)); eng.h2d(bptr, bid)
+            bside = eng.dev_side(d.build.contig, d.build.start, d.build.end, len(bid), bptr)
+            opts = _engine.make_opts(True, nc, k=k)
+            ix = eng.index_build_dev(bside, opts)
+            n_total = len(probe[0])
+            if op == "count":
+                cp = d.alloc(8 * n_total)
+                comm.count_overlaps_allgather_dev(ix, d.probe, opts, n_total, cp)
+                h = np.empty(n_total, np.int64); eng.d2h(h, cp)
+                out[rank] = (h,)
+            else:
+                ip, dp, fp = d.alloc(4 * n_total * k), d.alloc(8 * n_total * k), d.alloc(4 * n_total)
+                comm.nearest_allgather_dev(ix, d.probe, opts, n_total, ip, dp, fp)
+                hi, hd, hf = np.empty(n_total * k, np.int32), np.empty(n_total * k, np.int64), np.empty(n_total, np.int32)
+                eng.d2h(hi, ip); eng.d2h(hd, dp); eng.d2h(hf, fp)
+                out[rank] = (hi, hd, hf)
+            ix.close()
+        finally:
+            d.close()
+    except _engine.EngineError as e:
+        out[rank] = e
+
+
+def _pp_inputs(seed, nc=6, n_probe=150_000, n_build=40_000):
+    rng = np.random.default_rng(seed)
+    probe = random_side(rng, n_probe, nc + 1, 2_000_000, 400)      # contig id nc: outside the dictionary (no rank owns those rows)
+    build = random_side(rng, n_build, nc, 2_000_000, 400)
+    return probe, build, nc
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_count_overlaps_allgather_over_the_loopback_transport(world):
+    """ivj_count_overlaps_allgather_dev: every rank ends up with the int64 count of EVERY probe row at its global row."""
+    probe, build, nc = _pp_inputs(21)
+    exp = O.count_overlaps_fast(O.Index(O.Side(*build), nc), O.Side(*probe), True)
+    engines, comms = _local_group(world)
+    out = {}
+    _run_ranks(_pp_job, [(engines[r], comms[r], probe, build, nc, r, world, "count", 1, out) for r in range(world)])
+    assert sorted(out) == list(range(world))
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        assert (out[r][0] == exp).all(), r
+    for c in comms: c.close()
+    for e in engines: e.close()
+
+
+@pytest.mark.parametrize("world,k", [(1, 1), (2, 1), (2, 3), (8, 1)])
+def test_nearest_allgather_over_the_loopback_transport(world, k):
+    probe, build, nc = _pp_inputs(22)
+    ei, ed, en = O.nearest_fast(O.Index(O.Side(*build), nc), O.Side(*probe), True, k, True)
+    engines, comms = _local_group(world)
+    out = {}
+    _run_ranks(_pp_job, [(engines[r], comms[r], probe, build, nc, r, world, "nearest", k, out) for r in range(world)])
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        hi, hd, hf = out[r]
+        assert (hf == np.asarray(en).ravel()).all() and (hd == np.asarray(ed).ravel()).all() and (hi == np.asarray(ei).ravel()).all(), r
+    for c in comms: c.close()
+    for e in engines: e.close()
+
+
+def test_per_probe_allgather_failed_rank_strands_nobody(monkeypatch):
+    """Rank 1's shard fails: it still reaches the count all-gather (failure mark), returns its own error, rank 0 returns IVJ_EPEER,
+    nothing is exchanged, and the communicators serve the next call."""
+    probe, build, nc = _pp_inputs(23)
+    exp = O.count_overlaps_fast(O.Index(O.Side(*build), nc), O.Side(*probe), True)
+    engines, comms = _local_group(2)
+    monkeypatch.setenv("IVJ_FAULT_ALLGATHER", "1:0")
+    monkeypatch.setenv("IVJ_COMM_LOOPBACK_TIMEOUT", "30")
+    out = {}
+    _run_ranks(_pp_job, [(engines[r], comms[r], probe, build, nc, r, 2, "count", 1, out) for r in range(2)])
+    assert isinstance(out[1], _engine.EngineError) and "injected fault" in str(out[1]) and not isinstance(out[1], _engine.PeerError)
+    assert isinstance(out[0], _engine.PeerError) and "rank 1 failed" in str(out[0])
+    monkeypatch.delenv("IVJ_FAULT_ALLGATHER")
+    out = {}
+    _run_ranks(_pp_job, [(engines[r], comms[r], probe, build, nc, r, 2, "count", 1, out) for r in range(2)])
+    for r in range(2):
+        assert (out[r][0] == exp).all()
+    for c in comms: c.close()
+    for e in engines: e.close()
+
+
+def test_per_probe_allgather_rejects_rows_outside_n_total():
+    """A shard whose global rows do not fit n_total: IVJ_EINVAL (world 1: the scatter kernel's range check)."""
+    eng = _engine.Engine(0)
+    comm = _engine.Comm(eng, None, 0, 1)
+    rng = np.random.default_rng(3)
+    probe = random_side(rng, 1000, 2, 50000, 100)
+    build = random_side(rng, 500, 2, 50000, 100)
+    ids = np.arange(1000, dtype=np.int32) + 5
+    d = _Dev(eng, probe, build, ids)
+    try:
+        opts = _engine.make_opts(True, 2)
+        ix = eng.index_build_dev(d.build, opts)
+        cp = d.alloc(8 * 1004)
+        with pytest.raises(_engine.EngineError, match="outside"):
+            comm.count_overlaps_allgather_dev(ix, d.probe, opts, 1004, cp)
+        ix.close()
+    finally:
+        d.close()
+    comm.close()
+    eng.close()

@@ -305,3 +305,22 @@ def test_far_chain_down_a_7M_row_contig(eng):
             p, b = eng.overlap(probe, build, True, 1, partition_mode=pm)
         o = np.lexsort((b, p))
         assert len(p) == len(ep) and (p[o] == ep[oe]).all() and (b[o] == eb[oe]).all(), (pm, fused)
+
+
+@pytest.mark.parametrize("workload", ["overlap_100M_5M_24contig", "count_200M_200k_24contig"])
+def test_eight_ranks_on_one_gpu_dry_run_at_full_size(workload):
+    """The N = 8 code path at the stated sizes before any 8-GPU node exists (round 5): eight contexts on GPU 0, one host thread per
+    rank, the library's in-process transport -- LPT over 24 contigs onto 8 ranks, shard-only generation, 4 chunks x 8 ranks of
+    collectives per overlap step incl. one capacity regrow, the per-probe exchange of count_overlaps; every rank must end up with the
+    identical, cross-checked result (tools/dryrun_ranks.py).  Oversubscribed: the timing is not a scaling number."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dryrun_ranks import dry_run
+    line = dry_run(workload, world=8, scale=1.0, steps=1)
+    assert line["world"] == 8 and len(line["shards"]) == 8 and all(s["probe_rows"] > 0 and s["build_rows"] > 0 for s in line["shards"])
+    assert sum(s["probe_rows"] for s in line["shards"]) == (100_000_000 if workload.startswith("overlap") else 200_000_000)
+    if workload.startswith("overlap"):
+        exp = synth.expected_pairs(100_000_000, 5_000_000, 24)
+        assert abs(line["units"] / exp - 1) < 0.01, (line["units"], exp)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"dryrun8_{workload}.json"), "w") as f:
+        json.dump(line, f)

@@ -1194,6 +1194,9 @@ def test_nearest_lines_edge_shapes(strict):
     one = (np.zeros(1, np.int32), np.array([1000], np.int32), np.array([1010], np.int32))
     cases.append((random_side(rng, 513, 1, 3000, 50), one, 1))
     cases.append((random_side(rng, 1, 2, 3000, 50), random_side(rng, 1025, 2, 3000, 50), 2))
+    # a last tile whose upper wavefronts lie wholly beyond the probes, with the mask words reaching into scratch the index sort left
+    # full of records (round-4 advisor finding: those wavefronts' words were read without ever being written)
+    cases.append((random_side(rng, 512 * 2000 + 65, 2, 300000, 50), random_side(rng, 1025, 2, 300000, 50), 2))
     e_ = _engine.Engine(0)
     try:
         e_.enable_timing(2)
@@ -1243,3 +1246,83 @@ def test_sampled_partition_on_skewed_and_sorted_probes(shape, monkeypatch):
         assert (p == ep).all() and (b == eb).all()
     finally:
         e_.close()
+
+
+def _v3_cases():
+    rng = np.random.default_rng(515)
+    I32 = np.iinfo(np.int32)
+    cases = []
+    # (name, probe, build, n_contigs, expects the balanced build)
+    cases.append(("ragged multi-contig", random_side(rng, 9000, 6, 400_000, 600), random_side(rng, 12289, 5, 400_000, 600), 5, True))
+    cases.append(("one row", random_side(rng, 300, 2, 5000, 50), (np.zeros(1, np.int32), np.array([1000], np.int32), np.array([1200], np.int32)), 1, True))
+    b = random_side(rng, 70_000, 24, 3_000_000, 2000)
+    b[0][:40] = 30                                                             # rows outside the dictionary: parked last
+    cases.append(("70 k rows, 24 contigs, rows outside the dictionary", random_side(rng, 50_000, 25, 3_000_000, 150), b, 24, True))
+    s = rng.integers(-2000, 2000, 6000).astype(np.int32)
+    e = (s + rng.integers(0, 60, 6000)).astype(np.int32)
+    s[:3000] = 7; e[:3000] = 9                                                 # 3000 equal keys: the order of equal keys is the input order (stability of both passes)
+    ps = rng.integers(-2100, 2100, 4000).astype(np.int32)
+    cases.append(("negative starts, 3000 equal keys", (np.zeros(4000, np.int32), ps, (ps + rng.integers(0, 60, 4000)).astype(np.int32)),
+                  (np.zeros(6000, np.int32), s, e), 1, True))
+    s = np.full(20_000, 123_456, np.int32)
+    s[:5] = [I32.min, I32.min + 1, 0, I32.max - 1, I32.max - 60]               # the extremes of int32 on one contig, 19 995 equal starts in one bucket
+    e = np.minimum(s.astype(np.int64) + 50, I32.max).astype(np.int32)
+    ps = rng.integers(123_000, 124_000, 3000).astype(np.int32)
+    cases.append(("one bucket above the LDS capacity -> the LSD sort", (np.zeros(3000, np.int32), ps, ps + 40), (np.zeros(20_000, np.int32), s, e), 1, False))
+    # two contigs that both span nearly the whole int32 range: the linear keys need 33 bits -> the LSD sort
+    bs = np.concatenate([rng.integers(I32.min, I32.max - 100, 5000), rng.integers(I32.min, I32.max - 100, 5000)]).astype(np.int32)
+    bs[0], bs[1], bs[5000], bs[5001] = I32.min, I32.max - 100, I32.min, I32.max - 100
+    bc = np.repeat(np.arange(2, dtype=np.int32), 5000)
+    pq = rng.integers(I32.min, I32.max - 100, 3000).astype(np.int32)
+    cases.append(("linear keys beyond 32 bits -> the LSD sort", (rng.integers(0, 2, 3000).astype(np.int32), pq, (pq.astype(np.int64) + 90).astype(np.int32)),
+                  (bc, bs, (bs.astype(np.int64) + rng.integers(0, 100, 10_000)).astype(np.int32)), 2, False))
+    return cases
+
+
+def test_balanced_index_build_matches_the_lsd_build(monkeypatch):
+    """Round 5: the index built by ONE balanced bucket pass + an LDS sort per bucket (ixsort3.hip.h) is the index the three-pass LSD
+    sort builds -- same order (equal keys in input order), same prefix maxima, same segment offsets -- on shapes that stress it:
+    ragged sizes, a single row, rows outside the dictionary, negative starts with thousands of equal keys, and the two hand-overs to
+    the LSD sort (a bucket above the LDS capacity; linear keys beyond 32 bits).  Checked through every operation against the oracle,
+    with the balanced build forced for sizes the auto rule would leave to the LSD sort."""
+    monkeypatch.setenv("IVJ_IX_V3", "1")
+    e3 = _engine.Engine(0)
+    try:
+        e3.enable_timing(2)
+        for name, probe, build, nc, balanced in _v3_cases():
+            for strict in (True, False):
+                ps, bs = O.Side(*probe), O.Side(*build)
+                ix = O.Index(bs, nc)
+                ep, eb = O.overlap_fast(ix, ps, strict)
+                e3.timings()                                                    # (reading the timings clears them)
+                p, b = e3.overlap(probe, build, strict, nc, partition_mode=2)      # probe-row order: the order of equal keys shows
+                t = e3.timings()
+                assert ("ix3_local" in t) == balanced and ("ix_final" in t) != balanced, (name, sorted(t))
+                assert len(p) == len(ep) and (p == ep).all() and (b == eb).all(), name
+                p, b = _canon(*e3.overlap(probe, build, strict, nc, partition_mode=6))
+                assert len(p) == len(ep) and (p == ep).all() and (b == eb).all(), (name, "slices")
+                assert (e3.count_overlaps(probe, build, strict, nc) == O.count_overlaps_fast(ix, ps, strict)).all(), name
+                for k, inc, tm in ((1, True, 0), (1, True, 3), (3, False, 0)):
+                    ei, ed, en = O.nearest_fast(ix, ps, strict, k, inc)
+                    i, d, n = e3.nearest(probe, build, strict, nc, k, inc, table_mode=tm)
+                    assert (n == en).all() and (d == ed).all() and (i == ei).all(), (name, k, inc, tm)
+    finally:
+        e3.close()
+
+
+def test_balanced_index_build_is_the_default_at_bench_sizes():
+    """1 M build rows on one contig / 2 M on 24: the auto rule takes the balanced build (timings name its kernels), exact pairs."""
+    e = _engine.Engine(0)
+    try:
+        e.enable_timing(2)
+        for n_b, n_p, nc in ((1_000_000, 300_000, 1), (2_000_000, 400_000, 24)):
+            probe = synth.make_side(n_p, 42, synth.PROBE_LEN, nc)
+            build = synth.make_side(n_b, 43, synth.BUILD_LEN, nc)
+            ep, eb = O.overlap_fast(O.Index(O.Side(*build), nc), O.Side(*probe), True)
+            e.timings()
+            p, b = _canon(*e.overlap(probe, build, True, nc))
+            t = e.timings()
+            assert "ix3_local" in t and "ix_final" not in t, sorted(t)
+            assert len(p) == len(ep) and (p == ep).all() and (b == eb).all()
+    finally:
+        e.close()
