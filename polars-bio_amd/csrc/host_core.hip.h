@@ -96,6 +96,7 @@ struct ivj_ctx {
     uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
     bool part_attr_set = false;
     bool os_attr_set = false;
+    hipEvent_t ix3_event = nullptr;    // marks the read-back of the balanced build's {bad, largest bucket}
     bool ix3_attr_set = false;         // index build, round 5 (ixsort3.hip.h): LDS attributes set once
     int env_ix_v3 = -1;                // IVJ_IX_V3: -1 by size, 0 never (the round-2 LSD sort), 1 wherever it applies
     int64_t ix3_fallbacks = 0;         // builds the balanced pass handed back to the LSD sort (a bucket above V3_CAP rows, keys beyond 32 bits)

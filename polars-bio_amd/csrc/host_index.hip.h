@@ -260,7 +260,7 @@ int index_sort_v2(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
 
 // round-5 build (ixsort3.hip.h): per-contig extremes -> ONE balanced bucket pass over HBM -> LDS sort per bucket that writes the
 // index arrays.  *done = false hands the build to index_sort_v2 -- more contig keys than the LDS tables hold, linear keys beyond
-// 32 bits, or a bucket above V3_CAP rows (clustered build sides): known from 8 bytes read back after the bucket pass, so exactness
+// 32 bits, or a bucket above V3_CAP rows (clustered build sides): known from 8 bytes read back while the bucket pass runs, so exactness
 // never rests on the balance.  Auto: 128 k .. 7 M rows (below, the launches are the cost either way; above, 2048 buckets of V3_CAP
 // rows cannot hold the rows); IVJ_IX_V3 = 0 / 1 forces the choice (A/B runs, tests).
 bool ix3_wanted(const ivj_ctx* ctx, int64_t n, int nc) {
@@ -299,16 +299,21 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     }
     const unsigned sgrid = (unsigned)(tiles < 512 ? tiles : 512);
     LAUNCH(ctx, "ix3_stats", k_v3_stats, sgrid, OS_THREADS, build->start, build->end, build->contig, n, nc, meta);
-    LAUNCH(ctx, "ix3_hist", k_v3_hist, nchunks, OS_THREADS, build->contig, build->start, n, nc, (const V3Meta*)meta, (int)chunk, nchunks, hist);
+    LAUNCH(ctx, "ix3_hist", k_v3_hist, nchunks, OS_THREADS, build->contig, build->start, n, nc, meta, (int)chunk, nchunks, hist);
     LAUNCH(ctx, "ix_scan", (k_scan_lb_u32<SumOp, true>), hs_tiles, OS_THREADS, hist, hist_len, 0u, tick_scan, st_scan);
+    LAUNCH(ctx, "ix3_check", k_v3_check, 1, OS_THREADS, (const uint32_t*)hist, nchunks, n, meta);
+    // {bad, max_bucket} (adjacent in V3Meta) travel to the host WHILE the bucket pass runs: the copy is queued in front of the pass,
+    // the host waits for the copy's event only -- by the time it knows, the pass is still running and the local kernel is queued
+    // behind it without a bubble.  (A build that falls back has run the pass for nothing: rare, and exactness does not depend on it.)
+    HIP_TRY(hipMemcpyAsync(ctx->h_total + 6, &meta->bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->ix3_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ix3_event, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->ix3_event, ctx->stream));
     t_begin(ctx, "ix3_pass");
     hipLaunchKernelGGL(k_v3_scatter, dim3((unsigned)nchunks), dim3(OS_THREADS), pass_lds, ctx->stream, build->contig, build->start, build->end, build->row_id,
                        recs, n, nc, meta, (int)chunk, nchunks, (const uint32_t*)hist);
     t_end(ctx);
     HIP_TRY(hipGetLastError());
-    // {bad, max_bucket}: adjacent in V3Meta
-    HIP_TRY(hipMemcpyAsync(ctx->h_total + 6, &meta->bad, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ix3_event));
     const uint32_t* hv = reinterpret_cast<const uint32_t*>(ctx->h_total + 6);
     if (hv[0] != 0u || hv[1] > (uint32_t)V3_CAP) { ++ctx->ix3_fallbacks; return IVJ_OK; }
     t_begin(ctx, "ix3_local");

@@ -119,6 +119,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     for (auto& cb : ctx->st_cache) free_stream_bufs(cb);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
     if (ctx->nl_cache) (void)hipFree(ctx->nl_cache);
+    if (ctx->ix3_event) (void)hipEventDestroy(ctx->ix3_event);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
     ctx->xfer.release();
     for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);

@@ -4,24 +4,27 @@
 // and a scatter, then k_ix_final: 14 launches and ~0.45 ms for 5 M rows -- a fifth of a config-3 step, all of it latency (every pass
 // walks ~5 sub-tiles per workgroup behind seven barriers).  Here the records cross HBM ONCE between the caller's columns and the index:
 //
-//   k_v3_stats    per-contig min / max of the starts (LDS-privatised), inverted-row flag; the LAST workgroup to finish derives the key
-//                 geometry: the contigs' start ranges laid end to end give a DENSE linear key lin = base[c] + (start - min_c) < span,
-//                 and bucket(lin) = (lin * M) >> 32 with M = floor(2^43 / span) cuts [0, span) into 2048 equal ranges -- for rows
-//                 spread evenly over their contigs every bucket holds n / 2048 rows, whatever the contig lengths (a bit field of the
-//                 (contig, start) key would leave a human genome's 24 contigs in 739 of 2048 buckets)
-//   k_v3_hist     per-(bucket, chunk) histogram
+//   k_v3_stats    per-contig min / max of the starts (LDS-privatised), inverted-row flag
+//   k_v3_hist     key geometry (every workgroup derives it from the extremes, workgroup 0 records it): the contigs' start ranges laid
+//                 end to end give a DENSE linear key lin = base[c] + (start - min_c) < span, and bucket(lin) = (lin * M) >> 32 with
+//                 M = floor(2^43 / span) cuts [0, span) into 2048 equal ranges -- for rows spread evenly over their contigs every bucket
+//                 holds n / 2048 rows, whatever the contig lengths (a bit field of the (contig, start) key would leave a human genome's
+//                 24 contigs in 739 of 2048 buckets); then the per-(bucket, chunk) histogram
 //   k_scan_lb_u32 its exclusive scan (onesweep.hip.h)
+//   k_v3_check    rows of the largest bucket (one workgroup)
+//   -- 8 bytes to the host, read while the next kernel runs: a bucket above V3_CAP rows (clustered build sides) or a span beyond
+//      32 bits hands the build to the round-2 sort, so exactness never rests on the balance --
 //   k_v3_scatter  stable scatter of the 16-byte records {start, end, row, contig} into their buckets (the pass kernel of the round-2
-//                 sort with the bucket function above); workgroup 0 also reports the largest bucket
-//   -- 8 bytes to the host: a bucket above V3_CAP rows (clustered build sides) or a span beyond 32 bits hands the build to the
-//      round-2 sort, so exactness never rests on the balance --
-//   k_v3_local    one workgroup per bucket: rows -> LDS, stable LSD radix sort of (bucket-local key, slot) pairs inside LDS (2-3 passes
-//                 of <= 8 bits for ~21 key bits), then the index arrays straight from LDS in sorted order: b_start / (end, prefix max) /
-//                 b_row / b_contig, the prefix max carried across buckets by a decoupled look-back over (contig, end) composites
-//                 (k_ix_final's protocol; buckets are handed out by ticket, so every predecessor is running), segment offsets.
+//                 sort with the bucket function above)
+//   k_v3_local    one workgroup per bucket: rows -> LDS; the (contig, end) maximum of the bucket is published at once (it does not
+//                 depend on the order), then ONE counting pass inside LDS -- 4096 bins over the bucket-local key (~0.6 rows per bin),
+//                 exclusive scan, rows dropped into their bin's range, and every row ranks itself among the rows of its bin by
+//                 (key, slot): equal keys keep their input order -- then the index arrays straight from LDS in sorted order:
+//                 b_start / (end, prefix max) / b_row / b_contig, the prefix max carried across buckets by a wavefront-wide decoupled
+//                 look-back over the composites (buckets are handed out by ticket, so every predecessor is running), segment offsets.
 //
-// Five launches.  Order and content of the index are exactly the round-2 build's: rows sorted by (contig, start) with equal keys in
-// input order (both passes are stable), rows outside the dictionary parked last under contig id n_contigs.
+// Six launches, two of them one-workgroup kernels.  Order and content of the index are exactly the round-2 build's: rows sorted by
+// (contig, start) with equal keys in input order, rows outside the dictionary parked last under contig id n_contigs.
 #pragma once
 #include "onesweep.hip.h"
 
@@ -31,12 +34,12 @@ constexpr int V3_BUCKETS = OS_RADIX;                   // 2048: the pass kernel'
 constexpr int V3_ITEMS = 4;
 constexpr int V3_CAP = OS_THREADS * V3_ITEMS;          // rows of one bucket the local kernel holds in LDS
 constexpr int V3_MAX_KEYS = 256;                       // contig keys 0 .. n_contigs (the last one: rows outside the dictionary)
-constexpr int V3_LBITS = 8;                            // digit bits of a local pass, at most
-constexpr int V3_LRADIX = 1 << V3_LBITS;
+constexpr int V3_BIN_BITS = 12;                        // bins of the local counting pass: 4096 (>= V3_CAP: below one row per bin)
+constexpr int V3_BINS = 1 << V3_BIN_BITS;
 
 struct V3Meta {                                        // device-resident, zero-initialised before every build
     uint32_t inverted;                                 // some row of the dictionary has start > end
-    uint32_t done;                                     // workgroups of k_v3_stats that have published their extremes
+    uint32_t pad0;
     uint32_t bad;                                      // the linear keys do not fit 32 bits: the host takes the round-2 sort
     uint32_t max_bucket;                               // rows of the largest bucket (k_v3_scatter)
     uint32_t ticket;                                   // bucket tickets of k_v3_local
@@ -55,13 +58,11 @@ __device__ __forceinline__ void v3_load_tables(const V3Meta* __restrict__ meta, 
     for (int k = threadIdx.x; k < nk; k += OS_THREADS) { l_base[k] = meta->base[k]; l_cmin[k] = ~meta->cimn[k]; }
 }
 
-// ---- statistics + key geometry ---------------------------------------------------------------------------------------------------
+// ---- statistics ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(OS_THREADS) void k_v3_stats(const int32_t* __restrict__ start, const int32_t* __restrict__ end,
                                                         const int32_t* __restrict__ contig, int64_t n, int32_t n_contigs, V3Meta* __restrict__ meta) {
     __shared__ uint32_t l_mx[V3_MAX_KEYS], l_imn[V3_MAX_KEYS];
-    __shared__ unsigned long long l_ws[OS_WAVES];
     __shared__ uint32_t l_inv;
-    __shared__ int l_last;
     const int tid = threadIdx.x, nk = n_contigs + 1;
     for (int k = tid; k < V3_MAX_KEYS; k += OS_THREADS) { l_mx[k] = 0u; l_imn[k] = 0u; }
     if (tid == 0) l_inv = 0u;
@@ -78,47 +79,58 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_stats(const int32_t* __restri
     }
     if (inv) l_inv = 1u;
     __syncthreads();
+    // (no fence, no "last workgroup" here: a device-scope release costs an L2 write-back per workgroup on this part -- the geometry
+    // is derived by the next kernel, behind the kernel boundary)
     for (int k = tid; k < nk; k += OS_THREADS) {
         const uint32_t a = l_mx[k], b = l_imn[k];
         if (a > os_ld(&meta->cmax[k])) atomicMax(&meta->cmax[k], a);
         if (b > os_ld(&meta->cimn[k])) atomicMax(&meta->cimn[k], b);
     }
     if (tid == 0 && l_inv && !os_ld(&meta->inverted)) atomicOr(&meta->inverted, 1u);
-    // the last workgroup to get here sees every workgroup's extremes (device-scope fence before the counter) and lays the contigs out
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) l_last = atomicAdd(&meta->done, 1u) == gridDim.x - 1 ? 1 : 0;
-    __syncthreads();
-    if (!l_last) return;
-    __threadfence();
+}
+
+// key geometry from the per-contig extremes: every workgroup of k_v3_hist derives it (a 256-entry scan and one 64-bit division),
+// workgroup 0 records it for the kernels behind.  -> false: unusable (the linear keys do not fit 32 bits)
+struct V3Geom { unsigned long long M; uint32_t wbits; bool bad; };
+__device__ __forceinline__ V3Geom v3_geometry(V3Meta* __restrict__ meta, int nk, uint32_t* l_base, uint32_t* l_cmin, unsigned long long* l_ws /* OS_WAVES + 2 */, bool record) {
+    const int tid = threadIdx.x;
     unsigned long long sp = 0;
+    uint32_t cmn = 0xffffffffu;
     if (tid < nk) {
-        const uint32_t cmx = os_ld(&meta->cmax[tid]), cim = os_ld(&meta->cimn[tid]);
-        if ((cmx | cim) != 0u) sp = (unsigned long long)(cmx - ~cim) + 1ull;
+        const uint32_t cmx = meta->cmax[tid], cim = meta->cimn[tid];
+        cmn = ~cim;
+        if ((cmx | cim) != 0u) sp = (unsigned long long)(cmx - cmn) + 1ull;
     }
     unsigned long long total;
     const unsigned long long pre = sl_block_exclusive_sum<unsigned long long>(sp, l_ws, &total);
-    if (tid < nk) meta->base[tid] = (uint32_t)pre;                              // (meaningless when bad: nobody reads it then)
+    if (tid < nk) { l_base[tid] = (uint32_t)pre; l_cmin[tid] = cmn; if (record) meta->base[tid] = (uint32_t)pre; }
     if (tid == 0) {
         const bool bad = total == 0ull || total > 0xffffffffull;
-        meta->bad = bad ? 1u : 0u;
-        meta->span = total;
         const unsigned long long M = bad ? 1ull : (1ull << 43) / total;
-        meta->M = M;
         const unsigned long long wmax = (1ull << 32) / M;                       // bucket-local keys lie in [0, 2^32 / M]
-        meta->wbits = (uint32_t)os_bits_for(wmax > 0xffffffffull ? 0xffffffffu : (uint32_t)wmax);
+        const uint32_t wbits = (uint32_t)os_bits_for(wmax > 0xffffffffull ? 0xffffffffu : (uint32_t)wmax);
+        l_ws[OS_WAVES] = M;
+        l_ws[OS_WAVES + 1] = (unsigned long long)wbits | (bad ? (1ull << 32) : 0ull);
+        if (record) { meta->bad = bad ? 1u : 0u; meta->span = total; meta->M = M; meta->wbits = wbits; }
     }
+    __syncthreads();
+    V3Geom g;
+    g.M = l_ws[OS_WAVES];
+    g.wbits = (uint32_t)l_ws[OS_WAVES + 1];
+    g.bad = (l_ws[OS_WAVES + 1] >> 32) != 0ull;
+    return g;
 }
 
-// ---- per-(bucket, chunk) histogram (bucket-major: hist[b * nchunks + g]) ------------------------------------------------------------
+// ---- geometry + per-(bucket, chunk) histogram (bucket-major: hist[b * nchunks + g]) ------------------------------------------------
 __global__ __launch_bounds__(OS_THREADS) void k_v3_hist(const int32_t* __restrict__ contig, const int32_t* __restrict__ start, int64_t n,
-                                                       int32_t n_contigs, const V3Meta* __restrict__ meta, int chunk, int nchunks,
+                                                       int32_t n_contigs, V3Meta* __restrict__ meta, int chunk, int nchunks,
                                                        uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[V3_BUCKETS];
     __shared__ uint32_t l_base[V3_MAX_KEYS], l_cmin[V3_MAX_KEYS];
-    if (meta->bad) return;                                                      // uniform
-    const unsigned long long M = meta->M;
-    v3_load_tables(meta, n_contigs + 1, l_base, l_cmin);
+    __shared__ unsigned long long l_ws[OS_WAVES + 2];
+    const V3Geom g = v3_geometry(meta, n_contigs + 1, l_base, l_cmin, l_ws, blockIdx.x == 0);
+    if (g.bad) return;                                                          // uniform
+    const unsigned long long M = g.M;
     for (int k = threadIdx.x; k < V3_BUCKETS; k += OS_THREADS) h[k] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * chunk;
@@ -131,6 +143,30 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_hist(const int32_t* __restric
     }
     __syncthreads();
     for (int k = threadIdx.x; k < V3_BUCKETS; k += OS_THREADS) hist[(int64_t)k * nchunks + blockIdx.x] = h[k];
+}
+
+// rows of the largest bucket: bucket b = [off[b * nchunks], off[(b + 1) * nchunks]) of the scanned, bucket-major histogram.  One workgroup.
+__global__ __launch_bounds__(OS_THREADS) void k_v3_check(const uint32_t* __restrict__ off, int nchunks, int64_t n, V3Meta* __restrict__ meta) {
+    __shared__ uint32_t wmx[OS_WAVES];
+    if (meta->bad) return;
+    const int tid = threadIdx.x;
+    uint32_t mx = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int b = 2 * tid + q;
+        const uint32_t a = off[(int64_t)b * nchunks];
+        const uint32_t z = b + 1 < V3_BUCKETS ? off[(int64_t)(b + 1) * nchunks] : (uint32_t)n;
+        mx = z - a > mx ? z - a : mx;
+    }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(mx, d, kWave); mx = o > mx ? o : mx; }
+    if ((tid & (kWave - 1)) == 0) wmx[tid / kWave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 1; k < OS_WAVES; ++k) mx = wmx[k] > mx ? wmx[k] : mx;
+        meta->max_bucket = mx;
+    }
 }
 
 // ---- the one pass over HBM: stable scatter into the buckets (k_os_scatter<true> with the bucket function above) ---------------------
@@ -166,26 +202,6 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_scatter(const int32_t* __rest
     v3_load_tables(meta, n_contigs + 1, l_base, l_cmin);
     for (int k = tid; k < OS_RADIX; k += OS_THREADS) base[k] = off[(int64_t)k * nchunks + blockIdx.x];
     for (int k = tid; k < OS_RADIX * OS_WAVES / 2; k += OS_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
-    if (blockIdx.x == 0) {
-        // rows of the largest bucket: bucket b = [off[b * nchunks], off[(b + 1) * nchunks]) (the histogram is bucket-major)
-        uint32_t mx = 0;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int b = 2 * tid + q;
-            const uint32_t a = off[(int64_t)b * nchunks];
-            const uint32_t z = b + 1 < V3_BUCKETS ? off[(int64_t)(b + 1) * nchunks] : (uint32_t)n;
-            mx = z - a > mx ? z - a : mx;
-        }
-#pragma unroll
-        for (int d = kWave / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(mx, d, kWave); mx = o > mx ? o : mx; }
-        if (lane == 0) wsum[w] = mx;
-        __syncthreads();
-        if (tid == 0) {
-#pragma unroll
-            for (int k = 1; k < OS_WAVES; ++k) mx = wsum[k] > mx ? wsum[k] : mx;
-            meta->max_bucket = mx;
-        }
-    }
     __syncthreads();
     const int64_t cbase = (int64_t)blockIdx.x * chunk;
     const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
@@ -272,17 +288,16 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_scatter(const int32_t* __rest
 }
 
 // ---- one workgroup per bucket: LDS sort + index arrays ------------------------------------------------------------------------------
-struct V3LocalLds { int rec, ka, kb, ia, ib, wcnt, dstart, tbase, tcmin, wsum, total; };
+struct V3LocalLds { int rec, bst, cur, tk, ts, ifin, tbase, tcmin, wsum, total; };
 __host__ __device__ inline V3LocalLds v3_local_lds() {
     V3LocalLds L;
     int o = 0;
     L.rec = o; o += 16 * V3_CAP;
-    L.ka = o; o += 4 * V3_CAP;                         // (after the sort: the prefix maxima per sorted position)
-    L.kb = o; o += 4 * V3_CAP;
-    L.ia = o; o += 2 * V3_CAP;
-    L.ib = o; o += 2 * V3_CAP;
-    L.wcnt = o; o += 2 * V3_LRADIX * OS_WAVES;
-    L.dstart = o; o += 4 * V3_LRADIX;
+    L.bst = o; o += 4 * (V3_BINS + 4);                 // bin counts, then bin starts (exclusive scan); [V3_BINS] = rows of the bucket
+    L.cur = o; o += 4 * V3_BINS;                       // running cursor of every bin
+    L.tk = o; o += 4 * V3_CAP;                         // keys in bin order (after the ranking: the prefix maxima per sorted position)
+    L.ts = o; o += 2 * V3_CAP;                         // slots in bin order
+    L.ifin = o; o += 2 * V3_CAP;                       // slot of the row at sorted position q
     L.tbase = o; o += 4 * V3_MAX_KEYS;
     L.tcmin = o; o += 4 * V3_MAX_KEYS;
     L.wsum = (o + 15) & ~15; o = L.wsum + 8 * OS_WAVES;
@@ -297,15 +312,16 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char os_lds[];
     const V3LocalLds L = v3_local_lds();
     int4* l_rec = reinterpret_cast<int4*>(os_lds + L.rec);
-    uint32_t* l_k[2] = {reinterpret_cast<uint32_t*>(os_lds + L.ka), reinterpret_cast<uint32_t*>(os_lds + L.kb)};
-    unsigned short* l_i[2] = {reinterpret_cast<unsigned short*>(os_lds + L.ia), reinterpret_cast<unsigned short*>(os_lds + L.ib)};
-    unsigned short* wcnt = reinterpret_cast<unsigned short*>(os_lds + L.wcnt);
-    uint32_t* dstart = reinterpret_cast<uint32_t*>(os_lds + L.dstart);
+    uint32_t* bst = reinterpret_cast<uint32_t*>(os_lds + L.bst);
+    uint32_t* cur = reinterpret_cast<uint32_t*>(os_lds + L.cur);
+    uint32_t* tk = reinterpret_cast<uint32_t*>(os_lds + L.tk);
+    unsigned short* ts = reinterpret_cast<unsigned short*>(os_lds + L.ts);
+    unsigned short* iF = reinterpret_cast<unsigned short*>(os_lds + L.ifin);
     uint32_t* l_base = reinterpret_cast<uint32_t*>(os_lds + L.tbase);
     uint32_t* l_cmin = reinterpret_cast<uint32_t*>(os_lds + L.tcmin);
     unsigned long long* wmax = reinterpret_cast<unsigned long long*>(os_lds + L.wsum);
     uint32_t* wsum = reinterpret_cast<uint32_t*>(wmax);
-    uint32_t* l_pm = l_k[0];
+    uint32_t* l_pm = tk;
     __shared__ int l_tile;
     __shared__ uint32_t l_lo;
     __shared__ unsigned long long s_carry;
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
         l_lo = (uint32_t)((((unsigned long long)t << 32) + M - 1ull) / M);      // smallest linear key of bucket t
     }
     v3_load_tables(meta, n_contigs + 1, l_base, l_cmin);
-    for (int k = tid; k < V3_LRADIX * OS_WAVES / 2; k += OS_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
+    for (int k = tid; k < V3_BINS; k += OS_THREADS) { bst[k] = 0u; cur[k] = 0u; }
     __syncthreads();
     const int tile = l_tile;
     const uint32_t lo = l_lo;
@@ -325,90 +341,77 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
     const uint32_t b1 = tile + 1 < V3_BUCKETS ? off[(int64_t)(tile + 1) * nchunks] : (uint32_t)n;
     const int nb = (int)(b1 - b0);                                              // <= V3_CAP: checked by the host before this launch
     const int wbits = (int)meta->wbits;
-    const int P = (wbits + V3_LBITS - 1) / V3_LBITS;                            // >= 1
-    const int bits = (wbits + P - 1) / P;
-    const uint32_t dmask = (1u << bits) - 1u;
-    const int ndig = 1 << bits;
+    const int bshift = wbits > V3_BIN_BITS ? wbits - V3_BIN_BITS : 0;           // bin = key >> bshift < 4096
 
-    // rows of the bucket -> LDS (slot p = input order inside the bucket); wavefront w owns the slots [w * 256, (w + 1) * 256)
-    uint32_t kv[V3_ITEMS], iv[V3_ITEMS];
+    // rows of the bucket -> LDS (slot p = input order inside the bucket: item j of thread t = j * 1024 + t), bin counts, bucket maximum
+    uint32_t kv[V3_ITEMS];
+    unsigned long long cmx = 0ull;
 #pragma unroll
     for (int j = 0; j < V3_ITEMS; ++j) {
-        const int p = w * (V3_ITEMS * kWave) + j * kWave + lane;
-        kv[j] = 0u; iv[j] = (uint32_t)p;
+        const int p = j * OS_THREADS + tid;
+        kv[j] = 0u;
         if (p < nb) {
             const int4 r = rec[(int64_t)b0 + p];
             l_rec[p] = r;
             kv[j] = l_base[r.w] + (flip(r.x) - l_cmin[r.w]) - lo;
+            atomicAdd(&bst[kv[j] >> bshift], 1u);
+            const unsigned long long c = ((unsigned long long)(uint32_t)r.w << 32) | (unsigned long long)flip(r.y);
+            cmx = c > cmx ? c : cmx;
         }
     }
-    const uint64_t lt = lanemask_lt();
-    unsigned short* my = wcnt + w * V3_LRADIX;
-    const int npass = nb > 0 ? P : 0;                                           // (uniform) an empty bucket only takes part in the look-back
-    for (int pass = 0; pass < npass; ++pass) {
-        const int shift = pass * bits;
-        uint32_t* kd = l_k[pass & 1];
-        unsigned short* id = l_i[pass & 1];
-        if (pass > 0) {
-            const uint32_t* ks = l_k[(pass - 1) & 1];
-            const unsigned short* is = l_i[(pass - 1) & 1];
+    // the bucket's (contig, end) maximum does not depend on the order of its rows: it is published BEFORE the sort, so that by the
+    // time a later bucket looks back every running predecessor has at least its aggregate out
 #pragma unroll
-            for (int j = 0; j < V3_ITEMS; ++j) {
-                const int p = w * (V3_ITEMS * kWave) + j * kWave + lane;
-                if (p < nb) { kv[j] = ks[p]; iv[j] = is[p]; }
-            }
-        }
-        uint32_t dg[V3_ITEMS], rank[V3_ITEMS];
+    for (int d = kWave / 2; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(cmx, d, kWave); cmx = o > cmx ? o : cmx; }
+    if (lane == 0) wmax[w] = cmx;
+    __syncthreads();                                                            // (A) counts + wavefront maxima complete
+    if (tid == 0) {
+        unsigned long long tmax = 0;
 #pragma unroll
-        for (int j = 0; j < V3_ITEMS; ++j) {
-            const int p = w * (V3_ITEMS * kWave) + j * kWave + lane;
-            const bool valid = p < nb;
-            dg[j] = (kv[j] >> shift) & dmask;
-            uint64_t peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < V3_LBITS; ++b) {
-                if (b < bits) {                                                 // uniform
-                    const bool bit = (dg[j] >> b) & 1u;
-                    const uint64_t m = __ballot(valid && bit);
-                    peers &= bit ? m : ~m;
-                }
-            }
-            const uint32_t rk = (uint32_t)__popcll(peers & lt);
-            const uint32_t before = valid ? (uint32_t)my[dg[j]] : 0u;
-            rank[j] = before + rk;
-            __builtin_amdgcn_wave_barrier();
-            if (valid && rk == 0) my[dg[j]] = (unsigned short)(before + (uint32_t)__popcll(peers));
-            __builtin_amdgcn_wave_barrier();
-        }
-        __syncthreads();
-        // thread t < ndig owns digit t: exclusive prefix over the wavefronts, then over the digits
-        uint32_t tot = 0;
-        if (tid < ndig) {
-#pragma unroll
-            for (int k = 0; k < OS_WAVES; ++k) {
-                const uint32_t v = wcnt[k * V3_LRADIX + tid];
-                wcnt[k * V3_LRADIX + tid] = (unsigned short)tot;
-                tot += v;
-            }
-        }
+        for (int k = 0; k < OS_WAVES; ++k) tmax = wmax[k] > tmax ? wmax[k] : tmax;
+        os_st64(status64 + tile, ((tile == 0 ? 2ull : 1ull) << 62) | tmax);
+    }
+    // exclusive scan of the bin counts: thread t owns the bins 4 t .. 4 t + 3
+    {
+        uint4 c4 = *reinterpret_cast<const uint4*>(bst + 4 * tid);
+        const uint32_t s = c4.x + c4.y + c4.z + c4.w;
+        __syncthreads();                                                        // (wmax read by thread 0 before wsum is reused)
         uint32_t tsum;
-        const uint32_t pre = sl_block_exclusive_sum<uint32_t>(tot, wsum, &tsum);
-        if (tid < ndig) dstart[tid] = pre;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < V3_ITEMS; ++j) {
-            const int p = w * (V3_ITEMS * kWave) + j * kWave + lane;
-            if (p < nb) {
-                const uint32_t dpos = dstart[dg[j]] + (uint32_t)my[dg[j]] + rank[j];
-                kd[dpos] = kv[j];
-                id[dpos] = (unsigned short)iv[j];
-            }
-        }
-        __syncthreads();
-        for (int k = tid; k < V3_LRADIX * OS_WAVES / 2; k += OS_THREADS) reinterpret_cast<uint32_t*>(wcnt)[k] = 0;
-        __syncthreads();
+        uint32_t pre = sl_block_exclusive_sum<uint32_t>(s, wsum, &tsum);
+        uint4 o4;
+        o4.x = pre; pre += c4.x; o4.y = pre; pre += c4.y; o4.z = pre; pre += c4.z; o4.w = pre;
+        *reinterpret_cast<uint4*>(bst + 4 * tid) = o4;
+        if (tid == 0) bst[V3_BINS] = (uint32_t)nb;
     }
-    const unsigned short* iF = l_i[(P - 1) & 1];                                 // slot of the row at sorted position q
+    __syncthreads();                                                            // (B) bin starts
+#pragma unroll
+    for (int j = 0; j < V3_ITEMS; ++j) {
+        const int p = j * OS_THREADS + tid;
+        if (p < nb) {
+            const uint32_t bin = kv[j] >> bshift;
+            const uint32_t q = bst[bin] + atomicAdd(&cur[bin], 1u);             // arrival order inside the bin: settled by the ranking below
+            tk[q] = kv[j];
+            ts[q] = (unsigned short)p;
+        }
+    }
+    __syncthreads();                                                            // (C) rows in bin order
+    // rank inside the bin by (key, slot): equal keys keep their input order whatever the arrival order was
+#pragma unroll
+    for (int j = 0; j < V3_ITEMS; ++j) {
+        const int p = j * OS_THREADS + tid;
+        if (p < nb) {
+            const uint32_t bin = kv[j] >> bshift;
+            const uint32_t a = bst[bin], z = bst[bin + 1];
+            uint32_t r = a;
+            for (uint32_t q = a; q < z; ++q) {
+                const uint32_t k2 = tk[q];
+                const uint32_t s2 = ts[q];
+                r += (k2 < kv[j] || (k2 == kv[j] && s2 < (uint32_t)p)) ? 1u : 0u;
+            }
+            iF[r] = (unsigned short)p;
+        }
+    }
+    __syncthreads();                                                            // (D) iF complete; tk is free (l_pm)
 
     // prefix max of (contig, end) in sorted order: thread t holds the positions 4 t .. 4 t + 3
     unsigned long long comp[V3_ITEMS];
@@ -435,9 +438,30 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
         const unsigned long long o = __shfl_up(inc, dd, kWave);
         if (lane >= dd) inc = o > inc ? o : inc;
     }
-    __syncthreads();                                                            // (wsum / wmax: the last pass's scan has been read by everyone)
     if (lane == kWave - 1) wmax[w] = inc;
-    __syncthreads();
+    // wavefront 0: look-back over the earlier buckets, 64 status words per step (one thread walking 200 concurrently running
+    // predecessors pays a memory round trip per bucket)
+    if (w == 0) {
+        const unsigned long long VAL = (1ull << 62) - 1ull;
+        unsigned long long carry = 0;
+        for (int t0 = tile - 1; t0 >= 0; t0 -= kWave) {
+            const int t = t0 - lane;
+            unsigned long long v = 2ull << 62;                                  // before bucket 0: a complete prefix of nothing
+            if (t >= 0) {
+                v = os_ld64(status64 + t);
+                while ((v >> 62) == 0) { __builtin_amdgcn_s_sleep(2); v = os_ld64(status64 + t); }
+            }
+            const unsigned long long pre_mask = __ballot((v >> 62) == 2ull);
+            const int first = pre_mask ? __builtin_ctzll(pre_mask) : kWave;     // nearest predecessor that carries a complete prefix
+            unsigned long long x = lane <= first ? (v & VAL) : 0ull;
+#pragma unroll
+            for (int d = kWave / 2; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(x, d, kWave); x = o > x ? o : x; }
+            carry = x > carry ? x : carry;
+            if (pre_mask) break;
+        }
+        if (lane == 0) s_carry = carry;
+    }
+    __syncthreads();                                                            // (E) wavefront maxima + carry
     unsigned long long wpre = 0, tmax = 0;
 #pragma unroll
     for (int k = 0; k < OS_WAVES; ++k) { const unsigned long long x = wmax[k]; if (k < w) wpre = x > wpre ? x : wpre; tmax = x > tmax ? x : tmax; }
@@ -445,24 +469,9 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
     if (lane == 0) excl = 0;
     excl = wpre > excl ? wpre : excl;
     if (tid == 0) {
-        const unsigned long long VAL = (1ull << 62) - 1ull;
-        unsigned long long carry = 0;
-        if (tile == 0) os_st64(status64, (2ull << 62) | tmax);
-        else {
-            os_st64(status64 + tile, (1ull << 62) | tmax);
-            for (int t = tile - 1; t >= 0; --t) {
-                unsigned long long v = os_ld64(status64 + t);
-                while ((v >> 62) == 0) { __builtin_amdgcn_s_sleep(2); v = os_ld64(status64 + t); }
-                const unsigned long long x = v & VAL;
-                carry = x > carry ? x : carry;
-                if ((v >> 62) == 2ull) break;
-            }
-            os_st64(status64 + tile, (2ull << 62) | (carry > tmax ? carry : tmax));
-        }
-        s_carry = carry;
+        if (tile > 0) os_st64(status64 + tile, (2ull << 62) | (s_carry > tmax ? s_carry : tmax));
         if (tile == 0) flags[0] = (int32_t)meta->inverted;
     }
-    __syncthreads();
     const unsigned long long before = s_carry > excl ? s_carry : excl;
     // the row before this bucket's first one carries the largest contig key so far: the high word of the carried composite
     if (tid == 0) prev_c = b0 == 0u ? -1 : (int32_t)(s_carry >> 32);
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
             if (p == n - 1) for (int32_t kk = cc[k] + 1; kk <= n_contigs + 1; ++kk) seg[kk] = (int32_t)n;
         }
     }
-    __syncthreads();
+    __syncthreads();                                                            // (F) prefix maxima per position
     // index arrays, coalesced: position q = j * 1024 + tid
 #pragma unroll
     for (int j = 0; j < V3_ITEMS; ++j) {
