@@ -778,7 +778,8 @@ def main():
                                        f"{mode}-sharded x{n_gpus}, " + ((f"all-gatherv in timed region ({exchange}" + (f", {args.chunks} chunks, exchange overlapping the join" if exchange == "lib" and op == "overlap" else "") +
                                                                    (", per-probe results scattered to global probe order on every rank" if op != "overlap" else "") + ")") if gather else "no gather")),
                        "step": ("index build (radix sort) + probe partition (" +
-                                ("contig-aligned index slices, 12-byte records" if any(k.startswith("cs_") for k in ktimes) else
+                                (("contig-aligned index slices, 8-byte records" if ("cs_scatter12" in ktimes and ktimes["cs_scatter12"]["ms"] < ktimes.get("cs_scatter", {"ms": 0.0})["ms"]) else
+                                  "contig-aligned index slices, 12-byte records") if any(k.startswith("cs_") for k in ktimes) else
                                  "equal-row-count index slices, 16-byte records" if any(k.startswith("slice_") for k in ktimes) else "256 genomic buckets") + ") + " +
                                 ("count + scan + fill" if (args.two_pass or not any(k.startswith(("overlap_fused", "overlap_flat", "slice_join_fused", "cs_join_fused")) for k in ktimes)) else
                                  "fused count/fill into the preallocated result buffers") +

@@ -39,7 +39,12 @@ constexpr int CS_POS_BIAS = 1 << 23;                    // staging entries carry
 static_assert((long long)SL_MAX_BUCKETS * SL_MAX_ROWS <= CS_POS_BIAS, "an index of this path must fit a staging entry's row field");
 constexpr int CS_BIN_STRIDE_PAD = 2;                    // bins per slice in global memory: 2 R + 2 (u16)
 
+constexpr int CS_META_FMT = 8;                          // meta[8]: record format of the call (k_cs_regions): 0 = 12-byte records, LB > 0 = 8-byte records
+constexpr unsigned long long CS_STATE_REC8 = 8ull;     // state word, bit 8: a probe did not fit the 8-byte record form
+__host__ __device__ __forceinline__ int cs_bits_for(uint32_t v) { int b = 0; while (b < 32 && (v >> b) != 0) ++b; return b == 0 ? 1 : b; }
+
 typedef int cs_rec __attribute__((ext_vector_type(3), aligned(4)));      // one probe record {start, end, row}: 12 bytes, 4-byte aligned
+typedef int cs_rec8 __attribute__((ext_vector_type(2), aligned(8)));     // round 5, where a call's probes fit: {(end - slice minimum) << LB | (end - start), row}
 
 struct CsGeom {
     int nb;            // bucket SLOTS = upper bound on the number of slices (host-known); bucket nb = probes without a candidate row
@@ -328,12 +333,13 @@ __host__ __device__ inline CsPartLds cs_part_lds(int nb, int ncells, int n_conti
 // not fit its region raises bit 2 of the state word and is written over the region's start (in bounds: a region holds at least a
 // tile): the host discards the call's result and redoes it with the exact, histogram-first partition.  Probes without a candidate
 // row (bucket g.nb) are not stored at all.
-template <bool STRICT, int PITEMS, bool SAMPLED>
+template <bool STRICT, int PITEMS, bool SAMPLED, bool REC8 = false>
 __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
                                                           const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
                                                           int chunk, int nchunks, bool vec_ok, const uint32_t* __restrict__ blk_off,
                                                           uint32_t* __restrict__ rcur, unsigned long long* __restrict__ state,
-                                                          int32_t* __restrict__ out /* 3 int32 per record */, int ablate) {
+                                                          const int32_t* __restrict__ meta /* SAMPLED: [CS_META_FMT] = record format */,
+                                                          int32_t* __restrict__ out /* 3 (or 2) int32 per record */, int ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
     constexpr int TILE = CS_THREADS * PITEMS;
     const CsPartLds L = cs_part_lds(g.nb, g.ncells, g.n_contigs, PITEMS);
@@ -351,6 +357,12 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
     int* wsum = reinterpret_cast<int*>(cs_lds + L.wsum);
     const int tid = threadIdx.x;
     const int nbk = g.nb + 1;
+    // record format of this call (k_cs_regions, on the device): 0 = {start, end, row}; LB > 0 = {(end - slice minimum) << LB | (end - start), row}.
+    // The host launches BOTH forms of the sampled scatter; the one the format does not name leaves at once (a runtime branch between the
+    // two forms inside one kernel keeps the ends alive next to the packed words: 6 spilled VGPRs at this kernel's 128-register ceiling).
+    static_assert(!REC8 || SAMPLED, "8-byte records belong to the sampled partition");
+    const int lb = SAMPLED ? meta[CS_META_FMT] : 0;                             // uniform
+    if (SAMPLED && (lb != 0) != REC8) return;
     cs_load_tab(tab, g, l_spl, l_cm, l_cell, CS_THREADS);
     // exact: base[b] = running global offset of bucket b for this chunk; SAMPLED: base[b] = start of bucket b's region (b <= g.nb)
     for (int k = tid; k < nbk + 1; k += CS_THREADS) { base[k] = SAMPLED ? blk_off[k < nbk ? k : nbk - 1] : (k < nbk ? blk_off[(int64_t)k * nchunks + blockIdx.x] : 0u); cnt[k] = 0; }
@@ -389,6 +401,16 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
             if (ablate & 1024) d[j] = !valid ? 0u : (uint32_t)(((uint32_t)e[j] * 2654435761u) >> 12) % (uint32_t)g.nb;
             else d[j] = !valid ? 0u : cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, c[j], e[j]);
             rank[j] = valid ? atomicAdd(&cnt[d[j]], 1u) : 0u;
+            if constexpr (REC8) {                                               // the packed word takes the place of the start
+                uint32_t w0 = 0u;
+                if (valid && d[j] < (uint32_t)g.nb) {
+                    const uint32_t off = (uint32_t)e[j] - (uint32_t)unflip((uint32_t)l_spl[d[j]]);      // >= 0: the slice's first row starts below the end
+                    const uint32_t len = (uint32_t)e[j] - (uint32_t)s[j];
+                    if (e[j] < s[j] || (len >> lb) != 0u || (off >> (32 - lb)) != 0u) atomicOr(state + 1, CS_STATE_REC8);   // (redo with 12-byte records)
+                    w0 = (off << lb) | len;
+                }
+                s[j] = (int32_t)w0;
+            }
         }
         __syncthreads();                                                        // (A) bucket counts of the tile complete
         // thread t owns OWN consecutive buckets: tile-local starts, copy-out deltas, running global offsets; counters cleared
@@ -425,7 +447,8 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
         for (int j = 0; j < PITEMS; ++j) {
             if ((j / 4) * (CS_THREADS * 4) + tid * 4 + (j & 3) < tile_n) {
                 const uint32_t pos = lstart[d[j]] + rank[j];
-                l_rs[pos] = s[j]; l_re[pos] = e[j]; l_rr[pos] = r[j];
+                l_rs[pos] = s[j]; l_rr[pos] = r[j];
+                if constexpr (!REC8) l_re[pos] = e[j];
                 l_d[pos] = (unsigned short)d[j];
             }
         }
@@ -450,10 +473,15 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
         for (int j = 0; j < PITEMS; ++j) {
             const int il = j * CS_THREADS + tid;
             if (il < tile_n && !(ablate & 256) && !(SAMPLED && l_d[il] == (unsigned short)g.nb)) {
-                cs_rec v; v.x = l_rs[il]; v.y = l_re[il]; v.z = l_rr[il];
                 uint32_t oi = (uint32_t)il + delta[l_d[il]];
                 if (ablate & 2048) oi &= (1u << 22) - 1u;                      // profiling only: every store lands in the first 48 MB (address-translation probe)
-                *reinterpret_cast<cs_rec*>(out + 3 * (int64_t)oi) = v;
+                if constexpr (REC8) {
+                    cs_rec8 v; v.x = l_rs[il]; v.y = l_rr[il];
+                    *reinterpret_cast<cs_rec8*>(out + 2 * (int64_t)oi) = v;
+                } else {
+                    cs_rec v; v.x = l_rs[il]; v.y = l_re[il]; v.z = l_rr[il];
+                    *reinterpret_cast<cs_rec*>(out + 3 * (int64_t)oi) = v;
+                }
             }
         }
         // no barrier here: the next tile's barrier (A) separates this copy-out from the next placement
@@ -464,31 +492,68 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
 // Sample = groups of CS_SGROUP consecutive probes (one 32-byte sector per column) every CS_SGROUP * CS_SRATE probes; gh[b] += sampled
 // probes of bucket b.  A few hundred workgroups, the bucket table in LDS as in k_cs_hist.
 constexpr int CS_SGROUP = 8, CS_SRATE = 64;
+// gh[nb + 1] / gh[nb + 2] (round 5): the sample's largest probe length (end - start; 2^31 - 1 for an inverted row) and its largest
+// distance of a probe's end from its slice's smallest start -- what decides whether the call's records take the 8-byte form.
 template <bool STRICT>
-__global__ __launch_bounds__(CS_THREADS) void k_cs_sample_hist(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ pe,
-                                                              int64_t n, uint32_t* __restrict__ gh) {
+__global__ __launch_bounds__(CS_THREADS) void k_cs_sample_hist(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                              const int32_t* __restrict__ pe, int64_t n, uint32_t* __restrict__ gh) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
     int4* l_cm = reinterpret_cast<int4*>(cs_lds);
     unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(l_cm + CS_MAX_CONTIGS);
     uint32_t* l_cell = reinterpret_cast<uint32_t*>(l_spl + g.nb);
-    uint32_t* h = l_cell + g.ncells;
+    uint32_t* h = l_cell + g.ncells;                                            // nb + 1 counts, then the two maxima
     cs_load_tab(tab, g, l_spl, l_cm, l_cell, CS_THREADS);
-    for (int k = threadIdx.x; k <= g.nb; k += CS_THREADS) h[k] = 0;
+    for (int k = threadIdx.x; k <= g.nb + 2; k += CS_THREADS) h[k] = 0;
     __syncthreads();
+    uint32_t mlen = 0, moff = 0;
     const int64_t n_groups = (n + (int64_t)CS_SGROUP * CS_SRATE - 1) / ((int64_t)CS_SGROUP * CS_SRATE);
     for (int64_t t = (int64_t)blockIdx.x * CS_THREADS + threadIdx.x; t < n_groups * CS_SGROUP; t += (int64_t)gridDim.x * CS_THREADS) {
         const int64_t i = (t / CS_SGROUP) * ((int64_t)CS_SGROUP * CS_SRATE) + (t % CS_SGROUP);
-        if (i < n) atomicAdd(&h[cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, pc[i], pe[i])], 1u);
+        if (i < n) {
+            const int32_t qe = pe[i], qs = ps[i];
+            const uint32_t b = cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, pc[i], qe);
+            atomicAdd(&h[b], 1u);
+            if (b < (uint32_t)g.nb) {
+                const uint32_t len = qe >= qs ? (uint32_t)qe - (uint32_t)qs : 0x7fffffffu;
+                const uint32_t off = (uint32_t)qe - (uint32_t)unflip((uint32_t)l_spl[b]);       // >= 0 by the bucket's definition
+                mlen = len > mlen ? len : mlen;
+                moff = off > moff ? off : moff;
+            }
+        }
     }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        const uint32_t a = __shfl_xor(mlen, d, kWave), b = __shfl_xor(moff, d, kWave);
+        mlen = a > mlen ? a : mlen; moff = b > moff ? b : moff;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { atomicMax(&h[g.nb + 1], mlen); atomicMax(&h[g.nb + 2], moff); }
     __syncthreads();
     for (int k = threadIdx.x; k <= g.nb; k += CS_THREADS) if (h[k]) atomicAdd(&gh[k], h[k]);
+    if (threadIdx.x == 0) { atomicMax(&gh[g.nb + 1], h[g.nb + 1]); atomicMax(&gh[g.nb + 2], h[g.nb + 2]); }
 }
 
 // Regions of the record buffer: cap_b = 1.25 x (sampled count x CS_SRATE) + slack, starts aligned to 32 records (three 128-byte lines);
 // rstart[nb] = records reserved in total (bucket nb, "no candidate row", owns no region).  slack >= one partition tile, so that a run
 // which does not fit can be parked at its region's start without leaving it.  Clears the cursors.  One workgroup.
-__global__ __launch_bounds__(CS_THREADS) void k_cs_regions(const uint32_t* __restrict__ gh, int nb, uint32_t slack, uint32_t* __restrict__ rstart,
-                                                          uint32_t* __restrict__ rcur) {
+// Record format of the call (round 5), meta[CS_META_FMT]: 0 = 12-byte records {start, end, row}; LB > 0 = 8-byte records
+// {(end - smallest start of the probe's slice) << LB | (end - start), row}.  A bucket's probes all END inside one slice's start span
+// (that is what the bucket is), and probes are short: for the benchmark shapes 22 + 8 bits.  The choice is made HERE, on the device,
+// from the sample's maxima with margins (length x 2 + 64, offset x 1.25 + 4096); a probe that does not fit after all (an outlier the
+// sample missed) raises bit 8 of the state word in the scatter and the host redoes the call with 12-byte records: exactness never
+// rests on the sample.  allow8 = 0: the caller wants 12-byte records (the redo, IVJ_CS_REC8=0).
+__global__ __launch_bounds__(CS_THREADS) void k_cs_regions(const uint32_t* __restrict__ gh, int nb, uint32_t slack, int allow8, uint32_t* __restrict__ rstart,
+                                                          uint32_t* __restrict__ rcur, int32_t* __restrict__ meta) {
+    if (threadIdx.x == 0) {
+        int lb = 0;
+        if (allow8) {
+            const unsigned long long ml = (unsigned long long)gh[nb + 1] * 2ull + 64ull;
+            const unsigned long long mo = (unsigned long long)gh[nb + 2] + gh[nb + 2] / 4 + 4096ull;
+            const int lbits = ml > 0xffffffffull ? 33 : cs_bits_for((uint32_t)ml);
+            const int obits = mo > 0xffffffffull ? 33 : cs_bits_for((uint32_t)mo);
+            if (lbits + obits <= 32) lb = 32 - obits;                           // the spare bits go to the length
+        }
+        meta[CS_META_FMT] = lb;
+    }
     __shared__ __attribute__((aligned(16))) int wsum[CS_WAVES];
     constexpr int OWN = (SL_MAX_BUCKETS + 1 + CS_THREADS - 1) / CS_THREADS;
     uint32_t cap[OWN];
@@ -832,9 +897,21 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
     auto stv = [](int* p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
     // records of the tile: wavefront wv owns the contiguous probes [wv * 256, (wv + 1) * 256), item j of lane l = wv * 256 + j * 64 + l
+    // (lb > 0: 8-byte records {(end - slice minimum) << lb | (end - start), row}, unpacked in match_tile; uniform)
+    const int lb = A.meta[CS_META_FMT];
     cs_rec nxt[CS_ITEMS];
     auto load_tile = [&](int64_t tb) {
         const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
+        if (lb) {
+            const int32_t* tp = A.rec + 2 * tb;                                // uniform
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                const int il = wv * CS_WTILE + j * kWave + lane;
+                nxt[j].x = 0; nxt[j].y = 0; nxt[j].z = -1;
+                if (il < rem) { const cs_rec8 v = __builtin_nontemporal_load(reinterpret_cast<const cs_rec8*>(tp + 2 * il)); nxt[j].x = v.x; nxt[j].z = v.y; }
+            }
+            return;
+        }
         const int32_t* tp = A.rec + 3 * tb;                                    // uniform
 #pragma unroll
         for (int j = 0; j < CS_ITEMS; ++j) {
@@ -859,6 +936,15 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
         for (int j = 0; j < CS_ITEMS; ++j) {
             qs[j] = nxt[j].x; qe[j] = nxt[j].y; qrow[j] = nxt[j].z;
             valid[j] = wv * CS_WTILE + j * kWave + lane < rem;
+        }
+        if (lb) {                                                              // uniform: unpack the 8-byte form
+            const uint32_t lmask = (1u << lb) - 1u;
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                const uint32_t w0 = (uint32_t)qs[j];
+                qe[j] = (int32_t)((uint32_t)smin + (w0 >> lb));
+                qs[j] = (int32_t)((uint32_t)qe[j] - (w0 & lmask));
+            }
         }
         if (tb + CS_TILE < q1) load_tile(tb + CS_TILE);                        // next tile's records in flight
         // hi-bound: bin of the end, then the (at most four) rows of the bin that start below it.  Rows before the bin's first
@@ -1232,9 +1318,21 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     auto stv = [](int* p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
     // records of the tile: wavefront wv owns the contiguous probes [wv * 256, (wv + 1) * 256), item j of lane l = wv * 256 + j * 64 + l
+    // (lb > 0: 8-byte records {(end - slice minimum) << lb | (end - start), row}, unpacked in match_tile; uniform)
+    const int lb = A.meta[CS_META_FMT];
     cs_rec nxt[CS_ITEMS];
     auto load_tile = [&](int64_t tb) {
         const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
+        if (lb) {
+            const int32_t* tp = A.rec + 2 * tb;                                // uniform
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                const int il = wv * CS_WTILE + j * kWave + lane;
+                nxt[j].x = 0; nxt[j].y = 0; nxt[j].z = -1;
+                if (il < rem) { const cs_rec8 v = __builtin_nontemporal_load(reinterpret_cast<const cs_rec8*>(tp + 2 * il)); nxt[j].x = v.x; nxt[j].z = v.y; }
+            }
+            return;
+        }
         const int32_t* tp = A.rec + 3 * tb;                                    // uniform
 #pragma unroll
         for (int j = 0; j < CS_ITEMS; ++j) {
@@ -1278,6 +1376,15 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         for (int j = 0; j < CS_ITEMS; ++j) {
             qs[j] = nxt[j].x; qe[j] = nxt[j].y; qrow[j] = nxt[j].z;
             valid[j] = wv * CS_WTILE + j * kWave + lane < rem;
+        }
+        if (lb) {                                                              // uniform: unpack the 8-byte form
+            const uint32_t lmask = (1u << lb) - 1u;
+#pragma unroll
+            for (int j = 0; j < CS_ITEMS; ++j) {
+                const uint32_t w0 = (uint32_t)qs[j];
+                qe[j] = (int32_t)((uint32_t)smin + (w0 >> lb));
+                qs[j] = (int32_t)((uint32_t)qe[j] - (w0 & lmask));
+            }
         }
         if (tb + CS_TILE < q1) load_tile(tb + CS_TILE);                        // next tile's records in flight
         // hi-bound: bin of the end, then the (at most four) rows of the bin that start below it.  Rows before the bin's first
@@ -1620,6 +1727,8 @@ __global__ __launch_bounds__(CS_THREADS, TWO ? 8 : 4) void k_cs_fill(CsJoinArgs 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
     const int4 sm1 = A.smeta[2 * k + 1];
     const int seg_a = sm1.x, rk = sm1.z, r0 = sm1.w;
+    const int lb = A.meta[CS_META_FMT];                                        // record format of the call (uniform)
+    const int32_t smin = A.smeta[2 * k].x;
     for (int i = tid; i < rk; i += CS_THREADS) l_row[i] = A.b_row[r0 + i];
     __syncthreads();
 
@@ -1666,7 +1775,11 @@ __global__ __launch_bounds__(CS_THREADS, TWO ? 8 : 4) void k_cs_fill(CsJoinArgs 
             qrow[j] = n_row[j]; w[j] = n_w[j];
             qs[j] = 0;
             // (rare) the probe's start is only needed to redo a running-on window: fetched here, not prefetched
-            if (w[j] & CS_CACHE_FLAG) qs[j] = A.rec[3 * (tb0 + wv * CS_WTILE + j * kWave + lane)];
+            if (w[j] & CS_CACHE_FLAG) {
+                const int64_t ri = tb0 + wv * CS_WTILE + j * kWave + lane;
+                if (lb) { const uint32_t w0 = (uint32_t)A.rec[2 * ri]; qs[j] = (int32_t)((uint32_t)smin + (w0 >> lb) - (w0 & ((1u << lb) - 1u))); }
+                else qs[j] = A.rec[3 * ri];
+            }
         }
         if (!TWO && tix + 1 < ntile) load_tile(q0 + (int64_t)(tix + 1) * CS_TILE);
         int al[CS_ITEMS], cnt[CS_ITEMS];

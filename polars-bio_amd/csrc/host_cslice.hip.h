@@ -142,7 +142,7 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     if (!ctx->cs_attr_set) {
         IVJ_TRY(set_dyn_lds(&k_cs_hist<true>, 96 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_hist<false>, 96 * 1024));
         IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 4, false>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 4, false>), 160 * 1024));
-        IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, false>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 8, false>), 160 * 1024));
+        IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, false>), 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_FUSED>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_FUSED>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_COUNT>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_COUNT>, 160 * 1024));
         IVJ_TRY(set_dyn_lds(&k_cs_join<true, CS_FILL>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_join<false, CS_FILL>, 160 * 1024));
@@ -163,23 +163,34 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
             IVJ_TRY(set_dyn_lds(&k_cs_sample_hist<true>, 96 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_sample_hist<false>, 96 * 1024));
             IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 4, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 4, true>), 160 * 1024));
             IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 8, true>), 160 * 1024));
+            IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 4, true, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 4, true, true>), 160 * 1024));
+            IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, true, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 8, true, true>), 160 * 1024));
             ctx->cs_sattr_set = true;
         }
-        HIP_TRY(hipMemsetAsync(ctx->sl_gh, 0, (size_t)(g.nb + 2) * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->sl_gh, 0, (size_t)(g.nb + 4) * 4, ctx->stream));
         const int64_t n_samp = (n + CS_SRATE - 1) / CS_SRATE;
         const unsigned sgrid = (unsigned)std::min<int64_t>(256, (n_samp + CS_THREADS - 1) / CS_THREADS);
         t_begin(ctx, "cs_sample");
-        if (strict) hipLaunchKernelGGL((k_cs_sample_hist<true>), dim3(sgrid), dim3(CS_THREADS), hist_lds, ctx->stream, tab, g, probe->contig, probe->end, n, ctx->sl_gh);
-        else hipLaunchKernelGGL((k_cs_sample_hist<false>), dim3(sgrid), dim3(CS_THREADS), hist_lds, ctx->stream, tab, g, probe->contig, probe->end, n, ctx->sl_gh);
+        if (strict) hipLaunchKernelGGL((k_cs_sample_hist<true>), dim3(sgrid), dim3(CS_THREADS), hist_lds + 16, ctx->stream, tab, g, probe->contig, probe->start, probe->end, n, ctx->sl_gh);
+        else hipLaunchKernelGGL((k_cs_sample_hist<false>), dim3(sgrid), dim3(CS_THREADS), hist_lds + 16, ctx->stream, tab, g, probe->contig, probe->start, probe->end, n, ctx->sl_gh);
         t_end(ctx);
-        LAUNCH(ctx, "cs_regions", k_cs_regions, 1, CS_THREADS, (const uint32_t*)ctx->sl_gh, g.nb, cs_region_slack(ctx, g, n), ctx->sl_rstart, ctx->sl_rcur);
+        // the record format of the call (8-byte records where the sample says they fit) is decided in this kernel, on the device
+        const int allow8 = (ctx->cs_env_rec8 != 0 && !ctx->cs_force_rec12) ? 1 : 0;
+        LAUNCH(ctx, "cs_regions", k_cs_regions, 1, CS_THREADS, (const uint32_t*)ctx->sl_gh, g.nb, cs_region_slack(ctx, g, n), allow8, ctx->sl_rstart, ctx->sl_rcur, ctx->sl_meta);
         unsigned long long* state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
         t_begin(ctx, "cs_scatter");
-#define IVJ_CS_SCATTER_S(S, I)                                                                                                          \
-    hipLaunchKernelGGL((k_cs_scatter<S, I, true>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, \
-                       probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_rstart, ctx->sl_rcur, state, rec, ctx->sl_env_ablate)
-        if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER_S(true, 8); else IVJ_CS_SCATTER_S(true, 4); }
-        else { if (P.part_items == 8) IVJ_CS_SCATTER_S(false, 8); else IVJ_CS_SCATTER_S(false, 4); }
+#define IVJ_CS_SCATTER_S(S, I, R8)                                                                                                      \
+    hipLaunchKernelGGL((k_cs_scatter<S, I, true, R8>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, \
+                       probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_rstart, ctx->sl_rcur, state, (const int32_t*)ctx->sl_meta, rec, ctx->sl_env_ablate)
+        // both record forms are queued; the one the device-side format word does not name returns at once (allow8 = 0: only the 12-byte form)
+        if (allow8) {
+            if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER_S(true, 8, true); else IVJ_CS_SCATTER_S(true, 4, true); }
+            else { if (P.part_items == 8) IVJ_CS_SCATTER_S(false, 8, true); else IVJ_CS_SCATTER_S(false, 4, true); }
+        }
+        t_end(ctx);
+        t_begin(ctx, allow8 ? "cs_scatter12" : "cs_scatter");
+        if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER_S(true, 8, false); else IVJ_CS_SCATTER_S(true, 4, false); }
+        else { if (P.part_items == 8) IVJ_CS_SCATTER_S(false, 8, false); else IVJ_CS_SCATTER_S(false, 4, false); }
 #undef IVJ_CS_SCATTER_S
         t_end(ctx);
         LAUNCH(ctx, "cs_chunks", k_cs_chunks_sampled, 1, SL_THREADS, (const uint32_t*)ctx->sl_rstart, (const uint32_t*)ctx->sl_rcur, g.nb, P.jchunk, ctx->sl_bstart,
@@ -208,9 +219,15 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     t_begin(ctx, "cs_scatter");
 #define IVJ_CS_SCATTER(S, I)                                                                                                            \
     hipLaunchKernelGGL((k_cs_scatter<S, I, false>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, \
-                       probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, (uint32_t*)nullptr, (unsigned long long*)nullptr, rec, ctx->sl_env_ablate)
+                       probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, (uint32_t*)nullptr, (unsigned long long*)nullptr, (const int32_t*)nullptr, rec, ctx->sl_env_ablate)
     if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER(true, 8); else IVJ_CS_SCATTER(true, 4); }
-    else { if (P.part_items == 8) IVJ_CS_SCATTER(false, 8); else IVJ_CS_SCATTER(false, 4); }
+    else {
+        // Weak + histogram-first: the 8192-probe tile form of this variant needs 2 spilled VGPRs (12 bytes of scratch per lane) at the
+        // kernel's 128-register ceiling; it takes the 4096-probe tiles instead (the chunks are whole tiles of either size)
+        const size_t lds4 = (size_t)cs_part_lds(g.nb, g.ncells, g.n_contigs, 4).total;
+        hipLaunchKernelGGL((k_cs_scatter<false, 4, false>), dim3(P.nchunks), dim3(CS_THREADS), lds4, ctx->stream, tab, g, probe->contig, probe->start,
+                           probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_blk, (uint32_t*)nullptr, (unsigned long long*)nullptr, (const int32_t*)nullptr, rec, ctx->sl_env_ablate);
+    }
 #undef IVJ_CS_SCATTER
     t_end(ctx);
     HIP_TRY(hipGetLastError());
@@ -250,6 +267,12 @@ struct CsExactScope {
     explicit CsExactScope(ivj_ctx* c) : ctx(c) { ctx->cs_force_exact = true; ++ctx->cs_sampled_overflows; }
     ~CsExactScope() { ctx->cs_force_exact = false; }
 };
+// A probe that did not fit the 8-byte record form the sample had chosen (state bit 8): the call is redone with 12-byte records.
+struct CsRec12Scope {
+    ivj_ctx* ctx;
+    explicit CsRec12Scope(ivj_ctx* c) : ctx(c) { ctx->cs_force_rec12 = true; ++ctx->cs_rec8_overflows; }
+    ~CsRec12Scope() { ctx->cs_force_rec12 = false; }
+};
 
 int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
                      int64_t capacity, int64_t* n_pairs) {
@@ -258,7 +281,7 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     IVJ_TRY(cs_plan(ctx, ix, probe->n, opts, P, wcap));
     IVJ_TRY(ensure_sl(ctx, probe->n, P, cs_sampled_wanted(ctx, probe->n, false) ? cs_record_capacity(ctx, ix->cs_g, probe->n) : 0));
     ctx->sl_plan_valid = false;
-    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));                // {pairs, flags}: the sampled scatter may set bit 4
+    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 32, ctx->stream));                // {pairs, flags}: the sampled scatter may set bits 4 / 8; the record format (0 = 12-byte records)
     IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, false));
     if (ctx->sl_env_ablate & (256 | 1024 | 2048)) { *n_pairs = 0; HIP_TRY(hipStreamSynchronize(ctx->stream)); return IVJ_OK; }   // profiling: the records are not usable
     IVJ_TRY(cs_join_launch<CS_FUSED>(ctx, ix, opts, P, (long long)capacity, out_p, out_b));
@@ -267,6 +290,10 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     HIP_TRY(hipGetLastError());
     if ((ctx->h_total[1] & 4) && ctx->sl_sampled) {
         CsExactScope redo(ctx);
+        return cs_overlap_fused(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
+    }
+    if ((ctx->h_total[1] & CS_STATE_REC8) && ctx->sl_sampled && !ctx->cs_force_rec12) {
+        CsRec12Scope redo(ctx);
         return cs_overlap_fused(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
     }
     *n_pairs = ctx->h_total[0];
@@ -287,7 +314,7 @@ int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     const bool stable = opts->deterministic != 0 || ctx->sl_env_stable != 0;
     IVJ_TRY(ensure_sl(ctx, probe->n, P, cs_sampled_wanted(ctx, probe->n, stable) ? cs_record_capacity(ctx, ix->cs_g, probe->n) : 0));
     ctx->sl_plan_valid = false;
-    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 16, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 32, ctx->stream));
     IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, stable));
     HIP_TRY(hipMemsetAsync(ctx->sl_tile, 0, (size_t)(P.ntiles + 2) * 8, ctx->stream));
     IVJ_TRY(cs_join_launch<CS_COUNT>(ctx, ix, opts, P, 0, nullptr, nullptr));
@@ -298,6 +325,10 @@ int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     HIP_TRY(hipGetLastError());
     if ((ctx->h_total[1] & 4) && ctx->sl_sampled) {
         CsExactScope redo(ctx);
+        return cs_overlap_count(ctx, ix, probe, opts, n_pairs);
+    }
+    if ((ctx->h_total[1] & CS_STATE_REC8) && ctx->sl_sampled && !ctx->cs_force_rec12) {
+        CsRec12Scope redo(ctx);
         return cs_overlap_count(ctx, ix, probe, opts, n_pairs);
     }
     ctx->sl_plan_valid = true;

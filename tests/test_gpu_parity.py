@@ -1326,3 +1326,38 @@ def test_balanced_index_build_is_the_default_at_bench_sizes():
             assert len(p) == len(ep) and (p == ep).all() and (b == eb).all()
     finally:
         e.close()
+
+
+def test_eight_byte_probe_records_and_their_fallback(monkeypatch):
+    """Round 5: where the sample says a call's probes fit {(end - slice minimum) << LB | length, row}, the partition writes 8-byte
+    records and the join unpacks them (the 12-byte scatter, queued behind, returns at once); a probe the sample missed that does NOT
+    fit (long rows placed between the sampled groups) raises the state bit and the call is redone with 12-byte records.  Exact pairs
+    either way, fused pass and count -> fill pair, Strict and Weak."""
+    monkeypatch.setenv("IVJ_CS", "1")
+    build = synth.make_side(120_000, 43, synth.BUILD_LEN, 24)
+    probe = synth.make_side(400_000, 42, synth.PROBE_LEN, 24)
+    long_probe = tuple(a.copy() for a in probe)
+    idx = np.arange(100, 400_000, 512 * 37)                                     # rows the 1 / 64 sample (8 rows every 512) never sees
+    long_probe[2][idx] = np.minimum(long_probe[1][idx].astype(np.int64) + 3_000_000, np.iinfo(np.int32).max).astype(np.int32)
+    e = _engine.Engine(0)
+    try:
+        e.enable_timing(2)
+        for strict in (True, False):
+            for name, pr, redo in (("fits", probe, False), ("outliers", long_probe, True)):
+                ep, eb = O.overlap_fast(O.Index(O.Side(*build), 24), O.Side(*pr), strict)
+                oe = np.lexsort((eb, ep))
+                e.timings()
+                hp, hb = _fused_overlap(e, pr, build, strict, 24, 6, len(ep))
+                t = e.timings()
+                o = np.lexsort((hb, hp))
+                assert (hp[o] == ep[oe]).all() and (hb[o] == eb[oe]).all(), (name, strict, "fused")
+                assert "cs_scatter12" in t, sorted(t)
+                if redo:
+                    assert t["cs_scatter"]["launches"] == 2, (name, t["cs_scatter"])       # the 8-byte attempt + the redo with 12-byte records
+                else:
+                    assert t["cs_scatter"]["launches"] == 1 and t["cs_scatter12"]["ms"] < 0.5 * t["cs_scatter"]["ms"], (name, t)
+                p, b = e.overlap(pr, build, strict, 24, partition_mode=6)      # count -> fill pair
+                o = np.lexsort((b, p))
+                assert len(p) == len(ep) and (p[o] == ep[oe]).all() and (b[o] == eb[oe]).all(), (name, strict, "pair")
+    finally:
+        e.close()
