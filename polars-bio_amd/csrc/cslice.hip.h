@@ -907,8 +907,11 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
 #pragma unroll
             for (int j = 0; j < CS_ITEMS; ++j) {
                 const int il = wv * CS_WTILE + j * kWave + lane;
-                nxt[j].x = 0; nxt[j].y = 0; nxt[j].z = -1;
-                if (il < rem) { const cs_rec8 v = __builtin_nontemporal_load(reinterpret_cast<const cs_rec8*>(tp + 2 * il)); nxt[j].x = v.x; nxt[j].z = v.y; }
+                // (the two words land in the record's LOW components: the load then targets the registers itself -- with the row in
+                // .z the compiler loaded into a temporary and waited for it at once, which serialised the prefetch: join 0.93 -> 1.11 ms)
+                cs_rec8 v; v.x = 0; v.y = -1;
+                if (il < rem) v = __builtin_nontemporal_load(reinterpret_cast<const cs_rec8*>(tp + 2 * il));
+                nxt[j].x = v.x; nxt[j].y = v.y;
             }
             return;
         }
@@ -937,11 +940,12 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
             qs[j] = nxt[j].x; qe[j] = nxt[j].y; qrow[j] = nxt[j].z;
             valid[j] = wv * CS_WTILE + j * kWave + lane < rem;
         }
-        if (lb) {                                                              // uniform: unpack the 8-byte form
+        if (lb) {                                                              // uniform: unpack the 8-byte form {packed word, row}
             const uint32_t lmask = (1u << lb) - 1u;
 #pragma unroll
             for (int j = 0; j < CS_ITEMS; ++j) {
                 const uint32_t w0 = (uint32_t)qs[j];
+                qrow[j] = qe[j];
                 qe[j] = (int32_t)((uint32_t)smin + (w0 >> lb));
                 qs[j] = (int32_t)((uint32_t)qe[j] - (w0 & lmask));
             }
@@ -1328,8 +1332,11 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
 #pragma unroll
             for (int j = 0; j < CS_ITEMS; ++j) {
                 const int il = wv * CS_WTILE + j * kWave + lane;
-                nxt[j].x = 0; nxt[j].y = 0; nxt[j].z = -1;
-                if (il < rem) { const cs_rec8 v = __builtin_nontemporal_load(reinterpret_cast<const cs_rec8*>(tp + 2 * il)); nxt[j].x = v.x; nxt[j].z = v.y; }
+                // (the two words land in the record's LOW components: the load then targets the registers itself -- with the row in
+                // .z the compiler loaded into a temporary and waited for it at once, which serialised the prefetch: join 0.93 -> 1.11 ms)
+                cs_rec8 v; v.x = 0; v.y = -1;
+                if (il < rem) v = __builtin_nontemporal_load(reinterpret_cast<const cs_rec8*>(tp + 2 * il));
+                nxt[j].x = v.x; nxt[j].y = v.y;
             }
             return;
         }
@@ -1377,11 +1384,12 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
             qs[j] = nxt[j].x; qe[j] = nxt[j].y; qrow[j] = nxt[j].z;
             valid[j] = wv * CS_WTILE + j * kWave + lane < rem;
         }
-        if (lb) {                                                              // uniform: unpack the 8-byte form
+        if (lb) {                                                              // uniform: unpack the 8-byte form {packed word, row}
             const uint32_t lmask = (1u << lb) - 1u;
 #pragma unroll
             for (int j = 0; j < CS_ITEMS; ++j) {
                 const uint32_t w0 = (uint32_t)qs[j];
+                qrow[j] = qe[j];
                 qe[j] = (int32_t)((uint32_t)smin + (w0 >> lb));
                 qs[j] = (int32_t)((uint32_t)qe[j] - (w0 & lmask));
             }

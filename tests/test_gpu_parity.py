@@ -1334,10 +1334,10 @@ def test_eight_byte_probe_records_and_their_fallback(monkeypatch):
     fit (long rows placed between the sampled groups) raises the state bit and the call is redone with 12-byte records.  Exact pairs
     either way, fused pass and count -> fill pair, Strict and Weak."""
     monkeypatch.setenv("IVJ_CS", "1")
-    build = synth.make_side(120_000, 43, synth.BUILD_LEN, 24)
-    probe = synth.make_side(400_000, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(3_000_000, 43, synth.BUILD_LEN, 24)                 # ~ 980 slices of ~ 3.2 Mbp: 22 offset bits + 9 length bits
+    probe = synth.make_side(1_000_000, 42, synth.PROBE_LEN, 24)
     long_probe = tuple(a.copy() for a in probe)
-    idx = np.arange(100, 400_000, 512 * 37)                                     # rows the 1 / 64 sample (8 rows every 512) never sees
+    idx = np.arange(100, 1_000_000, 512 * 37)                                   # rows the 1 / 64 sample (8 rows every 512) never sees
     long_probe[2][idx] = np.minimum(long_probe[1][idx].astype(np.int64) + 3_000_000, np.iinfo(np.int32).max).astype(np.int32)
     e = _engine.Engine(0)
     try:
