@@ -178,7 +178,7 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         const int allow8 = (ctx->cs_env_rec8 != 0 && !ctx->cs_force_rec12) ? 1 : 0;
         LAUNCH(ctx, "cs_regions", k_cs_regions, 1, CS_THREADS, (const uint32_t*)ctx->sl_gh, g.nb, cs_region_slack(ctx, g, n), allow8, ctx->sl_rstart, ctx->sl_rcur, ctx->sl_meta);
         unsigned long long* state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
-        t_begin(ctx, "cs_scatter");
+        if (allow8) t_begin(ctx, "cs_scatter");
 #define IVJ_CS_SCATTER_S(S, I, R8)                                                                                                      \
     hipLaunchKernelGGL((k_cs_scatter<S, I, true, R8>), dim3(P.nchunks), dim3(CS_THREADS), P.part_lds, ctx->stream, tab, g, probe->contig, probe->start, \
                        probe->end, probe->row_id, n, P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_rstart, ctx->sl_rcur, state, (const int32_t*)ctx->sl_meta, rec, ctx->sl_env_ablate)
@@ -186,8 +186,8 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         if (allow8) {
             if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER_S(true, 8, true); else IVJ_CS_SCATTER_S(true, 4, true); }
             else { if (P.part_items == 8) IVJ_CS_SCATTER_S(false, 8, true); else IVJ_CS_SCATTER_S(false, 4, true); }
+            t_end(ctx);
         }
-        t_end(ctx);
         t_begin(ctx, allow8 ? "cs_scatter12" : "cs_scatter");
         if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER_S(true, 8, false); else IVJ_CS_SCATTER_S(true, 4, false); }
         else { if (P.part_items == 8) IVJ_CS_SCATTER_S(false, 8, false); else IVJ_CS_SCATTER_S(false, 4, false); }
@@ -288,6 +288,7 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_meta + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
+    if (std::getenv("IVJ_DEBUG_REDO")) std::fprintf(stderr, "[ivj] cs_overlap_fused: state flags %lld (sampled %d, exact %d, rec12 %d), pairs %lld\n", (long long)ctx->h_total[1], (int)ctx->sl_sampled, (int)ctx->cs_force_exact, (int)ctx->cs_force_rec12, (long long)ctx->h_total[0]);
     if ((ctx->h_total[1] & 4) && ctx->sl_sampled) {
         CsExactScope redo(ctx);
         return cs_overlap_fused(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
