@@ -96,8 +96,11 @@ struct ivj_ctx {
     uint32_t* pt_bstart = nullptr;     // PART_BUCKETS + 1 bucket starts of the last one-level partition
     bool part_attr_set = false;
     bool os_attr_set = false;
+    hipEvent_t cs_event = nullptr;     // marks the read-back of an index's far-row count (host_cslice.hip.h: cs_ensure_tables / cs_resolve_tables)
+    const ivj_index* cs_far_owner = nullptr;   //   ... whose count the pinned slot holds
     hipEvent_t ix3_event = nullptr;    // marks the read-back of the balanced build's {bad, largest bucket}
     bool ix3_attr_set = false;         // index build, round 5 (ixsort3.hip.h): LDS attributes set once
+    int env_ix_stage = -1;             // IVJ_IX_STAGE: the balanced build's local kernel with (1) / without (0) the rows staged in LDS; -1 by bucket size
     int env_ix_v3 = -1;                // IVJ_IX_V3: -1 by size, 0 never (the round-2 LSD sort), 1 wherever it applies
     int64_t ix3_fallbacks = 0;         // builds the balanced pass handed back to the LSD sort (a bucket above V3_CAP rows, keys beyond 32 bits)
     // slice path (host_slice.hip.h): bucket-ordered probe records, histogram, chunk table, tile totals
@@ -193,6 +196,7 @@ struct ivj_index {
     // contig-aligned slice path (cslice.hip.h): geometry fixed at build time, arrays in the slab, filled on first use
     CsGeom cs_g{0, 0, 0, 0, 0};
     bool cs_ok = false, cs_built = false;
+    bool cs_far_pending = false;         // the far-row count is on its way to the host: cs_walk is decided by cs_resolve_tables
     bool cs_walk = false;                // k_cs_join (windows that run on walk the block maxima) instead of k_cs_join_plain
     int64_t cs_far = 0;                  // rows whose window would overflow the branch-free one (k_cs_bins)
     int32_t* cs_bound = nullptr;

@@ -74,16 +74,35 @@ int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix) {
     // branch-free one.  Above CS_FAR_LIMIT (a tail of long rows: genes among exons, a contig-wide row) windows that run on are the
     // rule and k_cs_join walks them over the block maxima; below it (the synthetic configs: 2e-4) they are the rare exception
     // and k_cs_join_plain recounts them row by row -- without the walk in its hot loops and without the maxima being built.
-    // One 4-byte copy + stream synchronisation per index.  IVJ_CS_WALK = 0 / 1 forces the choice (tests, A/B runs).
-    {
+    // Round 5: the 4-byte count travels to the host behind an EVENT, not a stream synchronisation -- the partition of the call is
+    // queued right behind it and the host reads the count (cs_resolve_tables, before the join is launched) while the scatter
+    // runs: no bubble in the stream (round 4 synchronised here: ~ 20 us per index).  IVJ_CS_WALK = 0 / 1 forces the choice.
+    HIP_TRY(hipMemcpyAsync(ctx->h_total + 5, ix->flags + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->cs_event) HIP_TRY(hipEventCreateWithFlags(&ctx->cs_event, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->cs_event, ctx->stream));
+    ix->cs_far_pending = true;
+    ctx->cs_far_owner = ix;
+    ix->cs_built = true;
+    return IVJ_OK;
+}
+
+// the join kernel of the index (and the block maxima, when it is the walking one): called before the first join / fill launch
+int cs_resolve_tables(ivj_ctx* ctx, ivj_index* ix) {
+    if (!ix->cs_far_pending) return IVJ_OK;
+    if (ctx->cs_far_owner == ix) {
+        HIP_TRY(hipEventSynchronize(ctx->cs_event));
+        ix->cs_far = *reinterpret_cast<const int32_t*>(ctx->h_total + 5);
+        ctx->cs_far_owner = nullptr;
+    } else {
+        // another index's tables were launched in between and took the pinned slot: read this index's count again (rare)
         HIP_TRY(hipMemcpyAsync(ctx->h_total + 5, ix->flags + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ix->cs_far = *reinterpret_cast<const int32_t*>(ctx->h_total + 5);
-        const double share = ix->n > 0 ? (double)ix->cs_far / (double)ix->n : 0.0;
-        ix->cs_walk = ctx->cs_env_walk >= 0 ? ctx->cs_env_walk != 0 : share > CS_FAR_LIMIT;
     }
+    const double share = ix->n > 0 ? (double)ix->cs_far / (double)ix->n : 0.0;
+    ix->cs_walk = ctx->cs_env_walk >= 0 ? ctx->cs_env_walk != 0 : share > CS_FAR_LIMIT;
+    ix->cs_far_pending = false;
     if (ix->cs_walk) IVJ_TRY(ensure_hier(ctx, ix));
-    ix->cs_built = true;
     return IVJ_OK;
 }
 
@@ -237,6 +256,7 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
 template <int MODE>
 int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const SlicePlan& P, long long capacity, int32_t* out_p, int32_t* out_b) {
     const CsGeom& g = ix->cs_g;
+    IVJ_TRY(cs_resolve_tables(ctx, ix));
     CsJoinArgs A;
     A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta; A.hier = view_of(ix).hier;
     A.rec = reinterpret_cast<int32_t*>(ctx->sl_rec); A.bstart = ctx->sl_bstart; A.bend = ctx->sl_sampled ? ctx->sl_bend : nullptr; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;
@@ -342,6 +362,7 @@ int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
 // rows of a slice + the tile's probe rows + the staging fit 80 KB.  IVJ_CS_NOCACHE=1 keeps the round-3 form (match again).
 int cs_fill_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const SlicePlan& P, int32_t* out_p, int32_t* out_b) {
     const CsGeom& g = ix->cs_g;
+    IVJ_TRY(cs_resolve_tables(ctx, ix));
     CsJoinArgs A;
     A.b_start = ix->b_start; A.ep = ix->ep; A.b_row = ix->b_row; A.bins = ix->cs_bins; A.smeta = ix->cs_smeta; A.hier = view_of(ix).hier;
     A.rec = reinterpret_cast<int32_t*>(ctx->sl_rec); A.bstart = ctx->sl_bstart; A.bend = ctx->sl_sampled ? ctx->sl_bend : nullptr; A.meta = ctx->sl_meta; A.wg_map = ctx->sl_map;

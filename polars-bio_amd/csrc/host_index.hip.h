@@ -291,10 +291,11 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     unsigned long long* st_scan = (unsigned long long*)(z + z_meta + z_st);
     uint32_t* tick_scan = (uint32_t*)(z + z_meta + z_st + z_hs);
     HIP_TRY(hipMemsetAsync(z, 0, zero_bytes, ctx->stream));
-    const size_t pass_lds = (size_t)v3_pass_lds().total, local_lds = (size_t)v3_local_lds().total;
+    const size_t pass_lds = (size_t)v3_pass_lds().total;
     if (!ctx->ix3_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)local_lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_local<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_local<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->ix3_attr_set = true;
     }
     const unsigned sgrid = (unsigned)(tiles < 512 ? tiles : 512);
@@ -316,9 +317,17 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     HIP_TRY(hipEventSynchronize(ctx->ix3_event));
     const uint32_t* hv = reinterpret_cast<const uint32_t*>(ctx->h_total + 6);
     if (hv[0] != 0u || hv[1] > (uint32_t)V3_CAP) { ++ctx->ix3_fallbacks; return IVJ_OK; }
+    // the local kernel's LDS follows the LARGEST bucket (known now): rows staged in LDS while two workgroups still share a CU
+    // (<= 2048 rows), beyond that the rows are read again from their L2-resident records (IVJ_IX_STAGE = 0 / 1 forces either form)
+    const int cap = (int)std::max<uint32_t>(1024u, (hv[1] + 1023u) / 1024u * 1024u);
+    const int bin_bits = cap <= 1024 ? 10 : (cap <= 2048 ? 11 : V3_MAX_BIN_BITS);
+    const bool stage = ctx->env_ix_stage >= 0 ? ctx->env_ix_stage != 0 : cap <= 2048;
+    const size_t local_lds = (size_t)v3_local_lds(cap, 1 << bin_bits, stage).total;
     t_begin(ctx, "ix3_local");
-    hipLaunchKernelGGL(k_v3_local, dim3(V3_BUCKETS), dim3(OS_THREADS), local_lds, ctx->stream, (const int4*)recs, (const uint32_t*)hist, nchunks, n, nc, meta, st_local,
-                       ix->b_start, ix->ep, ix->b_row, ix->b_contig, ix->seg, ix->flags);
+    if (stage) hipLaunchKernelGGL(k_v3_local<true>, dim3(V3_BUCKETS), dim3(OS_THREADS), local_lds, ctx->stream, (const int4*)recs, (const uint32_t*)hist, nchunks, n, nc, cap, bin_bits,
+                                  meta, st_local, ix->b_start, ix->ep, ix->b_row, ix->b_contig, ix->seg, ix->flags);
+    else hipLaunchKernelGGL(k_v3_local<false>, dim3(V3_BUCKETS), dim3(OS_THREADS), local_lds, ctx->stream, (const int4*)recs, (const uint32_t*)hist, nchunks, n, nc, cap, bin_bits,
+                            meta, st_local, ix->b_start, ix->ep, ix->b_row, ix->b_contig, ix->seg, ix->flags);
     t_end(ctx);
     HIP_TRY(hipGetLastError());
     *done = true;

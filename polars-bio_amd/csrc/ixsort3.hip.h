@@ -34,8 +34,7 @@ constexpr int V3_BUCKETS = OS_RADIX;                   // 2048: the pass kernel'
 constexpr int V3_ITEMS = 4;
 constexpr int V3_CAP = OS_THREADS * V3_ITEMS;          // rows of one bucket the local kernel holds in LDS
 constexpr int V3_MAX_KEYS = 256;                       // contig keys 0 .. n_contigs (the last one: rows outside the dictionary)
-constexpr int V3_BIN_BITS = 12;                        // bins of the local counting pass: 4096 (>= V3_CAP: below one row per bin)
-constexpr int V3_BINS = 1 << V3_BIN_BITS;
+constexpr int V3_MAX_BIN_BITS = 12;                    // bins of the local counting pass: up to 4096 (>= the bucket capacity: below one row per bin)
 
 struct V3Meta {                                        // device-resident, zero-initialised before every build
     uint32_t inverted;                                 // some row of the dictionary has start > end
@@ -288,16 +287,20 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_scatter(const int32_t* __rest
 }
 
 // ---- one workgroup per bucket: LDS sort + index arrays ------------------------------------------------------------------------------
+// cap = rows the launch's buckets hold at most (the host knows the largest bucket: a multiple of 1024), bins = 1 << bin_bits >= cap.
+// STAGE: the rows themselves wait in LDS (16 bytes per row) -- two workgroups share a CU up to cap = 2048; beyond, the rows are
+// fetched again from the bucket's 16-byte records (contiguous, L2-resident) where the index arrays are written, and 8 bytes per row
+// of LDS keep two workgroups per CU at cap = 3072 as well.
 struct V3LocalLds { int rec, bst, cur, tk, ts, ifin, tbase, tcmin, wsum, total; };
-__host__ __device__ inline V3LocalLds v3_local_lds() {
+__host__ __device__ inline V3LocalLds v3_local_lds(int cap, int bins, bool stage) {
     V3LocalLds L;
     int o = 0;
-    L.rec = o; o += 16 * V3_CAP;
-    L.bst = o; o += 4 * (V3_BINS + 4);                 // bin counts, then bin starts (exclusive scan); [V3_BINS] = rows of the bucket
-    L.cur = o; o += 4 * V3_BINS;                       // running cursor of every bin
-    L.tk = o; o += 4 * V3_CAP;                         // keys in bin order (after the ranking: the prefix maxima per sorted position)
-    L.ts = o; o += 2 * V3_CAP;                         // slots in bin order
-    L.ifin = o; o += 2 * V3_CAP;                       // slot of the row at sorted position q
+    L.rec = o; o += stage ? 16 * cap : 0;
+    L.bst = o; o += 4 * (bins + 4);                    // bin counts, then bin starts (exclusive scan); [bins] = rows of the bucket
+    L.cur = o; o += 4 * bins;                          // running cursor of every bin
+    L.tk = o; o += 4 * cap;                            // keys in bin order (after the ranking: the prefix maxima per sorted position)
+    L.ts = o; o += 2 * cap;                            // slots in bin order
+    L.ifin = o; o += 2 * cap;                          // slot of the row at sorted position q
     L.tbase = o; o += 4 * V3_MAX_KEYS;
     L.tcmin = o; o += 4 * V3_MAX_KEYS;
     L.wsum = (o + 15) & ~15; o = L.wsum + 8 * OS_WAVES;
@@ -305,12 +308,14 @@ __host__ __device__ inline V3LocalLds v3_local_lds() {
     return L;
 }
 
-__global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict__ rec, const uint32_t* __restrict__ off, int nchunks, int64_t n,
-                                                        int32_t n_contigs, V3Meta* __restrict__ meta, unsigned long long* __restrict__ status64,
+template <bool STAGE>
+__global__ __launch_bounds__(OS_THREADS, 8) void k_v3_local(const int4* __restrict__ rec, const uint32_t* __restrict__ off, int nchunks, int64_t n,
+                                                        int32_t n_contigs, int cap, int bin_bits, V3Meta* __restrict__ meta, unsigned long long* __restrict__ status64,
                                                         int32_t* __restrict__ b_start, int2* __restrict__ ep, int32_t* __restrict__ b_row,
                                                         int32_t* __restrict__ b_contig, int32_t* __restrict__ seg, int32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char os_lds[];
-    const V3LocalLds L = v3_local_lds();
+    const int bins = 1 << bin_bits;
+    const V3LocalLds L = v3_local_lds(cap, bins, STAGE);
     int4* l_rec = reinterpret_cast<int4*>(os_lds + L.rec);
     uint32_t* bst = reinterpret_cast<uint32_t*>(os_lds + L.bst);
     uint32_t* cur = reinterpret_cast<uint32_t*>(os_lds + L.cur);
@@ -333,15 +338,17 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
         l_lo = (uint32_t)((((unsigned long long)t << 32) + M - 1ull) / M);      // smallest linear key of bucket t
     }
     v3_load_tables(meta, n_contigs + 1, l_base, l_cmin);
-    for (int k = tid; k < V3_BINS; k += OS_THREADS) { bst[k] = 0u; cur[k] = 0u; }
+    for (int k = tid; k < bins; k += OS_THREADS) { bst[k] = 0u; cur[k] = 0u; }
     __syncthreads();
     const int tile = l_tile;
     const uint32_t lo = l_lo;
     const uint32_t b0 = off[(int64_t)tile * nchunks];
     const uint32_t b1 = tile + 1 < V3_BUCKETS ? off[(int64_t)(tile + 1) * nchunks] : (uint32_t)n;
-    const int nb = (int)(b1 - b0);                                              // <= V3_CAP: checked by the host before this launch
+    const int nb = (int)(b1 - b0);                                              // <= cap: the host sized cap from the largest bucket
     const int wbits = (int)meta->wbits;
-    const int bshift = wbits > V3_BIN_BITS ? wbits - V3_BIN_BITS : 0;           // bin = key >> bshift < 4096
+    const int bshift = wbits > bin_bits ? wbits - bin_bits : 0;                 // bin = key >> bshift < bins
+    const int4* __restrict__ grec = rec + (int64_t)b0;                          // the bucket's rows in input order (slot p)
+    auto row_at = [&](int p) -> int4 { if constexpr (STAGE) return l_rec[p]; else return grec[p]; };
 
     // rows of the bucket -> LDS (slot p = input order inside the bucket: item j of thread t = j * 1024 + t), bin counts, bucket maximum
     uint32_t kv[V3_ITEMS];
@@ -351,8 +358,8 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
         const int p = j * OS_THREADS + tid;
         kv[j] = 0u;
         if (p < nb) {
-            const int4 r = rec[(int64_t)b0 + p];
-            l_rec[p] = r;
+            const int4 r = grec[p];
+            if constexpr (STAGE) l_rec[p] = r;
             kv[j] = l_base[r.w] + (flip(r.x) - l_cmin[r.w]) - lo;
             atomicAdd(&bst[kv[j] >> bshift], 1u);
             const unsigned long long c = ((unsigned long long)(uint32_t)r.w << 32) | (unsigned long long)flip(r.y);
@@ -371,17 +378,19 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
         for (int k = 0; k < OS_WAVES; ++k) tmax = wmax[k] > tmax ? wmax[k] : tmax;
         os_st64(status64 + tile, ((tile == 0 ? 2ull : 1ull) << 62) | tmax);
     }
-    // exclusive scan of the bin counts: thread t owns the bins 4 t .. 4 t + 3
+    // exclusive scan of the bin counts: thread t owns the bins 4 t .. 4 t + 3 (threads beyond the bins hold zeros)
     {
-        uint4 c4 = *reinterpret_cast<const uint4*>(bst + 4 * tid);
+        const bool own = 4 * tid < bins;
+        uint4 c4 = make_uint4(0u, 0u, 0u, 0u);
+        if (own) c4 = *reinterpret_cast<const uint4*>(bst + 4 * tid);
         const uint32_t s = c4.x + c4.y + c4.z + c4.w;
         __syncthreads();                                                        // (wmax read by thread 0 before wsum is reused)
         uint32_t tsum;
         uint32_t pre = sl_block_exclusive_sum<uint32_t>(s, wsum, &tsum);
         uint4 o4;
         o4.x = pre; pre += c4.x; o4.y = pre; pre += c4.y; o4.z = pre; pre += c4.z; o4.w = pre;
-        *reinterpret_cast<uint4*>(bst + 4 * tid) = o4;
-        if (tid == 0) bst[V3_BINS] = (uint32_t)nb;
+        if (own) *reinterpret_cast<uint4*>(bst + 4 * tid) = o4;
+        if (tid == 0) bst[bins] = (uint32_t)nb;
     }
     __syncthreads();                                                            // (B) bin starts
 #pragma unroll
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
         unsigned long long c = 0ull;
         cc[k] = 0;
         if (q < nb) {
-            const int4 r = l_rec[iF[q]];
+            const int4 r = row_at(iF[q]);
             c = ((unsigned long long)(uint32_t)r.w << 32) | (unsigned long long)flip(r.y);
             cc[k] = r.w;
         }
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
         comp[k] = run;
     }
     int32_t prev_c = -1;
-    if (tid > 0 && V3_ITEMS * tid < nb) prev_c = l_rec[iF[V3_ITEMS * tid - 1]].w;
+    if (tid > 0 && V3_ITEMS * tid < nb) prev_c = row_at(iF[V3_ITEMS * tid - 1]).w;
     unsigned long long inc = run;
 #pragma unroll
     for (int dd = 1; dd < kWave; dd <<= 1) {
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_local(const int4* __restrict_
     for (int j = 0; j < V3_ITEMS; ++j) {
         const int q = j * OS_THREADS + tid;
         if (q < nb) {
-            const int4 r = l_rec[iF[q]];
+            const int4 r = row_at(iF[q]);
             const int64_t g = (int64_t)b0 + q;
             b_start[g] = r.x;
             ep[g] = make_int2(r.y, unflip(l_pm[q]));
