@@ -294,8 +294,8 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     const size_t pass_lds = (size_t)v3_pass_lds().total;
     if (!ctx->ix3_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_local<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_local<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_local<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_local<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         ctx->ix3_attr_set = true;
     }
     const unsigned sgrid = (unsigned)(tiles < 512 ? tiles : 512);
