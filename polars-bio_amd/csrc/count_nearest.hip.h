@@ -207,9 +207,10 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
 }
 
 // k = 1 over the nearest LINES (index_build.hip.h, k_nearest_lines): probes in INPUT order, no bucketing, no inverse permutation.  One
-// 128-byte line per probe -- the start-table record of the bin its end falls into AND the records of the three positions hi can take
-// there -- fetched with seven independent 16-byte loads; only a bin with a third row below the probe's end, or a probe outside its
-// contig's table, takes the second (dependent) gather from nrec.  Per-contig metadata in LDS (n_contigs <= CM_LDS).
+// 64-byte line per probe (round 5; round 4: 128 bytes) -- the nearest record of the first position of the bin its end falls into AND
+// the three rows from there on, from which the records of the positions hi can take are replayed in registers -- fetched with four
+// independent 16-byte loads; only a bin with a fourth row below the probe's end, or a probe outside its contig's table, takes the
+// second (dependent) gather from nrec.  Per-contig metadata in LDS (n_contigs <= CM_LDS).
 template <bool STRICT, int N>
 __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_lines(IndexView ix, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
                                                                     const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
@@ -233,26 +234,26 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_lines(IndexView ix
     load_items_nt(pc, i0, n, vec_ok, -1, c);
     load_items_nt(ps, i0, n, vec_ok, 0, s);
     load_items_nt(pe, i0, n, vec_ok, 0, e);
-    int a[N], b[N], hi[N], shift[N];
+    int a[N], b[N], hi[N];
     unsigned long long tu[N];
-    uint32_t ulo[N];
     bool inb[N];
-    int4 W0[N], W1[N], W2[N], W3[N], W4[N], W5[N], W6[N];
+    int4 W0[N], W1[N], W2[N], W3[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        W0[k] = W1[k] = W2[k] = W3[k] = W4[k] = W5[k] = W6[k] = make_int4(0, 0, 0, 0);
+        W0[k] = W1[k] = W2[k] = W3[k] = make_int4(0, 0, 0, 0);
         const bool ok = i0 + k < n && (uint32_t)c[k] < (uint32_t)ix.n_contigs;
         int4 m0 = make_int4(0, 0, 0, 0), m1 = make_int4(0, 0, 0, 0);
         if (ok) { m0 = l_cm[2 * c[k]]; m1 = l_cm[2 * c[k] + 1]; }
-        a[k] = m0.x; b[k] = m0.y; ulo[k] = (uint32_t)m0.z; shift[k] = m1.x;
+        a[k] = m0.x; b[k] = m0.y;
+        const uint32_t ulo = (uint32_t)m0.z;
         tu[k] = (unsigned long long)flip(e[k]) + (STRICT ? 0ull : 1ull);
         inb[k] = false; hi[k] = a[k];
-        if (b[k] <= a[k] || tu[k] <= (unsigned long long)ulo[k]) hi[k] = a[k];
+        if (b[k] <= a[k] || tu[k] <= (unsigned long long)ulo) hi[k] = a[k];
         else if (tu[k] > (unsigned long long)(uint32_t)m0.w) hi[k] = b[k];
         else {
             inb[k] = true;
-            const int4* line = ix.nline + 8 * (int64_t)((uint32_t)m1.y + (((uint32_t)tu[k] - ulo[k]) >> m1.x));
-            W0[k] = line[0]; W1[k] = line[1]; W2[k] = line[2]; W3[k] = line[3]; W4[k] = line[4]; W5[k] = line[5]; W6[k] = line[6];
+            const int4* line = ix.nline + 4 * (int64_t)((uint32_t)m1.y + (((uint32_t)tu[k] - ulo) >> m1.x));
+            W0[k] = line[0]; W1[k] = line[1]; W2[k] = line[2]; W3[k] = line[3];
         }
     }
     int4 R[N], Q[N];
@@ -260,33 +261,49 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_lines(IndexView ix
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         R[k] = make_int4(0, -1, 0, 0); Q[k] = make_int4(-1, 0, -1, (int)0x80000000);
-        far[k] = i0 + k < n && b[k] > a[k];                                   // the record comes from nrec (outside the table / crowded bin)
+        far[k] = i0 + k < n && b[k] > a[k];                                   // the record comes from nrec (outside the table / a fourth row of the bin)
         if (inb[k]) {
-        // rank inside the bin from the start-table record (index_view.hip.h, lb_tab4): six inline key offsets, or three keys of a wide bin
-        const int4 rec = W0[k];
-        const int p0 = rec.x & 0x7fffffff;
-        int lo;
-        if (shift[k] <= 16) {
-            const uint32_t toff = ((uint32_t)tu[k] - ulo[k]) & ((1u << shift[k]) - 1u);
-            const uint32_t w1 = (uint32_t)rec.y, w2 = (uint32_t)rec.z, w3 = (uint32_t)rec.w;
-            const int cnt = ((w1 & 0xffffu) < toff ? 1 : 0) + ((w1 >> 16) < toff ? 1 : 0) + ((w2 & 0xffffu) < toff ? 1 : 0) +
-                            ((w2 >> 16) < toff ? 1 : 0) + ((w3 & 0xffffu) < toff ? 1 : 0) + ((w3 >> 16) < toff ? 1 : 0);
-            lo = p0 + cnt;
-        } else {
-            const bool n0 = (unsigned long long)flip(rec.y) < tu[k];
-            const bool n1 = n0 && (unsigned long long)flip(rec.z) < tu[k];
-            const bool n2 = n1 && (unsigned long long)flip(rec.w) < tu[k];
-            lo = p0 + (n0 ? 1 : 0) + (n1 ? 1 : 0) + (n2 ? 1 : 0);
-        }
-        hi[k] = lo;
-        const int d = lo - p0;                                                  // (a crowded bin, full && more, has d = 6 or 3: left to the list)
-        if (d <= 2) {
-            far[k] = false;
-            // (masks, not selects: the compiler turns a three-way select over loaded registers into an indexed read of a stack copy)
-            const int k0 = -(int)(d == 0), k1 = -(int)(d == 1), k2 = -(int)(d == 2);
-            R[k] = sel3(k0, W1[k], k1, W3[k], k2, W5[k]);
-            Q[k] = sel3(k0, W2[k], k1, W4[k], k2, W6[k]);
-        }
+            // the 64-byte line (index_build.hip.h, k_nearest_lines): {p0 | first << 30, record of p0, rows p0, p0 + 1, p0 + 2}
+            const int p0 = W0[k].x & 0x3fffffff;
+            const bool first = (W0[k].x & 0x40000000) != 0;
+            int32_t pm = W0[k].y, ar = W0[k].z, l1v = W0[k].w, l1r = W1[k].x, l2v = W1[k].y;
+            const int32_t s0 = W1[k].z, e0 = W1[k].w, r0 = W2[k].x, s1 = W2[k].y, e1 = W2[k].z, r1 = W2[k].w, s2 = W3[k].x, e2 = W3[k].y, r2 = W3[k].z;
+            // rank inside the bin: rows of later bins start above the target, rows past the segment carry INT32_MAX
+            // (a row past the segment has build row -1: it must not count even for the one target above INT32_MAX, a Weak probe ending there)
+            const bool n0 = r0 >= 0 && (unsigned long long)flip(s0) < tu[k];
+            const bool n1 = n0 && r1 >= 0 && (unsigned long long)flip(s1) < tu[k];
+            const bool n2 = n1 && r2 >= 0 && (unsigned long long)flip(s2) < tu[k];
+            const int d = (n0 ? 1 : 0) + (n1 ? 1 : 0) + (n2 ? 1 : 0);
+            hi[k] = p0 + d;
+            if (d <= 2) {
+                far[k] = false;
+                // the record of p + 1 from the record of p and row p: a row that ends above the prefix max so far opens a new level on
+                // top (it becomes the first row attaining the maximum), the old levels move one down; otherwise nothing changes.  The
+                // first row of a segment has nothing below it.  (Written with selects: no divergent control flow, no indexed registers.)
+                bool top_first = first;                                        // "the position being pushed is its segment's first row"
+                if (d >= 1) {
+                    const bool up = top_first || e0 > pm;
+                    const int32_t o_pm = pm, o_ar = ar, o_l1v = l1v, o_l1r = l1r;
+                    l2v = up ? (top_first || o_l1r < 0 ? (int32_t)0x80000000 : o_l1v) : l2v;
+                    l1v = up ? (top_first ? 0 : o_pm) : l1v;
+                    l1r = up ? (top_first ? -1 : o_ar) : l1r;
+                    pm = up ? e0 : pm;
+                    ar = up ? r0 : ar;
+                    top_first = false;
+                }
+                if (d >= 2) {
+                    const bool up = e1 > pm;
+                    const int32_t o_pm = pm, o_ar = ar, o_l1v = l1v, o_l1r = l1r;
+                    l2v = up ? (o_l1r < 0 ? (int32_t)0x80000000 : o_l1v) : l2v;
+                    l1v = up ? o_pm : l1v;
+                    l1r = up ? o_ar : l1r;
+                    pm = up ? e1 : pm;
+                    ar = up ? r1 : ar;
+                }
+                const int32_t hs = d == 0 ? s0 : (d == 1 ? s1 : s2), he = d == 0 ? e0 : (d == 1 ? e1 : e2), hr = d == 0 ? r0 : (d == 1 ? r1 : r2);
+                R[k] = make_int4(pm, ar, hs, he);
+                Q[k] = make_int4(hr, l1v, l1r, l2v);
+            }
         }
     }
     // The lanes this line cannot settle -- hi outside the line (a third row of the bin below the probe's end, a probe outside its

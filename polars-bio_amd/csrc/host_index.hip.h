@@ -197,13 +197,13 @@ int build_argmax(ivj_ctx* ctx, ivj_index* ix) {
     return IVJ_OK;
 }
 
-// nearest lines (k_nearest_lines): 128 bytes per table slot in an allocation of its own (kept by the context between indexes like
+// nearest lines (k_nearest_lines): 64 bytes per table slot (128 per build row) in an allocation of its own (kept by the context between indexes like
 // the index slab), on first use by nearest_dev
 int build_lines(ivj_ctx* ctx, ivj_index* ix) {
     if (ix->has_lines) return IVJ_OK;
     IVJ_TRY(need_tables(ctx, ix));
     IVJ_TRY(build_argmax(ctx, ix));
-    const size_t need = (size_t)ix->bins_len * 128;
+    const size_t need = (size_t)ix->bins_len * 64;
     if (ix->nline_cap < need) {
         if (ix->nline) { (void)hipFree(ix->nline); ix->nline = nullptr; ix->nline_cap = 0; }
         if (ctx->nl_cache && ctx->nl_cache_cap >= need) {
@@ -215,7 +215,8 @@ int build_lines(ivj_ctx* ctx, ivj_index* ix) {
             ix->nline_cap = need;
         }
     }
-    LAUNCH(ctx, "nearest_lines", k_nearest_lines, grid1d(ix->bins_len * 8, 256), 256, (const int4*)ix->brec, (const int4*)ix->nrec, ix->bins_len, ix->n, ix->nline);
+    LAUNCH(ctx, "nearest_lines", k_nearest_lines, grid1d(ix->bins_len * 4, 256), 256, (const uint32_t*)ix->bins, (const int4*)ix->cmeta, ix->n_contigs, (const int4*)ix->nrec,
+           (const int32_t*)ix->b_start, (const int2*)ix->ep, (const int32_t*)ix->b_row, ix->bins_len, ix->n, ix->nline);
     HIP_TRY(hipGetLastError());
     ix->has_lines = true;
     return IVJ_OK;

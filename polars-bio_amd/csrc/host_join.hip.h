@@ -344,7 +344,7 @@ int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_op
     if (k1 && ix->n > 0 && ix->n_contigs <= CM_LDS && ctx->env_nearest_lines != 0 &&
         (ctx->env_nearest_lines > 0 || ix->table_mode == 3 ||
          (opts->partition_mode == 0 && ix->table_mode == 0 && ix->n >= (128ll << 10) && (ix->has_lines || n >= 8 * ix->n))) &&
-        (size_t)ix->bins_len * 128 <= ((size_t)16 << 30) && n <= 0x7fffffffll) {
+        (size_t)ix->bins_len * 64 <= ((size_t)16 << 30) && n <= 0x7fffffffll) {
         IVJ_TRY(build_lines(ctx, ix));
         IndexView v = view_of(ix);
         constexpr int NT = PROBE_THREADS * PROBE_ITEMS_LAT;

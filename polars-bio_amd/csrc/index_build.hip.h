@@ -111,23 +111,48 @@ __global__ void k_nearest_records(const int32_t* __restrict__ b_start, const int
     nrec[2 * p + 1] = q;
 }
 
-// Nearest lines: table slot i -> one 128-byte line {brec[i], nrec of positions p0, p0 + 1, p0 + 2 (two words each), one spare word}, p0 =
-// the slot's first position.  A probe whose end falls into the slot has hi in {p0 .. p0 + rows of the bin}: with two bins per build row
-// 98.6 % of the bins hold at most two rows, so ONE line fetch answers the probe (gather_probe: a line fetched from beyond the L2 costs
-// ~20 ps per probe whatever its width up to 128 bytes and whatever the table size; two dependent gathers cost 38 ps).  Eight threads per
-// slot, 16 bytes each: coalesced writes, near-sequential reads of nrec.
-__global__ void k_nearest_lines(const int4* __restrict__ brec, const int4* __restrict__ nrec, int64_t slots, int64_t n, int4* __restrict__ nline) {
+// Nearest lines (round 5: 64 bytes per table slot, 128 bytes per build row; round 4: 128-byte lines).  A probe whose end falls into
+// slot i has its hi-bound in {p0 .. p0 + rows of the bin}, p0 = the slot's first position, and with two bins per build row 98.6 % of the
+// bins hold at most two rows -- so the line carries what the probe needs for hi = p0, p0 + 1, p0 + 2.  Round 4 stored the three 32-byte
+// nearest records side by side.  But the record of position p + 1 FOLLOWS from the record of p and row p: the prefix max either stays
+// (end[p] <= pmax[p-1]: same levels) or row p opens a new level on top (the old levels move one down), so the line holds ONE record and
+// three rows and the kernel replays at most two "pushes" in registers:
+//   word 0       p0 | first << 30          first: p0 is the first row of its contig's segment (nothing below it)
+//   words 1-5    pmax[p0-1], its first row, value and first row of the level below, value of the level below that   (= nrec of p0)
+//   words 6-14   {start, end, build row} of the rows p0, p0 + 1, p0 + 2   (rows past the segment: start INT32_MAX, never below a target)
+//   word 15      spare
+// The rank of the probe inside the bin is the number of the three starts below its end (rows of later bins start above it); three
+// below: a fourth row may follow -- left to the two-gather kernel like every probe a line cannot settle.  One line fetch of 64 bytes per
+// probe (gather_probe: the price of a gather from beyond the L2 is per REQUEST, ~ 20 ps, whatever its width up to a line -- but the
+// round-4 line was two 64-byte requests).  Four threads per slot, 16 bytes each: coalesced non-temporal writes.
+__global__ void k_nearest_lines(const uint32_t* __restrict__ bins, const int4* __restrict__ cmeta, int32_t n_contigs, const int4* __restrict__ nrec,
+                                const int32_t* __restrict__ b_start, const int2* __restrict__ ep, const int32_t* __restrict__ b_row,
+                                int64_t slots, int64_t n, int4* __restrict__ nline) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t slot = t >> 3;
-    const int w = (int)(t & 7);
+    const int64_t slot = t >> 2;
+    const int w = (int)(t & 3);
     if (slot >= slots) return;
-    const int4 br = brec[slot];
+    // last contig whose table offset tb = cmeta[2c+1].y is <= slot
+    int lo = 0, hi = n_contigs;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= slot) lo = m + 1; else hi = m; }
+    const int c = lo - 1;
     int4 v = make_int4(0, 0, 0, 0);
-    if (w == 0) v = br;
-    else if (w < 7) {
-        int64_t p = (int64_t)(br.x & 0x7fffffff) + ((w - 1) >> 1);
-        p = p < n ? p : n;
-        v = nrec[2 * p + ((w - 1) & 1)];
+    if (c >= 0) {
+        const int4 m0 = cmeta[2 * c];
+        const int64_t a = m0.x, b = m0.y;
+        int64_t p0 = (int64_t)bins[slot];
+        p0 = p0 < b ? p0 : b;
+        auto row = [&](int j, int32_t& s, int32_t& e, int32_t& r) {
+            const int64_t p = p0 + j;
+            s = INT32_MAX; e = 0; r = -1;
+            if (p < b) { s = b_start[p]; e = ep[p].x; r = b_row[p]; }
+        };
+        const int4 R = nrec[2 * p0], Q = nrec[2 * p0 + 1];
+        int32_t s0, e0, r0, s1, e1, r1, s2, e2, r2;
+        if (w == 0) v = make_int4((int)((uint32_t)p0 | (p0 == a ? 0x40000000u : 0u)), R.x, R.y, Q.y);
+        else if (w == 1) { row(0, s0, e0, r0); v = make_int4(Q.z, Q.w, s0, e0); }
+        else if (w == 2) { row(0, s0, e0, r0); row(1, s1, e1, r1); v = make_int4(r0, s1, e1, r1); }
+        else { row(2, s2, e2, r2); v = make_int4(s2, e2, r2, 0); }
     }
     __builtin_nontemporal_store(v.x, &nline[t].x); __builtin_nontemporal_store(v.y, &nline[t].y);
     __builtin_nontemporal_store(v.z, &nline[t].z); __builtin_nontemporal_store(v.w, &nline[t].w);
