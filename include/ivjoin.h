@@ -452,6 +452,28 @@ int ivj_nearest_arrow_stream(ivj_ctx* ctx, void* df1_stream, void* df2_stream, c
                              const ivj_opts* opts, const char* suffix1, const char* suffix2, int32_t with_distance, int64_t batch_rows,
                              int64_t limit, void* out_stream);
 
+/* The LAZY forms (round 5) -- /root/reference/src/lib.rs:154-214 range_operation_lazy, src/scan.rs:294-357, polars_bio/range_op_io.py:100-174:
+ * df2 (the build side) is drained, encoded and indexed once; df1 stays a STREAM and is pulled batch by batch from inside the result
+ * stream's get_next: a batch is encoded with the session's chrom dictionary, narrowed to int32, submitted to a streaming probe session
+ * (ivj_stream_*: its H2D copy overlaps the join of the batch before it and the D2H copy of the batch before that), and the results that
+ * come back -- those of the batch submitted two turns earlier -- are assembled into record batches of batch_rows rows.  Host memory:
+ * df2 + three df1 batches + one batch's result, whatever the length of df1 (which may pass 2^31 rows).  df1 batches above max_batch_rows
+ * (<= 0: 4 Mi; it sizes the session's pinned staging) are submitted in slices.  Result rows come in df1 batch order.  limit >= 0: no df1
+ * batch is pulled after the limit is reached.  Errors of a later batch (a coordinate beyond int32, a malformed batch) surface from
+ * get_next (errno, text from get_last_error) -- as the reference's surface at collect time.  OWNERSHIP (both forms, eager and lazy): the
+ * two input streams are consumed by the call whatever its outcome -- on every error path their release callbacks have run (the lazy
+ * form keeps df1 until the result stream is exhausted or released).  The result stream works on `ctx` whenever it is pulled: pull it
+ * from one thread at a time and not concurrently with other calls on the same context; release it before the context. */
+int ivj_overlap_arrow_stream_lazy(ivj_ctx* ctx, void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2,
+                                  const ivj_opts* opts, const char* suffix1, const char* suffix2, int64_t batch_rows, int64_t max_batch_rows,
+                                  int64_t limit, void* out_stream);
+int ivj_count_overlaps_arrow_stream_lazy(ivj_ctx* ctx, void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2,
+                                         const ivj_opts* opts, const char* suffix1, int64_t batch_rows, int64_t max_batch_rows, int64_t limit,
+                                         void* out_stream);
+int ivj_nearest_arrow_stream_lazy(ivj_ctx* ctx, void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2,
+                                  const ivj_opts* opts, const char* suffix1, const char* suffix2, int32_t with_distance, int64_t batch_rows,
+                                  int64_t max_batch_rows, int64_t limit, void* out_stream);
+
 /* The two host halves of that call on their own (no device, no context): */
 /* ... the key columns the join sees: both streams drained (and released), chrom encoded, coordinates narrowed */
 typedef struct {

@@ -124,30 +124,53 @@ struct AsTable {
     }
 };
 
+// one batch against the stream's schema: the record-batch struct itself carries no nulls, every column has the buffers its type
+// reads (a producer whose batch layout differs from its schema is refused by name, not dereferenced)
+int as_check_batch(const ArrowSchema& schema, const std::vector<AsType>& types, const ArrowArray& a, const char* what) {
+    if (a.n_children != schema.n_children) return fail(IVJ_EINVAL, std::string(what) + ": a batch disagrees with the schema on the number of columns");
+    if (a.null_count > 0) return fail(IVJ_EINVAL, std::string(what) + ": a record batch with null ROWS (a validity bitmap on the struct itself) is not supported");
+    for (int64_t c = 0; c < a.n_children; ++c) {
+        const ArrowArray* ch = a.children ? a.children[c] : nullptr;
+        const AsType& ty = types[(size_t)c];
+        const char* nm = schema.children[c]->name ? schema.children[c]->name : "";
+        if (!ch) return fail(IVJ_EINVAL, std::string(what) + ": column '" + nm + "' of a batch is missing");
+        if (ty.kind == AS_UNSUPPORTED) continue;                                // refused later, by name, if the result needs it
+        const int need = ty.dict ? 2 : (ty.kind == AS_STR32 || ty.kind == AS_STR64 ? 3 : 2);
+        if (ch->n_buffers < need || !ch->buffers) return fail(IVJ_EINVAL, std::string(what) + ": column '" + nm + "' of a batch has " + std::to_string(ch->n_buffers) + " buffers, its type needs " + std::to_string(need));
+        if (ch->length + ch->offset > 0 && !ch->buffers[1]) return fail(IVJ_EINVAL, std::string(what) + ": column '" + nm + "' of a batch has no data buffer");
+        if (ty.dict && !ch->dictionary) return fail(IVJ_EINVAL, std::string(what) + ": a batch of dictionary column '" + nm + "' carries no dictionary");
+        if (ch->length < a.length + a.offset - ch->offset && ch->length < a.length) return fail(IVJ_EINVAL, std::string(what) + ": column '" + nm + "' of a batch is shorter than the batch");
+    }
+    return IVJ_OK;
+}
+
+// The stream is CONSUMED whatever happens: on success and on every failure the producer's release callback has run when this
+// returns (a caller that gets an error back owns nothing any more -- the contract of the *_arrow_stream entry points).
 int as_drain(ArrowArrayStream* in, const char* what, AsTable& t) {
     if (!in || !in->get_schema || !in->get_next) return fail(IVJ_EINVAL, std::string(what) + ": not an ArrowArrayStream");
+    struct Consume { ArrowArrayStream* s; ~Consume() { if (s->release) s->release(s); } } consume{in};
     auto err = [&](const char* step) {
         const char* m = in->get_last_error ? in->get_last_error(in) : nullptr;
         return fail(IVJ_EINVAL, std::string(what) + ": " + step + " failed" + (m ? std::string(": ") + m : std::string()));
     };
     if (in->get_schema(in, &t.schema) != 0) return err("get_schema");
     if (!t.schema.format || std::strcmp(t.schema.format, "+s") != 0) return fail(IVJ_EINVAL, std::string(what) + ": the stream's schema is not a struct (record batches expected)");
+    t.types.resize((size_t)t.ncols());
+    for (int c = 0; c < t.ncols(); ++c) t.types[(size_t)c] = as_type_of(t.schema.children[c]);
     t.start.push_back(0);
     for (;;) {
         ArrowArray a{};
         a.release = nullptr;
         if (in->get_next(in, &a) != 0) return err("get_next");
         if (!a.release) break;                              // end of stream
-        if (a.n_children != t.schema.n_children) { a.release(&a); return fail(IVJ_EINVAL, std::string(what) + ": a batch disagrees with the schema on the number of columns"); }
+        const int rc = as_check_batch(t.schema, t.types, a, what);
+        if (rc != IVJ_OK) { a.release(&a); return rc; }
         if (a.length == 0) { a.release(&a); continue; }
         t.batches.push_back(a);
         t.n += a.length;
         t.start.push_back(t.n);
     }
     if (t.n > (int64_t)INT32_MAX) return fail(IVJ_EINVAL, std::string(what) + ": more than 2^31 - 1 rows on one side");
-    t.types.resize((size_t)t.ncols());
-    for (int c = 0; c < t.ncols(); ++c) t.types[(size_t)c] = as_type_of(t.schema.children[c]);
-    if (in->release) in->release(in);                       // the stream was consumed: the producer's resources go now
     return IVJ_OK;
 }
 
@@ -320,6 +343,10 @@ struct AsResult {
     ivj_pairs pairs{0, nullptr, nullptr};                  // overlap: the library-owned pair buffers idx[] point into
     std::vector<int32_t> chrom_ids[2];                     // per row of the side: id in `names` (-1: null chrom)
     std::vector<std::string> names;                        // the shared chrom dictionary
+    // ... or borrowed from a longer-lived owner (the lazy entry: one AsResult per probe batch over the session's dictionary)
+    const int32_t* cid[2] = {nullptr, nullptr};
+    int64_t cid_n[2] = {0, 0};
+    const std::vector<std::string>* names_ref = nullptr;
     std::vector<int64_t> extra;
     std::vector<uint8_t> extra_null;                       // 1 = null (distance of a probe row without a neighbour)
     std::string extra_name;
@@ -333,11 +360,12 @@ struct AsResult {
 struct AsBufOwner {                                        // one exported column: its buffers are malloc'ed and freed with it
     void* bufs[3] = {nullptr, nullptr, nullptr};
     const void* ptrs[3] = {nullptr, nullptr, nullptr};
+    AsBufOwner() = default;
+    AsBufOwner(const AsBufOwner&) = delete;
+    ~AsBufOwner() { for (void* p : bufs) std::free(p); }   // (also on the error paths of the column builders: the guard deletes the owner)
 };
 void as_release_col(ArrowArray* a) {
-    auto* o = static_cast<AsBufOwner*>(a->private_data);
-    for (void* p : o->bufs) std::free(p);
-    delete o;
+    delete static_cast<AsBufOwner*>(a->private_data);
     a->release = nullptr;
 }
 struct AsBatchOwner { std::vector<ArrowArray> child; std::vector<ArrowArray*> ptrs; const void* top_buf[1] = {nullptr}; };
@@ -409,7 +437,8 @@ inline bool as_resolve(const AsTable& t, const AsType& ty, int col, int b, int32
 
 // the chrom key column of output rows [lo, lo + n): names[ids[row]] -- offsets from the name lengths, bytes from the dictionary
 int as_chrom_col(const AsResult& R, const AsOutCol& oc, int64_t lo, int64_t n, int threads, ArrowArray* out) {
-    const std::vector<int32_t>& ids = R.chrom_ids[oc.side];
+    const int32_t* ids = R.cid[oc.side] ? R.cid[oc.side] : R.chrom_ids[oc.side].data();
+    const std::vector<std::string>& names = R.names_ref ? *R.names_ref : R.names;
     const int32_t* idx = R.idx[oc.side];
     const int ob = oc.type.kind == AS_STR32 ? 4 : 8;
     auto* own = new AsBufOwner();
@@ -419,16 +448,17 @@ int as_chrom_col(const AsResult& R, const AsOutCol& oc, int64_t lo, int64_t n, i
     if (!valid || !id) { std::free(valid); std::free(id); return fail(IVJ_ENOMEM, "result batch: out of memory"); }
     own->bufs[0] = valid;
     std::unique_ptr<int32_t, void (*)(void*)> idg(id, std::free);
-    std::vector<int64_t> nlen(R.names.size());
-    for (size_t v = 0; v < R.names.size(); ++v) nlen[v] = (int64_t)R.names[v].size();
+    std::vector<int64_t> nlen(names.size());
+    for (size_t v = 0; v < names.size(); ++v) nlen[v] = (int64_t)names[v].size();
     const int tn = fd_threads(n, threads, 1 << 15);
     std::vector<int64_t> part((size_t)tn + 1, 0), nulls((size_t)tn, 0);
-    const int64_t n_src = (int64_t)ids.size();
+    const int64_t n_src = R.cid[oc.side] ? R.cid_n[oc.side] : (int64_t)R.chrom_ids[oc.side].size();
     fd_parallel(n, tn, [&](int k, int64_t a, int64_t b) {
         int64_t bytes = 0, nn = 0;
         for (int64_t i = a; i < b; ++i) {
             const int64_t r = idx ? (int64_t)idx[lo + i] : lo + i;
-            const int32_t v = (r >= 0 && r < n_src) ? ids[(size_t)r] : -1;
+            int32_t v = (r >= 0 && r < n_src) ? ids[(size_t)r] : -1;
+            if (v >= (int32_t)names.size()) v = -1;
             id[i] = v;
             if (v >= 0) { bytes += nlen[(size_t)v]; valid[i >> 3] |= (uint8_t)(1u << (i & 7)); } else ++nn;
         }
@@ -446,7 +476,7 @@ int as_chrom_col(const AsResult& R, const AsOutCol& oc, int64_t lo, int64_t n, i
         for (int64_t i = a; i < b; ++i) {
             if (ob == 4) ((int32_t*)offs)[i] = (int32_t)o; else ((int64_t*)offs)[i] = o;
             const int32_t v = id[i];
-            if (v >= 0) { std::memcpy(bytes + o, R.names[(size_t)v].data(), (size_t)nlen[(size_t)v]); o += nlen[(size_t)v]; }
+            if (v >= 0) { std::memcpy(bytes + o, names[(size_t)v].data(), (size_t)nlen[(size_t)v]); o += nlen[(size_t)v]; }
         }
     });
     if (ob == 4) ((int32_t*)offs)[n] = (int32_t)total; else ((int64_t*)offs)[n] = total;
@@ -588,9 +618,8 @@ int as_stream_get_schema(ArrowArrayStream* s, ArrowSchema* out) {
     catch (const std::exception& e) { R->last_error = e.what(); return ENOMEM; }
 }
 
-int as_stream_get_next(ArrowArrayStream* s, ArrowArray* out) {
-    auto* R = static_cast<AsResult*>(s->private_data);
-    std::lock_guard<std::mutex> lk(R->mu);
+// the next batch_rows rows of R as one record batch (out->release == nullptr: R is exhausted); 0 or an errno, R->last_error set
+int as_next_batch(AsResult* R, ArrowArray* out) {
     try {
         if (R->cursor >= R->n_rows) { std::memset(out, 0, sizeof(*out)); out->release = nullptr; return 0; }     // end of stream
         const int64_t lo = R->cursor, hi = lo + R->batch_rows < R->n_rows ? lo + R->batch_rows : R->n_rows, n = hi - lo;
@@ -621,6 +650,11 @@ int as_stream_get_next(ArrowArrayStream* s, ArrowArray* out) {
         return 0;
     } catch (const std::bad_alloc&) { R->last_error = "out of memory"; return ENOMEM; }
     catch (const std::exception& e) { R->last_error = e.what(); return EINVAL; }
+}
+int as_stream_get_next(ArrowArrayStream* s, ArrowArray* out) {
+    auto* R = static_cast<AsResult*>(s->private_data);
+    std::lock_guard<std::mutex> lk(R->mu);
+    return as_next_batch(R, out);
 }
 const char* as_stream_last_error(ArrowArrayStream* s) {
     auto* R = static_cast<AsResult*>(s->private_data);
@@ -686,8 +720,12 @@ int ivj_arrow_encode_keys(void* df1_stream, void* df2_stream, const char* const*
     if (!df1_stream || !df2_stream || !out) return fail(IVJ_EINVAL, "encode keys: NULL argument");
     std::memset(out, 0, sizeof(*out));
     AsTable t1, t2;
-    IVJ_TRY(as_drain(static_cast<ArrowArrayStream*>(df1_stream), "df1", t1));
-    IVJ_TRY(as_drain(static_cast<ArrowArrayStream*>(df2_stream), "df2", t2));
+    // both streams are consumed whatever happens
+    const int r1 = as_drain(static_cast<ArrowArrayStream*>(df1_stream), "df1", t1);
+    const std::string why1 = g_err;
+    const int r2 = as_drain(static_cast<ArrowArrayStream*>(df2_stream), "df2", t2);
+    if (r1 != IVJ_OK) { g_err = why1; return r1; }
+    if (r2 != IVJ_OK) return r2;
     AsKeys K;
     IVJ_TRY(as_make_keys(t1, t2, cols1, cols2, K, 0));
     auto dup = [](const std::vector<int32_t>& v) -> int32_t* {
@@ -740,7 +778,11 @@ int as_open(ivj_ctx* ctx, void* df1, void* df2, const char* const* cols1, const 
     C.R = std::make_unique<AsResult>();
     C.R->t[0] = std::make_shared<AsTable>();
     C.R->t[1] = std::make_shared<AsTable>();
-    IVJ_TRY(as_drain(static_cast<ArrowArrayStream*>(df1), "df1", *C.R->t[0]));
+    {
+        // both streams are consumed whatever happens (as_drain releases the one it was given; the other one goes here)
+        const int r1 = as_drain(static_cast<ArrowArrayStream*>(df1), "df1", *C.R->t[0]);
+        if (r1 != IVJ_OK) { auto* s2 = static_cast<ArrowArrayStream*>(df2); const std::string why = g_err; if (s2->release) s2->release(s2); g_err = why; return r1; }
+    }
     IVJ_TRY(as_drain(static_cast<ArrowArrayStream*>(df2), "df2", *C.R->t[1]));
     IVJ_TRY(as_make_keys(*C.R->t[0], *C.R->t[1], cols1, cols2, C.K, 0));
     C.opts = *opts;
@@ -759,6 +801,269 @@ void as_keys_to_result(AsCall& C) {
     R.names = std::move(C.K.dict.names);
     for (AsOutCol& oc : R.cols)
         if (oc.side < 2 && oc.col == C.chrom_col[oc.side]) oc.from_ids = true;
+}
+}  // namespace
+
+namespace {
+// ---- the LAZY form of the one-call entry (round 5): df1 is never materialised whole ---------------------------------------------------
+// /root/reference/src/lib.rs:154-214 (range_operation_lazy) registers both Arrow streams as streaming tables and the result is pulled
+// batch by batch (src/scan.rs:294-357: fan-out with back-pressure, buffer 2; polars_bio/range_op_io.py:100-174).  Here: df2 is drained,
+// encoded and indexed ONCE (it is the build side: it has to be whole); df1 stays a stream.  Every get_next of the RESULT stream pulls
+// as many df1 batches as it needs to have a result batch: a batch is encoded with the session's chrom dictionary (names df2 does not
+// have get ids beyond the dictionary: they match nothing), narrowed to int32 with the range check, SUBMITTED to a streaming probe
+// session (ivj_stream_*: its H2D copy overlaps the join of the batch before and the D2H copy of the batch before that), and the
+// batch that comes back -- the one submitted two turns earlier -- is assembled into record batches of batch_rows rows.  Host memory:
+// df2 + three df1 batches + one batch's result, whatever the length of df1; df1 may hold more than 2^31 rows.  A df1 batch above
+// max_batch_rows is submitted in slices.  Errors of a LATER batch (a coordinate beyond int32, a column that vanished) surface from
+// get_next (errno + get_last_error), as the reference's do at collect time.
+struct AsLazy {
+    ivj_ctx* ctx = nullptr;
+    ivj_stream* st = nullptr;
+    int op = 0, k = 1, with_distance = 0;
+    ArrowArrayStream in{};                               // df1: moved in, released with the result stream (or at its end)
+    ArrowSchema schema1{};
+    std::vector<AsType> types1;
+    int key1[3] = {-1, -1, -1};
+    std::shared_ptr<AsTable> t2;
+    std::vector<int32_t> c2;                             // chrom ids of df2
+    AsDict dict;
+    AsResult proto;                                      // the result's columns
+    int64_t max_rows = 0, batch_rows = 1 << 20, limit = -1, rows_out = 0;
+    struct Pending { std::shared_ptr<AsTable> tb; std::shared_ptr<std::vector<int32_t>> cids; int64_t off, n; };
+    std::deque<Pending> pending;                         // submitted slices whose results are still in the session (delivery order)
+    std::deque<ArrowArray> ready;
+    std::shared_ptr<AsTable> cur;                        // the df1 batch being sliced, its keys
+    std::shared_ptr<std::vector<int32_t>> cur_c;
+    std::vector<int32_t> cur_s, cur_e;
+    int64_t cur_off = 0;
+    bool in_done = false, finished = false;
+    std::string last_error;
+    std::mutex mu;
+    AsLazy() { in.release = nullptr; schema1.release = nullptr; }
+    ~AsLazy() {
+        for (ArrowArray& a : ready) if (a.release) a.release(&a);
+        if (st) ivj_stream_close(st);
+        if (in.release) in.release(&in);
+        if (schema1.release) schema1.release(&schema1);
+    }
+};
+
+// the next df1 batch as a one-batch table view + its keys; L.cur stays empty at the end of the stream
+int lazy_pull(AsLazy& L) {
+    L.cur.reset(); L.cur_c.reset(); L.cur_off = 0;
+    while (!L.in_done) {
+        ArrowArray a{};
+        a.release = nullptr;
+        if (L.in.get_next(&L.in, &a) != 0) {
+            const char* m = L.in.get_last_error ? L.in.get_last_error(&L.in) : nullptr;
+            return fail(IVJ_EINVAL, std::string("df1: get_next failed") + (m ? std::string(": ") + m : std::string()));
+        }
+        if (!a.release) { L.in_done = true; if (L.in.release) L.in.release(&L.in); break; }
+        const int rc = as_check_batch(L.schema1, L.types1, a, "df1");
+        if (rc != IVJ_OK) { a.release(&a); return rc; }
+        if (a.length == 0) { a.release(&a); continue; }
+        if (a.length > (int64_t)INT32_MAX) { a.release(&a); return fail(IVJ_EINVAL, "df1: a batch of more than 2^31 - 1 rows"); }
+        auto tb = std::make_shared<AsTable>();
+        tb->schema = L.schema1; tb->schema.release = nullptr;                   // a view: the session owns the schema
+        tb->types = L.types1;
+        tb->batches.push_back(a);
+        tb->n = a.length;
+        tb->start = {0, a.length};
+        auto ids = std::make_shared<std::vector<int32_t>>((size_t)a.length);
+        L.cur_s.resize((size_t)a.length); L.cur_e.resize((size_t)a.length);
+        IVJ_TRY(as_encode_chrom(*tb, L.key1[0], "df1", L.dict, ids->data(), 0));
+        IVJ_TRY(as_narrow_coord(*tb, L.key1[1], "df1", L.cur_s.data(), 0));
+        IVJ_TRY(as_narrow_coord(*tb, L.key1[2], "df1", L.cur_e.data(), 0));
+        L.cur = tb; L.cur_c = ids;
+        return IVJ_OK;
+    }
+    return IVJ_OK;
+}
+
+// results of one delivered slice -> record batches in L.ready
+int lazy_assemble(AsLazy& L, const AsLazy::Pending& P, const ivj_stream_result& d) {
+    AsResult B;
+    B.t[0] = P.tb; B.t[1] = L.t2;
+    B.cols = L.proto.cols;
+    B.cid[0] = P.cids->data(); B.cid_n[0] = (int64_t)P.cids->size();
+    B.cid[1] = L.c2.data(); B.cid_n[1] = (int64_t)L.c2.size();
+    B.names_ref = &L.dict.names;
+    B.batch_rows = L.batch_rows;
+    const int32_t off = (int32_t)P.off;
+    if (L.op == IVJ_STREAM_OVERLAP) {
+        B.own_idx[0].resize((size_t)d.n);
+        for (int64_t i = 0; i < d.n; ++i) B.own_idx[0][(size_t)i] = d.probe_idx[i] + off;
+        B.idx[0] = B.own_idx[0].data();
+        B.idx[1] = d.build_idx;                                                // the session's pinned slot: valid until the next turn -- the batches are made now
+        B.n_rows = d.n;
+    } else if (L.op == IVJ_STREAM_COUNT) {
+        B.own_idx[0].resize((size_t)d.n_probe);
+        for (int64_t i = 0; i < d.n_probe; ++i) B.own_idx[0][(size_t)i] = (int32_t)i + off;
+        B.idx[0] = B.own_idx[0].data();
+        B.extra.assign(d.counts, d.counts + d.n_probe);
+        B.n_rows = d.n_probe;
+    } else {
+        for (int64_t i = 0; i < d.n_probe; ++i) {
+            const int32_t f = d.n_found[i];
+            for (int32_t j = 0; j < (f > 0 ? f : 1); ++j) {
+                const bool none = f <= 0;
+                B.own_idx[0].push_back((int32_t)i + off);
+                B.own_idx[1].push_back(none ? -1 : d.build_idx[i * L.k + j]);
+                B.extra.push_back(none ? 0 : d.dist[i * L.k + j]);
+                B.extra_null.push_back(none ? 1 : 0);
+            }
+        }
+        B.idx[0] = B.own_idx[0].data(); B.idx[1] = B.own_idx[1].data();
+        B.n_rows = (int64_t)B.own_idx[0].size();
+    }
+    if (L.limit >= 0 && L.rows_out + B.n_rows > L.limit) B.n_rows = L.limit - L.rows_out;
+    for (;;) {
+        ArrowArray a{};
+        const int rc = as_next_batch(&B, &a);
+        if (rc != 0) return fail(rc == ENOMEM ? IVJ_ENOMEM : IVJ_EINVAL, B.last_error.empty() ? std::string("result batch assembly failed") : B.last_error);
+        if (!a.release) break;
+        L.rows_out += a.length;
+        L.ready.push_back(a);
+    }
+    return IVJ_OK;
+}
+
+int lazy_get_next(ArrowArrayStream* s, ArrowArray* out) {
+    auto* L = static_cast<AsLazy*>(s->private_data);
+    std::lock_guard<std::mutex> lk(L->mu);
+    auto bad = [&](int rc) { L->last_error = g_err; L->finished = true; return rc == IVJ_ENOMEM ? ENOMEM : (rc == IVJ_EINVAL ? EINVAL : EIO); };
+    try {
+        for (;;) {
+            if (!L->ready.empty()) { *out = L->ready.front(); L->ready.pop_front(); return 0; }
+            if (L->finished) { std::memset(out, 0, sizeof(*out)); out->release = nullptr; return 0; }
+            if (L->limit >= 0 && L->rows_out >= L->limit) {                    // enough rows: the rest of df1 is never pulled
+                L->finished = true;
+                if (L->in.release) L->in.release(&L->in);
+                continue;
+            }
+            if (!L->cur || L->cur_off >= L->cur->n) { const int rc = lazy_pull(*L); if (rc != IVJ_OK) return bad(rc); }
+            ivj_stream_result done;
+            std::memset(&done, 0, sizeof(done));
+            done.batch = -1;
+            int rc;
+            if (L->cur && L->cur_off < L->cur->n) {
+                const int64_t n = std::min<int64_t>(L->max_rows, L->cur->n - L->cur_off);
+                const ivj_side side{L->cur_c->data() + L->cur_off, L->cur_s.data() + L->cur_off, L->cur_e.data() + L->cur_off, n, nullptr};
+                L->pending.push_back(AsLazy::Pending{L->cur, L->cur_c, L->cur_off, n});
+                L->cur_off += n;
+                rc = ivj_stream_submit(L->st, &side, &done);
+            } else {
+                rc = ivj_stream_flush(L->st, &done);
+                if (rc == IVJ_OK && done.batch < 0) { L->finished = true; continue; }
+            }
+            if (rc != IVJ_OK) return bad(rc);
+            if (done.batch >= 0) {
+                if (L->pending.empty()) { g_err = "lazy stream: a result without a pending batch (internal)"; return bad(IVJ_ESTATE); }
+                const AsLazy::Pending P = L->pending.front();
+                L->pending.pop_front();
+                rc = lazy_assemble(*L, P, done);
+                if (rc != IVJ_OK) return bad(rc);
+            }
+        }
+    } catch (const std::bad_alloc&) { L->last_error = "out of memory"; L->finished = true; return ENOMEM; }
+    catch (const std::exception& e) { L->last_error = e.what(); L->finished = true; return EINVAL; }
+}
+int lazy_get_schema(ArrowArrayStream* s, ArrowSchema* out) {
+    auto* L = static_cast<AsLazy*>(s->private_data);
+    try { return as_result_schema(L->proto, out) == IVJ_OK ? 0 : EINVAL; }
+    catch (const std::exception& e) { L->last_error = e.what(); return ENOMEM; }
+}
+const char* lazy_last_error(ArrowArrayStream* s) {
+    auto* L = static_cast<AsLazy*>(s->private_data);
+    return L->last_error.empty() ? nullptr : L->last_error.c_str();
+}
+void lazy_release(ArrowArrayStream* s) {
+    delete static_cast<AsLazy*>(s->private_data);
+    s->private_data = nullptr;
+    s->release = nullptr;
+}
+
+// df2 drained / encoded / indexed, df1's schema read, the result's columns laid out; on failure both input streams are released
+int lazy_open(ivj_ctx* ctx, void* df1, void* df2, const char* const* cols1, const char* const* cols2, const ivj_opts* opts, int op,
+              const char* suffix1, const char* suffix2, int with_distance, int64_t batch_rows, int64_t max_batch_rows, int64_t limit, void* out) {
+    auto* s1 = static_cast<ArrowArrayStream*>(df1);
+    auto* s2 = static_cast<ArrowArrayStream*>(df2);
+    auto L = std::make_unique<AsLazy>();
+    auto fail_both = [&](int rc) {                        // (df1 may already live in L: its destructor releases it)
+        const std::string why = g_err;
+        if (s1 && s1->release) s1->release(s1);
+        if (s2 && s2->release) s2->release(s2);
+        g_err = why;
+        return rc;
+    };
+    {
+        const int rc = as_check_common(ctx, opts, static_cast<ArrowArrayStream*>(out));
+        if (rc != IVJ_OK) return fail_both(rc);
+    }
+    if (!s1 || !s2 || !s1->get_schema || !s1->get_next) return fail_both(fail(IVJ_EINVAL, "an input stream is NULL or not an ArrowArrayStream"));
+    L->ctx = ctx; L->op = op; L->with_distance = with_distance; L->limit = limit;
+    if (batch_rows > 0) L->batch_rows = batch_rows;
+    L->max_rows = max_batch_rows > 0 ? max_batch_rows : (4ll << 20);
+    if (L->max_rows > 0x7fff0000ll) L->max_rows = 0x7fff0000ll;
+    L->in = *s1;                                          // moved: the caller's struct is marked released (Arrow C stream move semantics)
+    s1->release = nullptr;
+    s1 = nullptr;
+    if (L->in.get_schema(&L->in, &L->schema1) != 0) {
+        const char* m = L->in.get_last_error ? L->in.get_last_error(&L->in) : nullptr;
+        return fail_both(fail(IVJ_EINVAL, std::string("df1: get_schema failed") + (m ? std::string(": ") + m : std::string())));
+    }
+    if (!L->schema1.format || std::strcmp(L->schema1.format, "+s") != 0) return fail_both(fail(IVJ_EINVAL, "df1: the stream's schema is not a struct (record batches expected)"));
+    L->types1.resize((size_t)L->schema1.n_children);
+    for (int64_t c = 0; c < L->schema1.n_children; ++c) L->types1[(size_t)c] = as_type_of(L->schema1.children[c]);
+    L->t2 = std::make_shared<AsTable>();
+    {
+        const int rc = as_drain(s2, "df2", *L->t2);       // (releases df2 whatever happens)
+        s2 = nullptr;
+        if (rc != IVJ_OK) return fail_both(rc);
+    }
+    static const char* const dflt[3] = {"chrom", "start", "end"};
+    const char* const* n1 = cols1 ? cols1 : dflt;
+    const char* const* n2 = cols2 ? cols2 : dflt;
+    int i2[3];
+    auto find1 = [&](const char* nm) { for (int64_t c = 0; c < L->schema1.n_children; ++c) if (L->schema1.children[c]->name && !std::strcmp(L->schema1.children[c]->name, nm)) return (int)c; return -1; };
+    for (int q = 0; q < 3; ++q) {
+        if (!n1[q] || !n2[q]) return fail_both(fail(IVJ_EINVAL, "a key column name is NULL"));
+        L->key1[q] = find1(n1[q]); i2[q] = L->t2->find(n2[q]);
+        if (L->key1[q] < 0) return fail_both(fail(IVJ_EINVAL, std::string("df1: column '") + n1[q] + "' not found"));
+        if (i2[q] < 0) return fail_both(fail(IVJ_EINVAL, std::string("df2: column '") + n2[q] + "' not found"));
+    }
+    // df2's keys: the dictionary starts with ITS names, so opts.n_contigs = names so far covers every build row
+    std::vector<int32_t> s2v((size_t)L->t2->n), e2v((size_t)L->t2->n);
+    L->c2.resize((size_t)L->t2->n);
+    int rc = as_encode_chrom(*L->t2, i2[0], "df2", L->dict, L->c2.data(), 0);
+    if (rc == IVJ_OK) rc = as_narrow_coord(*L->t2, i2[1], "df2", s2v.data(), 0);
+    if (rc == IVJ_OK) rc = as_narrow_coord(*L->t2, i2[2], "df2", e2v.data(), 0);
+    if (rc != IVJ_OK) return fail_both(rc);
+    ivj_opts o = *opts;
+    o.n_contigs = (int32_t)L->dict.names.size();
+    if (op == IVJ_STREAM_NEAREST) { if (o.nearest_k < 1) o.nearest_k = 1; if (o.nearest_k > 1024) return fail_both(fail(IVJ_EINVAL, "nearest_k > 1024")); }
+    L->k = o.nearest_k < 1 ? 1 : o.nearest_k;
+    // the result's columns: df1's from a one-batch view per pulled batch, df2's from the drained table
+    {
+        auto v1 = std::make_shared<AsTable>();
+        v1->schema = L->schema1; v1->schema.release = nullptr; v1->types = L->types1;
+        L->proto.t[0] = v1; L->proto.t[1] = L->t2;
+        rc = as_add_side_cols(L->proto, 0, suffix1 ? suffix1 : (op == IVJ_STREAM_COUNT ? "" : "_1"));
+        if (rc == IVJ_OK && op != IVJ_STREAM_COUNT) rc = as_add_side_cols(L->proto, 1, suffix2 ? suffix2 : "_2");
+        if (rc != IVJ_OK) return fail_both(rc);
+        if (op == IVJ_STREAM_COUNT) L->proto.cols.push_back(AsOutCol{2, 0, "count", AsType()});
+        if (op == IVJ_STREAM_NEAREST && with_distance) L->proto.cols.push_back(AsOutCol{2, 0, "distance", AsType()});
+        for (AsOutCol& oc : L->proto.cols)
+            if ((oc.side == 0 && oc.col == L->key1[0]) || (oc.side == 1 && oc.col == i2[0])) oc.from_ids = true;
+        L->proto.t[0].reset(); L->proto.t[1].reset();
+    }
+    const ivj_side build{L->c2.data(), s2v.data(), e2v.data(), L->t2->n, nullptr};
+    rc = ivj_stream_open(ctx, &build, &o, op, L->max_rows, &L->st);
+    if (rc != IVJ_OK) return fail_both(rc);
+    auto* os = static_cast<ArrowArrayStream*>(out);
+    os->get_schema = lazy_get_schema; os->get_next = lazy_get_next; os->get_last_error = lazy_last_error; os->release = lazy_release;
+    os->private_data = L.release();
+    return IVJ_OK;
 }
 }  // namespace
 
@@ -826,6 +1131,24 @@ int ivj_nearest_arrow_stream(ivj_ctx* ctx, void* df1_stream, void* df2_stream, c
     as_keys_to_result(C);
     as_publish(C.R.release(), static_cast<ArrowArrayStream*>(out_stream));
     return IVJ_OK;
+} IVJ_ABI_CATCH
+
+int ivj_overlap_arrow_stream_lazy(ivj_ctx* ctx, void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2,
+                                  const ivj_opts* opts, const char* suffix1, const char* suffix2, int64_t batch_rows, int64_t max_batch_rows,
+                                  int64_t limit, void* out_stream) try {
+    return lazy_open(ctx, df1_stream, df2_stream, cols1, cols2, opts, IVJ_STREAM_OVERLAP, suffix1, suffix2, 0, batch_rows, max_batch_rows, limit, out_stream);
+} IVJ_ABI_CATCH
+
+int ivj_count_overlaps_arrow_stream_lazy(ivj_ctx* ctx, void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2,
+                                         const ivj_opts* opts, const char* suffix1, int64_t batch_rows, int64_t max_batch_rows, int64_t limit,
+                                         void* out_stream) try {
+    return lazy_open(ctx, df1_stream, df2_stream, cols1, cols2, opts, IVJ_STREAM_COUNT, suffix1, nullptr, 0, batch_rows, max_batch_rows, limit, out_stream);
+} IVJ_ABI_CATCH
+
+int ivj_nearest_arrow_stream_lazy(ivj_ctx* ctx, void* df1_stream, void* df2_stream, const char* const* cols1, const char* const* cols2,
+                                  const ivj_opts* opts, const char* suffix1, const char* suffix2, int32_t with_distance, int64_t batch_rows,
+                                  int64_t max_batch_rows, int64_t limit, void* out_stream) try {
+    return lazy_open(ctx, df1_stream, df2_stream, cols1, cols2, opts, IVJ_STREAM_NEAREST, suffix1, suffix2, with_distance, batch_rows, max_batch_rows, limit, out_stream);
 } IVJ_ABI_CATCH
 
 }  // extern "C"

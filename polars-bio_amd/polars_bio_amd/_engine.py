@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "ivj_allgather_counts", "ivj_allgatherv_dev", "ivj_overlap_allgather_dev",
     "ivj_count_overlaps_allgather_dev", "ivj_nearest_allgather_dev",
     "ivj_overlap_arrow_stream", "ivj_count_overlaps_arrow_stream", "ivj_nearest_arrow_stream", "ivj_arrow_encode_keys", "ivj_arrow_keys_free",
+    "ivj_overlap_arrow_stream_lazy", "ivj_count_overlaps_arrow_stream_lazy", "ivj_nearest_arrow_stream_lazy",
     "ivj_arrow_take_stream",
     "ivj_host_shard", "ivj_host_contig_hist",
     "ivj_host_narrow_i32", "ivj_host_encode_utf8", "ivj_host_encode_keys64", "ivj_host_remap_i32", "ivj_host_take", "ivj_host_widen_i32",
@@ -219,6 +220,9 @@ def load_library() -> C.CDLL:
         L.ivj_overlap_arrow_stream.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, vp]
         L.ivj_count_overlaps_arrow_stream.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_int64, C.c_int64, vp]
         L.ivj_nearest_arrow_stream.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, vp]
+        L.ivj_overlap_arrow_stream_lazy.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, vp]
+        L.ivj_count_overlaps_arrow_stream_lazy.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_int64, C.c_int64, C.c_int64, vp]
+        L.ivj_nearest_arrow_stream_lazy.argtypes = [vp, vp, vp, names3, names3, O, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, vp]
         L.ivj_arrow_encode_keys.argtypes = [vp, vp, names3, names3, C.POINTER(_ArrowKeys)]
         L.ivj_arrow_keys_free.argtypes = [C.POINTER(_ArrowKeys)]
         L.ivj_arrow_keys_free.restype = None
@@ -929,38 +933,57 @@ def arrow_take_stream(src, idx, batch_rows: int = 0):
 
 
 def _arrow_stream_call(engine, op: str, df1, df2, cols1, cols2, strict: bool, suffixes, k: int = 1, include_overlaps: bool = True,
-                       distance: bool = True, batch_rows: int = 0, limit=None):
+                       distance: bool = True, batch_rows: int = 0, limit=None, lazy: bool = False, max_batch_rows: int = 0):
     L = load_library()
     s1, s2, out = _export_stream(df1), _export_stream(df2), _ArrowStream()
     opts = make_opts(strict, 0, k, include_overlaps)
     lim = -1 if limit is None else int(limit)
     sfx = [None if x is None else str(x).encode() for x in suffixes]
+    a = (engine.h, C.addressof(s1), C.addressof(s2), _names3(cols1), _names3(cols2), C.byref(opts))
     with engine.lock:
         if op == "overlap":
-            rc = L.ivj_overlap_arrow_stream(engine.h, C.addressof(s1), C.addressof(s2), _names3(cols1), _names3(cols2), C.byref(opts), sfx[0], sfx[1],
-                                            int(batch_rows), lim, C.addressof(out))
+            rc = (L.ivj_overlap_arrow_stream_lazy(*a, sfx[0], sfx[1], int(batch_rows), int(max_batch_rows), lim, C.addressof(out)) if lazy else
+                  L.ivj_overlap_arrow_stream(*a, sfx[0], sfx[1], int(batch_rows), lim, C.addressof(out)))
         elif op == "count_overlaps":
-            rc = L.ivj_count_overlaps_arrow_stream(engine.h, C.addressof(s1), C.addressof(s2), _names3(cols1), _names3(cols2), C.byref(opts), sfx[0],
-                                                   int(batch_rows), lim, C.addressof(out))
+            rc = (L.ivj_count_overlaps_arrow_stream_lazy(*a, sfx[0], int(batch_rows), int(max_batch_rows), lim, C.addressof(out)) if lazy else
+                  L.ivj_count_overlaps_arrow_stream(*a, sfx[0], int(batch_rows), lim, C.addressof(out)))
         else:
-            rc = L.ivj_nearest_arrow_stream(engine.h, C.addressof(s1), C.addressof(s2), _names3(cols1), _names3(cols2), C.byref(opts), sfx[0], sfx[1],
-                                            1 if distance else 0, int(batch_rows), lim, C.addressof(out))
-    _check(L, rc, f"ivj_{op}_arrow_stream")
-    return _import_stream(out)
+            rc = (L.ivj_nearest_arrow_stream_lazy(*a, sfx[0], sfx[1], 1 if distance else 0, int(batch_rows), int(max_batch_rows), lim, C.addressof(out)) if lazy else
+                  L.ivj_nearest_arrow_stream(*a, sfx[0], sfx[1], 1 if distance else 0, int(batch_rows), lim, C.addressof(out)))
+    _check(L, rc, f"ivj_{op}_arrow_stream" + ("_lazy" if lazy else ""))
+    reader = _import_stream(out)
+    if not lazy:
+        return reader
+    # the lazy stream works on the engine's context whenever a batch is pulled: every pull is made under the engine's lock
+    import pyarrow as pa
+
+    def pull():
+        while True:
+            with engine.lock:
+                try:
+                    b = reader.read_next_batch()
+                except StopIteration:
+                    return
+            yield b
+    return pa.RecordBatchReader.from_batches(reader.schema, pull())
 
 
-def overlap_arrow_stream(engine, df1, df2, strict: bool, cols1=None, cols2=None, suffixes=("_1", "_2"), batch_rows: int = 0, limit=None):
-    """ivj_overlap_arrow_stream -> pyarrow.RecordBatchReader of the joined rows (every column of both sides, suffixed)."""
-    return _arrow_stream_call(engine, "overlap", df1, df2, cols1, cols2, strict, suffixes, batch_rows=batch_rows, limit=limit)
+def overlap_arrow_stream(engine, df1, df2, strict: bool, cols1=None, cols2=None, suffixes=("_1", "_2"), batch_rows: int = 0, limit=None,
+                         lazy: bool = False, max_batch_rows: int = 0):
+    """ivj_overlap_arrow_stream[_lazy] -> pyarrow.RecordBatchReader of the joined rows (every column of both sides, suffixed).
+    lazy: df1 is pulled batch by batch while the result is read (host memory bounded by max_batch_rows, not by len(df1))."""
+    return _arrow_stream_call(engine, "overlap", df1, df2, cols1, cols2, strict, suffixes, batch_rows=batch_rows, limit=limit, lazy=lazy, max_batch_rows=max_batch_rows)
 
 
-def count_overlaps_arrow_stream(engine, df1, df2, strict: bool, cols1=None, cols2=None, suffix="", batch_rows: int = 0, limit=None):
-    return _arrow_stream_call(engine, "count_overlaps", df1, df2, cols1, cols2, strict, (suffix, None), batch_rows=batch_rows, limit=limit)
+def count_overlaps_arrow_stream(engine, df1, df2, strict: bool, cols1=None, cols2=None, suffix="", batch_rows: int = 0, limit=None,
+                                lazy: bool = False, max_batch_rows: int = 0):
+    return _arrow_stream_call(engine, "count_overlaps", df1, df2, cols1, cols2, strict, (suffix, None), batch_rows=batch_rows, limit=limit, lazy=lazy,
+                              max_batch_rows=max_batch_rows)
 
 
 def nearest_arrow_stream(engine, df1, df2, strict: bool, cols1=None, cols2=None, suffixes=("_1", "_2"), k: int = 1, include_overlaps: bool = True,
-                         distance: bool = True, batch_rows: int = 0, limit=None):
-    return _arrow_stream_call(engine, "nearest", df1, df2, cols1, cols2, strict, suffixes, k, include_overlaps, distance, batch_rows, limit)
+                         distance: bool = True, batch_rows: int = 0, limit=None, lazy: bool = False, max_batch_rows: int = 0):
+    return _arrow_stream_call(engine, "nearest", df1, df2, cols1, cols2, strict, suffixes, k, include_overlaps, distance, batch_rows, limit, lazy, max_batch_rows)
 
 
 _default_engine: Optional[Engine] = None

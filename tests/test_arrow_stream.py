@@ -273,3 +273,148 @@ def test_arrow_stream_entries_on_empty_and_unsupported_inputs():
         assert E.arrow_encode_keys(t, nested)[2] == ["chr1"]
     finally:
         eng.close()
+
+
+# ---- the lazy forms (round 5): df1 pulled batch by batch from inside the result stream -------------------------------------------
+def _sorted_equal(a: pa.Table, b: pa.Table, key):
+    da, db = a.to_pandas(), b.to_pandas()
+    assert list(da.columns) == list(db.columns)
+    da, db = _canon(da, key), _canon(db, key)
+    for c in da.columns:
+        xa = da[c].astype(object).where(da[c].notna(), None).tolist()
+        xb = db[c].astype(object).where(db[c].notna(), None).tolist()
+        assert xa == xb, c
+
+
+@pytest.mark.gpu
+def test_lazy_arrow_streams_equal_the_eager_ones():
+    """ivj_*_arrow_stream_lazy against the eager entry on multi-batch inputs with every column kind: same rows (any order), same
+    schema; df1 batches larger than max_batch_rows are submitted in slices; a chrom that only df1 has matches nothing; limit."""
+    eng = E.Engine(0)
+    try:
+        rng = np.random.default_rng(15)
+        t1, t2 = _frames(rng, n1=9000, n2=900)
+        t1c, t2c = _rechunk(t1, [1000, 7, 2500, 3000]), _rechunk(t2, [100, 300])
+        key = ["start_1", "end_1", "start_2", "end_2", "gene_2", "score_1"]
+        for mbr in (0, 512):                                                    # default slices / every df1 batch cut into 512-row slices
+            lazy = E.overlap_arrow_stream(eng, t1c, t2c, strict=True, batch_rows=3000, lazy=True, max_batch_rows=mbr).read_all()
+            eager = E.overlap_arrow_stream(eng, t1c, t2c, strict=True).read_all()
+            assert lazy.schema == eager.schema and lazy.num_rows == eager.num_rows > 1000
+            assert max(len(b) for b in lazy.to_batches()) <= 3000
+            _sorted_equal(lazy, eager, key)
+        lc = E.count_overlaps_arrow_stream(eng, t1c, t2c, strict=False, lazy=True, max_batch_rows=2000).read_all()
+        ec = E.count_overlaps_arrow_stream(eng, t1c, t2c, strict=False).read_all()
+        assert lc.schema == ec.schema and lc.equals(ec)                         # df1 row order is kept batch by batch
+        for k in (1, 3):
+            ln = E.nearest_arrow_stream(eng, t1c, t2c, strict=True, k=k, lazy=True, max_batch_rows=700).read_all()
+            en = E.nearest_arrow_stream(eng, t1c, t2c, strict=True, k=k).read_all()
+            assert ln.schema == en.schema and ln.num_rows == en.num_rows
+            _sorted_equal(ln, en, ["start_1", "end_1", "score_1", "distance", "start_2", "gene_2"])
+        lim = E.overlap_arrow_stream(eng, t1c, t2c, strict=True, limit=17, lazy=True, max_batch_rows=600).read_all()
+        assert lim.num_rows == 17
+        empty = t1.slice(0, 0)
+        assert E.overlap_arrow_stream(eng, empty, t2c, strict=True, lazy=True).read_all().num_rows == 0
+        assert E.overlap_arrow_stream(eng, t1c, t2.slice(0, 0), strict=True, lazy=True).read_all().num_rows == 0
+        assert E.count_overlaps_arrow_stream(eng, t1c, t2.slice(0, 0), strict=True, lazy=True).read_all().column("count").to_pylist() == [0] * 9000
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_lazy_arrow_stream_never_holds_more_than_a_few_probe_batches():
+    """A generator-backed df1 of 40 batches: the library pulls them ONE AT A TIME while the result is read (at most three are alive
+    inside it at any moment, the session's depth), stops pulling once `limit` is reached, and an error in a LATE batch (a coordinate
+    beyond int32) surfaces from the result stream, after the earlier batches' rows were delivered."""
+    import gc
+    import weakref
+    eng = E.Engine(0)
+    try:
+        rng = np.random.default_rng(4)
+        t2 = pa.table({"chrom": ["chr1"] * 2000, "start": pa.array(np.arange(2000) * 500, pa.int64()), "end": pa.array(np.arange(2000) * 500 + 400, pa.int64())})
+        schema = pa.schema([("chrom", pa.string()), ("start", pa.int64()), ("end", pa.int64()), ("tag", pa.int32())])
+        state = {"made": 0, "alive": [], "max_alive": 0}
+
+        def batches(n_batches, rows, bad_at=None):
+            for b in range(n_batches):
+                s = rng.integers(0, 1_000_000, rows)
+                if bad_at is not None and b == bad_at:
+                    s = s.astype(np.int64); s[5] = 2**40
+                rb = pa.RecordBatch.from_arrays([pa.array(["chr1"] * rows), pa.array(s, pa.int64()), pa.array(s + 100, pa.int64()),
+                                                 pa.array(np.full(rows, b, np.int32))], schema=schema)
+                state["made"] += 1
+                state["alive"].append(weakref.ref(rb.column(1)))
+                yield rb
+                del rb
+                gc.collect()
+                state["max_alive"] = max(state["max_alive"], sum(1 for w in state["alive"] if w() is not None))
+
+        rd = E.overlap_arrow_stream(eng, pa.RecordBatchReader.from_batches(schema, batches(40, 5000)), t2, strict=True, lazy=True, max_batch_rows=8192)
+        assert state["made"] == 0                                              # nothing is pulled before the result is
+        seen, rows = set(), 0
+        for rb in rd:
+            seen.update(rb.column("tag_1").to_pylist()); rows += rb.num_rows
+            assert state["made"] <= max(seen) + 4                              # the library runs at most three batches ahead of what it has delivered
+        assert seen == set(range(40)) and rows > 40 * 1000 and state["made"] == 40
+        assert state["max_alive"] <= 5, state["max_alive"]
+        # limit: df1 is not pulled to its end
+        state.update(made=0, alive=[], max_alive=0)
+        rd = E.overlap_arrow_stream(eng, pa.RecordBatchReader.from_batches(schema, batches(40, 5000)), t2, strict=True, lazy=True, limit=3000)
+        assert rd.read_all().num_rows == 3000 and state["made"] <= 6
+        # a late failure
+        state.update(made=0, alive=[], max_alive=0)
+        rd = E.overlap_arrow_stream(eng, pa.RecordBatchReader.from_batches(schema, batches(10, 5000, bad_at=7)), t2, strict=True, lazy=True)
+        got = 0
+        with pytest.raises(Exception, match="does not fit int32|not in range"):
+            for rb in rd:
+                got += rb.num_rows
+        assert got > 0
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_lazy_arrow_stream_10M_x_1M_against_the_oracle():
+    """BASELINE config 2's shape through the lazy one-call entry: 10 M probe rows in 16 batches with a string chrom and int64
+    coordinates, 1 M build rows; the (probe row, build row) pairs -- recovered from payload columns that carry the row numbers --
+    equal the oracle's, bit for bit."""
+    from oracle import oracle as O
+    from polars_bio_amd import synth
+    probe = synth.make_side(10_000_000, 42, synth.PROBE_LEN, 1)
+    build = synth.make_side(1_000_000, 43, synth.BUILD_LEN, 1)
+    ep, eb = O.overlap_fast(O.Index(O.Side(*build), 1), O.Side(*probe), True)
+    t1 = pa.table({"chrom": pa.array(np.array(["chr1"], dtype=object)[probe[0]], pa.string()), "start": pa.array(probe[1].astype(np.int64)),
+                   "end": pa.array(probe[2].astype(np.int64)), "row": pa.array(np.arange(len(probe[0]), dtype=np.int32))})
+    t2 = pa.table({"chrom": pa.array(np.array(["chr1"], dtype=object)[build[0]], pa.string()), "start": pa.array(build[1].astype(np.int64)),
+                   "end": pa.array(build[2].astype(np.int64)), "row": pa.array(np.arange(len(build[0]), dtype=np.int32))})
+    t1c = pa.Table.from_batches(t1.to_batches(max_chunksize=625_000))
+    eng = E.Engine(0)
+    try:
+        import time
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            res = E.overlap_arrow_stream(eng, t1c, t2, strict=True, lazy=True, batch_rows=1 << 20, max_batch_rows=2_500_000).read_all()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        p, b = res.column("row_1").to_numpy(), res.column("row_2").to_numpy()
+        assert len(p) == len(ep)
+        o, oe = np.lexsort((b, p)), np.lexsort((eb, ep))
+        assert (p[o] == ep[oe]).all() and (b[o] == eb[oe]).all()
+        assert (res.column("start_1").to_numpy() == probe[1][p]).all() and (res.column("end_2").to_numpy() == build[2][b]).all()
+        print(f"lazy arrow stream 10M x 1M (string chrom, int64 coordinates, {len(p)} rows of 8 columns): {best:.3f} s")
+    finally:
+        eng.close()
+
+
+def test_a_failed_call_still_consumes_both_input_streams():
+    """ADVICE (round 4): the *_arrow_stream entry points and ivj_arrow_encode_keys consume their input streams whatever the outcome --
+    df1 fails its range check, and df2 (never looked at) has been released by the library all the same: its producer saw the release."""
+    import ctypes as C
+    t = pa.table({"chrom": ["chr1", "chr2"], "start": [1, 5], "end": [3, 9]})
+    bad = pa.table({"chrom": ["chr1"], "start": [2**40], "end": [2**40 + 5]})
+    s1, s2 = E._export_stream(bad), E._export_stream(t)
+    k = E._ArrowKeys()
+    L = E.load_library()
+    rc = L.ivj_arrow_encode_keys(C.addressof(s1), C.addressof(s2), None, None, C.byref(k))
+    assert rc != 0 and b"not in range" in L.ivj_last_error()
+    assert not s1.release and not s2.release                                   # both structs are marked released (Arrow C stream contract)
