@@ -46,6 +46,10 @@ def main():
         one = E.Engine(0)
         dt, n = best(lambda: E.overlap_arrow_stream(one, t1, t2, True).read_all().num_rows)
         print(f"ivj_overlap_arrow_stream 10M x 1M (string chrom, int64 coords, 1 extra column per side), all batches read   {dt:7.3f} s   rows {n:,}")
+        for mbr, chunks in ((2_500_000, 625_000), (2_500_000, 0), (5_000_000, 0)):
+            src = pa.Table.from_batches(t1.to_batches(max_chunksize=chunks)) if chunks else t1
+            dt, n = best(lambda: E.overlap_arrow_stream(one, src, t2, True, lazy=True, max_batch_rows=mbr).read_all().num_rows)
+            print(f"ivj_overlap_arrow_stream_lazy, df1 in {'%d-row batches' % chunks if chunks else 'one batch'}, slices of {mbr} rows   {dt:7.3f} s   rows {n:,}")
         dt, n = best(lambda: pb.overlap(t1, t2, output_type="pyarrow.Table").num_rows)
         print(f"pb.overlap (Python front door) on the same frames                                                          {dt:7.3f} s   rows {n:,}")
 
