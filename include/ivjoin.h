@@ -526,6 +526,13 @@ int ivj_host_remap_i32(const void* idx, int32_t idx_bytes, int64_t n, const int3
 /* dst[i] = src[idx[i]] for 4- or 8-byte values (0 for a negative index): the non-key columns of the joined rows. */
 int ivj_host_take(const void* src, int32_t elem_bytes, int64_t n_src, const int32_t* idx, int64_t n, void* dst, int32_t threads);
 
+/* dst[idx[i]] = src[i] for rows of row_bytes bytes: the mirror of ivj_host_take -- a shard's per-probe results (counts, nearest rows and
+ * distances) back to their GLOBAL probe rows when one process drives several devices (threaded; the indices of one call are distinct;
+ * an index outside [0, n_dst) is refused before anything is written).  remap (rows of int32 values only, NULL: none): the value stored is
+ * remap[src value] for a value in [0, remap_len) and -1 otherwise -- a shard's local build rows become global rows on the way. */
+int ivj_host_scatter(const void* src, int32_t row_bytes, int64_t n, const int32_t* idx, int64_t n_dst, void* dst, const int32_t* remap, int64_t remap_len,
+                     int32_t threads);
+
 /* Contig sharding of one side for `world` ranks ("host buckets both sides by contig id"; the reference's
  * partitioner cuts by row count, src/scan.rs:233-277): owner[c] = rank of contig c (n_contigs entries), a row whose contig lies
  * outside [0, n_contigs) belongs to no rank.  One counting pass fills counts[world]; with output columns (arrays of `world`

@@ -315,6 +315,46 @@ static int ivj_host_take_impl(const void* src, int32_t elem_bytes, int64_t n_src
     return IVJ_OK;
 }
 
+// dst[idx[i]] = src[i] (rows of row_bytes = 4, 8 or any other width): the mirror of ivj_host_take -- per-probe results of a shard back
+// to their global rows.  The indices of one call are distinct by contract (a shard's rows), so the threads never meet; an index outside
+// [0, n_dst) is refused before anything is written.  Optional remap (4-byte rows only): the stored value is remap[src[i]] for
+// src[i] >= 0 and -1 otherwise (a shard's local build rows -> global build rows on the way).
+static int ivj_host_scatter_impl(const void* src, int32_t row_bytes, int64_t n, const int32_t* idx, int64_t n_dst, void* dst, const int32_t* remap,
+                                 int64_t remap_len, int32_t threads) {
+    if (n < 0 || n_dst < 0 || row_bytes < 1 || (n > 0 && (!src || !idx || !dst))) return fail(IVJ_EINVAL, "host scatter: bad argument");
+    if (remap && row_bytes % 4 != 0) return fail(IVJ_EINVAL, "host scatter: a remap needs rows of 4-byte values");
+    if (n == 0) return IVJ_OK;
+    const int t = fd_threads(n, threads, 1 << 15);
+    std::vector<char> bad((size_t)t + 1, 0);
+    fd_parallel(n, t, [&](int k, int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) if ((uint64_t)(int64_t)idx[i] >= (uint64_t)n_dst) { bad[(size_t)k] = 1; break; }
+    });
+    for (char b : bad) if (b) return fail(IVJ_EINVAL, "host scatter: a row index lies outside the destination");
+    fd_parallel(n, t, [&](int, int64_t lo, int64_t hi) {
+        if (remap) {
+            const int w = row_bytes / 4;
+            for (int64_t i = lo; i < hi; ++i)
+                for (int j = 0; j < w; ++j) {
+                    const int32_t v = ((const int32_t*)src)[i * w + j];
+                    ((int32_t*)dst)[(int64_t)idx[i] * w + j] = (v >= 0 && (int64_t)v < remap_len) ? remap[v] : -1;
+                }
+        } else if (row_bytes == 8) {
+            for (int64_t i = lo; i < hi; ++i) {
+                if (i + 16 < hi) __builtin_prefetch((const char*)dst + (size_t)idx[i + 16] * 8, 1);
+                ((uint64_t*)dst)[idx[i]] = ((const uint64_t*)src)[i];
+            }
+        } else if (row_bytes == 4) {
+            for (int64_t i = lo; i < hi; ++i) {
+                if (i + 16 < hi) __builtin_prefetch((const char*)dst + (size_t)idx[i + 16] * 4, 1);
+                ((uint32_t*)dst)[idx[i]] = ((const uint32_t*)src)[i];
+            }
+        } else {
+            for (int64_t i = lo; i < hi; ++i) std::memcpy((char*)dst + (size_t)idx[i] * (size_t)row_bytes, (const char*)src + (size_t)i * (size_t)row_bytes, (size_t)row_bytes);
+        }
+    });
+    return IVJ_OK;
+}
+
 static int ivj_host_widen_i32_impl(const int32_t* src, int64_t n, int64_t* dst, int32_t threads) {
     if (n < 0 || (n > 0 && (!src || !dst))) return fail(IVJ_EINVAL, "widen: bad argument");
     if (n == 0) return IVJ_OK;
@@ -408,6 +448,10 @@ int ivj_host_remap_i32(const void* idx, int32_t idx_bytes, int64_t n, const int3
 }
 int ivj_host_take(const void* src, int32_t elem_bytes, int64_t n_src, const int32_t* idx, int64_t n, void* dst, int32_t threads) {
     IVJ_HOST_GUARD(ivj_host_take_impl(src, elem_bytes, n_src, idx, n, dst, threads))
+}
+int ivj_host_scatter(const void* src, int32_t row_bytes, int64_t n, const int32_t* idx, int64_t n_dst, void* dst, const int32_t* remap, int64_t remap_len,
+                     int32_t threads) {
+    IVJ_HOST_GUARD(ivj_host_scatter_impl(src, row_bytes, n, idx, n_dst, dst, remap, remap_len, threads))
 }
 int ivj_host_widen_i32(const int32_t* src, int64_t n, int64_t* dst, int32_t threads) {
     IVJ_HOST_GUARD(ivj_host_widen_i32_impl(src, n, dst, threads))

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "ivj_overlap_arrow_stream_lazy", "ivj_count_overlaps_arrow_stream_lazy", "ivj_nearest_arrow_stream_lazy",
     "ivj_arrow_take_stream",
     "ivj_host_shard", "ivj_host_contig_hist",
-    "ivj_host_narrow_i32", "ivj_host_encode_utf8", "ivj_host_encode_keys64", "ivj_host_remap_i32", "ivj_host_take", "ivj_host_widen_i32",
+    "ivj_host_narrow_i32", "ivj_host_encode_utf8", "ivj_host_encode_keys64", "ivj_host_remap_i32", "ivj_host_take", "ivj_host_scatter", "ivj_host_widen_i32",
 ]
 
 STREAM_OVERLAP, STREAM_COUNT, STREAM_NEAREST = 0, 1, 2
@@ -213,6 +213,7 @@ def load_library() -> C.CDLL:
         L.ivj_host_encode_keys64.argtypes = [vp, C.c_int64, vp, vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
         L.ivj_host_remap_i32.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32]
         L.ivj_host_take.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, vp, C.c_int32]
+        L.ivj_host_scatter.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, C.c_int32]
         L.ivj_host_widen_i32.argtypes = [vp, C.c_int64, vp, C.c_int32]
         L.ivj_host_shard.argtypes = [vp, vp, vp, C.c_int64, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_int32]
         L.ivj_host_contig_hist.argtypes = [vp, C.c_int64, C.c_int32, vp, C.c_int32]

@@ -80,6 +80,19 @@ def take(src: np.ndarray, idx: np.ndarray) -> np.ndarray:
     return out
 
 
+def scatter(dst: np.ndarray, idx: np.ndarray, src: np.ndarray, remap: np.ndarray = None):
+    """dst[idx] = src (rows of dst / src along axis 0; distinct indices), threaded and outside the GIL: the mirror of ``take``.
+    remap (int32 values only): stores remap[v] for v >= 0 and -1 otherwise."""
+    L = load_library()
+    src = np.ascontiguousarray(src, dst.dtype)
+    idx = np.ascontiguousarray(idx, np.int32)
+    assert dst.flags.c_contiguous and len(src) == len(idx) and src.shape[1:] == dst.shape[1:]
+    row_bytes = dst.dtype.itemsize * int(np.prod(dst.shape[1:], dtype=np.int64))
+    rm = None if remap is None else np.ascontiguousarray(remap, np.int32)
+    _check(L, L.ivj_host_scatter(_ptr(src), row_bytes, len(idx), _ptr(idx), len(dst), _ptr(dst), None if rm is None else _ptr(rm), 0 if rm is None else len(rm), THREADS),
+           "ivj_host_scatter")
+
+
 def widen_i64(src: np.ndarray) -> np.ndarray:
     L = load_library()
     out = np.empty(len(src), np.int64)

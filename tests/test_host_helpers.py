@@ -178,3 +178,35 @@ def test_host_worker_pool_under_concurrent_callers_and_after_fork():
         os._exit(0 if ok else 3)
     _, st = os.waitpid(pid, 0)
     assert os.WEXITSTATUS(st) == 0
+
+
+def test_host_scatter_is_the_mirror_of_take():
+    """ivj_host_scatter: dst[idx[i]] = src[i] for 4- / 8-byte values and k-wide rows, with the optional local -> global remap of
+    int32 values (negative stays -1); an index outside the destination is refused before anything is written (round 5:
+    MultiEngine puts per-probe results back with it instead of `out[pid] = c` under the GIL)."""
+    from polars_bio_amd import _host as H, _engine as E
+    rng = np.random.default_rng(1)
+    n, m = 200_000, 300_000
+    pid = rng.permutation(m)[:n].astype(np.int32)
+    out = np.zeros(m, np.int64)
+    c = rng.integers(0, 100, n)
+    H.scatter(out, pid, c)
+    ref = np.zeros(m, np.int64); ref[pid] = c
+    assert (out == ref).all()
+    f = np.zeros(m, np.int32)
+    H.scatter(f, pid, (c % 2).astype(np.int32))
+    assert (f[pid] == c % 2).all() and f.sum() == (c % 2).sum()
+    idx = np.full((m, 3), -7, np.int32)
+    i = rng.integers(-1, 50, (n, 3)).astype(np.int32)
+    bid = (np.arange(50) * 3).astype(np.int32)
+    H.scatter(idx, pid, i, remap=bid)
+    ref = np.full((m, 3), -7, np.int32); ref[pid] = np.where(i >= 0, bid[np.where(i >= 0, i, 0)], -1)
+    assert (idx == ref).all()
+    d = np.full((m, 3), -1, np.int64)
+    dv = rng.integers(0, 10**12, (n, 3))
+    H.scatter(d, pid, dv)
+    assert (d[pid] == dv).all()
+    before = out.copy()
+    with pytest.raises(E.EngineError, match="outside the destination"):
+        H.scatter(out, np.array([5, m], np.int32), np.array([1, 2]))
+    assert (out == before).all()

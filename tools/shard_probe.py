@@ -35,6 +35,13 @@ def main():
             eng = E.default_engine()
             t = time.perf_counter(); p, b = eng.overlap(probe, build, True, 24); dt = time.perf_counter() - t
             print(f"MultiEngine.overlap on device slots 0,0 (shard + 2 x join + merge)   {dt:7.3f} s   pairs {len(p):,}")
+            # per-probe results back to their global rows: one native threaded scatter per device, outside the GIL (config 5's shape)
+            p5 = synth.make_side(200_000_000, 42, synth.PROBE_LEN, 24); b5 = synth.make_side(200_000, 43, synth.BUILD_LEN, 24)
+            t = time.perf_counter(); c5 = eng.count_overlaps(p5, b5, True, 24); dt = time.perf_counter() - t
+            print(f"MultiEngine.count_overlaps 200M x 200k on device slots 0,0 (shard + 2 x count + native scatter)   {dt:7.3f} s   sum {int(c5.sum()):,}")
+            t = time.perf_counter(); ref = np.zeros(len(c5), np.int64); ref[np.arange(len(c5))] = c5; dt = time.perf_counter() - t
+            print(f"   (for scale: ONE numpy indexed store of 200 M int64 values, what the round-4 merge did per device   {dt:7.3f} s)")
+            del p5, b5, c5, ref
         finally:
             pb.set_option("ivj.devices", "auto")
         # the one-call Arrow entry on config-2-shaped frames
