@@ -92,9 +92,9 @@ typedef struct {
                                   row count + join on the slice held in LDS (overlap count / fill / fused; falls back to 1
                                   when the build side exceeds 1536 x 5120 rows or for the other operations) */
     int32_t table_mode;        /* direct-address table form: 0 auto (16-byte records for build sides >= 2^20 rows; nearest k = 1 over
-                                  128-byte LINES -- one fetch per probe, probes in input order -- for build sides >= 2^17 rows once
+                                  64-byte LINES -- one fetch per probe, probes in input order -- for build sides >= 2^17 rows once
                                   the probe side is >= 8 x the build side), 1 records, 2 plain 4-byte bins, 3 records + the nearest
-                                  lines whatever the sizes (256 bytes of index per build row; other operations: as 1) */
+                                  lines whatever the sizes (128 bytes of index per build row; other operations: as 1) */
     int32_t slice_rows;        /* slice path: build rows per slice, 0 = auto (rows / 1024, rounded up to 64, <= 5120) */
     int32_t slice_chunk;       /* slice path: probes per join workgroup, 0 = auto (multiple of 4096) */
     int32_t deterministic;     /* overlap count -> fill pair on the slice path: 1 = the output is identical from run to run (stable
@@ -117,6 +117,13 @@ typedef struct {
 } ivj_timing;
 
 /* ---- library / context -------------------------------------------------- */
+/* The structs of this header carry no size field: a host built against another revision of it would hand the library structs of
+ * another length.  IVJ_ABI_VERSION is bumped whenever a struct or a signature changes (5: ivj_opts.deterministic, the lazy Arrow
+ * entries, the per-probe all-gathers, ivj_host_scatter); a binding checks ivj_abi_version() == the IVJ_ABI_VERSION it was built
+ * against right after loading the library (the ctypes binding does: polars_bio_amd/_engine.py::load_library; the Rust sketch in
+ * INTEGRATION.md does) and refuses to run otherwise. */
+#define IVJ_ABI_VERSION 5
+int ivj_abi_version(void);
 const char* ivj_last_error(void);
 const char* ivj_version(void);
 int ivj_device_count(int* n);
@@ -142,10 +149,14 @@ int ivj_ctx_profile_mark(ivj_ctx* ctx);
  * Inputs are borrowed host buffers; results come back in host memory.       */
 
 /* pb.overlap: all (probe_row, build_row) pairs.  The pairs of one probe row are contiguous and
- * ordered by (build.start, build row).  Probe rows appear in input order, or -- when the probe
- * side was bucketed (partition_mode) -- in the deterministic bucket order of the partition
- * (by genomic position of the probe end, input order inside a bucket tile).  The reference leaves
- * the row order unspecified (every reference test sorts).  Free with ivj_pairs_free. */
+ * ordered by (build.start, build row).  Probe rows appear in input order (small inputs, partition_mode 2)
+ * or bucket by bucket -- by genomic position of the probe end -- when the probe side was partitioned:
+ * with partition_mode 1 (256 buckets) in the stable order of that partition; on the contig-aligned slice
+ * path (the automatic choice from 1.5 M probe rows x 256 k build rows on) the default partition is the
+ * UNORDERED sampled one, so the order of the probe rows inside a bucket (and with it the order of the
+ * output) may differ from run to run while the pair SET is exact; opts->deterministic = 1 selects the
+ * stable partition there and an output that is identical from run to run.  The reference leaves the row
+ * order unspecified (every reference test sorts).  Free with ivj_pairs_free. */
 int ivj_overlap(ivj_ctx* ctx, const ivj_side* probe, const ivj_side* build,
                 const ivj_opts* opts, ivj_pairs* out);
 void ivj_pairs_free(ivj_pairs* p);

@@ -45,6 +45,7 @@ extern "C" {
 
 const char* ivj_last_error(void) { return g_err.c_str(); }
 const char* ivj_version(void) { return "ivjoin-hip 0.1 (gfx950)"; }
+int ivj_abi_version(void) { return IVJ_ABI_VERSION; }
 int64_t ivj_host_mem_available(void) { return (int64_t)host_mem_available(); }
 
 int ivj_device_count(int* n) try {

@@ -24,7 +24,7 @@ FILTER_STRICT = 1  # FilterOp.Strict (0-based half-open)
 
 # every symbol include/ivjoin.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "ivj_last_error", "ivj_version", "ivj_device_count", "ivj_host_mem_available", "ivj_ctx_create", "ivj_ctx_destroy",
+    "ivj_last_error", "ivj_version", "ivj_abi_version", "ivj_device_count", "ivj_host_mem_available", "ivj_ctx_create", "ivj_ctx_destroy",
     "ivj_ctx_set_stream", "ivj_ctx_sync", "ivj_ctx_enable_timing", "ivj_ctx_get_timings", "ivj_ctx_profile_mark",
     "ivj_overlap", "ivj_pairs_free", "ivj_count_overlaps", "ivj_nearest",
     "ivj_index_build_dev", "ivj_index_free", "ivj_overlap_count_dev", "ivj_overlap_fill_dev", "ivj_overlap_fused_dev",
@@ -44,6 +44,7 @@ ABI_SYMBOLS = [
     "ivj_host_narrow_i32", "ivj_host_encode_utf8", "ivj_host_encode_keys64", "ivj_host_remap_i32", "ivj_host_take", "ivj_host_scatter", "ivj_host_widen_i32",
 ]
 
+ABI_VERSION = 5            # include/ivjoin.h: IVJ_ABI_VERSION (struct layouts and signatures this binding assumes)
 STREAM_OVERLAP, STREAM_COUNT, STREAM_NEAREST = 0, 1, 2
 
 ROW_COLUMNS = ("probe_idx", "build_idx", "contig", "start_1", "end_1", "start_2", "end_2")
@@ -142,6 +143,9 @@ def load_library() -> C.CDLL:
         P, O = C.POINTER(_Side), C.POINTER(_Opts)
         vp = C.c_void_p
         L.ivj_last_error.restype = C.c_char_p
+        if not hasattr(L, "ivj_abi_version") or L.ivj_abi_version() != ABI_VERSION:
+            raise EngineError(f"{LIB_PATH} speaks ABI version {L.ivj_abi_version() if hasattr(L, 'ivj_abi_version') else '?'}, this binding was written "
+                              f"against {ABI_VERSION} (include/ivjoin.h: IVJ_ABI_VERSION): rebuild the library")
         L.ivj_version.restype = C.c_char_p
         L.ivj_host_mem_available.restype = C.c_int64
         L.ivj_device_count.argtypes = [C.POINTER(C.c_int)]

@@ -263,6 +263,16 @@ def nearest_batches(df1, df2, suffixes=("_1", "_2"), cols1=None, cols2=None, k: 
     return gen
 
 
+def _is_one_shot(df) -> bool:
+    """True for a source that can be streamed only once: a pyarrow.RecordBatchReader, or an object that only offers
+    ``__arrow_c_stream__`` (tables, frames and paths can be opened again)."""
+    if isinstance(df, pa.RecordBatchReader):
+        return True
+    if isinstance(df, (pa.Table, pa.RecordBatch, str)) or hasattr(df, "to_arrow") or hasattr(df, "collect") or hasattr(df, "iloc"):
+        return False
+    return hasattr(df, "__arrow_c_stream__")
+
+
 def _polars_lazy_result(df1, df2, zero_based, limit, batches_fn, **kw):
     """``output_type="polars.LazyFrame"`` (the reference's default) with polars installed: a ``register_io_source`` LazyFrame
     over the streaming session -- nothing is read or joined until polars pulls, every collect() runs a fresh stream, a LazyFrame
@@ -274,6 +284,10 @@ def _polars_lazy_result(df1, df2, zero_based, limit, batches_fn, **kw):
     from ._metadata import set_coordinate_system
     if A.pl is None or S.source_schema(df1) is None:
         return None
+    if _is_one_shot(df1):
+        # a pyarrow.RecordBatchReader / a bare Arrow C stream can be read ONCE, a LazyFrame may be collected any number of times
+        # (and the schema probe below would already pull from it): such a source is materialised once, like the build side
+        df1 = A.to_arrow(df1)
     t2 = df2 if isinstance(df2, pa.Table) else A.to_arrow(df2)      # the build side is read ONCE, whatever the number of collects
     probe = batches_fn(df1, t2, as_reader=True, limit=0, _zero_based=zero_based, **kw)      # schema only: assembles an empty result
     schema = probe.schema

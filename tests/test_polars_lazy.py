@@ -130,3 +130,17 @@ def test_real_polars_lazy_scan_and_lazyframe_input(tmp_path):
                     output_type="polars.LazyFrame")
     pd.testing.assert_frame_equal(_sorted(lf.collect().to_pandas()), _sorted(exp), check_dtype=False)
     assert lf.head(3).collect().height == 3
+
+
+def test_one_shot_reader_input_can_be_collected_twice(fake_pl):
+    """ADVICE (round 4): df1 handed over as a pyarrow.RecordBatchReader (readable once) behind the default lazy output -- the
+    second collect() must see the same rows as the first, not an exhausted reader."""
+    pl, kind = fake_pl
+    r = pa.Table.from_pandas(pd.read_csv(f"{GOLDEN}/overlap/reads.csv"), preserve_index=False)
+    t = _csv(f"{GOLDEN}/overlap/targets.csv")
+    pb.set_option("datafusion.bio.coordinate_system_zero_based", "false")
+    res = pb.overlap(r.to_reader(), t, cols1=COLS, cols2=COLS)
+    assert isinstance(res, pl.LazyFrame)
+    exp = pd.read_csv(f"{GOLDEN}/expected_overlap.csv")
+    for _ in range(2):
+        pd.testing.assert_frame_equal(_sorted(res.collect().to_arrow().to_pandas()), _sorted(exp), check_dtype=False)
