@@ -62,6 +62,24 @@ run_stage() {
       python tools/pmc_summary.py $dirs > $o.summary.json 2> $o.summary.err; tail -3 $o.summary.err;
       python -c "import json,sys; d=json.load(open('$o.summary.json')); [print(k[:64], {n: round(v[n]['sum']/max(v[n]['rows'],1)) for n in v}) for k,v in d.items() if any(t in k for t in ('count_overlaps','nearest_k1','k_cs_join','k_cs_scatter','k_cs_hist','k_unpermute','k_part_scatter','k_overlap_fused'))]" ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
+    densehunt) echo "== dense variant: a step above 25 ms on this box gets a --hip-trace --kernel-trace run (VERDICT r4 item 7)";
+      timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 $Q 2>$o.err | tee $o.json | cut -c1-200;
+      ms=$(python -c "import json,sys; print(json.loads(open('$o.json').read().strip().splitlines()[-1])['ms_per_step'])" 2>/dev/null || echo 0);
+      echo "dense ms_per_step on this box: $ms";
+      if python -c "import sys; sys.exit(0 if float('$ms') > 25 else 1)"; then
+        echo "SLOW BOX: tracing";
+        (cd /tmp && timeout 900 rocprofv3 --hip-trace --kernel-trace --stats -d "$OLDPWD/${o}_trace" -o dn --output-format csv -- python "$OLDPWD/bench.py" --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --no-pmc --no-cpu-baseline --no-extras > "$OLDPWD/${o}_trace.out" 2> "$OLDPWD/${o}_trace.err");
+        for f in $(find ${o}_trace -name "*hip_api_stats.csv" -o -name "*kernel_stats.csv"); do cp $f ${o}_$(basename $f); head -14 $f; done;
+        python - <<PY
+import csv, glob
+f = glob.glob("${o}_trace/**/*hip_api_trace.csv", recursive=True)
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    rows.sort(key=lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), reverse=True)
+    for r in rows[:25]:
+        print(r["Function"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, "ms at", int(r["Start_Timestamp"]))
+PY
+      fi ;;
     dry8*) echo "== 8 ranks on one GPU (in-process transport), workload ${WL:-overlap_100M_5M_24contig}, scale ${SCALE:-1.0}";
       timeout 1500 python tools/dryrun_ranks.py --world ${WORLD:-8} --workload ${WL:-overlap_100M_5M_24contig} --scale ${SCALE:-1.0} --steps 2 2>$o.err | tee $o.json | cut -c1-1200; tail -3 $o.err ;;
     c4fd) timeout 900 $B --workload nearest_50M_2M_24contig --force-dist --steps 5 --warmup 2 $Q 2>$o.err | tee $o.json | cut -c1-900; tail -2 $o.err ;;
