@@ -144,6 +144,15 @@ int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     if (capacity < ctx->ov_total) return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->ov_total) + " pairs");
     if (ctx->ov_total == 0) return IVJ_OK;
     if (!out_p || !out_b) return fail(IVJ_EINVAL, "output buffers are NULL");
+    if (ctx->ov_slice && opts->partition_mode == 0 && !opts->deterministic && ix->n_contigs > 0 && ctx->ov_total >= 16 * probe->n) {
+        // DENSE result (>= 16 pairs per probe row, now known exactly): the slice FILL spends its time in the long windows -- 44 ms
+        // for the 3.7 G pairs of the dense 100 M x 5 M variant -- where the flat kernel tests every candidate with its own lane
+        // (12.5 ms + its tables).  The count is exact, so the fused flat pass runs with capacity = the count (round 5; a trace of
+        // the dense bench showed the warm-up's count -> fill pair at 50 ms next to 15-ms fused steps: what pb.overlap ran).
+        int64_t got = 0;
+        IVJ_TRY(overlap_fused(ctx, ix, probe, opts, out_p, out_b, ctx->ov_total, &got));
+        return IVJ_OK;
+    }
     if (ctx->ov_slice) return ctx->ov_cs ? cs_overlap_fill(ctx, ix, opts, out_p, out_b) : slice_overlap_fill(ctx, ix, opts, out_p, out_b);
     const int64_t n = probe->n;
     const int64_t tiles = (n + PROBE_TILE - 1) / PROBE_TILE;

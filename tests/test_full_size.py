@@ -324,3 +324,28 @@ def test_eight_ranks_on_one_gpu_dry_run_at_full_size(workload):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"dryrun8_{workload}.json"), "w") as f:
         json.dump(line, f)
+
+
+def test_dense_result_of_the_count_fill_pair_takes_the_flat_kernel(eng):
+    """pb.overlap's count -> fill pair on a DENSE result (~ 100 pairs per probe row, slice-path sizes): once the count says >= 16 pairs
+    per probe row the fill is the flat fused pass run at the exact capacity (round 5) -- same pair set, the size-independent
+    properties of the full-size tests pin it (multiplicities, predicate, contiguous ascending runs, checksum)."""
+    rng = np.random.default_rng(77)
+    n_p, n_b, span = 1_600_000, 260_000, 60_000_000
+    bs = rng.integers(0, span, n_b).astype(np.int32)
+    build = (np.zeros(n_b, np.int32), bs, (bs + rng.integers(5_000, 40_000, n_b)).astype(np.int32))
+    ps = rng.integers(0, span, n_p).astype(np.int32)
+    probe = (np.zeros(n_p, np.int32), ps, (ps + rng.integers(100, 150, n_p)).astype(np.int32))
+    ix = O.Index(O.Side(*build), 1)
+    counts = O.count_overlaps_fast(ix, O.Side(*probe), True)
+    assert counts.sum() >= 16 * n_p
+    ep, eb = O.overlap_fast(ix, O.Side(*probe), True)
+    checksum = int(eb.astype(np.int64).sum())
+    del ep, eb
+    eng.enable_timing(2)
+    eng.timings()
+    p, b = eng.overlap(probe, build, True, 1)
+    t = eng.timings()
+    eng.enable_timing(0)
+    assert "overlap_flat" in t and "cs_fill_cached" not in t, sorted(t)
+    _check_pair_properties(p, b, probe, build, counts, checksum, "dense count -> fill")
