@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0, help="bound the all-core CPU-baseline runs to the first N probe rows (0: the identical input, every row; the 1-thread runs always take 2 M rows)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip two_pass_ms_per_step / host_path_s")
+    ap.add_argument("--step-times", type=int, default=0,
+                    help="after the timed region: N more steps, each bracketed by a synchronize, their wall times (and the host time spent inside "
+                         "the step call before the synchronize) on stderr -- where a slow box loses its time (diagnostics only)")
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps: timed steps only
     ap.add_argument("--kernel-table", action="store_true", help="print a per-kernel HIP-event table to stderr")
     ap.add_argument("--two-pass", action="store_true",
@@ -684,6 +687,17 @@ def main():
                     "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in ktimes.items()}}
 
+    if args.step_times > 0:
+        rows = []
+        for _ in range(args.step_times):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            t2 = time.perf_counter()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            rows.append((round((t3 - t1) * 1e3, 3), round((t2 - t1) * 1e3, 3)))
+        log("[bench] per-step wall ms (step incl. synchronize, host inside the step call): " + " ".join(f"{a}/{b}" for a, b in rows))
     if args.kernel_table:
         join.engine.enable_timing(2)
         for _ in range(3):

@@ -137,6 +137,9 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     return IVJ_OK;
 }
 
+int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
+                  int64_t capacity, int64_t* n_pairs);
+
 int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
                  int64_t capacity) {
     if (ctx->ov_n != probe->n || ctx->ov_probe_start != probe->start || ctx->ov_ix != ix || ctx->ov_filter != opts->filter_op)
