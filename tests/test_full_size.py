@@ -331,7 +331,7 @@ def test_dense_result_of_the_count_fill_pair_takes_the_flat_kernel(eng):
     per probe row the fill is the flat fused pass run at the exact capacity (round 5) -- same pair set, the size-independent
     properties of the full-size tests pin it (multiplicities, predicate, contiguous ascending runs, checksum)."""
     rng = np.random.default_rng(77)
-    n_p, n_b, span = 1_600_000, 260_000, 60_000_000
+    n_p, n_b, span = 1_600_000, 270_000, 60_000_000
     bs = rng.integers(0, span, n_b).astype(np.int32)
     build = (np.zeros(n_b, np.int32), bs, (bs + rng.integers(5_000, 40_000, n_b)).astype(np.int32))
     ps = rng.integers(0, span, n_p).astype(np.int32)
