@@ -376,6 +376,7 @@ def respawn_under_torchrun(args):
 def _comm_canary(comm, rank, world, dev, timeout_s):
     """True when every rank's 1024 int32 arrive at this rank through the library communicator within `timeout_s` seconds."""
     import threading
+    import torch            # (module scope has no torch: round 4's canary died of a NameError and every N > 1 run fell back to torch.distributed)
     out = {}
 
     def run():
