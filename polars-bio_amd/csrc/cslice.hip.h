@@ -112,19 +112,26 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_prep(const int32_t* __restric
         }
     }
     __syncthreads();
+    // per contig, in parallel: slices, cells, cell shift (the shift loop is the long part: up to 31 trips of 64-bit shifts -- round 4 ran
+    // it for every contig on ONE thread); then one thread lays the prefix sums down
+    __shared__ int l_ns[CS_MAX_CONTIGS], l_ncl[CS_MAX_CONTIGS], l_sh[CS_MAX_CONTIGS];
+    for (int c = tid; c < nc; c += CS_THREADS) {
+        const int a = l_a[c], b = l_a[c + 1];
+        const int ns = (b - a + g.R - 1) / g.R;
+        int ncl = g.cps * ns;
+        if (ncl < 2) ncl = 2;                                      // two cells keep the shift <= 31 for any int32 span
+        const uint32_t ulo = l_lo[c], uhi = l_hi[c];
+        int shift = 0;
+        while (shift < 31 && ((unsigned long long)(uhi - ulo) >> shift) + 1ull > (unsigned long long)ncl) ++shift;
+        l_ns[c] = ns; l_ncl[c] = ncl; l_sh[c] = shift;
+    }
+    __syncthreads();
     if (tid == 0) {
         int fs = 0, tb = 0;
         for (int c = 0; c < nc; ++c) {
-            const int a = l_a[c], b = l_a[c + 1];
-            const int ns = (b - a + g.R - 1) / g.R;
-            int ncl = g.cps * ns;
-            if (ncl < 2) ncl = 2;                                  // two cells keep the shift <= 31 for any int32 span
-            const uint32_t ulo = l_lo[c], uhi = l_hi[c];
-            int shift = 0;
-            while (shift < 31 && ((unsigned long long)(uhi - ulo) >> shift) + 1ull > (unsigned long long)ncl) ++shift;
-            l_cm[c] = make_int4((int)ulo, (int)uhi, shift, tb | (fs << 16));
+            l_cm[c] = make_int4((int)l_lo[c], (int)l_hi[c], l_sh[c], tb | (fs << 16));
             l_fs[c] = fs;
-            fs += ns; tb += ncl;
+            fs += l_ns[c]; tb += l_ncl[c];
         }
         l_fs[nc] = fs;
         l_cells = tb;
@@ -194,15 +201,13 @@ __device__ __forceinline__ uint32_t cs_bucket(const unsigned long long* __restri
 // ---- per-slice start bins, built once per index: one workgroup per slice ---------------------------------------------------
 // bins[j * (2 R + 2) + cl] = first slice-local row whose (start - min start) >> shift reaches cell cl (two cells per row);
 // bins[.. + ncell] = rows of the slice.
-__global__ __launch_bounds__(CS_THREADS) void k_cs_bins(const int32_t* __restrict__ bound, const int32_t* __restrict__ b_start,
-                                                       const int2* __restrict__ ep, const int32_t* __restrict__ b_contig,
-                                                       const int32_t* __restrict__ seg, int R, unsigned short* __restrict__ bins,
-                                                       int4* __restrict__ smeta, int32_t* __restrict__ far_rows) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+__device__ __forceinline__ void cs_bins_body(unsigned char* cs_lds, uint32_t* wmin, int j, const int32_t* __restrict__ bound, const int32_t* __restrict__ b_start,
+                                             const int2* __restrict__ ep, const int32_t* __restrict__ b_contig,
+                                             const int32_t* __restrict__ seg, int R, unsigned short* __restrict__ bins,
+                                             int4* __restrict__ smeta, int32_t* __restrict__ far_rows) {
     int32_t* l_start = reinterpret_cast<int32_t*>(cs_lds);                     // R
     unsigned short* l_bin = reinterpret_cast<unsigned short*>(l_start + R);    // 2 R + 2
-    __shared__ uint32_t wmin[CS_WAVES];
-    const int j = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int r0 = bound[j];
     const int rk = bound[j + 1] - r0;
     if (rk <= 0) {                                                             // unused slot (uniform)
@@ -259,6 +264,14 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_bins(const int32_t* __restric
         for (int w = 0; w < CS_WAVES; ++w) t += wmin[w];
         if (t) atomicAdd(far_rows, (int)t);
     }
+}
+__global__ __launch_bounds__(CS_THREADS) void k_cs_bins(const int32_t* __restrict__ bound, const int32_t* __restrict__ b_start,
+                                                       const int2* __restrict__ ep, const int32_t* __restrict__ b_contig,
+                                                       const int32_t* __restrict__ seg, int R, unsigned short* __restrict__ bins,
+                                                       int4* __restrict__ smeta, int32_t* __restrict__ far_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    __shared__ uint32_t wmin[CS_WAVES];
+    cs_bins_body(cs_lds, wmin, (int)blockIdx.x, bound, b_start, ep, b_contig, seg, R, bins, smeta, far_rows);
 }
 
 // ---- partition, pass 1: per-chunk bucket histogram -----------------------------------------------------------------------------
@@ -495,9 +508,8 @@ constexpr int CS_SGROUP = 8, CS_SRATE = 64;
 // gh[nb + 1] / gh[nb + 2] (round 5): the sample's largest probe length (end - start; 2^31 - 1 for an inverted row) and its largest
 // distance of a probe's end from its slice's smallest start -- what decides whether the call's records take the 8-byte form.
 template <bool STRICT>
-__global__ __launch_bounds__(CS_THREADS) void k_cs_sample_hist(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
-                                                              const int32_t* __restrict__ pe, int64_t n, uint32_t* __restrict__ gh) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+__device__ __forceinline__ void cs_sample_body(unsigned char* cs_lds, unsigned bid, unsigned nblocks, CsTab tab, CsGeom g, const int32_t* __restrict__ pc,
+                                               const int32_t* __restrict__ ps, const int32_t* __restrict__ pe, int64_t n, uint32_t* __restrict__ gh) {
     int4* l_cm = reinterpret_cast<int4*>(cs_lds);
     unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(l_cm + CS_MAX_CONTIGS);
     uint32_t* l_cell = reinterpret_cast<uint32_t*>(l_spl + g.nb);
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_sample_hist(CsTab tab, CsGeom
     __syncthreads();
     uint32_t mlen = 0, moff = 0;
     const int64_t n_groups = (n + (int64_t)CS_SGROUP * CS_SRATE - 1) / ((int64_t)CS_SGROUP * CS_SRATE);
-    for (int64_t t = (int64_t)blockIdx.x * CS_THREADS + threadIdx.x; t < n_groups * CS_SGROUP; t += (int64_t)gridDim.x * CS_THREADS) {
+    for (int64_t t = (int64_t)bid * CS_THREADS + threadIdx.x; t < n_groups * CS_SGROUP; t += (int64_t)nblocks * CS_THREADS) {
         const int64_t i = (t / CS_SGROUP) * ((int64_t)CS_SGROUP * CS_SRATE) + (t % CS_SGROUP);
         if (i < n) {
             const int32_t qe = pe[i], qs = ps[i];
@@ -530,6 +542,26 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_sample_hist(CsTab tab, CsGeom
     __syncthreads();
     for (int k = threadIdx.x; k <= g.nb; k += CS_THREADS) if (h[k]) atomicAdd(&gh[k], h[k]);
     if (threadIdx.x == 0) { atomicMax(&gh[g.nb + 1], h[g.nb + 1]); atomicMax(&gh[g.nb + 2], h[g.nb + 2]); }
+}
+template <bool STRICT>
+__global__ __launch_bounds__(CS_THREADS) void k_cs_sample_hist(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                              const int32_t* __restrict__ pe, int64_t n, uint32_t* __restrict__ gh) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    cs_sample_body<STRICT>(cs_lds, blockIdx.x, gridDim.x, tab, g, pc, ps, pe, n, gh);
+}
+// Round 5: the first call on a fresh index runs the per-slice bins (once per index) and the probe sample (once per call) as ONE launch --
+// both only need k_cs_prep's tables and do not depend on each other: workgroups [0, n_bins) build bins, the rest sample.
+template <bool STRICT>
+__global__ __launch_bounds__(CS_THREADS) void k_cs_bins_sample(int n_bins, const int32_t* __restrict__ bound, const int32_t* __restrict__ b_start,
+                                                              const int2* __restrict__ ep, const int32_t* __restrict__ b_contig,
+                                                              const int32_t* __restrict__ seg, int R, unsigned short* __restrict__ bins,
+                                                              int4* __restrict__ smeta, int32_t* __restrict__ far_rows,
+                                                              CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                              const int32_t* __restrict__ pe, int64_t n, uint32_t* __restrict__ gh) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    __shared__ uint32_t wmin[CS_WAVES];
+    if ((int)blockIdx.x < n_bins) cs_bins_body(cs_lds, wmin, (int)blockIdx.x, bound, b_start, ep, b_contig, seg, R, bins, smeta, far_rows);
+    else cs_sample_body<STRICT>(cs_lds, blockIdx.x - (unsigned)n_bins, gridDim.x - (unsigned)n_bins, tab, g, pc, ps, pe, n, gh);
 }
 
 // Regions of the record buffer: cap_b = 1.25 x (sampled count x CS_SRATE) + slack, starts aligned to 32 records (three 128-byte lines);

@@ -135,6 +135,7 @@ struct ivj_ctx {
     int cs_env_slack = 0;              // IVJ_CS_SLACK: records of slack per bucket region (tests force the overflow path with a tiny one)
     int64_t cs_sampled_overflows = 0;  // calls redone because a sampled region overflowed (ivj_debug_counter)
     bool cs_force_exact = false;       // set while a call whose sampled regions overflowed is redone
+    int cs_env_fuse_sample = 1;        // IVJ_CS_FUSE_SAMPLE=0: the slice bins and the probe sample of a fresh index as two launches (A/B runs)
     int cs_env_rec8 = 1;               // IVJ_CS_REC8=0: always 12-byte probe records (A/B runs)
     bool cs_force_rec12 = false;       // set while a call whose 8-byte records overflowed is redone
     int64_t cs_rec8_overflows = 0;     // calls redone with 12-byte records

@@ -59,15 +59,33 @@ bool cs_wanted(const ivj_ctx* ctx, const ivj_index* ix, const ivj_opts* opts) {
 
 constexpr double CS_FAR_LIMIT = 5e-4;
 
-int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix) {
+// The probe sample of a call that finds the index without its slice tables rides in the bins launch (k_cs_bins_sample)
+struct CsSampleArgs { bool strict; const int32_t *pc, *ps, *pe; int64_t n; uint32_t* gh; unsigned sgrid; size_t lds; };
+
+int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix, const CsSampleArgs* sample = nullptr) {
     if (ix->cs_built) return IVJ_OK;
     const CsGeom& g = ix->cs_g;
     LAUNCH(ctx, "cs_prep", k_cs_prep, 1, CS_THREADS, (const int32_t*)ix->seg, (const int32_t*)ix->b_start, g, ix->cs_bound, ix->cs_spl, ix->cs_cm, ix->cs_cell);
     const size_t lds = (size_t)4 * g.R + (size_t)2 * (2 * g.R + 8);
-    t_begin(ctx, "cs_bins");
-    hipLaunchKernelGGL(k_cs_bins, dim3(g.nb), dim3(CS_THREADS), lds, ctx->stream, (const int32_t*)ix->cs_bound, (const int32_t*)ix->b_start, (const int2*)ix->ep,
-                       (const int32_t*)ix->b_contig, (const int32_t*)ix->seg, g.R, ix->cs_bins, ix->cs_smeta, ix->flags + 1);
-    t_end(ctx);
+    if (sample) {
+        const CsTab tab{ix->cs_spl, ix->cs_cm, ix->cs_cell};
+        const size_t l2 = std::max(lds, sample->lds);
+        t_begin(ctx, "cs_bins_sample");
+        if (sample->strict)
+            hipLaunchKernelGGL((k_cs_bins_sample<true>), dim3((unsigned)g.nb + sample->sgrid), dim3(CS_THREADS), l2, ctx->stream, g.nb, (const int32_t*)ix->cs_bound, (const int32_t*)ix->b_start,
+                               (const int2*)ix->ep, (const int32_t*)ix->b_contig, (const int32_t*)ix->seg, g.R, ix->cs_bins, ix->cs_smeta, ix->flags + 1, tab, g, sample->pc, sample->ps,
+                               sample->pe, sample->n, sample->gh);
+        else
+            hipLaunchKernelGGL((k_cs_bins_sample<false>), dim3((unsigned)g.nb + sample->sgrid), dim3(CS_THREADS), l2, ctx->stream, g.nb, (const int32_t*)ix->cs_bound, (const int32_t*)ix->b_start,
+                               (const int2*)ix->ep, (const int32_t*)ix->b_contig, (const int32_t*)ix->seg, g.R, ix->cs_bins, ix->cs_smeta, ix->flags + 1, tab, g, sample->pc, sample->ps,
+                               sample->pe, sample->n, sample->gh);
+        t_end(ctx);
+    } else {
+        t_begin(ctx, "cs_bins");
+        hipLaunchKernelGGL(k_cs_bins, dim3(g.nb), dim3(CS_THREADS), lds, ctx->stream, (const int32_t*)ix->cs_bound, (const int32_t*)ix->b_start, (const int2*)ix->ep,
+                           (const int32_t*)ix->b_contig, (const int32_t*)ix->seg, g.R, ix->cs_bins, ix->cs_smeta, ix->flags + 1);
+        t_end(ctx);
+    }
     HIP_TRY(hipGetLastError());
     // Which join kernel serves this index: the share of the build rows whose prefix max, CS_WIN rows back, still reaches past
     // their start (k_cs_bins counts them) = the share of positions where a short probe's window would NOT settle inside the
@@ -153,7 +171,9 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
     const int64_t n = probe->n;
     const CsGeom& g = ix->cs_g;
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
-    IVJ_TRY(cs_ensure_tables(ctx, ix));
+    ctx->sl_sampled = cs_sampled_wanted(ctx, n, stable);
+    const bool fuse_sample = ctx->sl_sampled && !ix->cs_built && ctx->cs_env_fuse_sample != 0;     // bins + sample in one launch (IVJ_CS_FUSE_SAMPLE=0: two)
+    if (!fuse_sample) IVJ_TRY(cs_ensure_tables(ctx, ix));
     const CsTab tab{ix->cs_spl, ix->cs_cm, ix->cs_cell};
     const bool vec = aligned16(probe->contig) && aligned16(probe->start) && aligned16(probe->end) && (!probe->row_id || aligned16(probe->row_id));
     const size_t hist_lds = (size_t)16 * CS_MAX_CONTIGS + (size_t)8 * g.nb + (size_t)4 * g.ncells + 4 * (g.nb + 1);
@@ -175,11 +195,11 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         ctx->cs_attr_set = true;
     }
     int32_t* rec = reinterpret_cast<int32_t*>(ctx->sl_rec);
-    ctx->sl_sampled = cs_sampled_wanted(ctx, n, stable);
     if (ctx->sl_sampled) {
         // region sizes from a 1 / 64 sample of the probe side, one returning atomic per (tile, bucket) run in the scatter, no histogram pass
         if (!ctx->cs_sattr_set) {
             IVJ_TRY(set_dyn_lds(&k_cs_sample_hist<true>, 96 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_sample_hist<false>, 96 * 1024));
+            IVJ_TRY(set_dyn_lds(&k_cs_bins_sample<true>, 96 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_bins_sample<false>, 96 * 1024));
             IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 4, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 4, true>), 160 * 1024));
             IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 8, true>), 160 * 1024));
             IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 4, true, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 4, true, true>), 160 * 1024));
@@ -189,10 +209,15 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         HIP_TRY(hipMemsetAsync(ctx->sl_gh, 0, (size_t)(g.nb + 4) * 4, ctx->stream));
         const int64_t n_samp = (n + CS_SRATE - 1) / CS_SRATE;
         const unsigned sgrid = (unsigned)std::min<int64_t>(256, (n_samp + CS_THREADS - 1) / CS_THREADS);
-        t_begin(ctx, "cs_sample");
-        if (strict) hipLaunchKernelGGL((k_cs_sample_hist<true>), dim3(sgrid), dim3(CS_THREADS), hist_lds + 16, ctx->stream, tab, g, probe->contig, probe->start, probe->end, n, ctx->sl_gh);
-        else hipLaunchKernelGGL((k_cs_sample_hist<false>), dim3(sgrid), dim3(CS_THREADS), hist_lds + 16, ctx->stream, tab, g, probe->contig, probe->start, probe->end, n, ctx->sl_gh);
-        t_end(ctx);
+        if (fuse_sample) {
+            const CsSampleArgs sa{strict, probe->contig, probe->start, probe->end, n, ctx->sl_gh, sgrid, hist_lds + 16};
+            IVJ_TRY(cs_ensure_tables(ctx, ix, &sa));
+        } else {
+            t_begin(ctx, "cs_sample");
+            if (strict) hipLaunchKernelGGL((k_cs_sample_hist<true>), dim3(sgrid), dim3(CS_THREADS), hist_lds + 16, ctx->stream, tab, g, probe->contig, probe->start, probe->end, n, ctx->sl_gh);
+            else hipLaunchKernelGGL((k_cs_sample_hist<false>), dim3(sgrid), dim3(CS_THREADS), hist_lds + 16, ctx->stream, tab, g, probe->contig, probe->start, probe->end, n, ctx->sl_gh);
+            t_end(ctx);
+        }
         // the record format of the call (8-byte records where the sample says they fit) is decided in this kernel, on the device
         const int allow8 = (ctx->cs_env_rec8 != 0 && !ctx->cs_force_rec12) ? 1 : 0;
         LAUNCH(ctx, "cs_regions", k_cs_regions, 1, CS_THREADS, (const uint32_t*)ctx->sl_gh, g.nb, cs_region_slack(ctx, g, n), allow8, ctx->sl_rstart, ctx->sl_rcur, ctx->sl_meta);

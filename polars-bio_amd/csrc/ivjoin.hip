@@ -83,6 +83,7 @@ int ivj_ctx_create(int device, ivj_ctx** out) try {
     if (const char* ev = std::getenv("IVJ_CS_SAMPLED")) ctx->cs_env_sampled = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_SLACK")) ctx->cs_env_slack = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_REC8")) ctx->cs_env_rec8 = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_CS_FUSE_SAMPLE")) ctx->cs_env_fuse_sample = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_FILL_TWO")) ctx->cs_env_fill_two = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_WALK")) ctx->cs_env_walk = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("IVJ_JOINT_BINS")) ctx->env_joint_bins = std::atoi(ev);
