@@ -613,12 +613,17 @@ def main():
     state.pop("gather_events", None)
     join.engine.enable_timing(1)          # HIP events around the probe kernels only, on the launch stream
     t0 = time.perf_counter()
+    t_host = [t0]
     for _ in range(args.steps):
         mark()
         local_units, out = step()
+        t_host.append(time.perf_counter())          # host clock only (no synchronisation): where a slow timed region lost its time
     mark()
     barrier()
     elapsed = time.perf_counter() - t0
+    if rank == 0 and args.step_times > 0:
+        log("[bench] timed region, host ms per step call: " + " ".join(f"{(b - a) * 1e3:.3f}" for a, b in zip(t_host, t_host[1:])) +
+            f"; closing barrier {(t0 + elapsed - t_host[-1]) * 1e3:.3f}")
     ktimes = join.engine.timings()
     join.engine.enable_timing(0)
 

@@ -63,10 +63,15 @@ run_stage() {
       python -c "import json,sys; d=json.load(open('$o.summary.json')); [print(k[:64], {n: round(v[n]['sum']/max(v[n]['rows'],1)) for n in v}) for k,v in d.items() if any(t in k for t in ('count_overlaps','nearest_k1','k_cs_join','k_cs_scatter','k_cs_hist','k_unpermute','k_part_scatter','k_overlap_fused'))]" ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     densehunt) echo "== dense variant: a step above 25 ms on this box gets a --hip-trace --kernel-trace run (VERDICT r4 item 7)";
-      timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --step-times 8 $Q 2>$o.err | tee $o.json | cut -c1-200; grep "per-step wall" $o.err;
+      timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --step-times 8 $Q 2>$o.err | tee $o.json | cut -c1-200; grep "per-step wall\|timed region" $o.err;
       ms=$(python -c "import json,sys; print(json.loads(open('$o.json').read().strip().splitlines()[-1])['ms_per_step'])" 2>/dev/null || echo 0);
       echo "dense ms_per_step on this box: $ms";
       if python -c "import sys; sys.exit(0 if float('$ms') > 25 else 1)"; then
+        grep "timed region" $o.err;
+        echo "SLOW BOX: three warm-up steps instead of one";
+        timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 3 --step-times 2 $Q 2>${o}_w3.err | tee ${o}_w3.json | cut -c1-200; grep "per-step wall\|timed region" ${o}_w3.err;
+        echo "SLOW BOX: HSA_ENABLE_INTERRUPT=0 (signal waits poll instead of sleeping on the interrupt)";
+        HSA_ENABLE_INTERRUPT=0 timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --step-times 2 $Q 2>${o}_noint.err | tee ${o}_noint.json | cut -c1-200; grep "per-step wall\|timed region" ${o}_noint.err;
         echo "SLOW BOX: the same command once more (is it the first process only?), then under the tracer";
         timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --step-times 8 $Q 2>${o}_again.err | tee ${o}_again.json | cut -c1-200; grep "per-step wall" ${o}_again.err;
         rocm-smi --showclocks --showperflevel 2>/dev/null | head -30 > ${o}_smi.txt; head -12 ${o}_smi.txt;
