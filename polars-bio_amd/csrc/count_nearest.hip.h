@@ -212,10 +212,10 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1(IndexView ix, cons
 // independent 16-byte loads; only a bin with a fourth row below the probe's end, or a probe outside its contig's table, takes the
 // second (dependent) gather from nrec.  Per-contig metadata in LDS (n_contigs <= CM_LDS).
 template <bool STRICT, int N>
-__global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_lines(IndexView ix, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+__global__ __launch_bounds__(PROBE_THREADS, 8) void k_nearest_k1_lines(IndexView ix, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
                                                                     const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
                                                                     int32_t* __restrict__ out_idx, long long* __restrict__ out_dist,
-                                                                    int32_t* __restrict__ out_n, unsigned long long* __restrict__ rest) {
+                                                                    int32_t* __restrict__ out_n, unsigned long long* __restrict__ rest, int64_t n_words) {
     __shared__ int4 l_cm[2 * CM_LDS];
     for (int i = threadIdx.x; i < 2 * ix.n_contigs; i += PROBE_THREADS) l_cm[i] = ix.cmeta[i];
     __syncthreads();
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_lines(IndexView ix
         if ((threadIdx.x & (kWave - 1)) == 0) {
             const int64_t wf0 = ((int64_t)blockIdx.x * PROBE_THREADS + threadIdx.x) / kWave;
 #pragma unroll
-            for (int k = 0; k < N; ++k) rest[N * wf0 + k] = 0ull;
+            for (int k = 0; k < N; ++k) { rest[N * wf0 + k] = 0ull; rest[n_words + N * wf0 + k] = 0ull; }
         }
         return;
     }
@@ -311,20 +311,28 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_lines(IndexView ix
     // a few per cent of the lanes, but some in nearly every wavefront, and each would put one or more dependent fabric round trips into
     // the wavefront's lifetime (measured: 1.9 instead of 1.0 ms for config 4).  They are marked in a bit mask per (wavefront, item) and
     // k_nearest_k1_rest finishes them with the two-gather form.
+    // A third class (round 5): an overlap below the record's two levels is SETTLED except for its build row -- distance 0, found 1 --
+    // and what the bound search needs is in registers here.  Those probes leave {hi-bound, segment start << 32 | probe start} in their
+    // own result slots (out_idx / out_dist) and a bit in the second mask: the rest kernel picks the search up from two reads instead
+    // of redoing the probe from its three columns and the start table (1.8 % of config 4's probes, 70 % of the leftovers).
     int32_t idx[N], found[N];
     long long dist[N];
-    bool slow[N];
+    bool slow[N], deep[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         idx[k] = -1; dist[k] = -1; found[k] = 0;
-        slow[k] = far[k];
+        slow[k] = far[k]; deep[k] = false;
         if (i0 + k < n && b[k] > a[k] && !far[k]) {
             const bool have_l = hi[k] > a[k], have_r = hi[k] < b[k];
             if (have_l && lt_op<STRICT>(s[k], R[k].x)) {
+                dist[k] = 0; found[k] = 1;
                 if (!(Q[k].z >= 0 && lt_op<STRICT>(s[k], Q[k].y))) idx[k] = R[k].y;
                 else if (!lt_op<STRICT>(s[k], Q[k].w)) idx[k] = Q[k].z;
-                else slow[k] = true;
-                dist[k] = 0; found[k] = 1;
+                else {
+                    deep[k] = true;
+                    idx[k] = hi[k];
+                    dist[k] = (long long)(((unsigned long long)(unsigned int)a[k] << 32) | (unsigned long long)(unsigned int)s[k]);
+                }
             } else {
                 const long long dl = (long long)s[k] - (long long)R[k].x;
                 const long long dr = have_r ? gap_dist(s[k], e[k], R[k].z, R[k].w) : 0;
@@ -339,8 +347,8 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_lines(IndexView ix
         const int64_t wf = ((int64_t)blockIdx.x * PROBE_THREADS + threadIdx.x) / kWave;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const unsigned long long m = __ballot(slow[k]);
-            if (lane == 0) rest[N * wf + k] = m;
+            const unsigned long long m = __ballot(slow[k]), m2 = __ballot(deep[k]);
+            if (lane == 0) { rest[N * wf + k] = m; rest[n_words + N * wf + k] = m2; }
         }
     }
     if (N == 2 && i0 + 2 <= n && ((reinterpret_cast<uintptr_t>(out_idx) | reinterpret_cast<uintptr_t>(out_n)) & 7u) == 0 &&
@@ -370,12 +378,14 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_rest(IndexView ix,
                                                                    const int32_t* __restrict__ pe, int64_t n, int64_t n_words,
                                                                    const unsigned long long* __restrict__ rest, int32_t* __restrict__ out_idx,
                                                                    long long* __restrict__ out_dist, int32_t* __restrict__ out_n) {
-    __shared__ int32_t l_list[REST_WORDS * 64];
+    __shared__ unsigned short l_list[REST_WORDS * 64];                        // (word of the workgroup) << 6 | lane: 16 KB, eight workgroups per CU
     __shared__ int l_wsum[PROBE_THREADS / kWave];
+    static_assert(REST_WORDS * 64 <= 0x2000 && (REST_WORDS & (REST_WORDS - 1)) == 0, "a list entry: class bit 13, word 7 bits, lane 6 bits");
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
     const int64_t w = (int64_t)blockIdx.x * REST_WORDS + tid;
     unsigned long long m = (tid < REST_WORDS && w < n_words) ? rest[w] : 0ull;
-    const int cnt = __popcll(m);
+    unsigned long long m2 = (tid < REST_WORDS && w < n_words) ? rest[n_words + w] : 0ull;      // settled but for the build row (see the lines kernel)
+    const int cnt = __popcll(m) + __popcll(m2);
     int inc = cnt;
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) { const int t = __shfl_up(inc, d, kWave); if (lane >= d) inc += t; }
@@ -385,16 +395,29 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_nearest_k1_rest(IndexView ix,
 #pragma unroll
     for (int i = 0; i < PROBE_THREADS / kWave; ++i) { const int x = l_wsum[i]; if (i < wv) pre += x; total += x; }
     // word w = N * wavefront + item; bit l = lane l of that wavefront; the lines kernel's probe of (wavefront, lane, item) = (64 wavefront + l) N + item
-    const int64_t pbase = (w / N) * (int64_t)(kWave * N) + (w % N);
     while (m) {
         const int l = __builtin_ctzll(m);
         m &= m - 1;
-        l_list[pre++] = (int32_t)(pbase + (int64_t)l * N);
+        l_list[pre++] = (unsigned short)((tid << 6) | l);
+    }
+    while (m2) {
+        const int l = __builtin_ctzll(m2);
+        m2 &= m2 - 1;
+        l_list[pre++] = (unsigned short)(0x2000 | (tid << 6) | l);
     }
     __syncthreads();
     for (int q = tid; q < total; q += PROBE_THREADS) {
-        const int64_t i = l_list[q];
+        const int ent = l_list[q];
+        const int64_t wq = (int64_t)blockIdx.x * REST_WORDS + ((ent >> 6) & (REST_WORDS - 1));
+        const int64_t i = (wq / N) * (int64_t)(kWave * N) + (wq % N) + (int64_t)(ent & 63) * N;
         if (i >= n) continue;                                                  // (defensive: the lines kernel never marks a row beyond n)
+        if (ent & 0x2000) {
+            const int hi2 = out_idx[i];
+            const unsigned long long st = (unsigned long long)out_dist[i];
+            out_idx[i] = ix.b_row[bound_lo_near<STRICT>(ix, (int)(st >> 32), hi2, (int32_t)(uint32_t)st)];
+            out_dist[i] = 0;
+            continue;
+        }
         int32_t c[1] = {pc[i]}, s = ps[i], e[1] = {pe[i]};
         bool valid[1] = {true};
         int a[1], b[1], hi[1];

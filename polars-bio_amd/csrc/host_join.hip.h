@@ -364,11 +364,13 @@ int nearest_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_op
         const bool vec = aligned16(qc) && aligned16(qs) && aligned16(qe);
         // the probes a line cannot settle: one bit each in scratch, finished by the two-gather kernel over the same thread <-> probe mapping
         const int64_t nwf = tiles * (PROBE_THREADS / kWave);
-        IVJ_TRY(arena_reserve(ctx, align_up((size_t)nwf * PROBE_ITEMS_LAT * 8) + 4096));
-        unsigned long long* rest = arena_take<unsigned long long>(ctx, nwf * PROBE_ITEMS_LAT);
-        if (strict) LAUNCH(ctx, "nearest_k1_lines", (k_nearest_k1_lines<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, idx, (long long*)dist, nf, rest);
-        else LAUNCH(ctx, "nearest_k1_lines", (k_nearest_k1_lines<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, idx, (long long*)dist, nf, rest);
-        const int64_t n_words = nwf * PROBE_ITEMS_LAT, rgrid = (n_words + REST_WORDS - 1) / REST_WORDS;
+        // (two masks per (wavefront, item): redo from the columns / settled but for the build row)
+        const int64_t n_words = nwf * PROBE_ITEMS_LAT;
+        IVJ_TRY(arena_reserve(ctx, align_up((size_t)n_words * 16) + 4096));
+        unsigned long long* rest = arena_take<unsigned long long>(ctx, 2 * n_words);
+        if (strict) LAUNCH(ctx, "nearest_k1_lines", (k_nearest_k1_lines<true, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, idx, (long long*)dist, nf, rest, n_words);
+        else LAUNCH(ctx, "nearest_k1_lines", (k_nearest_k1_lines<false, PROBE_ITEMS_LAT>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, idx, (long long*)dist, nf, rest, n_words);
+        const int64_t rgrid = (n_words + REST_WORDS - 1) / REST_WORDS;
         if (strict) LAUNCH(ctx, "nearest_k1_rest", (k_nearest_k1_rest<true, PROBE_ITEMS_LAT>), rgrid, PROBE_THREADS, v, qc, qs, qe, n, n_words, (const unsigned long long*)rest, idx, (long long*)dist, nf);
         else LAUNCH(ctx, "nearest_k1_rest", (k_nearest_k1_rest<false, PROBE_ITEMS_LAT>), rgrid, PROBE_THREADS, v, qc, qs, qe, n, n_words, (const unsigned long long*)rest, idx, (long long*)dist, nf);
         HIP_TRY(hipGetLastError());

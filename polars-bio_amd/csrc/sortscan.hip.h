@@ -557,29 +557,24 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_subtract_grid(SubGrid g, int3
             if (ub > ua) {
                 const long long lo = m0.x;
                 const unsigned long long span = (unsigned long long)(uint32_t)m0.y | ((unsigned long long)(uint32_t)m0.z << 32);
-                const long long pt[2] = {ls, le - 1};
-                int K[2]; bool IN[2];
-                int4 r[2];
-                uint32_t slot[2], d[2];
-                int st[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    st[h] = pt[h] < lo ? 0 : ((unsigned long long)(pt[h] - lo) >= span ? 1 : 2);
-                    const uint32_t o = (uint32_t)(pt[h] - lo);
-                    slot[h] = (uint32_t)m1.x + (o >> m0.w);
-                    d[h] = o & ((1u << m0.w) - 1u);
-                }
-                r[0] = make_int4(0, 0, 0, 0); r[1] = make_int4(0, 0, 0, 0);
-                if (st[1] == 2) r[1] = g.rec[slot[1]];
-                if (st[0] == 2) r[0] = (st[1] == 2 && slot[0] == slot[1]) ? r[1] : g.rec[slot[0]];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (st[h] == 0) { K[h] = ua; IN[h] = false; }
-                    else if (st[h] == 1) { K[h] = ub; IN[h] = false; }
-                    else sub_eval(r[h], d[h], u_start, u_end, ua, ub, pt[h], K[h], IN[h]);
-                }
-                first = K[0]; in_s = IN[0]; in_y = IN[1];
-                last = K[1] + (in_y ? 1 : 0);
+                // (scalars, not two-element arrays: indexed locals of this kernel went to 48 bytes of scratch per lane)
+                const long long pt0 = ls, pt1 = le - 1;
+                const int st0 = pt0 < lo ? 0 : ((unsigned long long)(pt0 - lo) >= span ? 1 : 2);
+                const int st1 = pt1 < lo ? 0 : ((unsigned long long)(pt1 - lo) >= span ? 1 : 2);
+                const uint32_t o0 = (uint32_t)(pt0 - lo), o1 = (uint32_t)(pt1 - lo);
+                const uint32_t slot0 = (uint32_t)m1.x + (o0 >> m0.w), slot1 = (uint32_t)m1.x + (o1 >> m0.w);
+                const uint32_t d0 = o0 & ((1u << m0.w) - 1u), d1 = o1 & ((1u << m0.w) - 1u);
+                int4 r0 = make_int4(0, 0, 0, 0), r1 = make_int4(0, 0, 0, 0);
+                if (st1 == 2) r1 = g.rec[slot1];
+                if (st0 == 2) r0 = (st1 == 2 && slot0 == slot1) ? r1 : g.rec[slot0];
+                int K0 = ua, K1 = ua;
+                bool IN0 = false, IN1 = false;
+                if (st0 == 1) K0 = ub;
+                else if (st0 == 2) sub_eval(r0, d0, u_start, u_end, ua, ub, pt0, K0, IN0);
+                if (st1 == 1) K1 = ub;
+                else if (st1 == 2) sub_eval(r1, d1, u_start, u_end, ua, ub, pt1, K1, IN1);
+                first = K0; in_s = IN0; in_y = IN1;
+                last = K1 + (in_y ? 1 : 0);
                 if (last > first) pieces = (in_s ? 0 : 1) + (long long)(last - first - 1) + (in_y ? 0 : 1);
             }
         }
