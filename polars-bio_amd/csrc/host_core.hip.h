@@ -100,6 +100,7 @@ struct ivj_ctx {
     const ivj_index* cs_far_owner = nullptr;   //   ... whose count the pinned slot holds
     hipEvent_t ix3_event = nullptr;    // marks the read-back of the balanced build's {bad, largest bucket}
     bool ix3_attr_set = false;         // index build, round 5 (ixsort3.hip.h): LDS attributes set once
+    int env_ix_merge = -1;             // IVJ_IX_MERGE: upper bound of the balanced build's merge shift (0 = always 2048 buckets); -1: up to V3_MAX_MERGE
     int env_ix_stage = -1;             // IVJ_IX_STAGE: the balanced build's local kernel with (1) / without (0) the rows staged in LDS; -1 by bucket size
     int env_ix_v3 = -1;                // IVJ_IX_V3: -1 by size, 0 never (the round-2 LSD sort), 1 wherever it applies
     int64_t ix3_fallbacks = 0;         // builds the balanced pass handed back to the LSD sort (a bucket above V3_CAP rows, keys beyond 32 bits)

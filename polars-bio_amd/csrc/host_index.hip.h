@@ -303,7 +303,9 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     LAUNCH(ctx, "ix3_stats", k_v3_stats, sgrid, OS_THREADS, build->start, build->end, build->contig, n, nc, meta);
     LAUNCH(ctx, "ix3_hist", k_v3_hist, nchunks, OS_THREADS, build->contig, build->start, n, nc, meta, (int)chunk, nchunks, hist);
     LAUNCH(ctx, "ix_scan", (k_scan_lb_u32<SumOp, true>), hs_tiles, OS_THREADS, hist, hist_len, 0u, tick_scan, st_scan);
-    LAUNCH(ctx, "ix3_check", k_v3_check, 1, OS_THREADS, (const uint32_t*)hist, nchunks, n, meta);
+    // (the check also picks the merge shift of the local kernel: 2^ms adjacent buckets per workgroup where they fit; IVJ_IX_MERGE pins an upper bound)
+    const int ms_max = ctx->env_ix_merge >= 0 ? std::min(ctx->env_ix_merge, V3_MAX_MERGE) : V3_MAX_MERGE;
+    LAUNCH(ctx, "ix3_check", k_v3_check, 1, OS_THREADS, (const uint32_t*)hist, nchunks, n, ms_max, meta);
     // {bad, max_bucket} (adjacent in V3Meta) travel to the host WHILE the bucket pass runs: the copy is queued in front of the pass,
     // the host waits for the copy's event only -- by the time it knows, the pass is still running and the local kernel is queued
     // behind it without a bubble.  (A build that falls back has run the pass for nothing: rare, and exactness does not depend on it.)
@@ -317,17 +319,19 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventSynchronize(ctx->ix3_event));
     const uint32_t* hv = reinterpret_cast<const uint32_t*>(ctx->h_total + 6);
-    if (hv[0] != 0u || hv[1] > (uint32_t)V3_CAP) { ++ctx->ix3_fallbacks; return IVJ_OK; }
+    const uint32_t max_bucket = hv[1] & 0xffffffu;
+    const int ms = (int)(hv[1] >> 24);
+    if (hv[0] != 0u || max_bucket > (uint32_t)V3_CAP) { ++ctx->ix3_fallbacks; return IVJ_OK; }
     // the local kernel's LDS follows the LARGEST bucket (known now): rows staged in LDS while two workgroups still share a CU
     // (<= 2048 rows), beyond that the rows are read again from their L2-resident records (IVJ_IX_STAGE = 0 / 1 forces either form)
-    const int cap = (int)std::max<uint32_t>(1024u, (hv[1] + 1023u) / 1024u * 1024u);
+    const int cap = (int)std::max<uint32_t>(1024u, (max_bucket + 1023u) / 1024u * 1024u);
     const int bin_bits = cap <= 1024 ? 10 : (cap <= 2048 ? 11 : V3_MAX_BIN_BITS);
     const bool stage = ctx->env_ix_stage >= 0 ? ctx->env_ix_stage != 0 : cap <= 2048;
     const size_t local_lds = (size_t)v3_local_lds(cap, 1 << bin_bits, stage).total;
     t_begin(ctx, "ix3_local");
-    if (stage) hipLaunchKernelGGL(k_v3_local<true>, dim3(V3_BUCKETS), dim3(OS_THREADS), local_lds, ctx->stream, (const int4*)recs, (const uint32_t*)hist, nchunks, n, nc, cap, bin_bits,
+    if (stage) hipLaunchKernelGGL(k_v3_local<true>, dim3(V3_BUCKETS >> ms), dim3(OS_THREADS), local_lds, ctx->stream, (const int4*)recs, (const uint32_t*)hist, nchunks, n, nc, cap, bin_bits, ms,
                                   meta, st_local, ix->b_start, ix->ep, ix->b_row, ix->b_contig, ix->seg, ix->flags);
-    else hipLaunchKernelGGL(k_v3_local<false>, dim3(V3_BUCKETS), dim3(OS_THREADS), local_lds, ctx->stream, (const int4*)recs, (const uint32_t*)hist, nchunks, n, nc, cap, bin_bits,
+    else hipLaunchKernelGGL(k_v3_local<false>, dim3(V3_BUCKETS >> ms), dim3(OS_THREADS), local_lds, ctx->stream, (const int4*)recs, (const uint32_t*)hist, nchunks, n, nc, cap, bin_bits, ms,
                             meta, st_local, ix->b_start, ix->ep, ix->b_row, ix->b_contig, ix->seg, ix->flags);
     t_end(ctx);
     HIP_TRY(hipGetLastError());

@@ -144,27 +144,48 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_hist(const int32_t* __restric
     for (int k = threadIdx.x; k < V3_BUCKETS; k += OS_THREADS) hist[(int64_t)k * nchunks + blockIdx.x] = h[k];
 }
 
-// rows of the largest bucket: bucket b = [off[b * nchunks], off[(b + 1) * nchunks]) of the scanned, bucket-major histogram.  One workgroup.
-__global__ __launch_bounds__(OS_THREADS) void k_v3_check(const uint32_t* __restrict__ off, int nchunks, int64_t n, V3Meta* __restrict__ meta) {
-    __shared__ uint32_t wmx[OS_WAVES];
+// Rows of the largest bucket: bucket b = [off[b * nchunks], off[(b + 1) * nchunks]) of the scanned, bucket-major histogram -- and of the
+// largest MERGED bucket for every merge shift ms = 1 .. V3_MAX_MERGE (2^ms adjacent buckets: contiguous in the scattered records, their
+// key ranges adjacent, so the local kernel can take them as one).  A small build side spread over 2048 buckets paid the local kernel's
+// fixed cost 2048 times (1 M rows: 0.056 ms; as 256 merged buckets 0.031 ms): the device picks the LARGEST shift whose largest merged
+// bucket still fits the local kernel (<= V3_CAP rows; ms_max pins an upper bound), so clustered build sides keep the fine buckets.
+// meta->max_bucket = rows of the largest bucket at the chosen shift | shift << 24 (n <= 2^23).  One workgroup.
+constexpr int V3_MAX_MERGE = 5;
+__global__ __launch_bounds__(OS_THREADS) void k_v3_check(const uint32_t* __restrict__ off, int nchunks, int64_t n, int ms_max, V3Meta* __restrict__ meta) {
+    __shared__ uint32_t wmx[V3_MAX_MERGE + 1][OS_WAVES];
     if (meta->bad) return;
     const int tid = threadIdx.x;
-    uint32_t mx = 0;
+    uint32_t sz[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int b = 2 * tid + q;
         const uint32_t a = off[(int64_t)b * nchunks];
         const uint32_t z = b + 1 < V3_BUCKETS ? off[(int64_t)(b + 1) * nchunks] : (uint32_t)n;
-        mx = z - a > mx ? z - a : mx;
+        sz[q] = z - a;
     }
+    uint32_t mx[V3_MAX_MERGE + 1];
+    mx[0] = sz[0] > sz[1] ? sz[0] : sz[1];
+    uint32_t sum = sz[0] + sz[1];                                               // shift 1: this thread's pair
+    mx[1] = sum;
 #pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(mx, d, kWave); mx = o > mx ? o : mx; }
-    if ((tid & (kWave - 1)) == 0) wmx[tid / kWave] = mx;
+    for (int k = 2; k <= V3_MAX_MERGE; ++k) { sum += __shfl_xor(sum, 1 << (k - 2), kWave); mx[k] = sum; }   // 2^(k-1) adjacent threads (inside a wavefront)
+#pragma unroll
+    for (int k = 0; k <= V3_MAX_MERGE; ++k) {
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(mx[k], d, kWave); mx[k] = o > mx[k] ? o : mx[k]; }
+        if ((tid & (kWave - 1)) == 0) wmx[k][tid / kWave] = mx[k];
+    }
     __syncthreads();
     if (tid == 0) {
+        uint32_t best = 0, best_ms = 0;
 #pragma unroll
-        for (int k = 1; k < OS_WAVES; ++k) mx = wmx[k] > mx ? wmx[k] : mx;
-        meta->max_bucket = mx;
+        for (int k = 0; k <= V3_MAX_MERGE; ++k) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int w = 0; w < OS_WAVES; ++w) m = wmx[k][w] > m ? wmx[k][w] : m;
+            if (k == 0 || (k <= ms_max && m <= (uint32_t)V3_CAP)) { best = m; best_ms = (uint32_t)k; }
+        }
+        meta->max_bucket = best | (best_ms << 24);
     }
 }
 
@@ -310,7 +331,7 @@ __host__ __device__ inline V3LocalLds v3_local_lds(int cap, int bins, bool stage
 
 template <bool STAGE>
 __global__ __launch_bounds__(OS_THREADS, 8) void k_v3_local(const int4* __restrict__ rec, const uint32_t* __restrict__ off, int nchunks, int64_t n,
-                                                        int32_t n_contigs, int cap, int bin_bits, V3Meta* __restrict__ meta, unsigned long long* __restrict__ status64,
+                                                        int32_t n_contigs, int cap, int bin_bits, int ms, V3Meta* __restrict__ meta, unsigned long long* __restrict__ status64,
                                                         int32_t* __restrict__ b_start, int2* __restrict__ ep, int32_t* __restrict__ b_row,
                                                         int32_t* __restrict__ b_contig, int32_t* __restrict__ seg, int32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char os_lds[];
@@ -335,17 +356,18 @@ __global__ __launch_bounds__(OS_THREADS, 8) void k_v3_local(const int4* __restri
         const int t = (int)atomicAdd(&meta->ticket, 1u);
         l_tile = t;
         const unsigned long long M = meta->M;
-        l_lo = (uint32_t)((((unsigned long long)t << 32) + M - 1ull) / M);      // smallest linear key of bucket t
+        l_lo = (uint32_t)((((unsigned long long)((unsigned)t << ms) << 32) + M - 1ull) / M);   // smallest linear key of bucket t << ms (merged buckets: the first of them)
     }
     v3_load_tables(meta, n_contigs + 1, l_base, l_cmin);
     for (int k = tid; k < bins; k += OS_THREADS) { bst[k] = 0u; cur[k] = 0u; }
     __syncthreads();
     const int tile = l_tile;
     const uint32_t lo = l_lo;
-    const uint32_t b0 = off[(int64_t)tile * nchunks];
-    const uint32_t b1 = tile + 1 < V3_BUCKETS ? off[(int64_t)(tile + 1) * nchunks] : (uint32_t)n;
+    const int fb0 = tile << ms, fb1 = (tile + 1) << ms;                          // the 2^ms fine buckets of this workgroup
+    const uint32_t b0 = off[(int64_t)fb0 * nchunks];
+    const uint32_t b1 = fb1 < V3_BUCKETS ? off[(int64_t)fb1 * nchunks] : (uint32_t)n;
     const int nb = (int)(b1 - b0);                                              // <= cap: the host sized cap from the largest bucket
-    const int wbits = (int)meta->wbits;
+    const int wbits = (int)meta->wbits + ms;                                     // merged buckets: 2^ms key ranges side by side
     const int bshift = wbits > bin_bits ? wbits - bin_bits : 0;                 // bin = key >> bshift < bins
     const int4* __restrict__ grec = rec + (int64_t)b0;                          // the bucket's rows in input order (slot p)
     auto row_at = [&](int p) -> int4 { if constexpr (STAGE) return l_rec[p]; else return grec[p]; };

@@ -1279,13 +1279,17 @@ def _v3_cases():
     return cases
 
 
-def test_balanced_index_build_matches_the_lsd_build(monkeypatch):
-    """Round 5: the index built by ONE balanced bucket pass + an LDS sort per bucket (ixsort3.hip.h) is the index the three-pass LSD
+@pytest.mark.parametrize("merge", [None, "0", "2"])
+def test_balanced_index_build_matches_the_lsd_build(merge, monkeypatch):
+    """(merge: IVJ_IX_MERGE, the upper bound of the device-chosen merge shift -- None: up to 32 adjacent buckets per workgroup where
+    they fit, which these small shapes do; "0": always 2048 buckets.)  Round 5: the index built by ONE balanced bucket pass + an LDS sort per bucket (ixsort3.hip.h) is the index the three-pass LSD
     sort builds -- same order (equal keys in input order), same prefix maxima, same segment offsets -- on shapes that stress it:
     ragged sizes, a single row, rows outside the dictionary, negative starts with thousands of equal keys, and the two hand-overs to
     the LSD sort (a bucket above the LDS capacity; linear keys beyond 32 bits).  Checked through every operation against the oracle,
     with the balanced build forced for sizes the auto rule would leave to the LSD sort."""
     monkeypatch.setenv("IVJ_IX_V3", "1")
+    if merge is not None:
+        monkeypatch.setenv("IVJ_IX_MERGE", merge)
     e3 = _engine.Engine(0)
     try:
         e3.enable_timing(2)

@@ -41,8 +41,8 @@ def main():
     t0 = time.time()
     seen = {}
     for it in range(iters):
-        flips = {k: v for k, v in (("IVJ_IX_V3", "0"), ("IVJ_CS_REC8", "0"), ("IVJ_CS_FUSE_SAMPLE", "0"), ("IVJ_IX_STAGE", "0")) if rng.random() < 0.25}
-        for k in ("IVJ_IX_V3", "IVJ_CS_REC8", "IVJ_CS_FUSE_SAMPLE", "IVJ_IX_STAGE"):
+        flips = {k: v for k, v in (("IVJ_IX_V3", "0"), ("IVJ_CS_REC8", "0"), ("IVJ_CS_FUSE_SAMPLE", "0"), ("IVJ_IX_STAGE", "0"), ("IVJ_IX_MERGE", str(int(rng.integers(0, 4))))) if rng.random() < 0.25}
+        for k in ("IVJ_IX_V3", "IVJ_CS_REC8", "IVJ_CS_FUSE_SAMPLE", "IVJ_IX_STAGE", "IVJ_IX_MERGE"):
             os.environ.pop(k, None)
         os.environ.update(flips)
         eng = _engine.Engine(0)
