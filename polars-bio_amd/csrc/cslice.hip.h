@@ -95,7 +95,12 @@ __device__ __forceinline__ int cs_count4(int h, int32_t s0, int32_t s1, int32_t 
 //   cell[i]   lo | hi << 16: range of "number of splitters below" a key of that cell can have
 __global__ __launch_bounds__(CS_THREADS) void k_cs_prep(const int32_t* __restrict__ seg, const int32_t* __restrict__ b_start, CsGeom g,
                                                        int32_t* __restrict__ bound, unsigned long long* __restrict__ spl,
-                                                       int4* __restrict__ cm, uint32_t* __restrict__ cell) {
+                                                       int4* __restrict__ cm, uint32_t* __restrict__ cell,
+                                                       uint32_t* __restrict__ zero_a, int n_zero_a, uint32_t* __restrict__ zero_b, int n_zero_b) {
+    // (round 5: the call state and the sample histogram of a call that launches this kernel are cleared here -- two fill
+    // operations less in the stream; every consumer of the words is queued behind this kernel)
+    for (int i = threadIdx.x; i < n_zero_a; i += CS_THREADS) zero_a[i] = 0u;
+    for (int i = threadIdx.x; i < n_zero_b; i += CS_THREADS) zero_b[i] = 0u;
     __shared__ int4 l_cm[CS_MAX_CONTIGS];
     __shared__ int l_a[CS_MAX_CONTIGS + 1], l_fs[CS_MAX_CONTIGS + 1];
     __shared__ uint32_t l_lo[CS_MAX_CONTIGS], l_hi[CS_MAX_CONTIGS];
@@ -574,7 +579,13 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_bins_sample(int n_bins, const
 // sample missed) raises bit 8 of the state word in the scatter and the host redoes the call with 12-byte records: exactness never
 // rests on the sample.  allow8 = 0: the caller wants 12-byte records (the redo, IVJ_CS_REC8=0).
 __global__ __launch_bounds__(CS_THREADS) void k_cs_regions(const uint32_t* __restrict__ gh, int nb, uint32_t slack, int allow8, uint32_t* __restrict__ rstart,
-                                                          uint32_t* __restrict__ rcur, int32_t* __restrict__ meta) {
+                                                          uint32_t* __restrict__ rcur, int32_t* __restrict__ meta, const int32_t* __restrict__ far_src,
+                                                          uint32_t* __restrict__ hw, uint32_t hw_seq) {
+    if (threadIdx.x == 0 && hw) {
+        // host words [4], [5]: the far-row count the bins kernel (queued in front of this one) left in the index, for cs_resolve_tables
+        hw_store(hw + 4, (uint32_t)__hip_atomic_load(far_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        hw_store(hw + 5, hw_seq);
+    }
     if (threadIdx.x == 0) {
         int lb = 0;
         if (allow8) {
@@ -825,7 +836,31 @@ struct CsJoinArgs {
     uint2* cache;                     // COUNT -> k_cs_fill: {cs_cache_word, probe row} per probe record, bucket order
     int32_t* out_probe;
     int32_t* out_build;
+    uint32_t* hw;                     // FUSED: host words [8..12] {pairs, flags, seq}, written by the last workgroup to finish (nullptr: the host copies the state)
+    uint32_t hw_seq;
+    uint32_t* done;                   // FUSED: finished workgroups (cleared with the state)
 };
+
+// FUSED: the last join workgroup to finish hands {pairs, flags} to the host words.  Every wavefront first waits for its own memory
+// operations (the tile cursors' atomics on the state words among them), the workgroup meets, one thread takes a ticket; the holder
+// of the last ticket reads the state words past the caches.  A wavefront that left on a protocol timeout has waited for its flag
+// (IVJ_TILE_WAIT); a workgroup all of whose wavefronts left never takes a ticket, the sequence number stays behind and the host copies.
+__device__ __forceinline__ void cs_publish_state(const CsJoinArgs& A, int total_wg) {
+    if (!A.hw) return;                                                         // uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(A.done, 1u);
+        if (t == (uint32_t)total_wg - 1u) {
+            const unsigned long long pairs = __hip_atomic_load(A.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long flags = __hip_atomic_load(A.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hw_store(A.hw + 8, (uint32_t)pairs); hw_store(A.hw + 9, (uint32_t)(pairs >> 32));
+            hw_store(A.hw + 10, (uint32_t)flags); hw_store(A.hw + 11, (uint32_t)(flags >> 32));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            hw_store(A.hw + 12, A.hw_seq);
+        }
+    }
+}
 
 // Copy-out of a wavefront's staged pairs (round 5): the output range starts at an arbitrary element of the two result columns, so a
 // plain `for (i = lane; ...)` makes EVERY 256-byte store instruction straddle five 64-byte lines (round-4 counters: 32.1 M write
@@ -1281,6 +1316,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
         } else pend_wtot = 0;
         pend_woff = woff;
     }
+    cs_publish_state(A, total_wg);
 }
 
 template <bool STRICT, int MODE>
@@ -1724,6 +1760,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         } else pend_wtot = 0;
         pend_woff = woff;
     }
+    cs_publish_state(A, total_wg);
 }
 
 

@@ -81,6 +81,18 @@ struct ivj_ctx {
     int32_t* ov_cnt = nullptr;
     long long* ov_tile = nullptr;   // ntiles + 1: tile bases, last = total
     long long* h_total = nullptr;   // pinned
+    // Host words (round 5): 64 pinned, host-coherent 32-bit words that KERNELS write with system-scope stores -- the few values the host
+    // needs mid-call (largest bucket of the balanced index build, far-row count of the slice tables, pairs + flags of the fused join)
+    // arrive without a copy operation in the stream; the host reads them after the event / synchronisation it waited on anyway and
+    // falls back to a copy when a word's sequence number is not the call's (IVJ_HOST_WORDS=0: always the copies).
+    //   [0] ix3 bad  [1] ix3 largest bucket | merge shift << 24  [2] seq     [4] far rows  [5] seq     [8..9] pairs  [10..11] flags  [12] seq
+    uint32_t* hw = nullptr;         // host address
+    uint32_t* hw_dev = nullptr;     // the same words as the device sees them
+    uint32_t hw_seq = 0;
+    uint32_t cs_far_hw_seq = 0;     // sequence number the pending far-row count was written under (0: it travels by copy)
+    uint32_t cs_fused_hw_seq = 0;   // sequence number of the running fused join's state words (0: by copy)
+    long long hw_misses = 0;        // host words that did not carry the call's sequence number (the value was copied instead)
+    bool cs_prep_zero = false;      // this call's k_cs_prep clears the call state and the sample histogram (no memsets queued)
     XferSlots xfer;                 // pinned staging slots of the host <-> HBM copies (HostXfer), allocated on first use
     // one released index slab kept for reuse (bench/streaming loops rebuild the index every call)
     char* nl_cache = nullptr;          // the nearest-line table of the last index freed on this context (reused like ix_cache)
@@ -180,6 +192,7 @@ struct ivj_index {
     int4* brec = nullptr;
     int4* brec_e = nullptr;
     int32_t* pargmax = nullptr;
+    char* ix3_z = nullptr;           // zeroed words of the balanced index build inside the slab's zeroed head (nullptr: the build takes them from the arena)
     int4* nrec = nullptr;
     int4* cmeta_j = nullptr;
     int4* crec = nullptr;

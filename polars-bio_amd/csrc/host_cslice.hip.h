@@ -65,7 +65,10 @@ struct CsSampleArgs { bool strict; const int32_t *pc, *ps, *pe; int64_t n; uint3
 int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix, const CsSampleArgs* sample = nullptr) {
     if (ix->cs_built) return IVJ_OK;
     const CsGeom& g = ix->cs_g;
-    LAUNCH(ctx, "cs_prep", k_cs_prep, 1, CS_THREADS, (const int32_t*)ix->seg, (const int32_t*)ix->b_start, g, ix->cs_bound, ix->cs_spl, ix->cs_cm, ix->cs_cell);
+    // (cs_prep_zero: the fused call that launches the tables clears its state words and sample histogram in this kernel)
+    const bool pz = ctx->cs_prep_zero && sample != nullptr;
+    LAUNCH(ctx, "cs_prep", k_cs_prep, 1, CS_THREADS, (const int32_t*)ix->seg, (const int32_t*)ix->b_start, g, ix->cs_bound, ix->cs_spl, ix->cs_cm, ix->cs_cell,
+           pz ? reinterpret_cast<uint32_t*>(ctx->sl_meta + 4) : (uint32_t*)nullptr, pz ? 8 : 0, pz ? ctx->sl_gh : (uint32_t*)nullptr, pz ? g.nb + 4 : 0);
     const size_t lds = (size_t)4 * g.R + (size_t)2 * (2 * g.R + 8);
     if (sample) {
         const CsTab tab{ix->cs_spl, ix->cs_cm, ix->cs_cell};
@@ -95,9 +98,15 @@ int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix, const CsSampleArgs* sample = n
     // Round 5: the 4-byte count travels to the host behind an EVENT, not a stream synchronisation -- the partition of the call is
     // queued right behind it and the host reads the count (cs_resolve_tables, before the join is launched) while the scatter
     // runs: no bubble in the stream (round 4 synchronised here: ~ 20 us per index).  IVJ_CS_WALK = 0 / 1 forces the choice.
-    HIP_TRY(hipMemcpyAsync(ctx->h_total + 5, ix->flags + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    // (host words: in the sampled flow k_cs_regions, queued right behind, stores the count into pinned memory itself -- no copy
+    // operation; cs_partition records the event behind that kernel)
     if (!ctx->cs_event) HIP_TRY(hipEventCreateWithFlags(&ctx->cs_event, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(ctx->cs_event, ctx->stream));
+    if (sample && ctx->hw) ctx->cs_far_hw_seq = ++ctx->hw_seq;
+    else {
+        ctx->cs_far_hw_seq = 0;
+        HIP_TRY(hipMemcpyAsync(ctx->h_total + 5, ix->flags + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->cs_event, ctx->stream));
+    }
     ix->cs_far_pending = true;
     ctx->cs_far_owner = ix;
     ix->cs_built = true;
@@ -107,11 +116,15 @@ int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix, const CsSampleArgs* sample = n
 // the join kernel of the index (and the block maxima, when it is the walking one): called before the first join / fill launch
 int cs_resolve_tables(ivj_ctx* ctx, ivj_index* ix) {
     if (!ix->cs_far_pending) return IVJ_OK;
+    bool have = false;
     if (ctx->cs_far_owner == ix) {
         HIP_TRY(hipEventSynchronize(ctx->cs_event));
-        ix->cs_far = *reinterpret_cast<const int32_t*>(ctx->h_total + 5);
         ctx->cs_far_owner = nullptr;
-    } else {
+        if (ctx->cs_far_hw_seq == 0) { ix->cs_far = *reinterpret_cast<const int32_t*>(ctx->h_total + 5); have = true; }
+        else if (reinterpret_cast<volatile uint32_t*>(ctx->hw)[5] == ctx->cs_far_hw_seq) { ix->cs_far = (int32_t)reinterpret_cast<volatile uint32_t*>(ctx->hw)[4]; have = true; }
+        else ++ctx->hw_misses;                                                 // the word did not arrive: read the count by copy
+    }
+    if (!have) {
         // another index's tables were launched in between and took the pinned slot: read this index's count again (rare)
         HIP_TRY(hipMemcpyAsync(ctx->h_total + 5, ix->flags + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -206,7 +219,8 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
             IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, true, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 8, true, true>), 160 * 1024));
             ctx->cs_sattr_set = true;
         }
-        HIP_TRY(hipMemsetAsync(ctx->sl_gh, 0, (size_t)(g.nb + 4) * 4, ctx->stream));
+        const bool pz = ctx->cs_prep_zero && fuse_sample;                    // k_cs_prep clears the histogram (and the call state)
+        if (!pz) HIP_TRY(hipMemsetAsync(ctx->sl_gh, 0, (size_t)(g.nb + 4) * 4, ctx->stream));
         const int64_t n_samp = (n + CS_SRATE - 1) / CS_SRATE;
         const unsigned sgrid = (unsigned)std::min<int64_t>(256, (n_samp + CS_THREADS - 1) / CS_THREADS);
         if (fuse_sample) {
@@ -220,7 +234,10 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         }
         // the record format of the call (8-byte records where the sample says they fit) is decided in this kernel, on the device
         const int allow8 = (ctx->cs_env_rec8 != 0 && !ctx->cs_force_rec12) ? 1 : 0;
-        LAUNCH(ctx, "cs_regions", k_cs_regions, 1, CS_THREADS, (const uint32_t*)ctx->sl_gh, g.nb, cs_region_slack(ctx, g, n), allow8, ctx->sl_rstart, ctx->sl_rcur, ctx->sl_meta);
+        const bool far_hw = fuse_sample && ix->cs_far_pending && ctx->cs_far_owner == ix && ctx->cs_far_hw_seq != 0;
+        LAUNCH(ctx, "cs_regions", k_cs_regions, 1, CS_THREADS, (const uint32_t*)ctx->sl_gh, g.nb, cs_region_slack(ctx, g, n), allow8, ctx->sl_rstart, ctx->sl_rcur, ctx->sl_meta,
+               (const int32_t*)(ix->flags + 1), far_hw ? ctx->hw_dev : (uint32_t*)nullptr, ctx->cs_far_hw_seq);
+        if (far_hw) HIP_TRY(hipEventRecord(ctx->cs_event, ctx->stream));
         unsigned long long* state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
         if (allow8) t_begin(ctx, "cs_scatter");
 #define IVJ_CS_SCATTER_S(S, I, R8)                                                                                                      \
@@ -290,6 +307,9 @@ int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     A.wslot = ctx->sl_tile;
     A.cache = (MODE == CS_FUSED || ctx->cs_env_nocache) ? nullptr : ctx->sl_cache;
     A.out_probe = out_p; A.out_build = out_b;
+    A.hw = nullptr; A.hw_seq = 0; A.done = reinterpret_cast<uint32_t*>(ctx->sl_meta + 10);
+    ctx->cs_fused_hw_seq = 0;
+    if (MODE == CS_FUSED && ctx->hw) { A.hw = ctx->hw_dev; A.hw_seq = ctx->cs_fused_hw_seq = ++ctx->hw_seq; }
     const unsigned grid = 8u * (unsigned)((P.gmax + 7) / 8);
     t_begin(ctx, MODE == CS_FUSED ? "cs_join_fused" : (MODE == CS_COUNT ? "cs_join_count" : "cs_join_fill"));
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
@@ -326,12 +346,29 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     IVJ_TRY(cs_plan(ctx, ix, probe->n, opts, P, wcap));
     IVJ_TRY(ensure_sl(ctx, probe->n, P, cs_sampled_wanted(ctx, probe->n, false) ? cs_record_capacity(ctx, ix->cs_g, probe->n) : 0));
     ctx->sl_plan_valid = false;
-    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 32, ctx->stream));                // {pairs, flags}: the sampled scatter may set bits 4 / 8; the record format (0 = 12-byte records)
+    // {pairs, flags, record format (0 = 12-byte records), finished workgroups}: the sampled scatter may set bits 4 / 8.  A call that
+    // also launches the index's slice tables has k_cs_prep clear these words and the sample histogram (two fills less in the stream).
+    struct PrepZero { ivj_ctx* c; ~PrepZero() { c->cs_prep_zero = false; } } prep_zero_scope{ctx};
+    ctx->cs_prep_zero = ctx->hw != nullptr && !ix->cs_built && ctx->cs_env_fuse_sample != 0 && cs_sampled_wanted(ctx, probe->n, false);
+    if (!ctx->cs_prep_zero) HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 32, ctx->stream));
     IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, false));
     if (ctx->sl_env_ablate & (256 | 1024 | 2048)) { *n_pairs = 0; HIP_TRY(hipStreamSynchronize(ctx->stream)); return IVJ_OK; }   // profiling: the records are not usable
     IVJ_TRY(cs_join_launch<CS_FUSED>(ctx, ix, opts, P, (long long)capacity, out_p, out_b));
-    HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_meta + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // {pairs, flags}: from the host words the last join workgroup wrote -- or by copy (no host words, no workgroup, a protocol timeout)
+    bool have_state = false;
+    if (ctx->cs_fused_hw_seq != 0) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const volatile uint32_t* w = reinterpret_cast<volatile uint32_t*>(ctx->hw);
+        if (w[12] == ctx->cs_fused_hw_seq) {
+            ctx->h_total[0] = (long long)((unsigned long long)w[8] | ((unsigned long long)w[9] << 32));
+            ctx->h_total[1] = (long long)((unsigned long long)w[10] | ((unsigned long long)w[11] << 32));
+            have_state = true;
+        } else ++ctx->hw_misses;
+    }
+    if (!have_state) {
+        HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_meta + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     HIP_TRY(hipGetLastError());
     if (std::getenv("IVJ_DEBUG_REDO")) std::fprintf(stderr, "[ivj] cs_overlap_fused: state flags %lld (sampled %d, exact %d, rec12 %d), pairs %lld\n", (long long)ctx->h_total[1], (int)ctx->sl_sampled, (int)ctx->cs_force_exact, (int)ctx->cs_force_rec12, (long long)ctx->h_total[0]);
     if ((ctx->h_total[1] & 4) && ctx->sl_sampled) {
@@ -395,6 +432,7 @@ int cs_fill_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
     A.wslot = ctx->sl_tile; A.cache = ctx->sl_cache;
     A.out_probe = out_p; A.out_build = out_b;
+    A.hw = nullptr; A.hw_seq = 0; A.done = nullptr;
     const size_t fixed = (size_t)cs_fill_lds(g.R, 0).total;
     const size_t half = 80 * 1024, full = 160 * 1024;
     // staging entries per wavefront: a wavefront-tile of 256 probes emits ~2 pairs per probe on the benchmark shapes.  One

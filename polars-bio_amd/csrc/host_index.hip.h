@@ -269,29 +269,41 @@ bool ix3_wanted(const ivj_ctx* ctx, int64_t n, int nc) {
     if (ctx->env_ix_v3 >= 0) return ctx->env_ix_v3 != 0;
     return n >= (128ll << 10) && n <= (7ll << 20);
 }
+struct V3Plan { int64_t chunk, hist_len, hs_tiles; int nchunks; size_t z_meta, z_st, z_hs, z_tick, zero_bytes; };
+V3Plan v3_plan(int64_t n) {
+    V3Plan p;
+    p.chunk = ((n + 255) / 256 + OS_TILE - 1) / OS_TILE * OS_TILE;             // one workgroup per CU, whole sub-tiles (as os_sort_plan)
+    if (p.chunk < OS_TILE) p.chunk = OS_TILE;
+    p.nchunks = (int)((n + p.chunk - 1) / p.chunk);
+    p.hist_len = (int64_t)V3_BUCKETS * p.nchunks;
+    p.hs_tiles = (p.hist_len + LB_TILE - 1) / LB_TILE;
+    p.z_meta = align_up(sizeof(V3Meta)); p.z_st = align_up((size_t)V3_BUCKETS * 8); p.z_hs = align_up((size_t)p.hs_tiles * 8); p.z_tick = align_up(16);
+    p.zero_bytes = p.z_meta + p.z_st + p.z_hs + p.z_tick;
+    return p;
+}
 int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_opts* opts, bool* done) {
     *done = false;
     const int64_t n = build->n;
     const int nc = opts->n_contigs;
     const int64_t tiles = (n + OS_TILE - 1) / OS_TILE;
-    int64_t chunk = ((n + 255) / 256 + OS_TILE - 1) / OS_TILE * OS_TILE;       // one workgroup per CU, whole sub-tiles (as os_sort_plan)
-    if (chunk < OS_TILE) chunk = OS_TILE;
-    const int nchunks = (int)((n + chunk - 1) / chunk);
-    const int64_t hist_len = (int64_t)V3_BUCKETS * nchunks;
-    const int64_t hs_tiles = (hist_len + LB_TILE - 1) / LB_TILE;
-    const size_t z_meta = align_up(sizeof(V3Meta)), z_st = align_up((size_t)V3_BUCKETS * 8), z_hs = align_up((size_t)hs_tiles * 8), z_tick = align_up(16);
-    const size_t zero_bytes = z_meta + z_st + z_hs + z_tick;
+    const V3Plan VP = v3_plan(n);
+    const int64_t chunk = VP.chunk, hist_len = VP.hist_len, hs_tiles = VP.hs_tiles;
+    const int nchunks = VP.nchunks;
+    const size_t z_meta = VP.z_meta, z_st = VP.z_st, z_hs = VP.z_hs, zero_bytes = VP.zero_bytes;
     OsSort S;                                                                   // (the arena must also hold the fallback's scratch: reserve the larger of the two once)
     const size_t v2_bytes = os_sort_plan(S, n, nc);
-    IVJ_TRY(arena_reserve(ctx, std::max(v2_bytes, zero_bytes + align_up((size_t)hist_len * 4) + align_up((size_t)n * 16)) + 4096));
-    char* z = arena_take<char>(ctx, zero_bytes);
+    // the words that start zeroed (V3Meta, status words of the two look-back chains, tickets) live in the index slab's zeroed head
+    // when the slab was carved for this build (ix->ix3_z: one fill per index build instead of two), else in the arena
+    const bool own_z = ix->ix3_z == nullptr;
+    IVJ_TRY(arena_reserve(ctx, std::max(v2_bytes, (own_z ? zero_bytes : 0) + align_up((size_t)hist_len * 4) + align_up((size_t)n * 16)) + 4096));
+    char* z = own_z ? arena_take<char>(ctx, zero_bytes) : ix->ix3_z;
     uint32_t* hist = arena_take<uint32_t>(ctx, (size_t)hist_len);
     int4* recs = arena_take<int4>(ctx, (size_t)n);
     V3Meta* meta = (V3Meta*)z;
     unsigned long long* st_local = (unsigned long long*)(z + z_meta);
     unsigned long long* st_scan = (unsigned long long*)(z + z_meta + z_st);
     uint32_t* tick_scan = (uint32_t*)(z + z_meta + z_st + z_hs);
-    HIP_TRY(hipMemsetAsync(z, 0, zero_bytes, ctx->stream));
+    if (own_z) HIP_TRY(hipMemsetAsync(z, 0, zero_bytes, ctx->stream));
     const size_t pass_lds = (size_t)v3_pass_lds().total;
     if (!ctx->ix3_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds));
@@ -305,11 +317,13 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     LAUNCH(ctx, "ix_scan", (k_scan_lb_u32<SumOp, true>), hs_tiles, OS_THREADS, hist, hist_len, 0u, tick_scan, st_scan);
     // (the check also picks the merge shift of the local kernel: 2^ms adjacent buckets per workgroup where they fit; IVJ_IX_MERGE pins an upper bound)
     const int ms_max = ctx->env_ix_merge >= 0 ? std::min(ctx->env_ix_merge, V3_MAX_MERGE) : V3_MAX_MERGE;
-    LAUNCH(ctx, "ix3_check", k_v3_check, 1, OS_THREADS, (const uint32_t*)hist, nchunks, n, ms_max, meta);
-    // {bad, max_bucket} (adjacent in V3Meta) travel to the host WHILE the bucket pass runs: the copy is queued in front of the pass,
-    // the host waits for the copy's event only -- by the time it knows, the pass is still running and the local kernel is queued
-    // behind it without a bubble.  (A build that falls back has run the pass for nothing: rare, and exactness does not depend on it.)
-    HIP_TRY(hipMemcpyAsync(ctx->h_total + 6, &meta->bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    const uint32_t hw_seq = ctx->hw ? ++ctx->hw_seq : 0u;
+    LAUNCH(ctx, "ix3_check", k_v3_check, 1, OS_THREADS, (const uint32_t*)hist, nchunks, n, ms_max, meta, ctx->hw_dev, hw_seq);
+    // {bad, max_bucket} travel to the host WHILE the bucket pass runs: the check kernel stores them into the host words (or, without
+    // those, a copy of the two adjacent V3Meta words is queued in front of the pass); the host waits for the event behind the check
+    // only -- by the time it knows, the pass is still running and the local kernel is queued behind it without a bubble.  (A build
+    // that falls back has run the pass for nothing: rare, and exactness does not depend on it.)
+    if (!ctx->hw) HIP_TRY(hipMemcpyAsync(ctx->h_total + 6, &meta->bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (!ctx->ix3_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ix3_event, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(ctx->ix3_event, ctx->stream));
     t_begin(ctx, "ix3_pass");
@@ -318,7 +332,16 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     t_end(ctx);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventSynchronize(ctx->ix3_event));
-    const uint32_t* hv = reinterpret_cast<const uint32_t*>(ctx->h_total + 6);
+    uint32_t* hv = reinterpret_cast<uint32_t*>(ctx->h_total + 6);
+    if (ctx->hw) {
+        const volatile uint32_t* w = reinterpret_cast<volatile uint32_t*>(ctx->hw);
+        if (w[2] == hw_seq) { hv[0] = w[0]; hv[1] = w[1]; }
+        else {                                                                 // the words did not arrive: by copy (the pass has to finish first)
+            ++ctx->hw_misses;
+            HIP_TRY(hipMemcpyAsync(ctx->h_total + 6, &meta->bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
     const uint32_t max_bucket = hv[1] & 0xffffffu;
     const int ms = (int)(hv[1] >> 24);
     if (hv[0] != 0u || max_bucket > (uint32_t)V3_CAP) { ++ctx->ix3_fallbacks; return IVJ_OK; }
@@ -377,7 +400,8 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         const size_t col = align_up(nn * 4);
         const size_t nc = (size_t)opts->n_contigs;
         ix->bins_len = 2 * (int64_t)nn + 2 * (int64_t)nc + 16;
-        const size_t small = align_up((nc + 2) * 4) + align_up(16) + 3 * align_up((nc + 1) * 32);   // seg, flags, cmeta, cmeta_e, cmeta_j
+        const size_t v3z = (n > 0 && ix3_wanted(ctx, n, opts->n_contigs)) ? v3_plan(n).zero_bytes : 0;      // the balanced build's zeroed words share the fill
+        const size_t small = align_up((nc + 2) * 4) + align_up(16) + 3 * align_up((nc + 1) * 32) + v3z;   // seg, flags, cmeta, cmeta_e, cmeta_j (+ ix3_z)
         const size_t flat_bytes = align_up((nn + 1) * 16) + 3 * align_up((size_t)ix->bins_len * 4);   // rec4, lot, tab2 (filled on demand)
         const size_t spl_bytes = align_up((size_t)SL_MAX_BUCKETS * 8) + align_up((size_t)SL_TAB_CONTIGS * 16) +
                                  align_up((size_t)(4 * SL_MAX_BUCKETS + 2 * SL_TAB_CONTIGS) * 4);
@@ -423,6 +447,7 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->cmeta = (int4*)p; p += align_up((nc + 1) * 32);
         ix->cmeta_e = (int4*)p; p += align_up((nc + 1) * 32);
         ix->cmeta_j = (int4*)p; p += align_up((nc + 1) * 32);
+        ix->ix3_z = v3z ? p : nullptr; p += v3z;
         if (ix->cs_ok) { cs_index_carve(ix, p); p += cs_bytes; }
         ix->hier = (int32_t*)p;
         // seg, flags and cmeta start zeroed: an empty index answers every probe with "no rows"

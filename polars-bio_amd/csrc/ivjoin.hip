@@ -95,6 +95,21 @@ int ivj_ctx_create(int device, ivj_ctx** out) try {
     if (const char* ev = std::getenv("IVJ_IX_STAGE")) ctx->env_ix_stage = std::atoi(ev) != 0 ? 1 : 0;
     e = hipHostMalloc((void**)&ctx->h_total, 64, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(IVJ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    {
+        // host words (host_core.hip.h): optional -- without them every value travels by copy as before
+        const char* ev = std::getenv("IVJ_HOST_WORDS");
+        if (!(ev && std::atoi(ev) == 0)) {
+            void* hp = nullptr;
+            void* dp = nullptr;
+            if (hipHostMalloc(&hp, 256, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+                if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
+                    std::memset(hp, 0, 256);
+                    ctx->hw = (uint32_t*)hp; ctx->hw_dev = (uint32_t*)dp;
+                } else (void)hipHostFree(hp);
+            }
+            (void)hipGetLastError();
+        }
+    }
     *out = ctx;
     return IVJ_OK;
 } IVJ_ABI_CATCH
@@ -127,6 +142,8 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     if (ctx->ix3_event) (void)hipEventDestroy(ctx->ix3_event);
     if (ctx->cs_event) (void)hipEventDestroy(ctx->cs_event);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+    if (std::getenv("IVJ_DEBUG_REDO")) std::fprintf(stderr, "[ivj] context: host words %s, %lld misses of %u; ix3 fallbacks %lld\n", ctx->hw ? "on" : "off", (long long)ctx->hw_misses, ctx->hw_seq, (long long)ctx->ix3_fallbacks);
+    if (ctx->hw) (void)hipHostFree(ctx->hw);
     ctx->xfer.release();
     for (hipEvent_t ev : ctx->pool) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

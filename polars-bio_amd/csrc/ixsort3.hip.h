@@ -151,9 +151,13 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_hist(const int32_t* __restric
 // bucket still fits the local kernel (<= V3_CAP rows; ms_max pins an upper bound), so clustered build sides keep the fine buckets.
 // meta->max_bucket = rows of the largest bucket at the chosen shift | shift << 24 (n <= 2^23).  One workgroup.
 constexpr int V3_MAX_MERGE = 5;
-__global__ __launch_bounds__(OS_THREADS) void k_v3_check(const uint32_t* __restrict__ off, int nchunks, int64_t n, int ms_max, V3Meta* __restrict__ meta) {
+__global__ __launch_bounds__(OS_THREADS) void k_v3_check(const uint32_t* __restrict__ off, int nchunks, int64_t n, int ms_max, V3Meta* __restrict__ meta,
+                                                        uint32_t* __restrict__ hw, uint32_t hw_seq) {
     __shared__ uint32_t wmx[V3_MAX_MERGE + 1][OS_WAVES];
-    if (meta->bad) return;
+    if (meta->bad) {
+        if (threadIdx.x == 0 && hw) { hw_store(hw + 0, 1u); hw_store(hw + 1, 0u); hw_store(hw + 2, hw_seq); }   // host words: {bad, largest bucket | shift << 24, seq}
+        return;
+    }
     const int tid = threadIdx.x;
     uint32_t sz[2];
 #pragma unroll
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_v3_check(const uint32_t* __restr
             if (k == 0 || (k <= ms_max && m <= (uint32_t)V3_CAP)) { best = m; best_ms = (uint32_t)k; }
         }
         meta->max_bucket = best | (best_ms << 24);
+        if (hw) { hw_store(hw + 0, 0u); hw_store(hw + 1, best | (best_ms << 24)); hw_store(hw + 2, hw_seq); }
     }
 }
 

@@ -572,9 +572,16 @@ constexpr int SL_ABLATE_TILE_FAULT = 4096;
         int spin_ = 0;                                                                                                          \
         for (; (STILL_WAITING) && spin_ < (BOUND); ++spin_) __builtin_amdgcn_s_sleep(1);                                        \
         if (__builtin_expect(spin_ >= (BOUND), 0)) {                                                                            \
-            if (STILL_WAITING) { if ((LANE) == 0) atomicOr((STATE) + 1, 2ull); ON_TIMEOUT; }                                    \
+            if (STILL_WAITING) {                                                                                                \
+                if ((LANE) == 0) atomicOr((STATE) + 1, 2ull);                                                                   \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* (the flag is out before this wavefront may end) */         \
+                ON_TIMEOUT;                                                                                                     \
+            }                                                                                                                   \
         }                                                                                                                       \
     }
+
+// host words (host_core.hip.h): a value the host reads after the kernel, stored with system scope into pinned host-coherent memory
+__device__ __forceinline__ void hw_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 struct SliceJoinArgs {
     // the build index as this kernel needs it (a slim copy: the full IndexView costs ~50 SGPRs of kernel arguments)
