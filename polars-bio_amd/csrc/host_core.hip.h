@@ -91,6 +91,7 @@ struct ivj_ctx {
     uint32_t hw_seq = 0;
     uint32_t cs_far_hw_seq = 0;     // sequence number the pending far-row count was written under (0: it travels by copy)
     uint32_t cs_fused_hw_seq = 0;   // sequence number of the running fused join's state words (0: by copy)
+    int env_spin_us = 4000;         // IVJ_SPIN_US: the host polls a stream / event this long (microseconds) before it blocks in the runtime's wait; 0: block at once
     long long hw_misses = 0;        // host words that did not carry the call's sequence number (the value was copied instead)
     bool cs_prep_zero = false;      // this call's k_cs_prep clears the call state and the sample histogram (no memsets queued)
     XferSlots xfer;                 // pinned staging slots of the host <-> HBM copies (HostXfer), allocated on first use
@@ -167,6 +168,35 @@ struct ivj_ctx {
     // communicators created on this context that are still alive: ivj_ctx_destroy detaches them (their handles stay destroyable)
     std::vector<struct ivj_comm*> comms;
 };
+
+// Waits of the hot path (round 5).  The runtime's hipStreamSynchronize / hipEventSynchronize sleep on the completion interrupt: tens of
+// microseconds between the kernel's end and the host's next launch -- per call, with the GPU idle.  The host polls the stream / event
+// for up to IVJ_SPIN_US microseconds first (default 4000: a call of the benchmark configurations ends within it
+// -- a call still running after that blocks in the runtime as before).  Same completion semantics as the runtime's wait.
+inline hipError_t wait_stream(ivj_ctx* ctx, hipStream_t s) {
+    if (ctx->env_spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0;; ++i) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) return e;
+            if ((i & 15) == 15 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > ctx->env_spin_us) break;
+        }
+        (void)hipGetLastError();                                               // (hipErrorNotReady is sticky in hipGetLastError)
+    }
+    return hipStreamSynchronize(s);
+}
+inline hipError_t wait_event(ivj_ctx* ctx, hipEvent_t ev) {
+    if (ctx->env_spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0;; ++i) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e != hipErrorNotReady) return e;
+            if ((i & 15) == 15 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > ctx->env_spin_us) break;
+        }
+        (void)hipGetLastError();
+    }
+    return hipEventSynchronize(ev);
+}
 
 struct ivj_index {
     ivj_ctx* ctx = nullptr;

@@ -118,7 +118,7 @@ int cs_resolve_tables(ivj_ctx* ctx, ivj_index* ix) {
     if (!ix->cs_far_pending) return IVJ_OK;
     bool have = false;
     if (ctx->cs_far_owner == ix) {
-        HIP_TRY(hipEventSynchronize(ctx->cs_event));
+        HIP_TRY(wait_event(ctx, ctx->cs_event));
         ctx->cs_far_owner = nullptr;
         if (ctx->cs_far_hw_seq == 0) { ix->cs_far = *reinterpret_cast<const int32_t*>(ctx->h_total + 5); have = true; }
         else if (reinterpret_cast<volatile uint32_t*>(ctx->hw)[5] == ctx->cs_far_hw_seq) { ix->cs_far = (int32_t)reinterpret_cast<volatile uint32_t*>(ctx->hw)[4]; have = true; }
@@ -357,7 +357,7 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     // {pairs, flags}: from the host words the last join workgroup wrote -- or by copy (no host words, no workgroup, a protocol timeout)
     bool have_state = false;
     if (ctx->cs_fused_hw_seq != 0) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(wait_stream(ctx, ctx->stream));
         const volatile uint32_t* w = reinterpret_cast<volatile uint32_t*>(ctx->hw);
         if (w[12] == ctx->cs_fused_hw_seq) {
             ctx->h_total[0] = (long long)((unsigned long long)w[8] | ((unsigned long long)w[9] << 32));
@@ -367,7 +367,7 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     }
     if (!have_state) {
         HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_meta + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(wait_stream(ctx, ctx->stream));
     }
     HIP_TRY(hipGetLastError());
     if (std::getenv("IVJ_DEBUG_REDO")) std::fprintf(stderr, "[ivj] cs_overlap_fused: state flags %lld (sampled %d, exact %d, rec12 %d), pairs %lld\n", (long long)ctx->h_total[1], (int)ctx->sl_sampled, (int)ctx->cs_force_exact, (int)ctx->cs_force_rec12, (long long)ctx->h_total[0]);
@@ -404,7 +404,7 @@ int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     device_scan<long long, SumOp, false>(ctx, "tile_scan", ctx->sl_tile, ctx->sl_tile, P.ntiles, 0ll, ctx->sl_tpart, ctx->sl_tile + P.ntiles);
     HIP_TRY(hipMemcpyAsync(ctx->h_total, ctx->sl_tile + P.ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_total + 1, ctx->sl_meta + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(wait_stream(ctx, ctx->stream));
     HIP_TRY(hipGetLastError());
     if ((ctx->h_total[1] & 4) && ctx->sl_sampled) {
         CsExactScope redo(ctx);

@@ -331,7 +331,7 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
                        recs, n, nc, meta, (int)chunk, nchunks, (const uint32_t*)hist);
     t_end(ctx);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventSynchronize(ctx->ix3_event));
+    HIP_TRY(wait_event(ctx, ctx->ix3_event));
     uint32_t* hv = reinterpret_cast<uint32_t*>(ctx->h_total + 6);
     if (ctx->hw) {
         const volatile uint32_t* w = reinterpret_cast<volatile uint32_t*>(ctx->hw);

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -91,6 +92,7 @@ int ivj_ctx_create(int device, ivj_ctx** out) try {
     if (const char* ev = std::getenv("IVJ_NEAREST_LINES")) ctx->env_nearest_lines = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_NOLDS")) ctx->env_count_nolds = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_IX_V3")) ctx->env_ix_v3 = std::atoi(ev) != 0 ? 1 : 0;
+    if (const char* ev = std::getenv("IVJ_SPIN_US")) ctx->env_spin_us = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_IX_MERGE")) ctx->env_ix_merge = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_IX_STAGE")) ctx->env_ix_stage = std::atoi(ev) != 0 ? 1 : 0;
     e = hipHostMalloc((void**)&ctx->h_total, 64, hipHostMallocDefault);
