@@ -1197,6 +1197,16 @@ def test_nearest_lines_edge_shapes(strict):
     # a last tile whose upper wavefronts lie wholly beyond the probes, with the mask words reaching into scratch the index sort left
     # full of records (round-4 advisor finding: those wavefronts' words were read without ever being written)
     cases.append((random_side(rng, 512 * 2000 + 65, 2, 300000, 50), random_side(rng, 1025, 2, 300000, 50), 2))
+    # round 5: overlaps BELOW the two prefix-max levels a line carries -- staircases of up to nine rows, each ending beyond the one
+    # before it, every 4000 coordinates, and probes that start inside the first steps: settled by the lines kernel but for the build
+    # row (search state parked in the result slots), finished by the rest kernel; a staircase at a contig's very first rows included
+    k = np.arange(9 * 400)
+    st_s = ((k // 9) * 4000 + (k % 9) * 20).astype(np.int32)
+    st_e = (st_s + 300 + (k % 9) * 40).astype(np.int32)
+    st_c = ((k // 9) % 2).astype(np.int32)
+    pp = rng.integers(0, 400 * 4000, 30000).astype(np.int32)
+    pp[:6000] = (rng.integers(0, 400, 6000) * 4000 + rng.integers(150, 320, 6000)).astype(np.int32)
+    cases.append(((rng.integers(0, 2, 30000).astype(np.int32), pp, (pp + rng.integers(0, 60, 30000)).astype(np.int32)), (st_c, st_s, st_e), 2))
     e_ = _engine.Engine(0)
     try:
         e_.enable_timing(2)
@@ -1312,6 +1322,32 @@ def test_balanced_index_build_matches_the_lsd_build(merge, monkeypatch):
                     assert (n == en).all() and (d == ed).all() and (i == ei).all(), (name, k, inc, tm)
     finally:
         e3.close()
+
+
+@pytest.mark.parametrize("env", [{"IVJ_HOST_WORDS": "0"}, {"IVJ_SPIN_US": "0"}, {"IVJ_HOST_WORDS": "0", "IVJ_SPIN_US": "0", "IVJ_IX_MERGE": "0"}])
+def test_host_words_and_copies_agree(env, monkeypatch):
+    """Round 5: the few values the host needs mid-call (largest bucket of the balanced index build, far-row count of the slice tables,
+    pairs + flags of the fused join) come from words the kernels store into pinned host memory; IVJ_HOST_WORDS=0 sends them by copy
+    operations as before, IVJ_SPIN_US=0 blocks in the runtime's waits instead of polling first.  Same pairs either way -- on a call
+    that fits its capacity, on one that does not (the need is reported), and through the count -> fill pair."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("IVJ_CS", "1")
+    probe = synth.make_side(700_000, 42, synth.PROBE_LEN, 24)
+    build = synth.make_side(300_000, 43, synth.BUILD_LEN, 24)
+    ep, eb = _canon(*O.overlap_fast(O.Index(O.Side(*build), 24), O.Side(*probe), True))
+    e = _engine.Engine(0)
+    try:
+        hp, hb = _fused_overlap(e, probe, build, True, 24, 6, len(ep))
+        p, b = _canon(hp, hb)
+        assert len(p) == len(ep) and (p == ep).all() and (b == eb).all()
+        with pytest.raises(AssertionError) as ei:                              # (the helper asserts `fits`; its message carries the reported need)
+            _fused_overlap(e, probe, build, True, 24, 6, len(ep), capacity=len(ep) // 2)
+        assert f", {len(ep)}, {len(ep)})" in str(ei.value), str(ei.value)      # need reported == the pairs there are
+        p, b = _canon(*e.overlap(probe, build, True, 24, partition_mode=6))
+        assert len(p) == len(ep) and (p == ep).all() and (b == eb).all()
+    finally:
+        e.close()
 
 
 def test_balanced_index_build_is_the_default_at_bench_sizes():
