@@ -467,10 +467,12 @@ int ivj_nearest_arrow_stream(ivj_ctx* ctx, void* df1_stream, void* df2_stream, c
  * df2 (the build side) is drained, encoded and indexed once; df1 stays a STREAM and is pulled batch by batch from inside the result
  * stream's get_next: a batch is encoded with the session's chrom dictionary, narrowed to int32, submitted to a streaming probe session
  * (ivj_stream_*: its H2D copy overlaps the join of the batch before it and the D2H copy of the batch before that), and the results that
- * come back -- those of the batch submitted two turns earlier -- are assembled into record batches of batch_rows rows.  Host memory:
- * df2 + three df1 batches + one batch's result, whatever the length of df1 (which may pass 2^31 rows).  df1 batches above max_batch_rows
- * (<= 0: 4 Mi; it sizes the session's pinned staging) are submitted in slices.  Result rows come in df1 batch order.  limit >= 0: no df1
- * batch is pulled after the limit is reached.  Errors of a later batch (a coordinate beyond int32, a malformed batch) surface from
+ * come back -- those of the batch submitted two turns earlier -- are assembled into record batches of batch_rows rows.  df1 batches
+ * above max_batch_rows (<= 0: 4 Mi; it sizes the session's pinned staging) are submitted in slices; batches BELOW min(max_batch_rows,
+ * 2 Mi) rows are coalesced: the library pulls until it holds that many rows (or df1 ends) and treats the group as one batch (a group
+ * never exceeds twice that size unless a single batch does).  Host memory: df2 + three such groups + one group's result, whatever the
+ * length of df1 (which may pass 2^31 rows).  Result rows come in df1 order.  limit >= 0: df1 is pulled ONE batch at a time (no
+ * coalescing: the call may need very little of it) and not at all after the limit is reached.  Errors of a later batch (a coordinate beyond int32, a malformed batch) surface from
  * get_next (errno, text from get_last_error) -- as the reference's surface at collect time.  OWNERSHIP (both forms, eager and lazy): the
  * two input streams are consumed by the call whatever its outcome -- on every error path their release callbacks have run (the lazy
  * form keeps df1 until the result stream is exhausted or released).  The result stream works on `ctx` whenever it is pulled: pull it

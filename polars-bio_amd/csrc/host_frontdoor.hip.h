@@ -112,7 +112,7 @@ struct FdEncoder {
 template <class Off>
 int fd_encode(const Off* off, const unsigned char* data, const uint8_t* validity, int64_t bit0, int64_t n, int32_t* ids, int64_t* dict_rows,
               int32_t dict_cap, int32_t* n_values, int threads) {
-    const int t = fd_threads(n, threads, 1 << 16);
+    const int t = fd_threads(n, threads, 1 << 14);
     std::vector<FdEncoder<Off>*> enc(t, nullptr);
     const int64_t data_end = (int64_t)off[n];
     for (int k = 0; k < t; ++k) enc[k] = new FdEncoder<Off>(off, data, data_end);
@@ -208,7 +208,7 @@ static int ivj_host_narrow_i32_impl(const void* src, int32_t src_bytes, int32_t 
     if (src_bytes != 1 && src_bytes != 2 && src_bytes != 4 && src_bytes != 8) return fail(IVJ_EINVAL, "narrow: src_bytes must be 1, 2, 4 or 8");
     *out_min = 0; *out_max = 0;
     if (n == 0) return IVJ_OK;
-    const int t = fd_threads(n, threads, 1 << 17);
+    const int t = fd_threads(n, threads, 1 << 15);
     std::vector<long long> mn(t, INT64_MAX), mx(t, INT64_MIN);
     fd_parallel(n, t, [&](int k, int64_t lo, int64_t hi) {
         long long a = 0, b = 0;

@@ -322,9 +322,10 @@ def test_lazy_arrow_streams_equal_the_eager_ones():
 
 @pytest.mark.gpu
 def test_lazy_arrow_stream_never_holds_more_than_a_few_probe_batches():
-    """A generator-backed df1 of 40 batches: the library pulls them ONE AT A TIME while the result is read (at most three are alive
-    inside it at any moment, the session's depth), stops pulling once `limit` is reached, and an error in a LATE batch (a coordinate
-    beyond int32) surfaces from the result stream, after the earlier batches' rows were delivered."""
+    """A generator-backed df1 of 40 batches: the library pulls them ONE GROUP AT A TIME while the result is read -- batches at or above
+    the slice size one by one (at most three alive inside it at any moment, the session's depth), smaller ones coalesced up to the slice
+    size (here: two per group) --, stops pulling once `limit` is reached (a call with a limit never coalesces), and an error in a LATE
+    batch (a coordinate beyond int32) surfaces from the result stream, after the earlier batches' rows were delivered."""
     import gc
     import weakref
     eng = E.Engine(0)
@@ -348,26 +349,32 @@ def test_lazy_arrow_stream_never_holds_more_than_a_few_probe_batches():
                 gc.collect()
                 state["max_alive"] = max(state["max_alive"], sum(1 for w in state["alive"] if w() is not None))
 
-        rd = E.overlap_arrow_stream(eng, pa.RecordBatchReader.from_batches(schema, batches(40, 5000)), t2, strict=True, lazy=True, max_batch_rows=8192)
-        assert state["made"] == 0                                              # nothing is pulled before the result is
-        seen, rows = set(), 0
-        for rb in rd:
-            seen.update(rb.column("tag_1").to_pylist()); rows += rb.num_rows
-            assert state["made"] <= max(seen) + 4                              # the library runs at most three batches ahead of what it has delivered
-        assert seen == set(range(40)) and rows > 40 * 1000 and state["made"] == 40
-        assert state["max_alive"] <= 5, state["max_alive"]
+        for mbr, ahead, alive in ((4096, 4, 5), (8192, 8, 9)):                 # slices of 4096 rows: one batch per group; of 8192 rows: two
+            state.update(made=0, alive=[], max_alive=0)
+            rd = E.overlap_arrow_stream(eng, pa.RecordBatchReader.from_batches(schema, batches(40, 5000)), t2, strict=True, lazy=True, max_batch_rows=mbr)
+            assert state["made"] == 0                                          # nothing is pulled before the result is
+            seen, rows = set(), 0
+            for rb in rd:
+                seen.update(rb.column("tag_1").to_pylist()); rows += rb.num_rows
+                assert state["made"] <= max(seen) + ahead                      # the library runs at most three groups ahead of what it has delivered
+            assert seen == set(range(40)) and rows > 40 * 1000 and state["made"] == 40
+            assert state["max_alive"] <= alive, (mbr, state["max_alive"])
         # limit: df1 is not pulled to its end
         state.update(made=0, alive=[], max_alive=0)
         rd = E.overlap_arrow_stream(eng, pa.RecordBatchReader.from_batches(schema, batches(40, 5000)), t2, strict=True, lazy=True, limit=3000)
         assert rd.read_all().num_rows == 3000 and state["made"] <= 6
         # a late failure
         state.update(made=0, alive=[], max_alive=0)
-        rd = E.overlap_arrow_stream(eng, pa.RecordBatchReader.from_batches(schema, batches(10, 5000, bad_at=7)), t2, strict=True, lazy=True)
+        rd = E.overlap_arrow_stream(eng, pa.RecordBatchReader.from_batches(schema, batches(10, 5000, bad_at=7)), t2, strict=True, lazy=True, max_batch_rows=4096)
         got = 0
         with pytest.raises(Exception, match="does not fit int32|not in range"):
             for rb in rd:
                 got += rb.num_rows
         assert got > 0
+        # the same stream coalesced into one group (default slice size): the bad batch fails the group it is in
+        rd = E.overlap_arrow_stream(eng, pa.RecordBatchReader.from_batches(schema, batches(10, 5000, bad_at=7)), t2, strict=True, lazy=True)
+        with pytest.raises(Exception, match="does not fit int32|not in range"):
+            rd.read_all()
     finally:
         eng.close()
 
