@@ -162,6 +162,15 @@ int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* 
     const int want_chunk = opts->slice_chunk > 0 ? opts->slice_chunk : ctx->sl_env_chunk;
     int64_t jchunk = want_chunk > 0 ? ((int64_t)want_chunk + CS_TILE - 1) / CS_TILE * CS_TILE
                                     : (n >= (32ll << 20) ? 4 * CS_TILE : (n >= (8ll << 20) ? 2 * CS_TILE : CS_TILE));
+    if (want_chunk <= 0 && n >= (32ll << 20)) {
+        // Large probe sides (round 5, measured on config 3 on two boxes: join 0.905 / 0.854 / 0.862 / 0.948 / 0.928 / 0.872 / 1.06 ms at
+        // 16 / 20 / 24 / 28 / 32 / 40 / 64 Ki probes per workgroup): ~ 20 Ki probes per workgroup, and the AVERAGE bucket cut into equal
+        // parts -- a bucket of 80 k probes is four workgroups of 20 k, not five of 16 k with the slice loaded once more.
+        const int64_t a = n / (g.nb > 0 ? g.nb : 1);
+        const int64_t m = std::max<int64_t>(1, (a + 10240) / 20480);
+        const int64_t per = (a + m - 1) / m;
+        jchunk = std::min<int64_t>(8 * CS_TILE, std::max<int64_t>(2 * CS_TILE, (per + CS_TILE - 1) / CS_TILE * CS_TILE));
+    }
     if (jchunk > 64 * CS_TILE) jchunk = 64 * CS_TILE;
     P.jchunk = (int)jchunk;
     P.gmax = (int)(g.nb + (n + jchunk - 1) / jchunk);
