@@ -96,65 +96,61 @@ def parse():
     return ap.parse_args()
 
 
-def gen_workload(name, scale):
-    from polars_bio_amd import synth
-    cfg = {
-        "overlap_1k_1k_1contig": (1_000, 1_000, 1, synth.BUILD_LEN, "overlap"),
-        "overlap_10M_1M_1contig": (10_000_000, 1_000_000, 1, synth.BUILD_LEN, "overlap"),
-        "overlap_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "overlap"),
-        "overlap_100M_5M_24contig_dense": (100_000_000, 5_000_000, 24, synth.DENSE_BUILD_LEN, "overlap"),
-        "overlap_100M_5M_24contig_mid": (100_000_000, 5_000_000, 24, (1000, 9000), "overlap"),      # ~8.3 pairs per probe
-        "nearest_50M_2M_24contig": (50_000_000, 2_000_000, 24, synth.BUILD_LEN, "nearest"),
-        "count_200M_200k_24contig": (200_000_000, 200_000, 24, synth.BUILD_LEN, "count_overlaps"),
-        "count_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "count_overlaps"),   # large build side
-        # sort-scan family; not headline workloads
-        "coverage_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "coverage"),
-        "subtract_20M_5M_24contig": (20_000_000, 5_000_000, 24, synth.BUILD_LEN, "subtract"),
-        "merge_100M_24contig": (1, 100_000_000, 24, synth.PROBE_LEN, "merge"),
-    }[name]
-    n_p, n_b, nc, blen, op = cfg
-    n_p, n_b = max(1, int(n_p * scale)), max(1, int(n_b * scale))
-    t0 = time.time()
-    probe = synth.make_side(n_p, 42, synth.PROBE_LEN, nc)
-    build = synth.make_side(n_b, 43, blen, nc)
-    log(f"[bench] generated {name}: probe {n_p:,} build {n_b:,} contigs {nc} in {time.time() - t0:.1f}s")
-    return probe, build, nc, op
-
-
+WORKLOADS = {
+    "overlap_1k_1k_1contig": (1_000, 1_000, 1, "BUILD_LEN", "overlap"),
+    "overlap_10M_1M_1contig": (10_000_000, 1_000_000, 1, "BUILD_LEN", "overlap"),
+    "overlap_100M_5M_24contig": (100_000_000, 5_000_000, 24, "BUILD_LEN", "overlap"),
+    "overlap_100M_5M_24contig_dense": (100_000_000, 5_000_000, 24, "DENSE_BUILD_LEN", "overlap"),
+    "overlap_100M_5M_24contig_mid": (100_000_000, 5_000_000, 24, (1000, 9000), "overlap"),      # ~8.3 pairs per probe
+    "nearest_50M_2M_24contig": (50_000_000, 2_000_000, 24, "BUILD_LEN", "nearest"),
+    "count_200M_200k_24contig": (200_000_000, 200_000, 24, "BUILD_LEN", "count_overlaps"),
+    "count_100M_5M_24contig": (100_000_000, 5_000_000, 24, "BUILD_LEN", "count_overlaps"),   # large build side
+    # sort-scan family; not headline workloads
+    "coverage_100M_5M_24contig": (100_000_000, 5_000_000, 24, "BUILD_LEN", "coverage"),
+    "subtract_20M_5M_24contig": (20_000_000, 5_000_000, 24, "BUILD_LEN", "subtract"),
+    "merge_100M_24contig": (1, 100_000_000, 24, "PROBE_LEN", "merge"),
+}
 WORKLOADS_SHARDABLE = ("overlap_10M_1M_1contig", "overlap_100M_5M_24contig", "overlap_100M_5M_24contig_dense", "overlap_100M_5M_24contig_mid",
                        "nearest_50M_2M_24contig", "count_200M_200k_24contig", "count_100M_5M_24contig")
 
 
+def _cfg(name, scale):
+    from polars_bio_amd import synth
+    n_p, n_b, nc, blen, op = WORKLOADS[name]
+    blen = getattr(synth, blen) if isinstance(blen, str) else blen
+    return max(1, int(n_p * scale)), max(1, int(n_b * scale)), nc, blen, op
+
+
+def gen_workload(name, scale):
+    """The workload's ONE table (synth.make_rows: the same rows whatever the rank count; round 6)."""
+    from polars_bio_amd import synth
+    n_p, n_b, nc, blen, op = _cfg(name, scale)
+    t0 = time.time()
+    probe = synth.make_rows(n_p, 42, synth.PROBE_LEN, nc)[0]
+    build = synth.make_rows(n_b, 43, blen, nc)[0]
+    log(f"[bench] generated {name}: probe {n_p:,} build {n_b:,} contigs {nc} in {time.time() - t0:.1f}s")
+    return probe, build, nc, op
+
+
 def gen_shard(name, scale, rank, world):
-    """N > 1: this rank's shard only (synth.make_shard: the same distribution drawn contig by contig from per-contig streams, so no
-    rank ever generates -- or filters -- the other ranks' rows).  -> (probe, probe ids, build, build ids, mode, nc, op, n_p, n_b)."""
+    """N > 1: this rank's share of the SAME table gen_workload makes (synth.make_rows with a contig selection: the rows of the rank's
+    contigs in global row order with their global row ids, the other contigs' coordinates are never drawn).
+    -> (probe, probe ids, build, build ids, mode, nc, op, n_p, n_b)."""
     from polars_bio_amd import synth
     from polars_bio_amd import distributed as D
-    cfg = {
-        "overlap_10M_1M_1contig": (10_000_000, 1_000_000, 1, synth.BUILD_LEN, "overlap"),
-        "overlap_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "overlap"),
-        "overlap_100M_5M_24contig_dense": (100_000_000, 5_000_000, 24, synth.DENSE_BUILD_LEN, "overlap"),
-        "overlap_100M_5M_24contig_mid": (100_000_000, 5_000_000, 24, (1000, 9000), "overlap"),
-        "nearest_50M_2M_24contig": (50_000_000, 2_000_000, 24, synth.BUILD_LEN, "nearest"),
-        "count_200M_200k_24contig": (200_000_000, 200_000, 24, synth.BUILD_LEN, "count_overlaps"),
-        "count_100M_5M_24contig": (100_000_000, 5_000_000, 24, synth.BUILD_LEN, "count_overlaps"),
-    }[name]
-    n_p, n_b, nc, blen, op = cfg
-    n_p, n_b = max(1, int(n_p * scale)), max(1, int(n_b * scale))
+    n_p, n_b, nc, blen, op = _cfg(name, scale)
     t0 = time.time()
-    rp, rb = synth.contig_rows(n_p, nc), synth.contig_rows(n_b, nc)
     if nc >= world:
+        rp, rb = synth.contig_counts(n_p, 42, nc), synth.contig_counts(n_b, 43, nc)
         owner = D.lpt_assign((rp + rb).astype(float), world)
         mine = [c for c in range(nc) if owner[c] == rank]
-        pp = [(c, 0, int(rp[c])) for c in mine]
-        pb = [(c, 0, int(rb[c])) for c in mine]
+        lp, lp_ids = synth.make_rows(n_p, 42, synth.PROBE_LEN, nc, contigs=mine)
+        lb, lb_ids = synth.make_rows(n_b, 43, blen, nc, contigs=mine)
         mode = "contig"
     else:   # fewer contigs than ranks (config 2): build side replicated, probe rows split
-        pp = [(c, int(rp[c]) * rank // world, int(rp[c]) * (rank + 1) // world) for c in range(nc)]
-        pb = [(c, 0, int(rb[c])) for c in range(nc)]
+        lp, lp_ids = synth.make_rows(n_p, 42, synth.PROBE_LEN, nc, row_range=(n_p * rank // world, n_p * (rank + 1) // world))
+        lb, lb_ids = synth.make_rows(n_b, 43, blen, nc)
         mode = "rows"
-    lp, lp_ids = synth.make_shard(n_p, 42, synth.PROBE_LEN, nc, pp, shuffle_seed=1000 + rank)
-    lb, lb_ids = synth.make_shard(n_b, 43, blen, nc, pb, shuffle_seed=2000 + (rank if mode == "contig" else 0))
     log(f"[bench] rank {rank}: generated its shard of {name} ({mode}): probe {len(lp_ids):,} of {n_p:,}, build {len(lb_ids):,} of {n_b:,} in {time.time() - t0:.1f}s")
     return lp, lp_ids, lb, lb_ids, mode, nc, op, n_p, n_b
 
@@ -242,7 +238,7 @@ def cpu_baseline(op, probe, build, nc, sample_rows):
         try:
             from polars_bio_amd import synth
             nd = min(n1, 1_000_000)
-            dbuild = synth.make_side(len(build[0]), 43, synth.DENSE_BUILD_LEN, nc)
+            dbuild = synth.make_rows(len(build[0]), 43, synth.DENSE_BUILD_LEN, nc)[0]
             dix = O.Index(O.Side(*dbuild), nc)
             dside = O.Side(probe[0][:nd], probe[1][:nd], probe[2][:nd])
             dt, units, _ = best_of(lambda: O.overlap_baseline(dix, dside, True, 1, False, True)[0], reps=2)

@@ -42,7 +42,9 @@ template <bool STRICT, int N, bool LM>
 __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, const int32_t* __restrict__ pc,
                                                                   const int32_t* __restrict__ ps,
                                                                   const int32_t* __restrict__ pe, int64_t n, bool vec_ok,
-                                                                  long long* __restrict__ counts, int ablate) {
+                                                                  long long* __restrict__ counts, int32_t* __restrict__ counts32, int ablate) {
+    // counts32 != nullptr: the counts as int32 (a count is bounded by the build rows) into counts32 instead of int64 into counts -- the
+    // wire format of the per-probe exchange (host_comm.hip.h), written here so that no pack pass re-reads 8 bytes per probe
     __shared__ int4 l_cm[LM ? 2 * CM_LDS : 1];
     if (LM) {
         for (int i = threadIdx.x; i < 2 * ix.n_contigs; i += PROBE_THREADS) l_cm[i] = ix.cmeta_j[i];
@@ -102,7 +104,16 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_count_overlaps(IndexView ix, 
         }
     }
     if ((ablate & 2) && cnt[0] != 123456789) continue;
-    if (i0 + N <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0 && (N % 2) == 0) {
+    if (counts32) {
+        if (N == 2 && i0 + N <= n && (reinterpret_cast<uintptr_t>(counts32) & 7u) == 0) {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            v2i v; v.x = (int)cnt[0]; v.y = (int)cnt[N - 1];
+            __builtin_nontemporal_store(v, reinterpret_cast<v2i*>(counts32 + i0));
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) if (i0 + k < n) counts32[i0 + k] = (int32_t)cnt[k];
+        }
+    } else if (i0 + N <= n && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0 && (N % 2) == 0) {
 #pragma unroll
         for (int k = 0; k < N; k += 2)
         {

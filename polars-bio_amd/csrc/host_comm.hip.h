@@ -106,6 +106,8 @@ struct ivj_comm {
     int device = 0;
     int rank = 0, world = 1;
     RcclComm comm = nullptr;             // nullptr for a single-rank communicator (nothing to exchange, RCCL never touched)
+    bool self_rccl = false;              // IVJ_COMM_NO_SHORTCUT=1 at creation: a world-1 communicator is a REAL RCCL communicator and this rank's
+                                         //   own slice travels through ncclSend / ncclRecv to itself -- the way a 1-GPU box executes the RCCL branch
     LoopGroup* loop = nullptr;           // in-process transport instead of RCCL (shared by the communicators of one create_local call)
     hipStream_t xstream = nullptr;       // the exchange runs on its own stream so that it overlaps the join
     long long* d_counts = nullptr;       // 2 * (world + 1) int64 in HBM: gathered values (<= 2 per rank), then this rank's send slots
@@ -116,6 +118,7 @@ struct ivj_comm {
     int64_t iota_n = 0;
     char* pp_buf = nullptr;              // scratch of the per-probe exchange (count_overlaps / nearest): local results, send and receive columns
     size_t pp_cap = 0;
+    long long pp_scatter_fallbacks = 0;  // per-probe exchanges whose senders were not ascending (scatter form instead of the merge)
 };
 
 namespace {
@@ -139,16 +142,18 @@ int comm_finish_create(ivj_comm* c) {
 
 // For every column: recv[k] + dst_off + (exclusive prefix of counts)[r] <- rank r's send[k][0 .. counts[r]) ; elem_bytes per element.
 // One grouped batch of sends / receives on the exchange stream (own slice: device copy).  Does NOT synchronise.
-int comm_exchange_v(ivj_comm* c, const void* const* send, void* const* recv, int n_cols, const int* elem_bytes_v, const int64_t* counts, int64_t dst_off) {
+// own_copy = false: this rank's own slice is NOT copied into recv (the caller reads it where it lies); with the self-RCCL mode it travels like a peer's.
+int comm_exchange_v(ivj_comm* c, const void* const* send, void* const* recv, int n_cols, const int* elem_bytes_v, const int64_t* counts, int64_t dst_off, bool own_copy = true) {
     std::vector<int64_t> off((size_t)c->world + 1, 0);
     for (int r = 0; r < c->world; ++r) off[r + 1] = off[r] + counts[r];
     const int64_t n_local = counts[c->rank];
-    for (int k = 0; k < n_cols; ++k) {
+    const bool self_rccl = c->self_rccl && c->comm;   // own slice through RCCL too (send / receive to self inside the group)
+    for (int k = 0; k < n_cols && !self_rccl && own_copy; ++k) {
         const int elem_bytes = elem_bytes_v[k];
         if (n_local > 0)
             HIP_TRY(hipMemcpyAsync((char*)recv[k] + (size_t)(dst_off + off[c->rank]) * elem_bytes, send[k], (size_t)n_local * elem_bytes, hipMemcpyDeviceToDevice, c->xstream));
     }
-    if (c->world == 1) return IVJ_OK;
+    if (c->world == 1 && !self_rccl) return IVJ_OK;
     if (c->loop) {
         LoopGroup* L = c->loop;
         if (n_cols > LoopGroup::MAX_COLS) return fail(IVJ_EINVAL, "loopback transport: too many columns");
@@ -170,7 +175,7 @@ int comm_exchange_v(ivj_comm* c, const void* const* send, void* const* recv, int
     for (int k = 0; k < n_cols; ++k) {
         const int elem_bytes = elem_bytes_v[k];
         for (int peer = 0; peer < c->world; ++peer) {
-            if (peer == c->rank) continue;
+            if (peer == c->rank && !self_rccl) continue;
             if (n_local > 0) RCCL_TRY(api, api->Send(send[k], (size_t)n_local * elem_bytes, RCCL_INT8, peer, c->comm, c->xstream));
             if (counts[peer] > 0)
                 RCCL_TRY(api, api->Recv((char*)recv[k] + (size_t)(dst_off + off[peer]) * elem_bytes, (size_t)counts[peer] * elem_bytes, RCCL_INT8, peer, c->comm, c->xstream));
@@ -194,7 +199,7 @@ __global__ void k_iota(int32_t* __restrict__ out, int64_t n) {
 
 // (values[0 .. nv) of every rank) -> all[r * nv + v], on the exchange stream; synchronises that stream.  nv <= 2.
 int comm_allgather_i64(ivj_comm* c, const int64_t* vals, int nv, int64_t* all) {
-    if (c->world == 1) { for (int v = 0; v < nv; ++v) all[v] = vals[v]; return IVJ_OK; }
+    if (c->world == 1 && !(c->self_rccl && c->comm)) { for (int v = 0; v < nv; ++v) all[v] = vals[v]; return IVJ_OK; }
     if (c->loop) {
         LoopGroup* L = c->loop;
         { std::lock_guard<std::mutex> lk(L->mu); for (int v = 0; v < nv; ++v) L->vals[(size_t)c->rank * 2 + v] = vals[v]; }
@@ -375,17 +380,161 @@ int overlap_allgather(ivj_comm* c, ivj_index* ix, const ivj_side* probe, const i
 
 // ---- count_overlaps / nearest of a shard + the exchange of the PER-PROBE results ---------------------------------
 // Every probe row lives on exactly one rank (contig sharding; global row in ivj_side.row_id), its result has a fixed width, and every
-// rank wants the full-length columns in the ORIGINAL probe order: local results -> packed send columns {global row, value ...} ->
-// count all-gather + ONE grouped send / receive batch -> a scatter kernel that stores every received value at its row.
-//   count_overlaps: {row int32, count int32} on the wire (a count is bounded by the build rows, < 2^31), widened to int64 by the scatter
-//   nearest:        {row int32, k build rows int32, k distances int64, n_found int32}
+// rank wants the full-length columns in the ORIGINAL probe order.
+//   wire, count_overlaps: {row int32, count int32}  (a count is bounded by the build rows, < 2^31; widened to int64 by the receiver)
+//   wire, nearest:        {row int32, k build rows int32, k distances int64, n_found int32}
 // Rows no rank reports keep the defaults (count 0; build row -1, distance -1, n_found 0).
-__global__ void k_pp_pack_count(const int32_t* __restrict__ row_id, const long long* __restrict__ cnt, int64_t n, int32_t* __restrict__ o_row, int32_t* __restrict__ o_cnt) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    o_row[i] = row_id ? row_id[i] : (int32_t)i;
-    o_cnt[i] = (int32_t)cnt[i];
+//
+// Round 6 -- the receiver MERGES instead of scattering.  A shard made by ivj_host_shard (or any host that keeps df1's order) lists its
+// global rows in ASCENDING order, so the rows of one output tile [t0, t0 + PP_TILE) are ONE contiguous segment of every sender's columns:
+// k_pp_tile_offsets finds the segment bounds (one bound search per (sender, tile), all in parallel), k_pp_merge_* reads the segments
+// coalesced, places the values by row in LDS and writes the tile coalesced with the defaults filled in -- no fill pass, no random 8-byte
+// store per row (round 5: 200 M of them for config 5, 8.4 of the call's 10.6 ms), no pack pass (the shard's kernel writes the wire columns
+// itself, the row column on the wire IS probe.row_id), and this rank's own slice is read where it lies instead of being copied.
+// Exactness does not rest on the order: every tile checks that what it placed belongs to it and that no row came twice, the placed rows
+// are counted, and a call whose senders are not ascending falls back to the scatter kernels (round-5 form: fill + one store per row).
+constexpr int PP_TILE = 4096;
+constexpr int PP_THREADS = 256;
+constexpr int PP_MAX_WORLD = 64;       // senders the merge kernels take (their table is a kernel argument); larger worlds scatter
+
+struct PpSrc {
+    int world, own;                     // own: the rank whose columns are read from the own_* pointers (-1: every slice lies in the receive columns)
+    long long off[PP_MAX_WORLD + 1];    // exclusive prefix of the per-rank row counts = position of rank r's slice in the receive columns
+};
+// flags[0] bit 0: a row outside [0, n_total) / outside the tile its segment belongs to (senders not ascending)   bit 1: a row reported twice
+// flags[2..3]: rows placed (uint64)
+
+__device__ __forceinline__ uint32_t pp_lower_bound(const int32_t* __restrict__ rows, uint32_t n, long long key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t m = lo + ((hi - lo) >> 1);
+        if ((long long)rows[m] < key) lo = m + 1; else hi = m;
+    }
+    return lo;
 }
+
+// toff[r * (ntiles + 1) + t] = first position of sender r whose row is >= t * PP_TILE   (rows == nullptr: the identity, world 1 only)
+__global__ void k_pp_tile_offsets(PpSrc S, const int32_t* __restrict__ recv_rows, const int32_t* __restrict__ own_rows, int64_t ntiles,
+                                  uint32_t* __restrict__ toff) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)S.world * (ntiles + 1)) return;
+    const int r = (int)(i / (ntiles + 1));
+    const int64_t t = i - (int64_t)r * (ntiles + 1);
+    const uint32_t n_r = (uint32_t)(S.off[r + 1] - S.off[r]);
+    const int32_t* rows = r == S.own ? own_rows : recv_rows + S.off[r];
+    const long long key = (long long)t * PP_TILE;
+    toff[i] = (r == S.own && !own_rows) ? (uint32_t)(key < (long long)n_r ? key : (long long)n_r) : pp_lower_bound(rows, n_r, key);
+}
+
+__global__ __launch_bounds__(PP_THREADS) void k_pp_merge_count(PpSrc S, const int32_t* __restrict__ recv_rows, const int32_t* __restrict__ own_rows,
+                                                               const int32_t* __restrict__ recv_cnt, const int32_t* __restrict__ own_cnt,
+                                                               int64_t n_total, int64_t ntiles, const uint32_t* __restrict__ toff,
+                                                               long long* __restrict__ out, unsigned int* __restrict__ flags) {
+    __shared__ int tile[PP_TILE];
+    __shared__ unsigned int l_placed, l_bad;
+    const int64_t t = blockIdx.x, t0 = t * PP_TILE;
+    for (int i = threadIdx.x; i < PP_TILE; i += PP_THREADS) tile[i] = -1;
+    if (threadIdx.x == 0) { l_placed = 0; l_bad = 0; }
+    __syncthreads();
+    unsigned int placed = 0, bad = 0;
+    for (int r = 0; r < S.world; ++r) {
+        const uint32_t a = toff[(int64_t)r * (ntiles + 1) + t];
+        uint32_t b = toff[(int64_t)r * (ntiles + 1) + t + 1];
+        if (b < a) b = a;
+        if (b - a > (uint32_t)PP_TILE) { bad |= 1u; b = a + PP_TILE; }
+        const bool own = r == S.own;
+        const int32_t* rows = own ? own_rows : recv_rows + S.off[r];
+        const int32_t* cnt = own ? own_cnt : recv_cnt + S.off[r];
+        for (uint32_t j = a + threadIdx.x; j < b; j += PP_THREADS) {
+            const long long g = rows ? (long long)__builtin_nontemporal_load(rows + j) : (long long)j;
+            const int v = __builtin_nontemporal_load(cnt + j);
+            const long long slot = g - t0;
+            if (slot < 0 || slot >= PP_TILE || g >= n_total || v < 0) { bad |= 1u; continue; }
+            if (atomicExch(&tile[slot], v) != -1) bad |= 2u;
+            ++placed;
+        }
+    }
+    if (placed) atomicAdd(&l_placed, placed);
+    if (bad) atomicOr(&l_bad, bad);
+    __syncthreads();
+    // the tile, coalesced, defaults filled in: two int64 per 16-byte store
+    typedef long long v2ll __attribute__((ext_vector_type(2)));
+    if (t0 + PP_TILE <= n_total && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+        for (int i = 2 * threadIdx.x; i < PP_TILE; i += 2 * PP_THREADS) {
+            const int2 c = *reinterpret_cast<const int2*>(&tile[i]);
+            v2ll v; v.x = c.x < 0 ? 0 : c.x; v.y = c.y < 0 ? 0 : c.y;
+            __builtin_nontemporal_store(v, reinterpret_cast<v2ll*>(out + t0 + i));
+        }
+    } else {
+        for (int i = threadIdx.x; i < PP_TILE; i += PP_THREADS)
+            if (t0 + i < n_total) out[t0 + i] = tile[i] < 0 ? 0 : tile[i];
+    }
+    if (threadIdx.x == 0) {
+        if (l_placed) atomicAdd(reinterpret_cast<unsigned long long*>(flags + 2), (unsigned long long)l_placed);
+        if (l_bad) atomicOr(flags, l_bad);
+    }
+}
+
+// nearest: the tile holds a REFERENCE per output row (sender << 13 | position inside the sender's segment); the k build rows, k distances
+// and n_found of a row are fetched through it at write-out, where consecutive lanes read consecutive positions of (at most `world`) segments
+__global__ __launch_bounds__(PP_THREADS) void k_pp_merge_nearest(PpSrc S, const int32_t* __restrict__ recv_rows, const int32_t* __restrict__ own_rows,
+                                                                 const int32_t* __restrict__ recv_idx, const int32_t* __restrict__ own_idx,
+                                                                 const long long* __restrict__ recv_dist, const long long* __restrict__ own_dist,
+                                                                 const int32_t* __restrict__ recv_nf, const int32_t* __restrict__ own_nf, int k,
+                                                                 int64_t n_total, int64_t ntiles, const uint32_t* __restrict__ toff,
+                                                                 int32_t* __restrict__ o_idx, long long* __restrict__ o_dist, int32_t* __restrict__ o_nf,
+                                                                 unsigned int* __restrict__ flags) {
+    __shared__ uint32_t tile[PP_TILE];
+    __shared__ uint32_t seg_a[PP_MAX_WORLD];
+    __shared__ unsigned int l_placed, l_bad;
+    const int64_t t = blockIdx.x, t0 = t * PP_TILE;
+    for (int i = threadIdx.x; i < PP_TILE; i += PP_THREADS) tile[i] = 0xffffffffu;
+    if (threadIdx.x < S.world) seg_a[threadIdx.x] = toff[(int64_t)threadIdx.x * (ntiles + 1) + t];
+    if (threadIdx.x == 0) { l_placed = 0; l_bad = 0; }
+    __syncthreads();
+    unsigned int placed = 0, bad = 0;
+    for (int r = 0; r < S.world; ++r) {
+        const uint32_t a = seg_a[r];
+        uint32_t b = toff[(int64_t)r * (ntiles + 1) + t + 1];
+        if (b < a) b = a;
+        if (b - a > (uint32_t)PP_TILE) { bad |= 1u; b = a + PP_TILE; }
+        const int32_t* rows = r == S.own ? own_rows : recv_rows + S.off[r];
+        for (uint32_t j = a + threadIdx.x; j < b; j += PP_THREADS) {
+            const long long g = rows ? (long long)__builtin_nontemporal_load(rows + j) : (long long)j;
+            const long long slot = g - t0;
+            if (slot < 0 || slot >= PP_TILE || g >= n_total) { bad |= 1u; continue; }
+            if (atomicExch(&tile[slot], ((uint32_t)r << 13) | (j - a)) != 0xffffffffu) bad |= 2u;
+            ++placed;
+        }
+    }
+    if (placed) atomicAdd(&l_placed, placed);
+    if (bad) atomicOr(&l_bad, bad);
+    __syncthreads();
+    for (int i = threadIdx.x; i < PP_TILE; i += PP_THREADS) {
+        const int64_t g = t0 + i;
+        if (g >= n_total) break;
+        const uint32_t ref = tile[i];
+        if (ref == 0xffffffffu) {
+            for (int q = 0; q < k; ++q) { o_idx[g * k + q] = -1; o_dist[g * k + q] = -1; }
+            o_nf[g] = 0;
+        } else {
+            const int r = (int)(ref >> 13);
+            const int64_t j = (int64_t)seg_a[r] + (ref & 8191u);
+            const bool own = r == S.own;
+            const int32_t* s_idx = own ? own_idx : recv_idx + S.off[r] * k;
+            const long long* s_dist = own ? own_dist : recv_dist + S.off[r] * k;
+            const int32_t* s_nf = own ? own_nf : recv_nf + S.off[r];
+            for (int q = 0; q < k; ++q) { o_idx[g * k + q] = s_idx[j * k + q]; o_dist[g * k + q] = s_dist[j * k + q]; }
+            o_nf[g] = s_nf[j];
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (l_placed) atomicAdd(reinterpret_cast<unsigned long long*>(flags + 2), (unsigned long long)l_placed);
+        if (l_bad) atomicOr(flags, l_bad);
+    }
+}
+
+// the scatter form (senders in any order): one store per reported row into columns that hold the defaults already
 __global__ void k_pp_rows(const int32_t* __restrict__ row_id, int64_t n, int32_t* __restrict__ o_row) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o_row[i] = row_id ? row_id[i] : (int32_t)i;
@@ -394,8 +543,8 @@ __global__ void k_pp_scatter_count(const int32_t* __restrict__ row, const int32_
                                    unsigned int* __restrict__ bad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int32_t r = row[i];
-    if ((uint64_t)(int64_t)r >= (uint64_t)n_out) { atomicOr(bad, 1u); return; }
+    const int64_t r = row ? (int64_t)row[i] : i;
+    if ((uint64_t)r >= (uint64_t)n_out) { atomicOr(bad, 1u); return; }
     out[r] = (long long)cnt[i];
 }
 __global__ void k_pp_scatter_nearest(const int32_t* __restrict__ row, const int32_t* __restrict__ idx, const long long* __restrict__ dist,
@@ -405,15 +554,11 @@ __global__ void k_pp_scatter_nearest(const int32_t* __restrict__ row, const int3
     if (t >= n * k) return;
     const int64_t i = t / k;
     const int j = (int)(t - i * k);
-    const int32_t r = row[i];
-    if ((uint64_t)(int64_t)r >= (uint64_t)n_out) { atomicOr(bad, 1u); return; }
-    o_idx[(int64_t)r * k + j] = idx[t];
-    o_dist[(int64_t)r * k + j] = dist[t];
+    const int64_t r = row ? (int64_t)row[i] : i;
+    if ((uint64_t)r >= (uint64_t)n_out) { atomicOr(bad, 1u); return; }
+    o_idx[r * k + j] = idx[t];
+    o_dist[r * k + j] = dist[t];
     if (j == 0) o_nf[r] = nf[i];
-}
-__global__ void k_pp_fill_i32(int32_t* __restrict__ p, int64_t n, int32_t v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
 }
 
 int pp_ensure(ivj_comm* c, size_t bytes) {
@@ -429,7 +574,10 @@ int pp_ensure(ivj_comm* c, size_t bytes) {
 // op: IVJ_STREAM_COUNT or IVJ_STREAM_NEAREST.  Failure protocol as overlap_allgather: every rank reaches the ONE count all-gather with
 // {rows it reports | -1 = its own work failed, the n_total it was given}; whether anything is moved is decided from the gathered values
 // alone (a failed rank: nobody sends or receives, the failed rank returns its own error, the others IVJ_EPEER; n_total differing between
-// the ranks or fewer output rows than reported rows: IVJ_EINVAL on every rank), so no rank is ever left waiting in a collective.
+// the ranks or fewer output rows than reported rows: IVJ_EINVAL on every rank), so no rank is ever left waiting in a collective.  Everything
+// of this rank's own that can fail (the shard's kernel, allocations, the stream synchronisation, the flag words) happens BEFORE the count
+// all-gather and is folded into the failure mark; between the all-gather and the grouped send / receive batch there is no fallible local
+// step, and what follows the batch (merge kernels, flag read-back) no peer waits for.
 int per_probe_allgather(ivj_comm* c, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int op, int64_t n_total,
                         int64_t* counts_out, int32_t* idx_out, int64_t* dist_out, int32_t* nf_out) {
     ivj_ctx* ctx = c->ctx;
@@ -440,59 +588,58 @@ int per_probe_allgather(ivj_comm* c, ivj_index* ix, const ivj_side* probe, const
     auto note = [&](int r) { if (r != IVJ_OK && rc == IVJ_OK) { rc = r; main_err = g_err; } };
     if (c->world > 1 && n > 0 && !probe->row_id) note(fail(IVJ_EINVAL, "a shard of a multi-rank call needs the global probe rows in probe.row_id"));
     if (n > n_total) note(fail(IVJ_EINVAL, "the shard has more probe rows than n_total"));
+    if (n_total > 0x7fffffffll) note(fail(IVJ_EINVAL, "n_total beyond int32 row ids"));
     if (rc == IVJ_OK && fault_injected(c->rank, 0)) note(fail(IVJ_EHIP, "injected fault (IVJ_FAULT_ALLGATHER) in the per-probe exchange"));
-    // scratch layout: [bad flag | local results | send columns | receive columns (n_total rows)]
-    const size_t a_row = align_up((size_t)std::max<int64_t>(n, 1) * 4), a_row_t = align_up((size_t)std::max<int64_t>(n_total, 1) * 4);
-    size_t local_b, send_b, recv_b;
-    if (op == IVJ_STREAM_COUNT) { local_b = align_up((size_t)std::max<int64_t>(n, 1) * 8); send_b = 2 * a_row; recv_b = 2 * a_row_t; }
-    else {
-        local_b = 0;                                                            // nearest_dev writes straight into the send columns
-        send_b = a_row + align_up((size_t)std::max<int64_t>(n, 1) * k * 4) + align_up((size_t)std::max<int64_t>(n, 1) * k * 8) + a_row;
-        recv_b = a_row_t + align_up((size_t)std::max<int64_t>(n_total, 1) * k * 4) + align_up((size_t)std::max<int64_t>(n_total, 1) * k * 8) + a_row_t;
-    }
-    if (rc == IVJ_OK) note(pp_ensure(c, 256 + local_b + send_b + recv_b));
+    const bool self_rccl = c->self_rccl && c->comm;
+    const bool own_in_recv = self_rccl;                                   // this rank's slice travels through RCCL like everybody else's
+    const bool need_recv = c->world > 1 || self_rccl;
+    const bool make_rows = !probe->row_id && self_rccl;                  // the wire needs a row column; a shard without ids has the identity
+    const int64_t ntiles = (n_total + PP_TILE - 1) / PP_TILE;
+    // scratch layout: [flag words | tile offsets | send columns | receive columns (n_total rows; only where something is received)]
+    const size_t n1 = (size_t)std::max<int64_t>(n, 1), nt1 = (size_t)std::max<int64_t>(n_total, 1);
+    const size_t toff_b = align_up((size_t)std::min<int>(c->world, PP_MAX_WORLD) * (size_t)(ntiles + 1) * 4);
+    const size_t a_row = align_up(n1 * 4), a_row_t = align_up(nt1 * 4);
+    const size_t a_idx = align_up(n1 * k * 4), a_dist = align_up(n1 * k * 8), a_idx_t = align_up(nt1 * k * 4), a_dist_t = align_up(nt1 * k * 8);
+    const size_t send_b = (make_rows ? a_row : 0) + (op == IVJ_STREAM_COUNT ? a_row : a_idx + a_dist + a_row);
+    const size_t recv_b = !need_recv ? 0 : (op == IVJ_STREAM_COUNT ? 2 * a_row_t : a_row_t + a_idx_t + a_dist_t + a_row_t);
+    if (rc == IVJ_OK) note(pp_ensure(c, 256 + toff_b + send_b + recv_b));
     char* base = c->pp_buf;
-    unsigned int* d_bad = reinterpret_cast<unsigned int*>(base);
-    char* p_local = base ? base + 256 : nullptr;
-    char* p_send = p_local ? p_local + local_b : nullptr;
+    unsigned int* d_flags = reinterpret_cast<unsigned int*>(base);
+    uint32_t* d_toff = base ? reinterpret_cast<uint32_t*>(base + 256) : nullptr;
+    char* p_send = base ? base + 256 + toff_b : nullptr;
     char* p_recv = p_send ? p_send + send_b : nullptr;
     const void* send[4] = {nullptr, nullptr, nullptr, nullptr};
     void* recv[4] = {nullptr, nullptr, nullptr, nullptr};
     int widths[4] = {4, 4, 8, 4};
     int n_cols = 2;
+    const int32_t* own_rows = probe->row_id;
     if (rc == IVJ_OK) {
+        char* q = p_send;
+        if (make_rows) { own_rows = (int32_t*)q; q += a_row; }
+        char* r = p_recv;
+        send[0] = own_rows; recv[0] = r; r += a_row_t;
         if (op == IVJ_STREAM_COUNT) {
-            int32_t* s_row = (int32_t*)p_send; int32_t* s_cnt = (int32_t*)(p_send + a_row);
-            send[0] = s_row; send[1] = s_cnt; recv[0] = p_recv; recv[1] = p_recv + a_row_t;
+            int32_t* s_cnt = (int32_t*)q;
+            send[1] = s_cnt; recv[1] = r;
             widths[0] = 4; widths[1] = 4; n_cols = 2;
-            if (n > 0) {
-                note(count_overlaps_dev(ctx, ix, probe, opts, (int64_t*)p_local));
-                if (rc == IVJ_OK) {
-                    hipLaunchKernelGGL(k_pp_pack_count, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, probe->row_id, (const long long*)p_local, n, s_row, s_cnt);
-                    if (hipGetLastError() != hipSuccess) note(fail(IVJ_EHIP, "k_pp_pack_count launch failed"));
-                }
-            }
+            if (n > 0) note(count_overlaps_dev(ctx, ix, probe, opts, nullptr, s_cnt));     // the wire column straight from the kernel
         } else {
-            char* q = p_send;
-            int32_t* s_row = (int32_t*)q; q += a_row;
-            int32_t* s_idx = (int32_t*)q; q += align_up((size_t)std::max<int64_t>(n, 1) * k * 4);
-            int64_t* s_dist = (int64_t*)q; q += align_up((size_t)std::max<int64_t>(n, 1) * k * 8);
+            int32_t* s_idx = (int32_t*)q; q += a_idx;
+            int64_t* s_dist = (int64_t*)q; q += a_dist;
             int32_t* s_nf = (int32_t*)q;
-            char* r = p_recv;
-            recv[0] = r; r += a_row_t;
-            recv[1] = r; r += align_up((size_t)std::max<int64_t>(n_total, 1) * k * 4);
-            recv[2] = r; r += align_up((size_t)std::max<int64_t>(n_total, 1) * k * 8);
+            recv[1] = r; r += a_idx_t;
+            recv[2] = r; r += a_dist_t;
             recv[3] = r;
-            send[0] = s_row; send[1] = s_idx; send[2] = s_dist; send[3] = s_nf;
+            send[1] = s_idx; send[2] = s_dist; send[3] = s_nf;
             widths[0] = 4; widths[1] = 4 * k; widths[2] = 8 * k; widths[3] = 4; n_cols = 4;
-            if (n > 0) {
-                note(nearest_dev(ctx, ix, probe, opts, s_idx, s_dist, s_nf));
-                if (rc == IVJ_OK) {
-                    hipLaunchKernelGGL(k_pp_rows, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, probe->row_id, n, s_row);
-                    if (hipGetLastError() != hipSuccess) note(fail(IVJ_EHIP, "k_pp_rows launch failed"));
-                }
-            }
+            if (n > 0) note(nearest_dev(ctx, ix, probe, opts, s_idx, s_dist, s_nf));
         }
+        if (rc == IVJ_OK && make_rows && n > 0) {
+            hipLaunchKernelGGL(k_pp_rows, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, (const int32_t*)nullptr, n, (int32_t*)own_rows);
+            if (hipGetLastError() != hipSuccess) note(fail(IVJ_EHIP, "k_pp_rows launch failed"));
+        }
+        if (rc == IVJ_OK && hipMemsetAsync(d_flags, 0, 16, ctx->stream) != hipSuccess) note(fail(IVJ_EHIP, "the flag words of the per-probe exchange: hipMemsetAsync failed"));
+        // (also covers whatever the context's stream still holds for the caller's output columns)
         if (rc == IVJ_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) note(fail(IVJ_EHIP, "the shard's per-probe kernel failed"));
     }
     // every rank, whatever happened to it so far
@@ -513,32 +660,65 @@ int per_probe_allgather(ivj_comm* c, ivj_index* ix, const ivj_side* probe, const
     if (failed_peer >= 0) return fail(IVJ_EPEER, "rank " + std::to_string(failed_peer) + " failed in the per-probe exchange; nothing was exchanged");
     if (mismatch) return fail(IVJ_EINVAL, "the ranks of a per-probe exchange disagree on n_total");
     if (tot > n_total) return fail(IVJ_EINVAL, "the ranks report " + std::to_string(tot) + " probe rows for n_total = " + std::to_string(n_total));
-    // defaults + exchange + scatter, all on the exchange stream (after whatever the context's stream still holds for the caller's columns)
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_bad, 0, 4, c->xstream));
-    if (n_total > 0) {
-        if (op == IVJ_STREAM_COUNT) HIP_TRY(hipMemsetAsync(counts_out, 0, (size_t)n_total * 8, c->xstream));
-        else {
-            HIP_TRY(hipMemsetAsync(idx_out, 0xff, (size_t)n_total * k * 4, c->xstream));       // -1
-            HIP_TRY(hipMemsetAsync(dist_out, 0xff, (size_t)n_total * k * 8, c->xstream));      // -1
-            HIP_TRY(hipMemsetAsync(nf_out, 0, (size_t)n_total * 4, c->xstream));
-        }
-    }
-    IVJ_TRY(comm_exchange_v(c, send, recv, n_cols, widths, counts.data(), 0));
-    if (tot > 0) {
+    // the ONE grouped batch: the peers' slices into the receive columns (this rank's own stays where the kernel wrote it)
+    if (need_recv) IVJ_TRY(comm_exchange_v(c, send, recv, n_cols, widths, counts.data(), 0, own_in_recv));
+    if (n_total == 0) { if (need_recv) HIP_TRY(hipStreamSynchronize(c->xstream)); return IVJ_OK; }
+    std::vector<int64_t> off((size_t)c->world + 1, 0);
+    for (int r = 0; r < c->world; ++r) off[r + 1] = off[r] + counts[r];
+    auto read_flags = [&](unsigned int* f) -> int {
+        HIP_TRY(hipMemcpyAsync(c->h_counts, d_flags, 16, hipMemcpyDeviceToHost, c->xstream));
+        HIP_TRY(hipStreamSynchronize(c->xstream));
+        std::memcpy(f, c->h_counts, 16);
+        return IVJ_OK;
+    };
+    const int32_t* r_rows = (const int32_t*)recv[0];
+    bool merged = false;
+    if (c->world <= PP_MAX_WORLD) {
+        PpSrc S;
+        S.world = c->world; S.own = own_in_recv ? -1 : c->rank;
+        for (int r = 0; r <= c->world; ++r) S.off[r] = off[r];
+        hipLaunchKernelGGL(k_pp_tile_offsets, dim3(grid1d((int64_t)c->world * (ntiles + 1), 256)), dim3(256), 0, c->xstream, S, r_rows, own_rows, ntiles, d_toff);
         if (op == IVJ_STREAM_COUNT)
-            hipLaunchKernelGGL(k_pp_scatter_count, dim3(grid1d(tot, 256)), dim3(256), 0, c->xstream, (const int32_t*)recv[0], (const int32_t*)recv[1], tot, n_total,
-                               (long long*)counts_out, d_bad);
+            hipLaunchKernelGGL(k_pp_merge_count, dim3((unsigned)ntiles), dim3(PP_THREADS), 0, c->xstream, S, r_rows, own_rows, (const int32_t*)recv[1], (const int32_t*)send[1],
+                               n_total, ntiles, (const uint32_t*)d_toff, (long long*)counts_out, d_flags);
         else
-            hipLaunchKernelGGL(k_pp_scatter_nearest, dim3(grid1d(tot * k, 256)), dim3(256), 0, c->xstream, (const int32_t*)recv[0], (const int32_t*)recv[1],
-                               (const long long*)recv[2], (const int32_t*)recv[3], tot, k, n_total, idx_out, (long long*)dist_out, nf_out, d_bad);
+            hipLaunchKernelGGL(k_pp_merge_nearest, dim3((unsigned)ntiles), dim3(PP_THREADS), 0, c->xstream, S, r_rows, own_rows, (const int32_t*)recv[1], (const int32_t*)send[1],
+                               (const long long*)recv[2], (const long long*)send[2], (const int32_t*)recv[3], (const int32_t*)send[3], k, n_total, ntiles,
+                               (const uint32_t*)d_toff, idx_out, (long long*)dist_out, nf_out, d_flags);
         HIP_TRY(hipGetLastError());
+        unsigned int f[4];
+        IVJ_TRY(read_flags(f));
+        unsigned long long placed; std::memcpy(&placed, f + 2, 8);
+        if (f[0] & 2u) return fail(IVJ_EINVAL, "a probe row id is reported twice in the per-probe exchange (by one rank or by two)");
+        merged = f[0] == 0 && placed == (unsigned long long)tot;
     }
-    unsigned int h_bad = 0;
-    HIP_TRY(hipMemcpyAsync(c->h_counts, d_bad, 4, hipMemcpyDeviceToHost, c->xstream));
-    HIP_TRY(hipStreamSynchronize(c->xstream));
-    h_bad = *reinterpret_cast<const unsigned int*>(c->h_counts);
-    if (h_bad) return fail(IVJ_EINVAL, "a probe row id of the per-probe exchange lies outside [0, n_total)");
+    if (merged) return IVJ_OK;
+    // senders that are not ascending (or more ranks than the merge kernels take): defaults, then one store per reported row
+    ++c->pp_scatter_fallbacks;
+    HIP_TRY(hipMemsetAsync(d_flags, 0, 16, c->xstream));
+    if (op == IVJ_STREAM_COUNT) HIP_TRY(hipMemsetAsync(counts_out, 0, (size_t)n_total * 8, c->xstream));
+    else {
+        HIP_TRY(hipMemsetAsync(idx_out, 0xff, (size_t)n_total * k * 4, c->xstream));       // -1
+        HIP_TRY(hipMemsetAsync(dist_out, 0xff, (size_t)n_total * k * 8, c->xstream));      // -1
+        HIP_TRY(hipMemsetAsync(nf_out, 0, (size_t)n_total * 4, c->xstream));
+    }
+    auto scatter = [&](const int32_t* rows, const void* c1, const void* c2, const void* c3, int64_t m) {
+        if (m <= 0) return;
+        if (op == IVJ_STREAM_COUNT)
+            hipLaunchKernelGGL(k_pp_scatter_count, dim3(grid1d(m, 256)), dim3(256), 0, c->xstream, rows, (const int32_t*)c1, m, n_total, (long long*)counts_out, d_flags);
+        else
+            hipLaunchKernelGGL(k_pp_scatter_nearest, dim3(grid1d(m * k, 256)), dim3(256), 0, c->xstream, rows, (const int32_t*)c1, (const long long*)c2, (const int32_t*)c3,
+                               m, k, n_total, idx_out, (long long*)dist_out, nf_out, d_flags);
+    };
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank && !own_in_recv) { scatter(own_rows, send[1], send[2], send[3], counts[r]); continue; }
+        scatter(r_rows + off[r], (const char*)recv[1] + (size_t)off[r] * widths[1], op == IVJ_STREAM_COUNT ? nullptr : (const char*)recv[2] + (size_t)off[r] * widths[2],
+                op == IVJ_STREAM_COUNT ? nullptr : (const char*)recv[3] + (size_t)off[r] * widths[3], counts[r]);
+    }
+    HIP_TRY(hipGetLastError());
+    unsigned int f[4];
+    IVJ_TRY(read_flags(f));
+    if (f[0]) return fail(IVJ_EINVAL, "a probe row id of the per-probe exchange lies outside [0, n_total)");
     return IVJ_OK;
 }
 

@@ -75,6 +75,7 @@ struct ivj_ctx {
     size_t ov_cap = 0;
     int64_t ov_n = -1;
     const void* ov_probe_start = nullptr;
+    const void *ov_probe_contig = nullptr, *ov_probe_end = nullptr;
     const ivj_index* ov_ix = nullptr;
     int32_t ov_filter = -1;
     int32_t* ov_hi = nullptr;

@@ -90,7 +90,7 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     ctx->ov_n = -1;
     ctx->ov_slice = false;
     if (n == 0 || ix->n == 0) {
-        ctx->ov_n = n; ctx->ov_total = 0; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
+        ctx->ov_n = n; ctx->ov_total = 0; ctx->ov_probe_start = probe->start; ctx->ov_probe_contig = probe->contig; ctx->ov_probe_end = probe->end; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
         *n_pairs = 0;
         return IVJ_OK;
     }
@@ -102,7 +102,7 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
         else IVJ_TRY(slice_overlap_count(ctx, ix, probe, opts, sg, &total));
         ctx->ov_slice = true;
         ctx->ov_total = total;
-        ctx->ov_n = n; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
+        ctx->ov_n = n; ctx->ov_probe_start = probe->start; ctx->ov_probe_contig = probe->contig; ctx->ov_probe_end = probe->end; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
         *n_pairs = total;
         return IVJ_OK;
     }
@@ -132,7 +132,7 @@ int overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
     ctx->ov_total = *ctx->h_total;
-    ctx->ov_n = n; ctx->ov_probe_start = probe->start; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
+    ctx->ov_n = n; ctx->ov_probe_start = probe->start; ctx->ov_probe_contig = probe->contig; ctx->ov_probe_end = probe->end; ctx->ov_ix = ix; ctx->ov_filter = opts->filter_op;
     *n_pairs = ctx->ov_total;
     return IVJ_OK;
 }
@@ -142,18 +142,25 @@ int overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_
 
 int overlap_fill(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int32_t* out_p, int32_t* out_b,
                  int64_t capacity) {
-    if (ctx->ov_n != probe->n || ctx->ov_probe_start != probe->start || ctx->ov_ix != ix || ctx->ov_filter != opts->filter_op)
+    // (the dense reroute below re-reads all three probe columns, so all three are part of the hand-over's identity)
+    if (ctx->ov_n != probe->n || ctx->ov_probe_start != probe->start || ctx->ov_probe_contig != probe->contig || ctx->ov_probe_end != probe->end ||
+        ctx->ov_ix != ix || ctx->ov_filter != opts->filter_op)
         return fail(IVJ_ESTATE, "ivj_overlap_fill_dev must follow ivj_overlap_count_dev with the same index, probe and filter_op");
     if (capacity < ctx->ov_total) return fail(IVJ_ECAPACITY, "output capacity " + std::to_string(capacity) + " < " + std::to_string(ctx->ov_total) + " pairs");
     if (ctx->ov_total == 0) return IVJ_OK;
     if (!out_p || !out_b) return fail(IVJ_EINVAL, "output buffers are NULL");
-    if (ctx->ov_slice && opts->partition_mode == 0 && !opts->deterministic && ix->n_contigs > 0 && ctx->ov_total >= 16 * probe->n) {
+    if (ctx->ov_slice && opts->partition_mode == 0 && !opts->deterministic && !ctx->sl_env_stable && ix->n_contigs > 0 && ctx->ov_total >= 16 * probe->n) {
         // DENSE result (>= 16 pairs per probe row, now known exactly): the slice FILL spends its time in the long windows -- 44 ms
         // for the 3.7 G pairs of the dense 100 M x 5 M variant -- where the flat kernel tests every candidate with its own lane
         // (12.5 ms + its tables).  The count is exact, so the fused flat pass runs with capacity = the count (round 5; a trace of
         // the dense bench showed the warm-up's count -> fill pair at 50 ms next to 15-ms fused steps: what pb.overlap ran).
+        // The flat kernel orders its tiles with an atomic cursor: not for opts.deterministic / IVJ_SLICE_STABLE=1 callers (they keep the slice FILL).
+        const int64_t want = ctx->ov_total;
         int64_t got = 0;
-        IVJ_TRY(overlap_fused(ctx, ix, probe, opts, out_p, out_b, ctx->ov_total, &got));
+        IVJ_TRY(overlap_fused(ctx, ix, probe, opts, out_p, out_b, want, &got));
+        if (got != want)
+            return fail(IVJ_ESTATE, "the fill pass found " + std::to_string(got) + " pairs where the count pass found " + std::to_string(want) +
+                                    ": the probe columns changed between ivj_overlap_count_dev and ivj_overlap_fill_dev");
         return IVJ_OK;
     }
     if (ctx->ov_slice) return ctx->ov_cs ? cs_overlap_fill(ctx, ix, opts, out_p, out_b) : slice_overlap_fill(ctx, ix, opts, out_p, out_b);
@@ -292,12 +299,17 @@ int overlap_fused_rows(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
     return IVJ_OK;
 }
 
-int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* counts) {
+// counts32 != nullptr: int32 counts into counts32 (the per-probe exchange's wire column), `counts` unused
+int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, int64_t* counts, int32_t* counts32 = nullptr) {
     // the kernel reads the joint grid only; the start table is needed by the (opt-in) bucketed form
     if (!ix->has_tables || opts->partition_mode == 1) IVJ_TRY(need_tables(ctx, ix));
     const int64_t n = probe->n;
     if (n == 0) return IVJ_OK;
-    if (ix->n == 0) { HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 8, ctx->stream)); return IVJ_OK; }
+    if (ix->n == 0) {
+        if (counts32) HIP_TRY(hipMemsetAsync(counts32, 0, (size_t)n * 4, ctx->stream));
+        else HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 8, ctx->stream));
+        return IVJ_OK;
+    }
     IVJ_TRY(build_end_order(ctx, ix));
     // partition_mode 1 only: bucket the probes by genomic position, count in bucket order into scratch, bring the
     // counts back to probe order with the coalesced inverse permutation.  Not the default: with ONE record gather per
@@ -305,7 +317,7 @@ int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
     // bucketed; nearest and coverage, with 3+ gathers per probe, do gain).
     const int32_t *qc = probe->contig, *qs = probe->start, *qe = probe->end;
     long long* o_counts = (long long*)counts;
-    const bool bucketed = opts->partition_mode == 1 && ix->n > 0;
+    const bool bucketed = opts->partition_mode == 1 && ix->n > 0 && !counts32;
     if (bucketed) {
         ivj_side plain = *probe;
         plain.row_id = nullptr;
@@ -323,11 +335,11 @@ int count_overlaps_dev(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const
     IndexView v = view_of(ix);
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
     if (ix->n_contigs <= CM_LDS && !ctx->env_count_nolds) {
-        if (strict) LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT, true>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, ctx->env_count_ablate);
-        else LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT, true>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, ctx->env_count_ablate);
+        if (strict) LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT, true>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, counts32, ctx->env_count_ablate);
+        else LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT, true>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, counts32, ctx->env_count_ablate);
     } else {
-        if (strict) LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT, false>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, ctx->env_count_ablate);
-        else LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT, false>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, ctx->env_count_ablate);
+        if (strict) LAUNCH(ctx, "count_overlaps", (k_count_overlaps<true, PROBE_ITEMS_LAT, false>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, counts32, ctx->env_count_ablate);
+        else LAUNCH(ctx, "count_overlaps", (k_count_overlaps<false, PROBE_ITEMS_LAT, false>), tiles, PROBE_THREADS, v, qc, qs, qe, n, vec, o_counts, counts32, ctx->env_count_ablate);
     }
     HIP_TRY(hipGetLastError());
     if (bucketed) {

@@ -295,11 +295,19 @@ int ivj_comm_create(ivj_ctx* ctx, const void* unique_id, int rank, int world, iv
     DeviceGuard g(ctx->device);
     ivj_comm* c = new ivj_comm();
     c->ctx = ctx; c->rank = rank; c->world = world;
-    if (world > 1) {
+    // IVJ_COMM_NO_SHORTCUT=1: also a single rank gets a real RCCL communicator and exchanges with itself through it (tests:
+    // the dlopen'ed entry points, the exchange stream's ordering and the error mapping run on a 1-GPU box)
+    const char* ns = std::getenv("IVJ_COMM_NO_SHORTCUT");
+    c->self_rccl = ns && std::atoi(ns) != 0;
+    if (world > 1 || c->self_rccl) {
         const RcclApi* api = rccl_api();
         if (!api) { delete c; return fail(IVJ_EHIP, g_rccl.error); }
         RcclUniqueId id;
-        std::memcpy(&id, unique_id, sizeof(id));
+        if (unique_id) std::memcpy(&id, unique_id, sizeof(id));
+        else {
+            const int ur = api->GetUniqueId(&id);
+            if (ur != 0) { delete c; return fail(IVJ_EHIP, std::string("ncclGetUniqueId: ") + api->GetErrorString(ur)); }
+        }
         const int r = api->CommInitRank(&c->comm, world, id, rank);
         if (r != 0) { delete c; return fail(IVJ_EHIP, std::string("ncclCommInitRank: ") + api->GetErrorString(r)); }
     }

@@ -415,3 +415,198 @@ def test_per_probe_allgather_rejects_rows_outside_n_total():
         d.close()
     comm.close()
     eng.close()
+
+
+# ---- real RCCL on ONE rank (round 6) ---------------------------------------------------------------------------------------------------
+# A world-1 communicator normally never touches RCCL (comm_allgather_i64 / comm_exchange_v return before it).  IVJ_COMM_NO_SHORTCUT=1 at
+# creation makes it a REAL communicator (ncclGetUniqueId + ncclCommInitRank) whose count all-gather is an ncclAllGather and whose own
+# slice travels through a grouped ncclSend + ncclRecv to itself: the dlopen'ed entry points (host_comm.hip.h:21-66), the exchange stream's
+# ordering against the join, the helper thread + ncclGroupStart/End and the RCCL_TRY error mapping all run on a 1-GPU box.
+_CANARY = {}
+_CANARY_SRC = r"""
+import os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(sys.argv[1], "polars-bio_amd"), sys.argv[1]]
+os.environ["IVJ_COMM_NO_SHORTCUT"] = "1"
+from polars_bio_amd import _engine
+eng = _engine.Engine(0)
+comm = _engine.Comm(eng, None, 0, 1)
+assert comm.allgather_counts(17) == [17]
+a = np.arange(1000, dtype=np.int64)
+src, dst = eng.dev_alloc(8000), eng.dev_alloc(8000)
+eng.h2d(src, a)
+comm.allgatherv_dev([src], [dst], 8, [1000])
+got = np.empty(1000, np.int64)
+eng.d2h(got, dst)
+assert (got == a).all()
+assert "librccl" in open("/proc/self/maps").read()
+comm.close(); eng.close()
+print("canary ok")
+"""
+
+
+def _rccl_self_ok():
+    """One ncclAllGather + one grouped send / receive to self in a SUBPROCESS with a deadline: a transport that hangs on this box must
+    not take the test process with it."""
+    if "ok" not in _CANARY:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        try:
+            r = subprocess.run([sys.executable, "-c", _CANARY_SRC, root], capture_output=True, text=True, timeout=240)
+            _CANARY["ok"] = r.returncode == 0 and "canary ok" in r.stdout
+            _CANARY["why"] = (r.stdout + r.stderr)[-1500:]
+        except subprocess.TimeoutExpired:
+            _CANARY["ok"], _CANARY["why"] = False, "the canary did not finish in 240 s"
+    return _CANARY["ok"]
+
+
+def test_real_rccl_on_one_rank_canary():
+    assert _rccl_self_ok(), _CANARY.get("why")
+
+
+@pytest.fixture
+def rccl_self(monkeypatch):
+    if not _rccl_self_ok():
+        pytest.skip("RCCL send / receive to self does not work on this box (see the canary test)")
+    monkeypatch.setenv("IVJ_COMM_NO_SHORTCUT", "1")
+
+
+def test_real_rccl_on_one_rank_overlap_allgather_matches_oracle(rccl_self, monkeypatch):
+    """ivj_overlap_allgather_dev through RCCL itself: 4 chunks (helper thread, count ncclAllGather per chunk, grouped ncclSend / ncclRecv of
+    the pairs on the exchange stream while the next chunk is joined), staging growth, the capacity protocol, fault injection."""
+    eng = _engine.Engine(0)
+    rng = np.random.default_rng(61)
+    probe = random_side(rng, 80000, 4, 300000, 300)
+    build = random_side(rng, 20000, 3, 300000, 300)
+    probe[0][:40000].sort()
+    ep, eb = _canon(*O.overlap_fast(O.Index(O.Side(*build), 3), O.Side(*probe), True))
+    total = len(ep)
+    comm = _engine.Comm(eng, None, 0, 1)
+    assert "librccl" in open("/proc/self/maps").read()
+    d = _Dev(eng, probe, build)
+    try:
+        opts = _engine.make_opts(True, 3)
+        ix = eng.index_build_dev(d.build, opts)
+        op, ob = d.alloc(4 * total), d.alloc(4 * total)
+        for chunks in (1, 4):
+            nt, nl, fits = comm.overlap_allgather_dev(ix, d.probe, opts, chunks, op, ob, total)
+            assert fits and nt == total and nl == total, (chunks, nt, nl, total)
+            hp, hb = np.empty(total, np.int32), np.empty(total, np.int32)
+            eng.d2h(hp, op); eng.d2h(hb, ob)
+            gp, gb = _canon(hp, hb)
+            assert (gp == ep).all() and (gb == eb).all(), chunks
+        nt, nl, fits = comm.overlap_allgather_dev(ix, d.probe, opts, 4, op, ob, total - 1)
+        assert not fits and nt == total
+        monkeypatch.setenv("IVJ_FAULT_ALLGATHER", "0:2")
+        with pytest.raises(_engine.EngineError, match="injected fault"):
+            comm.overlap_allgather_dev(ix, d.probe, opts, 4, op, ob, total)
+        monkeypatch.delenv("IVJ_FAULT_ALLGATHER")
+        nt, nl, fits = comm.overlap_allgather_dev(ix, d.probe, opts, 4, op, ob, total)          # the communicator is in step afterwards
+        assert fits and nt == nl == total
+        ix.close()
+    finally:
+        d.close()
+    assert comm.allgather_counts(5) == [5]
+    comm.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("with_ids", [False, True])
+def test_real_rccl_on_one_rank_per_probe_exchanges_match_oracle(rccl_self, with_ids):
+    """ivj_count_overlaps_allgather_dev / ivj_nearest_allgather_dev with the rank's own slice going through ncclSend / ncclRecv."""
+    probe, build, nc = _pp_inputs(31)
+    n = len(probe[0])
+    ix_o = O.Index(O.Side(*build), nc)
+    exp_c = O.count_overlaps_fast(ix_o, O.Side(*probe), True)
+    ids = np.arange(n, dtype=np.int32) if with_ids else None
+    eng = _engine.Engine(0)
+    comm = _engine.Comm(eng, None, 0, 1)
+    d = _Dev(eng, probe, build, ids)
+    try:
+        for k in (1, 3):
+            opts = _engine.make_opts(True, nc, k=k)
+            ix = eng.index_build_dev(d.build, opts)
+            if k == 1:
+                cp = d.alloc(8 * n)
+                comm.count_overlaps_allgather_dev(ix, d.probe, opts, n, cp)
+                h = np.empty(n, np.int64); eng.d2h(h, cp)
+                assert (h == exp_c).all()
+            ei, ed, en = O.nearest_fast(ix_o, O.Side(*probe), True, k, True)
+            ip, dp, fp = d.alloc(4 * n * k), d.alloc(8 * n * k), d.alloc(4 * n)
+            comm.nearest_allgather_dev(ix, d.probe, opts, n, ip, dp, fp)
+            hi, hd, hf = np.empty(n * k, np.int32), np.empty(n * k, np.int64), np.empty(n, np.int32)
+            eng.d2h(hi, ip); eng.d2h(hd, dp); eng.d2h(hf, fp)
+            assert (hf == en.ravel()).all() and (hd == ed.ravel()).all() and (hi == ei.ravel()).all(), k
+            ix.close()
+    finally:
+        d.close()
+    comm.close()
+    eng.close()
+
+
+# ---- the per-probe exchange merges ascending senders and scatters the others (round 6) ------------------------------------------------
+def _pp_job_shuffled(eng, comm, probe, build, nc, rank, world, seed, out):
+    """_pp_job with the shard's rows SHUFFLED (global ids no longer ascending): the merge's checks must send the call to the scatter form."""
+    try:
+        (lp, pid, lb, bid, _mode) = D.shard_sides(probe, build, nc, rank, world)
+        perm = np.random.default_rng(seed + rank).permutation(len(pid))
+        lp, pid = tuple(c[perm] for c in lp), pid[perm]
+        d = _Dev(eng, lp, lb, pid)
+        try:
+            bptr = d.alloc(4 * len(bid)); eng.h2d(bptr, bid)
+            opts = _engine.make_opts(True, nc)
+            ix = eng.index_build_dev(eng.dev_side(d.build.contig, d.build.start, d.build.end, len(bid), bptr), opts)
+            n_total = len(probe[0])
+            cp = d.alloc(8 * n_total)
+            comm.count_overlaps_allgather_dev(ix, d.probe, opts, n_total, cp)
+            h = np.empty(n_total, np.int64); eng.d2h(h, cp)
+            ip, dp, fp = d.alloc(4 * n_total), d.alloc(8 * n_total), d.alloc(4 * n_total)
+            comm.nearest_allgather_dev(ix, d.probe, opts, n_total, ip, dp, fp)
+            hi, hd, hf = np.empty(n_total, np.int32), np.empty(n_total, np.int64), np.empty(n_total, np.int32)
+            eng.d2h(hi, ip); eng.d2h(hd, dp); eng.d2h(hf, fp)
+            out[rank] = (h, hi, hd, hf)
+            ix.close()
+        finally:
+            d.close()
+    except _engine.EngineError as e:
+        out[rank] = e
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_per_probe_allgather_of_shuffled_shards_takes_the_scatter_form(world):
+    probe, build, nc = _pp_inputs(41)
+    ix_o = O.Index(O.Side(*build), nc)
+    exp = O.count_overlaps_fast(ix_o, O.Side(*probe), True)
+    ei, ed, en = O.nearest_fast(ix_o, O.Side(*probe), True, 1, True)
+    engines, comms = _local_group(world)
+    out = {}
+    _run_ranks(_pp_job_shuffled, [(engines[r], comms[r], probe, build, nc, r, world, 500, out) for r in range(world)])
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        h, hi, hd, hf = out[r]
+        assert (h == exp).all(), r
+        assert (hf == en.ravel()).all() and (hd == ed.ravel()).all() and (hi == ei.ravel()).all(), r
+    for c in comms: c.close()
+    for e in engines: e.close()
+
+
+def test_per_probe_allgather_refuses_a_row_reported_twice():
+    """Two probe rows of one shard carry the same global id: IVJ_EINVAL from the merge's tile check (round 5: the later store won)."""
+    eng = _engine.Engine(0)
+    comm = _engine.Comm(eng, None, 0, 1)
+    rng = np.random.default_rng(4)
+    probe = random_side(rng, 5000, 2, 50000, 100)
+    build = random_side(rng, 500, 2, 50000, 100)
+    ids = np.arange(5000, dtype=np.int32)
+    ids[1234] = 1233
+    d = _Dev(eng, probe, build, ids)
+    try:
+        opts = _engine.make_opts(True, 2)
+        ix = eng.index_build_dev(d.build, opts)
+        cp = d.alloc(8 * 5000)
+        with pytest.raises(_engine.EngineError, match="twice"):
+            comm.count_overlaps_allgather_dev(ix, d.probe, opts, 5000, cp)
+        ix.close()
+    finally:
+        d.close()
+    comm.close()
+    eng.close()

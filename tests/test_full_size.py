@@ -314,8 +314,12 @@ def test_eight_ranks_on_one_gpu_dry_run_at_full_size(workload):
     collectives per overlap step incl. one capacity regrow, the per-probe exchange of count_overlaps; every rank must end up with the
     identical, cross-checked result (tools/dryrun_ranks.py).  Oversubscribed: the timing is not a scaling number."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from dryrun_ranks import dry_run
-    line = dry_run(workload, world=8, scale=1.0, steps=1)
+    from dryrun_ranks import dry_run, oracle_expectation
+    # round 6: the shards are cut out of the N = 1 table (synth.make_rows), so the oracle's answer for THAT table is the expectation:
+    # every rank's gathered counts == O.count_overlaps_fast, the pair total and build-row checksum == O.overlap_baseline
+    expect = oracle_expectation(workload)
+    line = dry_run(workload, world=8, scale=1.0, steps=1, expect=expect)
+    assert line["oracle_checked"] and line["units"] == (expect["total"] if workload.startswith("overlap") else int(expect["counts"].sum()))
     assert line["world"] == 8 and len(line["shards"]) == 8 and all(s["probe_rows"] > 0 and s["build_rows"] > 0 for s in line["shards"])
     assert sum(s["probe_rows"] for s in line["shards"]) == (100_000_000 if workload.startswith("overlap") else 200_000_000)
     if workload.startswith("overlap"):
@@ -349,3 +353,74 @@ def test_dense_result_of_the_count_fill_pair_takes_the_flat_kernel(eng):
     eng.enable_timing(0)
     assert "overlap_flat" in t and "cs_fill_cached" not in t, sorted(t)
     _check_pair_properties(p, b, probe, build, counts, checksum, "dense count -> fill")
+
+
+def test_full_size_dense_variant_3_66e9_pairs_beyond_int32_offsets():
+    """The dense 100 M x 5 M variant (5-40 kb build rows, ~37 pairs per probe row, P = 3.66e9 > 2^31; the reference publishes results
+    of this scale, docs/performance.md:222-233) through BOTH entries -- the fused pass at the exact capacity (flat kernel, 64-bit pair
+    offsets) and the count -> fill pair (the fill of a dense result re-runs the flat kernel) -- checked against the oracle WITHOUT
+    bringing the 29-GB result to the host: total = O.overlap_baseline's, build-row checksum = its checksum, per-probe multiplicities =
+    O.count_overlaps_fast (bincount on the device, chunk by chunk), the predicate on every pair, and the pairs of one probe row are
+    one contiguous run ascending in (build.start, build row) -- so no pair is emitted twice, hence every probe row got exactly its rows."""
+    import torch
+    from polars_bio_amd.device_api import DeviceJoin, DeviceSide
+    probe, build, nc = synth.workload("overlap_100M_5M_24contig_dense")
+    n = len(probe[0])
+    cores = os.cpu_count() or 1
+    ix = O.Index(O.Side(*build), nc)
+    counts = O.count_overlaps_fast(ix, O.Side(*probe), True, threads=cores)
+    total, checksum = O.overlap_baseline(ix, O.Side(*probe), True, cores)
+    assert total == int(counts.sum()) and total > 2 ** 31, total
+    del ix
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dp = DeviceSide(up(probe[0]), up(probe[1]), up(probe[2]))
+    db = DeviceSide(up(build[0]), up(build[1]), up(build[2]))
+    d_counts = up(counts)
+    runs_expected = int((counts > 0).sum())
+    join = DeviceJoin(0)
+    out_p = torch.empty(total, dtype=torch.int32, device=dev)
+    out_b = torch.empty(total, dtype=torch.int32, device=dev)
+    CH = 1 << 28
+
+    def check(what):
+        mult = torch.zeros(n, dtype=torch.int64, device=dev)
+        csum, runs = 0, 0
+        prev_p = prev_b = None
+        for lo in range(0, total, CH):
+            hp, hb = out_p[lo:lo + CH].long(), out_b[lo:lo + CH].long()
+            assert int(hp.min()) >= 0 and int(hp.max()) < n and int(hb.min()) >= 0 and int(hb.max()) < db.n, what
+            mult += torch.bincount(hp, minlength=n)
+            csum += int(hb.sum())
+            assert bool(((dp.start[hp] < db.end[hb]) & (db.start[hb] < dp.end[hp])).all()), (what, "predicate")
+            if prev_p is not None:                              # the run that crosses the chunk boundary
+                hp, hb = torch.cat([prev_p, hp]), torch.cat([prev_b, hb])
+            same = hp[1:] == hp[:-1]
+            runs += int((~same).sum())
+            s0, s1 = db.start[hb[:-1]], db.start[hb[1:]]
+            asc = (s0 < s1) | ((s0 == s1) & (hb[:-1] < hb[1:]))
+            assert bool((asc | ~same).all()), (what, "order inside a probe row")
+            prev_p, prev_b = hp[-1:].clone(), hb[-1:].clone()
+            del hp, hb, same, s0, s1, asc
+        assert runs + 1 == runs_expected, (what, "pairs of one probe row are not contiguous", runs + 1, runs_expected)
+        assert bool((mult == d_counts).all()), (what, "per-probe multiplicities")
+        assert csum == checksum, (what, csum, checksum)
+
+    opts = _engine.make_opts(True, nc)
+    ixd = join.engine.index_build_dev(db.as_c(), opts, False)
+    try:
+        # 1. the fused pass at the exact capacity (capacity >= 16 n: the flat kernel), and one pair short of it
+        got, fits = join.engine.overlap_fused_dev(ixd, dp.as_c(), opts, out_p.data_ptr(), out_b.data_ptr(), total - 1)
+        assert not fits and got == total
+        got, fits = join.engine.overlap_fused_dev(ixd, dp.as_c(), opts, out_p.data_ptr(), out_b.data_ptr(), total)
+        assert fits and got == total
+        torch.cuda.synchronize()
+        check("fused")
+        # 2. the count -> fill pair (what ivj_overlap and the front door run)
+        out_p.fill_(-1); out_b.fill_(-1)
+        assert join.engine.overlap_count_dev(ixd, dp.as_c(), opts) == total
+        join.engine.overlap_fill_dev(ixd, dp.as_c(), opts, out_p.data_ptr(), out_b.data_ptr(), total)
+        torch.cuda.synchronize()
+        check("count -> fill")
+    finally:
+        ixd.close()

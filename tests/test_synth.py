@@ -56,3 +56,49 @@ def test_sharded_generator_is_consistent_and_follows_the_distribution():
     (bc, bs, be), _ = synth.make_shard(40_000, 43, synth.BUILD_LEN, nc, [(k, 0, 1 << 30) for k in range(nc)])
     pairs = int(O.count_overlaps_fast(O.Index(O.Side(bc, bs, be), nc), O.Side(c, s, e), True).sum())
     assert abs(pairs / synth.expected_pairs(n, 40_000, nc) - 1) < 0.05
+
+
+def test_make_rows_is_one_table_for_every_rank_count():
+    """Round 6: bench.py at every N joins ONE table.  synth.make_rows defines it (contig of a global row = a pure function of the row;
+    coordinates from the contig's block streams); a shard is a contig selection of it in global row order -- exactly what
+    distributed.shard_sides cuts out of the full table."""
+    import os, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    from polars_bio_amd import distributed as D
+    n, nc = 400_000, 24
+    (c, s, e), ids = synth.make_rows(n, 42, synth.PROBE_LEN, nc)
+    assert (ids == np.arange(n)).all() and c.dtype == s.dtype == e.dtype == np.int32
+    assert ((e - s) >= synth.PROBE_LEN[0]).all() and ((e - s) <= synth.PROBE_LEN[1]).all() and (s >= 0).all() and (e <= synth.CONTIG_LENGTHS[c]).all()
+    assert (np.diff(c) != 0).mean() > 0.8                                     # contigs interleave: unsorted input
+    frac = np.bincount(c, minlength=nc) / n
+    assert np.abs(frac - synth.CONTIG_LENGTHS / synth.CONTIG_LENGTHS.sum()).max() < 0.01
+    assert (synth.contig_counts(n, 42, nc) == np.bincount(c, minlength=nc)).all()
+    (c2, s2, e2), _ = synth.make_rows(n, 42, synth.PROBE_LEN, nc)
+    assert (c == c2).all() and (s == s2).all() and (e == e2).all()           # deterministic
+    for world in (2, 3, 8):
+        C, S, E = np.full(n, -1, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for r in range(world):
+            (cc, ss, ee), ii = synth.make_rows(n, 42, synth.PROBE_LEN, nc, contigs=[k for k in range(nc) if k % world == r])
+            assert (np.diff(ii) > 0).all() and (C[ii] == -1).all()
+            C[ii], S[ii], E[ii] = cc, ss, ee
+        assert (C == c).all() and (S == s).all() and (E == e).all(), world
+    (cc, ss, ee), ii = synth.make_rows(n, 42, synth.PROBE_LEN, nc, row_range=(100_000, 250_000))
+    assert (ii == np.arange(100_000, 250_000)).all() and (cc == c[ii]).all() and (ss == s[ii]).all() and (ee == e[ii]).all()
+    # bench.gen_shard == shard_sides(bench.gen_workload): same LPT owner, same rows, same order, same global ids
+    scale = 0.004
+    probe, build, nc, op = bench.gen_workload("overlap_100M_5M_24contig", scale)
+    for world in (2, 8):
+        for r in range(world):
+            lp, lp_ids, lb, lb_ids, mode, *_ = bench.gen_shard("overlap_100M_5M_24contig", scale, r, world)
+            (xp, xpi, xb, xbi, xmode) = D.shard_sides(probe, build, nc, r, world)
+            assert mode == xmode == "contig" and (lp_ids == xpi).all() and (lb_ids == xbi).all()
+            assert all((a == b).all() for a, b in zip(lp, xp)) and all((a == b).all() for a, b in zip(lb, xb))
+    p1, b1, nc1, _ = bench.gen_workload("overlap_10M_1M_1contig", 0.01)
+    lp, lp_ids, lb, lb_ids, mode, *_ = bench.gen_shard("overlap_10M_1M_1contig", 0.01, 1, 4)
+    (xp, xpi, xb, xbi, xmode) = D.shard_sides(p1, b1, nc1, 1, 4)
+    assert mode == xmode == "rows" and (lp_ids == xpi).all() and all((a == b).all() for a, b in zip(lp, xp)) and all((a == b).all() for a, b in zip(lb, xb))
+    # same pair density as the formula
+    pairs = int(O.count_overlaps_fast(O.Index(O.Side(*build), nc), O.Side(*probe), True).sum())
+    assert abs(pairs / synth.expected_pairs(len(probe[0]), len(build[0]), nc) - 1) < 0.05

@@ -53,8 +53,11 @@ class _Cols:
         self.ptrs = []
 
 
-def dry_run(workload="overlap_100M_5M_24contig", world=8, scale=1.0, steps=2, chunks=4, check=True, log=lambda *a: None):
-    """-> dict (the JSON line).  Raises AssertionError when a rank's result is wrong."""
+def dry_run(workload="overlap_100M_5M_24contig", world=8, scale=1.0, steps=2, chunks=4, check=True, log=lambda *a: None, expect=None):
+    """-> dict (the JSON line).  Raises AssertionError when a rank's result is wrong.
+    expect (round 6): what the CPU oracle says about the SAME table (bench.gen_workload = the N = 1 input; the shards are cut out of it):
+    {"counts": int64 per probe row, "total": pairs, "checksum": sum of the emitted build rows} for overlap / count_overlaps,
+    {"idx", "dist", "found"} for nearest -- every rank's gathered result is then compared with the oracle, not only with the other ranks."""
     import bench
     from polars_bio_amd import _engine as E
 
@@ -117,6 +120,10 @@ def dry_run(workload="overlap_100M_5M_24contig", world=8, scale=1.0, steps=2, ch
                     eng.d2h(hc, cp)
                     assert int(hc.sum()) == nt, (r, int(hc.sum()), nt)
                     assert (np.bincount(hp, minlength=n_p) == hc).all(), f"rank {r}: pair multiplicities differ from the gathered counts"
+                    if expect is not None:
+                        assert nt == expect["total"], (r, nt, expect["total"])
+                        assert (hc == expect["counts"]).all(), f"rank {r}: gathered counts differ from the oracle's"
+                        assert int(hb.astype(np.int64).sum()) == expect["checksum"], f"rank {r}: build-row checksum differs from the oracle's"
                     res["checksum"] = [int(hp.astype(np.int64).sum()), int(hb.astype(np.int64).sum()),
                                        int((hp.astype(np.uint64) * np.uint64(2654435761) ^ hb.astype(np.uint64)).sum(dtype=np.uint64))]
                     del hp, hb, hc
@@ -142,6 +149,8 @@ def dry_run(workload="overlap_100M_5M_24contig", world=8, scale=1.0, steps=2, ch
                     hl = np.empty(len(lp[0]), np.int64)
                     eng.d2h(hl, lc)
                     assert (hc[lp_ids] == hl).all(), f"rank {r}: own rows differ after the exchange"
+                    if expect is not None:
+                        assert (hc == expect["counts"]).all(), f"rank {r}: gathered counts differ from the oracle's"
                     res["checksum"] = [int(hc.sum()), int((hc * (np.arange(n_p, dtype=np.int64) % 1000003)).sum()), int((hc > 0).sum())]
                     res["total"] = int(hc.sum())
                     del hc, hl
@@ -160,6 +169,9 @@ def dry_run(workload="overlap_100M_5M_24contig", world=8, scale=1.0, steps=2, ch
                     hi, hd, hf = np.empty(n_p, np.int32), np.empty(n_p, np.int64), np.empty(n_p, np.int32)
                     eng.d2h(hi, ip); eng.d2h(hd, dp); eng.d2h(hf, fp)
                     assert ((hi >= 0) == (hf == 1)).all() and ((hd >= 0) == (hf == 1)).all()
+                    if expect is not None:
+                        assert (hf == expect["found"].ravel()).all() and (hd == expect["dist"].ravel()).all() and (hi == expect["idx"].ravel()).all(), \
+                            f"rank {r}: gathered nearest rows differ from the oracle's"
                     res["checksum"] = [int(hi.astype(np.int64).sum()), int(hd.sum()), int(hf.sum())]
                     res["total"] = int(hf.sum())
                     del hi, hd, hf
@@ -195,12 +207,32 @@ def dry_run(workload="overlap_100M_5M_24contig", world=8, scale=1.0, steps=2, ch
         "workload": workload, "scale": scale, "world": world, "op": op, "chunks": chunks if op == "overlap" else None, "steps": steps,
         "ms_per_step_oversubscribed": round(ms, 3), "units": units,
         "shards": [{k: out[r][k] for k in ("rank", "mode", "probe_rows", "build_rows")} for r in sorted(out)],
-        "checks": ("every rank holds the identical result (3 checksums); " +
+        "oracle_checked": expect is not None,
+        "checks": (("every rank's gathered result == the CPU oracle on the N = 1 table; " if expect is not None else "") +
+                   "every rank holds the identical result (3 checksums); " +
                    ("pair multiplicities per probe row == the gathered count_overlaps column; capacity regrow exercised (rank 0 short: all ranks report the need)" if op == "overlap" else
                     "own rows equal the no-exchange kernel's" if op == "count_overlaps" else "found <=> row >= 0 <=> distance >= 0")) if check else "none",
         "wall_s": round(time.perf_counter() - t_all, 1),
     }
     return line
+
+
+def oracle_expectation(workload, scale=1.0):
+    """The CPU oracle on the workload's ONE table (bench.gen_workload)."""
+    import bench
+    from oracle import oracle as O
+    probe, build, nc, op = bench.gen_workload(workload, scale)
+    cores = os.cpu_count() or 1
+    ix = O.Index(O.Side(*build), nc)
+    ps = O.Side(*probe)
+    if op == "nearest":
+        ei, ed, en = O.nearest_fast(ix, ps, True, 1, True, threads=cores)
+        return {"idx": ei, "dist": ed, "found": en}
+    exp = {"counts": O.count_overlaps_fast(ix, ps, True, threads=cores)}
+    if op == "overlap":
+        exp["total"], exp["checksum"] = O.overlap_baseline(ix, ps, True, cores)
+        assert exp["total"] == int(exp["counts"].sum())
+    return exp
 
 
 def main():
@@ -211,8 +243,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--chunks", type=int, default=4)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--oracle", action="store_true", help="also compare every rank's gathered result with the CPU oracle on the N = 1 table")
     a = ap.parse_args()
-    line = dry_run(a.workload, a.world, a.scale, a.steps, a.chunks, not a.no_check)
+    line = dry_run(a.workload, a.world, a.scale, a.steps, a.chunks, not a.no_check, expect=oracle_expectation(a.workload, a.scale) if a.oracle else None)
     print(json.dumps(line))
 
 
