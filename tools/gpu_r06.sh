@@ -61,6 +61,9 @@ run_stage() {
       done;
       python tools/pmc_summary.py $dirs > $o.summary.json 2> $o.summary.err; tail -3 $o.summary.err;
       python -c "import json,sys; d=json.load(open('$o.summary.json')); [print(k[:64], {n: round(v[n]['sum']/max(v[n]['rows'],1)) for n in v}) for k,v in d.items() if any(t in k for t in ('count_overlaps','nearest_k1','k_cs_join','k_cs_scatter','k_cs_hist','k_unpermute','k_part_scatter','k_overlap_fused'))]" ;;
+    rccl) echo "== real RCCL on one rank (IVJ_COMM_NO_SHORTCUT)"; timeout 700 python -m pytest tests/test_comm.py -q -x -k "real_rccl" 2>&1 | tee $o.log | tail -15 ;;
+    comm) echo "== tests/test_comm.py"; timeout 1200 python -m pytest tests/test_comm.py -q -x --durations=5 2>&1 | tee $o.log | tail -15 ;;
+    dense) echo "== dense variant at full size vs the oracle"; timeout 1800 python -m pytest tests/test_full_size.py -q -x -k "dense_variant" --durations=3 2>&1 | tee $o.log | tail -15 ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     densehunt) echo "== dense variant: a step above 25 ms on this box gets a --hip-trace --kernel-trace run (VERDICT r4 item 7)";
       timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --step-times 8 $Q 2>$o.err | tee $o.json | cut -c1-200; grep "per-step wall\|timed region" $o.err;
@@ -88,7 +91,7 @@ if f:
 PY
       fi ;;
     dry8*) echo "== 8 ranks on one GPU (in-process transport), workload ${WL:-overlap_100M_5M_24contig}, scale ${SCALE:-1.0}";
-      timeout 1500 python tools/dryrun_ranks.py --world ${WORLD:-8} --workload ${WL:-overlap_100M_5M_24contig} --scale ${SCALE:-1.0} --steps 2 2>$o.err | tee $o.json | cut -c1-1200; tail -3 $o.err ;;
+      timeout 1500 python tools/dryrun_ranks.py --world ${WORLD:-8} --workload ${WL:-overlap_100M_5M_24contig} --scale ${SCALE:-1.0} --steps 2 ${DRYARGS:-} 2>$o.err | tee $o.json | cut -c1-1200; tail -3 $o.err ;;
     c4fd) timeout 900 $B --workload nearest_50M_2M_24contig --force-dist --steps 5 --warmup 2 $Q 2>$o.err | tee $o.json | cut -c1-900; tail -2 $o.err ;;
     c5fd) timeout 900 $B --workload count_200M_200k_24contig --force-dist --steps 5 --warmup 2 $Q 2>$o.err | tee $o.json | cut -c1-900; tail -2 $o.err ;;
     c3g2) echo "== bench config3 --gpus 2 on this box"; timeout 1200 $B --gpus 2 --steps 3 --warmup 1 $Q 2>$o.err | tee $o.json | cut -c1-900; tail -2 $o.err ;;
