@@ -40,7 +40,8 @@ static_assert((long long)SL_MAX_BUCKETS * SL_MAX_ROWS <= CS_POS_BIAS, "an index 
 constexpr int CS_BIN_STRIDE_PAD = 2;                    // bins per slice in global memory: 2 R + 2 (u16)
 
 constexpr int CS_META_FMT = 8;                          // meta[8]: record format of the call (k_cs_regions): 0 = 12-byte records, LB > 0 = 8-byte records
-constexpr unsigned long long CS_STATE_REC8 = 8ull;     // state word, bit 8: a probe did not fit the 8-byte record form
+constexpr unsigned long long CS_STATE_REC8 = 8ull;     // state word, value 8 (bit 3): a probe did not fit the 8-byte record form
+constexpr int CS_REC8_GIVE_UP = 3;                      // overflows in a row after which a context stops offering the 8-byte form (host_cslice.hip.h)
 __host__ __device__ __forceinline__ int cs_bits_for(uint32_t v) { int b = 0; while (b < 32 && (v >> b) != 0) ++b; return b == 0 ? 1 : b; }
 
 typedef int cs_rec __attribute__((ext_vector_type(3), aligned(4)));      // one probe record {start, end, row}: 12 bytes, 4-byte aligned

@@ -147,8 +147,9 @@ int as_check_batch(const ArrowSchema& schema, const std::vector<AsType>& types, 
 // The stream is CONSUMED whatever happens: on success and on every failure the producer's release callback has run when this
 // returns (a caller that gets an error back owns nothing any more -- the contract of the *_arrow_stream entry points).
 int as_drain(ArrowArrayStream* in, const char* what, AsTable& t) {
-    if (!in || !in->get_schema || !in->get_next) return fail(IVJ_EINVAL, std::string(what) + ": not an ArrowArrayStream");
-    struct Consume { ArrowArrayStream* s; ~Consume() { if (s->release) s->release(s); } } consume{in};
+    if (!in) return fail(IVJ_EINVAL, std::string(what) + ": not an ArrowArrayStream");
+    struct Consume { ArrowArrayStream* s; ~Consume() { if (s->release) s->release(s); } } consume{in};      // (installed before ANY early return)
+    if (!in->get_schema || !in->get_next) return fail(IVJ_EINVAL, std::string(what) + ": not an ArrowArrayStream");
     auto err = [&](const char* step) {
         const char* m = in->get_last_error ? in->get_last_error(in) : nullptr;
         return fail(IVJ_EINVAL, std::string(what) + ": " + step + " failed" + (m ? std::string(": ") + m : std::string()));
@@ -877,6 +878,7 @@ struct AsLazy {
     std::vector<int32_t> cur_s, cur_e;
     int64_t cur_off = 0;
     bool in_done = false, finished = false;
+    int sticky_errno = 0;                 // first get_next failure, reported again by every later call
     double t_pull = 0, t_turn = 0, t_asm = 0;            // IVJ_DEBUG_TIMES: seconds in df1 pull + key encoding / session turns / batch assembly
     std::string last_error;
     std::mutex mu;
@@ -984,7 +986,9 @@ int lazy_assemble(AsLazy& L, const AsLazy::Pending& P, const ivj_stream_result& 
 int lazy_get_next(ArrowArrayStream* s, ArrowArray* out) {
     auto* L = static_cast<AsLazy*>(s->private_data);
     std::lock_guard<std::mutex> lk(L->mu);
-    auto bad = [&](int rc) { L->last_error = g_err; L->finished = true; return rc == IVJ_ENOMEM ? ENOMEM : (rc == IVJ_EINVAL ? EINVAL : EIO); };
+    // a failure is STICKY: every later get_next reports the same errno (a consumer that retries must not read a truncated result as complete)
+    auto bad = [&](int rc) { L->last_error = g_err; L->finished = true; L->sticky_errno = rc == IVJ_ENOMEM ? ENOMEM : (rc == IVJ_EINVAL ? EINVAL : EIO); return L->sticky_errno; };
+    if (L->sticky_errno) return L->sticky_errno;
     try {
         for (;;) {
             if (!L->ready.empty()) { *out = L->ready.front(); L->ready.pop_front(); return 0; }
@@ -1027,8 +1031,8 @@ int lazy_get_next(ArrowArrayStream* s, ArrowArray* out) {
                 if (rc != IVJ_OK) return bad(rc);
             }
         }
-    } catch (const std::bad_alloc&) { L->last_error = "out of memory"; L->finished = true; return ENOMEM; }
-    catch (const std::exception& e) { L->last_error = e.what(); L->finished = true; return EINVAL; }
+    } catch (const std::bad_alloc&) { L->last_error = "out of memory"; L->finished = true; L->sticky_errno = ENOMEM; return ENOMEM; }
+    catch (const std::exception& e) { L->last_error = e.what(); L->finished = true; L->sticky_errno = EINVAL; return EINVAL; }
 }
 int lazy_get_schema(ArrowArrayStream* s, ArrowSchema* out) {
     auto* L = static_cast<AsLazy*>(s->private_data);

@@ -65,7 +65,13 @@ struct XferSlots {                                         // owned by the conte
     }
 };
 
+inline std::atomic<int> g_live_contexts{0};     // contexts alive in this process (the hot-path waits yield when there are several)
+
 struct ivj_ctx {
+    ivj_ctx() { g_live_contexts.fetch_add(1, std::memory_order_relaxed); }
+    ~ivj_ctx() { g_live_contexts.fetch_sub(1, std::memory_order_relaxed); }
+    ivj_ctx(const ivj_ctx&) = delete;
+    ivj_ctx& operator=(const ivj_ctx&) = delete;
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -117,6 +123,8 @@ struct ivj_ctx {
     int env_ix_merge = -1;             // IVJ_IX_MERGE: upper bound of the balanced build's merge shift (0 = always 2048 buckets); -1: up to V3_MAX_MERGE
     int env_ix_stage = -1;             // IVJ_IX_STAGE: the balanced build's local kernel with (1) / without (0) the rows staged in LDS; -1 by bucket size
     int env_ix_v3 = -1;                // IVJ_IX_V3: -1 by size, 0 never (the round-2 LSD sort), 1 wherever it applies
+    int ix3_fallback_streak = 0;       // consecutive balanced builds handed back; from 2 on the balanced build is skipped except every 16th time
+    unsigned ix3_builds_since_fallback = 0;
     int64_t ix3_fallbacks = 0;         // builds the balanced pass handed back to the LSD sort (a bucket above V3_CAP rows, keys beyond 32 bits)
     // slice path (host_slice.hip.h): bucket-ordered probe records, histogram, chunk table, tile totals
     // staging of the last closed streaming session, kept for the next one (pinned allocations cost ~70 ms per GB)
@@ -153,6 +161,9 @@ struct ivj_ctx {
     int cs_env_fuse_sample = 1;        // IVJ_CS_FUSE_SAMPLE=0: the slice bins and the probe sample of a fresh index as two launches (A/B runs)
     int cs_env_rec8 = 1;               // IVJ_CS_REC8=0: always 12-byte probe records (A/B runs)
     bool cs_force_rec12 = false;       // set while a call whose 8-byte records overflowed is redone
+    int cs_rec8_streak = 0;            // consecutive calls whose 8-byte records overflowed (cleared by a call that kept them)
+    unsigned cs_rec8_skipped = 0;      // calls that did not try the 8-byte form because of the streak
+    bool cs_rec8_tried = false;        // the call in flight offered the 8-byte form
     int64_t cs_rec8_overflows = 0;     // calls redone with 12-byte records
     int cs_env_nocache = 0;            // IVJ_CS_NOCACHE=1: the FILL pass matches again instead of reading COUNT's words (A/B runs)
     // timing
@@ -174,28 +185,38 @@ struct ivj_ctx {
 // microseconds between the kernel's end and the host's next launch -- per call, with the GPU idle.  The host polls the stream / event
 // for up to IVJ_SPIN_US microseconds first (default 4000: a call of the benchmark configurations ends within it
 // -- a call still running after that blocks in the runtime as before).  Same completion semantics as the runtime's wait.
-inline hipError_t wait_stream(ivj_ctx* ctx, hipStream_t s) {
-    if (ctx->env_spin_us > 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0;; ++i) {
-            const hipError_t e = hipStreamQuery(s);
-            if (e != hipErrorNotReady) return e;
-            if ((i & 15) == 15 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > ctx->env_spin_us) break;
-        }
-        (void)hipGetLastError();                                               // (hipErrorNotReady is sticky in hipGetLastError)
+// Round 6: the poll loop executes `pause` between queries, and in a process that holds SEVERAL contexts (MultiEngine's per-device host
+// threads, the 8-rank dry run) it yields the core every few polls and polls for at most IVJ_SPIN_US / 8: N spinning waiters under a
+// cgroup CPU quota otherwise starve the producer threads (host_copy_parallel, Arrow assembly) they are waiting for.
+inline void spin_relax(int i, bool crowded) {
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+    __builtin_ia32_pause();
+#endif
+    if (crowded && (i & 7) == 7) std::this_thread::yield();
+}
+template <typename Query>
+inline bool spin_wait(ivj_ctx* ctx, Query&& q, hipError_t* out) {
+    if (ctx->env_spin_us <= 0) return false;
+    const bool crowded = g_live_contexts.load(std::memory_order_relaxed) > 1;
+    const long long budget = crowded ? std::max(ctx->env_spin_us / 8, 1) : ctx->env_spin_us;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0;; ++i) {
+        const hipError_t e = q();
+        if (e != hipErrorNotReady) { *out = e; return true; }
+        if ((i & 15) == 15 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > budget) break;
+        spin_relax(i, crowded);
     }
+    (void)hipGetLastError();                                                   // (hipErrorNotReady is sticky in hipGetLastError)
+    return false;
+}
+inline hipError_t wait_stream(ivj_ctx* ctx, hipStream_t s) {
+    hipError_t e;
+    if (spin_wait(ctx, [&] { return hipStreamQuery(s); }, &e)) return e;
     return hipStreamSynchronize(s);
 }
 inline hipError_t wait_event(ivj_ctx* ctx, hipEvent_t ev) {
-    if (ctx->env_spin_us > 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0;; ++i) {
-            const hipError_t e = hipEventQuery(ev);
-            if (e != hipErrorNotReady) return e;
-            if ((i & 15) == 15 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > ctx->env_spin_us) break;
-        }
-        (void)hipGetLastError();
-    }
+    hipError_t e;
+    if (spin_wait(ctx, [&] { return hipEventQuery(ev); }, &e)) return e;
     return hipEventSynchronize(ev);
 }
 

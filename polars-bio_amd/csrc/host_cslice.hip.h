@@ -242,7 +242,12 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
             t_end(ctx);
         }
         // the record format of the call (8-byte records where the sample says they fit) is decided in this kernel, on the device
-        const int allow8 = (ctx->cs_env_rec8 != 0 && !ctx->cs_force_rec12) ? 1 : 0;
+        // (a context whose calls keep overflowing the 8-byte form -- a probe side with inverted or very long rows between the sampled
+        // groups -- stops trying it after CS_REC8_GIVE_UP redos in a row: each redo costs a whole partition + join; a call that would have
+        // fitted resets the count only by being tried, so the form is offered again every 64th call)
+        const bool sticky12 = ctx->cs_rec8_streak >= CS_REC8_GIVE_UP && (++ctx->cs_rec8_skipped & 63) != 0;
+        const int allow8 = (ctx->cs_env_rec8 != 0 && !ctx->cs_force_rec12 && !sticky12) ? 1 : 0;
+        ctx->cs_rec8_tried = allow8 != 0;
         const bool far_hw = fuse_sample && ix->cs_far_pending && ctx->cs_far_owner == ix && ctx->cs_far_hw_seq != 0;
         LAUNCH(ctx, "cs_regions", k_cs_regions, 1, CS_THREADS, (const uint32_t*)ctx->sl_gh, g.nb, cs_region_slack(ctx, g, n), allow8, ctx->sl_rstart, ctx->sl_rcur, ctx->sl_meta,
                (const int32_t*)(ix->flags + 1), far_hw ? ctx->hw_dev : (uint32_t*)nullptr, ctx->cs_far_hw_seq);
@@ -344,7 +349,7 @@ struct CsExactScope {
 // A probe that did not fit the 8-byte record form the sample had chosen (state bit 8): the call is redone with 12-byte records.
 struct CsRec12Scope {
     ivj_ctx* ctx;
-    explicit CsRec12Scope(ivj_ctx* c) : ctx(c) { ctx->cs_force_rec12 = true; ++ctx->cs_rec8_overflows; }
+    explicit CsRec12Scope(ivj_ctx* c) : ctx(c) { ctx->cs_force_rec12 = true; ++ctx->cs_rec8_overflows; ++ctx->cs_rec8_streak; }
     ~CsRec12Scope() { ctx->cs_force_rec12 = false; }
 };
 
@@ -388,6 +393,7 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
         CsRec12Scope redo(ctx);
         return cs_overlap_fused(ctx, ix, probe, opts, out_p, out_b, capacity, n_pairs);
     }
+    if (ctx->cs_rec8_tried && !ctx->cs_force_rec12) ctx->cs_rec8_streak = 0;     // the 8-byte form was offered and no probe overflowed it
     *n_pairs = ctx->h_total[0];
     if (ctx->h_total[1] & 2)          // a bounded wait of the fused tile protocol ran out: the pairs cannot be trusted
         return fail(IVJ_EHIP, "tile protocol timeout in the fused slice join: a workgroup waited for a tile base that never came; the result was discarded");
@@ -423,6 +429,7 @@ int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
         CsRec12Scope redo(ctx);
         return cs_overlap_count(ctx, ix, probe, opts, n_pairs);
     }
+    if (ctx->cs_rec8_tried && !ctx->cs_force_rec12) ctx->cs_rec8_streak = 0;
     ctx->sl_plan_valid = true;
     ctx->sl_plan = P;
     *n_pairs = *ctx->h_total;

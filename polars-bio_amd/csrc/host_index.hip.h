@@ -267,6 +267,9 @@ int index_sort_v2(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
 bool ix3_wanted(const ivj_ctx* ctx, int64_t n, int nc) {
     if (nc + 1 > V3_MAX_KEYS || n <= 0 || n > (int64_t)V3_CAP * V3_BUCKETS) return false;
     if (ctx->env_ix_v3 >= 0) return ctx->env_ix_v3 != 0;
+    // a context whose last balanced builds were handed back (clustered build sides: every hand-over throws a scatter pass away) skips the
+    // balanced build for a while: after 2 hand-overs in a row only every 16th build tries it again
+    if (ctx->ix3_fallback_streak >= 2 && (ctx->ix3_builds_since_fallback & 15) != 15) return false;
     return n >= (128ll << 10) && n <= (7ll << 20);
 }
 struct V3Plan { int64_t chunk, hist_len, hs_tiles; int nchunks; size_t z_meta, z_st, z_hs, z_tick, zero_bytes; };
@@ -344,7 +347,8 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
     }
     const uint32_t max_bucket = hv[1] & 0xffffffu;
     const int ms = (int)(hv[1] >> 24);
-    if (hv[0] != 0u || max_bucket > (uint32_t)V3_CAP) { ++ctx->ix3_fallbacks; return IVJ_OK; }
+    if (hv[0] != 0u || max_bucket > (uint32_t)V3_CAP) { ++ctx->ix3_fallbacks; ++ctx->ix3_fallback_streak; ctx->ix3_builds_since_fallback = 0; return IVJ_OK; }
+    ctx->ix3_fallback_streak = 0;
     // the local kernel's LDS follows the LARGEST bucket (known now): rows staged in LDS while two workgroups still share a CU
     // (<= 2048 rows), beyond that the rows are read again from their L2-resident records (IVJ_IX_STAGE = 0 / 1 forces either form)
     const int cap = (int)std::max<uint32_t>(1024u, (max_bucket + 1023u) / 1024u * 1024u);
@@ -458,7 +462,9 @@ int index_build(ivj_ctx* ctx, const ivj_side* build, const ivj_opts* opts, int w
         ix->has_tables = !(with_end_order & 2);
         int r = IVJ_OK;
         bool sorted = false;
-        if (ix3_wanted(ctx, n, opts->n_contigs)) { r = index_sort_v3(ctx, ix, build, opts, &sorted); if (r != IVJ_OK) return cleanup(r); }
+        const bool try_v3 = ix3_wanted(ctx, n, opts->n_contigs);
+        ++ctx->ix3_builds_since_fallback;
+        if (try_v3) { r = index_sort_v3(ctx, ix, build, opts, &sorted); if (r != IVJ_OK) return cleanup(r); }
         if (!sorted) r = index_sort_v2(ctx, ix, build, opts);
         if (r != IVJ_OK) return cleanup(r);
         // 7. the flat overlap path's arrays (lot / tab2 / rec4) are filled on first use: build_flat

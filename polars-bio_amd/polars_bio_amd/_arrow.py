@@ -483,5 +483,14 @@ def from_arrow(t: pa.Table, output_type: str, zero_based: bool):
             df = df.lazy()
         return set_coordinate_system(df, zero_based)
     if output_type == "datafusion.DataFrame":
-        raise ImportError("datafusion is not part of this engine; use 'pyarrow.Table', 'pandas.DataFrame' or polars")
+        # the reference hands the joined DataFusion frame itself to callers that ask for it (range_op_helpers.py:362-370); here the
+        # executor is not DataFusion, so the Arrow result is registered with a SessionContext -- same rows, same schema
+        try:
+            import datafusion
+        except ImportError as e:
+            raise ImportError("output_type='datafusion.DataFrame' needs the `datafusion` package (the join itself does not); "
+                              "use 'pyarrow.Table', 'pandas.DataFrame' or polars") from e
+        t = set_coordinate_system(t, zero_based)
+        ctx = datafusion.SessionContext()
+        return ctx.from_arrow(t) if hasattr(ctx, "from_arrow") else ctx.from_arrow_table(t)
     raise ValueError("Only polars.LazyFrame, polars.DataFrame and pandas.DataFrame are supported")

@@ -210,3 +210,28 @@ def test_host_scatter_is_the_mirror_of_take():
     with pytest.raises(E.EngineError, match="outside the destination"):
         H.scatter(out, np.array([5, m], np.int32), np.array([1, 2]))
     assert (out == before).all()
+
+
+def test_datafusion_dataframe_output_registers_the_arrow_result(monkeypatch):
+    """output_type='datafusion.DataFrame' (reference: range_op_helpers.py:362-370): the Arrow result goes through
+    SessionContext().from_arrow when `datafusion` imports, and is an ImportError naming the package when it does not."""
+    import sys
+    import types
+    import pyarrow as pa
+    import pytest
+    from polars_bio_amd import _arrow
+    t = pa.table({"contig_1": ["chr1"], "pos_start_1": [1], "pos_end_1": [5]})
+    monkeypatch.setitem(sys.modules, "datafusion", None)                       # import datafusion -> ImportError
+    with pytest.raises(ImportError, match="datafusion"):
+        _arrow.from_arrow(t, "datafusion.DataFrame", True)
+    seen = {}
+
+    class _Ctx:
+        def from_arrow(self, table):
+            seen["table"] = table
+            return ("df", table.num_rows)
+
+    monkeypatch.setitem(sys.modules, "datafusion", types.SimpleNamespace(SessionContext=_Ctx))
+    assert _arrow.from_arrow(t, "datafusion.DataFrame", True) == ("df", 1)
+    assert seen["table"].column_names == t.column_names
+    assert seen["table"].schema.metadata                                       # the coordinate-system metadata rides along
