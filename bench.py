@@ -91,6 +91,10 @@ def parse():
     ap.add_argument("--chunks", type=int, default=4, help="N>1, lib exchange: probe chunks per rank (join of chunk i overlaps the exchange of chunk i-1)")
     ap.add_argument("--canary-timeout", type=float, default=180.0,
                     help="N>1, lib exchange: seconds the 4-KB canary exchange may take before the run falls back to torch.distributed")
+    ap.add_argument("--probe-order", choices=("given", "sorted"), default="given",
+                    help="diagnostics only (the line is marked): 'sorted' = the probe side sorted by (contig, start) before the upload -- with "
+                         "IVJ_SLICE_STABLE=1 adjacent lanes of the slice join then read adjacent LDS rows: the upper bound of what ordering a "
+                         "wavefront's probes by position could buy (VERDICT r5 item 1a)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-process code path (RCCL init, sharding, all-gatherv) even with one rank")
     return ap.parse_args()
@@ -440,6 +444,9 @@ def main():
     else:
         probe, build, nc, op = gen_workload(args.workload, args.scale)
         n_p_total, n_b_total = len(probe[0]), len(build[0])
+        if args.probe_order == "sorted":
+            o = np.lexsort((probe[1], probe[0]))
+            probe = tuple(np.ascontiguousarray(c[o]) for c in probe)
         if multi:
             lp, lp_ids, lb, lb_ids, mode = D.shard_sides(probe, build, nc, rank, n_gpus)
         else:
@@ -788,7 +795,8 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "int32",
-            "data": "synthetic" if args.scale == 1.0 else f"synthetic (scaled x{args.scale}: INVALID as a headline number)",
+            "data": ("synthetic" if args.scale == 1.0 else f"synthetic (scaled x{args.scale}: INVALID as a headline number)") +
+                    ("" if args.probe_order == "given" else " (probe side SORTED by position: a diagnostic, INVALID as a headline number)"),
             "config": {"workload": args.workload, "probe_rows": n_p_total, "build_rows": n_b_total, "contigs": nc,
                        "filter_op": "Strict", "units_per_step": total_units,
                        "parallelism": ("single GPU" if not multi else
