@@ -19,6 +19,9 @@ run_stage() {
     k=*) echo "== pytest -k ${stage#k=}"; timeout 1500 python -m pytest tests -m gpu -q -x -k "${stage#k=}" 2>&1 | tee $o.log | tail -25 ;;
     c3) echo "== bench config3 (default run: PMC passes, CPU baseline, extras)"; timeout 1500 $B --steps 10 --warmup 2 2>$o.err | tee $o.json | cut -c1-1500; tail -5 $o.err ;;
     c3q) timeout 900 $B --steps 10 --warmup 2 $Q 2>$o.err | tee $o.json | cut -c1-400; grep -A16 "per-kernel" $o.err ;;
+    c3sorted) echo "== config 3 with the probe side SORTED by position (diagnostic: upper bound of ordering a wavefront's probes, VERDICT r5 item 1a)";
+      timeout 900 $B --steps 10 --warmup 2 $Q --probe-order sorted 2>$o.err | tee $o.json | cut -c1-400; grep -A16 "per-kernel" $o.err ;;
+    calib) bash tools/write_calib.sh gpurun_out/${tag}_write_calibration.txt 2>&1 | tail -30 ;;
     c3old) IVJ_CS=0 timeout 900 $B --steps 10 --warmup 2 $Q 2>$o.err | tee $o.json | cut -c1-400; grep -A16 "per-kernel" $o.err ;;
     c3two) timeout 900 $B --steps 10 --warmup 2 $Q --two-pass 2>$o.err | tee $o.json | cut -c1-400; grep -A16 "per-kernel" $o.err ;;
     c1) timeout 600 $B --workload overlap_1k_1k_1contig --steps 20 --warmup 3 --no-pmc --kernel-table 2>$o.err | tee $o.json | cut -c1-600; grep -A12 "per-kernel" $o.err ;;
