@@ -131,11 +131,20 @@ __global__ void k_nearest_lines(const uint32_t* __restrict__ bins, const int4* _
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t slot = t >> 2;
     const int w = (int)(t & 3);
+    // last contig whose table offset tb = cmeta[2c+1].y is <= slot: ONE bound search per workgroup (its first slot), then a step forward
+    // where a contig's table ends inside the workgroup's 64 slots (round 6; the per-thread search was a chain of ~ 5 dependent loads in
+    // front of the three dependent levels the line itself needs)
+    __shared__ int s_c;
+    if (threadIdx.x == 0) {
+        const int64_t first = ((int64_t)blockIdx.x * blockDim.x) >> 2;
+        int lo = 0, hi = n_contigs;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= first) lo = m + 1; else hi = m; }
+        s_c = lo - 1;
+    }
+    __syncthreads();
     if (slot >= slots) return;
-    // last contig whose table offset tb = cmeta[2c+1].y is <= slot
-    int lo = 0, hi = n_contigs;
-    while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)cmeta[2 * m + 1].y <= slot) lo = m + 1; else hi = m; }
-    const int c = lo - 1;
+    int c = s_c;
+    while (c + 1 < n_contigs && (int64_t)cmeta[2 * (c + 1) + 1].y <= slot) ++c;
     int4 v = make_int4(0, 0, 0, 0);
     if (c >= 0) {
         const int4 m0 = cmeta[2 * c];
