@@ -507,6 +507,206 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
     }
 }
 
+// ---- the sampled scatter of 8-byte records on 12 288-probe tiles (round 6) --------------------------------------------------------------
+// What the scatter pays for is the SHAPE of its record stores (tools/micro/write_calib.hip, profiles/r06/write_calibration.txt: runs of
+// 8 records at a random 8-byte offset cost 1.36 x their bytes in 64 / 32-byte write requests, runs of 12 records 1.25 x, of 16 1.18 x) and
+// its per-tile fixed work (four barriers, a scan over the ~ 1000 buckets): 4096-probe tiles 1.12 ms, 8192-probe tiles 0.70 ms for config 3
+// (profiles/r06/ab_scatter_tile_4096.json).  This form takes 12 288 probes per tile -- runs of ~ 12 records / 93 bytes at 1040 buckets:
+//   * LDS: two 4-byte staging planes (packed word, row) + the 2-byte bucket plane = 10 bytes per probe (the 8192-probe form carries a third
+//     plane for the 12-byte records' ends) and no copy of the region starts (read from global memory, once per bucket and tile);
+//   * registers: the tile's columns are consumed out of the registers they were loaded into, {bucket, rank} share one word, the packed
+//     word is built while the bucket is looked up, the row is recomputed at placement time (or loaded there, when the side brings row ids),
+//     and the NEXT tile's columns are requested only once this tile's are dead -- 12 probes per thread inside the 128-register budget.
+// Same protocol as k_cs_scatter<.., SAMPLED = true, REC8 = true>: the host queues it INSTEAD of that kernel where cs_part12_lds fits the
+// LDS (the plan's part_items = 12), next to the 12-byte form that runs when the device-side format word says so.
+struct CsPart12Lds { int cm, cell, spl, lstart, delta, cnt, rs, rr, d, wsum, total; };
+__host__ __device__ inline CsPart12Lds cs_part12_lds(int nb, int ncells, int n_contigs) {
+    constexpr int tile = CS_THREADS * 12;
+    CsPart12Lds L;
+    int o = 0;
+    L.cm = o; o += 16 * ((n_contigs + 3) & ~3);
+    L.spl = o; o += 8 * nb;
+    L.cell = o; o += 4 * ncells;
+    L.rs = (o + 15) & ~15; o = L.rs + 4 * tile;
+    L.rr = o; o += 4 * tile;
+    L.lstart = o; o += 4 * (nb + 2);
+    L.delta = o; o += 4 * (nb + 2);
+    L.cnt = o; o += 4 * (nb + 2);
+    L.d = (o + 3) & ~3; o = L.d + 2 * tile;
+    L.wsum = (o + 15) & ~15; o = L.wsum + 4 * 2 * CS_WAVES;
+    L.total = o;
+    return L;
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
+                                                             const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
+                                                             int chunk, int nchunks, bool vec_ok, const uint32_t* __restrict__ rstart,
+                                                             uint32_t* __restrict__ rcur, unsigned long long* __restrict__ state,
+                                                             const int32_t* __restrict__ meta, int32_t* __restrict__ out, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    constexpr int PITEMS = 12, TILE = CS_THREADS * PITEMS;
+    const CsPart12Lds L = cs_part12_lds(g.nb, g.ncells, g.n_contigs);
+    unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(cs_lds + L.spl);
+    int4* l_cm = reinterpret_cast<int4*>(cs_lds + L.cm);
+    uint32_t* l_cell = reinterpret_cast<uint32_t*>(cs_lds + L.cell);
+    int32_t* l_rs = reinterpret_cast<int32_t*>(cs_lds + L.rs);
+    int32_t* l_rr = reinterpret_cast<int32_t*>(cs_lds + L.rr);
+    uint32_t* lstart = reinterpret_cast<uint32_t*>(cs_lds + L.lstart);
+    uint32_t* delta = reinterpret_cast<uint32_t*>(cs_lds + L.delta);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(cs_lds + L.cnt);
+    unsigned short* l_d = reinterpret_cast<unsigned short*>(cs_lds + L.d);
+    int* wsum = reinterpret_cast<int*>(cs_lds + L.wsum);
+    const int tid = threadIdx.x;
+    const int nbk = g.nb + 1;
+    const int lb = meta[CS_META_FMT];                                           // uniform: 0 = this call's records are the 12-byte ones (the other launch)
+    if (lb == 0) return;
+    cs_load_tab(tab, g, l_spl, l_cm, l_cell, CS_THREADS);
+    for (int k = tid; k < nbk + 1; k += CS_THREADS) cnt[k] = 0;
+    __syncthreads();
+    const int64_t cbase = (int64_t)blockIdx.x * chunk;
+    const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
+    // thread t holds the probes t * 4 .. t * 4 + 3 of every 4096-probe third of the tile (16-byte column loads).  The addresses are a
+    // UNIFORM tile pointer + a 32-bit lane offset (scalar base + vector offset in the instruction): nine 64-bit per-lane addresses kept
+    // across the tile loop were what spilled in the first version of this kernel
+    int32_t nc[PITEMS], ns[PITEMS], ne[PITEMS];
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    auto load4 = [&](const int32_t* __restrict__ col /* uniform */, uint32_t e0, uint32_t rem, int32_t fill, int32_t* dst) {
+        if (vec_ok && e0 + 4u <= rem) {
+            const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(col + e0));
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[u] = (e0 + (uint32_t)u < rem) ? __builtin_nontemporal_load(col + e0 + u) : fill;
+        }
+    };
+    auto load_tile = [&](int64_t tbase) {
+        const uint32_t rem = (uint32_t)((cend - tbase) < (int64_t)TILE ? (cend - tbase) : (int64_t)TILE);
+        const int32_t *bc = pc + tbase, *bs = ps + tbase, *be = pe + tbase;
+#pragma unroll
+        for (int h = 0; h < PITEMS / 4; ++h) {
+            const uint32_t e0 = (uint32_t)(h * (CS_THREADS * 4) + tid * 4);
+            load4(bc, e0, rem, -1, nc + 4 * h);
+            load4(bs, e0, rem, 0, ns + 4 * h);
+            load4(be, e0, rem, 0, ne + 4 * h);
+        }
+    };
+    load_tile(cbase);
+    int tix = 0;
+    for (int64_t tbase = cbase; tbase < cend; tbase += TILE, ++tix) {
+        const int tile_n = (int)((cend - tbase) < (int64_t)TILE ? (cend - tbase) : (int64_t)TILE);
+        uint32_t w0[PITEMS], dr[PITEMS];                                        // packed record word; bucket | rank << 11
+        static_assert(SL_MAX_BUCKETS + 1 <= (1 << 11) && TILE <= (1 << 21), "bucket and rank share one word");
+#pragma unroll
+        for (int j = 0; j < PITEMS; ++j) {
+            const bool valid = (j / 4) * (CS_THREADS * 4) + tid * 4 + (j & 3) < tile_n;
+            const uint32_t d = !valid ? 0u : cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, nc[j], ne[j]);
+            const uint32_t rank = valid ? atomicAdd(&cnt[d], 1u) : 0u;
+            uint32_t w = 0u;
+            if (valid && d < (uint32_t)g.nb) {
+                const uint32_t off = (uint32_t)ne[j] - (uint32_t)unflip((uint32_t)l_spl[d]);       // >= 0: the slice's first row starts below the end
+                const uint32_t len = (uint32_t)ne[j] - (uint32_t)ns[j];
+                if (ne[j] < ns[j] || (len >> lb) != 0u || (off >> (32 - lb)) != 0u) atomicOr(state + 1, CS_STATE_REC8);   // (redo with 12-byte records)
+                w = (off << lb) | len;
+            }
+            w0[j] = w; dr[j] = d | (rank << 11);
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);               // (four lookups in flight are enough: twelve interleaved ones cost 14 spilled registers)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tbase + TILE < cend) load_tile(tbase + TILE);                      // this tile's columns are dead: the next tile's travel during the rest of this one
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                                        // (A) bucket counts of the tile complete
+        // (the lane's index is made opaque once per tile: per-lane addresses derived from it -- the region cursors' 64-bit ones, the 3 x 12
+        // LDS addresses of the copy-out -- are otherwise loop invariants the compiler keeps in registers across the tile loop, and spills)
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        constexpr int OWN = (SL_MAX_BUCKETS + 1 + CS_THREADS - 1) / CS_THREADS;
+        int x[OWN];
+        int xs = 0;
+#pragma unroll
+        for (int q = 0; q < OWN; ++q) {
+            const int b = OWN * tv + q;
+            x[q] = 0;
+            if (b < nbk) { x[q] = (int)cnt[b]; cnt[b] = 0; }
+            xs += x[q];
+        }
+        // (B) workgroup exclusive sum with the DPP wavefront scan (no ds_bpermute lane-address registers to keep across the tile loop)
+        int pre;
+        {
+            int* part = wsum + (tix & 1) * CS_WAVES;
+            const int inc = wave_incl_sum_dpp(xs);
+            if ((tv & (kWave - 1)) == kWave - 1) part[tv / kWave] = inc;
+            __syncthreads();
+            int below = 0;
+#pragma unroll
+            for (int k = 0; k < CS_WAVES; k += 4) {
+                const int4 pw = *reinterpret_cast<const int4*>(part + k);
+                const int w = tv / kWave;
+                below += (k < w ? pw.x : 0) + (k + 1 < w ? pw.y : 0) + (k + 2 < w ? pw.z : 0) + (k + 3 < w ? pw.w : 0);
+            }
+            pre = below + (inc - xs);
+        }
+        uint32_t got[OWN];
+#pragma unroll
+        for (int q = 0; q < OWN; ++q) {
+            const int b = OWN * tv + q;
+            got[q] = 0u;
+            if (b < nbk) {
+                lstart[b] = (uint32_t)pre;
+                if (x[q] > 0 && b < g.nb) got[q] = atomicAdd(&rcur[b], (uint32_t)x[q]);       // split-phase: answered while the tile is placed
+            }
+            pre += x[q];
+        }
+        __syncthreads();                                                        // (C)
+#pragma unroll
+        for (int h = 0; h < PITEMS / 4; ++h) {
+            const int e0 = h * (CS_THREADS * 4) + tv * 4;
+            int32_t rw[4];
+            if (row_id) load4(row_id + tbase, (uint32_t)e0, (uint32_t)tile_n, -1, rw);
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rw[u] = (int32_t)(tbase + e0 + u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * h + u;
+                if (e0 + u < tile_n) {
+                    const uint32_t d = dr[j] & 2047u;
+                    const uint32_t pos = lstart[d] + (dr[j] >> 11);
+                    l_rs[pos] = (int32_t)w0[j]; l_rr[pos] = rw[u];
+                    l_d[pos] = (unsigned short)d;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = OWN - 1; q >= 0; --q) {
+            const int b = OWN * tv + q;
+            pre -= x[q];
+            if (b < nbk) {
+                uint32_t at = rstart[b < g.nb ? b : g.nb];                     // region start (an overflowing run lands here, in bounds)
+                if (x[q] > 0 && b < g.nb) {
+                    const uint32_t cap = rstart[b + 1] - at;
+                    if (got[q] + (uint32_t)x[q] <= cap) at += got[q];
+                    else atomicOr(state + 1, 4ull);
+                }
+                delta[b] = at - (uint32_t)pre;
+            }
+        }
+        __syncthreads();                                                        // (D) tile sorted in LDS
+#pragma unroll
+        for (int j = 0; j < PITEMS; ++j) {
+            const int il = j * CS_THREADS + tv;
+            if (il < tile_n && !(ablate & 256) && l_d[il] != (unsigned short)g.nb) {
+                const uint32_t oi = (uint32_t)il + delta[l_d[il]];
+                cs_rec8 v; v.x = l_rs[il]; v.y = l_rr[il];
+                *reinterpret_cast<cs_rec8*>(out + 2 * (int64_t)oi) = v;
+            }
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);               // (four records in flight per lane: all twelve at once spill next to the prefetched columns)
+        }
+        // no barrier here: the next tile's barrier (A) separates this copy-out from the next placement
+    }
+}
+
 // ---- SAMPLED partition: region sizes from 1 / 64 of the probe side ---------------------------------------------------------------
 // Sample = groups of CS_SGROUP consecutive probes (one 32-byte sector per column) every CS_SGROUP * CS_SRATE probes; gh[b] += sampled
 // probes of bucket b.  A few hundred workgroups, the bucket table in LDS as in k_cs_hist.

@@ -4,6 +4,8 @@ Bit-exact bar: integer index work -- pairs, counts, nearest rows and distances m
 identical, including output order (probe row, then (build.start, build row)).
 All tests need a real MI355X (-m gpu).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1399,5 +1401,65 @@ def test_eight_byte_probe_records_and_their_fallback(monkeypatch):
                 p, b = e.overlap(pr, build, strict, 24, partition_mode=6)      # count -> fill pair
                 o = np.lexsort((b, p))
                 assert len(p) == len(ep) and (p[o] == ep[oe]).all() and (b[o] == eb[oe]).all(), (name, strict, "pair")
+    finally:
+        e.close()
+
+
+def test_scatter_on_12288_probe_tiles_matches_the_oracle(monkeypatch):
+    """Round 6: from 8 M probes on the sampled scatter of 8-byte records takes 12 288-probe tiles (k_cs_scatter12k) where its staging
+    fits the LDS.  9 000 011 probes (a ragged last tile) x 1.2 M build rows: exact pairs against the oracle through the fused pass,
+    Strict and Weak, with and without row ids, next to the 8192-probe form (IVJ_CS_PTILE=8192) -- and with outliers the sample misses,
+    where the call is redone with 12-byte records."""
+    monkeypatch.setenv("IVJ_CS", "1")
+    build = synth.make_side(1_200_000, 43, synth.BUILD_LEN, 24)
+    probe = synth.make_side(9_000_011, 42, synth.PROBE_LEN, 24)
+    ix = O.Index(O.Side(*build), 24)
+    cores = os.cpu_count() or 1
+    exp = {}
+    for strict in (True, False):
+        ep, eb = O.overlap_fast(ix, O.Side(*probe), strict, threads=cores)
+        oe = np.lexsort((eb, ep))
+        exp[strict] = (ep[oe], eb[oe])
+    for ptile in ("", "8192"):
+        if ptile:
+            monkeypatch.setenv("IVJ_CS_PTILE", ptile)
+        e = _engine.Engine(0)
+        try:
+            for strict in (True, False):
+                ep, eb = exp[strict]
+                hp, hb = _fused_overlap(e, probe, build, strict, 24, 6, len(ep))
+                o = np.lexsort((hb, hp))
+                assert (hp[o] == ep).all() and (hb[o] == eb).all(), (ptile, strict)
+        finally:
+            e.close()
+    monkeypatch.delenv("IVJ_CS_PTILE")
+    # row ids (a shard's global rows) + outliers between the sampled groups: the redo with 12-byte records
+    ids = (np.arange(len(probe[0]), dtype=np.int64) * 3 % 2_000_000_011 % (1 << 31)).astype(np.int32)
+    long_probe = tuple(a.copy() for a in probe)
+    idx = np.arange(100, len(probe[0]), 512 * 1031)
+    long_probe[2][idx] = np.minimum(long_probe[1][idx].astype(np.int64) + 30_000_000, np.iinfo(np.int32).max).astype(np.int32)
+    ep, eb = O.overlap_fast(ix, O.Side(*long_probe), True, threads=cores)
+    e = _engine.Engine(0)
+    try:
+        ptrs = []
+        def up(a):
+            p = e.dev_alloc(max(4 * len(a), 16)); e.h2d(p, np.ascontiguousarray(a, np.int32)); ptrs.append(p); return p
+        sp = e.dev_side(up(long_probe[0]), up(long_probe[1]), up(long_probe[2]), len(ids), up(ids))
+        sb = e.dev_side(up(build[0]), up(build[1]), up(build[2]), len(build[0]))
+        opts = _engine.make_opts(True, 24, partition_mode=6)
+        ixd = e.index_build_dev(sb, opts)
+        op, ob = e.dev_alloc(4 * len(ep)), e.dev_alloc(4 * len(ep))
+        e.enable_timing(2); e.timings()
+        got, fits = e.overlap_fused_dev(ixd, sp, opts, op, ob, len(ep))
+        t = e.timings(); e.enable_timing(0)
+        assert fits and got == len(ep)
+        assert t["cs_scatter"]["launches"] == 2, t["cs_scatter"]                 # the 8-byte attempt (12 288-probe tiles) + the redo
+        hp, hb = np.empty(len(ep), np.int32), np.empty(len(ep), np.int32)
+        e.d2h(hp, op); e.d2h(hb, ob)
+        o, oe = np.lexsort((hb, hp)), np.lexsort((eb, ids[ep]))
+        assert (hp[o] == ids[ep][oe]).all() and (hb[o] == eb[oe]).all()
+        ixd.close()
+        for p in ptrs + [op, ob]:
+            e.dev_free(p)
     finally:
         e.close()
