@@ -375,7 +375,10 @@ void ivj_stream_close(ivj_stream* st);
  * (the reference builds one tree per contig, range_op.py:550), so every rank joins the rows of ITS contigs (global row
  * ids in ivj_side.row_id) with no collective on the data path, and the variable-length results are exchanged with one
  * ncclAllGather of the counts + ONE grouped batch of ncclSend / ncclRecv (every GPU pair on its own xGMI link).
- * RCCL is loaded on first use (librccl.so.1); nothing here needs PyTorch.  A communicator of world 1 never touches RCCL. */
+ * RCCL is loaded on first use (librccl.so.1); nothing here needs PyTorch.  A communicator of world 1 never touches RCCL --
+ * unless IVJ_COMM_NO_SHORTCUT=1 is set when it is created (round 6; tests): it is then a REAL communicator (ncclGetUniqueId +
+ * ncclCommInitRank), its count all-gather an ncclAllGather and its own slice travels through a grouped ncclSend + ncclRecv to
+ * itself, so that the RCCL branch of every call below runs on a 1-GPU box (tests/test_comm.py::test_real_rccl_on_one_rank_*). */
 typedef struct ivj_comm ivj_comm;
 #define IVJ_UNIQUE_ID_BYTES 128
 /* rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any channel the host has */
@@ -425,7 +428,14 @@ int ivj_overlap_allgather_dev(ivj_comm* comm, ivj_index* ix, const ivj_side* pro
  * Every rank ends up with the full-length columns in global probe order: counts_dev[n_total] (int64), or idx_dev[n_total * k] /
  * dist_dev[n_total * k] / n_found_dev[n_total] with k = opts->nearest_k.  Rows no rank reports keep count 0 / build row -1, distance -1,
  * n_found 0.  On the wire: {row int32, count int32} (8 bytes per probe; counts are bounded by the build rows) and
- * {row int32, k x int32, k x int64, int32}: ONE count all-gather + ONE grouped send / receive batch, then a scatter kernel.
+ * {row int32, k x int32, k x int64, int32}: ONE count all-gather + ONE grouped send / receive batch.  The row column on the wire IS
+ * probe_dev->row_id and the count column comes straight out of the shard's kernel (no pack pass); this rank's own slice is read where
+ * it lies.  Receiver (round 6): a shard whose global rows ASCEND -- what ivj_host_shard and every host that keeps df1's order produce --
+ * is MERGED: the rows of an output tile are one contiguous segment of every sender's columns (bound search per (sender, tile)), read
+ * coalesced, placed by row in LDS, written coalesced with the defaults filled in (config 5 through this call on one rank: 10.6 -> 2.8 ms).
+ * Senders in any other order are detected by the merge's own checks (every placed row belongs to its tile, the placed rows are counted)
+ * and take the round-5 form -- defaults, then one store per reported row.  A row id reported twice is IVJ_EINVAL (merge form; the
+ * scatter form keeps the later store), a row id outside [0, n_total) IVJ_EINVAL in both.
  * Failure contract: every rank reaches the count all-gather whatever happened to its own shard; a rank whose work failed returns its
  * own error, every other rank IVJ_EPEER, and nothing is sent or received (decided from the gathered values, so nobody waits in a
  * collective); ranks that disagree on n_total, or report more rows than n_total, get IVJ_EINVAL on every rank.

@@ -646,14 +646,17 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
             }
             pre = below + (inc - xs);
         }
-        uint32_t got[OWN];
+        uint32_t got[OWN], r_at[OWN], r_cap[OWN];
 #pragma unroll
         for (int q = 0; q < OWN; ++q) {
             const int b = OWN * tv + q;
-            got[q] = 0u;
+            got[q] = 0u; r_at[q] = 0u; r_cap[q] = 0u;
             if (b < nbk) {
                 lstart[b] = (uint32_t)pre;
-                if (x[q] > 0 && b < g.nb) got[q] = atomicAdd(&rcur[b], (uint32_t)x[q]);       // split-phase: answered while the tile is placed
+                // split-phase: the cursor's answer and the region's bounds (global memory: this form keeps no LDS copy of them) are
+                // requested here and used after the placement
+                r_at[q] = rstart[b < g.nb ? b : g.nb];
+                if (x[q] > 0 && b < g.nb) { r_cap[q] = rstart[b + 1]; got[q] = atomicAdd(&rcur[b], (uint32_t)x[q]); }
             }
             pre += x[q];
         }
@@ -683,9 +686,9 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
             const int b = OWN * tv + q;
             pre -= x[q];
             if (b < nbk) {
-                uint32_t at = rstart[b < g.nb ? b : g.nb];                     // region start (an overflowing run lands here, in bounds)
+                uint32_t at = r_at[q];                                          // region start (an overflowing run lands here, in bounds)
                 if (x[q] > 0 && b < g.nb) {
-                    const uint32_t cap = rstart[b + 1] - at;
+                    const uint32_t cap = r_cap[q] - at;
                     if (got[q] + (uint32_t)x[q] <= cap) at += got[q];
                     else atomicOr(state + 1, 4ull);
                 }

@@ -107,12 +107,6 @@ struct ivj_ctx {
     char* nl_cache = nullptr;          // the nearest-line table of the last index freed on this context (reused like ix_cache)
     size_t nl_cache_cap = 0;
     int env_nearest_lines = -1;        // IVJ_NEAREST_LINES: 0 never, 1 wherever the kernel applies, unset: by size
-    // Side stream (round 6): independent per-index table builds run next to each other -- the nearest path's prefix-max chain
-    // (pmax_change -> argmax_scan -> nearest_records) and bins_records beside contig_meta -> bins_mark -> bins_scan -> nearest_lines;
-    // each chain is 3-4 small launches the GPU is far from full with.  IVJ_SIDE_STREAM=0: everything on the one stream.
-    hipStream_t side_stream = nullptr;
-    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int env_side_stream = 1;
     char* ix_cache = nullptr;
     size_t ix_cache_cap = 0;
     int64_t ov_total = 0;
@@ -227,28 +221,6 @@ inline hipError_t wait_event(ivj_ctx* ctx, hipEvent_t ev) {
     return hipEventSynchronize(ev);
 }
 
-// ---- side stream: fork / join against the context's stream (events without timing; created on first use) ----------------------------
-inline int side_ensure(ivj_ctx* ctx) {
-    if (!ctx->side_stream) {
-        if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) { ctx->side_stream = nullptr; return -1; }
-        for (auto& e : ctx->side_ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return -1; }
-    }
-    return 0;
-}
-// `to` waits for everything queued on `from` so far (event k of the context's four)
-inline hipError_t stream_after(ivj_ctx* ctx, hipStream_t to, hipStream_t from, int k) {
-    hipError_t e = hipEventRecord(ctx->side_ev[k], from);
-    if (e == hipSuccess) e = hipStreamWaitEvent(to, ctx->side_ev[k], 0);
-    return e;
-}
-// launches inside the scope go to the side stream (LAUNCH and the helpers take ctx->stream)
-struct SideScope {
-    ivj_ctx* ctx; hipStream_t main;
-    explicit SideScope(ivj_ctx* c) : ctx(c), main(c->stream) { ctx->stream = ctx->side_stream; }
-    ~SideScope() { ctx->stream = main; }
-};
-
 struct ivj_index {
     ivj_ctx* ctx = nullptr;
     int device = 0;
@@ -304,7 +276,6 @@ struct ivj_index {
     int32_t* hier = nullptr;             // the sorted ends and their block maxima, level by level (k_hier_level); filled on first use
     bool hier_built = false;
     bool tables_built = false;   // the direct-address tables exist (built on first use)
-    bool brec_pending = false;   // ... but for the 16-byte bin records (build_brec)
     bool has_tables = true;    // false: built for merge / cluster only (with_end_order & 2)     // rec4 is filled on demand (join + materialisation path, flat path)
     char* slab = nullptr;      // single allocation holding every array above
     size_t slab_cap = 0;

@@ -4,8 +4,7 @@
 
 namespace {
 
-int build_tables(ivj_ctx* ctx, ivj_index* ix, bool defer_records = false);
-int build_brec(ivj_ctx* ctx, ivj_index* ix);
+int build_tables(ivj_ctx* ctx, ivj_index* ix);
 // contig-aligned slice path (host_cslice.hip.h): geometry and per-index arrays
 bool cs_geom(int64_t n, int nc, int want_rows, CsGeom& g);
 size_t cs_index_bytes(const CsGeom& g);
@@ -28,10 +27,7 @@ int ensure_hier(ivj_ctx* ctx, ivj_index* ix) {
 
 int need_tables(ivj_ctx* ctx, ivj_index* ix) {
     if (!ix->has_tables) return fail(IVJ_ESTATE, "this index was built for merge / cluster only (with_end_order & 2): it has no lookup tables");
-    if (ix->tables_built) {
-        if (ix->brec_pending) IVJ_TRY(build_brec(ctx, ix));       // (build_lines deferred the 16-byte records; a caller that wants them gets them now)
-        return IVJ_OK;
-    }
+    if (ix->tables_built) return IVJ_OK;
     return build_tables(ctx, ix);
 }
 
@@ -218,34 +214,13 @@ int build_lines(ivj_ctx* ctx, ivj_index* ix) {
             ix->nline_cap = need;
         }
     }
-    // Round 6: a fresh index runs its two table chains SIDE BY SIDE -- bins (contig_meta -> bins_mark -> bins_scan) on the context's
-    // stream, the prefix-max chain (pmax_change -> argmax_scan -> nearest_records) on the side stream, then the 16-byte bin records
-    // (only the leftovers' kernel reads them) on the side stream next to the line table's launch.  Each chain is 3 - 4 launches of
-    // 5 - 30 us that leave most of the chip idle: config 4 paid 0.12 ms for them in a row (profiles/r05/kernel_tables_hipevents.txt).
-    bool forked = false;
-    const bool fork = ctx->env_side_stream != 0 && !ix->tables_built && !ix->has_argmax && ix->n >= (64ll << 10) && ix->n_contigs > 0 &&
-                      side_ensure(ctx) == 0;
-    if (!fork) {
-        IVJ_TRY(need_tables(ctx, ix));
-        IVJ_TRY(build_argmax(ctx, ix));
-    } else {
-        struct Drain { ivj_ctx* c; bool armed = true; ~Drain() { if (armed) (void)hipStreamSynchronize(c->side_stream); } } drain{ctx};   // (an error below must not leave the side stream running into freed scratch)
-        hipStream_t main = ctx->stream;
-        // the scan of the prefix-max chain takes the context's look-back buffer, the bins' scan its own arena words: no shared scratch
-        IVJ_TRY(arena_reserve(ctx, align_up((size_t)((ix->bins_len + LB_TILE - 1) / LB_TILE) * 8) + align_up(16) + 8192));   // (before the fork: a growing arena synchronises)
-        HIP_TRY(stream_after(ctx, ctx->side_stream, main, 0));
-        { SideScope on_side(ctx); IVJ_TRY(build_argmax(ctx, ix)); }
-        HIP_TRY(hipEventRecord(ctx->side_ev[2], ctx->side_stream));       // nrec complete
-        IVJ_TRY(build_tables(ctx, ix, /*defer_records=*/true));
-        HIP_TRY(stream_after(ctx, ctx->side_stream, main, 1));            // the records need the scanned bins
-        { SideScope on_side(ctx); IVJ_TRY(build_brec(ctx, ix)); }
-        HIP_TRY(hipStreamWaitEvent(main, ctx->side_ev[2], 0));            // the line table needs bins (this stream) + nrec (side stream)
-        forked = true;
-        drain.armed = false;
-    }
+    // (Round 6, measured and dropped: the two table chains -- bins on the context's stream, pmax_change -> argmax_scan -> nearest_records
+    // + bins_records on a second stream -- ran config 4 at 1.598 ms against 1.600 on one stream: these 10 - 30 us kernels are already
+    // throughput-bound on their 16 - 64 MB of traffic, not launch- or latency-bound; profiles/r06/ab_nearest_side_stream_*.json)
+    IVJ_TRY(need_tables(ctx, ix));
+    IVJ_TRY(build_argmax(ctx, ix));
     LAUNCH(ctx, "nearest_lines", k_nearest_lines, grid1d(ix->bins_len * 4, 256), 256, (const uint32_t*)ix->bins, (const int4*)ix->cmeta, ix->n_contigs, (const int4*)ix->nrec,
            (const int32_t*)ix->b_start, (const int2*)ix->ep, (const int32_t*)ix->b_row, ix->bins_len, ix->n, ix->nline);
-    if (forked) HIP_TRY(stream_after(ctx, ctx->stream, ctx->side_stream, 3));   // ... and whatever comes next the bin records as well
     HIP_TRY(hipGetLastError());
     ix->has_lines = true;
     return IVJ_OK;
@@ -397,17 +372,7 @@ int index_sort_v3(ivj_ctx* ctx, ivj_index* ix, const ivj_side* build, const ivj_
 
 // direct-address table over the starts (lazily, on the sorted index): per-contig geometry, head marks, look-back max-scan,
 // 16-byte bin records
-int build_brec(ivj_ctx* ctx, ivj_index* ix) {
-    if (!ix->brec_pending) return IVJ_OK;
-    LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
-           (const int32_t*)ix->b_start, (const int4*)ix->cmeta, ix->n_contigs, ix->brec);
-    HIP_TRY(hipGetLastError());
-    ix->brec_pending = false;
-    return IVJ_OK;
-}
-
-// defer_records: stop after the bins (build_lines puts k_bins_records on the side stream, next to the line table's own launch)
-int build_tables(ivj_ctx* ctx, ivj_index* ix, bool defer_records) {
+int build_tables(ivj_ctx* ctx, ivj_index* ix) {
     const int nc = ix->n_contigs;
     const int64_t n = ix->n;
     if (n > 0 && nc > 0) {
@@ -422,8 +387,8 @@ int build_tables(ivj_ctx* ctx, ivj_index* ix, bool defer_records) {
                (const int4*)ix->cmeta, ix->bins);
         LAUNCH(ctx, "bins_scan", (k_scan_lb_u32<MaxOp, false>), lb_tiles, OS_THREADS, ix->bins, ix->bins_len, 0u,
                (uint32_t*)(z + align_up((size_t)lb_tiles * 8)), (unsigned long long*)z);
-        ix->brec_pending = true;
-        if (!defer_records) IVJ_TRY(build_brec(ctx, ix));
+        LAUNCH(ctx, "bins_records", k_bins_records, grid1d(ix->bins_len, 256), 256, (const uint32_t*)ix->bins, ix->bins_len,
+               (const int32_t*)ix->b_start, (const int4*)ix->cmeta, nc, ix->brec);
         HIP_TRY(hipGetLastError());
     }
     ix->tables_built = true;

@@ -91,7 +91,6 @@ int ivj_ctx_create(int device, ivj_ctx** out) try {
     if (const char* ev = std::getenv("IVJ_JOINT_BINS")) ctx->env_joint_bins = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_ABLATE")) ctx->env_count_ablate = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_NEAREST_LINES")) ctx->env_nearest_lines = std::atoi(ev);
-    if (const char* ev = std::getenv("IVJ_SIDE_STREAM")) ctx->env_side_stream = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_COUNT_NOLDS")) ctx->env_count_nolds = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_IX_V3")) ctx->env_ix_v3 = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("IVJ_SPIN_US")) ctx->env_spin_us = std::atoi(ev);
@@ -143,8 +142,6 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     for (auto& cb : ctx->st_cache) free_stream_bufs(cb);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
     if (ctx->nl_cache) (void)hipFree(ctx->nl_cache);
-    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
-    for (hipEvent_t ev : ctx->side_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->ix3_event) (void)hipEventDestroy(ctx->ix3_event);
     if (ctx->cs_event) (void)hipEventDestroy(ctx->cs_event);
     if (ctx->h_total) (void)hipHostFree(ctx->h_total);
@@ -159,7 +156,6 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
 int ivj_ctx_set_stream(ivj_ctx* ctx, void* hip_stream) try {
     if (!ctx) return fail(IVJ_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
     ctx->stream = (hip_stream == (void*)-1) ? ctx->own_stream : (hipStream_t)hip_stream;
     return IVJ_OK;
 } IVJ_ABI_CATCH

@@ -1407,11 +1407,12 @@ def test_eight_byte_probe_records_and_their_fallback(monkeypatch):
 
 def test_scatter_on_12288_probe_tiles_matches_the_oracle(monkeypatch):
     """Round 6: from 8 M probes on the sampled scatter of 8-byte records takes 12 288-probe tiles (k_cs_scatter12k) where its staging
-    fits the LDS.  9 000 011 probes (a ragged last tile) x 1.2 M build rows: exact pairs against the oracle through the fused pass,
+    fits the LDS.  9 000 011 probes (a ragged last tile) x 3 M build rows (~ 1000 slices of ~ 3.2 Mbp: 22 offset bits + 9 length bits, so
+    the device picks the 8-byte form): exact pairs against the oracle through the fused pass,
     Strict and Weak, with and without row ids, next to the 8192-probe form (IVJ_CS_PTILE=8192) -- and with outliers the sample misses,
     where the call is redone with 12-byte records."""
     monkeypatch.setenv("IVJ_CS", "1")
-    build = synth.make_side(1_200_000, 43, synth.BUILD_LEN, 24)
+    build = synth.make_side(3_000_000, 43, synth.BUILD_LEN, 24)
     probe = synth.make_side(9_000_011, 42, synth.PROBE_LEN, 24)
     ix = O.Index(O.Side(*build), 24)
     cores = os.cpu_count() or 1
@@ -1425,11 +1426,16 @@ def test_scatter_on_12288_probe_tiles_matches_the_oracle(monkeypatch):
             monkeypatch.setenv("IVJ_CS_PTILE", ptile)
         e = _engine.Engine(0)
         try:
+            e.enable_timing(2)
             for strict in (True, False):
                 ep, eb = exp[strict]
+                e.timings()
                 hp, hb = _fused_overlap(e, probe, build, strict, 24, 6, len(ep))
+                t = e.timings()
                 o = np.lexsort((hb, hp))
                 assert (hp[o] == ep).all() and (hb[o] == eb).all(), (ptile, strict)
+                # the 8-byte form ran (the 12-byte launch, queued behind it, returned at once)
+                assert t["cs_scatter"]["launches"] == 1 and t["cs_scatter12"]["ms"] < 0.5 * t["cs_scatter"]["ms"], (ptile, strict, t)
         finally:
             e.close()
     monkeypatch.delenv("IVJ_CS_PTILE")
