@@ -519,39 +519,44 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
 //     and the NEXT tile's columns are requested only once this tile's are dead -- 12 probes per thread inside the 128-register budget.
 // Same protocol as k_cs_scatter<.., SAMPLED = true, REC8 = true>: the host queues it INSTEAD of that kernel where cs_part12_lds fits the
 // LDS (the plan's part_items = 12), next to the 12-byte form that runs when the device-side format word says so.
+// items = 16 (16 384-probe tiles, sides WITHOUT row ids): the row plane holds the 2-byte tile-local element index (row = tile base + index)
+// and there is no bucket plane -- the copy-out walks the bucket runs instead of the elements: 6 bytes of staging per probe.
 struct CsPart12Lds { int cm, cell, spl, lstart, delta, cnt, rs, rr, d, wsum, total; };
-__host__ __device__ inline CsPart12Lds cs_part12_lds(int nb, int ncells, int n_contigs) {
-    constexpr int tile = CS_THREADS * 12;
+__host__ __device__ inline CsPart12Lds cs_part12_lds(int nb, int ncells, int n_contigs, int items = 12) {
+    const int tile = CS_THREADS * items;
     CsPart12Lds L;
     int o = 0;
     L.cm = o; o += 16 * ((n_contigs + 3) & ~3);
     L.spl = o; o += 8 * nb;
     L.cell = o; o += 4 * ncells;
     L.rs = (o + 15) & ~15; o = L.rs + 4 * tile;
-    L.rr = o; o += 4 * tile;
-    L.lstart = o; o += 4 * (nb + 2);
-    L.delta = o; o += 4 * (nb + 2);
-    L.cnt = o; o += 4 * (nb + 2);
-    L.d = (o + 3) & ~3; o = L.d + 2 * tile;
+    L.rr = o; o += (items == 16 ? 2 : 4) * tile;
+    L.lstart = o; o += 4 * (nb + 4);
+    L.delta = o; o += 4 * (nb + 4);
+    L.cnt = o; o += 4 * (nb + 4);
+    L.d = (o + 3) & ~3; o = L.d + (items == 16 ? 0 : 2 * tile);
     L.wsum = (o + 15) & ~15; o = L.wsum + 4 * 2 * CS_WAVES;
     L.total = o;
     return L;
 }
 
-template <bool STRICT>
+template <bool STRICT, int PITEMS>
 __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom g, const int32_t* __restrict__ pc, const int32_t* __restrict__ ps,
                                                              const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
                                                              int chunk, int nchunks, bool vec_ok, const uint32_t* __restrict__ rstart,
                                                              uint32_t* __restrict__ rcur, unsigned long long* __restrict__ state,
                                                              const int32_t* __restrict__ meta, int32_t* __restrict__ out, int ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
-    constexpr int PITEMS = 12, TILE = CS_THREADS * PITEMS;
-    const CsPart12Lds L = cs_part12_lds(g.nb, g.ncells, g.n_contigs);
+    constexpr int TILE = CS_THREADS * PITEMS;
+    constexpr bool RUNS = PITEMS == 16;                                         // 16 384-probe tiles: 2-byte row plane, copy-out by bucket runs (no row ids)
+    static_assert(PITEMS == 12 || PITEMS == 16, "tile sizes of this kernel");
+    const CsPart12Lds L = cs_part12_lds(g.nb, g.ncells, g.n_contigs, PITEMS);
     unsigned long long* l_spl = reinterpret_cast<unsigned long long*>(cs_lds + L.spl);
     int4* l_cm = reinterpret_cast<int4*>(cs_lds + L.cm);
     uint32_t* l_cell = reinterpret_cast<uint32_t*>(cs_lds + L.cell);
     int32_t* l_rs = reinterpret_cast<int32_t*>(cs_lds + L.rs);
     int32_t* l_rr = reinterpret_cast<int32_t*>(cs_lds + L.rr);
+    unsigned short* l_ri = reinterpret_cast<unsigned short*>(cs_lds + L.rr);    // RUNS: tile-local element index instead of the row
     uint32_t* lstart = reinterpret_cast<uint32_t*>(cs_lds + L.lstart);
     uint32_t* delta = reinterpret_cast<uint32_t*>(cs_lds + L.delta);
     uint32_t* cnt = reinterpret_cast<uint32_t*>(cs_lds + L.cnt);
@@ -563,6 +568,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
     if (lb == 0) return;
     cs_load_tab(tab, g, l_spl, l_cm, l_cell, CS_THREADS);
     for (int k = tid; k < nbk + 1; k += CS_THREADS) cnt[k] = 0;
+    if (RUNS && row_id) return;                                                  // (host contract: sides with row ids take the 12 288-probe form)
     __syncthreads();
     const int64_t cbase = (int64_t)blockIdx.x * chunk;
     const int64_t cend = cbase + chunk < n ? cbase + chunk : n;
@@ -595,25 +601,33 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
     int tix = 0;
     for (int64_t tbase = cbase; tbase < cend; tbase += TILE, ++tix) {
         const int tile_n = (int)((cend - tbase) < (int64_t)TILE ? (cend - tbase) : (int64_t)TILE);
-        uint32_t w0[PITEMS], dr[PITEMS];                                        // packed record word; bucket | rank << 11
+        // packed record word; bucket | rank << 11.  RUNS (16 probes per lane): the word is built at PLACEMENT time from the columns, which
+        // stay in their registers until then, and the next tile's columns are requested after the placement (their flight overlaps the
+        // copy-out and the tile's last barrier) -- sixteen packed words next to sixteen prefetched probes do not fit 128 registers
+        uint32_t w0[RUNS ? 1 : PITEMS], dr[PITEMS];
         static_assert(SL_MAX_BUCKETS + 1 <= (1 << 11) && TILE <= (1 << 21), "bucket and rank share one word");
 #pragma unroll
         for (int j = 0; j < PITEMS; ++j) {
             const bool valid = (j / 4) * (CS_THREADS * 4) + tid * 4 + (j & 3) < tile_n;
             const uint32_t d = !valid ? 0u : cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, nc[j], ne[j]);
             const uint32_t rank = valid ? atomicAdd(&cnt[d], 1u) : 0u;
-            uint32_t w = 0u;
-            if (valid && d < (uint32_t)g.nb) {
-                const uint32_t off = (uint32_t)ne[j] - (uint32_t)unflip((uint32_t)l_spl[d]);       // >= 0: the slice's first row starts below the end
-                const uint32_t len = (uint32_t)ne[j] - (uint32_t)ns[j];
-                if (ne[j] < ns[j] || (len >> lb) != 0u || (off >> (32 - lb)) != 0u) atomicOr(state + 1, CS_STATE_REC8);   // (redo with 12-byte records)
-                w = (off << lb) | len;
+            if constexpr (!RUNS) {
+                uint32_t w = 0u;
+                if (valid && d < (uint32_t)g.nb) {
+                    const uint32_t off = (uint32_t)ne[j] - (uint32_t)unflip((uint32_t)l_spl[d]);       // >= 0: the slice's first row starts below the end
+                    const uint32_t len = (uint32_t)ne[j] - (uint32_t)ns[j];
+                    if (ne[j] < ns[j] || (len >> lb) != 0u || (off >> (32 - lb)) != 0u) atomicOr(state + 1, CS_STATE_REC8);   // (redo with 12-byte records)
+                    w = (off << lb) | len;
+                }
+                w0[j] = w;
             }
-            w0[j] = w; dr[j] = d | (rank << 11);
+            dr[j] = d | (rank << 11);
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);               // (four lookups in flight are enough: twelve interleaved ones cost 14 spilled registers)
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (tbase + TILE < cend) load_tile(tbase + TILE);                      // this tile's columns are dead: the next tile's travel during the rest of this one
+        if constexpr (!RUNS) {
+            if (tbase + TILE < cend) load_tile(tbase + TILE);                  // this tile's columns are dead: the next tile's travel during the rest of this one
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                                        // (A) bucket counts of the tile complete
         // (the lane's index is made opaque once per tile: per-lane addresses derived from it -- the region cursors' 64-bit ones, the 3 x 12
@@ -653,6 +667,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
             got[q] = 0u; r_at[q] = 0u; r_cap[q] = 0u;
             if (b < nbk) {
                 lstart[b] = (uint32_t)pre;
+                if (RUNS && b == nbk - 1) lstart[nbk] = (uint32_t)(pre + x[q]);  // (the runs' copy-out reads bucket b's end at lstart[b + 1])
                 // split-phase: the cursor's answer and the region's bounds (global memory: this form keeps no LDS copy of them) are
                 // requested here and used after the placement
                 r_at[q] = rstart[b < g.nb ? b : g.nb];
@@ -665,10 +680,12 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
         for (int h = 0; h < PITEMS / 4; ++h) {
             const int e0 = h * (CS_THREADS * 4) + tv * 4;
             int32_t rw[4];
-            if (row_id) load4(row_id + tbase, (uint32_t)e0, (uint32_t)tile_n, -1, rw);
-            else {
+            if constexpr (!RUNS) {
+                if (row_id) load4(row_id + tbase, (uint32_t)e0, (uint32_t)tile_n, -1, rw);
+                else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rw[u] = (int32_t)(tbase + e0 + u);
+                    for (int u = 0; u < 4; ++u) rw[u] = (int32_t)(tbase + e0 + u);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -676,10 +693,23 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
                 if (e0 + u < tile_n) {
                     const uint32_t d = dr[j] & 2047u;
                     const uint32_t pos = lstart[d] + (dr[j] >> 11);
-                    l_rs[pos] = (int32_t)w0[j]; l_rr[pos] = rw[u];
-                    l_d[pos] = (unsigned short)d;
+                    if constexpr (RUNS) {
+                        uint32_t w = 0u;
+                        if (d < (uint32_t)g.nb) {
+                            const uint32_t off = (uint32_t)ne[j] - (uint32_t)unflip((uint32_t)l_spl[d]);
+                            const uint32_t len = (uint32_t)ne[j] - (uint32_t)ns[j];
+                            if (ne[j] < ns[j] || (len >> lb) != 0u || (off >> (32 - lb)) != 0u) atomicOr(state + 1, CS_STATE_REC8);
+                            w = (off << lb) | len;
+                        }
+                        l_rs[pos] = (int32_t)w; l_ri[pos] = (unsigned short)(e0 + u);
+                    } else { l_rs[pos] = (int32_t)w0[j]; l_rr[pos] = rw[u]; l_d[pos] = (unsigned short)d; }
                 }
             }
+        }
+        if constexpr (RUNS) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (tbase + TILE < cend) load_tile(tbase + TILE);                  // (the columns were consumed by the placement)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int q = OWN - 1; q >= 0; --q) {
@@ -696,6 +726,22 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
             }
         }
         __syncthreads();                                                        // (D) tile sorted in LDS
+        if constexpr (RUNS) {
+            // copy-out by RUNS: sixteen lanes per bucket run, four runs per wavefront step (a run holds ~ 16 records at 1040 buckets);
+            // bucket g.nb (no candidate row) is never copied
+            if (!(ablate & 256)) {
+                const int grp = (tv & (kWave - 1)) >> 4, sub = tv & 15;
+                for (int b0 = (tv / kWave) * 4; b0 < g.nb; b0 += CS_WAVES * 4) {
+                    const int b = b0 + grp;
+                    uint32_t rs0 = 0, re0 = 0, dl = 0;
+                    if (b < g.nb) { rs0 = lstart[b]; re0 = lstart[b + 1]; dl = delta[b]; }
+                    for (uint32_t kk = rs0 + (uint32_t)sub; kk < re0; kk += 16u) {
+                        cs_rec8 v; v.x = l_rs[kk]; v.y = (int32_t)(tbase + (int64_t)l_ri[kk]);
+                        *reinterpret_cast<cs_rec8*>(out + 2 * (int64_t)(kk + dl)) = v;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < PITEMS; ++j) {
             const int il = j * CS_THREADS + tv;
@@ -705,6 +751,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
                 *reinterpret_cast<cs_rec8*>(out + 2 * (int64_t)oi) = v;
             }
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);               // (four records in flight per lane: all twelve at once spill next to the prefetched columns)
+        }
         }
         // no barrier here: the next tile's barrier (A) separates this copy-out from the next placement
     }

@@ -50,6 +50,7 @@ struct SlicePlan {                     // slice path: launch geometry of one cal
     int64_t ntiles = 0;                // gmax * tiles_per_chunk
     int stage = 0, lds_seg = 0, items = 4, use_bins = 1, part_items = 4;
     bool part12 = false;               // the sampled scatter of 8-byte records on 12 288-probe tiles (k_cs_scatter12k)
+    bool part16 = false;               // ... on 16 384-probe tiles where the side brings no row ids
     size_t part_lds = 0, join_lds = 0, join_lds_count = 0;
 };
 

@@ -144,10 +144,10 @@ bool cs_sampled_wanted(const ivj_ctx* ctx, int64_t n, bool stable) {
 }
 uint32_t cs_region_slack(const ivj_ctx* ctx, const CsGeom& g, int64_t n) {
     if (ctx->cs_env_slack > 0) return (uint32_t)((ctx->cs_env_slack + 31) & ~31);        // (tests: below a tile, overflowing runs may leave the region -- only with regions that overflow anyway)
-    return (uint32_t)((3 * CS_TILE + n / (16 * (int64_t)(g.nb > 0 ? g.nb : 1)) + 31) & ~31ll);       // (>= the largest partition tile: 12 288 probes, round 6)
+    return (uint32_t)((4 * CS_TILE + n / (16 * (int64_t)(g.nb > 0 ? g.nb : 1)) + 31) & ~31ll);       // (>= the largest partition tile: 16 384 probes, round 6)
 }
 int64_t cs_record_capacity(const ivj_ctx* ctx, const CsGeom& g, int64_t n) {
-    return n + n / 4 + n / 32 + (int64_t)(cs_region_slack(ctx, g, n) + 64) * (g.nb + 2) + 3 * CS_TILE;
+    return n + n / 4 + n / 32 + (int64_t)(cs_region_slack(ctx, g, n) + 64) * (g.nb + 2) + 4 * CS_TILE;
 }
 
 int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* opts, SlicePlan& P, int& wcap) {
@@ -182,10 +182,13 @@ int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* 
     // round 6: the sampled scatter of 8-byte records takes 12 288-probe tiles where its staging fits (k_cs_scatter12k; IVJ_CS_PTILE=8192
     // pins the 8192-probe form); the chunks are then whole tiles of all three sizes
     P.part12 = P.part_items == 8 && ctx->cs_env_ptile != 8192 && n >= (8ll << 20) && (size_t)cs_part12_lds(g.nb, g.ncells, g.n_contigs).total <= 160 * 1024;
+    // ... and 16 384-probe tiles (6 bytes of staging per probe, copy-out by bucket runs) for sides without row ids from 32 M probes on;
+    // IVJ_CS_PTILE=12288 pins the 12 288-probe form
+    P.part16 = P.part12 && ctx->cs_env_ptile != 12288 && (n >= (32ll << 20) || ctx->cs_env_ptile == 16384) && (size_t)cs_part12_lds(g.nb, g.ncells, g.n_contigs, 16).total <= 160 * 1024;
     if (P.part12) {
-        const int64_t unit = 6 * CS_TILE;                                      // lcm(8192, 12288)
+        const int64_t unit = P.part16 ? 12 * CS_TILE : 6 * CS_TILE;            // lcm(8192, 12288[, 16384])
         int64_t c12 = ((n + 2047) / 2048 + unit - 1) / unit * unit;
-        if (c12 > 18 * CS_TILE) c12 = 18 * CS_TILE;
+        if (c12 > 24 * CS_TILE) c12 = 24 * CS_TILE;
         P.chunk = (int)c12;
         P.nchunks = (int)((n + c12 - 1) / c12);
     }
@@ -236,7 +239,8 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
             IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 8, true>), 160 * 1024));
             IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 4, true, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 4, true, true>), 160 * 1024));
             IVJ_TRY(set_dyn_lds((&k_cs_scatter<true, 8, true, true>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter<false, 8, true, true>), 160 * 1024));
-            IVJ_TRY(set_dyn_lds(&k_cs_scatter12k<true>, 160 * 1024)); IVJ_TRY(set_dyn_lds(&k_cs_scatter12k<false>, 160 * 1024));
+            IVJ_TRY(set_dyn_lds((&k_cs_scatter12k<true, 12>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter12k<false, 12>), 160 * 1024));
+            IVJ_TRY(set_dyn_lds((&k_cs_scatter12k<true, 16>), 160 * 1024)); IVJ_TRY(set_dyn_lds((&k_cs_scatter12k<false, 16>), 160 * 1024));
             ctx->cs_sattr_set = true;
         }
         const bool pz = ctx->cs_prep_zero && fuse_sample;                    // k_cs_prep clears the histogram (and the call state)
@@ -271,11 +275,14 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
         // both record forms are queued; the one the device-side format word does not name returns at once (allow8 = 0: only the 12-byte form)
         if (allow8) {
             if (P.part12) {
-                const size_t lds12 = (size_t)cs_part12_lds(g.nb, g.ncells, g.n_contigs).total;
-                if (strict) hipLaunchKernelGGL(k_cs_scatter12k<true>, dim3(P.nchunks), dim3(CS_THREADS), lds12, ctx->stream, tab, g, probe->contig, probe->start, probe->end, probe->row_id, n,
-                                               P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_rstart, ctx->sl_rcur, state, (const int32_t*)ctx->sl_meta, rec, ctx->sl_env_ablate);
-                else hipLaunchKernelGGL(k_cs_scatter12k<false>, dim3(P.nchunks), dim3(CS_THREADS), lds12, ctx->stream, tab, g, probe->contig, probe->start, probe->end, probe->row_id, n,
-                                        P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_rstart, ctx->sl_rcur, state, (const int32_t*)ctx->sl_meta, rec, ctx->sl_env_ablate);
+                const int wide = (P.part16 && !probe->row_id) ? 16 : 12;        // 16 384-probe tiles need the rows implied (row = position)
+                const size_t ldsw = (size_t)cs_part12_lds(g.nb, g.ncells, g.n_contigs, wide).total;
+#define IVJ_CS_SCATTER_W(S, I)                                                                                                          \
+    hipLaunchKernelGGL((k_cs_scatter12k<S, I>), dim3(P.nchunks), dim3(CS_THREADS), ldsw, ctx->stream, tab, g, probe->contig, probe->start, probe->end, probe->row_id, n, \
+                       P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_rstart, ctx->sl_rcur, state, (const int32_t*)ctx->sl_meta, rec, ctx->sl_env_ablate)
+                if (strict) { if (wide == 16) IVJ_CS_SCATTER_W(true, 16); else IVJ_CS_SCATTER_W(true, 12); }
+                else { if (wide == 16) IVJ_CS_SCATTER_W(false, 16); else IVJ_CS_SCATTER_W(false, 12); }
+#undef IVJ_CS_SCATTER_W
             }
             else if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER_S(true, 8, true); else IVJ_CS_SCATTER_S(true, 4, true); }
             else { if (P.part_items == 8) IVJ_CS_SCATTER_S(false, 8, true); else IVJ_CS_SCATTER_S(false, 4, true); }

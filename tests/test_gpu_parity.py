@@ -1407,7 +1407,7 @@ def test_eight_byte_probe_records_and_their_fallback(monkeypatch):
 
 def test_scatter_on_12288_probe_tiles_matches_the_oracle(monkeypatch):
     """Round 6: from 8 M probes on the sampled scatter of 8-byte records takes 12 288-probe tiles (k_cs_scatter12k) where its staging
-    fits the LDS.  9 000 011 probes (a ragged last tile) x 3 M build rows (~ 1000 slices of ~ 3.2 Mbp: 22 offset bits + 9 length bits, so
+    fits the LDS, from 32 M on 16 384-probe tiles when the side brings no row ids (6 bytes of staging per probe, copy-out by bucket runs).  9 000 011 probes (a ragged last tile) x 3 M build rows (~ 1000 slices of ~ 3.2 Mbp: 22 offset bits + 9 length bits, so
     the device picks the 8-byte form): exact pairs against the oracle through the fused pass,
     Strict and Weak, with and without row ids, next to the 8192-probe form (IVJ_CS_PTILE=8192) -- and with outliers the sample misses,
     where the call is redone with 12-byte records."""
@@ -1421,7 +1421,7 @@ def test_scatter_on_12288_probe_tiles_matches_the_oracle(monkeypatch):
         ep, eb = O.overlap_fast(ix, O.Side(*probe), strict, threads=cores)
         oe = np.lexsort((eb, ep))
         exp[strict] = (ep[oe], eb[oe])
-    for ptile in ("", "8192"):
+    for ptile in ("", "8192", "16384"):                                          # 12 288 (auto at this size), 8192, 16 384 (auto from 32 M probes on)
         if ptile:
             monkeypatch.setenv("IVJ_CS_PTILE", ptile)
         e = _engine.Engine(0)
