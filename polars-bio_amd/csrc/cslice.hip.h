@@ -1090,28 +1090,39 @@ struct CsJoinArgs {
     uint32_t* hw;                     // FUSED: host words [8..12] {pairs, flags, seq}, written by the last workgroup to finish (nullptr: the host copies the state)
     uint32_t hw_seq;
     uint32_t* done;                   // FUSED: finished workgroups (cleared with the state)
+    uint32_t* cursor;                 // persistent workgroups (k_cs_join_plain): items drawn from each XCD's part of the chunk list, zeroed per launch (nullptr: one item per workgroup)
+    int pmax, pgrain;                 // items per draw: clamp(items left in the XCD's part / pgrain, 1, pmax)
+    unsigned long long* trace;        // IVJ_CS_WGTRACE (diagnosis): {hw id | xcc << 32, start, slice staged, end, next run's preparation: start, end} per run, 100-MHz clock
 };
+
+// workgroup time line of the plain join (tools/wgtrace.py): who ran where and when -- tail, gaps between workgroups, slice staging share
+__device__ __forceinline__ void cs_trace(unsigned long long* trace, int v, int slot) {
+    if (!trace || threadIdx.x != 0) return;                                    // (uniform on the pointer)
+    if (slot == 0) trace[6 * (size_t)v] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    trace[6 * (size_t)v + 1 + slot] = wall_clock64();
+}
 
 // FUSED: the last join workgroup to finish hands {pairs, flags} to the host words.  Every wavefront first waits for its own memory
 // operations (the tile cursors' atomics on the state words among them), the workgroup meets, one thread takes a ticket; the holder
 // of the last ticket reads the state words past the caches.  A wavefront that left on a protocol timeout has waited for its flag
 // (IVJ_TILE_WAIT); a workgroup all of whose wavefronts left never takes a ticket, the sequence number stays behind and the host copies.
-__device__ __forceinline__ void cs_publish_state(const CsJoinArgs& A, int total_wg) {
-    if (!A.hw) return;                                                         // uniform
+__device__ __forceinline__ void cs_publish_state(uint32_t* hw, uint32_t hw_seq, uint32_t* done, unsigned long long* state, int total_wg) {
+    if (!hw) return;                                                           // uniform
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t t = atomicAdd(A.done, 1u);
+        const uint32_t t = atomicAdd(done, 1u);
         if (t == (uint32_t)total_wg - 1u) {
-            const unsigned long long pairs = __hip_atomic_load(A.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long flags = __hip_atomic_load(A.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hw_store(A.hw + 8, (uint32_t)pairs); hw_store(A.hw + 9, (uint32_t)(pairs >> 32));
-            hw_store(A.hw + 10, (uint32_t)flags); hw_store(A.hw + 11, (uint32_t)(flags >> 32));
+            const unsigned long long pairs = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long flags = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hw_store(hw + 8, (uint32_t)pairs); hw_store(hw + 9, (uint32_t)(pairs >> 32));
+            hw_store(hw + 10, (uint32_t)flags); hw_store(hw + 11, (uint32_t)(flags >> 32));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            hw_store(A.hw + 12, A.hw_seq);
+            hw_store(hw + 12, hw_seq);
         }
     }
 }
+__device__ __forceinline__ void cs_publish_state(const CsJoinArgs& A, int total_wg) { cs_publish_state(A.hw, A.hw_seq, A.done, A.state, total_wg); }
 
 // Copy-out of a wavefront's staged pairs (round 5): the output range starts at an arbitrary element of the two result columns, so a
 // plain `for (i = lane; ...)` makes EVERY 256-byte store instruction straddle five 64-byte lines (round-4 counters: 32.1 M write
@@ -1122,7 +1133,8 @@ __device__ __forceinline__ int cs_copy_align(const int32_t* op, int ablate) {
     return (ablate & CS_ABLATE_UNALIGNED) ? 0 : (int)((reinterpret_cast<uintptr_t>(op) >> 2) & 15u);
 }
 
-struct CsJoinLds { int end, pmx, start, row, bin, qrow, stage, ctl, total; };
+constexpr int CS_ARGS_LDS = 512;
+struct CsJoinLds { int end, pmx, start, row, bin, qrow, stage, ctl, args, total; };
 __host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
     CsJoinLds L;
     int o = 0;
@@ -1133,7 +1145,8 @@ __host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
     L.bin = o; o += 2 * (2 * R + 8);
     L.qrow = (o + 15) & ~15; o = L.qrow + 4 * CS_TILE;
     L.stage = o; o += 4 * wcap * CS_WAVES;
-    L.ctl = (o + 15) & ~15; o = L.ctl + 64;
+    L.ctl = (o + 15) & ~15; o = L.ctl + 160;               // tile control blocks (64 bytes) + the run loop: group in hand (32), next run (64)
+    L.args = o; o += CS_ARGS_LDS;                          // k_cs_join_plain: the kernel arguments its cold code reads
     L.total = o;
     return L;
 }
@@ -1147,7 +1160,14 @@ __host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
 template <bool STRICT, int MODE>
 __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
+    // Arguments the tile loops do not need are read from a COPY IN LDS at their (cold) place of use: pointers loaded at the kernel's entry
+    // stay in scalar registers for its whole life, and with the run loop's state the kernel needed 106 of them -- the compiler parked the
+    // excess in vector-register lanes (226 v_readlane in the listing, the join 4 % slower).  (Re-reading the kernel-argument segment
+    // itself was worse: it lives in host memory, every miss of the scalar cache is a trip over the bus -- the join 0.91 -> 1.0 ms.)
+    static_assert(sizeof(CsJoinArgs) <= CS_ARGS_LDS && sizeof(CsJoinArgs) % 4 == 0, "LDS copy of the arguments");
+    typedef const __attribute__((address_space(3))) CsJoinArgs* cs_largs_t;
     const CsJoinLds L = cs_join_lds(A.R, A.wcap);
+    auto ca = [&]() { return (cs_largs_t)(cs_lds + L.args); };
     int32_t* l_end = reinterpret_cast<int32_t*>(cs_lds + L.end);
     int32_t* l_pmx = reinterpret_cast<int32_t*>(cs_lds + L.pmx);
     int32_t* l_start = reinterpret_cast<int32_t*>(cs_lds + L.start);
@@ -1158,56 +1178,80 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
     unsigned long long* lc = reinterpret_cast<unsigned long long*>(cs_lds + L.ctl);     // [2][2] {cursor, base}
     int* li = reinterpret_cast<int*>(lc + 4);                                           // [2][4] {arrived, done, ready, seq}
 
-    // XCD-affine order: workgroup b runs on XCD b % 8 (observed); XCD x takes the contiguous eighth of the (bucket, chunk) list
-    const int total_wg = A.meta[0];
-    const int per = (total_wg + 7) / 8;
-    const int wslot = (int)(blockIdx.x >> 3);
-    const int v = (int)(blockIdx.x & 7) * per + wslot;
-    if (wslot >= per || v >= total_wg) return;                                 // uniform
-    const int2 bc = A.wg_map[v];
-    const int k = bc.x;
-    const int64_t q0 = (int64_t)A.bstart[k] + (int64_t)bc.y * A.jchunk;
-    const int64_t qend = A.bend ? (int64_t)A.bend[k] : (int64_t)A.bstart[k + 1];
-    const int64_t q1 = q0 + A.jchunk < qend ? q0 + A.jchunk : qend;
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-
-    const int4 sm0 = A.smeta[2 * k], sm1 = A.smeta[2 * k + 1];
-    const int32_t smin = sm0.x;
-    const int bshift = sm0.y, ncell = sm0.z;
-    const int seg_a = sm1.x, rk = sm1.z, r0 = sm1.w;
-    // slice k = sorted rows [r0, r0 + rk): ends / prefix maxima / starts / build rows / bins -> LDS
+    // The chunk list {(bucket, chunk of jchunk probes)} is cut into eight contiguous parts, one per XCD (the slices of neighbouring
+    // buckets meet in one L2).  Round 6: the workgroups are PERSISTENT (A.cursor; one per CU, grid = CUs): a workgroup draws GROUPS of
+    // consecutive list items from its XCD's cursor -- up to A.pmax at a time while the list is long, single items towards its end, and
+    // from the other XCDs' lists once its own is empty -- and joins consecutive items of one bucket as ONE run over the slice it staged
+    // once (tools/wgtrace.py, profiles/r06/wgtrace_*.txt: with one workgroup per item 8.2 % of the CU time passed between workgroups
+    // or behind the last one, and 9.3 % of a workgroup's time was the staging of its slice).  A.cursor = nullptr: one item per
+    // workgroup in launch order, workgroup b on XCD b % 8 (rounds 3-5; IVJ_CS_PERSIST=0).
+    {
+        const __attribute__((address_space(4))) uint32_t* kp = (const __attribute__((address_space(4))) uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+        if (threadIdx.x < sizeof(CsJoinArgs) / 4) reinterpret_cast<uint32_t*>(cs_lds + L.args)[threadIdx.x] = kp[threadIdx.x];   // (A is the only parameter: offset 0)
+        __syncthreads();
+    }
+    // (the thread index is made opaque once per run: the per-lane addresses derived from it -- staging regions, LDS slots of the items --
+    // are otherwise invariants of the run loop, kept in registers across the slice staging, and spilled: 60 bytes of scratch per lane)
+    int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+    // the run in hand (uniform): list items [v, v + nch) = probes [q0, q1) of bucket k, whose slice is in LDS
+    int v = 0, k = -1;
+    int64_t q0 = 0, q1 = 0;
+    int32_t smin = 0;
+    int bshift = 0, ncell = 1, seg_a = 0, rk = 0, r0 = 0;
+    // slice k = sorted rows [r0, r0 + rk): ends / prefix maxima / starts / build rows / bins -> LDS.  Every global load of the slice is
+    // requested before the first LDS store (two row quads and six bin words per thread at most): one memory round trip instead of three
     typedef int v4u __attribute__((ext_vector_type(4), aligned(4)));             // 16-byte global loads at any 4-byte aligned row
-    for (int i = tid * 4; i < rk; i += CS_THREADS * 4) {
-        if (i + 4 <= rk) {
-            const v4u s4 = *reinterpret_cast<const v4u*>(A.b_start + r0 + i);
-            const v4u r4 = *reinterpret_cast<const v4u*>(A.b_row + r0 + i);
-            const v4u e01 = *reinterpret_cast<const v4u*>(reinterpret_cast<const int32_t*>(A.ep + r0 + i));
-            const v4u e23 = *reinterpret_cast<const v4u*>(reinterpret_cast<const int32_t*>(A.ep + r0 + i + 2));
+    static_assert(SL_MAX_ROWS <= 2 * CS_THREADS * 4 && SL_MAX_ROWS + 1 <= 6 * CS_THREADS, "trip counts of the slice staging");
+    int32_t pm0 = 0;                                                             // prefix max of the row below the slice
+    auto stage_slice = [&]() {
+        const cs_largs_t P = ca();
+        // 2 R + 2 bins per slice: the stride is even, so pairs of bins are 4-byte aligned
+        const uint32_t* gb32 = reinterpret_cast<const uint32_t*>(P->bins + (size_t)k * (size_t)(2 * P->R + CS_BIN_STRIDE_PAD));
+        uint32_t* lb32 = reinterpret_cast<uint32_t*>(l_bin);
+        const int nb32 = (ncell + 2) / 2;
+        const int32_t* gs = P->b_start + r0;
+        const int32_t* gr = P->b_row + r0;
+        const int32_t* ge = reinterpret_cast<const int32_t*>(P->ep + r0);
+        // rows 0 .. 4095 (every thread one quad) and the bins travel together; rows 4096 .. (a quarter of the threads) behind them; the
+        // (up to three) rows beyond the last whole quad one by one
+        const int rk4 = rk & ~3;
+        auto put_quad = [&](int i, const v4u& s4, const v4u& r4, const v4u& e01, const v4u& e23) {
             *reinterpret_cast<int4*>(l_start + i) = make_int4(s4.x, s4.y, s4.z, s4.w);
             *reinterpret_cast<int4*>(l_row + i) = make_int4(r4.x, r4.y, r4.z, r4.w);
             *reinterpret_cast<int4*>(l_end + i) = make_int4(e01.x, e01.z, e23.x, e23.z);
             l_pmx[i + 1] = e01.y; l_pmx[i + 2] = e01.w; l_pmx[i + 3] = e23.y; l_pmx[i + 4] = e23.w;
-        } else {
-            for (int j = i; j < rk; ++j) {
-                l_start[j] = A.b_start[r0 + j]; l_row[j] = A.b_row[r0 + j];
-                const int2 e = A.ep[r0 + j];
-                l_end[j] = e.x; l_pmx[j + 1] = e.y;
+        };
+        {
+            const int i = tid * 4;
+            v4u s4 = {0, 0, 0, 0}, r4 = s4, e01 = s4, e23 = s4;
+            if (i < rk4) {
+                s4 = *reinterpret_cast<const v4u*>(gs + i); r4 = *reinterpret_cast<const v4u*>(gr + i);
+                e01 = *reinterpret_cast<const v4u*>(ge + 2 * i); e23 = *reinterpret_cast<const v4u*>(ge + 2 * i + 4);
+            }
+            uint32_t bw[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { const int i2 = tid + u * CS_THREADS; bw[u] = i2 < nb32 ? gb32[i2] : 0u; }
+            if (i < rk4) put_quad(i, s4, r4, e01, e23);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { const int i2 = tid + u * CS_THREADS; if (i2 < nb32) lb32[i2] = bw[u]; }
+        }
+        {
+            const int i = tid * 4 + CS_THREADS * 4;
+            if (i < rk4) {
+                const v4u s4 = *reinterpret_cast<const v4u*>(gs + i), r4 = *reinterpret_cast<const v4u*>(gr + i);
+                const v4u e01 = *reinterpret_cast<const v4u*>(ge + 2 * i), e23 = *reinterpret_cast<const v4u*>(ge + 2 * i + 4);
+                put_quad(i, s4, r4, e01, e23);
             }
         }
-    }
-    if (tid < 4) l_start[rk + tid] = INT32_MAX;
-    if (tid < 16) l_end[rk + tid] = INT32_MIN;
-    if (tid == 0) l_pmx[0] = sm0.w;
-    {
-        const unsigned short* gb = A.bins + (size_t)k * (size_t)(2 * A.R + CS_BIN_STRIDE_PAD);
-        // 2 R + 2 entries per slice: the stride is even, so pairs of bins are 4-byte aligned
-        const uint32_t* gb32 = reinterpret_cast<const uint32_t*>(gb);
-        uint32_t* lb32 = reinterpret_cast<uint32_t*>(l_bin);
-        for (int i = tid; i < (ncell + 2) / 2; i += CS_THREADS) lb32[i] = gb32[i];
-    }
-    if (tid < 4) lc[tid] = 0;
-    if (tid < 8) li[tid] = (tid == 7) ? 1 : 0;                                 // block 1 serves tile 1 first (seq = li[1][3])
-    __syncthreads();
+        if (tid < (rk & 3)) {
+            const int j = rk4 + tid;
+            l_start[j] = gs[j]; l_row[j] = gr[j];
+            l_end[j] = ge[2 * j]; l_pmx[j + 1] = ge[2 * j + 1];
+        }
+        if (tid < 4) l_start[rk + tid] = INT32_MAX;
+        if (tid < 16) l_end[rk + tid] = INT32_MIN;
+        if (tid == 0) l_pmx[0] = pm0;
+    };
 
     uint32_t* stw = l_stage + wv * A.wcap;                                     // this wavefront's staging entries
     int32_t* qrw = l_qrow + wv * CS_WTILE;                                     // this wavefront's probe rows of the tile
@@ -1216,7 +1260,123 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
 
     // records of the tile: wavefront wv owns the contiguous probes [wv * 256, (wv + 1) * 256), item j of lane l = wv * 256 + j * 64 + l
     // (lb > 0: 8-byte records {(end - slice minimum) << lb | (end - start), row}, unpacked in match_tile; uniform)
-    const int lb = A.meta[CS_META_FMT];
+    const int lb = __builtin_amdgcn_readfirstlane(ca()->meta[CS_META_FMT]);
+    // The run loop's own state lives in LDS, not in scalar registers (the tile loops need every one of those), and run i + 1 is prepared by
+    // the FIRST WAVEFRONT TO FINISH run i, while the others still work on their last tiles: drawing a group from the list cursors, the
+    // items' (bucket, chunk) entries, the bucket's bounds and the slice's metadata are a chain of four dependent memory round trips -- in
+    // front of every run they cost 5 us of an idle CU, and on one wavefront at the START of a run they delay every tile of it (a tile's
+    // output range is reserved when its LAST wavefront arrives).
+    //   l_item = {first item of the group in hand, its items, items already taken, lists given up | a draw happened << 8, bucket of the
+    //            slice in LDS, own cursor after the last draw, wavefronts that finished the run, items of the list} (the preparing lane only);
+    //   l_next = the next run: {1 | stage the slice << 1 (-1: no more work, -2: this workgroup never had any), first item, bucket, -,
+    //            q0, q1 (64 bits each), the slice's two metadata quads}, written behind barrier (B) of run i, read behind barrier (T) of run i + 1
+    int* l_item = li + 8;
+    int* l_next = li + 16;
+    auto prepare_next = [&]() {                                                 // one lane
+        // (three dependent memory round trips, ~ 2 us each under load: the cursor's atomic, the group's list entries at once, the run's
+        // bounds and slice metadata at once -- the list length is kept in LDS and a cursor's position is guessed from the last draw)
+        const cs_largs_t P = ca();
+        int g_v0 = l_item[0], g_cnt = l_item[1], g_i = l_item[2];
+        const int2* wm = P->wg_map;
+        if (g_i >= g_cnt) {
+            int v0 = -1, cnt = 0;
+            const int total_wg = l_item[7];
+            const int per = (total_wg + 7) / 8;
+            int victim = l_item[3] & 255;
+            const int drew = l_item[3] >> 8;
+            uint32_t* cur = P->cursor;
+            if (cur) {
+                const int home = (int)(__builtin_amdgcn_s_getreg(63508) & 7u);  // XCC_ID: the list this CU serves first
+                const int pgrain = P->pgrain, pmax = P->pmax;
+                int seen = victim == 0 ? l_item[5] : 0;                         // own list: at least what the last draw saw
+                while (victim < 8) {
+                    const int x = (home + victim) & 7;
+                    const int lo = x * per;
+                    const int len = per < total_wg - lo ? per : total_wg - lo;
+                    if (len > 0 && seen < len) {
+                        int m = 1;
+                        if (victim == 0) { m = (len - seen) / pgrain; m = m < 1 ? 1 : (m > pmax ? pmax : m); }
+                        const int t = (int)atomicAdd(cur + x, (uint32_t)m);
+                        if (t < len) { v0 = lo + t; cnt = m < len - t ? m : len - t; l_item[5] = t + m; break; }
+                    }
+                    ++victim; seen = 0;
+                }
+            } else if (!drew) {
+                const int ws = (int)(blockIdx.x >> 3);
+                const int vv = (int)(blockIdx.x & 7) * per + ws;
+                if (ws < per && vv < total_wg) { v0 = vv; cnt = 1; }
+            }
+            l_item[0] = v0; l_item[1] = cnt; l_item[3] = victim | ((drew || v0 >= 0) ? 256 : 0);
+            g_v0 = v0; g_cnt = cnt; g_i = 0;
+            if (v0 < 0) { l_next[0] = (!cur && !drew) ? -2 : -1; return; }
+        }
+        const int vv = g_v0 + g_i;
+        const int left = g_cnt - g_i;
+        // the group's consecutive items of one bucket are ONE run (entries read four at a time)
+        const int2 bc = wm[vv];
+        int nch = 1;
+        for (int b0 = 1; b0 < left; b0 += 4) {
+            int kx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kx[u] = b0 + u < left ? wm[vv + b0 + u].x : -1;
+            int same = 0;
+#pragma unroll
+            for (int u = 3; u >= 0; --u) same = kx[u] == bc.x ? same + 1 : 0;   // (leading entries of this bucket)
+            nch += same;
+            if (same < 4) break;
+        }
+        l_item[2] = g_i + nch;
+        const int jc = P->jchunk;
+        const uint32_t* be = P->bend;
+        const uint32_t* bs = P->bstart;
+        const uint32_t bs0 = bs[bc.x], be0 = be ? be[bc.x] : bs[bc.x + 1];
+        const int4 m0 = P->smeta[2 * bc.x], m1 = P->smeta[2 * bc.x + 1];
+        const int64_t a0 = (int64_t)bs0 + (int64_t)bc.y * jc;
+        const int64_t qe = a0 + (int64_t)nch * jc;
+        const int64_t a1 = qe < (int64_t)be0 ? qe : (int64_t)be0;
+        l_next[0] = 1 | (bc.x != l_item[4] ? 2 : 0); l_next[1] = vv; l_next[2] = bc.x;
+        l_next[4] = (int)(uint32_t)a0; l_next[5] = (int)(a0 >> 32); l_next[6] = (int)(uint32_t)a1; l_next[7] = (int)(a1 >> 32);
+        *reinterpret_cast<int4*>(l_next + 8) = m0; *reinterpret_cast<int4*>(l_next + 12) = m1;
+        l_item[4] = bc.x;
+    };
+    auto end_run = [&]() {
+        if (lane == 0 && atomicAdd(&l_item[6], 1) == 0) {
+            unsigned long long* tr = ca()->trace;
+            if (tr) tr[6 * (size_t)v + 4] = wall_clock64();
+            prepare_next();
+            if (tr) tr[6 * (size_t)v + 5] = wall_clock64();
+        }
+    };
+    if (tid == 0) { l_item[0] = -1; l_item[1] = 0; l_item[2] = 0; l_item[3] = 0; l_item[4] = -1; l_item[5] = 0; l_item[6] = 0; l_item[7] = ca()->meta[0]; }
+    __syncthreads();
+    for (;;) {
+        end_run();                                                              // (the first wavefront to get here prepares the next run -- or the first one)
+        __syncthreads();                                                        // (T) every wavefront has left the previous run; l_next is this run
+        auto rf = [&](int i) { return __builtin_amdgcn_readfirstlane(l_next[i]); };
+        const int flag = rf(0);
+        if (flag < 0) {
+            if (flag == -2) return;                                             // (a workgroup beyond the list: it never takes a ticket)
+            break;
+        }
+        v = rf(1); k = rf(2);
+        q0 = (int64_t)(((uint64_t)(uint32_t)rf(5) << 32) | (uint32_t)rf(4));
+        q1 = (int64_t)(((uint64_t)(uint32_t)rf(7) << 32) | (uint32_t)rf(6));
+        smin = rf(8); bshift = rf(9); ncell = rf(10); pm0 = rf(11);
+        seg_a = rf(12); rk = rf(14); r0 = rf(15);
+        cs_trace(ca()->trace, v, 0);
+        tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (flag & 2) stage_slice();
+        tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                                           // (again: nothing the tile loops derive from it is alive during the staging)
+        lane = tid & (kWave - 1); wv = tid / kWave;
+        stw = l_stage + wv * A.wcap; qrw = l_qrow + wv * CS_WTILE;
+        if (tid < 4) { unsigned long long z = 0; asm volatile("" : "+v"(z)); lc[tid] = z; }   // (made here: hoisted out of the run loop the zero pair was spilled)
+        if (tid < 8) li[tid] = (tid == 7) ? 1 : 0;                             // block 1 serves tile 1 first (seq = li[1][3])
+        if (tid == 0) l_item[6] = 0;                                            // (wavefronts that have finished the run in hand)
+        __syncthreads();                                                        // (B)
+        cs_trace(ca()->trace, v, 1);
+        // (the tile state is declared per run: at function scope its registers were carried from run to run -- through the staging, which spilled)
     cs_rec nxt[CS_ITEMS];
     auto load_tile = [&](int64_t tb) {
         const int rem = (int)((q1 - tb) < (int64_t)CS_TILE ? (q1 - tb) : (int64_t)CS_TILE);
@@ -1344,7 +1504,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
                     for (int p = r0 + hi[j] - 1; p >= seg_a; --p) {
                         const int i = p - r0;
                         int2 vv = make_int2(l_end[i < 0 ? 0 : i], l_pmx[i < 0 ? 1 : i + 1]);
-                        if (i < 0) vv = A.ep[p];
+                        if (i < 0) vv = ca()->ep[p];
                         if (!lt_op<STRICT>(qs[j], vv.y)) break;
                         c2 += lt_op<STRICT>(qs[j], vv.x) ? 1 : 0;
                     }
@@ -1354,11 +1514,12 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
         }
     };
 
+
     if constexpr (MODE != CS_FUSED) {
         // deterministic pair: slot of (workgroup v, tile tix, wavefront wv); every wavefront works on its own
         load_tile(q0);
         const int ntile = (int)((q1 - q0 + CS_TILE - 1) / CS_TILE);
-        const int tiles_per_chunk = A.jchunk / CS_TILE;
+        const int tiles_per_chunk = __builtin_amdgcn_readfirstlane(ca()->jchunk) / CS_TILE;
         for (int tix = 0; tix < ntile; ++tix) {
             match_tile(q0 + (int64_t)tix * CS_TILE);
             const long long slot = ((long long)v * tiles_per_chunk + tix) * CS_WAVES + wv;
@@ -1430,10 +1591,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
                         for (int p = r0 + hi[j] - 1; o >= off; --p) {
                             const int i = p - r0;
                             int32_t ev = l_end[i < 0 ? 0 : i];
-                            if (i < 0) ev = A.ep[p].x;
+                            if (i < 0) ev = ca()->ep[p].x;
                             if (lt_op<STRICT>(qs[j], ev)) {
                                 int32_t rv = l_row[i < 0 ? 0 : i];
-                                if (i < 0) rv = A.b_row[p];
+                                if (i < 0) rv = ca()->b_row[p];
                                 A.out_probe[o] = qrow[j]; A.out_build[o] = rv; --o;
                             }
                         }
@@ -1442,7 +1603,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
                 }
             }
         }
-        return;
+        continue;                                                              // (the next run)
     }
     // Barrier-free tile loop (protocol of slice.hip.h's fused mode): a wavefront's pairs of a tile are contiguous in the
     // tile's output range at the offset a returning LDS atomic on the tile's cursor gives it; the LAST wavefront to arrive
@@ -1552,10 +1713,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
                         for (int p = r0 + hi[j] - 1; o >= off; --p) {
                             const int i = p - r0;
                             int32_t ev = l_end[i < 0 ? 0 : i];
-                            if (i < 0) ev = A.ep[p].x;
+                            if (i < 0) ev = ca()->ep[p].x;
                             if (lt_op<STRICT>(qs[j], ev)) {
                                 int32_t rv = l_row[i < 0 ? 0 : i];
-                                if (i < 0) rv = A.b_row[p];
+                                if (i < 0) rv = ca()->b_row[p];
                                 A.out_probe[o] = qrow[j]; A.out_build[o] = rv; --o;
                             }
                         }
@@ -1567,7 +1728,9 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
         } else pend_wtot = 0;
         pend_woff = woff;
     }
-    cs_publish_state(A, total_wg);
+    if (ca()->trace) { end_run(); __syncthreads(); cs_trace(ca()->trace, v, 2); }   // (end_run: only the first call of a run prepares)         // (diagnosis runs only: every wavefront has finished its tiles)
+    }                                                                          // (runs of this workgroup)
+    cs_publish_state(ca()->hw, ca()->hw_seq, ca()->done, A.state, ca()->cursor ? (int)gridDim.x : ca()->meta[0]);
 }
 
 template <bool STRICT, int MODE>

@@ -68,7 +68,7 @@ int cs_ensure_tables(ivj_ctx* ctx, ivj_index* ix, const CsSampleArgs* sample = n
     // (cs_prep_zero: the fused call that launches the tables clears its state words and sample histogram in this kernel)
     const bool pz = ctx->cs_prep_zero && sample != nullptr;
     LAUNCH(ctx, "cs_prep", k_cs_prep, 1, CS_THREADS, (const int32_t*)ix->seg, (const int32_t*)ix->b_start, g, ix->cs_bound, ix->cs_spl, ix->cs_cm, ix->cs_cell,
-           pz ? reinterpret_cast<uint32_t*>(ctx->sl_meta + 4) : (uint32_t*)nullptr, pz ? 8 : 0, pz ? ctx->sl_gh : (uint32_t*)nullptr, pz ? g.nb + 4 : 0);
+           pz ? reinterpret_cast<uint32_t*>(ctx->sl_meta + 4) : (uint32_t*)nullptr, pz ? 16 : 0, pz ? ctx->sl_gh : (uint32_t*)nullptr, pz ? g.nb + 4 : 0);
     const size_t lds = (size_t)4 * g.R + (size_t)2 * (2 * g.R + 8);
     if (sample) {
         const CsTab tab{ix->cs_spl, ix->cs_cm, ix->cs_cell};
@@ -347,9 +347,27 @@ int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     A.cache = (MODE == CS_FUSED || ctx->cs_env_nocache) ? nullptr : ctx->sl_cache;
     A.out_probe = out_p; A.out_build = out_b;
     A.hw = nullptr; A.hw_seq = 0; A.done = reinterpret_cast<uint32_t*>(ctx->sl_meta + 10);
+    A.trace = nullptr;
+    // persistent workgroups of the plain join (one per CU) draw their items from sl_meta[12..19], cleared with the call's state words;
+    // the FILL launch of a pair follows a COUNT launch that used them
+    const bool persist = !ix->cs_walk && ctx->cs_env_persist != 0 && ctx->n_cus > 0;
+    A.cursor = persist ? reinterpret_cast<uint32_t*>(ctx->sl_meta + 12) : nullptr;
+    A.pmax = ctx->cs_env_pmax > 0 ? ctx->cs_env_pmax : 4;
+    A.pgrain = ctx->cs_env_pgrain > 0 ? ctx->cs_env_pgrain : 64;
+    if (persist && MODE == CS_FILL) HIP_TRY(hipMemsetAsync(ctx->sl_meta + 12, 0, 32, ctx->stream));
+    if (MODE == CS_FUSED && ctx->cs_env_wgtrace && !ix->cs_walk) {            // diagnosis: one record per workgroup, dumped after the call
+        if (ctx->cs_trace_cap < (size_t)P.gmax) {
+            if (ctx->cs_trace_buf) HIP_TRY(hipFree(ctx->cs_trace_buf));
+            ctx->cs_trace_buf = nullptr; ctx->cs_trace_cap = 0;
+            HIP_TRY(hipMalloc((void**)&ctx->cs_trace_buf, (size_t)P.gmax * 48));
+            ctx->cs_trace_cap = (size_t)P.gmax;
+        }
+        HIP_TRY(hipMemsetAsync(ctx->cs_trace_buf, 0, (size_t)P.gmax * 48, ctx->stream));
+        A.trace = ctx->cs_trace_buf;
+    }
     ctx->cs_fused_hw_seq = 0;
     if (MODE == CS_FUSED && ctx->hw) { A.hw = ctx->hw_dev; A.hw_seq = ctx->cs_fused_hw_seq = ++ctx->hw_seq; }
-    const unsigned grid = 8u * (unsigned)((P.gmax + 7) / 8);
+    const unsigned grid = persist ? (unsigned)std::min(ctx->n_cus, 8 * ((P.gmax + 7) / 8)) : 8u * (unsigned)((P.gmax + 7) / 8);
     t_begin(ctx, MODE == CS_FUSED ? "cs_join_fused" : (MODE == CS_COUNT ? "cs_join_count" : "cs_join_fill"));
     const bool strict = opts->filter_op == IVJ_FILTER_STRICT;
     if (ix->cs_walk) {                                     // a tail of long build rows: windows that run on walk the block maxima
@@ -361,6 +379,15 @@ int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     }
     t_end(ctx);
     HIP_TRY(hipGetLastError());
+    if (A.trace) {                                         // (synchronous on purpose: a diagnosis run)
+        std::vector<unsigned long long> h((size_t)P.gmax * 6);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(h.data(), ctx->cs_trace_buf, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(ctx->cs_env_wgtrace, "ab")) {
+            const unsigned long long head[4] = {0x57475452ull, (unsigned long long)P.gmax, (unsigned long long)P.jchunk, (unsigned long long)g.nb};
+            std::fwrite(head, 8, 4, f); std::fwrite(h.data(), 8, h.size(), f); std::fclose(f);
+        }
+    }
     return IVJ_OK;
 }
 
@@ -389,7 +416,7 @@ int cs_overlap_fused(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     // also launches the index's slice tables has k_cs_prep clear these words and the sample histogram (two fills less in the stream).
     struct PrepZero { ivj_ctx* c; ~PrepZero() { c->cs_prep_zero = false; } } prep_zero_scope{ctx};
     ctx->cs_prep_zero = ctx->hw != nullptr && !ix->cs_built && ctx->cs_env_fuse_sample != 0 && cs_sampled_wanted(ctx, probe->n, false);
-    if (!ctx->cs_prep_zero) HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 32, ctx->stream));
+    if (!ctx->cs_prep_zero) HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 64, ctx->stream));           // state, format, finished workgroups, the join's list cursors
     IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, false));
     if (ctx->sl_env_ablate & (256 | 1024 | 2048)) { *n_pairs = 0; HIP_TRY(hipStreamSynchronize(ctx->stream)); return IVJ_OK; }   // profiling: the records are not usable
     IVJ_TRY(cs_join_launch<CS_FUSED>(ctx, ix, opts, P, (long long)capacity, out_p, out_b));
@@ -437,7 +464,7 @@ int cs_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const i
     const bool stable = opts->deterministic != 0 || ctx->sl_env_stable != 0;
     IVJ_TRY(ensure_sl(ctx, probe->n, P, cs_sampled_wanted(ctx, probe->n, stable) ? cs_record_capacity(ctx, ix->cs_g, probe->n) : 0));
     ctx->sl_plan_valid = false;
-    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 32, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->sl_meta + 4, 0, 64, ctx->stream));           // state, format, finished workgroups, the join's list cursors
     IVJ_TRY(cs_partition(ctx, ix, probe, opts, P, stable));
     HIP_TRY(hipMemsetAsync(ctx->sl_tile, 0, (size_t)(P.ntiles + 2) * 8, ctx->stream));
     IVJ_TRY(cs_join_launch<CS_COUNT>(ctx, ix, opts, P, 0, nullptr, nullptr));
@@ -473,7 +500,7 @@ int cs_fill_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     A.state = reinterpret_cast<unsigned long long*>(ctx->sl_meta + 4);
     A.wslot = ctx->sl_tile; A.cache = ctx->sl_cache;
     A.out_probe = out_p; A.out_build = out_b;
-    A.hw = nullptr; A.hw_seq = 0; A.done = nullptr;
+    A.hw = nullptr; A.hw_seq = 0; A.done = nullptr; A.trace = nullptr; A.cursor = nullptr; A.pmax = 1; A.pgrain = 1;
     const size_t fixed = (size_t)cs_fill_lds(g.R, 0).total;
     const size_t half = 80 * 1024, full = 160 * 1024;
     // staging entries per wavefront: a wavefront-tile of 256 probes emits ~2 pairs per probe on the benchmark shapes.  One

@@ -67,6 +67,7 @@ int ivj_ctx_create(int device, ivj_ctx** out) try {
     HIP_TRY(hipSetDevice(device));
     ivj_ctx* ctx = new ivj_ctx();
     ctx->device = device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) ctx->n_cus = cus; }
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(IVJ_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     ctx->stream = ctx->own_stream;
@@ -82,6 +83,10 @@ int ivj_ctx_create(int device, ivj_ctx** out) try {
     if (const char* ev = std::getenv("IVJ_CS")) ctx->cs_env_off = std::atoi(ev) == 0 ? 1 : 0;
     if (const char* ev = std::getenv("IVJ_CS_PTILE")) ctx->cs_env_ptile = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_NOCACHE")) ctx->cs_env_nocache = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_CS_PERSIST")) ctx->cs_env_persist = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_CS_PMAX")) ctx->cs_env_pmax = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_CS_PGRAIN")) ctx->cs_env_pgrain = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_CS_WGTRACE")) ctx->cs_env_wgtrace = ev[0] ? ev : nullptr;
     if (const char* ev = std::getenv("IVJ_CS_SAMPLED")) ctx->cs_env_sampled = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_SLACK")) ctx->cs_env_slack = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_REC8")) ctx->cs_env_rec8 = std::atoi(ev);
@@ -138,6 +143,7 @@ void ivj_ctx_destroy(ivj_ctx* ctx) {
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->ov_buf) (void)hipFree(ctx->ov_buf);
     if (ctx->sl_buf) (void)hipFree(ctx->sl_buf);
+    if (ctx->cs_trace_buf) (void)hipFree(ctx->cs_trace_buf);
     if (ctx->lb_buf) (void)hipFree(ctx->lb_buf);
     for (auto& cb : ctx->st_cache) free_stream_bufs(cb);
     if (ctx->ix_cache) (void)hipFree(ctx->ix_cache);
