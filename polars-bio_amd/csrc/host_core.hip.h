@@ -170,6 +170,7 @@ struct ivj_ctx {
     int cs_env_nocache = 0;            // IVJ_CS_NOCACHE=1: the FILL pass matches again instead of reading COUNT's words (A/B runs)
     int cs_env_persist = 1;            // IVJ_CS_PERSIST=0: one join workgroup per list item instead of persistent ones (rounds 3-5; A/B runs)
     int cs_env_pmax = 0, cs_env_pgrain = 0;   // IVJ_CS_PMAX / IVJ_CS_PGRAIN: items per draw of a persistent workgroup (defaults 4 / 64)
+    int cs_env_pchunks = 0;            // IVJ_CS_PCHUNKS: scatter workgroups of the wide-tile sampled partition (0: ~ 2048)
     int n_cus = 0;                     // compute units of the device
     const char* cs_env_wgtrace = nullptr;   // IVJ_CS_WGTRACE=<file>: the fused plain join records its workgroups' time line (diagnosis; tools/wgtrace.py)
     unsigned long long* cs_trace_buf = nullptr;

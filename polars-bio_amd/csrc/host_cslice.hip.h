@@ -189,6 +189,7 @@ int cs_plan(const ivj_ctx* ctx, const ivj_index* ix, int64_t n, const ivj_opts* 
         const int64_t unit = P.part16 ? 12 * CS_TILE : 6 * CS_TILE;            // lcm(8192, 12288[, 16384])
         int64_t c12 = ((n + 2047) / 2048 + unit - 1) / unit * unit;
         if (c12 > 24 * CS_TILE) c12 = 24 * CS_TILE;
+        if (ctx->cs_env_pchunks > 0) c12 = std::max<int64_t>(unit, ((n + ctx->cs_env_pchunks - 1) / ctx->cs_env_pchunks + unit - 1) / unit * unit);   // IVJ_CS_PCHUNKS: ~ that many scatter workgroups
         P.chunk = (int)c12;
         P.nchunks = (int)((n + c12 - 1) / c12);
     }
@@ -350,7 +351,7 @@ int cs_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const Slic
     A.trace = nullptr;
     // persistent workgroups of the plain join (one per CU) draw their items from sl_meta[12..19], cleared with the call's state words;
     // the FILL launch of a pair follows a COUNT launch that used them
-    const bool persist = !ix->cs_walk && ctx->cs_env_persist != 0 && ctx->n_cus > 0;
+    const bool persist = !ix->cs_walk && ctx->cs_env_persist != 0 && ctx->n_cus > 0;   // (k_cs_join keeps one item per workgroup: the run loop costs it 27 spilled registers, config 2 0.227 -> 0.234 ms)
     A.cursor = persist ? reinterpret_cast<uint32_t*>(ctx->sl_meta + 12) : nullptr;
     A.pmax = ctx->cs_env_pmax > 0 ? ctx->cs_env_pmax : 4;
     A.pgrain = ctx->cs_env_pgrain > 0 ? ctx->cs_env_pgrain : 64;

@@ -84,6 +84,7 @@ int ivj_ctx_create(int device, ivj_ctx** out) try {
     if (const char* ev = std::getenv("IVJ_CS_PTILE")) ctx->cs_env_ptile = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_NOCACHE")) ctx->cs_env_nocache = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_PERSIST")) ctx->cs_env_persist = std::atoi(ev);
+    if (const char* ev = std::getenv("IVJ_CS_PCHUNKS")) ctx->cs_env_pchunks = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_PMAX")) ctx->cs_env_pmax = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_PGRAIN")) ctx->cs_env_pgrain = std::atoi(ev);
     if (const char* ev = std::getenv("IVJ_CS_WGTRACE")) ctx->cs_env_wgtrace = ev[0] ? ev : nullptr;

@@ -1469,3 +1469,52 @@ def test_scatter_on_12288_probe_tiles_matches_the_oracle(monkeypatch):
             e.dev_free(p)
     finally:
         e.close()
+
+
+def test_persistent_join_workgroups_match_the_oracle(monkeypatch):
+    """Round 6: k_cs_join_plain runs one PERSISTENT workgroup per CU; a workgroup draws groups of (bucket, chunk) list items from its
+    XCD's cursor (from the other XCDs' once its own list is empty), joins consecutive items of one bucket as one run over a slice staged
+    once, and the first wavefront to finish a run prepares the next.  Exact pairs against the oracle for the fused pass and for the
+    deterministic count -> fill pair (COUNT runs in the same kernel), Strict and Weak, over the knobs that change who joins what:
+    the default draw, one item per draw, draws of up to 16 items of one tile each (runs longer than the four list entries read at a
+    time), one item per workgroup (IVJ_CS_PERSIST=0, rounds 3-5) -- on a probe side with fewer list items than CUs x XCD lists
+    (most workgroups steal or find nothing) and on one with thousands of items."""
+    monkeypatch.setenv("IVJ_CS", "1")
+    cores = os.cpu_count() or 1
+    shapes = ((150_000, 60_000), (6_000_011, 900_000))
+    sides, exp = {}, {}
+    for np_, nb_ in shapes:
+        probe = synth.make_side(np_, 52, synth.PROBE_LEN, 24)
+        build = synth.make_side(nb_, 53, synth.BUILD_LEN, 24)
+        ix = O.Index(O.Side(*build), 24)
+        sides[np_] = (probe, build)
+        for strict in (True, False):
+            ep, eb = O.overlap_fast(ix, O.Side(*probe), strict, threads=cores)
+            oe = np.lexsort((eb, ep))
+            exp[np_, strict] = (ep[oe], eb[oe])
+    knobs = ({}, {"IVJ_CS_PMAX": "1"}, {"IVJ_CS_PMAX": "16", "IVJ_SLICE_CHUNK": "4096", "IVJ_CS_PGRAIN": "8"}, {"IVJ_CS_PERSIST": "0"})
+    for kn in knobs:
+        for k_, v_ in kn.items():
+            monkeypatch.setenv(k_, v_)
+        e = _engine.Engine(0)
+        try:
+            e.enable_timing(2)
+            for np_, nb_ in shapes:
+                probe, build = sides[np_]
+                for strict in (True, False):
+                    ep, eb = exp[np_, strict]
+                    e.timings()
+                    hp, hb = _fused_overlap(e, probe, build, strict, 24, 6, len(ep))
+                    t = e.timings()
+                    assert "cs_join_fused" in t, (kn, sorted(t))                 # the contig-aligned slice path ran
+                    o = np.lexsort((hb, hp))
+                    assert (hp[o] == ep).all() and (hb[o] == eb).all(), (kn, np_, strict, "fused")
+                    p1, b1 = e.overlap(probe, build, strict, 24, partition_mode=6, deterministic=True)
+                    p2, b2 = e.overlap(probe, build, strict, 24, partition_mode=6, deterministic=True)
+                    assert (p1 == p2).all() and (b1 == b2).all(), (kn, np_, strict, "pair: run to run")
+                    o = np.lexsort((b1, p1))
+                    assert len(p1) == len(ep) and (p1[o] == ep).all() and (b1[o] == eb).all(), (kn, np_, strict, "pair")
+        finally:
+            e.close()
+        for k_ in kn:
+            monkeypatch.delenv(k_)
