@@ -39,6 +39,8 @@ constexpr int CS_POS_BIAS = 1 << 23;                    // staging entries carry
 static_assert((long long)SL_MAX_BUCKETS * SL_MAX_ROWS <= CS_POS_BIAS, "an index of this path must fit a staging entry's row field");
 constexpr int CS_BIN_STRIDE_PAD = 2;                    // bins per slice in global memory: 2 R + 2 (u16)
 
+constexpr int CS_CUR_STRIDE = 1;                        // words between two region cursors (32 = one cursor per 128-byte line: measured, no change -- the
+                                                        // latency of the returning atomics, 8 - 11 us under load, does not come from lines shared by cursors)
 constexpr int CS_META_FMT = 8;                          // meta[8]: record format of the call (k_cs_regions): 0 = 12-byte records, LB > 0 = 8-byte records
 constexpr unsigned long long CS_STATE_REC8 = 8ull;     // state word, value 8 (bit 3): a probe did not fit the 8-byte record form
 constexpr int CS_REC8_GIVE_UP = 3;                      // overflows in a row after which a context stops offering the 8-byte form (host_cslice.hip.h)
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter(CsTab tab, CsGeom g, 
             if (b < nbk) {
                 lstart[b] = (uint32_t)pre;
                 if constexpr (SAMPLED) {
-                    if (x[q] > 0 && b < g.nb) got[q] = atomicAdd(&rcur[b], (uint32_t)x[q]);
+                    if (x[q] > 0 && b < g.nb) got[q] = atomicAdd(&rcur[(size_t)b * CS_CUR_STRIDE], (uint32_t)x[q]);
                 } else { delta[b] = base[b] - (uint32_t)pre; base[b] += (uint32_t)x[q]; }
             }
             pre += x[q];
@@ -545,7 +547,8 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
                                                              const int32_t* __restrict__ pe, const int32_t* __restrict__ row_id, int64_t n,
                                                              int chunk, int nchunks, bool vec_ok, const uint32_t* __restrict__ rstart,
                                                              uint32_t* __restrict__ rcur, unsigned long long* __restrict__ state,
-                                                             const int32_t* __restrict__ meta, int32_t* __restrict__ out, int ablate) {
+                                                             const int32_t* __restrict__ meta, int32_t* __restrict__ out, int ablate,
+                                                             unsigned long long* __restrict__ ptrace /* IVJ_CS_PTRACE (diagnosis): phase stamps of every workgroup's second tile */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cs_lds[];
     constexpr int TILE = CS_THREADS * PITEMS;
     constexpr bool RUNS = PITEMS == 16;                                         // 16 384-probe tiles: 2-byte row plane, copy-out by bucket runs (no row ids)
@@ -601,6 +604,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
     int tix = 0;
     for (int64_t tbase = cbase; tbase < cend; tbase += TILE, ++tix) {
         const int tile_n = (int)((cend - tbase) < (int64_t)TILE ? (cend - tbase) : (int64_t)TILE);
+        if (ptrace && (tix == 1 || tix == 2) && tid == 0) ptrace[8 * (size_t)blockIdx.x + (tix == 1 ? 0 : 5)] = wall_clock64();
         // packed record word; bucket | rank << 11.  RUNS (16 probes per lane): the word is built at PLACEMENT time from the columns, which
         // stay in their registers until then, and the next tile's columns are requested after the placement (their flight overlaps the
         // copy-out and the tile's last barrier) -- sixteen packed words next to sixteen prefetched probes do not fit 128 registers
@@ -630,6 +634,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                                        // (A) bucket counts of the tile complete
+        if (ptrace && tix == 1 && tid == 0) ptrace[8 * (size_t)blockIdx.x + 1] = wall_clock64();
         // (the lane's index is made opaque once per tile: per-lane addresses derived from it -- the region cursors' 64-bit ones, the 3 x 12
         // LDS addresses of the copy-out -- are otherwise loop invariants the compiler keeps in registers across the tile loop, and spills)
         int tv = tid;
@@ -671,11 +676,12 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
                 // split-phase: the cursor's answer and the region's bounds (global memory: this form keeps no LDS copy of them) are
                 // requested here and used after the placement
                 r_at[q] = rstart[b < g.nb ? b : g.nb];
-                if (x[q] > 0 && b < g.nb) { r_cap[q] = rstart[b + 1]; got[q] = atomicAdd(&rcur[b], (uint32_t)x[q]); }
+                if (x[q] > 0 && b < g.nb) { r_cap[q] = rstart[b + 1]; got[q] = atomicAdd(&rcur[(size_t)b * CS_CUR_STRIDE], (uint32_t)x[q]); }
             }
             pre += x[q];
         }
         __syncthreads();                                                        // (C)
+        if (ptrace && tix == 1 && tid == 0) ptrace[8 * (size_t)blockIdx.x + 2] = wall_clock64();
 #pragma unroll
         for (int h = 0; h < PITEMS / 4; ++h) {
             const int e0 = h * (CS_THREADS * 4) + tv * 4;
@@ -706,6 +712,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
                 }
             }
         }
+        if (ptrace && tix == 1 && tid == 0) ptrace[8 * (size_t)blockIdx.x + 6] = wall_clock64();
         if constexpr (RUNS) {
             __builtin_amdgcn_sched_barrier(0);
             if (tbase + TILE < cend) load_tile(tbase + TILE);                  // (the columns were consumed by the placement)
@@ -725,7 +732,9 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
                 delta[b] = at - (uint32_t)pre;
             }
         }
+        if (ptrace && tix == 1 && tid == 0) ptrace[8 * (size_t)blockIdx.x + 7] = wall_clock64();
         __syncthreads();                                                        // (D) tile sorted in LDS
+        if (ptrace && tix == 1 && tid == 0) ptrace[8 * (size_t)blockIdx.x + 3] = wall_clock64();
         if constexpr (RUNS) {
             // copy-out by RUNS: sixteen lanes per bucket run, four runs per wavefront step (a run holds ~ 16 records at 1040 buckets);
             // bucket g.nb (no candidate row) is never copied
@@ -754,6 +763,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
         }
         }
         // no barrier here: the next tile's barrier (A) separates this copy-out from the next placement
+        if (ptrace && tix == 1 && tid == 0) ptrace[8 * (size_t)blockIdx.x + 4] = wall_clock64();
     }
 }
 
@@ -869,10 +879,10 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_regions(const uint32_t* __res
 #pragma unroll
     for (int q = 0; q < OWN; ++q) {
         const int b = OWN * threadIdx.x + q;
-        if (b < nb) { rstart[b] = (uint32_t)pre; rcur[b] = 0u; }
+        if (b < nb) { rstart[b] = (uint32_t)pre; rcur[(size_t)b * CS_CUR_STRIDE] = 0u; }
         pre += cap[q];
     }
-    if (threadIdx.x == 0) { rstart[nb] = (uint32_t)total; rcur[nb] = 0u; }
+    if (threadIdx.x == 0) { rstart[nb] = (uint32_t)total; rcur[(size_t)nb * CS_CUR_STRIDE] = 0u; }
 }
 
 // chunk table of the join from the regions and their final cursors (k_slice_chunks' counterpart): bstart / bend per bucket, the
@@ -891,7 +901,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_cs_chunks_sampled(const uint32_t
         if (b <= nb) {
             const uint32_t s = rstart[b];
             uint32_t c = 0;
-            if (b < nb) { const uint32_t cap = rstart[b + 1] - s; c = rcur[b] < cap ? rcur[b] : cap; }
+            if (b < nb) { const uint32_t cap = rstart[b + 1] - s; const uint32_t cu = rcur[(size_t)b * CS_CUR_STRIDE]; c = cu < cap ? cu : cap; }
             bstart[b] = s; bend[b] = s + c;
             if (b == nb) { bstart[nb + 1] = s; bend[nb + 1] = s; }
             if (b < nb) cnt2[k] = (int)((c + (uint32_t)jchunk - 1u) / (uint32_t)jchunk);

@@ -280,10 +280,26 @@ int cs_partition(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_o
                 const size_t ldsw = (size_t)cs_part12_lds(g.nb, g.ncells, g.n_contigs, wide).total;
 #define IVJ_CS_SCATTER_W(S, I)                                                                                                          \
     hipLaunchKernelGGL((k_cs_scatter12k<S, I>), dim3(P.nchunks), dim3(CS_THREADS), ldsw, ctx->stream, tab, g, probe->contig, probe->start, probe->end, probe->row_id, n, \
-                       P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_rstart, ctx->sl_rcur, state, (const int32_t*)ctx->sl_meta, rec, ctx->sl_env_ablate)
+                       P.chunk, P.nchunks, vec, (const uint32_t*)ctx->sl_rstart, ctx->sl_rcur, state, (const int32_t*)ctx->sl_meta, rec, ctx->sl_env_ablate, ptrace)
+                unsigned long long* ptrace = nullptr;                           // IVJ_CS_PTRACE=<file> (diagnosis; tools/ptrace.py): phase stamps of the scatter's tiles
+                const char* ptrace_path = std::getenv("IVJ_CS_PTRACE");
+                if (ptrace_path && ptrace_path[0]) {
+                    HIP_TRY(hipMalloc((void**)&ptrace, (size_t)P.nchunks * 64));
+                    HIP_TRY(hipMemsetAsync(ptrace, 0, (size_t)P.nchunks * 64, ctx->stream));
+                }
                 if (strict) { if (wide == 16) IVJ_CS_SCATTER_W(true, 16); else IVJ_CS_SCATTER_W(true, 12); }
                 else { if (wide == 16) IVJ_CS_SCATTER_W(false, 16); else IVJ_CS_SCATTER_W(false, 12); }
 #undef IVJ_CS_SCATTER_W
+                if (ptrace) {
+                    std::vector<unsigned long long> h((size_t)P.nchunks * 8);
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    HIP_TRY(hipMemcpy(h.data(), ptrace, h.size() * 8, hipMemcpyDeviceToHost));
+                    (void)hipFree(ptrace);
+                    if (FILE* f = std::fopen(ptrace_path, "ab")) {
+                        const unsigned long long head[4] = {0x50545243ull, (unsigned long long)P.nchunks, (unsigned long long)P.chunk, (unsigned long long)wide};
+                        std::fwrite(head, 8, 4, f); std::fwrite(h.data(), 8, h.size(), f); std::fclose(f);
+                    }
+                }
             }
             else if (strict) { if (P.part_items == 8) IVJ_CS_SCATTER_S(true, 8, true); else IVJ_CS_SCATTER_S(true, 4, true); }
             else { if (P.part_items == 8) IVJ_CS_SCATTER_S(false, 8, true); else IVJ_CS_SCATTER_S(false, 4, true); }

@@ -105,7 +105,7 @@ int slice_plan(const ivj_index* ix, int64_t n, const ivj_opts* opts, const Slice
 int ensure_sl(ivj_ctx* ctx, int64_t n, const SlicePlan& P, int64_t rec_cap = 0) {
     const size_t hist = (size_t)(P.g.nb + 1) * (size_t)P.nchunks;
     const size_t rc = (size_t)(rec_cap > n ? rec_cap : n);
-    const size_t need = align_up(rc * 16) + align_up(rc * 8) + 4 * align_up((size_t)(P.g.nb + 4) * 4) + align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4) +
+    const size_t need = align_up(rc * 16) + align_up(rc * 8) + 3 * align_up((size_t)(P.g.nb + 4) * 4) + align_up((size_t)(P.g.nb + 4) * 4 * CS_CUR_STRIDE) + align_up(hist * 4) + align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4) +
                         align_up((size_t)(P.g.nb + 2) * 4) + align_up(64) + align_up((size_t)P.gmax * 8) +
                         align_up((size_t)(P.ntiles + 2) * 8) + align_up((size_t)(scan_num_tiles(P.ntiles) + 2) * 8) + 4096;
     if (need > ctx->sl_cap) {
@@ -125,7 +125,7 @@ int ensure_sl(ivj_ctx* ctx, int64_t n, const SlicePlan& P, int64_t rec_cap = 0) 
     ctx->sl_cache = (uint2*)p; p += align_up(rc * 8);          // COUNT -> FILL words of the contig-aligned pair (cslice.hip.h)
     ctx->sl_gh = (uint32_t*)p; p += align_up((size_t)(P.g.nb + 4) * 4);         // sampled partition: sample histogram,
     ctx->sl_rstart = (uint32_t*)p; p += align_up((size_t)(P.g.nb + 4) * 4);     //   region starts,
-    ctx->sl_rcur = (uint32_t*)p; p += align_up((size_t)(P.g.nb + 4) * 4);       //   region cursors,
+    ctx->sl_rcur = (uint32_t*)p; p += align_up((size_t)(P.g.nb + 4) * 4 * CS_CUR_STRIDE);   //   region cursors (one per 128-byte line),
     ctx->sl_bend = (uint32_t*)p; p += align_up((size_t)(P.g.nb + 4) * 4);       //   bucket ends
     ctx->sl_blk = (uint32_t*)p; p += align_up(hist * 4);
     ctx->sl_part = (uint32_t*)p; p += align_up((size_t)(scan_num_tiles((int64_t)hist) + 1) * 4);
