@@ -12,6 +12,7 @@ NAMES = {
     "c1": "bench_overlap_1k_1k", "c3fd": "bench_overlap_100M_5M_multi_rank_path_world1", "c3m1": "bench_overlap_100M_5M_mode1_window_scan",
     "c3m6": "bench_overlap_100M_5M_mode6_slices", "c2": "bench_overlap_10M_1M", "c4": "bench_nearest_50M_2M", "c5": "bench_count_200M_200k",
     "c3dense": "bench_overlap_100M_5M_dense", "c3rows": "bench_overlap_100M_5M_rows",
+    "c4fd": "bench_nearest_50M_2M_multi_rank_path_world1", "c5fd": "bench_count_200M_200k_multi_rank_path_world1",
     "sortscan_coverage_100M_5M_24contig": "bench_coverage_100M_5M", "sortscan_subtract_20M_5M_24contig": "bench_subtract_20M_5M",
     "sortscan_merge_100M_24contig": "bench_merge_100M",
 }
@@ -58,6 +59,10 @@ def main():
                            (f"{tag}_pmctcc_WL_overlap_100M_5M_24contig.summary.json", "pmc_tcc_overlap_100M_5M.json", "`rocprofv3 --kernel-trace --pmc` L2 <-> fabric request counters by size (TCC_EA0_RDREQ / _32B / _64B / _128B, WRREQ / _64B, DRAM, TCC hit / miss; `tools/gpu_r04.sh pmctcc`), config 3, per kernel, mean per launch"),
                            (f"{tag}_pmctcc_WL_nearest_50M_2M_24contig.summary.json", "pmc_tcc_nearest_50M_2M.json", "the same request-size passes for config 4"),
                            (f"{tag}_pmctcc.summary.json", "pmc_tcc_count_200M_200k.json", "the same request-size passes for config 5 (the evidence behind its 14.6 GB of `traffic`: 101.6 M fabric reads, ALL of them 128-byte requests)"),
+                           (f"{tag}_wgtrace.txt", "wgtrace_join_persistent.txt", "`tools/wgtrace.py` (IVJ_CS_WGTRACE): time line of the fused join's persistent workgroups, config 3 -- runs per CU, staging share, gaps, tail, the next run's preparation"),
+                           (f"{tag}_ptrace.txt", "ptrace_scatter16.txt", "`tools/ptrace.py` (IVJ_CS_PTRACE): phase times of the 16 384-probe scatter's tiles, config 3"),
+                           (f"{tag}_dry8_count.json", "dryrun8_count_200M_200k_24contig.json", "`tools/dryrun_ranks.py`: eight ranks of config 5 on one GPU over the in-process transport, per-probe exchange, checked against the oracle (oversubscribed: not a scaling number)"),
+                           (f"{tag}_dry8_overlap.json", "dryrun8_overlap_100M_5M_24contig.json", "the same for config 3 (four chunks x eight ranks of collectives per step)"),
                            (f"{tag}_shard.txt", "shard_probe.txt", "`tools/shard_probe.py`: host sharding behind MultiEngine at 100 M x 5 M rows (native one-pass form against the per-rank numpy form), MultiEngine.overlap on two slots of one GPU, the one-call Arrow entry against pb.overlap"),
                            (f"{tag}_sweep.txt", "policy_sweep.txt", "`tools/policy_sweep.py`: whole steps (index build + tables + partition + fused join), 256-bucket window scan (mode 1) against contig-aligned slices (mode 6) and the automatic choice, over a grid of sizes"),
                            (f"{tag}_frontend.txt", "frontend_e2e.txt", "`tools/frontend_e2e.py`: pb.overlap end to end through the Python front door, per stage")):
