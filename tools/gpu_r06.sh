@@ -71,6 +71,7 @@ run_stage() {
       IVJ_CS_WGTRACE=$o.bin timeout 600 $B --steps 3 --warmup 1 $Q $BARGS 2>$o.err | cut -c1-200; python tools/wgtrace.py $o.bin | tee $o.txt; rm -f $o.bin ;;
     ptrace) echo "== phase times of the wide-tile scatter (IVJ_CS_PTRACE)"; rm -f $o.bin;
       IVJ_CS_PTRACE=$o.bin timeout 600 $B --steps 3 --warmup 1 $Q $BARGS 2>$o.err | cut -c1-200; python tools/ptrace.py $o.bin | tee $o.txt; rm -f $o.bin ;;
+    stress*) echo "== tools/stress_r06.py ${ITERS:-16} iterations, seed ${SEED:-1}"; timeout 2400 python tools/stress_r06.py ${ITERS:-16} ${SEED:-1} 2>&1 | tee $o.txt | tail -${ITERS:-16} | cut -c1-260 ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     densehunt) echo "== dense variant: a step above 25 ms on this box gets a --hip-trace --kernel-trace run (VERDICT r4 item 7)";
       timeout 900 $B --workload overlap_100M_5M_24contig_dense --steps 3 --warmup 1 --step-times 8 $Q 2>$o.err | tee $o.json | cut -c1-200; grep "per-step wall\|timed region" $o.err;
