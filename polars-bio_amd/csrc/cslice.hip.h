@@ -1624,39 +1624,41 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
     const bool tile_fault = (A.ablate & SL_ABLATE_TILE_FAULT) && v == 0;
     int pend_wtot = -1;                                                        // this wavefront's staged pairs of the previous tile
     long long pend_woff = 0;
-    for (int tix = 0; tix <= ntile; ++tix) {
-        if (tix < ntile) match_tile(q0 + (int64_t)tix * CS_TILE);
-        if (tix > 0) {
-            // finish tile tix - 1: its base was requested one iteration ago
-            __builtin_amdgcn_wave_barrier();
-            int* c = li + ((tix - 1) & 1) * 4;
-            unsigned long long* c64 = lc + ((tix - 1) & 1) * 2;
-            bool timed_out = false;
-            IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
-            long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (timed_out) tb = -1;
-            if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
-                int32_t* op = A.out_probe + tb + pend_woff;
-                int32_t* ob = A.out_build + tb + pend_woff;
-                const int ca = cs_copy_align(op, A.ablate);
+    // (finishing tile t -- the copy-out of this wavefront's staged pairs at the base the tile's last wavefront reserved -- happens one
+    // iteration later, behind the next tile's matching; the loop is written with the last finish peeled off: with one loop of ntile + 1
+    // iterations and the matching under a condition the compiler carried every per-tile register from iteration to iteration)
+    auto finish_tile = [&](int t) {
+        __builtin_amdgcn_wave_barrier();
+        int* c = li + (t & 1) * 4;
+        unsigned long long* c64 = lc + (t & 1) * 2;
+        bool timed_out = false;
+        IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
+        long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (timed_out) tb = -1;
+        if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
+            int32_t* op = A.out_probe + tb + pend_woff;
+            int32_t* ob = A.out_build + tb + pend_woff;
+            const int ca = cs_copy_align(op, A.ablate);
 #pragma unroll 4
-                for (int i = lane - ca; i < pend_wtot; i += kWave) {
-                    if ((unsigned)i < (unsigned)pend_wtot) {
-                        const uint32_t e = stw[i];
-                        __builtin_nontemporal_store(qrw[e >> 16], op + i);
-                        __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
-                    }
-                }
-            }
-            if (lane == 0) {
-                if (atomicAdd(c + 1, 1) == CS_WAVES - 1) {                     // last wavefront out: recycle the block for tile tix + 1
-                    __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    stv(c + 0, 0); stv(c + 1, 0); stv(c + 2, 0);
-                    stv(c + 3, tix + 1);
+            for (int i = lane - ca; i < pend_wtot; i += kWave) {
+                if ((unsigned)i < (unsigned)pend_wtot) {
+                    const uint32_t e = stw[i];
+                    __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                    __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
                 }
             }
         }
-        if (tix == ntile) break;
+        if (lane == 0) {
+            if (atomicAdd(c + 1, 1) == CS_WAVES - 1) {                         // last wavefront out: recycle the block for tile t + 2
+                __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                stv(c + 0, 0); stv(c + 1, 0); stv(c + 2, 0);
+                stv(c + 3, t + 2);
+            }
+        }
+    };
+    for (int tix = 0; tix < ntile; ++tix) {
+        match_tile(q0 + (int64_t)tix * CS_TILE);
+        if (tix > 0) finish_tile(tix - 1);                                     // its base was requested one iteration ago
         int* c = li + (tix & 1) * 4;
         unsigned long long* c64 = lc + (tix & 1) * 2;
         IVJ_TILE_WAIT(ld(c + 3) != tix, spin_bound, A.state, lane, return);       // the block is ours (recycled after tile tix - 2)
@@ -1738,6 +1740,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join_plain(CsJoinArgs A) {
         } else pend_wtot = 0;
         pend_woff = woff;
     }
+    if (ntile > 0) finish_tile(ntile - 1);
     if (ca()->trace) { end_run(); __syncthreads(); cs_trace(ca()->trace, v, 2); }   // (end_run: only the first call of a run prepares)         // (diagnosis runs only: every wavefront has finished its tiles)
     }                                                                          // (runs of this workgroup)
     cs_publish_state(ca()->hw, ca()->hw_seq, ca()->done, A.state, ca()->cursor ? (int)gridDim.x : ca()->meta[0]);
@@ -2108,29 +2111,29 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
     int pend_wtot = -1;                                                        // this wavefront's staged pairs of the previous tile
     bool pend_below = false;                                                   //   ... some of them below the slice
     long long pend_woff = 0;
-    for (int tix = 0; tix <= ntile; ++tix) {
-        if (tix < ntile) match_tile(q0 + (int64_t)tix * CS_TILE);
-        if (tix > 0) {
-            // finish tile tix - 1: its base was requested one iteration ago
-            __builtin_amdgcn_wave_barrier();
-            int* c = li + ((tix - 1) & 1) * 4;
-            unsigned long long* c64 = lc + ((tix - 1) & 1) * 2;
-            bool timed_out = false;
-            IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
-            long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (timed_out) tb = -1;
-            if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
-                copy_out(A.out_probe + tb + pend_woff, A.out_build + tb + pend_woff, pend_wtot, pend_below);
-            }
-            if (lane == 0) {
-                if (atomicAdd(c + 1, 1) == CS_WAVES - 1) {                     // last wavefront out: recycle the block for tile tix + 1
-                    __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    stv(c + 0, 0); stv(c + 1, 0); stv(c + 2, 0);
-                    stv(c + 3, tix + 1);
-                }
+    // (the last finish is peeled off the loop: see k_cs_join_plain)
+    auto finish_tile = [&](int t) {
+        __builtin_amdgcn_wave_barrier();
+        int* c = li + (t & 1) * 4;
+        unsigned long long* c64 = lc + (t & 1) * 2;
+        bool timed_out = false;
+        IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
+        long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (timed_out) tb = -1;
+        if (tb >= 0 && pend_wtot > 0 && !(A.ablate & 32)) {
+            copy_out(A.out_probe + tb + pend_woff, A.out_build + tb + pend_woff, pend_wtot, pend_below);
+        }
+        if (lane == 0) {
+            if (atomicAdd(c + 1, 1) == CS_WAVES - 1) {                         // last wavefront out: recycle the block for tile t + 2
+                __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                stv(c + 0, 0); stv(c + 1, 0); stv(c + 2, 0);
+                stv(c + 3, t + 2);
             }
         }
-        if (tix == ntile) break;
+    };
+    for (int tix = 0; tix < ntile; ++tix) {
+        match_tile(q0 + (int64_t)tix * CS_TILE);
+        if (tix > 0) finish_tile(tix - 1);                                     // its base was requested one iteration ago
         int* c = li + (tix & 1) * 4;
         unsigned long long* c64 = lc + (tix & 1) * 2;
         IVJ_TILE_WAIT(ld(c + 3) != tix, spin_bound, A.state, lane, return);       // the block is ours (recycled after tile tix - 2)
@@ -2184,6 +2187,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_join(CsJoinArgs A) {
         } else pend_wtot = 0;
         pend_woff = woff;
     }
+    if (ntile > 0) finish_tile(ntile - 1);
     cs_publish_state(A, total_wg);
 }
 
