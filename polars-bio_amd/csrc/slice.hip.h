@@ -883,32 +883,33 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
         const bool tile_fault = (A.ablate & SL_ABLATE_TILE_FAULT) && v == 0;
         int pend_wtot = -1;                                                    // this wavefront's staged pairs of the previous tile
         long long pend_woff = 0;
-        for (int tix = 0; tix <= ntile; ++tix) {
-            if (tix < ntile) match_tile(q0 + (int64_t)tix * TILE);
-            if (tix > 0) {
-                // finish tile tix - 1: its base was requested one iteration ago
-                int* c = li + ((tix - 1) & 1) * 4;
-                unsigned long long* c64 = lc + ((tix - 1) & 1) * 2;
-                bool timed_out = false;
-                IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
-                long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (timed_out) tb = -1;
-                if (tb >= 0 && pend_wtot > 0 && pend_wtot <= wcap && !(A.ablate & 32)) {
-                    for (int i = lane; i < pend_wtot; i += kWave) {
-                        const int2 pr = stw[i];
-                        __builtin_nontemporal_store(pr.x, A.out_probe + tb + pend_woff + i);
-                        __builtin_nontemporal_store(pr.y, A.out_build + tb + pend_woff + i);
-                    }
-                }
-                if (lane == 0) {
-                    if (atomicAdd(c + 1, 1) == SL_WAVES - 1) {                 // last wavefront out: recycle the block for tile tix + 1
-                        __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        stv(c + 0, 0); stv(c + 1, 0); stv(c + 2, 0);
-                        stv(c + 3, tix + 1);
-                    }
+        // (the last tile's finish is peeled off the loop: one loop of ntile + 1 iterations with the matching under a condition made the
+        // compiler carry every per-tile register from iteration to iteration -- cslice.hip.h, round 6)
+        auto finish_tile = [&](int t) {
+            int* c = li + (t & 1) * 4;
+            unsigned long long* c64 = lc + (t & 1) * 2;
+            bool timed_out = false;
+            IVJ_TILE_WAIT(ld(c + 2) == 0, spin_bound, A.state, lane, timed_out = true);
+            long long tb = (long long)__hip_atomic_load(c64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (timed_out) tb = -1;
+            if (tb >= 0 && pend_wtot > 0 && pend_wtot <= wcap && !(A.ablate & 32)) {
+                for (int i = lane; i < pend_wtot; i += kWave) {
+                    const int2 pr = stw[i];
+                    __builtin_nontemporal_store(pr.x, A.out_probe + tb + pend_woff + i);
+                    __builtin_nontemporal_store(pr.y, A.out_build + tb + pend_woff + i);
                 }
             }
-            if (tix == ntile) break;
+            if (lane == 0) {
+                if (atomicAdd(c + 1, 1) == SL_WAVES - 1) {                     // last wavefront out: recycle the block for tile t + 2
+                    __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    stv(c + 0, 0); stv(c + 1, 0); stv(c + 2, 0);
+                    stv(c + 3, t + 2);
+                }
+            }
+        };
+        for (int tix = 0; tix < ntile; ++tix) {
+            match_tile(q0 + (int64_t)tix * TILE);
+            if (tix > 0) finish_tile(tix - 1);                                 // its base was requested one iteration ago
             int* c = li + (tix & 1) * 4;
             unsigned long long* c64 = lc + (tix & 1) * 2;
             IVJ_TILE_WAIT(ld(c + 3) != tix, spin_bound, A.state, lane, return);   // the block is ours (recycled after tile tix - 2)
@@ -978,6 +979,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             }
             pend_wtot = wtot; pend_woff = woff;
         }
+        if (ntile > 0) finish_tile(ntile - 1);
         return;
     }
     // Tile loop, rotated so that the matching code exists once: iteration t matches tile t, THEN finishes tile t - 1 (reads
@@ -1013,10 +1015,9 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
         if (!(A.ablate & 64)) __syncthreads();                                 // staging buffer (and s_base) free again
         pending = false;
     };
-    for (int tix = 0; tix <= ntile; ++tix) {
-        if (tix < ntile) match_tile(q0 + (int64_t)tix * TILE);
+    for (int tix = 0; tix < ntile; ++tix) {                                      // (the last finish_pending is peeled off: see the fused loop above)
+        match_tile(q0 + (int64_t)tix * TILE);
         if (MODE != SL_COUNT) finish_pending();
-        if (tix == ntile) break;
         const long long tile_id = (long long)v * tiles_per_chunk + tix;
         if (MODE == SL_COUNT) {
             // only the tile total is needed: wavefront sums go straight to the (zeroed) tile slot, no workgroup barrier
@@ -1124,6 +1125,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_slice_join(SliceGeom g, int64_t 
             __syncthreads();
         }
     }
+    if (MODE != SL_COUNT) finish_pending();
 }
 
 }  // namespace ivj
