@@ -206,6 +206,36 @@ __device__ __forceinline__ uint32_t cs_bucket(const unsigned long long* __restri
     return pos <= (int)((uint32_t)m.w >> 16) ? (uint32_t)nb : (uint32_t)(pos - 1);
 }
 
+// The same bucket without divergent control flow (round 6, the wide-tile scatter): the scatter's lookups ran ~ 5 exec-mask branches per
+// probe (83 M scalar + 33 M branch instructions per launch next to 148 M vector ones).  A contig outside the dictionary is looked up as
+// contig 0 and answered with nb at the end; the cell's (at most two, nearly always) splitters are compared at once; only a cell with more
+// than two splitters below the key takes the loop (one uniform branch on a ballot).  l_spl is read up to two entries behind its end.
+template <bool STRICT>
+__device__ __forceinline__ uint32_t cs_bucket_flat(const unsigned long long* __restrict__ l_spl, const int4* __restrict__ l_cm,
+                                                   const uint32_t* __restrict__ l_cell, int nb, int32_t n_contigs, int32_t c, int32_t qe) {
+    const bool okc = (uint32_t)c < (uint32_t)n_contigs;
+    const int cc = okc ? c : 0;
+    const unsigned long long tu = (unsigned long long)flip(qe) + (STRICT ? 0ull : 1ull);
+    const unsigned long long key = ((unsigned long long)(uint32_t)cc << 32) + tu;
+    const int4 m = l_cm[cc];
+    const uint32_t ulo = (uint32_t)m.x, uhi = (uint32_t)m.y;
+    unsigned long long tc = tu < (unsigned long long)ulo ? (unsigned long long)ulo : tu;
+    tc = tc > (unsigned long long)uhi ? (unsigned long long)uhi : tc;
+    const uint32_t k = ((uint32_t)tc - ulo) >> m.z;
+    const uint32_t lh = l_cell[(m.w & 0xffff) + k];
+    int pos = (int)(lh & 0xffffu);
+    const int hi = (int)(lh >> 16);
+    const unsigned long long s0 = l_spl[pos], s1 = l_spl[pos + 1];
+    const bool c0 = pos < hi && s0 < key;
+    const bool c1 = c0 && pos + 1 < hi && s1 < key;
+    pos += (int)c0 + (int)c1;
+    if (__builtin_expect(__ballot(c1 && pos < hi) != 0ull, 0)) {                // uniform, rare
+        if (c1) { while (pos < hi && l_spl[pos] < key) ++pos; }
+    }
+    const uint32_t b = pos <= (int)((uint32_t)m.w >> 16) ? (uint32_t)nb : (uint32_t)(pos - 1);
+    return okc ? b : (uint32_t)nb;
+}
+
 // ---- per-slice start bins, built once per index: one workgroup per slice ---------------------------------------------------
 // bins[j * (2 R + 2) + cl] = first slice-local row whose (start - min start) >> shift reaches cell cl (two cells per row);
 // bins[.. + ncell] = rows of the slice.
@@ -609,21 +639,18 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
         // stay in their registers until then, and the next tile's columns are requested after the placement (their flight overlaps the
         // copy-out and the tile's last barrier) -- sixteen packed words next to sixteen prefetched probes do not fit 128 registers
         uint32_t w0[RUNS ? 1 : PITEMS], dr[PITEMS];
+        bool bad = false;                                                       // a probe of this lane does not fit the 8-byte form
         static_assert(SL_MAX_BUCKETS + 1 <= (1 << 11) && TILE <= (1 << 21), "bucket and rank share one word");
 #pragma unroll
         for (int j = 0; j < PITEMS; ++j) {
-            const bool valid = (j / 4) * (CS_THREADS * 4) + tid * 4 + (j & 3) < tile_n;
-            const uint32_t d = !valid ? 0u : cs_bucket<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, nc[j], ne[j]);
-            const uint32_t rank = valid ? atomicAdd(&cnt[d], 1u) : 0u;
+            // (no test for the tile's end: a lane beyond it holds the fill values -- contig -1 -- and counts into bucket nb, which is never copied)
+            const uint32_t d = cs_bucket_flat<STRICT>(l_spl, l_cm, l_cell, g.nb, g.n_contigs, nc[j], ne[j]);
+            const uint32_t rank = atomicAdd(&cnt[d], 1u);
             if constexpr (!RUNS) {
-                uint32_t w = 0u;
-                if (valid && d < (uint32_t)g.nb) {
-                    const uint32_t off = (uint32_t)ne[j] - (uint32_t)unflip((uint32_t)l_spl[d]);       // >= 0: the slice's first row starts below the end
-                    const uint32_t len = (uint32_t)ne[j] - (uint32_t)ns[j];
-                    if (ne[j] < ns[j] || (len >> lb) != 0u || (off >> (32 - lb)) != 0u) atomicOr(state + 1, CS_STATE_REC8);   // (redo with 12-byte records)
-                    w = (off << lb) | len;
-                }
-                w0[j] = w;
+                const uint32_t off = (uint32_t)ne[j] - (uint32_t)unflip((uint32_t)l_spl[d < (uint32_t)g.nb ? d : 0u]);   // >= 0: the slice's first row starts below the end
+                const uint32_t len = (uint32_t)ne[j] - (uint32_t)ns[j];
+                bad = bad || (d < (uint32_t)g.nb && (ne[j] < ns[j] || (len >> lb) != 0u || (off >> (32 - lb)) != 0u));
+                w0[j] = (off << lb) | len;                                     // (bucket nb: garbage, never copied)
             }
             dr[j] = d | (rank << 11);
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);               // (four lookups in flight are enough: twelve interleaved ones cost 14 spilled registers)
@@ -696,22 +723,18 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = 4 * h + u;
-                if (e0 + u < tile_n) {
-                    const uint32_t d = dr[j] & 2047u;
-                    const uint32_t pos = lstart[d] + (dr[j] >> 11);
-                    if constexpr (RUNS) {
-                        uint32_t w = 0u;
-                        if (d < (uint32_t)g.nb) {
-                            const uint32_t off = (uint32_t)ne[j] - (uint32_t)unflip((uint32_t)l_spl[d]);
-                            const uint32_t len = (uint32_t)ne[j] - (uint32_t)ns[j];
-                            if (ne[j] < ns[j] || (len >> lb) != 0u || (off >> (32 - lb)) != 0u) atomicOr(state + 1, CS_STATE_REC8);
-                            w = (off << lb) | len;
-                        }
-                        l_rs[pos] = (int32_t)w; l_ri[pos] = (unsigned short)(e0 + u);
-                    } else { l_rs[pos] = (int32_t)w0[j]; l_rr[pos] = rw[u]; l_d[pos] = (unsigned short)d; }
-                }
+                // (every lane places: the lanes beyond the tile's end were ranked into bucket nb)
+                const uint32_t d = dr[j] & 2047u;
+                const uint32_t pos = lstart[d] + (dr[j] >> 11);
+                if constexpr (RUNS) {
+                    const uint32_t off = (uint32_t)ne[j] - (uint32_t)unflip((uint32_t)l_spl[d < (uint32_t)g.nb ? d : 0u]);
+                    const uint32_t len = (uint32_t)ne[j] - (uint32_t)ns[j];
+                    bad = bad || (d < (uint32_t)g.nb && (ne[j] < ns[j] || (len >> lb) != 0u || (off >> (32 - lb)) != 0u));
+                    l_rs[pos] = (int32_t)((off << lb) | len); l_ri[pos] = (unsigned short)(e0 + u);
+                } else { l_rs[pos] = (int32_t)w0[j]; l_rr[pos] = rw[u]; l_d[pos] = (unsigned short)d; }
             }
         }
+        if (bad) atomicOr(state + 1, CS_STATE_REC8);                            // (redo with 12-byte records)
         if (ptrace && tix == 1 && tid == 0) ptrace[8 * (size_t)blockIdx.x + 6] = wall_clock64();
         if constexpr (RUNS) {
             __builtin_amdgcn_sched_barrier(0);
