@@ -1166,6 +1166,41 @@ __device__ __forceinline__ int cs_copy_align(const int32_t* op, int ablate) {
     return (ablate & CS_ABLATE_UNALIGNED) ? 0 : (int)((reinterpret_cast<uintptr_t>(op) >> 2) & 15u);
 }
 
+// Copy-out of a wavefront's staged pairs with SIXTEEN bytes per lane and store (round 6).  A wavefront's output range starts and ends inside
+// 64-byte lines it shares with its neighbours' ranges, and what those shared lines cost depends on the store width (tools/micro/write_bw.hip,
+// profiles/r06/write_bw_by_store_width.txt: ranges of 508 elements to two columns reach 3.0 TB/s with 4-byte stores, 3.9 with 16-byte ones;
+// ranges of whole lines 6.0).  Quads of elements aligned to 16 bytes in global memory: quad q = elements [4 q - E, 4 q - E + 4), E = the
+// range's element offset inside its first line; the (at most three) elements of a quad cut by either end of the range go one by one.
+// Entry = probe slot << SLOT_SHIFT | row; rows[] may be an LDS pointer with a bias folded in.  k_cs_fill: 0.70 -> 0.61 ms on config 3; the
+// fused joins (not bound by their stores: k_cs_join_plain 0.818 / 0.810 against 0.810 / 0.815 ms, k_cs_join 0.226 against 0.224) keep the 4-byte form.  IVJ_SLICE_ABLATE bit 16384: 4-byte stores (A/B, exact).
+constexpr int CS_ABLATE_STORE4 = 16384;
+template <int SLOT_SHIFT, class RowPtr>
+__device__ __forceinline__ void cs_copy_pairs16(const uint32_t* stw, const int32_t* qrw, RowPtr rows, int32_t* op, int32_t* ob, int n, int lane) {
+    constexpr uint32_t RM = (1u << SLOT_SHIFT) - 1u;
+    const int E = (int)((reinterpret_cast<uintptr_t>(op) >> 2) & 15u);
+    typedef int cs_v4 __attribute__((ext_vector_type(4)));
+    for (int i0 = 4 * lane - E; i0 < n; i0 += 4 * kWave) {
+        if (i0 >= 0 && i0 + 4 <= n) {
+            const uint32_t e0 = stw[i0], e1 = stw[i0 + 1], e2 = stw[i0 + 2], e3 = stw[i0 + 3];
+            cs_v4 vp, vb;
+            vp.x = qrw[e0 >> SLOT_SHIFT]; vp.y = qrw[e1 >> SLOT_SHIFT]; vp.z = qrw[e2 >> SLOT_SHIFT]; vp.w = qrw[e3 >> SLOT_SHIFT];
+            vb.x = (int32_t)rows[e0 & RM]; vb.y = (int32_t)rows[e1 & RM]; vb.z = (int32_t)rows[e2 & RM]; vb.w = (int32_t)rows[e3 & RM];
+            __builtin_nontemporal_store(vp, reinterpret_cast<cs_v4*>(op + i0));
+            __builtin_nontemporal_store(vb, reinterpret_cast<cs_v4*>(ob + i0));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                if ((unsigned)i < (unsigned)n) {
+                    const uint32_t e = stw[i];
+                    __builtin_nontemporal_store(qrw[e >> SLOT_SHIFT], op + i);
+                    __builtin_nontemporal_store((int32_t)rows[e & RM], ob + i);
+                }
+            }
+        }
+    }
+}
+
 constexpr int CS_ARGS_LDS = 512;
 struct CsJoinLds { int end, pmx, start, row, bin, qrow, stage, ctl, args, total; };
 __host__ __device__ inline CsJoinLds cs_join_lds(int R, int wcap) {
@@ -2368,15 +2403,17 @@ __global__ __launch_bounds__(CS_THREADS, TWO ? 8 : 4) void k_cs_fill(CsJoinArgs 
                 __builtin_amdgcn_wave_barrier();
                 int32_t* op = A.out_probe + wbase;
                 int32_t* ob = A.out_build + wbase;
-                const int ca = cs_copy_align(op, A.ablate);
+                if (TWO || (A.ablate & CS_ABLATE_STORE4)) {                     // (four bytes per lane and store: rounds 3-5, A/B runs; the 64-register form of two workgroups per CU)
+                    const int ca = cs_copy_align(op, A.ablate);
 #pragma unroll 4
-                for (int i = lane - ca; i < wtot; i += kWave) {
-                    if ((unsigned)i < (unsigned)wtot) {
-                        const uint32_t e = stw[i];
-                        __builtin_nontemporal_store(qrw[e >> 16], op + i);
-                        __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                    for (int i = lane - ca; i < wtot; i += kWave) {
+                        if ((unsigned)i < (unsigned)wtot) {
+                            const uint32_t e = stw[i];
+                            __builtin_nontemporal_store(qrw[e >> 16], op + i);
+                            __builtin_nontemporal_store(l_row[e & 0xffffu], ob + i);
+                        }
                     }
-                }
+                } else cs_copy_pairs16<16>(stw, qrw, l_row, op, ob, wtot, lane);
                 __builtin_amdgcn_wave_barrier();
             } else {
                 // k_cs_join's entries {wave-local probe slot << 24 | (row - first row of the slice) + bias}: rows below the slice
@@ -2410,14 +2447,20 @@ __global__ __launch_bounds__(CS_THREADS, TWO ? 8 : 4) void k_cs_fill(CsJoinArgs 
                 __builtin_amdgcn_wave_barrier();
                 int32_t* op = A.out_probe + wbase;
                 int32_t* ob = A.out_build + wbase;
-                for (int i = lane; i < wtot; i += kWave) {
-                    const uint32_t e = stw[i];
-                    const int pos = (int)(e & 0xffffffu) - CS_POS_BIAS;
-                    int32_t br = 0;
-                    if (!any_below || pos >= 0) br = l_row[pos];
-                    if (any_below && pos < 0) br = __builtin_nontemporal_load(A.b_row + (r0 + pos));
-                    __builtin_nontemporal_store(qrw[e >> 24], op + i);
-                    __builtin_nontemporal_store(br, ob + i);
+                if (!any_below && !(A.ablate & CS_ABLATE_STORE4)) {            // (uniform) every row in LDS: sixteen bytes per lane and store
+                    typedef __attribute__((address_space(3))) const int32_t lds_ci32;
+                    lds_ci32* rowb = (lds_ci32*)(uintptr_t)((uint32_t)(uintptr_t)(lds_ci32*)l_row - 4u * (uint32_t)CS_POS_BIAS);
+                    cs_copy_pairs16<24>(stw, qrw, rowb, op, ob, wtot, lane);
+                } else {
+                    for (int i = lane; i < wtot; i += kWave) {
+                        const uint32_t e = stw[i];
+                        const int pos = (int)(e & 0xffffffu) - CS_POS_BIAS;
+                        int32_t br = 0;
+                        if (!any_below || pos >= 0) br = l_row[pos];
+                        if (any_below && pos < 0) br = __builtin_nontemporal_load(A.b_row + (r0 + pos));
+                        __builtin_nontemporal_store(qrw[e >> 24], op + i);
+                        __builtin_nontemporal_store(br, ob + i);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
