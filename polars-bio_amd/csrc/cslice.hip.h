@@ -762,6 +762,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
             // copy-out by RUNS: sixteen lanes per bucket run, four runs per wavefront step (a run holds ~ 16 records at 1040 buckets);
             // bucket g.nb (no candidate row) is never copied
             if (!(ablate & 256)) {
+                if (ablate & 32768) {                                           // (IVJ_SLICE_ABLATE bit 32768, A/B: one 8-byte record per lane and store: 0.554 - 0.571 against 0.547 - 0.548 ms)
                 const int grp = (tv & (kWave - 1)) >> 4, sub = tv & 15;
                 for (int b0 = (tv / kWave) * 4; b0 < g.nb; b0 += CS_WAVES * 4) {
                     const int b = b0 + grp;
@@ -771,6 +772,27 @@ __global__ __launch_bounds__(CS_THREADS) void k_cs_scatter12k(CsTab tab, CsGeom 
                         cs_rec8 v; v.x = l_rs[kk]; v.y = (int32_t)(tbase + (int64_t)l_ri[kk]);
                         *reinterpret_cast<cs_rec8*>(out + 2 * (int64_t)(kk + dl)) = v;
                     }
+                }
+                } else {
+                // eight lanes per run, TWO records = 16 bytes per lane and store, pairs aligned to 16 bytes in the record buffer
+                const int grp = (tv & (kWave - 1)) >> 3, sub = tv & 7;
+                typedef int cs_v4 __attribute__((ext_vector_type(4)));
+                for (int b0 = (tv / kWave) * 8; b0 < g.nb; b0 += CS_WAVES * 8) {
+                    const int b = b0 + grp;
+                    uint32_t rs0 = 0, re0 = 0, dl = 0;
+                    if (b < g.nb) { rs0 = lstart[b]; re0 = lstart[b + 1]; dl = delta[b]; }
+                    // (signed: the pair in front of an odd first record starts one record before the run)
+                    for (int kk = (int)rs0 - (int)((rs0 + dl) & 1u) + 2 * sub; kk < (int)re0; kk += 16) {
+                        const bool v0 = kk >= (int)rs0, v1 = kk + 1 < (int)re0;
+                        const int k0 = v0 ? kk : kk + 1, k1 = v1 ? kk + 1 : kk;
+                        const int32_t w0 = l_rs[k0], r0 = (int32_t)(tbase + (int64_t)l_ri[k0]);
+                        const int32_t w1 = l_rs[k1], r1 = (int32_t)(tbase + (int64_t)l_ri[k1]);
+                        int32_t* dst = out + 2 * ((int64_t)kk + (int64_t)dl);
+                        if (v0 && v1) { cs_v4 v = {w0, r0, w1, r1}; *reinterpret_cast<cs_v4*>(dst) = v; }
+                        else if (v0) { cs_rec8 v; v.x = w0; v.y = r0; *reinterpret_cast<cs_rec8*>(dst) = v; }
+                        else if (v1) { cs_rec8 v; v.x = w1; v.y = r1; *reinterpret_cast<cs_rec8*>(dst + 2) = v; }
+                    }
+                }
                 }
             }
         } else {
