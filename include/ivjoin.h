@@ -96,7 +96,8 @@ typedef struct {
                                   the probe side is >= 8 x the build side), 1 records, 2 plain 4-byte bins, 3 records + the nearest
                                   lines whatever the sizes (128 bytes of index per build row; other operations: as 1) */
     int32_t slice_rows;        /* slice path: build rows per slice, 0 = auto (rows / 1024, rounded up to 64, <= 5120) */
-    int32_t slice_chunk;       /* slice path: probes per join workgroup, 0 = auto (multiple of 4096) */
+    int32_t slice_chunk;       /* slice path: probes per work item of the join (round 6: the contig-aligned join's persistent workgroups draw groups of
+                                  items and join a bucket's consecutive items as one run; the other slice joins: per workgroup), 0 = auto (multiple of 4096) */
     int32_t deterministic;     /* overlap count -> fill pair on the slice path: 1 = the output is identical from run to run (stable
                                   partition behind a histogram pass, +0.7 ms per 100 M probes); 0 = same pairs, the order of the probe rows inside a
                                   bucket tile may differ between runs (the reference leaves the row order unspecified) */
