@@ -3,7 +3,8 @@
 #   tests:    fast (pytest -m gpu without the full-size configs) | full (full-size configs + multi-GPU tests) | k=<expr> (pytest -k)
 #   benches:  c3 (default run) c3q (no PMC / baseline / extras, kernel table) c3old (IVJ_CS=0: round-2 slice kernels) c2 c4 c5 c1 c3two c3dense c3rows sortscan
 #             env=<VAR=val,...>:<stage> runs a stage under extra environment variables (A/B knobs)
-#   profiles: prof (rocprofv3 --kernel-trace --stats of config 3) | pmcsq (SQ / TCP / LDS counter passes of config 3)
+#   profiles: prof (rocprofv3 --kernel-trace --stats of config 3) | pmcsq (SQ / TCP / LDS counter passes of config 3) | pmctcc* (WL=<workload>)
+#   round 6:  rccl comm dense (test groups) | c3sorted calib | wgtrace ptrace (time lines: tools/wgtrace.py, tools/ptrace.py) | stress (ITERS= SEED=)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
