@@ -51,7 +51,9 @@ bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, Sli
         // bucketing pays at all: 4 M x 256 k rows -13 %, 10 M x 1 M (config 2) -18 %, 30 M x 1 M -25 %, 100 M x 5 M -31 %; with the
         // sampled partition also on the shards of an 8-rank run and their chunks (2 M x 625 k x 3 contigs -16 %, 3 M x 625 k -12 %,
         // 12.5 M x 625 k -27 %; 1 M probes: a tie).
-        if (cs) { if (!(on && n_probe >= (3ll << 19) && ix->n >= (256ll << 10))) return false; }
+        // (round 6, profiles/r06/policy_sweep_small_build_sides.txt: with the persistent join the contig-aligned form also wins on build sides of
+        // 64 k - 256 k rows -- 10 M x 192 k x 1 contig 0.339 -> 0.263 ms, 30 M x 200 k 0.633 -> 0.507, 100 M x 200 k 1.77 -> 1.23; a tie at 2 M x 64 k)
+        if (cs) { if (!(on && n_probe >= (3ll << 19) && ix->n >= (64ll << 10))) return false; }
         else if (!(on && n_probe >= (24ll << 20) && ix->n >= (4ll << 20))) return false;
     }
     return slice_geom(ix, opts, g);
