@@ -53,7 +53,8 @@ bool want_slices(const ivj_index* ix, int64_t n_probe, const ivj_opts* opts, Sli
         // 12.5 M x 625 k -27 %; 1 M probes: a tie).
         // (round 6, profiles/r06/policy_sweep_small_build_sides.txt: with the persistent join the contig-aligned form also wins on build sides of
         // 64 k - 256 k rows -- 10 M x 192 k x 1 contig 0.339 -> 0.263 ms, 30 M x 200 k 0.633 -> 0.507, 100 M x 200 k 1.77 -> 1.23; a tie at 2 M x 64 k)
-        if (cs) { if (!(on && n_probe >= (3ll << 19) && ix->n >= (64ll << 10))) return false; }
+        // ... and from 512 Ki probes on (was 1.5 Mi): 0.5 M x 1 M x 24 0.219 -> 0.187 ms, 1 M x 1 M 0.227 -> 0.199, 1.5 M x 1 M 0.245 -> 0.208
+        if (cs) { if (!(on && n_probe >= (1ll << 19) && ix->n >= (64ll << 10))) return false; }
         else if (!(on && n_probe >= (24ll << 20) && ix->n >= (4ll << 20))) return false;
     }
     return slice_geom(ix, opts, g);
