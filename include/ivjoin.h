@@ -83,8 +83,8 @@ typedef struct {
     int32_t nearest_k;         /* RangeOptions.nearest_k, >= 1 (default 1) */
     int32_t include_overlaps;  /* RangeOptions.include_overlaps (default 1) */
     int32_t partition_mode;    /* how the probe side is ordered before the join kernels run.  0 auto: overlap (the fused pass and the
-                                  count -> fill pair) takes the contig-aligned slice path (6) from 1.5 M probe rows against 256 k
-                                  build rows on (dictionaries of <= 256 contigs; tools/policy_sweep.py), large inputs outside
+                                  count -> fill pair) takes the contig-aligned slice path (6) from 512 Ki probe rows against 64 Ki
+                                  build rows on (round 6; rounds 4-5: 1.5 Mi x 256 Ki; dictionaries of <= 256 contigs; tools/policy_sweep.py), large inputs outside
                                   that and the per-probe kernels the 256-bucket path (1), small ones none (2); 1 256 genomic buckets + window-scan kernels (deterministic); 2 never (probe order);
                                   5 flat (256 buckets + load-balanced candidate test, ivj_overlap_fused_dev only; with 0 the
                                   fused entry point picks it by itself when capacity >= 16 pairs per probe row, i.e. for dense
@@ -153,7 +153,7 @@ int ivj_ctx_profile_mark(ivj_ctx* ctx);
  * ordered by (build.start, build row).  Probe rows appear in input order (small inputs, partition_mode 2)
  * or bucket by bucket -- by genomic position of the probe end -- when the probe side was partitioned:
  * with partition_mode 1 (256 buckets) in the stable order of that partition; on the contig-aligned slice
- * path (the automatic choice from 1.5 M probe rows x 256 k build rows on) the default partition is the
+ * path (the automatic choice from 512 Ki probe rows x 64 Ki build rows on) the default partition is the
  * UNORDERED sampled one, so the order of the probe rows inside a bucket (and with it the order of the
  * output) may differ from run to run while the pair SET is exact; opts->deterministic = 1 selects the
  * stable partition there and an output that is identical from run to run.  The reference leaves the row
