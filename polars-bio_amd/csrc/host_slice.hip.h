@@ -233,14 +233,18 @@ int slice_join_launch_n(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const
 }
 template <int MODE>
 int slice_join_launch(ivj_ctx* ctx, ivj_index* ix, const ivj_opts* opts, const SlicePlan& P, long long capacity, int32_t* out_p, int32_t* out_b) {
-    return P.items == 2 ? slice_join_launch_n<MODE, 2>(ctx, ix, opts, P, capacity, out_p, out_b)
-                        : slice_join_launch_n<MODE, 4>(ctx, ix, opts, P, capacity, out_p, out_b);
+    // (four probes per thread -- IVJ_SLICE_ITEMS=4, a tuning knob -- only for the fused pass: the FILL form of it needs 48 bytes of scratch
+    // per lane at the kernel's 128 registers, and the pair's two kernels must agree on the tile; slice_overlap_count plans with two)
+    if constexpr (MODE == SL_FUSED) {
+        if (P.items == 4) return slice_join_launch_n<MODE, 4>(ctx, ix, opts, P, capacity, out_p, out_b);
+    }
+    return slice_join_launch_n<MODE, 2>(ctx, ix, opts, P, capacity, out_p, out_b);
 }
 
 // count pass of the two-pass pair: partition + join<COUNT> + scan of the tile totals
 int slice_overlap_count(ivj_ctx* ctx, ivj_index* ix, const ivj_side* probe, const ivj_opts* opts, const SliceGeom& g, int64_t* n_pairs) {
     SlicePlan P;
-    IVJ_TRY(slice_plan(ix, probe->n, opts, g, ctx->sl_items, P));
+    IVJ_TRY(slice_plan(ix, probe->n, opts, g, 2, P));                            // (two probes per thread for the pair: see slice_join_launch)
     IVJ_TRY(ensure_sl(ctx, probe->n, P));
     IVJ_TRY(slice_partition(ctx, ix, probe, opts, P, true));
     HIP_TRY(hipMemsetAsync(ctx->sl_tile, 0, (size_t)(P.ntiles + 2) * 8, ctx->stream));

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(PROBE_THREADS) void k_overlap_count(IndexView ix, c
 
 // Pass 2.  tile_base = exclusive scan of tile_tot.
 template <bool STRICT>
-__global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fill(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
+__global__ __launch_bounds__(PROBE_THREADS, 5) void k_overlap_fill(IndexView ix, const int32_t* __restrict__ ps, int64_t n,
                                                                 bool vec_ok, const int32_t* __restrict__ hi_in,
                                                                 const int32_t* __restrict__ cnt_in,
                                                                 const long long* __restrict__ tile_base,
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fill(IndexView ix,
 // run to run (the two-pass path is the deterministic one).  state[0] = cursor (= total on exit),
 // state[1] = 1 when the capacity was exceeded (nothing is written past it).
 template <bool STRICT>
-__global__ __launch_bounds__(PROBE_THREADS, 6) void k_overlap_fused(IndexView ix, const int32_t* __restrict__ pc,
+__global__ __launch_bounds__(PROBE_THREADS, 5) void k_overlap_fused(IndexView ix, const int32_t* __restrict__ pc,
                                                                  const int32_t* __restrict__ ps,
                                                                  const int32_t* __restrict__ pe,
                                                                  const int32_t* __restrict__ probe_ids, int64_t n,
